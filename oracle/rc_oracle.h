@@ -1,0 +1,93 @@
+/* TEST INFRASTRUCTURE - NOT PART OF THE PRODUCT.
+ *
+ * CPU restatement (plain C) of the reference's per-frame shader chain: what
+ * ShaderEngine::applyShader (reference src/shader/ShaderEngine.cpp:1531-1879) makes the GL
+ * driver compute when it draws each pass of a .glslp preset, with the arithmetic of the
+ * GLSL shader assets (reference shaders/shaders_glsl/...) written out by hand per pass.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker.  The product (retrocapture_amd/) never links it.
+ *
+ * Pinning: the reference ShaderEngine itself cannot be built here without a stand-in for
+ * GLFW, so engine-level parity is pinned by (a) the reference's own preset parser compiled
+ * unmodified (oracle/_ref/dump_preset) and (b) golden vectors produced by executing the
+ * reference's GLSL files on Mesa llvmpipe 23.2.1 through oracle/glrun (tests/golden/).
+ * The float primitives below (pow/exp2/log2/sin/cos, texel decode, filtering, varying
+ * interpolation, UNORM8 store) reproduce llvmpipe's results bit-for-bit as measured by
+ * oracle/probes/; the sRGB8 encode is a monotone threshold table (llvmpipe's own encode goes
+ * through the x86 RSQRTPS approximation and is not monotone).
+ */
+#ifndef RC_ORACLE_H
+#define RC_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y, z, w; } o_vec4;
+
+/* ---- float primitives (rc_math.c) ---------------------------------------------------- */
+float o_exp2(float x);
+float o_log2(float x);
+float o_pow(float x, float y);
+float o_exp(float x);
+float o_log(float x);
+float o_sin(float x);
+float o_cos(float x);
+
+/* ---- textures / sampling (rc_sampler.c) ---------------------------------------------- */
+enum { O_FMT_RGBA8 = 0, O_FMT_SRGB8 = 1, O_FMT_RGBX8 = 2, O_FMT_F32 = 3 };
+enum { O_WRAP_EDGE = 0, O_WRAP_BORDER = 1, O_WRAP_REPEAT = 2, O_WRAP_MIRROR = 3 };
+
+typedef struct {
+  const void* data; /* row 0 = t 0; RGBA8/SRGB8/RGBX8: 4 bytes per texel; F32: 4 floats */
+  int w, h;
+  int fmt;
+  int linear; /* filter: 1 = GL_LINEAR, 0 = GL_NEAREST */
+  int wrap;
+} o_tex;
+
+o_vec4 o_texel(const o_tex* t, int x, int y); /* decoded texel, no wrap */
+o_vec4 o_sample(const o_tex* t, float s, float v);
+extern const float o_srgb_decode_table[256];
+uint8_t o_store_unorm8(float x);
+uint8_t o_store_srgb8(float x);
+
+/* ---- varyings (rc_varying.c) --------------------------------------------------------- */
+/* A varying written by the vertex shader, as the rasteriser hands it to pixel (x, y) of a
+ * W x H target: plane-equation setup per triangle of the quad (BL,BR,TR)+(TR,TL,BL). */
+typedef struct { float a0_lo, dx_lo, dy_lo, a0_up, dx_up, dy_up; } o_varying;
+o_varying o_varying_setup(float a_bl, float a_br, float a_tr, float a_tl, int W, int H, int out_fmt);
+static inline int o_lower_tri(int x, int y, int W, int H) {
+  return ((double)y + 0.5) * (double)W < ((double)x + 0.5) * (double)H;
+}
+float o_varying_at(const o_varying* v, int x, int y, int lower);
+
+/* ---- passes ---------------------------------------------------------------------------- */
+/* Every pass renders a full out_w x out_h target from `in` (the previous pass's output with
+ * the sampler state the pass's preset entry sets on it).  dst receives stored texels
+ * (4 bytes, or 4 floats for O_FMT_F32).  `frame_count` is the value of the FrameCount
+ * uniform (first applied frame = 1).  params: the pass's #pragma parameter values in
+ * declaration order. */
+typedef struct {
+  const o_tex* in;       /* "Texture" sampler */
+  const o_tex* extra[8]; /* PassPrev / alias / LUT samplers, pass specific */
+  int src_w, src_h;      /* OriginalSize: size of the frame handed to applyShader */
+  int out_w, out_h;
+  int out_fmt;           /* O_FMT_RGBA8 / SRGB8 / F32 */
+  int frame_count;
+  const float* params;
+  void* dst;
+  int y0, y1;            /* row range to render (for threading); 0,out_h for all */
+} o_pass_args;
+
+void o_pass_stock(const o_pass_args* a);
+void o_pass_scanline(const o_pass_args* a);
+void o_pass_crt_pi(const o_pass_args* a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,113 @@
+/* TEST INFRASTRUCTURE - see rc_oracle.h.
+ *
+ * Hand restatement of the arithmetic of three reference shader assets:
+ *   stock    shaders/shaders_glsl/stock.glsl                      (passthrough)
+ *   scanline shaders/shaders_glsl/scanlines/shaders/scanline.glsl (VS line 50, FS 107-113)
+ *   crt-pi   shaders/shaders_glsl/crt/shaders/crt-pi.glsl         (VS 96-103, FS 131-232;
+ *            compile-time switches SCANLINES, MULTISAMPLE, GAMMA, MASK_TYPE 1 as shipped)
+ * Operation order follows the GLSL expression trees; nothing is fused.
+ */
+#include <math.h>
+
+#include "rc_oracle.h"
+
+static void store_px(const o_pass_args* a, int x, int y, o_vec4 c) {
+  size_t i = ((size_t)y * a->out_w + x) * 4;
+  if (a->out_fmt == O_FMT_F32) {
+    float* d = (float*)a->dst + i;
+    d[0] = c.x; d[1] = c.y; d[2] = c.z; d[3] = c.w;
+  } else if (a->out_fmt == O_FMT_SRGB8) {
+    uint8_t* d = (uint8_t*)a->dst + i;
+    d[0] = o_store_srgb8(c.x); d[1] = o_store_srgb8(c.y); d[2] = o_store_srgb8(c.z);
+    d[3] = o_store_unorm8(c.w);
+  } else {
+    uint8_t* d = (uint8_t*)a->dst + i;
+    d[0] = o_store_unorm8(c.x); d[1] = o_store_unorm8(c.y); d[2] = o_store_unorm8(c.z);
+    d[3] = o_store_unorm8(c.w);
+  }
+}
+
+void o_store_pixel(const o_pass_args* a, int x, int y, o_vec4 c) { store_px(a, x, y, c); }
+
+void o_pass_stock(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      store_px(a, x, y, o_sample(a->in, o_varying_at(&tu, x, y, lo), o_varying_at(&tv, x, y, lo)));
+    }
+}
+
+/* params: SCANLINE_BASE_BRIGHTNESS, SCANLINE_SINE_COMP_A, SCANLINE_SINE_COMP_B, size */
+void o_pass_scanline(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float base = a->params[0], comp_a = a->params[1], comp_b = a->params[2], size = a->params[3];
+  const float pi = 3.141592654f;
+  /* VS: omega = vec2(pi * size * OutputSize.x, 2.0 * pi * TextureSize.y); same at all 4
+   * vertices, so the interpolated value is the vertex value. */
+  const float omega_x = (pi * size) * (float)W;
+  const float omega_y = (2.0f * pi) * (float)a->in->h;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      o_vec4 res = o_sample(a->in, u, v);
+      float d = comp_a * o_sin(u * omega_x) + comp_b * o_sin(v * omega_y);
+      float k = base + d;
+      o_vec4 c = {res.x * k, res.y * k, res.z * k, 1.0f};
+      store_px(a, x, y, c);
+    }
+}
+
+/* params: CURVATURE_X, CURVATURE_Y, MASK_BRIGHTNESS, SCANLINE_WEIGHT,
+ *         SCANLINE_GAP_BRIGHTNESS, BLOOM_FACTOR, INPUT_GAMMA, OUTPUT_GAMMA */
+static inline float crtpi_weight(float dist, float sw, float gap) {
+  float w = 1.0f - (dist * dist) * sw;
+  return w > gap ? w : gap; /* max(w, gap) */
+}
+
+void o_pass_crt_pi(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float mask_b = a->params[2], sw = a->params[3], gap = a->params[4], bloom = a->params[5];
+  const float in_gamma = a->params[6], out_gamma = a->params[7];
+  const float tsy = (float)a->in->h; /* TextureSize == InputSize */
+  /* VS: filterWidth = (InputSize.y / OutputSize.y) / 3.0;  TEX0 = TexCoord * 1.0001 */
+  const float filter_width = (tsy / (float)H) / 3.0f;
+  const float k1 = 1.0001f;
+  o_varying tu = o_varying_setup(0.f * k1, 1.f * k1, 1.f * k1, 0.f * k1, W, H, a->out_fmt);
+  o_varying tv = o_varying_setup(0.f * k1, 0.f * k1, 1.f * k1, 1.f * k1, W, H, a->out_fmt);
+  const float inv_out_gamma = 1.0f / out_gamma;
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      float tcx = o_varying_at(&tu, x, y, lo), tcy = o_varying_at(&tv, x, y, lo);
+      float pix_y = tcy * tsy;
+      float temp_y = floorf(pix_y) + 0.5f;
+      float y_coord = temp_y / tsy;
+      float dy = pix_y - temp_y;
+      float slw = crtpi_weight(dy, sw, gap);
+      slw += crtpi_weight(dy - filter_width, sw, gap);
+      slw += crtpi_weight(dy + filter_width, sw, gap);
+      slw *= 0.3333333f;
+      float sign_y = dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f);
+      dy = dy * dy;
+      dy = dy * dy;
+      dy *= 8.0f;
+      dy /= tsy;
+      dy *= sign_y;
+      o_vec4 c = o_sample(a->in, tcx, y_coord + dy);
+      float r = o_pow(c.x, in_gamma), g = o_pow(c.y, in_gamma), b = o_pow(c.z, in_gamma);
+      slw *= bloom;
+      r *= slw; g *= slw; b *= slw;
+      r = o_pow(r, inv_out_gamma); g = o_pow(g, inv_out_gamma); b = o_pow(b, inv_out_gamma);
+      float fx = ((float)x + 0.5f) * 1.0001f * 0.5f;
+      float which = fx - floorf(fx);
+      o_vec4 o;
+      if (which < 0.5f) { o.x = r * mask_b; o.y = g * 1.0f; o.z = b * mask_b; }
+      else { o.x = r * 1.0f; o.y = g * mask_b; o.z = b * 1.0f; }
+      o.w = 1.0f;
+      store_px(a, x, y, o);
+    }
+}

@@ -1,0 +1,134 @@
+/* TEST INFRASTRUCTURE - see rc_oracle.h.
+ *
+ * Texture unit and render-target store, as the GL that runs the reference's shaders
+ * (Mesa 23.2.1 llvmpipe) behaves for the state the reference sets
+ * (ShaderEngine.cpp:1008-1036 filter/wrap on the input texture, :2872-2923 target formats,
+ * :944-952 GL_FRAMEBUFFER_SRGB).  Measured facts restated here (oracle/probes/):
+ *   - UNORM8 texel -> float: k * (1/255f);  sRGB8 texel: table, decoded before filtering;
+ *     GL_RGB source: alpha 1.
+ *   - NEAREST: texel floor(s*W) (wrap applied to the integer index).
+ *   - LINEAR, float path (sRGB8 / F32 textures, or any texture with clamp_to_border):
+ *     u = s*W - 0.5, weights frac(u), lerp = fma(w, b - a, a), x first then y.
+ *   - LINEAR, 8-bit fixed-point path (RGBA8 / RGBX8 with edge / repeat / mirror wrap):
+ *     weights rint(frac(u)*256), lerp = a + ((w*(b-a) + 128) >> 8) on bytes, x then y,
+ *     result k * (1/255f).
+ *   - store: UNORM8 = rint(clamp(x,0,1) * 255) (ties to even); sRGB8: monotone table.
+ */
+#include <math.h>
+
+#include "rc_oracle.h"
+#include "rc_tables.inc"
+
+static inline o_vec4 v4(float x, float y, float z, float w) { o_vec4 r = {x, y, z, w}; return r; }
+
+o_vec4 o_texel(const o_tex* t, int x, int y) {
+  if (t->fmt == O_FMT_F32) {
+    const float* p = (const float*)t->data + ((size_t)y * t->w + x) * 4;
+    return v4(p[0], p[1], p[2], p[3]);
+  }
+  const uint8_t* p = (const uint8_t*)t->data + ((size_t)y * t->w + x) * 4;
+  const float k = 1.0f / 255.0f;
+  if (t->fmt == O_FMT_SRGB8)
+    return v4(o_srgb_decode_table[p[0]], o_srgb_decode_table[p[1]], o_srgb_decode_table[p[2]],
+              (float)p[3] * k);
+  if (t->fmt == O_FMT_RGBX8) return v4((float)p[0] * k, (float)p[1] * k, (float)p[2] * k, 1.0f);
+  return v4((float)p[0] * k, (float)p[1] * k, (float)p[2] * k, (float)p[3] * k);
+}
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline int modi(int v, int n) { int r = v % n; return r < 0 ? r + n : r; }
+static inline int mirrori(int v, int n) { int p = modi(v, 2 * n); return p < n ? p : 2 * n - 1 - p; }
+
+/* integer texel index after wrap; returns -1 for "border" */
+static inline int wrap_index(int i, int n, int wrap) {
+  switch (wrap) {
+    case O_WRAP_REPEAT: return modi(i, n);
+    case O_WRAP_MIRROR: return mirrori(i, n);
+    case O_WRAP_BORDER: return (i < 0 || i >= n) ? -1 : i;
+    default: return clampi(i, 0, n - 1);
+  }
+}
+
+static inline o_vec4 fetch_wrapped(const o_tex* t, int x, int y) {
+  int xi = wrap_index(x, t->w, t->wrap), yi = wrap_index(y, t->h, t->wrap);
+  if (xi < 0 || yi < 0) return v4(0.f, 0.f, 0.f, 0.f); /* border colour (GL default) */
+  return o_texel(t, xi, yi);
+}
+
+static inline float lerpf(float w, float a, float b) { return fmaf(w, b - a, a); }
+
+static inline float linear_coord(float s, int n, int wrap) {
+  if (wrap == O_WRAP_REPEAT) s = s - floorf(s);
+  float u = s * (float)n;
+  if (wrap == O_WRAP_EDGE) u = fminf(fmaxf(u, 0.0f), (float)n);
+  return u - 0.5f;
+}
+
+o_vec4 o_sample(const o_tex* t, float s, float v) {
+  if (!t->linear) {
+    float fs = s, fv = v;
+    if (t->wrap == O_WRAP_REPEAT) { fs = s - floorf(s); fv = v - floorf(v); }
+    int x = (int)floorf(fs * (float)t->w), y = (int)floorf(fv * (float)t->h);
+    if (t->wrap == O_WRAP_REPEAT) { x = clampi(x, 0, t->w - 1); y = clampi(y, 0, t->h - 1); }
+    return fetch_wrapped(t, x, y);
+  }
+  int fixed = (t->fmt == O_FMT_RGBA8 || t->fmt == O_FMT_RGBX8) && t->wrap != O_WRAP_BORDER;
+  if (!fixed) {
+    float u = linear_coord(s, t->w, t->wrap), w = linear_coord(v, t->h, t->wrap);
+    float x0f = floorf(u), y0f = floorf(w);
+    float wx = u - x0f, wy = w - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f;
+    o_vec4 a = fetch_wrapped(t, x0, y0), b = fetch_wrapped(t, x0 + 1, y0);
+    o_vec4 c = fetch_wrapped(t, x0, y0 + 1), d = fetch_wrapped(t, x0 + 1, y0 + 1);
+    o_vec4 r;
+    r.x = lerpf(wy, lerpf(wx, a.x, b.x), lerpf(wx, c.x, d.x));
+    r.y = lerpf(wy, lerpf(wx, a.y, b.y), lerpf(wx, c.y, d.y));
+    r.z = lerpf(wy, lerpf(wx, a.z, b.z), lerpf(wx, c.z, d.z));
+    r.w = lerpf(wy, lerpf(wx, a.w, b.w), lerpf(wx, c.w, d.w));
+    return r;
+  }
+  /* 8-bit fixed-point path */
+  float fs = s, fv = v;
+  if (t->wrap == O_WRAP_REPEAT) { fs = s - floorf(s); fv = v - floorf(v); }
+  float u = fs * (float)t->w - 0.5f, w = fv * (float)t->h - 0.5f;
+  if (t->wrap == O_WRAP_EDGE) {
+    u = fminf(fmaxf(u, 0.0f), (float)(t->w - 1));
+    w = fminf(fmaxf(w, 0.0f), (float)(t->h - 1));
+  }
+  float x0f = floorf(u), y0f = floorf(w);
+  int wx = (int)rintf((u - x0f) * 256.0f), wy = (int)rintf((w - y0f) * 256.0f);
+  int x0 = wrap_index((int)x0f, t->w, t->wrap), x1 = wrap_index((int)x0f + 1, t->w, t->wrap);
+  int y0 = wrap_index((int)y0f, t->h, t->wrap), y1 = wrap_index((int)y0f + 1, t->h, t->wrap);
+  const uint8_t* base = (const uint8_t*)t->data;
+  const uint8_t* p00 = base + ((size_t)y0 * t->w + x0) * 4;
+  const uint8_t* p10 = base + ((size_t)y0 * t->w + x1) * 4;
+  const uint8_t* p01 = base + ((size_t)y1 * t->w + x0) * 4;
+  const uint8_t* p11 = base + ((size_t)y1 * t->w + x1) * 4;
+  float out[4];
+  for (int c = 0; c < 4; ++c) {
+    int a = p00[c], b = p10[c], cc = p01[c], d = p11[c];
+    if (c == 3 && t->fmt == O_FMT_RGBX8) a = b = cc = d = 255;
+    int top = (a + ((wx * (b - a) + 128) >> 8)) & 255;
+    int bot = (cc + ((wx * (d - cc) + 128) >> 8)) & 255;
+    int r = (top + ((wy * (bot - top) + 128) >> 8)) & 255;
+    out[c] = (float)r * (1.0f / 255.0f);
+  }
+  return v4(out[0], out[1], out[2], out[3]);
+}
+
+uint8_t o_store_unorm8(float x) {
+  if (!(x > 0.0f)) return 0; /* also NaN */
+  if (x > 1.0f) x = 1.0f;
+  return (uint8_t)rintf(x * 255.0f);
+}
+
+uint8_t o_store_srgb8(float x) {
+  if (!(x > 0.0f)) return 0;
+  /* number of thresholds <= x */
+  int lo = 0, hi = 255;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (o_srgb_encode_thresholds[mid] <= x) lo = mid + 1; else hi = mid;
+  }
+  return (uint8_t)lo;
+}

@@ -1,0 +1,72 @@
+"""ctypes binding of oracle/liboracle.so (TEST INFRASTRUCTURE: the checker, never the product)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+FMT = {"rgba8": 0, "srgb8": 1, "rgbx8": 2, "f32": 3}
+WRAP = {"clamp_to_edge": 0, "clamp_to_border": 1, "repeat": 2, "mirrored_repeat": 3}
+
+
+class OTex(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("w", C.c_int), ("h", C.c_int), ("fmt", C.c_int),
+                ("linear", C.c_int), ("wrap", C.c_int)]
+
+
+class OPassArgs(C.Structure):
+    _fields_ = [("inp", C.POINTER(OTex)), ("extra", C.POINTER(OTex) * 8), ("src_w", C.c_int),
+                ("src_h", C.c_int), ("out_w", C.c_int), ("out_h", C.c_int), ("out_fmt", C.c_int),
+                ("frame_count", C.c_int), ("params", C.POINTER(C.c_float)), ("dst", C.c_void_p),
+                ("y0", C.c_int), ("y1", C.c_int)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+        _LIB = C.CDLL(path)
+        for f in ("o_exp2", "o_log2", "o_exp", "o_log", "o_sin", "o_cos"):
+            getattr(_LIB, f).restype = C.c_float
+            getattr(_LIB, f).argtypes = [C.c_float]
+        _LIB.o_pow.restype = C.c_float
+        _LIB.o_pow.argtypes = [C.c_float, C.c_float]
+    return _LIB
+
+
+class Tex:
+    """A texture as a pass sees it: array + format + the sampler state set on it."""
+
+    def __init__(self, arr, fmt, linear, wrap):
+        self.arr = np.ascontiguousarray(arr)
+        self.c = OTex(self.arr.ctypes.data, self.arr.shape[1], self.arr.shape[0], FMT[fmt],
+                      int(bool(linear)), WRAP.get(wrap, 0))
+        self.fmt = fmt
+
+
+def run_pass(name, tex, out_w, out_h, out_fmt="rgba8", params=(), frame_count=1, extra=(),
+             src_w=None, src_h=None):
+    """Render one pass with the oracle; returns (out_h, out_w, 4) uint8 or float32."""
+    L = lib()
+    fn = getattr(L, "o_pass_" + name)
+    fn.restype = None
+    fn.argtypes = [C.POINTER(OPassArgs)]
+    dst = np.zeros((out_h, out_w, 4), np.float32 if out_fmt == "f32" else np.uint8)
+    p = (C.c_float * max(1, len(params)))(*params)
+    a = OPassArgs()
+    a.inp = C.pointer(tex.c)
+    for i, e in enumerate(extra):
+        a.extra[i] = C.pointer(e.c)
+    a.src_w = src_w or tex.c.w
+    a.src_h = src_h or tex.c.h
+    a.out_w, a.out_h, a.out_fmt = out_w, out_h, FMT[out_fmt]
+    a.frame_count = frame_count
+    a.params = p
+    a.dst = dst.ctypes.data
+    a.y0, a.y1 = 0, out_h
+    fn(C.byref(a))
+    return dst
