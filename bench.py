@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Shader-chain throughput benchmark (driver contract: see the task description).
+
+A "step" = one pass of the hot path (every pass of the preset) over one batch of synthetic
+frames that are already resident in HBM.  One process per GPU; frames are independent, so N
+GPUs shard the batch with no data-path collective (weak scaling: --batch frames per GPU per
+step).  torch is used for device memory, the stream and the barrier / MAX-over-ranks reduce.
+
+Prints ONE JSON line on rank 0 with the BASELINE metric plus `roofline` (dominant kernel,
+HIP-event timed on the launch stream) and `cpu_baseline` (the oracle, timed on the host cores
+on a bounded sample of the same workload; reported baseline only).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); measured copy ~6300
+
+WORKLOADS = {
+    # key: (chain_specs preset key, source w, h, viewport w, h, description)
+    "crt-royale": ("crt-royale", 1920, 1080, 1920, 1080, "crt/crt-royale.glslp 12-pass, 1920x1080 RGBA8 frames"),
+    "crt-pi": ("crt-pi", 1920, 1080, 1920, 1080, "crt/crt-pi.glslp 1-pass, 1920x1080 RGBA8 frames"),
+    "scanline": ("scanline", 320, 240, 320, 240, "scanlines/shaders/scanline.glsl 1-pass, 320x240"),
+}
+
+
+def default_workload():
+    import chain_specs
+    return "crt-royale" if "crt-royale" in chain_specs.PRESETS else "crt-pi"
+
+
+def cpu_baseline(key, w, h, vw, vh, tree, budget_s=15.0):
+    """Oracle (C restatement) on the host cores, rows of each pass split across threads."""
+    import numpy as np
+    import chain_specs
+    import oracle_chain
+    import oracle_lib
+    from retrocapture_amd import engine as eng
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    passes = eng.preset_dump(tree[key])["passes"]
+    rng = np.random.default_rng(123)
+    frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    oracle_lib.set_threads(cores)
+    oracle_chain.run_chain(passes, frame[: max(8, h // 16)], vw, max(8, vh // 16))  # warm (page in)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        oracle_chain.run_chain(passes, frame, vw, vh, frame_count=n + 1)
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 32:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d full frame(s) of the same workload through oracle/liboracle.so, %d threads by rows, %.1f s"
+                      % (n, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--chunk", type=int, default=0, help="frames per kernel launch (0 = engine default)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import chain_specs
+    from retrocapture_amd import ShaderEngine
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+
+    wl = args.workload or default_workload()
+    key, w, h, vw, vh, desc = WORKLOADS[wl]
+    tmp = tempfile.TemporaryDirectory()
+    tree = chain_specs.write_tree(tmp.name)
+
+    stream = torch.cuda.current_stream()
+    e = ShaderEngine()
+    if not e.init(local, stream.cuda_stream):
+        raise SystemExit("ShaderEngine.init failed (no HIP device; there is no CPU fallback)")
+    e.setAllowMissingSources(True)
+    st = e.loadPresetStatus(tree[key])
+    if st != 0:
+        raise SystemExit("preset %s not fully supported (status %d)" % (key, st))
+    e.setViewport(vw, vh)
+    if args.chunk:
+        e.setChunkFrames(args.chunk)
+
+    # synthetic frames, resident in HBM before the timed region: uniform noise, alpha 255
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234 + rank)
+    frames = torch.randint(0, 256, (args.batch, h, w, 4), dtype=torch.uint8, device="cuda", generator=g)
+    frames[..., 3] = 255
+
+    def step():
+        e.applyShaderBatch(frames, args.batch, w, h)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel timing with HIP events on the launch stream, over the same steps again
+    e.setProfiling(True)
+    for _ in range(args.steps):
+        step()
+    prof = [e.passProfile(i) for i in range(e.passCount())]
+    infos = [e.passInfo(i) for i in range(e.passCount())]
+    e.setProfiling(False)
+    dom = max(range(len(prof)), key=lambda i: prof[i]["total_ms"])
+    p = prof[dom]
+    frames_per_launch = p["frames"] / max(1, p["launches"])
+    bytes_per_launch = (p["read_bytes_per_frame"] + p["write_bytes_per_frame"]) * frames_per_launch
+    avg_ms = p["total_ms"] / max(1, p["launches"])
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    chain_bytes = sum(q["read_bytes_per_frame"] + q["write_bytes_per_frame"] for q in prof)
+
+    total_frames = args.batch * args.steps * world
+    value = total_frames / dt
+    out = {
+        "metric": "1080p frames/sec, crt-royale 12-pass, 1/2/4/8 MI355X; % HBM roofline",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "frames_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
+                   "chunk_frames": args.chunk or "default", "parallelism": "frames sharded, no collective",
+                   "algorithmic_bytes_per_frame": chain_bytes,
+                   "hbm_roofline_frac_whole_chain": value / world * chain_bytes / (HBM_PEAK_GBS * 1e9)},
+        "roofline": {"bound": "hbm", "kernel": infos[dom]["kernel"], "pass": dom, "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch,
+                     "algorithmic_bytes_per_launch": bytes_per_launch},
+        "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in prof],
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(key, w, h, vw, vh, tree)
+        print(json.dumps(out))
+    e.shutdown()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

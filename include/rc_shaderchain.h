@@ -1,0 +1,155 @@
+/* rc_shaderchain.h - C ABI of the MI355X shader-chain engine (librcshaderchain.so).
+ *
+ * Drop-in boundary for RetroCapture's per-frame RetroArch-GLSL shader chain: every entry
+ * point replaces one member of the reference's C++ class `ShaderEngine`
+ * (reference src/shader/ShaderEngine.h:42-98; implementation src/shader/ShaderEngine.cpp).
+ * Plain pointers and sizes only; frames are DEVICE pointers to 8-bit RGBA texels, row 0
+ * first (= texture coordinate t 0, the reference's upload order, FrameProcessor.cpp:172-205),
+ * alpha ignored on input (the reference's source texture is GL_RGB) and written by the last
+ * pass on output.  Output frames are owned by the engine and stay valid until the next
+ * apply / load / destroy on the same engine (reference ShaderEngine.cpp:1873).
+ *
+ * Error convention, as in the reference: calls return a status / handle and describe the
+ * failure in the log (stderr, level from RETROCAPTURE_LOG_LEVEL); rc_last_error() returns the
+ * last error text of the calling thread.  No C++ exception crosses this boundary.
+ *
+ * Threading, as in the reference: one thread drives an engine (create, load, viewport,
+ * apply); rc_engine_param_* and rc_engine_preset_path may additionally be called from
+ * other threads (the reference's HTTP worker does, APIController.cpp:1046,1340,1759) and
+ * are internally locked here.
+ */
+#ifndef RC_SHADERCHAIN_H
+#define RC_SHADERCHAIN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rc_engine rc_engine;
+
+enum {
+  RC_OK = 0,
+  RC_ERR_INVALID = -1,     /* bad handle / argument                                        */
+  RC_ERR_LOAD = -2,        /* preset / shader could not be parsed or opened                */
+  RC_ERR_DEVICE = -3,      /* HIP failure (allocation, launch)                             */
+  RC_WARN_PASSES = 1       /* preset loaded, but >= 1 pass has no kernel and is skipped,
+                              exactly like a pass whose GLSL failed to compile in the
+                              reference (ShaderEngine.cpp:968-975)                          */
+};
+
+/* ShaderEngine::ShaderEngine + init() (ShaderEngine.cpp:22-60).  device < 0 keeps the
+ * calling thread's current HIP device; hip_stream is a hipStream_t (NULL = default
+ * stream) on which every kernel of this engine is enqueued.  NULL on failure (no HIP
+ * device: there is no CPU fallback). */
+rc_engine* rc_engine_create(int device, void* hip_stream);
+/* shutdown() + destructor (ShaderEngine.cpp:62-86). */
+void rc_engine_destroy(rc_engine* e);
+
+/* loadPreset(path) (ShaderEngine.cpp:228-319): parses the .glslp, loads LUT PNGs, reads
+ * each pass's #pragma parameters and resolves its HIP kernel.  Clears custom parameters. */
+int rc_engine_load_preset(rc_engine* e, const char* glslp_path);
+/* loadShader(path) (ShaderEngine.cpp:149-226): one .glsl file as a one-pass chain. */
+int rc_engine_load_shader(rc_engine* e, const char* glsl_path);
+/* getPresetPath() (ShaderEngine.h:56).  Copies up to cap-1 bytes; returns full length. */
+size_t rc_engine_preset_path(rc_engine* e, char* buf, size_t cap);
+/* disableShader() / isShaderActive() (ShaderEngine.h:65-67). */
+void rc_engine_disable(rc_engine* e);
+int rc_engine_is_active(rc_engine* e);
+
+/* setViewport(w,h) (ShaderEngine.cpp:3154-3206): must precede apply for presets. */
+void rc_engine_set_viewport(rc_engine* e, uint32_t width, uint32_t height);
+/* setMaxShaderResolution(w,h) (ShaderEngine.h:74-76); 0,0 = off (default). */
+void rc_engine_set_max_resolution(rc_engine* e, uint32_t max_width, uint32_t max_height);
+
+/* applyShader(texture, w, h) (ShaderEngine.cpp:1531-1879).  d_in: device pointer to
+ * width*height RGBA8 texels.  *d_out receives the device pointer of the output frame:
+ * the engine's buffer, or d_in itself when no shader is active / no pass is usable (the
+ * reference returns the input texture in those cases, :1533, :1606-1619).  Advances the
+ * engine's FrameCount by one (:1688).  Work is enqueued on the engine's stream and NOT
+ * synchronised. */
+int rc_engine_apply(rc_engine* e, const void* d_in, uint32_t width, uint32_t height,
+                    const void** d_out, uint32_t* out_width, uint32_t* out_height);
+/* N independent frames in one call: frame k (0-based) is processed with the FrameCount
+ * that the k-th of N successive rc_engine_apply calls would see.  frame_stride = bytes
+ * between input frames (0 = width*height*4).  *d_out: N output frames, tightly packed. */
+int rc_engine_apply_batch(rc_engine* e, const void* d_in, uint32_t n_frames, uint32_t width,
+                          uint32_t height, uint64_t frame_stride, const void** d_out,
+                          uint32_t* out_width, uint32_t* out_height);
+/* getOutputWidth()/getOutputHeight() (ShaderEngine.h:70-71): size of the last output. */
+uint32_t rc_engine_output_width(rc_engine* e);
+uint32_t rc_engine_output_height(rc_engine* e);
+/* hipStreamSynchronize on the engine's stream. */
+int rc_engine_sync(rc_engine* e);
+
+/* getShaderParameters() (ShaderEngine.cpp:3264-3351): union of all passes' #pragma
+ * parameters, sorted by name; value = custom > preset > default. */
+typedef struct {
+  char name[64];
+  char description[128];
+  float value, default_value, min, max, step;
+} rc_param;
+int rc_engine_param_count(rc_engine* e);
+int rc_engine_param_get(rc_engine* e, int index, rc_param* out);
+/* setShaderParameter(name, v) (ShaderEngine.cpp:3353-3387): clamps to [min,max];
+ * returns 1 if the parameter exists, 0 otherwise. */
+int rc_engine_param_set(rc_engine* e, const char* name, float value);
+/* setUniform(name, ...) x3 (ShaderEngine.cpp:3006-3041): recorded only; as in the
+ * reference they do not reach preset passes. */
+void rc_engine_set_uniform1(rc_engine* e, const char* name, float x);
+void rc_engine_set_uniform2(rc_engine* e, const char* name, float x, float y);
+void rc_engine_set_uniform4(rc_engine* e, const char* name, float x, float y, float z, float w);
+/* ShaderPreset::saveAs via getPreset() (ShaderPreset.cpp:557-661) with the engine's custom
+ * parameters, as the reference's UI does (UICallbackWiring.cpp:172-175). */
+int rc_engine_save_preset(rc_engine* e, const char* path);
+
+/* ---- inspection (no reference counterpart; used by tests and tools) -------------------- */
+typedef struct {
+  uint32_t width, height;   /* render-target size at the last apply                       */
+  int format;               /* 0 RGBA8, 1 sRGB8_ALPHA8, 3 RGBA32F                          */
+  int has_kernel;           /* 0: pass is skipped                                          */
+  int filter_linear;        /* the pass's filter_linear / wrap (state set on its INPUT)    */
+  int wrap;                 /* 0 edge, 1 border, 2 repeat, 3 mirrored_repeat               */
+  char kernel[48];
+  char alias[48];
+} rc_pass_info;
+int rc_engine_pass_count(rc_engine* e);
+int rc_engine_pass_info(rc_engine* e, int pass, rc_pass_info* out);
+/* Copies pass `pass`'s render target of frame `frame` (index within the last batch; an
+ * intermediate pass only holds the last chunk) to host memory.  Synchronises. */
+int rc_engine_read_pass(rc_engine* e, int pass, uint32_t frame, void* host, size_t bytes);
+/* Per-pass device timing (HIP events on the engine's stream around every pass launch) and
+ * the pass's algorithmic bytes per frame (each distinct sampled texture once at its stored
+ * size + the target once).  rc_engine_pass_profile synchronises the stream. */
+typedef struct {
+  double total_ms;
+  uint64_t launches;
+  uint64_t frames;
+  uint64_t read_bytes_per_frame;
+  uint64_t write_bytes_per_frame;
+} rc_pass_profile;
+void rc_engine_set_profiling(rc_engine* e, int on);
+int rc_engine_pass_profile(rc_engine* e, int pass, rc_pass_profile* out);
+/* Frames processed per kernel launch through the whole chain (default 4). */
+void rc_engine_set_chunk_frames(rc_engine* e, uint32_t n);
+/* 1: a pass whose .glsl file is unreadable still runs if its shader identity is registered
+ * (built-in parameter table).  Default 0 = the reference's behaviour (pass fails). */
+void rc_engine_set_allow_missing_sources(rc_engine* e, int allow);
+
+const char* rc_last_error(void);
+const char* rc_version(void);
+/* Names of the registered kernels ("identity\n" list) for diagnostics. */
+size_t rc_kernel_list(char* buf, size_t cap);
+
+/* Standalone preset parser check (ShaderPreset::load, ShaderPreset.cpp:18-333): writes a JSON
+ * description of the parsed preset; returns the length needed.  No GPU needed. */
+size_t rc_preset_dump_json(const char* glslp_path, char* buf, size_t cap);
+/* #pragma parameter scan of one shader file (ShaderPreprocessor.cpp:30-79) as JSON. */
+size_t rc_shader_params_json(const char* glsl_path, char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RC_SHADERCHAIN_H */

@@ -1,0 +1,47 @@
+// Registry of hand-written HIP pass kernels, keyed by shader identity.
+//
+// There is no GLSL compiler in this engine: a preset pass can run only if its shader file
+// is one the registry knows (identity = the path below ".../shaders_glsl/", falling back to
+// the last two path components).  Each entry carries what the reference would have learnt
+// from compiling the GLSL: which samplers the shader declares besides its input
+// (reference ShaderEngine.cpp:1049-1415 binds them by uniform name) and the #pragma
+// parameter table (used when the .glsl file itself is not readable, e.g. on a machine that
+// has presets but not the shader sources).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "kernels/pass_launch.h"
+#include "pragma_params.h"
+
+namespace rc {
+
+struct PassGeometry {  // what a kernel's setup hook may look at
+  int pass_index;
+  int in_w, in_h;    // TextureSize == InputSize (reference ShaderEngine.cpp:2401-2437)
+  int out_w, out_h, out_fmt;
+  int src_w, src_h;  // OriginalSize
+  int vp_w, vp_h;
+};
+
+struct KernelParam {
+  const char* name;
+  float def, min, max, step;
+  const char* description;
+};
+
+struct KernelEntry {
+  const char* identity;                 // e.g. "crt/shaders/crt-pi.glsl"
+  const char* name;                     // short name, also used by rc_engine_pass_kernel()
+  std::vector<KernelParam> params;      // in the order the kernel expects them in PassLaunch::params
+  std::vector<const char*> samplers;    // extra sampler uniform names, in PassLaunch::extra order
+  rck::LaunchFn launch;
+  void (*setup)(const PassGeometry& g, rcd::PassLaunch& L);  // planes + derived constants
+  bool frame_invariant;                 // output does not depend on the frame (may be cached)
+};
+
+const KernelEntry* findKernel(const std::string& shaderPath);
+const std::vector<KernelEntry>& allKernels();
+std::string shaderIdentity(const std::string& shaderPath);
+
+}  // namespace rc

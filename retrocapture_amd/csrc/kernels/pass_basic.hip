@@ -1,0 +1,121 @@
+// Pass kernels for three reference shader assets (arithmetic spec = the GLSL text):
+//   stock.glsl                         shaders/shaders_glsl/stock.glsl
+//   scanlines/shaders/scanline.glsl    VS line 50, FS lines 107-113
+//   crt/shaders/crt-pi.glsl            VS lines 96-103, FS lines 131-232
+//     (compile-time switches as shipped: SCANLINES, MULTISAMPLE, GAMMA, MASK_TYPE 1)
+// One thread per target pixel; blockIdx.z = frame of the batch.
+#include "pass_launch.h"
+
+using namespace rcd;
+
+namespace {
+
+__global__ void __launch_bounds__(256) k_stock(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, z = blockIdx.z;
+  if (x >= L.out_w || y >= L.out_h) return;
+  const bool lo = lower_tri(x, y, L.out_w, L.out_h);
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  store_rt(L, z, x, y, sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds), &lds);
+}
+
+// params: SCANLINE_BASE_BRIGHTNESS, SCANLINE_SINE_COMP_A, SCANLINE_SINE_COMP_B, size
+__global__ void __launch_bounds__(256) k_scanline(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, z = blockIdx.z;
+  if (x >= L.out_w || y >= L.out_h) return;
+  const float base = L.params[0], comp_a = L.params[1], comp_b = L.params[2], size = L.params[3];
+  const float pi = 3.141592654f;
+  const float omega_x = (pi * size) * (float)L.out_w;
+  const float omega_y = (2.0f * pi) * (float)L.in.h;
+  const bool lo = lower_tri(x, y, L.out_w, L.out_h);
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float4 res = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+  const float d = comp_a * sin_(u * omega_x) + comp_b * sin_(v * omega_y);
+  const float k = base + d;
+  store_rt(L, z, x, y, make_float4(res.x * k, res.y * k, res.z * k, 1.0f), &lds);
+}
+
+__device__ __forceinline__ float crtpi_weight(float dist, float sw, float gap) {
+  float w = 1.0f - (dist * dist) * sw;
+  return w > gap ? w : gap;
+}
+
+// params: CURVATURE_X, CURVATURE_Y, MASK_BRIGHTNESS, SCANLINE_WEIGHT,
+//         SCANLINE_GAP_BRIGHTNESS, BLOOM_FACTOR, INPUT_GAMMA, OUTPUT_GAMMA
+// plane[0], plane[1]: TEX0 = TexCoord * 1.0001
+template <int IN_FMT, int IN_LINEAR, int IN_WRAP, int OUT_FMT, bool GENERIC>
+__global__ void __launch_bounds__(256) k_crt_pi(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  if (GENERIC || IN_FMT == FMT_SRGB8 || OUT_FMT == FMT_SRGB8) load_srgb_tables(lds);
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, z = blockIdx.z;
+  if (x >= L.out_w || y >= L.out_h) return;
+  const float mask_b = L.params[2], sw = L.params[3], gap = L.params[4], bloom = L.params[5];
+  const float in_gamma = L.params[6], out_gamma = L.params[7];
+  const float tsy = (float)L.in.h;
+  const float filter_width = (tsy / (float)L.out_h) / 3.0f;
+  const float inv_out_gamma = 1.0f / out_gamma;
+  const bool lo = lower_tri(x, y, L.out_w, L.out_h);
+  const float tcx = vary(L.plane[0], x, y, lo), tcy = vary(L.plane[1], x, y, lo);
+  const float pix_y = tcy * tsy;
+  const float temp_y = __builtin_floorf(pix_y) + 0.5f;
+  const float y_coord = temp_y / tsy;
+  float dy = pix_y - temp_y;
+  float slw = crtpi_weight(dy, sw, gap);
+  slw += crtpi_weight(dy - filter_width, sw, gap);
+  slw += crtpi_weight(dy + filter_width, sw, gap);
+  slw *= 0.3333333f;
+  const float sign_y = dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f);
+  dy = dy * dy;
+  dy = dy * dy;
+  dy *= 8.0f;
+  dy /= tsy;
+  dy *= sign_y;
+  const uint8_t* img = frame_ptr(L.in, z);
+  const float4 c = GENERIC ? sample_rt(L.in, img, tcx, y_coord + dy, &lds)
+                           : sample<IN_FMT, IN_LINEAR, IN_WRAP>(L.in, img, tcx, y_coord + dy, &lds);
+  float r = pow_(c.x, in_gamma), g = pow_(c.y, in_gamma), b = pow_(c.z, in_gamma);
+  slw *= bloom;
+  r *= slw;
+  g *= slw;
+  b *= slw;
+  r = pow_(r, inv_out_gamma);
+  g = pow_(g, inv_out_gamma);
+  b = pow_(b, inv_out_gamma);
+  const float fx = ((float)x + 0.5f) * 1.0001f * 0.5f;
+  const float which = fx - __builtin_floorf(fx);
+  float4 o;
+  if (which < 0.5f) {
+    o = make_float4(r * mask_b, g * 1.0f, b * mask_b, 1.0f);
+  } else {
+    o = make_float4(r * 1.0f, g * mask_b, b * 1.0f, 1.0f);
+  }
+  if (GENERIC) store_rt(L, z, x, y, o, &lds);
+  else store<OUT_FMT>(L, z, x, y, o, &lds);
+}
+
+}  // namespace
+
+namespace rck {
+
+hipError_t launch_stock(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_stock, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_scanline, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_crt_pi(const PassLaunch& L, hipStream_t s) {
+  // the shipped preset's configuration (crt/crt-pi.glslp: linear, clamp_to_border, RGBA8 out,
+  // on the RGB source frame) gets a specialised instantiation
+  if (L.in.fmt == FMT_RGBX8 && L.in.linear && L.in.wrap == WRAP_BORDER && L.out_fmt == FMT_RGBA8)
+    hipLaunchKernelGGL((k_crt_pi<FMT_RGBX8, 1, WRAP_BORDER, FMT_RGBA8, false>), px_grid(L), px_block(), 0, s, L);
+  else
+    hipLaunchKernelGGL((k_crt_pi<0, 0, 0, 0, true>), px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+
+}  // namespace rck

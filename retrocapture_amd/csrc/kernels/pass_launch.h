@@ -1,0 +1,22 @@
+// Host-visible entry points of the pass kernels: one launch function per registered
+// shader.  A launch renders L.n_frames frames (grid z) of one pass on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rc_device.h"
+
+namespace rck {
+using rcd::PassLaunch;
+typedef hipError_t (*LaunchFn)(const PassLaunch& L, hipStream_t stream);
+
+hipError_t launch_stock(const PassLaunch& L, hipStream_t s);
+hipError_t launch_scanline(const PassLaunch& L, hipStream_t s);
+hipError_t launch_crt_pi(const PassLaunch& L, hipStream_t s);
+
+// 64x4 pixel workgroups: one wave per target row segment, 4 rows per group, so each wave
+// stores 256 contiguous bytes of an RGBA8 row.
+inline dim3 px_block() { return dim3(64, 4, 1); }
+inline dim3 px_grid(const PassLaunch& L) {
+  return dim3((unsigned)((L.out_w + 63) / 64), (unsigned)((L.out_h + 3) / 4), (unsigned)L.n_frames);
+}
+}  // namespace rck

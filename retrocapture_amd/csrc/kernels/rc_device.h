@@ -1,0 +1,333 @@
+// Device-side building blocks shared by every pass kernel (gfx950 / CDNA4 only).
+//
+// A pass kernel computes, for each pixel of its render target, exactly what the GL
+// fragment pipeline computes for the reference's draw call (reference
+// src/shader/ShaderEngine.cpp:850-1475): varyings from the quad's plane equations, texture
+// taps with the sampler state the preset sets, the shader's arithmetic, and the
+// target-format store.  The float behaviour that defines "the same result" is that of the GL
+// the reference is measured on (Mesa llvmpipe 23.2.1): its pow/exp2/log2/sin/cos
+// polynomials (fused multiply-adds where llvmpipe fuses), its texel decode and two filter
+// paths, its varying setup and its store rounding.  All of that is written here directly in
+// HIP; the file is compiled with -ffp-contract=off so only the explicit __builtin_fmaf calls
+// fuse, and float division / sqrt are IEEE-correct (hipcc default).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rcd {
+
+// ---------------------------------------------------------------- launch descriptors ----
+enum Fmt : int { FMT_RGBA8 = 0, FMT_SRGB8 = 1, FMT_RGBX8 = 2, FMT_F32 = 3 };
+enum Wrap : int { WRAP_EDGE = 0, WRAP_BORDER = 1, WRAP_REPEAT = 2, WRAP_MIRROR = 3 };
+
+struct Tex {
+  const void* base;      // frame 0 of the batch
+  uint64_t frame_stride; // bytes between consecutive frames (0: one image shared by all)
+  int w, h;
+  int fmt, linear, wrap;
+};
+
+// Plane equation of one varying for the two triangles of the quad (see host varying.cpp).
+struct Plane {
+  float a0_lo, dx_lo, dy_lo, a0_up, dx_up, dy_up;
+};
+
+constexpr int kMaxExtra = 6;
+constexpr int kMaxPlanes = 6;
+constexpr int kMaxParams = 48;
+
+struct PassLaunch {
+  Tex in;                 // the pass's "Texture" sampler
+  Tex extra[kMaxExtra];   // PassPrev / alias / OrigTexture / LUT samplers, kernel specific
+  void* out;
+  uint64_t out_frame_stride;
+  int out_w, out_h, out_fmt;
+  int src_w, src_h;       // OriginalSize
+  int vp_w, vp_h;         // viewport
+  int frame_count0;       // FrameCount of frame 0 of this launch; frame z sees frame_count0+z
+  int n_frames;
+  Plane plane[kMaxPlanes];
+  float params[kMaxParams];
+};
+
+// -------------------------------------------------------------------- float primitives ----
+__device__ __forceinline__ float bits2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t f2bits(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+__device__ __forceinline__ float exp2_(float x) {
+  x = x > 128.0f ? 128.0f : x;
+  x = x < -126.99999f ? -126.99999f : x;
+  float ip = __builtin_floorf(x);
+  float fp = x - ip;
+  float e = bits2f((uint32_t)(((int32_t)ip + 127) << 23));
+  float x2 = fp * fp;
+  float even = fma_(x2, 0.00898934009049466391101f, 0.240153617044375388211f);
+  even = fma_(x2, even, 1.0f);
+  float odd = fma_(x2, 0.00187757667519147912699f, 0.0558263180532956664775f);
+  odd = fma_(x2, odd, 0.693153073200168932794f);
+  return e * fma_(odd, fp, even);
+}
+
+__device__ __forceinline__ float log2_(float x) {
+  uint32_t i = f2bits(x);
+  float logexp = (float)((int32_t)((i & 0x7f800000u) >> 23) - 127);
+  float mant = bits2f((i & 0x007fffffu) | 0x3f800000u);
+  float y = (mant - 1.0f) / (mant + 1.0f);
+  float z = y * y;
+  float z2 = z * z;
+  float even = fma_(z2, 0.406718052498846252698f, 0.577440339438736392009f);
+  even = fma_(z2, even, 2.88539009343309178325f);
+  float odd = fma_(z2, 0.403343858251329912514f, 0.961791550404184197881f);
+  float p = fma_(odd, z, even);
+  return fma_(y, p, logexp);
+}
+
+__device__ __forceinline__ float pow_(float x, float y) { return exp2_(log2_(x) * y); }
+__device__ __forceinline__ float exp_(float x) { return exp2_(x * 1.4426950408889634f); }
+__device__ __forceinline__ float log_(float x) { return log2_(x) * 0.69314718055994529f; }
+
+template <bool COS>
+__device__ __forceinline__ float sincos_(float x) {
+  uint32_t xi = f2bits(x);
+  float xa = bits2f(xi & 0x7fffffffu);
+  uint32_t sign = xi & 0x80000000u;
+  float y = xa * 1.27323954473516f;
+  int32_t j = (int32_t)y;
+  j = (j + 1) & ~1;
+  float y2 = (float)j;
+  int32_t j2 = COS ? j - 2 : j;
+  uint32_t swap = COS ? (((uint32_t)~j2 & 4u) << 29) : (((uint32_t)j & 4u) << 29);
+  bool poly_sin = (j2 & 2) == 0;
+  float x3 = fma_(y2, -0.78515625f, xa);
+  x3 = fma_(y2, -2.4187564849853515625e-4f, x3);
+  x3 = fma_(y2, -3.77489497744594108e-8f, x3);
+  float z = x3 * x3;
+  float ys = fma_(-1.9515295891E-4f, z, 8.3321608736E-3f);
+  ys = fma_(ys, z, -1.6666654611E-1f);
+  ys = ys * z;
+  ys = fma_(ys, x3, x3);
+  float yc = fma_(2.443315711809948E-005f, z, -1.388731625493765E-003f);
+  yc = fma_(yc, z, 4.166664568298827E-002f);
+  yc = yc * z;
+  yc = yc * z;
+  yc = yc - z * 0.5f;
+  yc = yc + 1.0f;
+  float r = poly_sin ? ys : yc;
+  uint32_t sb = COS ? swap : (sign ^ swap);
+  return bits2f(f2bits(r) ^ sb);
+}
+__device__ __forceinline__ float sin_(float x) { return sincos_<false>(x); }
+__device__ __forceinline__ float cos_(float x) { return sincos_<true>(x); }
+
+// ----------------------------------------------------------------------------- varyings ----
+__device__ __forceinline__ bool lower_tri(int x, int y, int W, int H) {
+  return (2 * y + 1) * W < (2 * x + 1) * H;  // pixel centre below the BL-TR diagonal
+}
+__device__ __forceinline__ float vary(const Plane& p, int x, int y, bool lower) {
+  float a0 = lower ? p.a0_lo : p.a0_up, dx = lower ? p.dx_lo : p.dx_up, dy = lower ? p.dy_lo : p.dy_up;
+  return fma_(dy, (float)y, fma_(dx, (float)x, a0));
+}
+
+// ------------------------------------------------------------------------------- tables ----
+// sRGB8 -> linear float as the texture unit decodes it, and the thresholds of the sRGB8
+// encode (tables measured on the GL; the same numbers as oracle/rc_tables.inc
+// but owned by the product).
+#include "rc_tables_device.inc"  // k_srgb_decode[256], k_srgb_encode_thr[256] ([255] = +inf)
+
+struct SrgbLds {
+  float dec[256];
+  float thr[256];
+};
+// Every thread of the block must call this before sampling sRGB textures / storing sRGB.
+__device__ __forceinline__ void load_srgb_tables(SrgbLds& t) {
+  for (int i = threadIdx.y * blockDim.x + threadIdx.x; i < 256; i += blockDim.x * blockDim.y) {
+    t.dec[i] = k_srgb_decode[i];
+    t.thr[i] = k_srgb_encode_thr[i];
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------ sampling ----
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int modi(int v, int n) {
+  int r = v % n;
+  return r < 0 ? r + n : r;
+}
+template <int WRAP>
+__device__ __forceinline__ int wrap_index(int i, int n) {
+  if (WRAP == WRAP_REPEAT) return modi(i, n);
+  if (WRAP == WRAP_MIRROR) {
+    int p = modi(i, 2 * n);
+    return p < n ? p : 2 * n - 1 - p;
+  }
+  if (WRAP == WRAP_BORDER) return (i < 0 || i >= n) ? -1 : i;
+  return clampi(i, 0, n - 1);
+}
+
+template <int FMT>
+__device__ __forceinline__ float4 texel(const Tex& t, const uint8_t* img, int x, int y, const SrgbLds* lds) {
+  if (FMT == FMT_F32) {
+    return *reinterpret_cast<const float4*>(img + ((size_t)y * t.w + x) * 16);
+  }
+  uint32_t p = *reinterpret_cast<const uint32_t*>(img + ((size_t)y * t.w + x) * 4);
+  const float k = 1.0f / 255.0f;
+  uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u, a = p >> 24;
+  if (FMT == FMT_SRGB8) return make_float4(lds->dec[r], lds->dec[g], lds->dec[b], (float)a * k);
+  if (FMT == FMT_RGBX8) return make_float4((float)r * k, (float)g * k, (float)b * k, 1.0f);
+  return make_float4((float)r * k, (float)g * k, (float)b * k, (float)a * k);
+}
+
+template <int FMT, int WRAP>
+__device__ __forceinline__ float4 fetch_wrapped(const Tex& t, const uint8_t* img, int x, int y, const SrgbLds* lds) {
+  int xi = wrap_index<WRAP>(x, t.w), yi = wrap_index<WRAP>(y, t.h);
+  if (WRAP == WRAP_BORDER && (xi < 0 || yi < 0)) return make_float4(0.f, 0.f, 0.f, 0.f);
+  return texel<FMT>(t, img, xi, yi, lds);
+}
+
+__device__ __forceinline__ float lerp_(float w, float a, float b) { return fma_(w, b - a, a); }
+
+template <int WRAP>
+__device__ __forceinline__ float linear_coord(float s, int n) {
+  if (WRAP == WRAP_REPEAT) s = s - __builtin_floorf(s);
+  float u = s * (float)n;
+  if (WRAP == WRAP_EDGE) u = fminf(fmaxf(u, 0.0f), (float)n);
+  return u - 0.5f;
+}
+
+// GL_NEAREST
+template <int FMT, int WRAP>
+__device__ __forceinline__ float4 sample_nearest(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* lds) {
+  if (WRAP == WRAP_REPEAT) {
+    s = s - __builtin_floorf(s);
+    v = v - __builtin_floorf(v);
+  }
+  int x = (int)__builtin_floorf(s * (float)t.w), y = (int)__builtin_floorf(v * (float)t.h);
+  if (WRAP == WRAP_REPEAT) {
+    x = clampi(x, 0, t.w - 1);
+    y = clampi(y, 0, t.h - 1);
+  }
+  return fetch_wrapped<FMT, WRAP>(t, img, x, y, lds);
+}
+
+// GL_LINEAR, float filter path (sRGB8 / F32 textures, or clamp_to_border)
+template <int FMT, int WRAP>
+__device__ __forceinline__ float4 sample_linear_f(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* lds) {
+  float u = linear_coord<WRAP>(s, t.w), w = linear_coord<WRAP>(v, t.h);
+  float x0f = __builtin_floorf(u), y0f = __builtin_floorf(w);
+  float wx = u - x0f, wy = w - y0f;
+  int x0 = (int)x0f, y0 = (int)y0f;
+  float4 a = fetch_wrapped<FMT, WRAP>(t, img, x0, y0, lds), b = fetch_wrapped<FMT, WRAP>(t, img, x0 + 1, y0, lds);
+  float4 c = fetch_wrapped<FMT, WRAP>(t, img, x0, y0 + 1, lds), d = fetch_wrapped<FMT, WRAP>(t, img, x0 + 1, y0 + 1, lds);
+  return make_float4(lerp_(wy, lerp_(wx, a.x, b.x), lerp_(wx, c.x, d.x)), lerp_(wy, lerp_(wx, a.y, b.y), lerp_(wx, c.y, d.y)),
+                     lerp_(wy, lerp_(wx, a.z, b.z), lerp_(wx, c.z, d.z)), lerp_(wy, lerp_(wx, a.w, b.w), lerp_(wx, c.w, d.w)));
+}
+
+// GL_LINEAR, 8-bit fixed-point filter path (RGBA8 / RGBX8 with edge / repeat / mirror wrap)
+template <int FMT, int WRAP>
+__device__ __forceinline__ float4 sample_linear_u8(const Tex& t, const uint8_t* img, float s, float v) {
+  if (WRAP == WRAP_REPEAT) {
+    s = s - __builtin_floorf(s);
+    v = v - __builtin_floorf(v);
+  }
+  float u = s * (float)t.w - 0.5f, w = v * (float)t.h - 0.5f;
+  if (WRAP == WRAP_EDGE) {
+    u = fminf(fmaxf(u, 0.0f), (float)(t.w - 1));
+    w = fminf(fmaxf(w, 0.0f), (float)(t.h - 1));
+  }
+  float x0f = __builtin_floorf(u), y0f = __builtin_floorf(w);
+  int wx = (int)__builtin_rintf((u - x0f) * 256.0f), wy = (int)__builtin_rintf((w - y0f) * 256.0f);
+  int x0 = wrap_index<WRAP>((int)x0f, t.w), x1 = wrap_index<WRAP>((int)x0f + 1, t.w);
+  int y0 = wrap_index<WRAP>((int)y0f, t.h), y1 = wrap_index<WRAP>((int)y0f + 1, t.h);
+  uint32_t p00 = *reinterpret_cast<const uint32_t*>(img + ((size_t)y0 * t.w + x0) * 4);
+  uint32_t p10 = *reinterpret_cast<const uint32_t*>(img + ((size_t)y0 * t.w + x1) * 4);
+  uint32_t p01 = *reinterpret_cast<const uint32_t*>(img + ((size_t)y1 * t.w + x0) * 4);
+  uint32_t p11 = *reinterpret_cast<const uint32_t*>(img + ((size_t)y1 * t.w + x1) * 4);
+  float o[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    int a = (p00 >> (8 * c)) & 255, b = (p10 >> (8 * c)) & 255, cc = (p01 >> (8 * c)) & 255, d = (p11 >> (8 * c)) & 255;
+    if (c == 3 && FMT == FMT_RGBX8) a = b = cc = d = 255;
+    int top = (a + ((wx * (b - a) + 128) >> 8)) & 255;
+    int bot = (cc + ((wx * (d - cc) + 128) >> 8)) & 255;
+    int r = (top + ((wy * (bot - top) + 128) >> 8)) & 255;
+    o[c] = (float)r * (1.0f / 255.0f);
+  }
+  return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+template <int FMT, int LINEAR, int WRAP>
+__device__ __forceinline__ float4 sample(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* lds) {
+  if (!LINEAR) return sample_nearest<FMT, WRAP>(t, img, s, v, lds);
+  if ((FMT == FMT_RGBA8 || FMT == FMT_RGBX8) && WRAP != WRAP_BORDER) return sample_linear_u8<FMT, WRAP>(t, img, s, v);
+  return sample_linear_f<FMT, WRAP>(t, img, s, v, lds);
+}
+
+__device__ __forceinline__ const uint8_t* frame_ptr(const Tex& t, int z) {
+  return static_cast<const uint8_t*>(t.base) + t.frame_stride * (uint64_t)z;
+}
+
+// --------------------------------------------------------------------------------- store ----
+__device__ __forceinline__ uint32_t unorm8(float x) {
+  if (!(x > 0.0f)) return 0u;
+  x = x > 1.0f ? 1.0f : x;
+  return (uint32_t)__builtin_rintf(x * 255.0f);
+}
+// count of thresholds <= x, thresholds ascending (255 entries + inf sentinel)
+__device__ __forceinline__ uint32_t srgb8(float x, const SrgbLds* t) {
+  if (!(x > 0.0f)) return 0u;
+  int lo = 0;
+#pragma unroll
+  for (int step = 128; step >= 1; step >>= 1) {
+    int probe = lo + step - 1;  // thresholds index
+    lo = (probe < 255 && t->thr[probe] <= x) ? lo + step : lo;
+  }
+  return (uint32_t)lo;
+}
+
+template <int OUT_FMT>
+__device__ __forceinline__ void store(const PassLaunch& L, int z, int x, int y, float4 c, const SrgbLds* t) {
+  uint8_t* o = static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z;
+  if (OUT_FMT == FMT_F32) {
+    *reinterpret_cast<float4*>(o + ((size_t)y * L.out_w + x) * 16) = c;
+  } else if (OUT_FMT == FMT_SRGB8) {
+    uint32_t p = srgb8(c.x, t) | (srgb8(c.y, t) << 8) | (srgb8(c.z, t) << 16) | (unorm8(c.w) << 24);
+    *reinterpret_cast<uint32_t*>(o + ((size_t)y * L.out_w + x) * 4) = p;
+  } else {
+    uint32_t p = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (unorm8(c.w) << 24);
+    *reinterpret_cast<uint32_t*>(o + ((size_t)y * L.out_w + x) * 4) = p;
+  }
+}
+
+}  // namespace rcd
+
+namespace rcd {
+// Run-time selected sampler (all selectors are wave-uniform kernel arguments, so the
+// branches are scalar).  Hot kernels instantiate sample<> directly instead.
+template <int FMT, int LINEAR>
+__device__ __forceinline__ float4 sample_rt_wrap(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* lds) {
+  switch (t.wrap) {
+    case WRAP_BORDER: return sample<FMT, LINEAR, WRAP_BORDER>(t, img, s, v, lds);
+    case WRAP_REPEAT: return sample<FMT, LINEAR, WRAP_REPEAT>(t, img, s, v, lds);
+    case WRAP_MIRROR: return sample<FMT, LINEAR, WRAP_MIRROR>(t, img, s, v, lds);
+    default: return sample<FMT, LINEAR, WRAP_EDGE>(t, img, s, v, lds);
+  }
+}
+template <int FMT>
+__device__ __forceinline__ float4 sample_rt_filter(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* lds) {
+  return t.linear ? sample_rt_wrap<FMT, 1>(t, img, s, v, lds) : sample_rt_wrap<FMT, 0>(t, img, s, v, lds);
+}
+__device__ __forceinline__ float4 sample_rt(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* lds) {
+  switch (t.fmt) {
+    case FMT_SRGB8: return sample_rt_filter<FMT_SRGB8>(t, img, s, v, lds);
+    case FMT_RGBX8: return sample_rt_filter<FMT_RGBX8>(t, img, s, v, lds);
+    case FMT_F32: return sample_rt_filter<FMT_F32>(t, img, s, v, lds);
+    default: return sample_rt_filter<FMT_RGBA8>(t, img, s, v, lds);
+  }
+}
+__device__ __forceinline__ void store_rt(const PassLaunch& L, int z, int x, int y, float4 c, const SrgbLds* t) {
+  if (L.out_fmt == FMT_F32) store<FMT_F32>(L, z, x, y, c, t);
+  else if (L.out_fmt == FMT_SRGB8) store<FMT_SRGB8>(L, z, x, y, c, t);
+  else store<FMT_RGBA8>(L, z, x, y, c, t);
+}
+}  // namespace rcd

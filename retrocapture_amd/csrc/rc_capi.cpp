@@ -1,0 +1,320 @@
+// extern "C" shim over rc::ShaderEngine - see include/rc_shaderchain.h for the contract.
+#include "../../include/rc_shaderchain.h"
+
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+
+#include "rc_log.h"
+#include "shader_engine.h"
+
+struct rc_engine {
+  rc::ShaderEngine impl;
+};
+
+namespace {
+
+size_t copy_out(const std::string& s, char* buf, size_t cap) {
+  if (buf && cap) {
+    size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+    std::memcpy(buf, s.data(), n);
+    buf[n] = 0;
+  }
+  return s.size();
+}
+
+std::string jstr(const std::string& s) {
+  std::string o = "\"";
+  for (char c : s) {
+    if (c == '"' || c == '\\') o += '\\';
+    if ((unsigned char)c < 0x20) {
+      char b[8];
+      std::snprintf(b, sizeof b, "\\u%04x", c);
+      o += b;
+      continue;
+    }
+    o += c;
+  }
+  return o + "\"";
+}
+std::string jnum(float v) {
+  char b[32];
+  std::snprintf(b, sizeof b, "%.9g", v);
+  return b;
+}
+
+template <typename F>
+int guarded(F&& f) {
+  try {
+    return f();
+  } catch (const std::exception& ex) {
+    RC_LOG_ERROR(std::string("exception: ") + ex.what());
+    return RC_ERR_INVALID;
+  } catch (...) {
+    RC_LOG_ERROR("unknown exception");
+    return RC_ERR_INVALID;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+rc_engine* rc_engine_create(int device, void* hip_stream) {
+  rc_engine* e = nullptr;
+  try {
+    e = new rc_engine();
+    if (!e->impl.init(device, static_cast<hipStream_t>(hip_stream))) {
+      delete e;
+      return nullptr;
+    }
+  } catch (...) {
+    delete e;
+    return nullptr;
+  }
+  return e;
+}
+
+void rc_engine_destroy(rc_engine* e) {
+  try {
+    delete e;
+  } catch (...) {
+  }
+}
+
+static int load_status(rc_engine* e, bool ok) {
+  if (!ok) return RC_ERR_LOAD;
+  for (size_t i = 0; i < e->impl.passCount(); ++i)
+    if (!e->impl.pass(i)->kernel) return RC_WARN_PASSES;
+  return RC_OK;
+}
+
+int rc_engine_load_preset(rc_engine* e, const char* path) {
+  if (!e || !path) return RC_ERR_INVALID;
+  return guarded([&] { return load_status(e, e->impl.loadPreset(path)); });
+}
+
+int rc_engine_load_shader(rc_engine* e, const char* path) {
+  if (!e || !path) return RC_ERR_INVALID;
+  return guarded([&] { return load_status(e, e->impl.loadShader(path)); });
+}
+
+size_t rc_engine_preset_path(rc_engine* e, char* buf, size_t cap) {
+  if (!e) return 0;
+  return copy_out(e->impl.getPresetPath(), buf, cap);
+}
+
+void rc_engine_disable(rc_engine* e) {
+  if (e) e->impl.disableShader();
+}
+int rc_engine_is_active(rc_engine* e) { return e && e->impl.isShaderActive() ? 1 : 0; }
+
+void rc_engine_set_viewport(rc_engine* e, uint32_t w, uint32_t h) {
+  if (e) e->impl.setViewport(w, h);
+}
+void rc_engine_set_max_resolution(rc_engine* e, uint32_t w, uint32_t h) {
+  if (e) e->impl.setMaxShaderResolution(w, h);
+}
+
+int rc_engine_apply_batch(rc_engine* e, const void* d_in, uint32_t n, uint32_t w, uint32_t h, uint64_t stride,
+                          const void** d_out, uint32_t* ow, uint32_t* oh) {
+  if (!e || !d_out) return RC_ERR_INVALID;
+  return guarded([&] {
+    const void* out = e->impl.applyShaderBatch(d_in, n, w, h, stride);
+    *d_out = out;
+    if (!out) return (int)RC_ERR_INVALID;
+    const bool passthrough = (out == d_in);
+    if (ow) *ow = passthrough ? w : e->impl.getOutputWidth();
+    if (oh) *oh = passthrough ? h : e->impl.getOutputHeight();
+    if (passthrough && e->impl.isShaderActive() && !rc::last_error().empty()) {
+      // active engine that fell back to the input: a device failure or no usable pass
+      bool any = false;
+      for (size_t i = 0; i < e->impl.passCount(); ++i) any |= e->impl.pass(i)->kernel != nullptr;
+      if (any) return (int)RC_ERR_DEVICE;
+    }
+    return (int)RC_OK;
+  });
+}
+
+int rc_engine_apply(rc_engine* e, const void* d_in, uint32_t w, uint32_t h, const void** d_out, uint32_t* ow,
+                    uint32_t* oh) {
+  return rc_engine_apply_batch(e, d_in, 1, w, h, 0, d_out, ow, oh);
+}
+
+uint32_t rc_engine_output_width(rc_engine* e) { return e ? e->impl.getOutputWidth() : 0; }
+uint32_t rc_engine_output_height(rc_engine* e) { return e ? e->impl.getOutputHeight() : 0; }
+
+int rc_engine_sync(rc_engine* e) {
+  if (!e) return RC_ERR_INVALID;
+  return hipStreamSynchronize(e->impl.stream()) == hipSuccess ? RC_OK : RC_ERR_DEVICE;
+}
+
+int rc_engine_param_count(rc_engine* e) {
+  if (!e) return 0;
+  return guarded([&] { return (int)e->impl.getShaderParameters().size(); });
+}
+
+int rc_engine_param_get(rc_engine* e, int index, rc_param* out) {
+  if (!e || !out || index < 0) return RC_ERR_INVALID;
+  return guarded([&] {
+    auto ps = e->impl.getShaderParameters();
+    if ((size_t)index >= ps.size()) return (int)RC_ERR_INVALID;
+    const auto& p = ps[(size_t)index];
+    std::memset(out, 0, sizeof(*out));
+    std::snprintf(out->name, sizeof(out->name), "%s", p.name.c_str());
+    std::snprintf(out->description, sizeof(out->description), "%s", p.description.c_str());
+    out->value = p.value;
+    out->default_value = p.defaultValue;
+    out->min = p.min;
+    out->max = p.max;
+    out->step = p.step;
+    return (int)RC_OK;
+  });
+}
+
+int rc_engine_param_set(rc_engine* e, const char* name, float value) {
+  if (!e || !name) return 0;
+  return guarded([&] { return e->impl.setShaderParameter(name, value) ? 1 : 0; });
+}
+
+void rc_engine_set_uniform1(rc_engine* e, const char* n, float x) {
+  if (e && n) e->impl.setUniform(n, x);
+}
+void rc_engine_set_uniform2(rc_engine* e, const char* n, float x, float y) {
+  if (e && n) e->impl.setUniform(n, x, y);
+}
+void rc_engine_set_uniform4(rc_engine* e, const char* n, float x, float y, float z, float w) {
+  if (e && n) e->impl.setUniform(n, x, y, z, w);
+}
+
+int rc_engine_save_preset(rc_engine* e, const char* path) {
+  if (!e || !path) return RC_ERR_INVALID;
+  return guarded([&] {
+    std::unordered_map<std::string, float> custom;
+    for (const auto& p : e->impl.getShaderParameters())
+      if (p.value != p.defaultValue) custom[p.name] = p.value;
+    return e->impl.getPreset().saveAs(path, custom) ? (int)RC_OK : (int)RC_ERR_LOAD;
+  });
+}
+
+int rc_engine_pass_count(rc_engine* e) { return e ? (int)e->impl.passCount() : 0; }
+
+int rc_engine_pass_info(rc_engine* e, int pass, rc_pass_info* out) {
+  if (!e || !out || pass < 0) return RC_ERR_INVALID;
+  const rc::ShaderPassData* pd = e->impl.pass((size_t)pass);
+  if (!pd) return RC_ERR_INVALID;
+  std::memset(out, 0, sizeof(*out));
+  out->width = pd->width;
+  out->height = pd->height;
+  out->format = pd->format;
+  out->has_kernel = pd->kernel ? 1 : 0;
+  out->filter_linear = pd->passInfo.filterLinear ? 1 : 0;
+  const std::string& w = pd->passInfo.wrapMode;
+  out->wrap = w == "repeat" ? 2 : w == "mirrored_repeat" ? 3 : w == "clamp_to_border" ? 1 : 0;
+  std::snprintf(out->kernel, sizeof(out->kernel), "%s", pd->kernel ? pd->kernel->name : "");
+  std::snprintf(out->alias, sizeof(out->alias), "%s", pd->passInfo.alias.c_str());
+  return RC_OK;
+}
+
+int rc_engine_read_pass(rc_engine* e, int pass, uint32_t frame, void* host, size_t bytes) {
+  if (!e || pass < 0) return RC_ERR_INVALID;
+  return guarded([&] { return e->impl.readPass((size_t)pass, frame, host, bytes) ? (int)RC_OK : (int)RC_ERR_INVALID; });
+}
+
+void rc_engine_set_profiling(rc_engine* e, int on) {
+  if (e) e->impl.setProfiling(on != 0);
+}
+
+int rc_engine_pass_profile(rc_engine* e, int pass, rc_pass_profile* out) {
+  if (!e || !out || pass < 0) return RC_ERR_INVALID;
+  return guarded([&] {
+    std::vector<rc::ShaderEngine::PassProfile> prof;
+    if (!e->impl.collectProfile(&prof)) return (int)RC_ERR_DEVICE;
+    if ((size_t)pass >= prof.size()) return (int)RC_ERR_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    out->total_ms = prof[(size_t)pass].totalMs;
+    out->launches = prof[(size_t)pass].launches;
+    out->frames = prof[(size_t)pass].frames;
+    e->impl.passBytes((size_t)pass, &out->read_bytes_per_frame, &out->write_bytes_per_frame);
+    return (int)RC_OK;
+  });
+}
+
+void rc_engine_set_chunk_frames(rc_engine* e, uint32_t n) {
+  if (e) e->impl.setChunkFrames(n);
+}
+void rc_engine_set_allow_missing_sources(rc_engine* e, int allow) {
+  if (e) e->impl.setAllowMissingSources(allow != 0);
+}
+
+const char* rc_last_error(void) { return rc::last_error().c_str(); }
+const char* rc_version(void) { return "retrocapture_amd shaderchain 0.1 (gfx950)"; }
+
+size_t rc_kernel_list(char* buf, size_t cap) {
+  std::string s;
+  for (const auto& k : rc::allKernels()) s += std::string(k.identity) + "\n";
+  return copy_out(s, buf, cap);
+}
+
+size_t rc_preset_dump_json(const char* path, char* buf, size_t cap) {
+  if (!path) return 0;
+  std::string out;
+  try {
+    rc::ShaderPreset p;
+    const bool ok = p.load(path);
+    std::ostringstream o;
+    o << "{\"preset\":" << jstr(path) << ",\"ok\":" << (ok ? "true" : "false") << ",\"passes\":[";
+    bool first = true;
+    for (const auto& s : p.getPasses()) {
+      o << (first ? "" : ",") << "{\"shader\":" << jstr(s.shaderPath) << ",\"filter_linear\":" << (s.filterLinear ? "true" : "false")
+        << ",\"wrap\":" << jstr(s.wrapMode) << ",\"mipmap\":" << (s.mipmapInput ? "true" : "false") << ",\"alias\":" << jstr(s.alias)
+        << ",\"float_fb\":" << (s.floatFramebuffer ? "true" : "false") << ",\"srgb_fb\":" << (s.srgbFramebuffer ? "true" : "false")
+        << ",\"fcm\":" << s.frameCountMod << ",\"stx\":" << jstr(s.scaleTypeX) << ",\"sx\":" << jnum(s.scaleX)
+        << ",\"sty\":" << jstr(s.scaleTypeY) << ",\"sy\":" << jnum(s.scaleY) << "}";
+      first = false;
+    }
+    o << "],\"textures\":{";
+    first = true;
+    for (const auto& t : p.getTextures()) {
+      o << (first ? "" : ",") << jstr(t.first) << ":{\"path\":" << jstr(t.second.path) << ",\"wrap\":" << jstr(t.second.wrapMode)
+        << ",\"mipmap\":" << (t.second.mipmap ? "true" : "false") << ",\"linear\":" << (t.second.linear ? "true" : "false") << "}";
+      first = false;
+    }
+    o << "},\"params\":{";
+    first = true;
+    for (const auto& q : p.getParameters()) {
+      o << (first ? "" : ",") << jstr(q.first) << ":" << jnum(q.second);
+      first = false;
+    }
+    o << "}}";
+    out = o.str();
+  } catch (const std::exception& ex) {
+    out = std::string("{\"preset\":") + jstr(path) + ",\"ok\":false,\"exception\":" + jstr(ex.what()) + "}";
+  }
+  return copy_out(out, buf, cap);
+}
+
+size_t rc_shader_params_json(const char* path, char* buf, size_t cap) {
+  if (!path) return 0;
+  std::string out;
+  try {
+    rc::ShaderSourceInfo info = rc::scanShaderSource(path);
+    std::ostringstream o;
+    o << "{\"readable\":" << (info.readable ? "true" : "false") << ",\"parameter_uniform\":" << (info.parameterUniform ? "true" : "false")
+      << ",\"params\":[";
+    bool first = true;
+    for (const auto& name : info.declarationOrder) {
+      const auto& p = info.parameterInfo.at(name);
+      o << (first ? "" : ",") << "{\"name\":" << jstr(name) << ",\"description\":" << jstr(p.description) << ",\"default\":" << jnum(p.defaultValue)
+        << ",\"min\":" << jnum(p.min) << ",\"max\":" << jnum(p.max) << ",\"step\":" << jnum(p.step) << "}";
+      first = false;
+    }
+    o << "]}";
+    out = o.str();
+  } catch (const std::exception& ex) {
+    out = std::string("{\"readable\":false,\"exception\":") + jstr(ex.what()) + "}";
+  }
+  return copy_out(out, buf, cap);
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+#include "rc_log.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+
+namespace rc {
+namespace {
+LogLevel threshold() {
+  static LogLevel lvl = [] {
+    const char* e = std::getenv("RETROCAPTURE_LOG_LEVEL");
+    std::string s = e ? e : "warn";
+    std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+    if (s == "debug") return LogLevel::Debug;
+    if (s == "info") return LogLevel::Info;
+    if (s == "error") return LogLevel::Error;
+    return LogLevel::Warn;
+  }();
+  return lvl;
+}
+thread_local std::string t_last_error;
+std::mutex g_io;
+}  // namespace
+
+void log(LogLevel level, const std::string& msg) {
+  if (level == LogLevel::Error) t_last_error = msg;
+  if (level < threshold()) return;
+  static const char* names[] = {"DEBUG", "INFO", "WARN", "ERROR"};
+  std::lock_guard<std::mutex> lock(g_io);
+  std::fprintf(stderr, "[rc %s] %s\n", names[(int)level], msg.c_str());
+}
+
+const std::string& last_error() { return t_last_error; }
+}  // namespace rc

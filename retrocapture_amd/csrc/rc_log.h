@@ -1,0 +1,17 @@
+// Minimal logger with the reference's convention: functions return bool / handles and
+// describe failures through the log (reference src/utils/Logger.h:18-21; level from the
+// RETROCAPTURE_LOG_LEVEL environment variable, Logger.cpp:41-44).  The last error text is
+// also kept per thread so the C ABI can hand it to a caller (rc_last_error()).
+#pragma once
+#include <string>
+
+namespace rc {
+enum class LogLevel { Debug = 0, Info = 1, Warn = 2, Error = 3 };
+void log(LogLevel level, const std::string& msg);
+const std::string& last_error();
+}  // namespace rc
+
+#define RC_LOG_DEBUG(m) ::rc::log(::rc::LogLevel::Debug, (m))
+#define RC_LOG_INFO(m) ::rc::log(::rc::LogLevel::Info, (m))
+#define RC_LOG_WARN(m) ::rc::log(::rc::LogLevel::Warn, (m))
+#define RC_LOG_ERROR(m) ::rc::log(::rc::LogLevel::Error, (m))

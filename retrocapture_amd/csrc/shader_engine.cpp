@@ -1,0 +1,696 @@
+// ShaderEngine on HIP.  Section references are to the reference implementation
+// (src/shader/ShaderEngine.cpp) whose observable behaviour each block keeps.
+#include "shader_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <filesystem>
+
+#include "png_lut.h"
+#include "rc_log.h"
+
+namespace fs = std::filesystem;
+
+namespace rc {
+namespace {
+
+int wrapFromString(const std::string& w) {  // ShaderEngine.cpp:3208-3228
+  if (w == "repeat") return rcd::WRAP_REPEAT;
+  if (w == "mirrored_repeat") return rcd::WRAP_MIRROR;
+  if (w == "clamp_to_border") return rcd::WRAP_BORDER;
+  return rcd::WRAP_EDGE;
+}
+
+size_t texelBytes(int fmt) { return fmt == rcd::FMT_F32 ? 16 : 4; }
+
+bool hipOk(hipError_t e, const char* what) {
+  if (e == hipSuccess) return true;
+  RC_LOG_ERROR(std::string(what) + ": " + hipGetErrorString(e));
+  return false;
+}
+
+std::string lowerExt(const std::string& path) {
+  std::string e = fs::path(path).extension().string();
+  std::transform(e.begin(), e.end(), e.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+  return e;
+}
+
+// Uniforms the reference overwrites with fixed values after the #pragma parameters
+// (ShaderEngine.cpp:2260-2374 and :2382-2392).
+const std::pair<const char*, float> kHardCoded[] = {
+    {"BLURSCALEX", 0.30f}, {"LOWLUMSCAN", 6.0f}, {"HILUMSCAN", 8.0f}, {"BRIGHTBOOST", 1.25f},
+    {"MASK_DARK", 0.25f}, {"MASK_FADE", 0.8f}, {"RESSWITCH_ENABLE", 1.0f},
+    {"RESSWITCH_GLITCH_TRESHOLD", 0.1f}, {"RESSWITCH_GLITCH_BAR_STR", 0.6f},
+    {"RESSWITCH_GLITCH_BAR_SIZE", 0.5f}, {"RESSWITCH_GLITCH_BAR_SMOOTH", 1.0f},
+    {"RESSWITCH_GLITCH_SHAKE_MAX", 0.25f}, {"RESSWITCH_GLITCH_ROT_MAX", 0.2f},
+    {"RESSWITCH_GLITCH_WOB_MAX", 0.1f}, {"AS", 0.20f}, {"asat", 0.33f}, {"PR", 0.32f},
+    {"PG", 0.32f}, {"PB", 0.32f}, {"internal_res", 1.0f}, {"auto_res", 0.0f}};
+
+}  // namespace
+
+ShaderEngine::ShaderEngine() {}
+ShaderEngine::~ShaderEngine() { shutdown(); }
+
+bool ShaderEngine::init(int device, hipStream_t stream) {  // :22-60
+  if (m_initialized) return true;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+    RC_LOG_ERROR("ShaderEngine: no HIP device available (this engine has no CPU fallback)");
+    return false;
+  }
+  if (device >= 0) {
+    if (!hipOk(hipSetDevice(device), "hipSetDevice")) return false;
+    m_device = device;
+  } else if (!hipOk(hipGetDevice(&m_device), "hipGetDevice")) {
+    return false;
+  }
+  hipDeviceProp_t prop;
+  if (hipOk(hipGetDeviceProperties(&prop, m_device), "hipGetDeviceProperties")) {
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+      RC_LOG_WARN(std::string("ShaderEngine: kernels are built for gfx950, device is ") + prop.gcnArchName);
+  }
+  m_stream = stream;
+  m_initialized = true;
+  return true;
+}
+
+void ShaderEngine::shutdown() {  // :62-86
+  if (!m_initialized) return;
+  disableShader();
+  cleanupPresetPasses();
+  cleanupTextureReferences();
+  if (m_batchOutput.ptr) (void)hipFree(m_batchOutput.ptr);
+  m_batchOutput = DeviceBuffer();
+  m_initialized = false;
+}
+
+void ShaderEngine::cleanupPresetPasses() {
+  for (auto& p : m_passes)
+    if (p.target.ptr) (void)hipFree(p.target.ptr);
+  m_passes.clear();
+}
+
+void ShaderEngine::cleanupTextureReferences() {
+  for (auto& t : m_textureReferences)
+    if (t.second.data.ptr) (void)hipFree(t.second.data.ptr);
+  m_textureReferences.clear();
+}
+
+std::string ShaderEngine::getPresetPath() const {
+  std::lock_guard<std::mutex> lock(m_paramMutex);
+  return m_presetPath;
+}
+
+void ShaderEngine::disableShader() {
+  m_shaderActive = false;
+}
+
+// A single .glsl file runs as a one-pass preset (the reference has a separate "simple mode",
+// :149-226, whose draw is the same full-target quad; its output size is the input size).
+bool ShaderEngine::loadShader(const std::string& shaderPath) {
+  if (!m_initialized) {
+    RC_LOG_ERROR("ShaderEngine not initialized");
+    return false;
+  }
+  disableShader();
+  cleanupPresetPasses();
+  cleanupTextureReferences();
+  m_preset.clear();
+  {
+    std::lock_guard<std::mutex> lock(m_paramMutex);
+    m_customParameters.clear();
+    m_presetPath.clear();
+  }
+  if (lowerExt(shaderPath) == ".slang") {
+    RC_LOG_ERROR("Slang shaders (.slang) are not supported; use GLSL shaders (.glsl)");
+    return false;
+  }
+  m_passes.resize(1);
+  m_passes[0].passInfo.shaderPath = shaderPath;
+  m_passes[0].passInfo.scaleTypeX = m_passes[0].passInfo.scaleTypeY = "source";
+  if (!compilePass(0)) {
+    cleanupPresetPasses();
+    return false;
+  }
+  m_singleShader = true;
+  m_shaderActive = true;
+  return true;
+}
+
+bool ShaderEngine::loadPreset(const std::string& presetPath) {  // :228-319
+  if (!m_initialized) {
+    RC_LOG_ERROR("ShaderEngine not initialized");
+    return false;
+  }
+  disableShader();
+  cleanupPresetPasses();
+  cleanupTextureReferences();
+  m_singleShader = false;
+
+  const std::string ext = lowerExt(presetPath);
+  if (ext == ".slangp") {
+    RC_LOG_ERROR("Slang presets (.slangp) are not supported. Use GLSLP presets (.glslp)");
+    return false;
+  }
+  if (ext != ".glslp" && !ext.empty()) RC_LOG_WARN("Unrecognized preset extension: " + ext + ". Expected .glslp");
+  {
+    std::lock_guard<std::mutex> lock(m_paramMutex);
+    m_customParameters.clear();
+  }
+  if (!m_preset.load(presetPath)) return false;
+  {
+    std::lock_guard<std::mutex> lock(m_paramMutex);
+    m_presetPath = presetPath;
+  }
+  for (const auto& tex : m_preset.getTextures())
+    if (!loadTextureReference(tex.first, tex.second.path)) RC_LOG_ERROR("Failed to load reference texture: " + tex.first);
+
+  const bool passesLoaded = loadPresetPasses();
+  size_t totalParams = 0;
+  for (const auto& p : m_passes) totalParams += p.parameterInfo.size();
+  if (passesLoaded) {
+    RC_LOG_INFO("Preset loaded with " + std::to_string(m_passes.size()) + " pass(es) and " +
+                std::to_string(totalParams) + " parameter(s)");
+  } else if (totalParams > 0) {
+    RC_LOG_WARN("Preset loaded but some passes have no kernel; " + std::to_string(totalParams) +
+                " parameter(s) extracted");
+  } else {
+    RC_LOG_WARN("Preset loaded but no pass is usable");
+  }
+  // As in the reference, a preset that parsed is "active" even if passes failed (:316-318).
+  m_shaderActive = true;
+  return true;
+}
+
+bool ShaderEngine::loadPresetPasses() {  // :750-848
+  const auto& passes = m_preset.getPasses();
+  cleanupPresetPasses();
+  m_passes.resize(passes.size());
+  bool all = true;
+  for (size_t i = 0; i < passes.size(); ++i) {
+    m_passes[i].passInfo = passes[i];
+    if (!compilePass(i)) all = false;
+  }
+  return all;
+}
+
+// "Compiling" a pass = reading its #pragma parameters from the shader file and finding the
+// hand-written kernel registered for that shader (:321-748).
+bool ShaderEngine::compilePass(size_t i) {
+  ShaderPassData& pd = m_passes[i];
+  const ShaderPass& pi = pd.passInfo;
+  pd.kernel = nullptr;
+  pd.format = pi.floatFramebuffer ? rcd::FMT_F32 : (pi.srgbFramebuffer ? rcd::FMT_SRGB8 : rcd::FMT_RGBA8);  // :2882-2890
+
+  if (lowerExt(pi.shaderPath) == ".slang") {
+    RC_LOG_ERROR("Slang shaders (.slang) are not supported in pass " + std::to_string(i));
+    return false;
+  }
+  const KernelEntry* entry = findKernel(pi.shaderPath);
+  ShaderSourceInfo src = scanShaderSource(pi.shaderPath);
+  if (!src.readable) {
+    if (!m_allowMissingSources || !entry) {
+      RC_LOG_ERROR("Failed to open shader for pass " + std::to_string(i) + ": " + pi.shaderPath);
+      return false;
+    }
+    // No shader text on this machine: take the parameter table the registry carries.
+    RC_LOG_WARN("Shader file not readable, using the built-in parameter table: " + pi.shaderPath);
+    for (const KernelParam& kp : entry->params) {
+      ShaderParameterInfo info;
+      info.defaultValue = kp.def;
+      info.min = kp.min;
+      info.max = kp.max;
+      info.step = kp.step;
+      info.description = kp.description;
+      src.parameterInfo[kp.name] = info;
+    }
+  }
+  pd.parameterInfo = src.parameterInfo;
+  pd.extractedParameters.clear();
+  for (const auto& kv : src.parameterInfo) pd.extractedParameters[kv.first] = kv.second.defaultValue;
+
+  if (!entry) {
+    RC_LOG_ERROR("No HIP kernel is registered for shader of pass " + std::to_string(i) + " (" +
+                 shaderIdentity(pi.shaderPath) + "); the pass will be skipped");
+    return false;
+  }
+  if (pi.mipmapInput) {
+    RC_LOG_ERROR("mipmap_input is not supported by the HIP shader chain (pass " + std::to_string(i) + ")");
+    return false;
+  }
+  pd.kernel = entry;
+  return true;
+}
+
+bool ShaderEngine::loadTextureReference(const std::string& name, const std::string& path) {  // :2535-2706
+  if (m_textureReferences.count(name)) return true;
+  std::vector<uint8_t> rgba;
+  int w = 0, h = 0;
+  std::string err;
+  if (!loadPngRgba8(path, &rgba, &w, &h, &err)) {
+    RC_LOG_ERROR("Texture " + name + ": " + err);
+    return false;
+  }
+  LutTexture t;
+  t.width = w;
+  t.height = h;
+  if (!ensureBuffer(t.data, rgba.size())) return false;
+  if (!hipOk(hipMemcpy(t.data.ptr, rgba.data(), rgba.size(), hipMemcpyHostToDevice), "LUT upload")) return false;
+  m_textureReferences[name] = t;
+  return true;
+}
+
+void ShaderEngine::setMaxShaderResolution(uint32_t maxWidth, uint32_t maxHeight) {
+  m_maxShaderWidth = maxWidth;
+  m_maxShaderHeight = maxHeight;
+}
+
+void ShaderEngine::setViewport(uint32_t width, uint32_t height) {  // :3154-3206
+  if (m_maxShaderWidth > 0 && m_maxShaderHeight > 0 && (width > m_maxShaderWidth || height > m_maxShaderHeight)) {
+    const float aspect = (float)width / (float)height;
+    uint32_t w = width, h = height;
+    if (width > m_maxShaderWidth) {
+      w = m_maxShaderWidth;
+      h = (uint32_t)std::round(m_maxShaderWidth / aspect);
+    }
+    if (h > m_maxShaderHeight) {
+      h = m_maxShaderHeight;
+      w = (uint32_t)std::round(m_maxShaderHeight * aspect);
+    }
+    m_viewportWidth = (w / 2) * 2;
+    m_viewportHeight = (h / 2) * 2;
+    return;
+  }
+  m_viewportWidth = width;
+  m_viewportHeight = height;
+}
+
+// In the reference these only feed the single-shader mode's uniform map (:3006-3041); the
+// kernels take their inputs from the preset, so the values are recorded and otherwise unused.
+void ShaderEngine::setUniform(const std::string& name, float value) { m_uniforms[name] = {value, 0, 0, 0}; }
+void ShaderEngine::setUniform(const std::string& name, float x, float y) { m_uniforms[name] = {x, y, 0, 0}; }
+void ShaderEngine::setUniform(const std::string& name, float x, float y, float z, float w) { m_uniforms[name] = {x, y, z, w}; }
+
+std::vector<ShaderEngine::ShaderParameter> ShaderEngine::getShaderParameters() const {  // :3264-3351
+  std::vector<ShaderParameter> out;
+  if (!m_shaderActive || m_passes.empty()) return out;
+  std::lock_guard<std::mutex> lock(m_paramMutex);
+  std::map<std::string, ShaderParameter> byName;
+  for (const auto& pd : m_passes)
+    for (const auto& kv : pd.parameterInfo) {
+      if (byName.count(kv.first)) continue;  // first pass that declares it wins
+      ShaderParameter p;
+      p.name = kv.first;
+      p.defaultValue = kv.second.defaultValue;
+      p.min = kv.second.min;
+      p.max = kv.second.max;
+      p.step = kv.second.step;
+      p.description = kv.second.description;
+      auto c = m_customParameters.find(kv.first);
+      if (c != m_customParameters.end()) {
+        p.value = c->second;
+      } else {
+        auto g = m_preset.getParameters().find(kv.first);
+        p.value = g != m_preset.getParameters().end() ? g->second : kv.second.defaultValue;
+      }
+      byName[kv.first] = p;
+    }
+  for (const auto& kv : byName) out.push_back(kv.second);
+  return out;
+}
+
+bool ShaderEngine::setShaderParameter(const std::string& name, float value) {  // :3353-3387
+  if (!m_shaderActive) return false;
+  for (const auto& pd : m_passes) {
+    auto it = pd.parameterInfo.find(name);
+    if (it == pd.parameterInfo.end()) continue;
+    const float clamped = std::max(it->second.min, std::min(it->second.max, value));
+    std::lock_guard<std::mutex> lock(m_paramMutex);
+    m_customParameters[name] = clamped;
+    return true;
+  }
+  return false;
+}
+
+// Value a pass's kernel sees for one of its parameters.  Order of the reference's uniform
+// writes (later write wins): #pragma value as custom > preset > default (:2227-2249), then
+// the hard-coded names (:2260-2374, :2382-2392), then every global preset parameter by name
+// (:2512-2520) - so a preset-file value beats a custom one at draw time.
+float ShaderEngine::effectiveParameter(const ShaderPassData& pass, const KernelParam& kp,
+                                       const std::map<std::string, float>& custom) const {
+  float v = kp.def;
+  auto declared = pass.extractedParameters.find(kp.name);
+  const bool isDeclared = declared != pass.extractedParameters.end();
+  if (isDeclared) {
+    v = declared->second;
+    auto c = custom.find(kp.name);
+    if (c != custom.end()) {
+      v = c->second;
+    } else {
+      auto g = m_preset.getParameters().find(kp.name);
+      if (g != m_preset.getParameters().end()) v = g->second;
+    }
+  }
+  for (const auto& hc : kHardCoded)
+    if (hc.first == std::string(kp.name)) v = hc.second;
+  auto g = m_preset.getParameters().find(kp.name);
+  if (g != m_preset.getParameters().end()) v = g->second;
+  return v;
+}
+
+uint32_t ShaderEngine::calculateScale(uint32_t sourceSize, const std::string& scaleType, float scale,
+                                      uint32_t viewportSize) const {  // :1881-1910
+  if (scaleType.empty() || scaleType == "source") {
+    if (scale == 0.0f) scale = 1.0f;
+    return (uint32_t)std::round(sourceSize * scale);
+  }
+  if (scaleType == "viewport") {
+    if (scale == 0.0f) scale = 1.0f;
+    return (uint32_t)std::round(viewportSize * scale);
+  }
+  if (scaleType == "absolute") return (uint32_t)std::round(scale);
+  return sourceSize;
+}
+
+// Output size of every pass for this input size / viewport (:856-910).
+void ShaderEngine::resolvePassSizes(uint32_t width, uint32_t height) {
+  uint32_t cw = width, ch = height;
+  for (size_t i = 0; i < m_passes.size(); ++i) {
+    ShaderPassData& pd = m_passes[i];
+    const ShaderPass& pi = pd.passInfo;
+    std::string tx = pi.scaleTypeX, ty = pi.scaleTypeY;
+    float sx = pi.scaleX, sy = pi.scaleY;
+    const bool last = (i == m_passes.size() - 1);
+    if (!m_singleShader) {
+      // last pass: "source x1.0" (or unspecified) means the viewport, per axis (:871-889)
+      if (last && tx != "viewport" && (tx.empty() || (tx == "source" && sx == 1.0f))) {
+        tx = "viewport";
+        sx = 1.0f;
+      }
+      if (last && ty != "viewport" && (ty.empty() || (ty == "source" && sy == 1.0f))) {
+        ty = "viewport";
+        sy = 1.0f;
+      }
+    }
+    uint32_t ow = calculateScale(cw, tx, sx, m_viewportWidth);
+    uint32_t oh = calculateScale(ch, ty, sy, m_viewportHeight);
+    if (m_maxShaderWidth > 0 && ow > m_maxShaderWidth) {  // :897-903
+      const float aspect = (float)ow / (float)oh;
+      ow = m_maxShaderWidth;
+      oh = ((uint32_t)std::round(m_maxShaderWidth / aspect) / 2) * 2;
+    }
+    if (m_maxShaderHeight > 0 && oh > m_maxShaderHeight) {  // :904-910
+      const float aspect = (float)ow / (float)oh;
+      oh = m_maxShaderHeight;
+      ow = ((uint32_t)std::round(m_maxShaderHeight * aspect) / 2) * 2;
+    }
+    pd.width = ow;
+    pd.height = oh;
+    pd.frameBytes = (size_t)ow * oh * texelBytes(pd.format);
+    cw = ow;
+    ch = oh;
+  }
+}
+
+bool ShaderEngine::ensureBuffer(DeviceBuffer& b, size_t bytes) {
+  if (b.ptr && b.bytes >= bytes) return true;
+  if (b.ptr) (void)hipFree(b.ptr);
+  b = DeviceBuffer();
+  if (bytes == 0) return true;
+  if (!hipOk(hipMalloc(&b.ptr, bytes), "hipMalloc")) return false;
+  b.bytes = bytes;
+  return true;
+}
+
+// Texture view of pass p's target with the sampler state that persists on it: a pass's
+// output is first consumed as the next pass's input, which sets filter/wrap on the texture
+// object (:1008-1036); later PassPrev / alias reads see that state.  The last pass's target
+// keeps its creation state, LINEAR + CLAMP_TO_EDGE (:2903-2906).
+rcd::Tex ShaderEngine::passTexture(size_t p) const {
+  const ShaderPassData& pd = m_passes[p];
+  rcd::Tex t;
+  t.base = pd.target.ptr;
+  t.frame_stride = pd.frameBytes;
+  t.w = (int)pd.width;
+  t.h = (int)pd.height;
+  t.fmt = pd.format;
+  if (p + 1 < m_passes.size()) {
+    t.linear = m_passes[p + 1].passInfo.filterLinear ? 1 : 0;
+    t.wrap = wrapFromString(m_passes[p + 1].passInfo.wrapMode);
+  } else {
+    t.linear = 1;
+    t.wrap = rcd::WRAP_EDGE;
+  }
+  return t;
+}
+
+// Which texture a sampler uniform of pass i is bound to (:1091-1415).
+rcd::Tex ShaderEngine::samplerFor(const std::string& name, size_t i, const rcd::Tex& inputTex,
+                                  const rcd::Tex& sourceTex) const {
+  // PassPrev<N>Texture / Prev[N]Texture -> output of pass i-N (:1163-1189); N > i -> the
+  // original input (:1234-1245)
+  if (name.rfind("PassPrev", 0) == 0 && name.size() > 15 && name.compare(name.size() - 7, 7, "Texture") == 0) {
+    const int n = std::atoi(name.substr(8, name.size() - 15).c_str());
+    if (n >= 1 && (size_t)n <= i) return passTexture(i - (size_t)n);
+    if (n > (int)i) return sourceTex;
+  }
+  if (name == "OrigTexture") return sourceTex;  // :1351-1358
+  for (size_t p = 0; p < i; ++p)                // aliases (:1251-1266)
+    if (!m_passes[p].passInfo.alias.empty() && m_passes[p].passInfo.alias == name) return passTexture(p);
+  auto lut = m_textureReferences.find(name);    // LUTs (:1361-1415)
+  if (lut != m_textureReferences.end()) {
+    rcd::Tex t;
+    t.base = lut->second.data.ptr;
+    t.frame_stride = 0;
+    t.w = lut->second.width;
+    t.h = lut->second.height;
+    t.fmt = rcd::FMT_RGBA8;
+    t.linear = 1;
+    t.wrap = rcd::WRAP_EDGE;
+    auto st = m_preset.getTextures().find(name);
+    if (st != m_preset.getTextures().end()) {
+      t.linear = st->second.linear ? 1 : 0;
+      t.wrap = wrapFromString(st->second.wrapMode);
+    }
+    return t;
+  }
+  // A sampler uniform that nothing binds keeps its default value 0 = the unit holding the
+  // pass input.
+  return inputTex;
+}
+
+const void* ShaderEngine::applyShader(const void* input, uint32_t width, uint32_t height) {
+  return applyShaderBatch(input, 1, width, height, 0);
+}
+
+const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames, uint32_t width, uint32_t height,
+                                           uint64_t frameStride) {  // :1531-1879
+  if (!m_shaderActive) return inputs;
+  if (m_passes.empty()) return inputs;
+  bool hasValidPass = false;
+  for (const auto& p : m_passes) hasValidPass |= (p.kernel != nullptr);
+  if (!hasValidPass) {
+    RC_LOG_ERROR("No valid pass found in preset. Returning original frame.");
+    return inputs;
+  }
+  if (!inputs) {
+    RC_LOG_ERROR("applyShader: invalid input frame (null)");
+    return nullptr;
+  }
+  if (nFrames == 0) return inputs;
+  if (frameStride == 0) frameStride = (uint64_t)width * height * 4;
+
+  // optional processing-resolution clamp (:1623-1660)
+  uint32_t pw = width, ph = height;
+  if (m_maxShaderWidth > 0 && m_maxShaderHeight > 0 && (width > m_maxShaderWidth || height > m_maxShaderHeight)) {
+    const float aspect = (float)width / (float)height;
+    if (width > m_maxShaderWidth) {
+      pw = m_maxShaderWidth;
+      ph = (uint32_t)std::round(m_maxShaderWidth / aspect);
+    }
+    if (ph > m_maxShaderHeight) {
+      ph = m_maxShaderHeight;
+      pw = (uint32_t)std::round(m_maxShaderHeight * aspect);
+    }
+    pw = (pw / 2) * 2;
+    ph = (ph / 2) * 2;
+  }
+  m_sourceWidth = pw;
+  m_sourceHeight = ph;
+  if (m_singleShader || m_viewportWidth == 0 || m_viewportHeight == 0) {
+    // single-shader mode renders at the input size; a preset needs setViewport() first
+    if (m_viewportWidth == 0 || m_viewportHeight == 0) {
+      m_viewportWidth = pw;
+      m_viewportHeight = ph;
+    }
+  }
+  resolvePassSizes(pw, ph);
+
+  // buffers: every pass holds `chunk` frames, except the last which holds the whole batch
+  const uint32_t chunk = std::min(m_chunk, nFrames);
+  for (size_t i = 0; i + 1 < m_passes.size(); ++i)
+    if (!ensureBuffer(m_passes[i].target, m_passes[i].frameBytes * chunk)) return inputs;
+  ShaderPassData& lastPass = m_passes.back();
+  if (!ensureBuffer(lastPass.target, lastPass.frameBytes * nFrames)) return inputs;
+
+  for (uint32_t f0 = 0; f0 < nFrames; f0 += chunk) {
+    const uint32_t n = std::min(chunk, nFrames - f0);
+    // FrameCount is a float that is incremented once per frame (:1688) and handed to int
+    // uniforms by truncation (:2138)
+    const int firstCount = (int)(m_frameCount + 1.0f);
+    const uint8_t* in = static_cast<const uint8_t*>(inputs) + frameStride * f0;
+    uint8_t* out = static_cast<uint8_t*>(lastPass.target.ptr) + lastPass.frameBytes * f0;
+    if (!runChunk(in, frameStride, width, height, n, firstCount, out)) return inputs;
+    for (uint32_t k = 0; k < n; ++k) {
+      m_frameCount += 1.0f;
+      m_time += 0.016f;
+    }
+    m_lastChunkFrames = n;
+    m_lastChunkFirst = f0;
+  }
+  m_outputWidth = lastPass.width;
+  m_outputHeight = lastPass.height;
+  return lastPass.target.ptr;
+}
+
+bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t width, uint32_t height,
+                            uint32_t nFrames, int firstFrameCount, void* finalOut) {
+  rcd::Tex sourceTex;
+  sourceTex.base = inputs;
+  sourceTex.frame_stride = inStride;
+  sourceTex.w = (int)width;
+  sourceTex.h = (int)height;
+  sourceTex.fmt = rcd::FMT_RGBX8;  // GL_RGB texture: alpha reads 1.0
+  // pass 0 sets the source texture's sampler state when it binds it (:1008-1036)
+  sourceTex.linear = m_passes[0].passInfo.filterLinear ? 1 : 0;
+  sourceTex.wrap = wrapFromString(m_passes[0].passInfo.wrapMode);
+
+  rcd::Tex current = sourceTex;
+  std::map<std::string, float> custom;
+  {
+    std::lock_guard<std::mutex> lock(m_paramMutex);
+    custom = m_customParameters;
+  }
+  for (size_t i = 0; i < m_passes.size(); ++i) {
+    ShaderPassData& pd = m_passes[i];
+    const bool last = (i + 1 == m_passes.size());
+    void* target = last ? finalOut : pd.target.ptr;
+    if (!pd.kernel) {
+      // A pass without a program is skipped after its target was cleared to (0,0,0,0); the
+      // cleared target is the next pass's input (:959-975).
+      if (!hipOk(hipMemsetAsync(target, 0, pd.frameBytes * nFrames, m_stream), "clear")) return false;
+    } else {
+      rcd::PassLaunch L;
+      std::memset(&L, 0, sizeof(L));
+      L.in = current;
+      L.out = target;
+      L.out_frame_stride = pd.frameBytes;
+      L.out_w = (int)pd.width;
+      L.out_h = (int)pd.height;
+      L.out_fmt = pd.format;
+      L.src_w = (int)m_sourceWidth;
+      L.src_h = (int)m_sourceHeight;
+      L.vp_w = (int)m_viewportWidth;
+      L.vp_h = (int)m_viewportHeight;
+      L.frame_count0 = firstFrameCount;
+      L.n_frames = (int)nFrames;
+      const KernelEntry& k = *pd.kernel;
+      for (size_t s = 0; s < k.samplers.size() && s < (size_t)rcd::kMaxExtra; ++s)
+        L.extra[s] = samplerFor(k.samplers[s], i, current, sourceTex);
+      for (size_t q = 0; q < k.params.size() && q < (size_t)rcd::kMaxParams; ++q) {
+        L.params[q] = effectiveParameter(pd, k.params[q], custom);
+      }
+      PassGeometry geo;
+      geo.pass_index = (int)i;
+      geo.in_w = current.w;
+      geo.in_h = current.h;
+      geo.out_w = L.out_w;
+      geo.out_h = L.out_h;
+      geo.out_fmt = L.out_fmt;
+      geo.src_w = L.src_w;
+      geo.src_h = L.src_h;
+      geo.vp_w = L.vp_w;
+      geo.vp_h = L.vp_h;
+      if (k.setup) k.setup(geo, L);
+      // algorithmic read bytes per frame: distinct sampled textures, once each
+      {
+        const void* seen[1 + rcd::kMaxExtra];
+        int ns = 0;
+        uint64_t rb = 0;
+        auto add = [&](const rcd::Tex& t) {
+          for (int q = 0; q < ns; ++q)
+            if (seen[q] == t.base) return;
+          seen[ns++] = t.base;
+          rb += (uint64_t)t.w * t.h * texelBytes(t.fmt);
+        };
+        add(L.in);
+        for (size_t s2 = 0; s2 < k.samplers.size() && s2 < (size_t)rcd::kMaxExtra; ++s2) add(L.extra[s2]);
+        if (m_passReadBytes.size() != m_passes.size()) m_passReadBytes.assign(m_passes.size(), 0);
+        m_passReadBytes[i] = rb;
+      }
+      TimedLaunch tl{i, nFrames, nullptr, nullptr};
+      if (m_profiling) {
+        if (!hipOk(hipEventCreate(&tl.start), "hipEventCreate") || !hipOk(hipEventCreate(&tl.stop), "hipEventCreate")) return false;
+        (void)hipEventRecord(tl.start, m_stream);
+      }
+      if (!hipOk(k.launch(L, m_stream), k.name)) return false;
+      if (m_profiling) {
+        (void)hipEventRecord(tl.stop, m_stream);
+        m_timed.push_back(tl);
+      }
+    }
+    // this pass's output becomes the next pass's input
+    rcd::Tex next = passTexture(i);
+    next.base = target;
+    current = next;
+  }
+  return true;
+}
+
+void ShaderEngine::setProfiling(bool on) {
+  m_profiling = on;
+  if (on) m_profile.assign(m_passes.size(), PassProfile());
+}
+
+bool ShaderEngine::collectProfile(std::vector<PassProfile>* out) {
+  if (!hipOk(hipStreamSynchronize(m_stream), "sync")) return false;
+  if (m_profile.size() != m_passes.size()) m_profile.assign(m_passes.size(), PassProfile());
+  for (auto& t : m_timed) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess && t.pass < m_profile.size()) {
+      m_profile[t.pass].totalMs += ms;
+      m_profile[t.pass].launches += 1;
+      m_profile[t.pass].frames += t.frames;
+    }
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  m_timed.clear();
+  if (out) *out = m_profile;
+  return true;
+}
+
+void ShaderEngine::passBytes(size_t i, uint64_t* readBytes, uint64_t* writeBytes) const {
+  if (readBytes) *readBytes = i < m_passReadBytes.size() ? m_passReadBytes[i] : 0;
+  if (writeBytes) *writeBytes = i < m_passes.size() && m_passes[i].kernel ? m_passes[i].frameBytes : 0;
+}
+
+bool ShaderEngine::readPass(size_t i, uint32_t frame, void* host, size_t bytes) {
+  if (i >= m_passes.size() || !host) return false;
+  const ShaderPassData& pd = m_passes[i];
+  if (!pd.target.ptr || bytes < pd.frameBytes) return false;
+  const bool last = (i + 1 == m_passes.size());
+  // intermediates hold the last chunk only; the last pass holds the whole batch
+  uint64_t index = frame;
+  if (!last) {
+    if (frame < m_lastChunkFirst || frame >= m_lastChunkFirst + m_lastChunkFrames) return false;
+    index = frame - m_lastChunkFirst;
+  }
+  if (!hipOk(hipStreamSynchronize(m_stream), "sync")) return false;
+  return hipOk(hipMemcpy(host, static_cast<const uint8_t*>(pd.target.ptr) + pd.frameBytes * index, pd.frameBytes,
+                         hipMemcpyDeviceToHost),
+               "readPass");
+}
+
+}  // namespace rc

@@ -1,0 +1,173 @@
+// ShaderEngine: the reference's shader-chain API (reference src/shader/ShaderEngine.h:42-98)
+// executed by HIP pass kernels on an MI355X instead of OpenGL FBO ping-pong.
+//
+// Same method names, argument meaning and error behaviour as the reference class; the
+// only change of type is that a frame is a device pointer to RGBA8 texels (row 0 first =
+// texture t 0, alpha ignored and read as 1.0, like the reference's GL_RGB source texture,
+// FrameProcessor.cpp:172-205) instead of a GLuint texture name.  Output frames stay owned by
+// the engine and are valid until the next apply, as in the reference (ShaderEngine.cpp:1873).
+//
+// Additions for throughput: applyShaderBatch() runs N independent frames per call (frame k
+// sees FrameCount = count+1+k, exactly what N successive applyShader calls would see);
+// frames are the grid's z dimension, processed `chunk` at a time through the whole chain so
+// intermediates stay cache resident.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernel_registry.h"
+#include "pragma_params.h"
+#include "shader_preset.h"
+
+namespace rc {
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+};
+
+struct ShaderPassData {  // reference ShaderEngine.h:19-40
+  ShaderPass passInfo;
+  const KernelEntry* kernel = nullptr;  // "program": null = pass failed to "compile"
+  uint32_t width = 0, height = 0;
+  int format = rcd::FMT_RGBA8;
+  DeviceBuffer target;      // [chunk or batch][height][width] texels
+  size_t frameBytes = 0;
+  std::map<std::string, float> extractedParameters;
+  std::map<std::string, ShaderParameterInfo> parameterInfo;
+};
+
+struct LutTexture {
+  DeviceBuffer data;
+  int width = 0, height = 0;
+};
+
+class ShaderEngine {
+ public:
+  ShaderEngine();
+  ~ShaderEngine();
+
+  // device < 0: keep the current HIP device.  stream may be null (default stream).
+  bool init(int device = -1, hipStream_t stream = nullptr);
+  void shutdown();
+
+  bool loadShader(const std::string& shaderPath);
+  bool loadPreset(const std::string& presetPath);
+  std::string getPresetPath() const;
+
+  // One frame.  Returns the device pointer of the output frame (engine owned); returns
+  // `input` itself when no shader is active or no pass is usable, nullptr for a null input.
+  const void* applyShader(const void* input, uint32_t width, uint32_t height);
+  // N frames, `frameStride` bytes apart (0 = tightly packed width*height*4).
+  const void* applyShaderBatch(const void* inputs, uint32_t nFrames, uint32_t width, uint32_t height,
+                               uint64_t frameStride = 0);
+
+  void setViewport(uint32_t width, uint32_t height);
+  void disableShader();
+  bool isShaderActive() const { return m_shaderActive; }
+  uint32_t getOutputWidth() const { return m_outputWidth; }
+  uint32_t getOutputHeight() const { return m_outputHeight; }
+  void setMaxShaderResolution(uint32_t maxWidth, uint32_t maxHeight);
+  uint32_t getMaxShaderWidth() const { return m_maxShaderWidth; }
+  uint32_t getMaxShaderHeight() const { return m_maxShaderHeight; }
+
+  void setUniform(const std::string& name, float value);
+  void setUniform(const std::string& name, float x, float y);
+  void setUniform(const std::string& name, float x, float y, float z, float w);
+
+  struct ShaderParameter {
+    std::string name;
+    float value, defaultValue, min, max, step;
+    std::string description;
+  };
+  std::vector<ShaderParameter> getShaderParameters() const;
+  bool setShaderParameter(const std::string& name, float value);
+
+  ShaderPreset& getPreset() { return m_preset; }
+  const ShaderPreset& getPreset() const { return m_preset; }
+
+  // ---- not in the reference -------------------------------------------------------------
+  void setInputFilterLinear(bool linear) { m_inputLinear = linear; }  // FrameProcessor's texture filter
+  void setChunkFrames(uint32_t n) { m_chunk = n ? n : 1; }
+  // Accept presets whose .glsl files are absent when the registry knows the shader (the
+  // registry's parameter table is used).  Off by default: the reference fails such a pass.
+  void setAllowMissingSources(bool allow) { m_allowMissingSources = allow; }
+  uint32_t getChunkFrames() const { return m_chunk; }
+  hipStream_t stream() const { return m_stream; }
+  size_t passCount() const { return m_passes.size(); }
+  const ShaderPassData* pass(size_t i) const { return i < m_passes.size() ? &m_passes[i] : nullptr; }
+  uint64_t outputFrameBytes() const { return (uint64_t)m_outputWidth * m_outputHeight * 4; }
+  // Copies pass `i`'s target for frame `frame` of the last processed chunk to host memory.
+  bool readPass(size_t i, uint32_t frame, void* host, size_t bytes);
+  float frameCount() const { return m_frameCount; }
+  // Per-pass device timing with HIP events on the engine's stream (off by default; when on,
+  // every pass launch is bracketed by two events that are read back at collectProfile()).
+  void setProfiling(bool on);
+  struct PassProfile {
+    double totalMs = 0.0;   // summed launch durations
+    uint64_t launches = 0;  // kernel launches
+    uint64_t frames = 0;    // frames those launches processed
+  };
+  bool collectProfile(std::vector<PassProfile>* out);  // synchronises the stream
+  // Algorithmic bytes one frame of pass i moves: each distinct texture it samples once at its
+  // stored size, plus its target once (SURVEY.md section 8d convention).
+  void passBytes(size_t i, uint64_t* readBytes, uint64_t* writeBytes) const;
+
+ private:
+  bool m_initialized = false;
+  bool m_shaderActive = false;
+  int m_device = -1;
+  hipStream_t m_stream = nullptr;
+
+  ShaderPreset m_preset;
+  std::string m_presetPath;
+  std::vector<ShaderPassData> m_passes;
+  std::unordered_map<std::string, LutTexture> m_textureReferences;
+  uint32_t m_sourceWidth = 0, m_sourceHeight = 0;
+  uint32_t m_viewportWidth = 0, m_viewportHeight = 0;
+  uint32_t m_outputWidth = 0, m_outputHeight = 0;
+  uint32_t m_maxShaderWidth = 0, m_maxShaderHeight = 0;
+  float m_frameCount = 0.0f;
+  float m_time = 0.0f;
+  bool m_inputLinear = false;
+  uint32_t m_chunk = 4;
+  uint32_t m_lastChunkFrames = 0;
+  uint32_t m_lastChunkFirst = 0;
+  bool m_singleShader = false;
+  bool m_allowMissingSources = false;
+  struct Vec4 { float x, y, z, w; };
+  std::unordered_map<std::string, Vec4> m_uniforms;
+  DeviceBuffer m_batchOutput;
+  bool m_profiling = false;
+  struct TimedLaunch { size_t pass; uint32_t frames; hipEvent_t start, stop; };
+  std::vector<TimedLaunch> m_timed;
+  std::vector<PassProfile> m_profile;
+  std::vector<uint64_t> m_passReadBytes;
+
+  mutable std::mutex m_paramMutex;  // the reference shares these maps across threads unguarded
+  std::map<std::string, float> m_customParameters;
+
+  bool loadPresetPasses();
+  bool compilePass(size_t i);
+  void cleanupPresetPasses();
+  void cleanupTextureReferences();
+  bool loadTextureReference(const std::string& name, const std::string& path);
+  uint32_t calculateScale(uint32_t sourceSize, const std::string& scaleType, float scale, uint32_t viewportSize) const;
+  void resolvePassSizes(uint32_t width, uint32_t height);
+  bool ensureBuffer(DeviceBuffer& b, size_t bytes);
+  float effectiveParameter(const ShaderPassData& pass, const KernelParam& kp,
+                           const std::map<std::string, float>& custom) const;
+  rcd::Tex samplerFor(const std::string& uniformName, size_t passIndex, const rcd::Tex& inputTex,
+                      const rcd::Tex& sourceTex) const;
+  rcd::Tex passTexture(size_t passIndex) const;
+  bool runChunk(const void* inputs, uint64_t inStride, uint32_t width, uint32_t height, uint32_t nFrames,
+                int firstFrameCount, void* finalOut);
+};
+
+}  // namespace rc

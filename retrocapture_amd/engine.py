@@ -1,0 +1,287 @@
+"""ctypes mirror of the reference's ShaderEngine API (reference src/shader/ShaderEngine.h:42-98)
+over the C ABI in include/rc_shaderchain.h.  Method names and meanings follow the reference
+class; frames are device pointers (ints) or objects exposing ``data_ptr()`` (torch tensors).
+"""
+import ctypes as C
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class RcError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "librcshaderchain.so")
+
+
+class _RcParam(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("description", C.c_char * 128), ("value", C.c_float),
+                ("default_value", C.c_float), ("min", C.c_float), ("max", C.c_float), ("step", C.c_float)]
+
+
+class _RcPassInfo(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_int), ("has_kernel", C.c_int),
+                ("filter_linear", C.c_int), ("wrap", C.c_int), ("kernel", C.c_char * 48), ("alias", C.c_char * 48)]
+
+
+class _RcPassProfile(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("launches", C.c_uint64), ("frames", C.c_uint64),
+                ("read_bytes_per_frame", C.c_uint64), ("write_bytes_per_frame", C.c_uint64)]
+
+
+# every symbol include/rc_shaderchain.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("rc_engine_create", C.c_void_p, [C.c_int, C.c_void_p]),
+    ("rc_engine_destroy", None, [C.c_void_p]),
+    ("rc_engine_load_preset", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("rc_engine_load_shader", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("rc_engine_preset_path", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    ("rc_engine_disable", None, [C.c_void_p]),
+    ("rc_engine_is_active", C.c_int, [C.c_void_p]),
+    ("rc_engine_set_viewport", None, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    ("rc_engine_set_max_resolution", None, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    ("rc_engine_apply", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("rc_engine_apply_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("rc_engine_output_width", C.c_uint32, [C.c_void_p]),
+    ("rc_engine_output_height", C.c_uint32, [C.c_void_p]),
+    ("rc_engine_sync", C.c_int, [C.c_void_p]),
+    ("rc_engine_param_count", C.c_int, [C.c_void_p]),
+    ("rc_engine_param_get", C.c_int, [C.c_void_p, C.c_int, C.POINTER(_RcParam)]),
+    ("rc_engine_param_set", C.c_int, [C.c_void_p, C.c_char_p, C.c_float]),
+    ("rc_engine_set_uniform1", None, [C.c_void_p, C.c_char_p, C.c_float]),
+    ("rc_engine_set_uniform2", None, [C.c_void_p, C.c_char_p, C.c_float, C.c_float]),
+    ("rc_engine_set_uniform4", None, [C.c_void_p, C.c_char_p, C.c_float, C.c_float, C.c_float, C.c_float]),
+    ("rc_engine_save_preset", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("rc_engine_pass_count", C.c_int, [C.c_void_p]),
+    ("rc_engine_pass_info", C.c_int, [C.c_void_p, C.c_int, C.POINTER(_RcPassInfo)]),
+    ("rc_engine_read_pass", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]),
+    ("rc_engine_set_profiling", None, [C.c_void_p, C.c_int]),
+    ("rc_engine_pass_profile", C.c_int, [C.c_void_p, C.c_int, C.POINTER(_RcPassProfile)]),
+    ("rc_engine_set_chunk_frames", None, [C.c_void_p, C.c_uint32]),
+    ("rc_engine_set_allow_missing_sources", None, [C.c_void_p, C.c_int]),
+    ("rc_last_error", C.c_char_p, []),
+    ("rc_version", C.c_char_p, []),
+    ("rc_kernel_list", C.c_size_t, [C.c_char_p, C.c_size_t]),
+    ("rc_preset_dump_json", C.c_size_t, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("rc_shader_params_json", C.c_size_t, [C.c_char_p, C.c_char_p, C.c_size_t]),
+]
+
+
+def load_library():
+    """Loads librcshaderchain.so (built in-tree by __graft_entry__.build()); fails loudly."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RcError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % path)
+        lib = C.CDLL(path)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def _ptr(frame):
+    if frame is None:
+        return None
+    if hasattr(frame, "data_ptr"):
+        return frame.data_ptr()
+    return int(frame)
+
+
+def _json_call(fn, path):
+    buf = C.create_string_buffer(1 << 16)
+    n = fn(path.encode(), buf, len(buf))
+    if n >= len(buf):
+        buf = C.create_string_buffer(n + 1)
+        fn(path.encode(), buf, len(buf))
+    return json.loads(buf.value.decode())
+
+
+def preset_dump(path):
+    """Parsed preset (passes / textures / params) as the engine's parser sees it."""
+    return _json_call(load_library().rc_preset_dump_json, path)
+
+
+def shader_params(path):
+    return _json_call(load_library().rc_shader_params_json, path)
+
+
+def kernel_list():
+    lib = load_library()
+    buf = C.create_string_buffer(1 << 14)
+    lib.rc_kernel_list(buf, len(buf))
+    return [l for l in buf.value.decode().split("\n") if l]
+
+
+class ShaderParameter:
+    __slots__ = ("name", "value", "defaultValue", "min", "max", "step", "description")
+
+    def __init__(self, p):
+        self.name = p.name.decode()
+        self.description = p.description.decode()
+        self.value, self.defaultValue, self.min, self.max, self.step = p.value, p.default_value, p.min, p.max, p.step
+
+    def __repr__(self):
+        return "ShaderParameter(%s=%g [%g..%g] default %g)" % (self.name, self.value, self.min, self.max, self.defaultValue)
+
+
+class ShaderEngine:
+    """Same surface as the reference's ShaderEngine; `init()` needs a HIP device."""
+
+    def __init__(self):
+        self._lib = load_library()
+        self._h = None
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def init(self, device=-1, stream=None):
+        if self._h:
+            return True
+        self._h = self._lib.rc_engine_create(int(device), C.c_void_p(stream) if stream else None)
+        return bool(self._h)
+
+    def shutdown(self):
+        if self._h:
+            self._lib.rc_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.shutdown()
+        except Exception:
+            pass
+
+    def _need(self):
+        if not self._h:
+            raise RcError("ShaderEngine not initialized")
+        return self._h
+
+    # -- reference API -----------------------------------------------------------------------
+    def loadPreset(self, presetPath):
+        return self._lib.rc_engine_load_preset(self._need(), str(presetPath).encode()) >= 0
+
+    def loadPresetStatus(self, presetPath):
+        """0 ok, 1 loaded with skipped passes, <0 failure (C ABI status)."""
+        return self._lib.rc_engine_load_preset(self._need(), str(presetPath).encode())
+
+    def loadShader(self, shaderPath):
+        return self._lib.rc_engine_load_shader(self._need(), str(shaderPath).encode()) >= 0
+
+    def getPresetPath(self):
+        buf = C.create_string_buffer(4096)
+        self._lib.rc_engine_preset_path(self._need(), buf, len(buf))
+        return buf.value.decode()
+
+    def setViewport(self, width, height):
+        self._lib.rc_engine_set_viewport(self._need(), int(width), int(height))
+
+    def disableShader(self):
+        self._lib.rc_engine_disable(self._need())
+
+    def isShaderActive(self):
+        return bool(self._lib.rc_engine_is_active(self._need()))
+
+    def getOutputWidth(self):
+        return self._lib.rc_engine_output_width(self._need())
+
+    def getOutputHeight(self):
+        return self._lib.rc_engine_output_height(self._need())
+
+    def setMaxShaderResolution(self, maxWidth, maxHeight):
+        self._lib.rc_engine_set_max_resolution(self._need(), int(maxWidth), int(maxHeight))
+
+    def applyShader(self, inputFrame, width, height):
+        """Returns (device_pointer, out_width, out_height).  The pointer equals the input's when
+        the engine is inactive / has no usable pass, as in the reference."""
+        out, ow, oh = C.c_void_p(), C.c_uint32(), C.c_uint32()
+        rc = self._lib.rc_engine_apply(self._need(), _ptr(inputFrame), int(width), int(height), C.byref(out),
+                                       C.byref(ow), C.byref(oh))
+        if rc < 0:
+            raise RcError("applyShader failed (%d): %s" % (rc, self._lib.rc_last_error().decode()))
+        return out.value, ow.value, oh.value
+
+    def applyShaderBatch(self, inputFrames, nFrames, width, height, frameStride=0):
+        out, ow, oh = C.c_void_p(), C.c_uint32(), C.c_uint32()
+        rc = self._lib.rc_engine_apply_batch(self._need(), _ptr(inputFrames), int(nFrames), int(width), int(height),
+                                             int(frameStride), C.byref(out), C.byref(ow), C.byref(oh))
+        if rc < 0:
+            raise RcError("applyShaderBatch failed (%d): %s" % (rc, self._lib.rc_last_error().decode()))
+        return out.value, ow.value, oh.value
+
+    def getShaderParameters(self):
+        n = self._lib.rc_engine_param_count(self._need())
+        out = []
+        for i in range(n):
+            p = _RcParam()
+            if self._lib.rc_engine_param_get(self._h, i, C.byref(p)) == 0:
+                out.append(ShaderParameter(p))
+        return out
+
+    def setShaderParameter(self, name, value):
+        return bool(self._lib.rc_engine_param_set(self._need(), name.encode(), float(value)))
+
+    def setUniform(self, name, *v):
+        if len(v) == 1:
+            self._lib.rc_engine_set_uniform1(self._need(), name.encode(), *map(float, v))
+        elif len(v) == 2:
+            self._lib.rc_engine_set_uniform2(self._need(), name.encode(), *map(float, v))
+        elif len(v) == 4:
+            self._lib.rc_engine_set_uniform4(self._need(), name.encode(), *map(float, v))
+        else:
+            raise TypeError("setUniform takes 1, 2 or 4 floats")
+
+    def savePreset(self, path):
+        return self._lib.rc_engine_save_preset(self._need(), str(path).encode()) == 0
+
+    # -- additions ---------------------------------------------------------------------------
+    def sync(self):
+        if self._lib.rc_engine_sync(self._need()) != 0:
+            raise RcError("device error: " + self._lib.rc_last_error().decode())
+
+    def setChunkFrames(self, n):
+        self._lib.rc_engine_set_chunk_frames(self._need(), int(n))
+
+    def setAllowMissingSources(self, allow):
+        self._lib.rc_engine_set_allow_missing_sources(self._need(), int(bool(allow)))
+
+    def setProfiling(self, on):
+        self._lib.rc_engine_set_profiling(self._need(), int(bool(on)))
+
+    def passProfile(self, i):
+        p = _RcPassProfile()
+        if self._lib.rc_engine_pass_profile(self._need(), int(i), C.byref(p)) != 0:
+            raise RcError("passProfile failed: " + self._lib.rc_last_error().decode())
+        return {"total_ms": p.total_ms, "launches": p.launches, "frames": p.frames,
+                "read_bytes_per_frame": p.read_bytes_per_frame, "write_bytes_per_frame": p.write_bytes_per_frame}
+
+    def passCount(self):
+        return self._lib.rc_engine_pass_count(self._need())
+
+    def passInfo(self, i):
+        info = _RcPassInfo()
+        if self._lib.rc_engine_pass_info(self._need(), int(i), C.byref(info)) != 0:
+            raise IndexError(i)
+        return {"width": info.width, "height": info.height, "format": {0: "rgba8", 1: "srgb8", 3: "f32"}[info.format],
+                "has_kernel": bool(info.has_kernel), "filter_linear": bool(info.filter_linear),
+                "wrap": ["clamp_to_edge", "clamp_to_border", "repeat", "mirrored_repeat"][info.wrap],
+                "kernel": info.kernel.decode(), "alias": info.alias.decode()}
+
+    def readPass(self, i, frame=0):
+        """Host copy (numpy) of pass i's render target for `frame` of the last batch."""
+        import numpy as np
+        info = self.passInfo(i)
+        dt = np.float32 if info["format"] == "f32" else np.uint8
+        arr = np.empty((info["height"], info["width"], 4), dt)
+        rc = self._lib.rc_engine_read_pass(self._h, int(i), int(frame), arr.ctypes.data, arr.nbytes)
+        if rc != 0:
+            raise RcError("readPass(%d,%d) failed: %s" % (i, frame, self._lib.rc_last_error().decode()))
+        return arr

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz: golden vectors for the shader chain.
+
+Runs ONLY in the build container (needs /root/reference and oracle/_ref, built by
+`make -C oracle ref`): each case executes the reference's own GLSL shader files on Mesa
+llvmpipe through oracle/_ref/glchain (pass plumbing restated from ShaderEngine.cpp, preset
+parsed by the reference's own ShaderPreset.cpp) and stores the input frame plus every
+pass's stored texels.  What is committed is data (inputs and outputs), never shader text.
+
+    python tests/golden/make_golden.py [case ...]
+"""
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+GLSL = REF + "/shaders/shaders_glsl"
+GLCHAIN = os.path.join(ROOT, "oracle", "_ref", "glchain")
+
+
+def bars(w, h, f=0):
+    """The reference's synthetic source (VideoCaptureTestPattern.cpp:65-101): 8 colour bars
+    plus a black 8-px marker that moves with the frame number."""
+    cols = np.array([[255, 255, 255], [255, 255, 0], [0, 255, 255], [0, 255, 0], [255, 0, 255], [255, 0, 0],
+                     [0, 0, 255], [16, 16, 16]], np.uint8)
+    bw = max(1, w // 8)
+    idx = np.minimum(np.arange(w) // bw, 7)
+    img = np.broadcast_to(cols[idx][None, :, :], (h, w, 3)).copy()
+    x0 = f % w
+    img[: h // 8, x0:min(w, x0 + 8)] = 0
+    return img
+
+
+def noise(w, h, seed):
+    return np.random.default_rng(seed).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+def mixed(w, h, seed):
+    """Left half bars, right half noise, plus a smooth gradient band: exercises flat
+    regions, hard edges and every byte value."""
+    img = bars(w, h, 3)
+    img[:, w // 2:] = noise(w - w // 2, h, seed)
+    g = (np.arange(w) * 255 // max(1, w - 1)).astype(np.uint8)
+    img[h // 3: h // 3 + max(2, h // 8)] = np.stack([g, g[::-1], g], -1)[None]
+    return img
+
+
+def write_preset(d, text):
+    p = os.path.join(d, "case.glslp")
+    open(p, "w").write(text)
+    return p
+
+
+def run_case(name, preset, rgb, vw, vh, frames=1, luts=(), params=()):
+    h, w, _ = rgb.shape
+    with tempfile.TemporaryDirectory() as d:
+        rgb.tofile(os.path.join(d, "in.rgb"))
+        cmd = [GLCHAIN, "--preset", preset, "--input", os.path.join(d, "in.rgb"), "--w", str(w), "--h", str(h),
+               "--vw", str(vw), "--vh", str(vh), "--frames", str(frames), "--out", d]
+        for n, (path, lw, lh) in luts:
+            cmd += ["--lut", "%s=%s:%d:%d" % (n, path, lw, lh)]
+        for k, v in params:
+            cmd += ["--param", "%s=%g" % (k, v)]
+        env = dict(os.environ, RETROCAPTURE_LOG_LEVEL="error")
+        r = subprocess.run(cmd, cwd=REF, env=env, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(r.stderr)
+        out = {"input_rgb": rgb, "viewport": np.array([vw, vh]), "frames": np.array(frames)}
+        meta = open(os.path.join(d, "meta.txt")).read().splitlines()
+        k = 0
+        for line in meta:
+            if not line.startswith("pass "):
+                continue
+            _, i, pw, ph, fmt = line.split()[:5]
+            pw, ph = int(pw), int(ph)
+            dt = np.float32 if fmt == "f32" else np.uint8
+            out["pass%d" % k] = np.fromfile(os.path.join(d, "pass%s.bin" % i), dtype=dt).reshape(ph, pw, 4)
+            out["pass%d_fmt" % k] = np.array(fmt)
+            k += 1
+        out["n_passes"] = np.array(k)
+        out["sha256_last"] = np.array(hashlib.sha256(out["pass%d" % (k - 1)].tobytes()).hexdigest())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {kk: getattr(v, "shape", None) for kk, v in out.items() if kk.startswith("pass") and not kk.endswith("fmt")})
+
+
+def case_scanline():
+    # BASELINE config 1: misc/scanline.glslp does not exist in the reference; the shader is
+    # run from a synthesized one-pass preset (SURVEY.md, facts established by probing).
+    with tempfile.TemporaryDirectory() as d:
+        p = write_preset(d, 'shaders = 1\nshader0 = %s/scanlines/shaders/scanline.glsl\n' % GLSL)
+        run_case("scanline_320x240", p, mixed(320, 240, 1), 320, 240)
+        run_case("scanline_64x48_to_160x100", p, mixed(64, 48, 2), 160, 100)
+
+
+def case_crt_pi():
+    run_case("crt_pi_96x64_to_192x128", GLSL + "/crt/crt-pi.glslp", mixed(96, 64, 3), 192, 128)
+    run_case("crt_pi_80x60_to_250x190", GLSL + "/crt/crt-pi.glslp", noise(80, 60, 4), 250, 190)
+
+
+CASES = {"scanline": case_scanline, "crt_pi": case_crt_pi}
+
+if __name__ == "__main__":
+    for c in (sys.argv[1:] or list(CASES)):
+        CASES[c]()

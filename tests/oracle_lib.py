@@ -6,6 +6,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = None
+_THREADS = 1
+
+
+def set_threads(n):
+    """Rows of every pass are split over n threads (ctypes releases the GIL)."""
+    global _THREADS
+    _THREADS = max(1, int(n))
 
 FMT = {"rgba8": 0, "srgb8": 1, "rgbx8": 2, "f32": 3}
 WRAP = {"clamp_to_edge": 0, "clamp_to_border": 1, "repeat": 2, "mirrored_repeat": 3}
@@ -67,6 +74,44 @@ def run_pass(name, tex, out_w, out_h, out_fmt="rgba8", params=(), frame_count=1,
     a.frame_count = frame_count
     a.params = p
     a.dst = dst.ctypes.data
-    a.y0, a.y1 = 0, out_h
-    fn(C.byref(a))
+    if _THREADS > 1 and out_h >= 4 * _THREADS:
+        import copy
+        import threading
+        ths = []
+        for k in range(_THREADS):
+            b = OPassArgs()
+            C.memmove(C.byref(b), C.byref(a), C.sizeof(OPassArgs))
+            b.y0, b.y1 = out_h * k // _THREADS, out_h * (k + 1) // _THREADS
+            t = threading.Thread(target=fn, args=(C.byref(b),))
+            t.start()
+            ths.append((t, b))
+        for t, _ in ths:
+            t.join()
+    else:
+        a.y0, a.y1 = 0, out_h
+        fn(C.byref(a))
     return dst
+
+
+def run_pass_rows(name, tex, out_w, out_h, y0, y1, out_fmt="rgba8", params=(), frame_count=1, extra=(),
+                  src_w=None, src_h=None):
+    """Rows [y0, y1) of a pass rendered at full target size (for full-size spot checks)."""
+    L = lib()
+    fn = getattr(L, "o_pass_" + name)
+    fn.restype = None
+    fn.argtypes = [C.POINTER(OPassArgs)]
+    dst = np.zeros((out_h, out_w, 4), np.float32 if out_fmt == "f32" else np.uint8)
+    p = (C.c_float * max(1, len(params)))(*params)
+    a = OPassArgs()
+    a.inp = C.pointer(tex.c)
+    for i, e in enumerate(extra):
+        a.extra[i] = C.pointer(e.c)
+    a.src_w = src_w or tex.c.w
+    a.src_h = src_h or tex.c.h
+    a.out_w, a.out_h, a.out_fmt = out_w, out_h, FMT[out_fmt]
+    a.frame_count = frame_count
+    a.params = p
+    a.dst = dst.ctypes.data
+    a.y0, a.y1 = y0, y1
+    fn(C.byref(a))
+    return dst[y0:y1].copy()
