@@ -44,7 +44,8 @@ def cpu_baseline(key, w, h, vw, vh, tree, budget_s=15.0):
     import oracle_chain
     import oracle_lib
     from retrocapture_amd import engine as eng
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    # the GPU box gives a one-GPU job 16 host cores; never start more workers than that
+    cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
     passes = eng.preset_dump(tree[key])["passes"]
     rng = np.random.default_rng(123)
     frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)

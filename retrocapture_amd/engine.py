@@ -81,6 +81,15 @@ def load_library():
         if not os.path.exists(path):
             raise RcError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)" % path)
+        # PyTorch wheels bundle their own libamdhip64; if this process is going to use torch for
+        # device memory as well, its HIP runtime must be the one (and only one) that gets loaded,
+        # so it is imported first and our library then binds to the already-loaded runtime.
+        # A process without torch simply uses /opt/rocm's.
+        if os.environ.get("RC_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         lib = C.CDLL(path)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)
