@@ -11,6 +11,7 @@
  */
 #include <math.h>
 #include <string.h>
+#include <xmmintrin.h>
 
 #include "rc_oracle.h"
 
@@ -34,7 +35,12 @@ float o_exp2(float x) {
 
 /* log2(m) for m in [1,2) as y*P(y^2), y = (m-1)/(m+1), degree-4 P; + exponent */
 float o_log2(float x) {
+  /* edge cases as llvmpipe's lp_build_log2 "safe" form returns them (measured): zero and
+   * denormals (the GL runs with denormals-are-zero) -> -inf, negative -> NaN, +inf -> +inf */
   uint32_t i = f2bits(x);
+  if ((i & 0x7f800000u) == 0) return -INFINITY;
+  if (i & 0x80000000u) return NAN;
+  if (i == 0x7f800000u) return INFINITY;
   float logexp = (float)((int32_t)((i & 0x7f800000u) >> 23) - 127);
   float mant = bits2f((i & 0x007fffffu) | 0x3f800000u);
   float y = (mant - 1.0f) / (mant + 1.0f);
@@ -86,3 +92,12 @@ static float sincos_impl(float x, int want_cos) {
 }
 float o_sin(float x) { return sincos_impl(x, 0); }
 float o_cos(float x) { return sincos_impl(x, 1); }
+
+/* llvmpipe executes shaders with flush-to-zero and denormals-are-zero set in MXCSR; every
+ * oracle pass runs between these two calls so that tiny intermediates behave the same. */
+unsigned o_fp_enter(void) {
+  unsigned old = _mm_getcsr();
+  _mm_setcsr(old | 0x8040u); /* FTZ (bit 15) | DAZ (bit 6) */
+  return old;
+}
+void o_fp_leave(unsigned old) { _mm_setcsr(old); }

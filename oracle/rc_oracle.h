@@ -36,6 +36,8 @@ float o_exp(float x);
 float o_log(float x);
 float o_sin(float x);
 float o_cos(float x);
+unsigned o_fp_enter(void);      /* set FTZ|DAZ, returns the previous MXCSR */
+void o_fp_leave(unsigned old);
 
 /* ---- textures / sampling (rc_sampler.c) ---------------------------------------------- */
 enum { O_FMT_RGBA8 = 0, O_FMT_SRGB8 = 1, O_FMT_RGBX8 = 2, O_FMT_F32 = 3 };
@@ -81,11 +83,37 @@ typedef struct {
   const float* params;
   void* dst;
   int y0, y1;            /* row range to render (for threading); 0,out_h for all */
+  /* chain geometry, for shaders that read PassPrev<N>TextureSize / InputSize uniforms
+   * (reference ShaderEngine.cpp:1191-1227): output size of every pass, and this pass's index */
+  int pass_index;
+  int n_passes;
+  int chain_w[16], chain_h[16];
+  int vp_w, vp_h;
+  int flags;             /* pass specific, see O_FLAG_* */
 } o_pass_args;
+
+/* crt-royale pass 6 reads a varying its vertex shader never writes.  On Mesa llvmpipe the
+ * undefined value makes the fragment shader discard every pixel (default, flags = 0); GL
+ * drivers that hand back 0 for such a varying render the resized mask instead. */
+#define O_FLAG_ROYALE_UNDEF_VARYING_ZERO 1
 
 void o_pass_stock(const o_pass_args* a);
 void o_pass_scanline(const o_pass_args* a);
 void o_pass_crt_pi(const o_pass_args* a);
+/* crt-royale (shaders/shaders_glsl/crt/shaders/crt-royale/src/*.glsl, blurs/blur9fast-*.glsl) */
+void o_pass_royale_first(const o_pass_args* a);       /* P0  first-pass-linearize-crt-gamma-bob-fields */
+void o_pass_royale_scan_v(const o_pass_args* a);      /* P1  scanlines-vertical-interlacing */
+void o_pass_royale_bloom_approx(const o_pass_args* a);/* P2  bloom-approx; extra[0] = PassPrev2Texture */
+void o_pass_blur9_v(const o_pass_args* a);            /* P3  blurs/blur9fast-vertical */
+void o_pass_blur9_h(const o_pass_args* a);            /* P4  blurs/blur9fast-horizontal */
+void o_pass_royale_mask_v(const o_pass_args* a);      /* P5  mask-resize-vertical; extra[0] = mask_slot_texture_small */
+void o_pass_royale_mask_h(const o_pass_args* a);      /* P6  mask-resize-horizontal */
+void o_pass_royale_scan_h(const o_pass_args* a);      /* P7  scanlines-horizontal-apply-mask; extra = PassPrev6, PassPrev3 */
+void o_pass_royale_brightpass(const o_pass_args* a);  /* P8  brightpass; extra[0] = PassPrev4 */
+void o_pass_royale_bloom_v(const o_pass_args* a);     /* P9  bloom-vertical */
+void o_pass_royale_bloom_h(const o_pass_args* a);     /* P10 bloom-horizontal-reconstitute; extra = PassPrev3, PassPrev2, PassPrev6 */
+void o_pass_royale_last(const o_pass_args* a);        /* P11 geometry-aa-last-pass; 44 params */
+void o_store_pixel(const o_pass_args* a, int x, int y, o_vec4 c);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,13 @@ static void store_px(const o_pass_args* a, int x, int y, o_vec4 c) {
 
 void o_store_pixel(const o_pass_args* a, int x, int y, o_vec4 c) { store_px(a, x, y, c); }
 
+static void o_pass_stock_body(const o_pass_args* a);
 void o_pass_stock(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  o_pass_stock_body(a);
+  o_fp_leave(csr);
+}
+static void o_pass_stock_body(const o_pass_args* a) {
   const int W = a->out_w, H = a->out_h;
   o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
   for (int y = a->y0; y < a->y1; ++y)
@@ -40,7 +46,13 @@ void o_pass_stock(const o_pass_args* a) {
 }
 
 /* params: SCANLINE_BASE_BRIGHTNESS, SCANLINE_SINE_COMP_A, SCANLINE_SINE_COMP_B, size */
+static void o_pass_scanline_body(const o_pass_args* a);
 void o_pass_scanline(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  o_pass_scanline_body(a);
+  o_fp_leave(csr);
+}
+static void o_pass_scanline_body(const o_pass_args* a) {
   const int W = a->out_w, H = a->out_h;
   const float base = a->params[0], comp_a = a->params[1], comp_b = a->params[2], size = a->params[3];
   const float pi = 3.141592654f;
@@ -68,7 +80,13 @@ static inline float crtpi_weight(float dist, float sw, float gap) {
   return w > gap ? w : gap; /* max(w, gap) */
 }
 
+static void o_pass_crt_pi_body(const o_pass_args* a);
 void o_pass_crt_pi(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  o_pass_crt_pi_body(a);
+  o_fp_leave(csr);
+}
+static void o_pass_crt_pi_body(const o_pass_args* a) {
   const int W = a->out_w, H = a->out_h;
   const float mask_b = a->params[2], sw = a->params[3], gap = a->params[4], bloom = a->params[5];
   const float in_gamma = a->params[6], out_gamma = a->params[7];

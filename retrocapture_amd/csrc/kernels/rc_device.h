@@ -9,7 +9,8 @@
 // polynomials (fused multiply-adds where llvmpipe fuses), its texel decode and two filter
 // paths, its varying setup and its store rounding.  All of that is written here directly in
 // HIP; the file is compiled with -ffp-contract=off so only the explicit __builtin_fmaf calls
-// fuse, and float division / sqrt are IEEE-correct (hipcc default).
+// fuse, and float division / sqrt are IEEE-correct (hipcc default).  Denormals are flushed
+// (-fgpu-flush-denormals-to-zero), like the GL's FTZ/DAZ execution mode.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -71,6 +72,10 @@ __device__ __forceinline__ float exp2_(float x) {
 
 __device__ __forceinline__ float log2_(float x) {
   uint32_t i = f2bits(x);
+  // zero / denormal -> -inf, negative -> NaN, +inf -> +inf (the GL's "safe" log2)
+  if ((i & 0x7f800000u) == 0u) return -__builtin_inff();
+  if (i & 0x80000000u) return __builtin_nanf("");
+  if (i == 0x7f800000u) return __builtin_inff();
   float logexp = (float)((int32_t)((i & 0x7f800000u) >> 23) - 127);
   float mant = bits2f((i & 0x007fffffu) | 0x3f800000u);
   float y = (mant - 1.0f) / (mant + 1.0f);

@@ -103,7 +103,36 @@ def case_crt_pi():
     run_case("crt_pi_80x60_to_250x190", GLSL + "/crt/crt-pi.glslp", noise(80, 60, 4), 250, 190)
 
 
-CASES = {"scanline": case_scanline, "crt_pi": case_crt_pi}
+def royale_luts(d):
+    """LUT PNGs decoded to RGBA8 exactly as the reference's loader does for 8-bit RGB files
+    (opaque alpha added, ShaderEngine.cpp:2535-2706); glchain uploads the raw texels."""
+    from PIL import Image
+    names = {
+        "mask_grille_texture_small": "TileableLinearApertureGrille15Wide8And5d5SpacingResizeTo64.png",
+        "mask_grille_texture_large": "TileableLinearApertureGrille15Wide8And5d5Spacing.png",
+        "mask_slot_texture_small": "TileableLinearSlotMaskTall15Wide9And4d5Horizontal9d14VerticalSpacingResizeTo64.png",
+        "mask_slot_texture_large": "TileableLinearSlotMaskTall15Wide9And4d5Horizontal9d14VerticalSpacing.png",
+        "mask_shadow_texture_small": "TileableLinearShadowMaskEDPResizeTo64.png",
+        "mask_shadow_texture_large": "TileableLinearShadowMaskEDP.png",
+    }
+    out = []
+    for n, f in names.items():
+        im = Image.open(GLSL + "/crt/shaders/crt-royale/" + f).convert("RGBA")
+        raw = os.path.join(d, n + ".rgba")
+        np.asarray(im).tofile(raw)
+        out.append((n, (raw, im.size[0], im.size[1])))
+    return out
+
+
+def case_crt_royale():
+    with tempfile.TemporaryDirectory() as d:
+        luts = royale_luts(d)
+        run_case("crt_royale_160x120_to_320x240", GLSL + "/crt/crt-royale.glslp", mixed(160, 120, 5), 320, 240,
+                 frames=2, luts=luts)
+        run_case("crt_royale_128x96_to_400x300", GLSL + "/crt/crt-royale.glslp", noise(128, 96, 6), 400, 300, luts=luts)
+
+
+CASES = {"scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale}
 
 if __name__ == "__main__":
     for c in (sys.argv[1:] or list(CASES)):

@@ -27,7 +27,9 @@ class OPassArgs(C.Structure):
     _fields_ = [("inp", C.POINTER(OTex)), ("extra", C.POINTER(OTex) * 8), ("src_w", C.c_int),
                 ("src_h", C.c_int), ("out_w", C.c_int), ("out_h", C.c_int), ("out_fmt", C.c_int),
                 ("frame_count", C.c_int), ("params", C.POINTER(C.c_float)), ("dst", C.c_void_p),
-                ("y0", C.c_int), ("y1", C.c_int)]
+                ("y0", C.c_int), ("y1", C.c_int), ("pass_index", C.c_int), ("n_passes", C.c_int),
+                ("chain_w", C.c_int * 16), ("chain_h", C.c_int * 16), ("vp_w", C.c_int), ("vp_h", C.c_int),
+                ("flags", C.c_int)]
 
 
 def lib():
@@ -55,9 +57,8 @@ class Tex:
         self.fmt = fmt
 
 
-def run_pass(name, tex, out_w, out_h, out_fmt="rgba8", params=(), frame_count=1, extra=(),
-             src_w=None, src_h=None):
-    """Render one pass with the oracle; returns (out_h, out_w, 4) uint8 or float32."""
+def _call(name, tex, out_w, out_h, y0, y1, out_fmt, params, frame_count, extra, src_w, src_h, chain, pass_index,
+          vp, flags, threads):
     L = lib()
     fn = getattr(L, "o_pass_" + name)
     fn.restype = None
@@ -74,44 +75,40 @@ def run_pass(name, tex, out_w, out_h, out_fmt="rgba8", params=(), frame_count=1,
     a.frame_count = frame_count
     a.params = p
     a.dst = dst.ctypes.data
-    if _THREADS > 1 and out_h >= 4 * _THREADS:
-        import copy
+    a.pass_index = pass_index
+    a.n_passes = len(chain) if chain else 1
+    for k, (cw, ch) in enumerate(chain or []):
+        a.chain_w[k], a.chain_h[k] = cw, ch
+    a.vp_w, a.vp_h = vp if vp else (out_w, out_h)
+    a.flags = flags
+    rows = y1 - y0
+    if threads > 1 and rows >= 4 * threads:
         import threading
         ths = []
-        for k in range(_THREADS):
+        for k in range(threads):
             b = OPassArgs()
             C.memmove(C.byref(b), C.byref(a), C.sizeof(OPassArgs))
-            b.y0, b.y1 = out_h * k // _THREADS, out_h * (k + 1) // _THREADS
+            b.y0, b.y1 = y0 + rows * k // threads, y0 + rows * (k + 1) // threads
             t = threading.Thread(target=fn, args=(C.byref(b),))
             t.start()
             ths.append((t, b))
         for t, _ in ths:
             t.join()
     else:
-        a.y0, a.y1 = 0, out_h
+        a.y0, a.y1 = y0, y1
         fn(C.byref(a))
     return dst
 
 
+def run_pass(name, tex, out_w, out_h, out_fmt="rgba8", params=(), frame_count=1, extra=(), src_w=None, src_h=None,
+             chain=None, pass_index=0, vp=None, flags=0):
+    """Render one pass with the oracle; returns (out_h, out_w, 4) uint8 or float32."""
+    return _call(name, tex, out_w, out_h, 0, out_h, out_fmt, params, frame_count, extra, src_w, src_h, chain,
+                 pass_index, vp, flags, _THREADS)
+
+
 def run_pass_rows(name, tex, out_w, out_h, y0, y1, out_fmt="rgba8", params=(), frame_count=1, extra=(),
-                  src_w=None, src_h=None):
+                  src_w=None, src_h=None, chain=None, pass_index=0, vp=None, flags=0):
     """Rows [y0, y1) of a pass rendered at full target size (for full-size spot checks)."""
-    L = lib()
-    fn = getattr(L, "o_pass_" + name)
-    fn.restype = None
-    fn.argtypes = [C.POINTER(OPassArgs)]
-    dst = np.zeros((out_h, out_w, 4), np.float32 if out_fmt == "f32" else np.uint8)
-    p = (C.c_float * max(1, len(params)))(*params)
-    a = OPassArgs()
-    a.inp = C.pointer(tex.c)
-    for i, e in enumerate(extra):
-        a.extra[i] = C.pointer(e.c)
-    a.src_w = src_w or tex.c.w
-    a.src_h = src_h or tex.c.h
-    a.out_w, a.out_h, a.out_fmt = out_w, out_h, FMT[out_fmt]
-    a.frame_count = frame_count
-    a.params = p
-    a.dst = dst.ctypes.data
-    a.y0, a.y1 = y0, y1
-    fn(C.byref(a))
-    return dst[y0:y1].copy()
+    return _call(name, tex, out_w, out_h, y0, y1, out_fmt, params, frame_count, extra, src_w, src_h, chain,
+                 pass_index, vp, flags, 1)[y0:y1].copy()
