@@ -391,3 +391,269 @@ void o_pass_royale_mask_h(const o_pass_args* a) {
     }
   LEAVE;
 }
+
+/* =========================================================================== P7 ====== */
+/* scanlines-horizontal-apply-mask.glsl: VS 6103-6135, FS 10877-11030;
+ * sample_single_scanline_horizontal 5198-5241 (beam_horiz_filter 0: Quilez weights),
+ * get_interpolated_linear_color 5080-5163 (linear RGB weight 1 -> linear_mixed_color),
+ * get_mask_sampling_parameters 5875-5908, convert_phosphor_tile_uv_wrap_to_tex_uv 5965-5992.
+ * extra[0] = PassPrev6Texture (VERTICAL_SCANLINES), extra[1] = PassPrev3Texture (HALATION_BLUR). */
+static void prev_pass_sizes(const o_pass_args* a, int n, float* in_w, float* in_h, float* tex_w, float* tex_h) {
+  /* PassPrev<n>InputSize / TextureSize as the reference engine sets them
+   * (ShaderEngine.cpp:1191-1227): target pass p = pass_index - n; TextureSize = p's output
+   * size; InputSize = what p received = output of p-1, or the source frame for p = 0. */
+  int p = a->pass_index - n;
+  *tex_w = (float)a->chain_w[p];
+  *tex_h = (float)a->chain_h[p];
+  *in_w = p == 0 ? (float)a->src_w : (float)a->chain_w[p - 1];
+  *in_h = p == 0 ? (float)a->src_h : (float)a->chain_h[p - 1];
+}
+
+static float scanline_horizontal_1ch(const o_tex* t, float u, float v, float tsx, float tsy, float tix, float tiy, int ch) {
+  float ctx = u * tsx, cty = v * tsy;
+  float ptx = floorf(ctx - under_half) + 0.5f;
+  float phx = ptx, phy = cty;
+  float puv_x = phx * tix, puv_y = phy * tiy;
+  float prev_dist = ctx - phx;
+  float x = prev_dist;
+  float w2 = x * x * x * (x * (x * 6.0f - 15.0f) + 10.0f);
+  float wx = 0.0f, wy = 1.0f - w2, wz = w2, ww = 0.0f;
+  float dot = ((wx * 1.0f + wy * 1.0f) + wz * 1.0f) + ww * 1.0f;
+  float fx = wx / dot, fy = wy / dot, fz = wz / dot, fw = ww / dot;
+  o_vec4 c1 = o_sample(t, puv_x, puv_y);
+  o_vec4 c2 = o_sample(t, puv_x + tix, puv_y + 0.0f);
+  float a1 = ch == 0 ? c1.x : (ch == 1 ? c1.y : c1.z);
+  float a2 = ch == 0 ? c2.x : (ch == 1 ? c2.y : c2.z);
+  float m = ((0.0f * fx + a1 * fy) + a2 * fz) + 0.0f * fw;
+  return maxps(m, 0.0f);
+}
+
+void o_pass_royale_scan_h(const o_pass_args* a) {
+  ENTER;
+  const int W = a->out_w, H = a->out_h;
+  const float ox = (float)W, oy = (float)H;
+  const float tsx = (float)a->in->w, tsy = (float)a->in->h; /* MASK_RESIZE texture/video size */
+  float p6iw, p6ih, p6tw, p6th;
+  prev_pass_sizes(a, 6, &p6iw, &p6ih, &p6tw, &p6th);
+  const float stix = 1.0f / p6tw, stiy = 1.0f / p6th; /* scanline_texture_size_inv */
+  /* vertex values */
+  const float vu1 = (1.0f * tsx) / tsx, vv1 = (1.0f * tsy) / tsy, vu0 = (0.0f * tsx) / tsx, vv0 = (0.0f * tsy) / tsy;
+  o_varying p_vu = plane_u(vu0, vu1, W, H, a->out_fmt), p_vv = plane_v(vv0, vv1, W, H, a->out_fmt);
+  o_varying p_su = plane_u(vu0 * p6iw * stix, vu1 * p6iw * stix, W, H, a->out_fmt);
+  o_varying p_sv = plane_v(vv0 * p6ih * stiy, vv1 * p6ih * stiy, W, H, a->out_fmt);
+  /* get_mask_sampling_parameters(MASK_RESIZE texture size, video size, output_size) */
+  v2 tile = resized_mask_tile_size(tsx, tsy);
+  const float uvs_x = tile.x / tsx, uvs_y = tile.y / tsy;                 /* mask_tile_uv_size */
+  const float start_x = (0.0f / tile.x) * uvs_x, start_y = (0.0f / tile.y) * uvs_y; /* mask_start_texels = 0 */
+  const float tps_x = ox / tile.x, tps_y = oy / tile.y;                    /* mask_tiles_per_screen */
+  const float conv_x[3] = {0.1f, 0.3f, 0.5f};
+  const o_tex* scan = a->extra[0];
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      float vu = o_varying_at(&p_vu, x, y, lo), vv = o_varying_at(&p_vv, x, y, lo);
+      float su = o_varying_at(&p_su, x, y, lo), sv = o_varying_at(&p_sv, x, y, lo);
+      float scanc[3];
+      for (int ch = 0; ch < 3; ++ch) {
+        float off = conv_x[ch] * stix;
+        scanc[ch] = scanline_horizontal_1ch(scan, su - off, sv - 0.0f, p6tw, p6th, stix, stiy, ch);
+      }
+      float twx = vu * tps_x, twy = vv * tps_y;
+      float tux = fractf(twx * 0.5f) * 2.0f, tuy = fractf(twy * 0.5f) * 2.0f;
+      float mu = start_x + tux * uvs_x, mv = start_y + tuy * uvs_y;
+      o_vec4 mask = o_sample(a->in, mu, mv);
+      /* electron_intensity_dim = lerp(scanline, halation_intensity, halation_weight = 0) */
+      o_vec4 o = {scanc[0] * mask.x, scanc[1] * mask.y, scanc[2] * mask.z, 1.0f};
+      o_store_pixel(a, x, y, o);
+    }
+  LEAVE;
+}
+
+/* ===================================================================== P8 - P10 ====== */
+/* bloom sigma: VS of brightpass / bloom-vertical / bloom-horizontal-reconstitute
+ * (e.g. brightpass.glsl 6616-6649): get_min_sigma_to_blur_triad(tile_x / 8, 1/256). */
+static float bloom_sigma_runtime(float ox, float oy) {
+  v2 tile = resized_mask_tile_size(ox * 0.0625f, oy * 0.0625f);
+  float triad = tile.x / mask_triads_per_tile;
+  const float thresh = 1.0f / 256.0f;
+  return -0.05168f + 0.6113f * triad - 1.122f * triad * sqrtf(0.000416f + thresh);
+}
+/* get_fast_gaussian_weight_sum_inv (bloom-vertical.glsl 6624-6628), evaluated per fragment */
+static float center_weight(float sigma) {
+  return minps(o_exp(o_exp(0.348348412457428f / (sigma - 0.0860587260734721f))), 0.399334576340352f / sigma);
+}
+static const float mask_amplify = 1.0f / (46.0f / 255.0f); /* mask_type 1: 1/mask_slot_avg_color */
+
+/* brightpass.glsl FS 14610-14663; extra[0] = PassPrev4Texture */
+void o_pass_royale_brightpass(const o_pass_args* a) {
+  ENTER;
+  const int W = a->out_w, H = a->out_h;
+  const float tsx = (float)a->in->w, tsy = (float)a->in->h;
+  float qiw, qih, qtw, qth;
+  prev_pass_sizes(a, 4, &qiw, &qih, &qtw, &qth);
+  const float vu1 = (1.0f * tsx) / tsx, vv1 = (1.0f * tsy) / tsy, vu0 = (0.0f * tsx) / tsx, vv0 = (0.0f * tsy) / tsy;
+  o_varying p_su = plane_u(vu0 * tsx / tsx, vu1 * tsx / tsx, W, H, a->out_fmt), p_sv = plane_v(vv0 * tsy / tsy, vv1 * tsy / tsy, W, H, a->out_fmt);
+  o_varying p_bu = plane_u(vu0 * qiw / qtw, vu1 * qiw / qtw, W, H, a->out_fmt), p_bv = plane_v(vv0 * qih / qth, vv1 * qih / qth, W, H, a->out_fmt);
+  const float sigma = bloom_sigma_runtime((float)W, (float)H);
+  const float undim = 1.0f / 0.5f;
+  const float under = 0.8f; /* bloom_underestimate_levels */
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      o_vec4 idim = o_sample(a->in, o_varying_at(&p_su, x, y, lo), o_varying_at(&p_sv, x, y, lo));
+      o_vec4 blur = o_sample(a->extra[0], o_varying_at(&p_bu, x, y, lo), o_varying_at(&p_bv, x, y, lo));
+      const float cw = center_weight(sigma);
+      float in3[3] = {idim.x, idim.y, idim.z}, bl3[3] = {blur.x, blur.y, blur.z}, out[3];
+      for (int c = 0; c < 3; ++c) {
+        float intensity = in3[c] * undim * mask_amplify * 1.0f;
+        float pba = 1.0f * bl3[c];
+        float max_area = maxps(pba - cw * intensity, 0.0f);
+        float area_under = under * max_area;
+        float int_under = under * intensity;
+        float ratio_temp = ((1.0f - area_under) / int_under - 1.0f) / (cw - 1.0f);
+        float ratio = clampf(ratio_temp, 0.0f, 1.0f);
+        out[c] = in3[c] * ratio; /* lerp(blur_ratio, 1, bloom_excess = 0) = blur_ratio */
+      }
+      o_vec4 o = {out[0], out[1], out[2], 1.0f};
+      o_store_pixel(a, x, y, o);
+    }
+  LEAVE;
+}
+
+/* tex2Dblur17fast (bloom-vertical.glsl 7132-7176) with a run-time sigma */
+typedef struct { float w0, w12, w34, w56, w78, k12, k34, k56, k78, sum_inv; } blur17_w;
+static blur17_w blur17_weights(float sigma) {
+  blur17_w b;
+  float denom_inv = 0.5f / (sigma * sigma);
+  float w1 = o_exp(-1.0f * denom_inv), w2 = o_exp(-4.0f * denom_inv), w3 = o_exp(-9.0f * denom_inv);
+  float w4 = o_exp(-16.0f * denom_inv), w5 = o_exp(-25.0f * denom_inv), w6 = o_exp(-36.0f * denom_inv);
+  float w7 = o_exp(-49.0f * denom_inv), w8 = o_exp(-64.0f * denom_inv);
+  b.w0 = 1.0f;
+  b.sum_inv = center_weight(sigma);
+  b.w12 = w1 + w2; b.w34 = w3 + w4; b.w56 = w5 + w6; b.w78 = w7 + w8;
+  b.k12 = 1.0f + w2 / b.w12; b.k34 = 3.0f + w4 / b.w34; b.k56 = 5.0f + w6 / b.w56; b.k78 = 7.0f + w8 / b.w78;
+  return b;
+}
+static v3 blur17(const o_tex* t, float u, float v, float dx, float dy, const blur17_w* b) {
+  const float ks[9] = {-b->k78, -b->k56, -b->k34, -b->k12, 0.0f, b->k12, b->k34, b->k56, b->k78};
+  const float ws[9] = {b->w78, b->w56, b->w34, b->w12, b->w0, b->w12, b->w34, b->w56, b->w78};
+  v3 sum = {0.f, 0.f, 0.f};
+  for (int i = 0; i < 9; ++i) {
+    o_vec4 s;
+    if (i < 4) s = o_sample(t, u - (-ks[i]) * dx, v - (-ks[i]) * dy);
+    else if (i == 4) s = o_sample(t, u, v);
+    else s = o_sample(t, u + ks[i] * dx, v + ks[i] * dy);
+    sum.x += ws[i] * s.x; sum.y += ws[i] * s.y; sum.z += ws[i] * s.z;
+  }
+  v3 r = {sum.x * b->sum_inv, sum.y * b->sum_inv, sum.z * b->sum_inv};
+  return r;
+}
+
+/* bloom-vertical.glsl: VS 3851-3861, FS 8605-8613 */
+void o_pass_royale_bloom_v(const o_pass_args* a) {
+  ENTER;
+  const int W = a->out_w, H = a->out_h;
+  const float tsx = (float)a->in->w, tsy = (float)a->in->h;
+  uvplanes tc = texcoord_planes(1.0001f, W, H, a->out_fmt);
+  const float dy = (tsy / (float)H) / tsy;
+  (void)tsx;
+  const float sigma = bloom_sigma_runtime((float)W, (float)H);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      blur17_w b = blur17_weights(sigma);
+      v3 c = blur17(a->in, o_varying_at(&tc.u, x, y, lo), o_varying_at(&tc.v, x, y, lo), 0.0f, dy, &b);
+      o_vec4 o = {c.x, c.y, c.z, 1.0f};
+      o_store_pixel(a, x, y, o);
+    }
+  LEAVE;
+}
+
+/* bloom-horizontal-reconstitute.glsl: VS 6641-6660, FS 11407-11439.
+ * extra[0] = PassPrev3Texture (MASKED_SCANLINES), extra[1] = PassPrev2Texture (BRIGHTPASS),
+ * extra[2] = PassPrev6Texture (HALATION_BLUR). */
+void o_pass_royale_bloom_h(const o_pass_args* a) {
+  ENTER;
+  const int W = a->out_w, H = a->out_h;
+  const float tsx = (float)a->in->w, tsy = (float)a->in->h;
+  float m_iw, m_ih, m_tw, m_th, b_iw, b_ih, b_tw, b_th, h_iw, h_ih, h_tw, h_th;
+  prev_pass_sizes(a, 3, &m_iw, &m_ih, &m_tw, &m_th);
+  prev_pass_sizes(a, 2, &b_iw, &b_ih, &b_tw, &b_th);
+  prev_pass_sizes(a, 6, &h_iw, &h_ih, &h_tw, &h_th);
+  const float vu1 = (1.0f * tsx) / tsx, vv1 = (1.0f * tsy) / tsy, vu0 = (0.0f * tsx) / tsx, vv0 = (0.0f * tsy) / tsy;
+  o_varying p_mu = plane_u(vu0 * m_iw / m_tw, vu1 * m_iw / m_tw, W, H, a->out_fmt), p_mv = plane_v(vv0 * m_ih / m_th, vv1 * m_ih / m_th, W, H, a->out_fmt);
+  o_varying p_hu = plane_u(vu0 * h_iw / h_tw, vu1 * h_iw / h_tw, W, H, a->out_fmt), p_hv = plane_v(vv0 * h_ih / h_th, vv1 * h_ih / h_th, W, H, a->out_fmt);
+  o_varying p_bu = plane_u(vu0 * b_iw / b_tw, vu1 * b_iw / b_tw, W, H, a->out_fmt), p_bv = plane_v(vv0 * b_ih / b_th, vv1 * b_ih / b_th, W, H, a->out_fmt);
+  uvplanes tc = texcoord_planes(1.0f, W, H, a->out_fmt);
+  const float dx = 1.0f / tsx;
+  const float sigma = bloom_sigma_runtime((float)W, (float)H);
+  const float undim = 1.0f / 0.5f;
+  const float diffusion = 0.075f;
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      blur17_w b = blur17_weights(sigma);
+      v3 blurred = blur17(a->in, o_varying_at(&tc.u, x, y, lo), o_varying_at(&tc.v, x, y, lo), dx, 0.0f, &b);
+      o_vec4 idim = o_sample(a->extra[0], o_varying_at(&p_mu, x, y, lo), o_varying_at(&p_mv, x, y, lo));
+      o_vec4 bright = o_sample(a->extra[1], o_varying_at(&p_bu, x, y, lo), o_varying_at(&p_bv, x, y, lo));
+      o_vec4 hal = o_sample(a->extra[2], o_varying_at(&p_hu, x, y, lo), o_varying_at(&p_hv, x, y, lo));
+      float i3[3] = {idim.x, idim.y, idim.z}, b3[3] = {bright.x, bright.y, bright.z}, bl[3] = {blurred.x, blurred.y, blurred.z};
+      float h3[3] = {hal.x, hal.y, hal.z}, out[3];
+      for (int c = 0; c < 3; ++c) {
+        float dimpass = i3[c] - b3[c];
+        float phosphor_bloom = (dimpass + bl[c]) * mask_amplify * undim * 1.0f;
+        float diffusion_color = 1.0f * h3[c];
+        out[c] = phosphor_bloom * (1.0f - diffusion) + diffusion_color * diffusion; /* lerp, constant t */
+      }
+      o_vec4 o = {out[0], out[1], out[2], 1.0f};
+      o_store_pixel(a, x, y, o);
+    }
+  LEAVE;
+}
+
+/* ========================================================================== P11 ====== */
+/* geometry-aa-last-pass.glsl: VS 5337-5400, FS 5451-5531, get_border_dim_factor 5250-5261,
+ * get_aspect_vector 2512-2520.  LAST_PASS + SIMULATE_CRT_ON_LCD: output gamma = lcd_gamma.
+ * params: the file's 44 #pragma parameters in declaration order (lines 21-64).
+ * Only the flat path (geom_mode_runtime <= 0.5 and overscan == 1) is restated. */
+enum { RP_LCD_GAMMA = 1, RP_GEOM_MODE = 30, RP_OVERSCAN_X = 37, RP_OVERSCAN_Y = 38, RP_BORDER_SIZE = 39,
+       RP_BORDER_DARKNESS = 40, RP_BORDER_COMPRESS = 41 };
+
+void o_pass_royale_last(const o_pass_args* a) {
+  ENTER;
+  const int W = a->out_w, H = a->out_h;
+  const float tsx = (float)a->in->w, tsy = (float)a->in->h; /* texture_size == video_size */
+  const float* P = a->params;
+  const float lcd_gamma = P[RP_LCD_GAMMA], osx = P[RP_OVERSCAN_X], osy = P[RP_OVERSCAN_Y];
+  const float border_size = P[RP_BORDER_SIZE], border_darkness = P[RP_BORDER_DARKNESS], border_compress = P[RP_BORDER_COMPRESS];
+  /* VS */
+  const float vsix = 1.0f / tsx, vsiy = 1.0f / tsy, tsix = 1.0f / tsx, tsiy = 1.0f / tsy;
+  const float ar = (float)W / (float)H;
+  const float gx = minps(ar, 4.0f / 3.0f), gy = 1.0f;
+  const float rs = 1.0f / sqrtf(gx * gx + gy * gy);
+  const float geom_aspect_x = gx * rs, geom_aspect_y = gy * rs;
+  /* This pass's vertex shader emits eye_pos_local, which is NaN in the flat geometry mode;
+   * llvmpipe only takes its single-plane rectangle path when every varying is consistent
+   * across the quad, so this pass is rasterised as two triangles even on an RGBA8 target
+   * (measured: per-pixel intermediates differ across the BL-TR diagonal). */
+  uvplanes tc = texcoord_planes(1.0f, W, H, O_FMT_SRGB8 /* = two-triangle planes */);
+  const float inv_gamma = 1.0f / lcd_gamma;
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      float u = o_varying_at(&tc.u, x, y, lo), v = o_varying_at(&tc.v, x, y, lo);
+      float fu = u * (tsx * vsix), fv = v * (tsy * vsiy);          /* flat_video_uv */
+      float vu = (fu - 0.5f) / osx + 0.5f, vv = (fv - 0.5f) / osy + 0.5f; /* video_uv */
+      float tu = vu * (tsx * tsix), tv = vv * (tsy * tsiy);
+      o_vec4 c = o_sample(a->in, tu, tv);
+      /* get_border_dim_factor */
+      float ex = minps(vu, 1.0f - vu) * geom_aspect_x, ey = minps(vv, 1.0f - vv) * geom_aspect_y;
+      float bx = maxps(border_size - ex, 0.0f), by = maxps(border_size - ey, 0.0f);
+      float pen = sqrtf(bx * bx + by * by) / border_size;
+      float esc = maxps(1.0f - pen, 0.0f);
+      float f = minps(o_pow(esc, border_darkness) * maxps(1.0f, border_compress), 1.0f);
+      o_vec4 o = {o_pow(c.x * f, inv_gamma), o_pow(c.y * f, inv_gamma), o_pow(c.z * f, inv_gamma), 1.0f};
+      o_store_pixel(a, x, y, o);
+    }
+  LEAVE;
+}

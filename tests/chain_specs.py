@@ -11,7 +11,108 @@ PRESETS = {
                'wrap_mode0 = "clamp_to_border"\nmipmap_input0 = "false"\nalias0 = ""\n'
                'float_framebuffer0 = "false"\nsrgb_framebuffer0 = "false"\n'),
     "stock": ("stock.glslp", 'shaders = "1"\nshader0 = "stock.glsl"\nfilter_linear0 = "false"\n'),
+    # Same keys / values as the reference's crt/crt-royale.glslp for the 12 passes, including the
+    # three `"true" # comment` booleans that its parser reads as false; only the LUT that the
+    # default (slot mask) path samples is declared.
+    "crt-royale": ("crt/crt-royale.glslp", """shaders = "12"
+textures = "mask_slot_texture_small"
+mask_slot_texture_small = "shaders/crt-royale/mask_slot_small_64.png"
+mask_slot_texture_small_wrap_mode = "repeat"
+mask_slot_texture_small_linear = "true"
+mask_slot_texture_small_mipmap = "false"  # trailing comments make this parse as false anyway
+shader0 = "shaders/crt-royale/src/crt-royale-first-pass-linearize-crt-gamma-bob-fields.glsl"
+alias0 = "ORIG_LINEARIZED"
+filter_linear0 = "false"
+scale_type0 = "source"
+scale0 = "1.0"
+srgb_framebuffer0 = "true"
+shader1 = "shaders/crt-royale/src/crt-royale-scanlines-vertical-interlacing.glsl"
+alias1 = "VERTICAL_SCANLINES"
+filter_linear1 = "true"
+scale_type_x1 = "source"
+scale_x1 = "1.0"
+scale_type_y1 = "viewport"
+scale_y1 = "1.0"
+srgb_framebuffer1 = "true"
+shader2 = "shaders/crt-royale/src/crt-royale-bloom-approx.glsl"
+alias2 = "BLOOM_APPROX"
+filter_linear2 = "true"
+scale_type2 = "absolute"
+scale_x2 = "320"
+scale_y2 = "240"
+srgb_framebuffer2 = "true"
+shader3 = "../blurs/blur9fast-vertical.glsl"
+filter_linear3 = "true"
+scale_type3 = "source"
+scale3 = "1.0"
+srgb_framebuffer3 = "true"
+shader4 = "../blurs/blur9fast-horizontal.glsl"
+alias4 = "HALATION_BLUR"
+filter_linear4 = "true"
+scale_type4 = "source"
+scale4 = "1.0"
+srgb_framebuffer4 = "true"
+shader5 = "shaders/crt-royale/src/crt-royale-mask-resize-vertical.glsl"
+filter_linear5 = "true"
+scale_type_x5 = "absolute"
+scale_x5 = "64"
+scale_type_y5 = "viewport"
+scale_y5 = "0.0625" # viewport fraction
+shader6 = "shaders/crt-royale/src/crt-royale-mask-resize-horizontal.glsl"
+alias6 = "MASK_RESIZE"
+filter_linear6 = "false"
+scale_type_x6 = "viewport"
+scale_x6 = "0.0625"
+scale_type_y6 = "source"
+scale_y6 = "1.0"
+shader7 = "shaders/crt-royale/src/crt-royale-scanlines-horizontal-apply-mask.glsl"
+alias7 = "MASKED_SCANLINES"
+filter_linear7 = "true" # parsed as false
+scale_type7 = "viewport"
+scale7 = "1.0"
+srgb_framebuffer7 = "true"
+shader8 = "shaders/crt-royale/src/crt-royale-brightpass.glsl"
+alias8 = "BRIGHTPASS"
+filter_linear8 = "true" # parsed as false
+scale_type8 = "viewport"
+scale8 = "1.0"
+srgb_framebuffer8 = "true"
+shader9 = "shaders/crt-royale/src/crt-royale-bloom-vertical.glsl"
+filter_linear9 = "true" # parsed as false
+scale_type9 = "source"
+scale9 = "1.0"
+srgb_framebuffer9 = "true"
+shader10 = "shaders/crt-royale/src/crt-royale-bloom-horizontal-reconstitute.glsl"
+filter_linear10 = "true"
+scale_type10 = "source"
+scale10 = "1.0"
+srgb_framebuffer10 = "true"
+shader11 = "shaders/crt-royale/src/crt-royale-geometry-aa-last-pass.glsl"
+filter_linear11 = "true"
+scale_type11 = "viewport"
+mipmap_input11 = "false"
+texture_wrap_mode11 = "clamp_to_edge"
+"""),
 }
+
+# files copied next to a preset: name -> (preset key, relative path below the preset dir, source under tests/golden)
+ASSETS = {"mask_slot_small_64.png": ("crt-royale", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png")}
+
+ROYALE_LAST_PARAMS = [
+    ("crt_gamma", 2.5), ("lcd_gamma", 2.2), ("levels_contrast", 1.0), ("halation_weight", 0.0),
+    ("diffusion_weight", 0.075), ("bloom_underestimate_levels", 0.8), ("bloom_excess", 0.0), ("beam_min_sigma", 0.02),
+    ("beam_max_sigma", 0.3), ("beam_spot_power", 0.33), ("beam_min_shape", 2.0), ("beam_max_shape", 4.0),
+    ("beam_shape_power", 0.25), ("beam_horiz_filter", 0.0), ("beam_horiz_sigma", 0.35),
+    ("beam_horiz_linear_rgb_weight", 1.0), ("convergence_offset_x_r", 0.0), ("convergence_offset_x_g", 0.0),
+    ("convergence_offset_x_b", 0.0), ("convergence_offset_y_r", 0.0), ("convergence_offset_y_g", 0.0),
+    ("convergence_offset_y_b", 0.0), ("mask_type", 1.0), ("mask_sample_mode_desired", 0.0),
+    ("mask_specify_num_triads", 0.0), ("mask_triad_size_desired", 3.0), ("mask_num_triads_desired", 480.0),
+    ("aa_subpixel_r_offset_y_runtime", 0.0), ("aa_cubic_c", 0.5), ("aa_gauss_sigma", 0.5), ("geom_mode_runtime", 0.0),
+    ("geom_radius", 2.0), ("geom_view_dist", 2.0), ("geom_tilt_angle_x", 0.0), ("geom_tilt_angle_y", 0.0),
+    ("geom_aspect_ratio_x", 432.0), ("geom_aspect_ratio_y", 329.0), ("geom_overscan_x", 1.0), ("geom_overscan_y", 1.0),
+    ("border_size", 0.015), ("border_darkness", 2.0), ("border_compress", 2.5), ("interlace_bff", 0.0),
+    ("interlace_1080i", 0.0)]
+_R = "crt/shaders/crt-royale/src/crt-royale-"
 
 # shader identity -> oracle pass function, parameter order (name, default), extra samplers
 SHADERS = {
@@ -26,6 +127,20 @@ SHADERS = {
         "params": [("CURVATURE_X", 0.10), ("CURVATURE_Y", 0.15), ("MASK_BRIGHTNESS", 0.70), ("SCANLINE_WEIGHT", 6.0),
                    ("SCANLINE_GAP_BRIGHTNESS", 0.12), ("BLOOM_FACTOR", 1.5), ("INPUT_GAMMA", 2.4), ("OUTPUT_GAMMA", 2.2)],
         "samplers": []},
+    _R + "first-pass-linearize-crt-gamma-bob-fields.glsl": {"oracle": "royale_first", "params": [], "samplers": []},
+    _R + "scanlines-vertical-interlacing.glsl": {"oracle": "royale_scan_v", "params": [], "samplers": []},
+    _R + "bloom-approx.glsl": {"oracle": "royale_bloom_approx", "params": [], "samplers": ["PassPrev2Texture"]},
+    "blurs/blur9fast-vertical.glsl": {"oracle": "blur9_v", "params": [], "samplers": []},
+    "blurs/blur9fast-horizontal.glsl": {"oracle": "blur9_h", "params": [], "samplers": []},
+    _R + "mask-resize-vertical.glsl": {"oracle": "royale_mask_v", "params": [], "samplers": ["mask_slot_texture_small"]},
+    _R + "mask-resize-horizontal.glsl": {"oracle": "royale_mask_h", "params": [], "samplers": []},
+    _R + "scanlines-horizontal-apply-mask.glsl": {"oracle": "royale_scan_h", "params": [],
+                                                   "samplers": ["PassPrev6Texture", "PassPrev3Texture"]},
+    _R + "brightpass.glsl": {"oracle": "royale_brightpass", "params": [], "samplers": ["PassPrev4Texture"]},
+    _R + "bloom-vertical.glsl": {"oracle": "royale_bloom_v", "params": [], "samplers": []},
+    _R + "bloom-horizontal-reconstitute.glsl": {"oracle": "royale_bloom_h", "params": [],
+                                                 "samplers": ["PassPrev3Texture", "PassPrev2Texture", "PassPrev6Texture"]},
+    _R + "geometry-aa-last-pass.glsl": {"oracle": "royale_last", "params": ROYALE_LAST_PARAMS, "samplers": []},
 }
 
 
@@ -37,6 +152,12 @@ def write_tree(root):
         with open(p, "w") as f:
             f.write(text)
         out[name] = p
+    import shutil
+    here = os.path.dirname(os.path.abspath(__file__))
+    for _, (key, rel, src) in ASSETS.items():
+        dst = os.path.join(os.path.dirname(out[key]), rel)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        shutil.copy(os.path.join(here, "golden", src), dst)
     return out
 
 

@@ -132,7 +132,34 @@ def case_crt_royale():
         run_case("crt_royale_128x96_to_400x300", GLSL + "/crt/crt-royale.glslp", noise(128, 96, 6), 400, 300, luts=luts)
 
 
-CASES = {"scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale}
+def case_crt_royale_mask_active():
+    """crt-royale as a GL driver that returns 0 for an unwritten varying would render it.
+    Pass 6's fragment shader tests `max(tile_uv_wrap.x, tile_uv_wrap.y) <= mask_resize_num_tiles`
+    on a varying its vertex shader never writes (the VS shadows it with a local).  Mesa llvmpipe
+    discards every fragment there; drivers that read 0 keep them all.  To produce vectors for
+    that second behaviour the pass-6 file is copied to a temp dir with that one test replaced by
+    the constant it would see (0.0); nothing of the copy is kept."""
+    import shutil
+    with tempfile.TemporaryDirectory() as d:
+        dst = os.path.join(d, "shaders_glsl")
+        os.makedirs(os.path.join(dst, "crt", "shaders"))
+        shutil.copytree(GLSL + "/crt/shaders/crt-royale", dst + "/crt/shaders/crt-royale")
+        shutil.copytree(GLSL + "/blurs", dst + "/blurs")
+        shutil.copy(GLSL + "/crt/crt-royale.glslp", dst + "/crt/crt-royale.glslp")
+        f = dst + "/crt/shaders/crt-royale/src/crt-royale-mask-resize-horizontal.glsl"
+        txt = open(f).read()
+        needle = "max(tile_uv_wrap.x, tile_uv_wrap.y) <= mask_resize_num_tiles"
+        assert txt.count(needle) == 1
+        open(f, "w").write(txt.replace(needle, "0.0 <= mask_resize_num_tiles"))
+        luts = royale_luts(d)
+        run_case("crt_royale_maskon_160x120_to_320x240", dst + "/crt/crt-royale.glslp", mixed(160, 120, 5), 320, 240,
+                 luts=luts)
+        run_case("crt_royale_maskon_96x128_to_512x384", dst + "/crt/crt-royale.glslp", noise(96, 128, 7), 512, 384,
+                 luts=luts)
+
+
+CASES = {"scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+         "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":
     for c in (sys.argv[1:] or list(CASES)):

@@ -46,9 +46,12 @@ def pass_sizes(passes, w, h, vw, vh):
     return out
 
 
-def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global_params=None):
+def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global_params=None, flags=0,
+              given=None):
     """passes: list of dicts as produced by the preset dump (shader, filter_linear, wrap,
     alias, float_fb, srgb_fb, stx, sx, sty, sy).  rgb: (h, w, 3) uint8 source frame.
+    luts: name -> (rgba array, linear, wrap).  given: optional list of per-pass arrays to feed forward
+    instead of the oracle's own outputs (isolates each pass when checking against golden data).
     Returns the list of per-pass outputs."""
     h, w, _ = rgb.shape
     src = np.concatenate([rgb, np.full((h, w, 1), 255, np.uint8)], -1)
@@ -58,7 +61,7 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
 
     def tex_of_pass(k):
         nxt = passes[k + 1] if k + 1 < len(passes) else {"filter_linear": True, "wrap": "clamp_to_edge"}
-        return Tex(outs[k], fmts[k], nxt["filter_linear"], nxt["wrap"])
+        return Tex(given[k] if given is not None else outs[k], fmts[k], nxt["filter_linear"], nxt["wrap"])
 
     source_tex = Tex(src, "rgbx8", passes[0]["filter_linear"], passes[0]["wrap"])
     cur = source_tex
@@ -90,7 +93,7 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
             params.append(v)
         ow, oh = sizes[i]
         o = run_pass(spec["oracle"], cur, ow, oh, out_fmt=fmts[i], params=params, frame_count=frame_count,
-                     extra=extra, src_w=w, src_h=h)
+                     extra=extra, src_w=w, src_h=h, chain=sizes, pass_index=i, vp=(vw, vh), flags=flags)
         outs.append(o)
         cur = tex_of_pass(i)
     return outs

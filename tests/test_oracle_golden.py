@@ -17,10 +17,23 @@ CASES = {
     "scanline_64x48_to_160x100": "scanline",
     "crt_pi_96x64_to_192x128": "crt-pi",
     "crt_pi_80x60_to_250x190": "crt-pi",
+    "crt_royale_160x120_to_320x240": "crt-royale",
+    "crt_royale_128x96_to_400x300": "crt-royale",
+    # the same preset as a GL that reads 0 from pass 6's unwritten varying renders it
+    "crt_royale_maskon_160x120_to_320x240": "crt-royale",
+    "crt_royale_maskon_96x128_to_512x384": "crt-royale",
 }
 
 # exact-match floor per preset (fraction of bytes identical to llvmpipe) and max |diff|
-BAR = {"scanline": (1.0, 0), "crt-pi": (1.0, 0)}
+# crt-royale: every pass that stores to an sRGB8 target can differ from llvmpipe by 1 LSB in
+# ~0.3 % of the bytes, because llvmpipe's sRGB encode runs through the x86 RSQRTPS
+# approximation and is not monotone ("sRGB8 store"); RGBA8 passes must be exact.
+BAR = {"scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1)}
+
+
+def royale_luts():
+    lut = np.load(os.path.join(GOLD, "lut_mask_slot_small_64.npy"))
+    return {"mask_slot_texture_small": (lut, True, "repeat")}
 
 
 def preset_passes(tmp_path, key):
@@ -36,7 +49,12 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
     key = CASES[case]
     passes = preset_passes(tmp_path, key)
     vw, vh = [int(v) for v in g["viewport"]]
-    outs = run_chain(passes, g["input_rgb"], vw, vh, frame_count=int(g["frames"]))
+    flags = 1 if "maskon" in case else 0
+    luts = royale_luts() if key == "crt-royale" else None
+    golden = [g["pass%d" % i] for i in range(int(g["n_passes"]))]
+    # every pass fed with the GOLDEN outputs of the passes before it (isolates each pass) ...
+    outs = run_chain(passes, g["input_rgb"], vw, vh, frame_count=int(g["frames"]), luts=luts, flags=flags,
+                     given=golden)
     assert len(outs) == int(g["n_passes"])
     floor, maxdiff = BAR[key]
     for i, o in enumerate(outs):
@@ -45,9 +63,23 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
         if ref.dtype == np.uint8:
             d = np.abs(o.astype(np.int32) - ref.astype(np.int32))
             exact = float((d == 0).mean())
+            fmt = str(g["pass%d_fmt" % i])
+            if fmt == "rgba8":
+                assert d.max() == 0, "RGBA8 pass %d must be bit-exact: exact %.5f max %d" % (i, exact, d.max())
             assert d.max() <= maxdiff and exact >= floor, "pass %d: exact %.5f max %d" % (i, exact, d.max())
         else:
             assert np.array_equal(o.view(np.uint32), ref.view(np.uint32)) or np.allclose(o, ref, rtol=1e-6, atol=1e-7)
+    # ... and the whole chain end to end on the oracle's own intermediates
+    if key == "crt-royale":
+        own = run_chain(passes, g["input_rgb"], vw, vh, frame_count=int(g["frames"]), luts=luts, flags=flags)
+        d = np.abs(own[-1].astype(np.int32) - golden[-1].astype(np.int32))
+        exact = float((d == 0).mean())
+        # With the mask active, pass 8's brightpass ratio is discontinuous in its inputs, so a 1-LSB
+        # sRGB-encode difference upstream can flip isolated output pixels by a large amount; only the
+        # match rate is bounded there.  In the default mode the chain is smooth: max 2 LSB.
+        assert exact >= 0.97, "end to end: exact %.5f max %d" % (exact, d.max())
+        if not flags:
+            assert d.max() <= 2, "end to end: exact %.5f max %d" % (exact, d.max())
 
 
 def test_every_golden_file_has_a_case():
