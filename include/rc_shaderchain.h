@@ -138,6 +138,13 @@ void rc_engine_set_chunk_frames(rc_engine* e, uint32_t n);
  * (built-in parameter table).  Default 0 = the reference's behaviour (pass fails). */
 void rc_engine_set_allow_missing_sources(rc_engine* e, int allow);
 
+/* crt-royale's pass 6 (mask-resize-horizontal.glsl FS ~3377) tests a varying that its vertex
+ * shader never writes (VS 3288-3328 shadows it with a local).  0 (default): every fragment of
+ * that pass is discarded, which is what Mesa llvmpipe - the GL the parity vectors come from -
+ * does; 1: the varying reads 0, as GL drivers that zero undefined varyings behave, and the
+ * resized phosphor mask is rendered. */
+void rc_engine_set_undefined_varying_zero(rc_engine* e, int zero);
+
 const char* rc_last_error(void);
 const char* rc_version(void);
 /* Names of the registered kernels ("identity\n" list) for diagnostics. */

@@ -1,5 +1,6 @@
 #include "kernel_registry.h"
 
+#include "royale_setup.h"
 #include "varying.h"
 
 namespace rc {
@@ -35,6 +36,7 @@ std::vector<KernelEntry> build() {
                 {"INPUT_GAMMA", 2.4f, 0.0f, 5.0f, 0.01f, "Input gamma"},
                 {"OUTPUT_GAMMA", 2.2f, 0.0f, 5.0f, 0.01f, "Output gamma"}},
                {}, rck::launch_crt_pi, setupCrtPi, false});
+  registerRoyaleKernels(r);
   return r;
 }
 

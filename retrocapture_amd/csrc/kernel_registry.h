@@ -22,6 +22,8 @@ struct PassGeometry {  // what a kernel's setup hook may look at
   int out_w, out_h, out_fmt;
   int src_w, src_h;  // OriginalSize
   int vp_w, vp_h;
+  int n_passes;                 // output size of every pass of the chain (PassPrev<N> sizes)
+  int chain_w[32], chain_h[32];
 };
 
 struct KernelParam {

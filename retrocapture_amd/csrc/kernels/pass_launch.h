@@ -12,6 +12,17 @@ typedef hipError_t (*LaunchFn)(const PassLaunch& L, hipStream_t stream);
 hipError_t launch_stock(const PassLaunch& L, hipStream_t s);
 hipError_t launch_scanline(const PassLaunch& L, hipStream_t s);
 hipError_t launch_crt_pi(const PassLaunch& L, hipStream_t s);
+hipError_t launch_royale_first(const PassLaunch& L, hipStream_t s);
+hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s);
+hipError_t launch_royale_bloom_approx(const PassLaunch& L, hipStream_t s);
+hipError_t launch_blur9(const PassLaunch& L, hipStream_t s);
+hipError_t launch_royale_mask_v(const PassLaunch& L, hipStream_t s);
+hipError_t launch_royale_mask_h(const PassLaunch& L, hipStream_t s);
+hipError_t launch_royale_scan_h(const PassLaunch& L, hipStream_t s);
+hipError_t launch_royale_brightpass(const PassLaunch& L, hipStream_t s);
+hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s);
+hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s);
+hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s);
 
 // 64x4 pixel workgroups: one wave per target row segment, 4 rows per group, so each wave
 // stores 256 contiguous bytes of an RGBA8 row.

@@ -1,0 +1,456 @@
+// Pass kernels for the crt-royale preset (reference shaders/shaders_glsl/crt/crt-royale.glslp):
+// GLSL files crt/shaders/crt-royale/src/crt-royale-*.glsl and blurs/blur9fast-{vertical,
+// horizontal}.glsl.  Passes 0-10 carry no #pragma parameter, so the reference compiles them
+// without PARAMETER_UNIFORM and they run on the static user-settings constants (first-pass file
+// lines 104-473); pass 11 takes its 44 parameters from PassLaunch::params.
+//
+// Everything a vertex shader derives from uniforms alone (tile sizes, blur sigma and weights,
+// uv scales) is computed once per launch on the host (royale_setup.cpp) with the same float
+// operations and handed over in PassLaunch::params / planes; the kernels do the per-pixel part.
+// One thread per target pixel, 64x4 workgroups, blockIdx.z = frame.
+#include "pass_launch.h"
+#include "royale_params.h"
+
+using namespace rcd;
+
+namespace {
+
+__device__ __forceinline__ float minps(float a, float b) { return a < b ? a : b; }  // NaN -> b
+__device__ __forceinline__ float maxps(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return minps(maxps(x, lo), hi); }
+__device__ __forceinline__ float fractf(float x) { return x - __builtin_floorf(x); }
+__device__ __forceinline__ float mod_glsl(float x, float y) { return x - y * __builtin_floorf(x / y); }
+__device__ __forceinline__ float mix_rt(float a, float b, float t) { return a + t * (b - a); }
+
+#define RC_PIXEL_PROLOGUE                                                                   \
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, z = blockIdx.z; \
+  const bool inside = x < L.out_w && y < L.out_h;                                             \
+  const bool lo = lower_tri(x, y, L.out_w, L.out_h)
+
+constexpr float kUnderHalf = 0.4995f;
+
+// ------------------------------------------------------------------------------- P0 ------
+// first-pass-linearize-crt-gamma-bob-fields.glsl FS 4850-4884.  The source texel is a byte per
+// channel, so pow(texel, crt_gamma = 2.5) takes 256 values: tabulated once per workgroup.
+__global__ void __launch_bounds__(256) k_royale_first(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  __shared__ float lin[256];
+  load_srgb_tables(lds);
+  {
+    const int t = threadIdx.y * 64 + threadIdx.x;
+    lin[t] = pow_((float)t * (1.0f / 255.0f), 2.5f);
+  }
+  __syncthreads();
+  RC_PIXEL_PROLOGUE;
+  if (!inside) return;
+  const float tsy = (float)L.in.h;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const uint8_t* img = frame_ptr(L.in, z);
+  const float interlaced = L.params[RP0_INTERLACED];
+  // tex2D_linearize on the byte texels: decode == table lookup of the stored byte
+  auto tap = [&](float tv) -> float4 {
+    // the generic sampler returns byte/255 for RGBX8/RGBA8 nearest taps; recover the byte
+    float4 c = sample_rt(L.in, img, u, tv, &lds);
+    if (L.in.fmt == FMT_RGBX8 || L.in.fmt == FMT_RGBA8) {
+      if (!L.in.linear || true) {
+        // values are k/255 only for nearest or fixed-point linear filtering (both quantised)
+        int r = (int)__builtin_rintf(c.x * 255.0f), g = (int)__builtin_rintf(c.y * 255.0f), b = (int)__builtin_rintf(c.z * 255.0f);
+        if ((float)r * (1.0f / 255.0f) == c.x && (float)g * (1.0f / 255.0f) == c.y && (float)b * (1.0f / 255.0f) == c.z)
+          return make_float4(lin[r], lin[g], lin[b], c.w);
+      }
+    }
+    return make_float4(pow_(c.x, 2.5f), pow_(c.y, 2.5f), pow_(c.z, 2.5f), c.w);
+  };
+  const float4 cur = tap(v);
+  float4 o = make_float4(cur.x, cur.y, cur.z, 1.0f);
+  if (interlaced != 0.0f) {
+    const float uv_step_y = 1.0f / tsy;
+    const float4 last = tap(v - uv_step_y), next = tap(v + uv_step_y);
+    const float ix = 0.5f * (last.x + next.x), iy = 0.5f * (last.y + next.y), iz = 0.5f * (last.z + next.z);
+    const float modulus = interlaced + 1.0f;
+    const float field_offset = mod_glsl((float)(L.frame_count0 + z) + 0.0f, modulus);
+    const float line_num_last = __builtin_floorf(v * tsy - kUnderHalf);
+    const float wrong_field = mod_glsl(line_num_last + field_offset, modulus);
+    o = make_float4(mix_rt(cur.x, ix, wrong_field), mix_rt(cur.y, iy, wrong_field), mix_rt(cur.z, iz, wrong_field), 1.0f);
+  }
+  // progressive source: modulus 1 makes wrong_field exactly 0, and cur + 0*(interp - cur) == cur
+  store_rt(L, z, x, y, o, &lds);
+}
+
+// ------------------------------------------------------------------------------- P1 ------
+// scanlines-vertical-interlacing.glsl FS 5982-6141; beam functions 4775-4998; gamma_impl 3907.
+__device__ __forceinline__ float gamma_impl1(float s, float s_inv) {
+  const float g = 1.12906830989f, c0 = 0.8109119309638332633713423362694399653724431f;
+  const float c1 = 0.4808354605142681877121661197951496120000040f, e = 2.71828182845904523536028747135266249775724709f;
+  const float sph = s + 0.5f;
+  const float lanczos_sum = c0 + c1 / (s + 1.0f);
+  const float base = (sph + g) / e;
+  return (pow_(base, sph) * lanczos_sum) * s_inv;
+}
+
+struct BeamShape {  // per (scanline colour, channel): everything that does not depend on dist
+  float alpha_inv, beta, scale3;
+};
+__device__ __forceinline__ BeamShape beam_shape(float color, float sigma_range, float shape_range) {
+  const float lg = log2_(color);  // pow(color, p) = exp2(log2(color) * p) for both exponents
+  const float sigma = 0.02f + sigma_range * exp2_(lg * (1.0f / 3.0f));
+  const float alpha = 1.41421356237309504880f * sigma;  // sqrtf(2.0f)
+  const float beta = 2.0f + shape_range * exp2_(lg * (1.0f / 4.0f));
+  BeamShape b;
+  b.alpha_inv = 1.0f / alpha;
+  b.beta = beta;
+  const float beta_inv = 1.0f / beta;
+  const float scale = color * beta * 0.5f * b.alpha_inv / gamma_impl1(beta_inv, beta);
+  b.scale3 = scale / 3.0f;
+  return b;
+}
+__device__ __forceinline__ float beam_contrib(const BeamShape& b, float dist, float off) {
+  const float d2 = dist + off, d3 = __builtin_fabsf(dist - off);
+  const float w1 = exp_(-pow_(__builtin_fabsf(dist * b.alpha_inv), b.beta));
+  const float w2 = exp_(-pow_(__builtin_fabsf(d2 * b.alpha_inv), b.beta));
+  const float w3 = exp_(-pow_(__builtin_fabsf(d3 * b.alpha_inv), b.beta));
+  return b.scale3 * (w1 + w2 + w3);
+}
+
+__global__ void __launch_bounds__(256) k_royale_scan_v(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_PIXEL_PROLOGUE;
+  if (!inside) return;
+  const float tsx = (float)L.in.w, tsy = (float)L.in.h;
+  const float y_step = L.params[RP1_Y_STEP], uv_step_y = L.params[RP1_UV_STEP_Y], ph = L.params[RP1_PH];
+  const float tix = 1.0f / tsx, tiy = 1.0f / tsy;
+  const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  // get_last_scanline_uv
+  const float frame_count = (float)(L.frame_count0 + z);
+  const float field_offset = __builtin_floorf(y_step * 0.75f) * mod_glsl(frame_count + 0.0f, 2.0f);
+  const float ctx = u * tsx, cty = v * tsy;
+  const float ptx = __builtin_floorf(ctx - kUnderHalf), pty = __builtin_floorf(cty - kUnderHalf);
+  const float wrong_field = mod_glsl(pty + field_offset, y_step);
+  const float stx = (ptx - 0.0f) + 0.5f, sty = (pty - wrong_field) + 0.5f;
+  const float su = stx * tix, sv = sty * tiy;
+  const float dist = (cty - sty) / y_step;
+  const uint8_t* img = frame_ptr(L.in, z);
+  const float4 s2 = sample_rt(L.in, img, su, sv, &lds);
+  const float4 s3 = sample_rt(L.in, img, su + 0.0f, sv + uv_step_y, &lds);
+  const float dist_round = __builtin_rintf(dist);
+  const float off_x = mix_rt(-0.0f, 2.0f * 0.0f, dist_round);
+  const float off_y = mix_rt(-uv_step_y, 2.0f * uv_step_y, dist_round);
+  const float4 so = sample_rt(L.in, img, su + off_x, sv + off_y, &lds);
+  const float off = ph / 3.0f;
+  const float c2[3] = {s2.x, s2.y, s2.z}, c3[3] = {s3.x, s3.y, s3.z}, co[3] = {so.x, so.y, so.z};
+  const float conv_y[3] = {0.2f, 0.4f, 0.6f};
+  float out[3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const float d2 = dist - conv_y[ch];
+    const float k2 = beam_contrib(beam_shape(c2[ch], sigma_range, shape_range), d2, off);
+    // additive constants re-associated as the GL's compiler does: 1-(dist-c) -> (1+c)-dist, ...
+    const float k3 = beam_contrib(beam_shape(c3[ch], sigma_range, shape_range), __builtin_fabsf((1.0f + conv_y[ch]) - dist), off);
+    float inten = k2 + k3;
+    const float d14 = mix_rt(dist + (1.0f - conv_y[ch]), (2.0f + conv_y[ch]) - dist, dist_round);
+    inten += beam_contrib(beam_shape(co[ch], sigma_range, shape_range), d14, off);
+    out[ch] = inten * 0.5f;
+  }
+  store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+}
+
+// ------------------------------------------------------------------------------- P2 ------
+// bloom-approx.glsl FS 14053-14184: the only live statement samples extra[0] at tex_uv.
+__global__ void __launch_bounds__(256) k_royale_bloom_approx(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_PIXEL_PROLOGUE;
+  if (!inside) return;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  store_rt(L, z, x, y, sample_rt(L.extra[0], frame_ptr(L.extra[0], z), u, v, &lds), &lds);
+}
+
+// -------------------------------------------------------------------------- P3 / P4 ------
+// blurs/blur9fast-*.glsl: tex2Dblur9fast 1496-1524; weights are compile-time constants there,
+// folded by the host (royale_setup.cpp) the way the GL's compiler folds them.
+__global__ void __launch_bounds__(256) k_blur9(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_PIXEL_PROLOGUE;
+  if (!inside) return;
+  const float w12 = L.params[RPB_W12], w34 = L.params[RPB_W34], k12 = L.params[RPB_K12], k34 = L.params[RPB_K34];
+  const float sum_inv = L.params[RPB_SUM_INV], dx = L.params[RPB_DX], dy = L.params[RPB_DY];
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const uint8_t* img = frame_ptr(L.in, z);
+  const float4 s0 = sample_rt(L.in, img, u - k34 * dx, v - k34 * dy, &lds);
+  const float4 s1 = sample_rt(L.in, img, u - k12 * dx, v - k12 * dy, &lds);
+  const float4 s2 = sample_rt(L.in, img, u, v, &lds);
+  const float4 s3 = sample_rt(L.in, img, u + k12 * dx, v + k12 * dy, &lds);
+  const float4 s4 = sample_rt(L.in, img, u + k34 * dx, v + k34 * dy, &lds);
+  float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+  sx += w34 * s0.x; sy += w34 * s0.y; sz += w34 * s0.z;
+  sx += w12 * s1.x; sy += w12 * s1.y; sz += w12 * s1.z;
+  sx += 1.0f * s2.x; sy += 1.0f * s2.y; sz += 1.0f * s2.z;
+  sx += w12 * s3.x; sy += w12 * s3.y; sz += w12 * s3.z;
+  sx += w34 * s4.x; sy += w34 * s4.y; sz += w34 * s4.z;
+  store_rt(L, z, x, y, make_float4(sx * sum_inv, sy * sum_inv, sz * sum_inv, 1.0f), &lds);
+}
+
+// -------------------------------------------------------------------------- P5 / P6 ------
+// mask-resize-{vertical,horizontal}.glsl: 24-tap Lanczos-windowed sinc (phosphor-mask-resizing
+// functions 2624-2994, USE_SINGLE_STATIC_LOOP).
+template <bool VERTICAL>
+__device__ __forceinline__ float4 sinc_tiled(const Tex& t, const uint8_t* img, float fixed_coord, float r_coord, float r_size, float dr,
+                                            float magnification, float tile_size_uv_r, const SrgbLds* lds) {
+  const float pi = 3.141592653589f, pi_over_lobes = pi / 3.0f;
+  const float tiles_per_tex = 1.0f / tile_size_uv_r;
+  const float curr = r_coord * r_size;
+  const float prev = __builtin_floorf(curr - kUnderHalf) + 0.5f;
+  const float first = prev - (24.0f / 2.0f - 1.0f);
+  const float uv_wrap = first * dr;
+  const float first_dist = curr - first;
+  const float tile_uv_wrap = uv_wrap * tiles_per_tex;
+  const float first_tile_uv = fractf(tile_uv_wrap) + (tile_uv_wrap < 0.0f ? 1.0f : 0.0f);
+  const float tile_dr = dr * tiles_per_tex;
+  float wsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  for (int i = 0; i < 24; i += 4) {
+    float w[4];
+    float4 s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float true_i = (float)i + (float)k;
+      const float tile_uv_r = fractf(first_tile_uv + true_i * tile_dr);
+      const float tex_uv_r = tile_uv_r * tile_size_uv_r;
+      s[k] = VERTICAL ? sample_rt(t, img, fixed_coord, tex_uv_r, lds) : sample_rt(t, img, tex_uv_r, fixed_coord, lds);
+      const float dist = magnification * __builtin_fabsf(first_dist - true_i);
+      const float pi_dist = pi * dist;
+      const float pdl = pi_over_lobes * dist;
+      w[k] = minps(sin_(pi_dist) * sin_(pdl) / (pi_dist * pdl), 1.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      cx += s[k].x * w[k]; cy += s[k].y * w[k]; cz += s[k].z * w[k];
+      wsum[k] += w[k];
+    }
+  }
+  const float total = (wsum[0] + wsum[2]) + (wsum[1] + wsum[3]);
+  return make_float4(cx / total, cy / total, cz / total, 1.0f);
+}
+
+__global__ void __launch_bounds__(256) k_royale_mask_v(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_PIXEL_PROLOGUE;
+  if (!inside) return;
+  const float wu = vary(L.plane[0], x, y, lo), wv = vary(L.plane[1], x, y, lo);
+  uint8_t* o = static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z;
+  if (wv <= 2.0f) {  // mask_resize_num_tiles
+    const float4 c = sinc_tiled<true>(L.extra[0], frame_ptr(L.extra[0], z), fractf(wu), fractf(wv), 64.0f, 1.0f / 64.0f,
+                                      L.params[RP5_MAG_Y], 1.0f, &lds);
+    store_rt(L, z, x, y, c, &lds);
+  } else {  // discard: the target keeps its clear colour (0,0,0,0)
+    *reinterpret_cast<uint32_t*>(o + ((size_t)y * L.out_w + x) * texel_bytes(L.out_fmt)) = 0u;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_royale_mask_h(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_PIXEL_PROLOGUE;
+  if (!inside) return;
+  uint8_t* o = static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z;
+  if (!(L.flags & RC_FLAG_UNDEF_VARYING_ZERO)) {
+    // The fragment shader's keep/discard test reads a varying that its vertex shader never
+    // writes; on the GL this engine is matched against, that discards every fragment.
+    *reinterpret_cast<uint32_t*>(o + ((size_t)y * L.out_w + x) * 4) = 0u;
+    return;
+  }
+  const float wu = vary(L.plane[0], x, y, lo), wv = vary(L.plane[1], x, y, lo);
+  const float4 c = sinc_tiled<false>(L.in, frame_ptr(L.in, z), fractf(wv), fractf(wu), (float)L.in.w, L.params[RP6_SRC_DX],
+                                     L.params[RP6_MAG_X], L.params[RP6_TILE_SIZE_UV_X], &lds);
+  store_rt(L, z, x, y, c, &lds);
+}
+
+// ------------------------------------------------------------------------------- P7 ------
+// scanlines-horizontal-apply-mask.glsl FS 10877-11030; sample_single_scanline_horizontal
+// 5198-5241 with the Quilez weights (beam_horiz_filter 0) and linear-RGB mixing.
+__device__ __forceinline__ float scanline_h_1ch(const Tex& t, const uint8_t* img, float u, float v, float tsx, float tsy, float tix,
+                                                float tiy, int ch, const SrgbLds* lds) {
+  const float ctx = u * tsx, cty = v * tsy;
+  const float phx = __builtin_floorf(ctx - kUnderHalf) + 0.5f;
+  const float puv_x = phx * tix, puv_y = cty * tiy;
+  const float xd = ctx - phx;
+  const float w2 = xd * xd * xd * (xd * (xd * 6.0f - 15.0f) + 10.0f);
+  const float wy = 1.0f - w2, wz = w2;
+  const float dot = ((0.0f * 1.0f + wy * 1.0f) + wz * 1.0f) + 0.0f * 1.0f;
+  const float fx = 0.0f / dot, fy = wy / dot, fz = wz / dot, fw = 0.0f / dot;
+  const float4 c1 = sample_rt(t, img, puv_x, puv_y, lds);
+  const float4 c2 = sample_rt(t, img, puv_x + tix, puv_y + 0.0f, lds);
+  const float a1 = ch == 0 ? c1.x : (ch == 1 ? c1.y : c1.z);
+  const float a2 = ch == 0 ? c2.x : (ch == 1 ? c2.y : c2.z);
+  const float m = ((0.0f * fx + a1 * fy) + a2 * fz) + 0.0f * fw;
+  return maxps(m, 0.0f);
+}
+
+__global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_PIXEL_PROLOGUE;
+  if (!inside) return;
+  const float vu = vary(L.plane[0], x, y, lo), vv = vary(L.plane[1], x, y, lo);
+  const float twx = vu * L.params[RP7_TPS_X], twy = vv * L.params[RP7_TPS_Y];
+  const float tux = fractf(twx * 0.5f) * 2.0f, tuy = fractf(twy * 0.5f) * 2.0f;
+  const float mu = L.params[RP7_START_X] + tux * L.params[RP7_UVS_X], mv = L.params[RP7_START_Y] + tuy * L.params[RP7_UVS_Y];
+  const float4 mask = sample_rt(L.in, frame_ptr(L.in, z), mu, mv, &lds);
+  float4 o = make_float4(0.f, 0.f, 0.f, 1.0f);
+  // scan * 0 is 0 (or NaN, which every target format stores as 0): skip the scanline taps
+  if (mask.x != 0.0f || mask.y != 0.0f || mask.z != 0.0f) {
+    const float su = vary(L.plane[2], x, y, lo), sv = vary(L.plane[3], x, y, lo);
+    const Tex& scan = L.extra[0];
+    const uint8_t* simg = frame_ptr(scan, z);
+    const float tsx = L.params[RP7_SCAN_TW], tsy = L.params[RP7_SCAN_TH], tix = L.params[RP7_SCAN_TIX], tiy = L.params[RP7_SCAN_TIY];
+    const float conv_x[3] = {0.1f, 0.3f, 0.5f};
+    float sc[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) sc[ch] = scanline_h_1ch(scan, simg, su - conv_x[ch] * tix, sv - 0.0f, tsx, tsy, tix, tiy, ch, &lds);
+    o = make_float4(sc[0] * mask.x, sc[1] * mask.y, sc[2] * mask.z, 1.0f);
+  }
+  store_rt(L, z, x, y, o, &lds);
+}
+
+// ------------------------------------------------------------------------------- P8 ------
+// brightpass.glsl FS 14610-14663; extra[0] = PassPrev4Texture.
+__global__ void __launch_bounds__(256) k_royale_brightpass(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_PIXEL_PROLOGUE;
+  if (!inside) return;
+  const float4 idim = sample_rt(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
+  float4 o = make_float4(0.f, 0.f, 0.f, 1.0f);
+  // brightpass = intensity_dim * ratio: a zero (or NaN-producing) input stores 0 whatever the ratio
+  if (idim.x != 0.0f || idim.y != 0.0f || idim.z != 0.0f) {
+    const float4 blur = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), vary(L.plane[2], x, y, lo), vary(L.plane[3], x, y, lo), &lds);
+    const float cw = L.params[RP8_CENTER_WEIGHT], mask_amplify = L.params[RP8_MASK_AMPLIFY];
+    const float in3[3] = {idim.x, idim.y, idim.z}, bl3[3] = {blur.x, blur.y, blur.z};
+    float out[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float intensity = in3[c] * 2.0f * mask_amplify * 1.0f;
+      const float pba = 1.0f * bl3[c];
+      const float max_area = maxps(pba - cw * intensity, 0.0f);
+      const float area_under = 0.8f * max_area;
+      const float int_under = 0.8f * intensity;
+      const float ratio_temp = ((1.0f - area_under) / int_under - 1.0f) / (cw - 1.0f);
+      out[c] = in3[c] * clampf(ratio_temp, 0.0f, 1.0f);
+    }
+    o = make_float4(out[0], out[1], out[2], 1.0f);
+  }
+  store_rt(L, z, x, y, o, &lds);
+}
+
+// ------------------------------------------------------------------------ P9 / P10 ------
+// tex2Dblur17fast (bloom-vertical.glsl 7132-7176); the nine (offset, weight) pairs come from
+// the host, evaluated with the run-time sigma exactly as the fragment shader would.
+__device__ __forceinline__ float4 blur17(const Tex& t, const uint8_t* img, float u, float v, float dx, float dy, const float* P,
+                                        const SrgbLds* lds) {
+  const float k[4] = {P[RPG_K78], P[RPG_K56], P[RPG_K34], P[RPG_K12]};
+  const float w[4] = {P[RPG_W78], P[RPG_W56], P[RPG_W34], P[RPG_W12]};
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 s = sample_rt(t, img, u - k[i] * dx, v - k[i] * dy, lds);
+    sx += w[i] * s.x; sy += w[i] * s.y; sz += w[i] * s.z;
+  }
+  {
+    const float4 s = sample_rt(t, img, u, v, lds);
+    sx += 1.0f * s.x; sy += 1.0f * s.y; sz += 1.0f * s.z;
+  }
+#pragma unroll
+  for (int i = 3; i >= 0; --i) {
+    const float4 s = sample_rt(t, img, u + k[i] * dx, v + k[i] * dy, lds);
+    sx += w[i] * s.x; sy += w[i] * s.y; sz += w[i] * s.z;
+  }
+  const float si = P[RPG_SUM_INV];
+  return make_float4(sx * si, sy * si, sz * si, 1.0f);
+}
+
+__global__ void __launch_bounds__(256) k_royale_bloom_v(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_PIXEL_PROLOGUE;
+  if (!inside) return;
+  const float4 c = blur17(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), 0.0f, L.params[RPG_DXY],
+                          L.params, &lds);
+  store_rt(L, z, x, y, c, &lds);
+}
+
+// bloom-horizontal-reconstitute.glsl FS 11407-11439.
+// extra[0] = PassPrev3 (MASKED_SCANLINES), extra[1] = PassPrev2 (BRIGHTPASS), extra[2] = PassPrev6 (HALATION_BLUR)
+__global__ void __launch_bounds__(256) k_royale_bloom_h(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_PIXEL_PROLOGUE;
+  if (!inside) return;
+  const float4 blurred = blur17(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), L.params[RPG_DXY], 0.0f,
+                                L.params, &lds);
+  const float4 idim = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), vary(L.plane[2], x, y, lo), vary(L.plane[3], x, y, lo), &lds);
+  const float4 bright = sample_rt(L.extra[1], frame_ptr(L.extra[1], z), vary(L.plane[4], x, y, lo), vary(L.plane[5], x, y, lo), &lds);
+  const float4 hal = sample_rt(L.extra[2], frame_ptr(L.extra[2], z), vary(L.plane[6], x, y, lo), vary(L.plane[7], x, y, lo), &lds);
+  const float mask_amplify = L.params[RPG_MASK_AMPLIFY];
+  const float i3[3] = {idim.x, idim.y, idim.z}, b3[3] = {bright.x, bright.y, bright.z}, bl[3] = {blurred.x, blurred.y, blurred.z};
+  const float h3[3] = {hal.x, hal.y, hal.z};
+  float out[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float dimpass = i3[c] - b3[c];
+    const float phosphor_bloom = (dimpass + bl[c]) * mask_amplify * 2.0f * 1.0f;
+    const float diffusion_color = 1.0f * h3[c];
+    out[c] = phosphor_bloom * (1.0f - 0.075f) + diffusion_color * 0.075f;
+  }
+  store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+}
+
+// ------------------------------------------------------------------------------ P11 ------
+// geometry-aa-last-pass.glsl FS 5451-5531 (flat geometry path), get_border_dim_factor 5250.
+__global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_PIXEL_PROLOGUE;
+  if (!inside) return;
+  const float tsx = (float)L.in.w, tsy = (float)L.in.h;
+  const float* P = L.params;
+  const float lcd_gamma = P[1], osx = P[37], osy = P[38], border_size = P[39], border_darkness = P[40], border_compress = P[41];
+  const float vsix = 1.0f / tsx, vsiy = 1.0f / tsy;
+  const float geom_aspect_x = P[RP11_ASPECT_X], geom_aspect_y = P[RP11_ASPECT_Y];
+  const float inv_gamma = 1.0f / lcd_gamma;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float fu = u * (tsx * vsix), fv = v * (tsy * vsiy);
+  const float vu = (fu - 0.5f) / osx + 0.5f, vv = (fv - 0.5f) / osy + 0.5f;
+  const float tu = vu * (tsx * vsix), tv = vv * (tsy * vsiy);
+  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), tu, tv, &lds);
+  const float ex = minps(vu, 1.0f - vu) * geom_aspect_x, ey = minps(vv, 1.0f - vv) * geom_aspect_y;
+  const float bx = maxps(border_size - ex, 0.0f), by = maxps(border_size - ey, 0.0f);
+  const float pen = __builtin_sqrtf(bx * bx + by * by) / border_size;
+  const float esc = maxps(1.0f - pen, 0.0f);
+  const float f = minps(pow_(esc, border_darkness) * maxps(1.0f, border_compress), 1.0f);
+  store_rt(L, z, x, y, make_float4(pow_(c.x * f, inv_gamma), pow_(c.y * f, inv_gamma), pow_(c.z * f, inv_gamma), 1.0f), &lds);
+}
+
+}  // namespace
+
+namespace rck {
+#define RC_LAUNCH(fn, kernel)                                         \
+  hipError_t fn(const PassLaunch& L, hipStream_t s) {                 \
+    hipLaunchKernelGGL(kernel, px_grid(L), px_block(), 0, s, L);      \
+    return hipGetLastError();                                         \
+  }
+RC_LAUNCH(launch_royale_first, k_royale_first)
+RC_LAUNCH(launch_royale_scan_v, k_royale_scan_v)
+RC_LAUNCH(launch_royale_bloom_approx, k_royale_bloom_approx)
+RC_LAUNCH(launch_blur9, k_blur9)
+RC_LAUNCH(launch_royale_mask_v, k_royale_mask_v)
+RC_LAUNCH(launch_royale_mask_h, k_royale_mask_h)
+RC_LAUNCH(launch_royale_scan_h, k_royale_scan_h)
+RC_LAUNCH(launch_royale_brightpass, k_royale_brightpass)
+RC_LAUNCH(launch_royale_bloom_v, k_royale_bloom_v)
+RC_LAUNCH(launch_royale_bloom_h, k_royale_bloom_h)
+RC_LAUNCH(launch_royale_last, k_royale_last)
+}  // namespace rck

@@ -34,7 +34,7 @@ struct Plane {
 };
 
 constexpr int kMaxExtra = 6;
-constexpr int kMaxPlanes = 6;
+constexpr int kMaxPlanes = 8;
 constexpr int kMaxParams = 48;
 
 struct PassLaunch {
@@ -47,16 +47,20 @@ struct PassLaunch {
   int vp_w, vp_h;         // viewport
   int frame_count0;       // FrameCount of frame 0 of this launch; frame z sees frame_count0+z
   int n_frames;
+  int flags;              // kernel specific (e.g. RC_FLAG_UNDEF_VARYING_ZERO)
   Plane plane[kMaxPlanes];
   float params[kMaxParams];
 };
 
 // -------------------------------------------------------------------- float primitives ----
-__device__ __forceinline__ float bits2f(uint32_t u) { return __uint_as_float(u); }
-__device__ __forceinline__ uint32_t f2bits(float f) { return __float_as_uint(f); }
-__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// The float primitives are __host__ __device__: the host evaluates them for per-launch
+// constants (e.g. blur weights of a run-time sigma) with the very same operations.
+#define RC_HD __host__ __device__ __forceinline__
+RC_HD float bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+RC_HD uint32_t f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+RC_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-__device__ __forceinline__ float exp2_(float x) {
+RC_HD float exp2_(float x) {
   x = x > 128.0f ? 128.0f : x;
   x = x < -126.99999f ? -126.99999f : x;
   float ip = __builtin_floorf(x);
@@ -70,7 +74,7 @@ __device__ __forceinline__ float exp2_(float x) {
   return e * fma_(odd, fp, even);
 }
 
-__device__ __forceinline__ float log2_(float x) {
+RC_HD float log2_(float x) {
   uint32_t i = f2bits(x);
   // zero / denormal -> -inf, negative -> NaN, +inf -> +inf (the GL's "safe" log2)
   if ((i & 0x7f800000u) == 0u) return -__builtin_inff();
@@ -88,12 +92,12 @@ __device__ __forceinline__ float log2_(float x) {
   return fma_(y, p, logexp);
 }
 
-__device__ __forceinline__ float pow_(float x, float y) { return exp2_(log2_(x) * y); }
-__device__ __forceinline__ float exp_(float x) { return exp2_(x * 1.4426950408889634f); }
-__device__ __forceinline__ float log_(float x) { return log2_(x) * 0.69314718055994529f; }
+RC_HD float pow_(float x, float y) { return exp2_(log2_(x) * y); }
+RC_HD float exp_(float x) { return exp2_(x * 1.4426950408889634f); }
+RC_HD float log_(float x) { return log2_(x) * 0.69314718055994529f; }
 
 template <bool COS>
-__device__ __forceinline__ float sincos_(float x) {
+RC_HD float sincos_(float x) {
   uint32_t xi = f2bits(x);
   float xa = bits2f(xi & 0x7fffffffu);
   uint32_t sign = xi & 0x80000000u;
@@ -122,8 +126,8 @@ __device__ __forceinline__ float sincos_(float x) {
   uint32_t sb = COS ? swap : (sign ^ swap);
   return bits2f(f2bits(r) ^ sb);
 }
-__device__ __forceinline__ float sin_(float x) { return sincos_<false>(x); }
-__device__ __forceinline__ float cos_(float x) { return sincos_<true>(x); }
+RC_HD float sin_(float x) { return sincos_<false>(x); }
+RC_HD float cos_(float x) { return sincos_<true>(x); }
 
 // ----------------------------------------------------------------------------- varyings ----
 __device__ __forceinline__ bool lower_tri(int x, int y, int W, int H) {
@@ -268,6 +272,7 @@ __device__ __forceinline__ float4 sample(const Tex& t, const uint8_t* img, float
   return sample_linear_f<FMT, WRAP>(t, img, s, v, lds);
 }
 
+__device__ __forceinline__ int texel_bytes(int fmt) { return fmt == FMT_F32 ? 16 : 4; }
 __device__ __forceinline__ const uint8_t* frame_ptr(const Tex& t, int z) {
   return static_cast<const uint8_t*>(t.base) + t.frame_stride * (uint64_t)z;
 }

@@ -1,0 +1,28 @@
+// Indices into PassLaunch::params for the crt-royale kernels: per-launch constants that the
+// GLSL vertex shaders derive from uniforms, computed on the host by royale_setup.cpp.
+#pragma once
+
+enum {  // pass 0
+  RP0_INTERLACED = 0,
+};
+enum {  // pass 1
+  RP1_Y_STEP = 0, RP1_UV_STEP_Y, RP1_PH,
+};
+enum {  // blur9 (passes 3, 4)
+  RPB_W12 = 0, RPB_W34, RPB_K12, RPB_K34, RPB_SUM_INV, RPB_DX, RPB_DY,
+};
+enum { RP5_MAG_Y = 0 };
+enum { RP6_MAG_X = 0, RP6_SRC_DX, RP6_TILE_SIZE_UV_X };
+enum {  // pass 7
+  RP7_TPS_X = 0, RP7_TPS_Y, RP7_START_X, RP7_START_Y, RP7_UVS_X, RP7_UVS_Y, RP7_SCAN_TW, RP7_SCAN_TH, RP7_SCAN_TIX, RP7_SCAN_TIY,
+};
+enum { RP8_CENTER_WEIGHT = 0, RP8_MASK_AMPLIFY };
+enum {  // blur17 (passes 9, 10)
+  RPG_W12 = 0, RPG_W34, RPG_W56, RPG_W78, RPG_K12, RPG_K34, RPG_K56, RPG_K78, RPG_SUM_INV, RPG_DXY, RPG_MASK_AMPLIFY,
+};
+enum {  // pass 11: params[0..43] are the shader's 44 #pragma parameters; derived values follow
+  RP11_ASPECT_X = 44, RP11_ASPECT_Y = 45,
+};
+
+// PassLaunch::flags
+enum { RC_FLAG_UNDEF_VARYING_ZERO = 1 };

@@ -243,6 +243,9 @@ int rc_engine_pass_profile(rc_engine* e, int pass, rc_pass_profile* out) {
 void rc_engine_set_chunk_frames(rc_engine* e, uint32_t n) {
   if (e) e->impl.setChunkFrames(n);
 }
+void rc_engine_set_undefined_varying_zero(rc_engine* e, int zero) {
+  if (e) e->impl.setUndefinedVaryingZero(zero != 0);
+}
 void rc_engine_set_allow_missing_sources(rc_engine* e, int allow) {
   if (e) e->impl.setAllowMissingSources(allow != 0);
 }

@@ -612,6 +612,12 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
       geo.src_h = L.src_h;
       geo.vp_w = L.vp_w;
       geo.vp_h = L.vp_h;
+      geo.n_passes = (int)std::min<size_t>(m_passes.size(), 32);
+      for (int q = 0; q < geo.n_passes; ++q) {
+        geo.chain_w[q] = (int)m_passes[(size_t)q].width;
+        geo.chain_h[q] = (int)m_passes[(size_t)q].height;
+      }
+      L.flags = m_undefVaryingZero ? 1 : 0;
       if (k.setup) k.setup(geo, L);
       // algorithmic read bytes per frame: distinct sampled textures, once each
       {

@@ -98,6 +98,10 @@ class ShaderEngine {
   // Accept presets whose .glsl files are absent when the registry knows the shader (the
   // registry's parameter table is used).  Off by default: the reference fails such a pass.
   void setAllowMissingSources(bool allow) { m_allowMissingSources = allow; }
+  // crt-royale pass 6 tests a varying its vertex shader never writes.  false (default): the
+  // fragment shader discards everything, as on Mesa llvmpipe; true: the varying reads 0, as on
+  // GL drivers that zero undefined varyings, and the resized phosphor mask is rendered.
+  void setUndefinedVaryingZero(bool zero) { m_undefVaryingZero = zero; }
   uint32_t getChunkFrames() const { return m_chunk; }
   hipStream_t stream() const { return m_stream; }
   size_t passCount() const { return m_passes.size(); }
@@ -141,6 +145,7 @@ class ShaderEngine {
   uint32_t m_lastChunkFirst = 0;
   bool m_singleShader = false;
   bool m_allowMissingSources = false;
+  bool m_undefVaryingZero = false;
   struct Vec4 { float x, y, z, w; };
   std::unordered_map<std::string, Vec4> m_uniforms;
   DeviceBuffer m_batchOutput;

@@ -65,6 +65,7 @@ SYMBOLS = [
     ("rc_engine_pass_profile", C.c_int, [C.c_void_p, C.c_int, C.POINTER(_RcPassProfile)]),
     ("rc_engine_set_chunk_frames", None, [C.c_void_p, C.c_uint32]),
     ("rc_engine_set_allow_missing_sources", None, [C.c_void_p, C.c_int]),
+    ("rc_engine_set_undefined_varying_zero", None, [C.c_void_p, C.c_int]),
     ("rc_last_error", C.c_char_p, []),
     ("rc_version", C.c_char_p, []),
     ("rc_kernel_list", C.c_size_t, [C.c_char_p, C.c_size_t]),
@@ -271,6 +272,9 @@ class ShaderEngine:
             raise RcError("passProfile failed: " + self._lib.rc_last_error().decode())
         return {"total_ms": p.total_ms, "launches": p.launches, "frames": p.frames,
                 "read_bytes_per_frame": p.read_bytes_per_frame, "write_bytes_per_frame": p.write_bytes_per_frame}
+
+    def setUndefinedVaryingZero(self, zero):
+        self._lib.rc_engine_set_undefined_varying_zero(self._need(), int(bool(zero)))
 
     def passCount(self):
         return self._lib.rc_engine_pass_count(self._need())

@@ -36,6 +36,60 @@ def test_engine_matches_golden(case, preset_tree, rc_lib):
     e.shutdown()
 
 
+def royale_luts():
+    lut = np.load(os.path.join(GOLD, "lut_mask_slot_small_64.npy"))
+    return {"mask_slot_texture_small": (lut, True, "repeat")}
+
+
+ROYALE_GOLDEN = ["crt_royale_160x120_to_320x240", "crt_royale_128x96_to_400x300",
+                 "crt_royale_maskon_160x120_to_320x240", "crt_royale_maskon_96x128_to_512x384"]
+
+
+@pytest.mark.parametrize("case", ROYALE_GOLDEN)
+def test_royale_matches_oracle_and_golden(case, preset_tree, rc_lib):
+    """All 12 crt-royale passes: bit-exact against the oracle run on the same input, and within
+    the documented sRGB-encode tolerance of the llvmpipe golden vectors."""
+    from gpu_util import make_engine, run_engine
+    from retrocapture_amd import engine as eng
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    vw, vh = [int(v) for v in g["viewport"]]
+    maskon = "maskon" in case
+    frames = int(g["frames"])
+    passes = eng.preset_dump(preset_tree["crt-royale"])["passes"]
+    assert len(passes) == 12
+    want = run_chain(passes, g["input_rgb"], vw, vh, frame_count=frames, luts=royale_luts(), flags=1 if maskon else 0)
+    e = make_engine(preset_tree["crt-royale"], vw, vh)
+    e.setUndefinedVaryingZero(maskon)
+    for _ in range(frames):                 # the golden run applied `frames` frames; the last one is kept
+        final = run_engine(e, g["input_rgb"])
+    for i in range(12):
+        got = e.readPass(i, 0)
+        assert got.shape == want[i].shape, (i, got.shape, want[i].shape)
+        assert np.array_equal(got, want[i]), "pass %d vs oracle: %d differing values" % (i, int((got != want[i]).sum()))
+    ref = g["pass11"]
+    d = np.abs(final[0].astype(np.int32) - ref.astype(np.int32))
+    assert float((d == 0).mean()) >= 0.97
+    if not maskon:
+        assert d.max() <= 2
+    e.shutdown()
+
+
+def test_royale_interlaced_source_and_batch(preset_tree, rc_lib):
+    """A 480-line source is 'interlaced' for crt-royale (288.5 < lines < 576.5): pass 0 bobs fields
+    and pass 1 doubles the scanline step, both depending on FrameCount.  Batch of 3 frames."""
+    from gpu_util import make_engine, run_engine
+    from retrocapture_amd import engine as eng
+    rng = np.random.default_rng(21)
+    frames = rng.integers(0, 256, (3, 480, 96, 3), dtype=np.uint8)
+    passes = eng.preset_dump(preset_tree["crt-royale"])["passes"]
+    e = make_engine(preset_tree["crt-royale"], 160, 360, chunk=2)
+    final = run_engine(e, frames)
+    for k in range(3):
+        want = run_chain(passes, frames[k], 160, 360, frame_count=k + 1, luts=royale_luts())
+        assert np.array_equal(final[k], want[-1]), "frame %d" % k
+    e.shutdown()
+
+
 @pytest.mark.parametrize("key,w,h,vw,vh", [
     ("scanline", 33, 17, 33, 17),       # ragged: not a multiple of the 64x4 workgroup
     ("scanline", 320, 240, 320, 240),   # BASELINE config 1
