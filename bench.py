@@ -32,6 +32,17 @@ WORKLOADS = {
 }
 
 
+def shard_frames(total_frames, rank, world):
+    """Contiguous block of frame indices owned by `rank` (frames are independent: no exchange)."""
+    per = (total_frames + world - 1) // world
+    return range(min(total_frames, rank * per), min(total_frames, (rank + 1) * per))
+
+
+def aggregate(frames_per_rank, steps, seconds):
+    """Whole-job throughput: frames all ranks processed / max-over-ranks time."""
+    return sum(frames_per_rank) * steps / seconds
+
+
 def default_workload():
     import chain_specs
     return "crt-royale" if "crt-royale" in chain_specs.PRESETS else "crt-pi"
@@ -148,8 +159,7 @@ def main():
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     chain_bytes = sum(q["read_bytes_per_frame"] + q["write_bytes_per_frame"] for q in prof)
 
-    total_frames = args.batch * args.steps * world
-    value = total_frames / dt
+    value = aggregate([args.batch] * world, args.steps, dt)
     out = {
         "metric": "1080p frames/sec, crt-royale 12-pass, 1/2/4/8 MI355X; % HBM roofline",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -153,6 +153,9 @@ size_t rc_kernel_list(char* buf, size_t cap);
 /* Standalone preset parser check (ShaderPreset::load, ShaderPreset.cpp:18-333): writes a JSON
  * description of the parsed preset; returns the length needed.  No GPU needed. */
 size_t rc_preset_dump_json(const char* glslp_path, char* buf, size_t cap);
+/* LUT decode as loadTextureReference does it (ShaderEngine.cpp:2535-2706): PNG -> RGBA8, row 0
+ * first.  Returns 0 and the size, or <0 (buffer too small / not a PNG).  No GPU needed. */
+int rc_png_decode_rgba8(const char* png_path, void* rgba, size_t cap, int* width, int* height);
 /* #pragma parameter scan of one shader file (ShaderPreprocessor.cpp:30-79) as JSON. */
 size_t rc_shader_params_json(const char* glsl_path, char* buf, size_t cap);
 

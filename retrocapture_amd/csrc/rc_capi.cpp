@@ -5,6 +5,7 @@
 #include <cstring>
 #include <sstream>
 
+#include "png_lut.h"
 #include "rc_log.h"
 #include "shader_engine.h"
 
@@ -295,6 +296,24 @@ size_t rc_preset_dump_json(const char* path, char* buf, size_t cap) {
     out = std::string("{\"preset\":") + jstr(path) + ",\"ok\":false,\"exception\":" + jstr(ex.what()) + "}";
   }
   return copy_out(out, buf, cap);
+}
+
+int rc_png_decode_rgba8(const char* path, void* rgba, size_t cap, int* width, int* height) {
+  if (!path || !rgba) return RC_ERR_INVALID;
+  return guarded([&] {
+    std::vector<uint8_t> px;
+    int w = 0, h = 0;
+    std::string err;
+    if (!rc::loadPngRgba8(path, &px, &w, &h, &err)) {
+      RC_LOG_ERROR(err);
+      return (int)RC_ERR_LOAD;
+    }
+    if (width) *width = w;
+    if (height) *height = h;
+    if (px.size() > cap) return (int)RC_ERR_INVALID;
+    std::memcpy(rgba, px.data(), px.size());
+    return (int)RC_OK;
+  });
 }
 
 size_t rc_shader_params_json(const char* path, char* buf, size_t cap) {

@@ -237,6 +237,13 @@ void setupLast(const PassGeometry& g, PassLaunch& L) {
   L.params[RP11_ASPECT_Y] = gy * rs;
 }
 
+const char* validateLast(const float* P) {
+  // only the flat path of geometry-aa-last-pass.glsl is restated (FS 5480-5515)
+  if (P[30] > 0.5f) return "crt-royale: geom_mode_runtime > 0.5 (curved geometry) is not supported by the HIP kernel";
+  if (P[37] != 1.0f || P[38] != 1.0f) return "crt-royale: geom_overscan != 1 (tex2Daa path) is not supported by the HIP kernel";
+  return nullptr;
+}
+
 }  // namespace
 
 void registerRoyaleKernels(std::vector<KernelEntry>& r) {
@@ -306,6 +313,11 @@ void registerRoyaleKernels(std::vector<KernelEntry>& r) {
                 {"interlace_bff", 0.0f, 0.0f, 1.0f, 1.0f, "Interlacing - Bottom Field First"},
                 {"interlace_1080i", 0.0f, 0.0f, 1.0f, 1.0f, "Interlace - Detect 1080i"}},
                {}, rck::launch_royale_last, setupLast, false});
+  r.back().validate = validateLast;
+  for (auto& e : r) {
+    const std::string n = e.name;
+    if (n == "royale-bloom-approx" || n == "royale-mask-v") e.reads_input = false;
+  }
 }
 
 }  // namespace rc

@@ -619,6 +619,12 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
       }
       L.flags = m_undefVaryingZero ? 1 : 0;
       if (k.setup) k.setup(geo, L);
+      if (k.validate) {
+        if (const char* why = k.validate(L.params)) {
+          RC_LOG_ERROR(why);
+          return false;
+        }
+      }
       // algorithmic read bytes per frame: distinct sampled textures, once each
       {
         const void* seen[1 + rcd::kMaxExtra];
@@ -630,7 +636,7 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
           seen[ns++] = t.base;
           rb += (uint64_t)t.w * t.h * texelBytes(t.fmt);
         };
-        add(L.in);
+        if (k.reads_input) add(L.in);
         for (size_t s2 = 0; s2 < k.samplers.size() && s2 < (size_t)rcd::kMaxExtra; ++s2) add(L.extra[s2]);
         if (m_passReadBytes.size() != m_passes.size()) m_passReadBytes.assign(m_passes.size(), 0);
         m_passReadBytes[i] = rb;

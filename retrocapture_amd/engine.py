@@ -71,6 +71,7 @@ SYMBOLS = [
     ("rc_kernel_list", C.c_size_t, [C.c_char_p, C.c_size_t]),
     ("rc_preset_dump_json", C.c_size_t, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("rc_shader_params_json", C.c_size_t, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("rc_png_decode_rgba8", C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 ]
 
 
