@@ -22,6 +22,33 @@ __device__ __forceinline__ float fractf(float x) { return x - __builtin_floorf(x
 __device__ __forceinline__ float mod_glsl(float x, float y) { return x - y * __builtin_floorf(x / y); }
 __device__ __forceinline__ float mix_rt(float a, float b, float t) { return a + t * (b - a); }
 
+// Sampler / store policies: the shipped preset's texture formats and sampler states get
+// compile-time specialised kernels; any other configuration runs the run-time selected ones.
+template <int FMT, int LIN, int WRAP>
+struct S {
+  static __device__ __forceinline__ float4 get(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* l) {
+    return sample<FMT, LIN, WRAP>(t, img, s, v, l);
+  }
+  static bool matches(const Tex& t) { return t.fmt == FMT && (t.linear != 0) == (LIN != 0) && t.wrap == WRAP; }
+};
+struct SRT {
+  static __device__ __forceinline__ float4 get(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* l) {
+    return sample_rt(t, img, s, v, l);
+  }
+  static bool matches(const Tex&) { return true; }
+};
+template <int OUT>
+struct St {
+  static __device__ __forceinline__ void put(const PassLaunch& L, int z, int x, int y, float4 c, const SrgbLds* l) { store<OUT>(L, z, x, y, c, l); }
+  static bool matches(const PassLaunch& L) { return L.out_fmt == OUT; }
+};
+struct StRT {
+  static __device__ __forceinline__ void put(const PassLaunch& L, int z, int x, int y, float4 c, const SrgbLds* l) { store_rt(L, z, x, y, c, l); }
+  static bool matches(const PassLaunch&) { return true; }
+};
+using SrgbLinEdge = S<FMT_SRGB8, 1, WRAP_EDGE>;
+using SrgbNearEdge = S<FMT_SRGB8, 0, WRAP_EDGE>;
+
 #define RC_PIXEL_PROLOGUE                                                                   \
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, z = blockIdx.z; \
   const bool inside = x < L.out_w && y < L.out_h;                                             \
@@ -112,6 +139,7 @@ __device__ __forceinline__ float beam_contrib(const BeamShape& b, float dist, fl
   return b.scale3 * (w1 + w2 + w3);
 }
 
+template <class SI, class SO>
 __global__ void __launch_bounds__(256) k_royale_scan_v(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
@@ -132,12 +160,12 @@ __global__ void __launch_bounds__(256) k_royale_scan_v(const PassLaunch L) {
   const float su = stx * tix, sv = sty * tiy;
   const float dist = (cty - sty) / y_step;
   const uint8_t* img = frame_ptr(L.in, z);
-  const float4 s2 = sample_rt(L.in, img, su, sv, &lds);
-  const float4 s3 = sample_rt(L.in, img, su + 0.0f, sv + uv_step_y, &lds);
+  const float4 s2 = SI::get(L.in, img, su, sv, &lds);
+  const float4 s3 = SI::get(L.in, img, su + 0.0f, sv + uv_step_y, &lds);
   const float dist_round = __builtin_rintf(dist);
   const float off_x = mix_rt(-0.0f, 2.0f * 0.0f, dist_round);
   const float off_y = mix_rt(-uv_step_y, 2.0f * uv_step_y, dist_round);
-  const float4 so = sample_rt(L.in, img, su + off_x, sv + off_y, &lds);
+  const float4 so = SI::get(L.in, img, su + off_x, sv + off_y, &lds);
   const float off = ph / 3.0f;
   const float c2[3] = {s2.x, s2.y, s2.z}, c3[3] = {s3.x, s3.y, s3.z}, co[3] = {so.x, so.y, so.z};
   const float conv_y[3] = {0.2f, 0.4f, 0.6f};
@@ -153,23 +181,25 @@ __global__ void __launch_bounds__(256) k_royale_scan_v(const PassLaunch L) {
     inten += beam_contrib(beam_shape(co[ch], sigma_range, shape_range), d14, off);
     out[ch] = inten * 0.5f;
   }
-  store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+  SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
 }
 
 // ------------------------------------------------------------------------------- P2 ------
 // bloom-approx.glsl FS 14053-14184: the only live statement samples extra[0] at tex_uv.
+template <class S0, class SO>
 __global__ void __launch_bounds__(256) k_royale_bloom_approx(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
   RC_PIXEL_PROLOGUE;
   if (!inside) return;
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
-  store_rt(L, z, x, y, sample_rt(L.extra[0], frame_ptr(L.extra[0], z), u, v, &lds), &lds);
+  SO::put(L, z, x, y, S0::get(L.extra[0], frame_ptr(L.extra[0], z), u, v, &lds), &lds);
 }
 
 // -------------------------------------------------------------------------- P3 / P4 ------
 // blurs/blur9fast-*.glsl: tex2Dblur9fast 1496-1524; weights are compile-time constants there,
 // folded by the host (royale_setup.cpp) the way the GL's compiler folds them.
+template <class SI, class SO>
 __global__ void __launch_bounds__(256) k_blur9(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
@@ -179,18 +209,18 @@ __global__ void __launch_bounds__(256) k_blur9(const PassLaunch L) {
   const float sum_inv = L.params[RPB_SUM_INV], dx = L.params[RPB_DX], dy = L.params[RPB_DY];
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
   const uint8_t* img = frame_ptr(L.in, z);
-  const float4 s0 = sample_rt(L.in, img, u - k34 * dx, v - k34 * dy, &lds);
-  const float4 s1 = sample_rt(L.in, img, u - k12 * dx, v - k12 * dy, &lds);
-  const float4 s2 = sample_rt(L.in, img, u, v, &lds);
-  const float4 s3 = sample_rt(L.in, img, u + k12 * dx, v + k12 * dy, &lds);
-  const float4 s4 = sample_rt(L.in, img, u + k34 * dx, v + k34 * dy, &lds);
+  const float4 s0 = SI::get(L.in, img, u - k34 * dx, v - k34 * dy, &lds);
+  const float4 s1 = SI::get(L.in, img, u - k12 * dx, v - k12 * dy, &lds);
+  const float4 s2 = SI::get(L.in, img, u, v, &lds);
+  const float4 s3 = SI::get(L.in, img, u + k12 * dx, v + k12 * dy, &lds);
+  const float4 s4 = SI::get(L.in, img, u + k34 * dx, v + k34 * dy, &lds);
   float sx = 0.0f, sy = 0.0f, sz = 0.0f;
   sx += w34 * s0.x; sy += w34 * s0.y; sz += w34 * s0.z;
   sx += w12 * s1.x; sy += w12 * s1.y; sz += w12 * s1.z;
   sx += 1.0f * s2.x; sy += 1.0f * s2.y; sz += 1.0f * s2.z;
   sx += w12 * s3.x; sy += w12 * s3.y; sz += w12 * s3.z;
   sx += w34 * s4.x; sy += w34 * s4.y; sz += w34 * s4.z;
-  store_rt(L, z, x, y, make_float4(sx * sum_inv, sy * sum_inv, sz * sum_inv, 1.0f), &lds);
+  SO::put(L, z, x, y, make_float4(sx * sum_inv, sy * sum_inv, sz * sum_inv, 1.0f), &lds);
 }
 
 // -------------------------------------------------------------------------- P5 / P6 ------
@@ -272,6 +302,7 @@ __global__ void __launch_bounds__(256) k_royale_mask_h(const PassLaunch L) {
 // ------------------------------------------------------------------------------- P7 ------
 // scanlines-horizontal-apply-mask.glsl FS 10877-11030; sample_single_scanline_horizontal
 // 5198-5241 with the Quilez weights (beam_horiz_filter 0) and linear-RGB mixing.
+template <class SS>
 __device__ __forceinline__ float scanline_h_1ch(const Tex& t, const uint8_t* img, float u, float v, float tsx, float tsy, float tix,
                                                 float tiy, int ch, const SrgbLds* lds) {
   const float ctx = u * tsx, cty = v * tsy;
@@ -282,14 +313,15 @@ __device__ __forceinline__ float scanline_h_1ch(const Tex& t, const uint8_t* img
   const float wy = 1.0f - w2, wz = w2;
   const float dot = ((0.0f * 1.0f + wy * 1.0f) + wz * 1.0f) + 0.0f * 1.0f;
   const float fx = 0.0f / dot, fy = wy / dot, fz = wz / dot, fw = 0.0f / dot;
-  const float4 c1 = sample_rt(t, img, puv_x, puv_y, lds);
-  const float4 c2 = sample_rt(t, img, puv_x + tix, puv_y + 0.0f, lds);
+  const float4 c1 = SS::get(t, img, puv_x, puv_y, lds);
+  const float4 c2 = SS::get(t, img, puv_x + tix, puv_y + 0.0f, lds);
   const float a1 = ch == 0 ? c1.x : (ch == 1 ? c1.y : c1.z);
   const float a2 = ch == 0 ? c2.x : (ch == 1 ? c2.y : c2.z);
   const float m = ((0.0f * fx + a1 * fy) + a2 * fz) + 0.0f * fw;
   return maxps(m, 0.0f);
 }
 
+template <class SI, class S0, class SO>
 __global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
@@ -299,7 +331,7 @@ __global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
   const float twx = vu * L.params[RP7_TPS_X], twy = vv * L.params[RP7_TPS_Y];
   const float tux = fractf(twx * 0.5f) * 2.0f, tuy = fractf(twy * 0.5f) * 2.0f;
   const float mu = L.params[RP7_START_X] + tux * L.params[RP7_UVS_X], mv = L.params[RP7_START_Y] + tuy * L.params[RP7_UVS_Y];
-  const float4 mask = sample_rt(L.in, frame_ptr(L.in, z), mu, mv, &lds);
+  const float4 mask = SI::get(L.in, frame_ptr(L.in, z), mu, mv, &lds);
   float4 o = make_float4(0.f, 0.f, 0.f, 1.0f);
   // scan * 0 is 0 (or NaN, which every target format stores as 0): skip the scanline taps
   if (mask.x != 0.0f || mask.y != 0.0f || mask.z != 0.0f) {
@@ -310,24 +342,25 @@ __global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
     const float conv_x[3] = {0.1f, 0.3f, 0.5f};
     float sc[3];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) sc[ch] = scanline_h_1ch(scan, simg, su - conv_x[ch] * tix, sv - 0.0f, tsx, tsy, tix, tiy, ch, &lds);
+    for (int ch = 0; ch < 3; ++ch) sc[ch] = scanline_h_1ch<S0>(scan, simg, su - conv_x[ch] * tix, sv - 0.0f, tsx, tsy, tix, tiy, ch, &lds);
     o = make_float4(sc[0] * mask.x, sc[1] * mask.y, sc[2] * mask.z, 1.0f);
   }
-  store_rt(L, z, x, y, o, &lds);
+  SO::put(L, z, x, y, o, &lds);
 }
 
 // ------------------------------------------------------------------------------- P8 ------
 // brightpass.glsl FS 14610-14663; extra[0] = PassPrev4Texture.
+template <class SI, class S0, class SO>
 __global__ void __launch_bounds__(256) k_royale_brightpass(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
   RC_PIXEL_PROLOGUE;
   if (!inside) return;
-  const float4 idim = sample_rt(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
+  const float4 idim = SI::get(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
   float4 o = make_float4(0.f, 0.f, 0.f, 1.0f);
   // brightpass = intensity_dim * ratio: a zero (or NaN-producing) input stores 0 whatever the ratio
   if (idim.x != 0.0f || idim.y != 0.0f || idim.z != 0.0f) {
-    const float4 blur = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), vary(L.plane[2], x, y, lo), vary(L.plane[3], x, y, lo), &lds);
+    const float4 blur = S0::get(L.extra[0], frame_ptr(L.extra[0], z), vary(L.plane[2], x, y, lo), vary(L.plane[3], x, y, lo), &lds);
     const float cw = L.params[RP8_CENTER_WEIGHT], mask_amplify = L.params[RP8_MASK_AMPLIFY];
     const float in3[3] = {idim.x, idim.y, idim.z}, bl3[3] = {blur.x, blur.y, blur.z};
     float out[3];
@@ -343,12 +376,13 @@ __global__ void __launch_bounds__(256) k_royale_brightpass(const PassLaunch L) {
     }
     o = make_float4(out[0], out[1], out[2], 1.0f);
   }
-  store_rt(L, z, x, y, o, &lds);
+  SO::put(L, z, x, y, o, &lds);
 }
 
 // ------------------------------------------------------------------------ P9 / P10 ------
 // tex2Dblur17fast (bloom-vertical.glsl 7132-7176); the nine (offset, weight) pairs come from
 // the host, evaluated with the run-time sigma exactly as the fragment shader would.
+template <class SI>
 __device__ __forceinline__ float4 blur17(const Tex& t, const uint8_t* img, float u, float v, float dx, float dy, const float* P,
                                         const SrgbLds* lds) {
   const float k[4] = {P[RPG_K78], P[RPG_K56], P[RPG_K34], P[RPG_K12]};
@@ -356,44 +390,46 @@ __device__ __forceinline__ float4 blur17(const Tex& t, const uint8_t* img, float
   float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float4 s = sample_rt(t, img, u - k[i] * dx, v - k[i] * dy, lds);
+    const float4 s = SI::get(t, img, u - k[i] * dx, v - k[i] * dy, lds);
     sx += w[i] * s.x; sy += w[i] * s.y; sz += w[i] * s.z;
   }
   {
-    const float4 s = sample_rt(t, img, u, v, lds);
+    const float4 s = SI::get(t, img, u, v, lds);
     sx += 1.0f * s.x; sy += 1.0f * s.y; sz += 1.0f * s.z;
   }
 #pragma unroll
   for (int i = 3; i >= 0; --i) {
-    const float4 s = sample_rt(t, img, u + k[i] * dx, v + k[i] * dy, lds);
+    const float4 s = SI::get(t, img, u + k[i] * dx, v + k[i] * dy, lds);
     sx += w[i] * s.x; sy += w[i] * s.y; sz += w[i] * s.z;
   }
   const float si = P[RPG_SUM_INV];
   return make_float4(sx * si, sy * si, sz * si, 1.0f);
 }
 
+template <class SI, class SO>
 __global__ void __launch_bounds__(256) k_royale_bloom_v(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
   RC_PIXEL_PROLOGUE;
   if (!inside) return;
-  const float4 c = blur17(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), 0.0f, L.params[RPG_DXY],
+  const float4 c = blur17<SI>(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), 0.0f, L.params[RPG_DXY],
                           L.params, &lds);
-  store_rt(L, z, x, y, c, &lds);
+  SO::put(L, z, x, y, c, &lds);
 }
 
 // bloom-horizontal-reconstitute.glsl FS 11407-11439.
 // extra[0] = PassPrev3 (MASKED_SCANLINES), extra[1] = PassPrev2 (BRIGHTPASS), extra[2] = PassPrev6 (HALATION_BLUR)
+template <class SI, class S0, class S1, class S2, class SO>
 __global__ void __launch_bounds__(256) k_royale_bloom_h(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
   RC_PIXEL_PROLOGUE;
   if (!inside) return;
-  const float4 blurred = blur17(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), L.params[RPG_DXY], 0.0f,
+  const float4 blurred = blur17<SI>(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), L.params[RPG_DXY], 0.0f,
                                 L.params, &lds);
-  const float4 idim = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), vary(L.plane[2], x, y, lo), vary(L.plane[3], x, y, lo), &lds);
-  const float4 bright = sample_rt(L.extra[1], frame_ptr(L.extra[1], z), vary(L.plane[4], x, y, lo), vary(L.plane[5], x, y, lo), &lds);
-  const float4 hal = sample_rt(L.extra[2], frame_ptr(L.extra[2], z), vary(L.plane[6], x, y, lo), vary(L.plane[7], x, y, lo), &lds);
+  const float4 idim = S0::get(L.extra[0], frame_ptr(L.extra[0], z), vary(L.plane[2], x, y, lo), vary(L.plane[3], x, y, lo), &lds);
+  const float4 bright = S1::get(L.extra[1], frame_ptr(L.extra[1], z), vary(L.plane[4], x, y, lo), vary(L.plane[5], x, y, lo), &lds);
+  const float4 hal = S2::get(L.extra[2], frame_ptr(L.extra[2], z), vary(L.plane[6], x, y, lo), vary(L.plane[7], x, y, lo), &lds);
   const float mask_amplify = L.params[RPG_MASK_AMPLIFY];
   const float i3[3] = {idim.x, idim.y, idim.z}, b3[3] = {bright.x, bright.y, bright.z}, bl[3] = {blurred.x, blurred.y, blurred.z};
   const float h3[3] = {hal.x, hal.y, hal.z};
@@ -405,11 +441,12 @@ __global__ void __launch_bounds__(256) k_royale_bloom_h(const PassLaunch L) {
     const float diffusion_color = 1.0f * h3[c];
     out[c] = phosphor_bloom * (1.0f - 0.075f) + diffusion_color * 0.075f;
   }
-  store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+  SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
 }
 
 // ------------------------------------------------------------------------------ P11 ------
 // geometry-aa-last-pass.glsl FS 5451-5531 (flat geometry path), get_border_dim_factor 5250.
+template <class SI, class SO>
 __global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
@@ -425,13 +462,13 @@ __global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
   const float fu = u * (tsx * vsix), fv = v * (tsy * vsiy);
   const float vu = (fu - 0.5f) / osx + 0.5f, vv = (fv - 0.5f) / osy + 0.5f;
   const float tu = vu * (tsx * vsix), tv = vv * (tsy * vsiy);
-  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), tu, tv, &lds);
+  const float4 c = SI::get(L.in, frame_ptr(L.in, z), tu, tv, &lds);
   const float ex = minps(vu, 1.0f - vu) * geom_aspect_x, ey = minps(vv, 1.0f - vv) * geom_aspect_y;
   const float bx = maxps(border_size - ex, 0.0f), by = maxps(border_size - ey, 0.0f);
   const float pen = __builtin_sqrtf(bx * bx + by * by) / border_size;
   const float esc = maxps(1.0f - pen, 0.0f);
   const float f = minps(pow_(esc, border_darkness) * maxps(1.0f, border_compress), 1.0f);
-  store_rt(L, z, x, y, make_float4(pow_(c.x * f, inv_gamma), pow_(c.y * f, inv_gamma), pow_(c.z * f, inv_gamma), 1.0f), &lds);
+  SO::put(L, z, x, y, make_float4(pow_(c.x * f, inv_gamma), pow_(c.y * f, inv_gamma), pow_(c.z * f, inv_gamma), 1.0f), &lds);
 }
 
 }  // namespace
@@ -443,14 +480,49 @@ namespace rck {
     return hipGetLastError();                                         \
   }
 RC_LAUNCH(launch_royale_first, k_royale_first)
-RC_LAUNCH(launch_royale_scan_v, k_royale_scan_v)
-RC_LAUNCH(launch_royale_bloom_approx, k_royale_bloom_approx)
-RC_LAUNCH(launch_blur9, k_blur9)
 RC_LAUNCH(launch_royale_mask_v, k_royale_mask_v)
 RC_LAUNCH(launch_royale_mask_h, k_royale_mask_h)
-RC_LAUNCH(launch_royale_scan_h, k_royale_scan_h)
-RC_LAUNCH(launch_royale_brightpass, k_royale_brightpass)
-RC_LAUNCH(launch_royale_bloom_v, k_royale_bloom_v)
-RC_LAUNCH(launch_royale_bloom_h, k_royale_bloom_h)
-RC_LAUNCH(launch_royale_last, k_royale_last)
+
+#define GO(...)                                                                 \
+  do {                                                                          \
+    hipLaunchKernelGGL((__VA_ARGS__), px_grid(L), px_block(), 0, s, L);          \
+    return hipGetLastError();                                                   \
+  } while (0)
+using OutS = St<FMT_SRGB8>;
+
+hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s) {
+  if (SrgbLinEdge::matches(L.in) && OutS::matches(L)) GO(k_royale_scan_v<SrgbLinEdge, OutS>);
+  GO(k_royale_scan_v<SRT, StRT>);
+}
+hipError_t launch_royale_bloom_approx(const PassLaunch& L, hipStream_t s) {
+  if (SrgbLinEdge::matches(L.extra[0]) && OutS::matches(L)) GO(k_royale_bloom_approx<SrgbLinEdge, OutS>);
+  GO(k_royale_bloom_approx<SRT, StRT>);
+}
+hipError_t launch_blur9(const PassLaunch& L, hipStream_t s) {
+  if (SrgbLinEdge::matches(L.in) && OutS::matches(L)) GO(k_blur9<SrgbLinEdge, OutS>);
+  GO(k_blur9<SRT, StRT>);
+}
+hipError_t launch_royale_scan_h(const PassLaunch& L, hipStream_t s) {
+  using MaskS = S<FMT_RGBA8, 0, WRAP_EDGE>;
+  if (MaskS::matches(L.in) && SrgbLinEdge::matches(L.extra[0]) && OutS::matches(L)) GO(k_royale_scan_h<MaskS, SrgbLinEdge, OutS>);
+  GO(k_royale_scan_h<SRT, SRT, StRT>);
+}
+hipError_t launch_royale_brightpass(const PassLaunch& L, hipStream_t s) {
+  if (SrgbNearEdge::matches(L.in) && SrgbLinEdge::matches(L.extra[0]) && OutS::matches(L)) GO(k_royale_brightpass<SrgbNearEdge, SrgbLinEdge, OutS>);
+  GO(k_royale_brightpass<SRT, SRT, StRT>);
+}
+hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s) {
+  if (SrgbNearEdge::matches(L.in) && OutS::matches(L)) GO(k_royale_bloom_v<SrgbNearEdge, OutS>);
+  GO(k_royale_bloom_v<SRT, StRT>);
+}
+hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
+  if (SrgbLinEdge::matches(L.in) && SrgbNearEdge::matches(L.extra[0]) && SrgbNearEdge::matches(L.extra[1]) &&
+      SrgbLinEdge::matches(L.extra[2]) && OutS::matches(L))
+    GO(k_royale_bloom_h<SrgbLinEdge, SrgbNearEdge, SrgbNearEdge, SrgbLinEdge, OutS>);
+  GO(k_royale_bloom_h<SRT, SRT, SRT, SRT, StRT>);
+}
+hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
+  if (SrgbLinEdge::matches(L.in) && St<FMT_RGBA8>::matches(L)) GO(k_royale_last<SrgbLinEdge, St<FMT_RGBA8>>);
+  GO(k_royale_last<SRT, StRT>);
+}
 }  // namespace rck

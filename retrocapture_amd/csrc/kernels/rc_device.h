@@ -147,6 +147,7 @@ __device__ __forceinline__ float vary(const Plane& p, int x, int y, bool lower) 
 struct SrgbLds {
   float dec[256];
   float thr[256];
+  uint32_t coarse[kSrgbCoarseWords];
 };
 // Every thread of the block must call this before sampling sRGB textures / storing sRGB.
 __device__ __forceinline__ void load_srgb_tables(SrgbLds& t) {
@@ -154,6 +155,8 @@ __device__ __forceinline__ void load_srgb_tables(SrgbLds& t) {
     t.dec[i] = k_srgb_decode[i];
     t.thr[i] = k_srgb_encode_thr[i];
   }
+  for (int i = threadIdx.y * blockDim.x + threadIdx.x; i < kSrgbCoarseWords; i += blockDim.x * blockDim.y)
+    t.coarse[i] = k_srgb_encode_coarse[i];
   __syncthreads();
 }
 
@@ -283,16 +286,19 @@ __device__ __forceinline__ uint32_t unorm8(float x) {
   x = x > 1.0f ? 1.0f : x;
   return (uint32_t)__builtin_rintf(x * 255.0f);
 }
-// count of thresholds <= x, thresholds ascending (255 entries + inf sentinel)
+// sRGB8 encode = number of thresholds <= x (255 ascending thresholds + an inf sentinel).
+// A coarse table indexed by the float's upper bits gives the count at the bucket's lower bound;
+// at most two more thresholds lie inside a bucket.
 __device__ __forceinline__ uint32_t srgb8(float x, const SrgbLds* t) {
-  if (!(x > 0.0f)) return 0u;
-  int lo = 0;
-#pragma unroll
-  for (int step = 128; step >= 1; step >>= 1) {
-    int probe = lo + step - 1;  // thresholds index
-    lo = (probe < 255 && t->thr[probe] <= x) ? lo + step : lo;
-  }
-  return (uint32_t)lo;
+  if (!(x > 0.0f)) return 0u;  // also NaN
+  if (x >= 1.0f) return 255u;
+  const uint32_t b = f2bits(x);
+  if (b < 0x39000000u) return 0u;  // below 2^-13 < first threshold
+  const uint32_t idx = (b - 0x39000000u) >> 15;
+  uint32_t k = (t->coarse[idx >> 2] >> ((idx & 3u) * 8u)) & 255u;
+  k += (t->thr[k] <= x) ? 1u : 0u;
+  k += (t->thr[k] <= x) ? 1u : 0u;
+  return k;
 }
 
 template <int OUT_FMT>
