@@ -132,7 +132,7 @@ typedef struct {
 } rc_pass_profile;
 void rc_engine_set_profiling(rc_engine* e, int on);
 int rc_engine_pass_profile(rc_engine* e, int pass, rc_pass_profile* out);
-/* Frames processed per kernel launch through the whole chain (default 4). */
+/* Frames processed per kernel launch through the whole chain (default 8). */
 void rc_engine_set_chunk_frames(rc_engine* e, uint32_t n);
 /* 1: a pass whose .glsl file is unreadable still runs if its shader identity is registered
  * (built-in parameter table).  Default 0 = the reference's behaviour (pass fails). */

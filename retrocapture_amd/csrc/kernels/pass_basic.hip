@@ -13,29 +13,27 @@ namespace {
 __global__ void __launch_bounds__(256) k_stock(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, z = blockIdx.z;
-  if (x >= L.out_w || y >= L.out_h) return;
-  const bool lo = lower_tri(x, y, L.out_w, L.out_h);
+  RC_TILE_LOOP_BEGIN
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
   store_rt(L, z, x, y, sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds), &lds);
+  RC_TILE_LOOP_END
 }
 
 // params: SCANLINE_BASE_BRIGHTNESS, SCANLINE_SINE_COMP_A, SCANLINE_SINE_COMP_B, size
 __global__ void __launch_bounds__(256) k_scanline(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, z = blockIdx.z;
-  if (x >= L.out_w || y >= L.out_h) return;
+  RC_TILE_LOOP_BEGIN
   const float base = L.params[0], comp_a = L.params[1], comp_b = L.params[2], size = L.params[3];
   const float pi = 3.141592654f;
   const float omega_x = (pi * size) * (float)L.out_w;
   const float omega_y = (2.0f * pi) * (float)L.in.h;
-  const bool lo = lower_tri(x, y, L.out_w, L.out_h);
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
   const float4 res = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
   const float d = comp_a * sin_(u * omega_x) + comp_b * sin_(v * omega_y);
   const float k = base + d;
   store_rt(L, z, x, y, make_float4(res.x * k, res.y * k, res.z * k, 1.0f), &lds);
+  RC_TILE_LOOP_END
 }
 
 __device__ __forceinline__ float crtpi_weight(float dist, float sw, float gap) {
@@ -50,14 +48,12 @@ template <int IN_FMT, int IN_LINEAR, int IN_WRAP, int OUT_FMT, bool GENERIC>
 __global__ void __launch_bounds__(256) k_crt_pi(const PassLaunch L) {
   __shared__ SrgbLds lds;
   if (GENERIC || IN_FMT == FMT_SRGB8 || OUT_FMT == FMT_SRGB8) load_srgb_tables(lds);
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, z = blockIdx.z;
-  if (x >= L.out_w || y >= L.out_h) return;
+  RC_TILE_LOOP_BEGIN
   const float mask_b = L.params[2], sw = L.params[3], gap = L.params[4], bloom = L.params[5];
   const float in_gamma = L.params[6], out_gamma = L.params[7];
   const float tsy = (float)L.in.h;
   const float filter_width = (tsy / (float)L.out_h) / 3.0f;
   const float inv_out_gamma = 1.0f / out_gamma;
-  const bool lo = lower_tri(x, y, L.out_w, L.out_h);
   const float tcx = vary(L.plane[0], x, y, lo), tcy = vary(L.plane[1], x, y, lo);
   const float pix_y = tcy * tsy;
   const float temp_y = __builtin_floorf(pix_y) + 0.5f;
@@ -94,6 +90,7 @@ __global__ void __launch_bounds__(256) k_crt_pi(const PassLaunch L) {
   }
   if (GENERIC) store_rt(L, z, x, y, o, &lds);
   else store<OUT_FMT>(L, z, x, y, o, &lds);
+  RC_TILE_LOOP_END
 }
 
 }  // namespace

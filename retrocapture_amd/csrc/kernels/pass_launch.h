@@ -24,10 +24,13 @@ hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s);
 
-// 64x4 pixel workgroups: one wave per target row segment, 4 rows per group, so each wave
-// stores 256 contiguous bytes of an RGBA8 row.
+// 64x4 pixel tiles: one wave per row segment, so each wave stores 256 contiguous bytes of an
+// RGBA8 row.  A workgroup walks tiles grid-stride (tile index = frame, tile row, tile column),
+// which amortises its prologue (sRGB tables into LDS) over many tiles; the grid is capped at
+// 8 workgroups per CU on a 256-CU part.
 inline dim3 px_block() { return dim3(64, 4, 1); }
 inline dim3 px_grid(const PassLaunch& L) {
-  return dim3((unsigned)((L.out_w + 63) / 64), (unsigned)((L.out_h + 3) / 4), (unsigned)L.n_frames);
+  const long tiles = (long)((L.out_w + 63) / 64) * ((L.out_h + 3) / 4) * L.n_frames;
+  return dim3((unsigned)(tiles < 2048 ? (tiles > 0 ? tiles : 1) : 2048), 1, 1);
 }
 }  // namespace rck

@@ -49,11 +49,6 @@ struct StRT {
 using SrgbLinEdge = S<FMT_SRGB8, 1, WRAP_EDGE>;
 using SrgbNearEdge = S<FMT_SRGB8, 0, WRAP_EDGE>;
 
-#define RC_PIXEL_PROLOGUE                                                                   \
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, z = blockIdx.z; \
-  const bool inside = x < L.out_w && y < L.out_h;                                             \
-  const bool lo = lower_tri(x, y, L.out_w, L.out_h)
-
 constexpr float kUnderHalf = 0.4995f;
 
 // ------------------------------------------------------------------------------- P0 ------
@@ -68,8 +63,7 @@ __global__ void __launch_bounds__(256) k_royale_first(const PassLaunch L) {
     lin[t] = pow_((float)t * (1.0f / 255.0f), 2.5f);
   }
   __syncthreads();
-  RC_PIXEL_PROLOGUE;
-  if (!inside) return;
+  RC_TILE_LOOP_BEGIN
   const float tsy = (float)L.in.h;
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
   const uint8_t* img = frame_ptr(L.in, z);
@@ -102,6 +96,7 @@ __global__ void __launch_bounds__(256) k_royale_first(const PassLaunch L) {
   }
   // progressive source: modulus 1 makes wrong_field exactly 0, and cur + 0*(interp - cur) == cur
   store_rt(L, z, x, y, o, &lds);
+  RC_TILE_LOOP_END
 }
 
 // ------------------------------------------------------------------------------- P1 ------
@@ -111,8 +106,9 @@ __device__ __forceinline__ float gamma_impl1(float s, float s_inv) {
   const float c1 = 0.4808354605142681877121661197951496120000040f, e = 2.71828182845904523536028747135266249775724709f;
   const float sph = s + 0.5f;
   const float lanczos_sum = c0 + c1 / (s + 1.0f);
-  const float base = (sph + g) / e;
-  return (pow_(base, sph) * lanczos_sum) * s_inv;
+  // base is in [0.69, 0.78] for s = 1/beta in [1/4, 1/2]: a positive normal, no log2 edge cases
+  const float base = div_const_(sph + g, e, 1.0f / e);
+  return (exp2_(log2_core_(base) * sph) * lanczos_sum) * s_inv;
 }
 
 struct BeamShape {  // per (scanline colour, channel): everything that does not depend on dist
@@ -128,23 +124,25 @@ __device__ __forceinline__ BeamShape beam_shape(float color, float sigma_range, 
   b.beta = beta;
   const float beta_inv = 1.0f / beta;
   const float scale = color * beta * 0.5f * b.alpha_inv / gamma_impl1(beta_inv, beta);
-  b.scale3 = scale / 3.0f;
+  b.scale3 = div_const_(scale, 3.0f, 1.0f / 3.0f);
   return b;
 }
 __device__ __forceinline__ float beam_contrib(const BeamShape& b, float dist, float off) {
   const float d2 = dist + off, d3 = __builtin_fabsf(dist - off);
-  const float w1 = exp_(-pow_(__builtin_fabsf(dist * b.alpha_inv), b.beta));
-  const float w2 = exp_(-pow_(__builtin_fabsf(d2 * b.alpha_inv), b.beta));
-  const float w3 = exp_(-pow_(__builtin_fabsf(d3 * b.alpha_inv), b.beta));
+  // pow(a, beta) with a >= 0 and beta in [2, 4]: for a zero or denormal `a` the full log2 returns
+  // -inf and the core returns a value <= -126; times beta both are below exp2's clamp and give
+  // exactly 0, so the edge-case selects of log2 are not needed here.
+  const float w1 = exp_(-exp2_(log2_core_(__builtin_fabsf(dist * b.alpha_inv)) * b.beta));
+  const float w2 = exp_(-exp2_(log2_core_(__builtin_fabsf(d2 * b.alpha_inv)) * b.beta));
+  const float w3 = exp_(-exp2_(log2_core_(__builtin_fabsf(d3 * b.alpha_inv)) * b.beta));
   return b.scale3 * (w1 + w2 + w3);
 }
 
 template <class SI, class SO>
-__global__ void __launch_bounds__(256) k_royale_scan_v(const PassLaunch L) {
+__global__ void __launch_bounds__(256, 8) k_royale_scan_v(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
-  RC_PIXEL_PROLOGUE;
-  if (!inside) return;
+  RC_TILE_LOOP_BEGIN
   const float tsx = (float)L.in.w, tsy = (float)L.in.h;
   const float y_step = L.params[RP1_Y_STEP], uv_step_y = L.params[RP1_UV_STEP_Y], ph = L.params[RP1_PH];
   const float tix = 1.0f / tsx, tiy = 1.0f / tsy;
@@ -182,6 +180,7 @@ __global__ void __launch_bounds__(256) k_royale_scan_v(const PassLaunch L) {
     out[ch] = inten * 0.5f;
   }
   SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+  RC_TILE_LOOP_END
 }
 
 // ------------------------------------------------------------------------------- P2 ------
@@ -190,10 +189,10 @@ template <class S0, class SO>
 __global__ void __launch_bounds__(256) k_royale_bloom_approx(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
-  RC_PIXEL_PROLOGUE;
-  if (!inside) return;
+  RC_TILE_LOOP_BEGIN
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
   SO::put(L, z, x, y, S0::get(L.extra[0], frame_ptr(L.extra[0], z), u, v, &lds), &lds);
+  RC_TILE_LOOP_END
 }
 
 // -------------------------------------------------------------------------- P3 / P4 ------
@@ -203,8 +202,7 @@ template <class SI, class SO>
 __global__ void __launch_bounds__(256) k_blur9(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
-  RC_PIXEL_PROLOGUE;
-  if (!inside) return;
+  RC_TILE_LOOP_BEGIN
   const float w12 = L.params[RPB_W12], w34 = L.params[RPB_W34], k12 = L.params[RPB_K12], k34 = L.params[RPB_K34];
   const float sum_inv = L.params[RPB_SUM_INV], dx = L.params[RPB_DX], dy = L.params[RPB_DY];
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
@@ -221,6 +219,7 @@ __global__ void __launch_bounds__(256) k_blur9(const PassLaunch L) {
   sx += w12 * s3.x; sy += w12 * s3.y; sz += w12 * s3.z;
   sx += w34 * s4.x; sy += w34 * s4.y; sz += w34 * s4.z;
   SO::put(L, z, x, y, make_float4(sx * sum_inv, sy * sum_inv, sz * sum_inv, 1.0f), &lds);
+  RC_TILE_LOOP_END
 }
 
 // -------------------------------------------------------------------------- P5 / P6 ------
@@ -268,8 +267,7 @@ __device__ __forceinline__ float4 sinc_tiled(const Tex& t, const uint8_t* img, f
 __global__ void __launch_bounds__(256) k_royale_mask_v(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
-  RC_PIXEL_PROLOGUE;
-  if (!inside) return;
+  RC_TILE_LOOP_BEGIN
   const float wu = vary(L.plane[0], x, y, lo), wv = vary(L.plane[1], x, y, lo);
   uint8_t* o = static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z;
   if (wv <= 2.0f) {  // mask_resize_num_tiles
@@ -279,24 +277,25 @@ __global__ void __launch_bounds__(256) k_royale_mask_v(const PassLaunch L) {
   } else {  // discard: the target keeps its clear colour (0,0,0,0)
     *reinterpret_cast<uint32_t*>(o + ((size_t)y * L.out_w + x) * texel_bytes(L.out_fmt)) = 0u;
   }
+  RC_TILE_LOOP_END
 }
 
 __global__ void __launch_bounds__(256) k_royale_mask_h(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
-  RC_PIXEL_PROLOGUE;
-  if (!inside) return;
+  RC_TILE_LOOP_BEGIN
   uint8_t* o = static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z;
   if (!(L.flags & RC_FLAG_UNDEF_VARYING_ZERO)) {
     // The fragment shader's keep/discard test reads a varying that its vertex shader never
     // writes; on the GL this engine is matched against, that discards every fragment.
     *reinterpret_cast<uint32_t*>(o + ((size_t)y * L.out_w + x) * 4) = 0u;
-    return;
+    continue;
   }
   const float wu = vary(L.plane[0], x, y, lo), wv = vary(L.plane[1], x, y, lo);
   const float4 c = sinc_tiled<false>(L.in, frame_ptr(L.in, z), fractf(wv), fractf(wu), (float)L.in.w, L.params[RP6_SRC_DX],
                                      L.params[RP6_MAG_X], L.params[RP6_TILE_SIZE_UV_X], &lds);
   store_rt(L, z, x, y, c, &lds);
+  RC_TILE_LOOP_END
 }
 
 // ------------------------------------------------------------------------------- P7 ------
@@ -325,8 +324,7 @@ template <class SI, class S0, class SO>
 __global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
-  RC_PIXEL_PROLOGUE;
-  if (!inside) return;
+  RC_TILE_LOOP_BEGIN
   const float vu = vary(L.plane[0], x, y, lo), vv = vary(L.plane[1], x, y, lo);
   const float twx = vu * L.params[RP7_TPS_X], twy = vv * L.params[RP7_TPS_Y];
   const float tux = fractf(twx * 0.5f) * 2.0f, tuy = fractf(twy * 0.5f) * 2.0f;
@@ -346,6 +344,7 @@ __global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
     o = make_float4(sc[0] * mask.x, sc[1] * mask.y, sc[2] * mask.z, 1.0f);
   }
   SO::put(L, z, x, y, o, &lds);
+  RC_TILE_LOOP_END
 }
 
 // ------------------------------------------------------------------------------- P8 ------
@@ -354,8 +353,7 @@ template <class SI, class S0, class SO>
 __global__ void __launch_bounds__(256) k_royale_brightpass(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
-  RC_PIXEL_PROLOGUE;
-  if (!inside) return;
+  RC_TILE_LOOP_BEGIN
   const float4 idim = SI::get(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
   float4 o = make_float4(0.f, 0.f, 0.f, 1.0f);
   // brightpass = intensity_dim * ratio: a zero (or NaN-producing) input stores 0 whatever the ratio
@@ -377,6 +375,7 @@ __global__ void __launch_bounds__(256) k_royale_brightpass(const PassLaunch L) {
     o = make_float4(out[0], out[1], out[2], 1.0f);
   }
   SO::put(L, z, x, y, o, &lds);
+  RC_TILE_LOOP_END
 }
 
 // ------------------------------------------------------------------------ P9 / P10 ------
@@ -410,21 +409,20 @@ template <class SI, class SO>
 __global__ void __launch_bounds__(256) k_royale_bloom_v(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
-  RC_PIXEL_PROLOGUE;
-  if (!inside) return;
+  RC_TILE_LOOP_BEGIN
   const float4 c = blur17<SI>(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), 0.0f, L.params[RPG_DXY],
                           L.params, &lds);
   SO::put(L, z, x, y, c, &lds);
+  RC_TILE_LOOP_END
 }
 
 // bloom-horizontal-reconstitute.glsl FS 11407-11439.
 // extra[0] = PassPrev3 (MASKED_SCANLINES), extra[1] = PassPrev2 (BRIGHTPASS), extra[2] = PassPrev6 (HALATION_BLUR)
 template <class SI, class S0, class S1, class S2, class SO>
-__global__ void __launch_bounds__(256) k_royale_bloom_h(const PassLaunch L) {
+__global__ void __launch_bounds__(256, 4) k_royale_bloom_h(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
-  RC_PIXEL_PROLOGUE;
-  if (!inside) return;
+  RC_TILE_LOOP_BEGIN
   const float4 blurred = blur17<SI>(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), L.params[RPG_DXY], 0.0f,
                                 L.params, &lds);
   const float4 idim = S0::get(L.extra[0], frame_ptr(L.extra[0], z), vary(L.plane[2], x, y, lo), vary(L.plane[3], x, y, lo), &lds);
@@ -442,6 +440,7 @@ __global__ void __launch_bounds__(256) k_royale_bloom_h(const PassLaunch L) {
     out[c] = phosphor_bloom * (1.0f - 0.075f) + diffusion_color * 0.075f;
   }
   SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+  RC_TILE_LOOP_END
 }
 
 // ------------------------------------------------------------------------------ P11 ------
@@ -450,8 +449,7 @@ template <class SI, class SO>
 __global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
-  RC_PIXEL_PROLOGUE;
-  if (!inside) return;
+  RC_TILE_LOOP_BEGIN
   const float tsx = (float)L.in.w, tsy = (float)L.in.h;
   const float* P = L.params;
   const float lcd_gamma = P[1], osx = P[37], osy = P[38], border_size = P[39], border_darkness = P[40], border_compress = P[41];
@@ -469,6 +467,7 @@ __global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
   const float esc = maxps(1.0f - pen, 0.0f);
   const float f = minps(pow_(esc, border_darkness) * maxps(1.0f, border_compress), 1.0f);
   SO::put(L, z, x, y, make_float4(pow_(c.x * f, inv_gamma), pow_(c.y * f, inv_gamma), pow_(c.z * f, inv_gamma), 1.0f), &lds);
+  RC_TILE_LOOP_END
 }
 
 }  // namespace

@@ -92,6 +92,29 @@ RC_HD float log2_(float x) {
   return fma_(y, p, logexp);
 }
 
+// log2_ without the zero / negative / infinity selects, for arguments known to be positive
+// normal numbers, or where the caller proves the selects cannot change its own result.
+RC_HD float log2_core_(float x) {
+  uint32_t i = f2bits(x);
+  float logexp = (float)((int32_t)((i & 0x7f800000u) >> 23) - 127);
+  float mant = bits2f((i & 0x007fffffu) | 0x3f800000u);
+  float y = (mant - 1.0f) / (mant + 1.0f);
+  float z = y * y;
+  float z2 = z * z;
+  float even = fma_(z2, 0.406718052498846252698f, 0.577440339438736392009f);
+  even = fma_(z2, even, 2.88539009343309178325f);
+  float odd = fma_(z2, 0.403343858251329912514f, 0.961791550404184197881f);
+  float p = fma_(odd, z, even);
+  return fma_(y, p, logexp);
+}
+// x / c for a compile-time constant c with rc = RN(1/c): one multiply and one fused correction
+// step give the correctly rounded quotient (checked exhaustively over every mantissa for
+// c = e and c = 3; quotients scale exactly across binades away from overflow / underflow).
+RC_HD float div_const_(float x, float c, float rc) {
+  float q = x * rc;
+  float r = fma_(-c, q, x);
+  return fma_(r, rc, q);
+}
 RC_HD float pow_(float x, float y) { return exp2_(log2_(x) * y); }
 RC_HD float exp_(float x) { return exp2_(x * 1.4426950408889634f); }
 RC_HD float log_(float x) { return log2_(x) * 0.69314718055994529f; }
@@ -316,6 +339,21 @@ __device__ __forceinline__ void store(const PassLaunch& L, int z, int x, int y, 
 }
 
 }  // namespace rcd
+
+// Grid-stride walk over the 64x4 tiles of all frames of a launch (see pass_launch.h).  Defines
+// x, y, z (frame) and `lo` (triangle of the quad the pixel centre falls in) for the body.
+#define RC_TILE_LOOP_BEGIN                                                              \
+  const int tiles_x_ = (L.out_w + 63) >> 6, tiles_y_ = (L.out_h + 3) >> 2;               \
+  const int tiles_per_frame_ = tiles_x_ * tiles_y_;                                     \
+  const int n_tiles_ = tiles_per_frame_ * L.n_frames;                                   \
+  for (int tile_ = blockIdx.x; tile_ < n_tiles_; tile_ += gridDim.x) {                  \
+    const int z = tile_ / tiles_per_frame_;                                             \
+    const int rem_ = tile_ - z * tiles_per_frame_;                                      \
+    const int ty_ = rem_ / tiles_x_;                                                    \
+    const int x = (rem_ - ty_ * tiles_x_) * 64 + (int)threadIdx.x, y = ty_ * 4 + (int)threadIdx.y; \
+    if (x >= L.out_w || y >= L.out_h) continue;                                         \
+    const bool lo = rcd::lower_tri(x, y, L.out_w, L.out_h);
+#define RC_TILE_LOOP_END }
 
 namespace rcd {
 // Run-time selected sampler (all selectors are wave-uniform kernel arguments, so the

@@ -140,7 +140,7 @@ class ShaderEngine {
   float m_frameCount = 0.0f;
   float m_time = 0.0f;
   bool m_inputLinear = false;
-  uint32_t m_chunk = 4;
+  uint32_t m_chunk = 8;
   uint32_t m_lastChunkFrames = 0;
   uint32_t m_lastChunkFirst = 0;
   bool m_singleShader = false;
