@@ -113,6 +113,10 @@ void o_pass_royale_brightpass(const o_pass_args* a);  /* P8  brightpass; extra[0
 void o_pass_royale_bloom_v(const o_pass_args* a);     /* P9  bloom-vertical */
 void o_pass_royale_bloom_h(const o_pass_args* a);     /* P10 bloom-horizontal-reconstitute; extra = PassPrev3, PassPrev2, PassPrev6 */
 void o_pass_royale_last(const o_pass_args* a);        /* P11 geometry-aa-last-pass; 44 params */
+/* ntsc/ntsc-256px-svideo.glslp (2 passes) and xbr/xbr-lv3.glslp (1 pass) */
+void o_pass_ntsc_pass1_svideo_3phase(const o_pass_args* a);
+void o_pass_ntsc_pass2_3phase_gamma(const o_pass_args* a);
+void o_pass_xbr_lv3(const o_pass_args* a);            /* 5 params */
 void o_store_pixel(const o_pass_args* a, int x, int y, o_vec4 c);
 
 #ifdef __cplusplus

@@ -1,0 +1,281 @@
+/* TEST INFRASTRUCTURE - see rc_oracle.h.
+ *
+ * Hand restatement of the arithmetic of three more reference shader assets:
+ *   ntsc pass 1  shaders/shaders_glsl/ntsc/shaders/ntsc-pass1-svideo-3phase.glsl (VS 64-70, FS 147-166)
+ *   ntsc pass 2  shaders/shaders_glsl/ntsc/shaders/ntsc-pass2-3phase-gamma.glsl  (VS 44-49, FS 215-281;
+ *                the file keeps "#version 130", so the unrolled macro_loopz branch is the one compiled)
+ *   xbr-lv3      shaders/shaders_glsl/xbr/shaders/xbr-lv3.glsl                   (VS 77-100, FS 171-352)
+ * Operation order follows what Mesa's GLSL->NIR lowering produces (measured with
+ * oracle/_ref/glprobe): vec*mat is a dot per column evaluated x*c0 + (y*c1 + z*c2);
+ * mat*vec accumulates columns left to right; mod(x,c) = x - c*floor(x/c) with a true
+ * division; smoothstep with constant edges divides by the folded (e1-e0); nothing is fused.
+ */
+#include <math.h>
+
+#include "rc_oracle.h"
+
+/* ------------------------------------------------------------------------- ntsc pass 1 -- */
+static void ntsc_pass1_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float tsx = (float)a->in->w, tsy = (float)a->in->h; /* TextureSize == InputSize */
+  /* VS :69  pix_no = vTexCoord * SourceSize.xy * (outsize.xy / InputSize.xy) */
+  const float px1 = (1.0f * tsx) * ((float)W / tsx), py1 = (1.0f * tsy) * ((float)H / tsy);
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt);
+  o_varying tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  o_varying pu = o_varying_setup(0.f, px1, px1, 0.f, W, H, a->out_fmt);
+  o_varying pv = o_varying_setup(0.f, 0.f, py1, py1, W, H, a->out_fmt);
+  const float k_phase = 0.6667f * 3.14159265f;    /* folded constant */
+  const float k_freq = 3.14159265f / 3.0f;        /* CHROMA_MOD_FREQ */
+  const float fc = (float)a->frame_count;
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      float pnx = o_varying_at(&pu, x, y, lo), pny = o_varying_at(&pv, x, y, lo);
+      o_vec4 col = o_sample(a->in, u, v);
+      /* rgb2yiq: col * yiq_mat */
+      float yy = col.x * 0.2989f + (col.y * 0.5870f + col.z * 0.1140f);
+      float ii = col.x * 0.5959f + (col.y * -0.2744f + col.z * -0.3216f);
+      float qq = col.x * 0.2115f + (col.y * -0.5229f + col.z * 0.3114f);
+      float m3 = pny - 3.0f * floorf(pny / 3.0f);
+      float chroma_phase = k_phase * (m3 + fc);
+      float mod_phase = chroma_phase + pnx * k_freq;
+      float i_mod = o_cos(mod_phase), q_mod = o_sin(mod_phase);
+      ii *= i_mod; qq *= q_mod;           /* modulate */
+      ii *= 2.0f; qq *= 2.0f;             /* mix_mat = diag(1, 2, 2) for SVIDEO */
+      ii *= i_mod; qq *= q_mod;           /* demodulate */
+      o_vec4 o = {yy, ii, qq, 1.0f};
+      o_store_pixel(a, x, y, o);
+    }
+}
+void o_pass_ntsc_pass1_svideo_3phase(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  ntsc_pass1_body(a);
+  o_fp_leave(csr);
+}
+
+/* ------------------------------------------------------------------------- ntsc pass 2 -- */
+static const float k_luma[25] = {
+    -0.000012020f, -0.000022146f, -0.000013155f, -0.000012020f, -0.000049979f, -0.000113940f, -0.000122150f,
+    -0.000005612f, 0.000170516f,  0.000237199f,  0.000169640f,  0.000285688f,  0.000984574f,  0.002018683f,
+    0.002002275f,  -0.000909882f, -0.007049081f, -0.013222860f, -0.012606931f, 0.002460860f,  0.035868225f,
+    0.084016453f,  0.135563500f,  0.175261268f,  0.190176552f};
+static const float k_chroma[25] = {
+    -0.000118847f, -0.000271306f, -0.000502642f, -0.000930833f, -0.001451013f, -0.002064744f, -0.002700432f,
+    -0.003241276f, -0.003524948f, -0.003350284f, -0.002491729f, -0.000721149f, 0.002164659f,  0.006313635f,
+    0.011789103f,  0.018545660f,  0.026414396f,  0.035100710f,  0.044196567f,  0.053207202f,  0.061590275f,
+    0.068803602f,  0.074356193f,  0.077856564f,  0.079052396f};
+
+static void ntsc_pass2_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float tsx = (float)a->in->w;
+  /* VS :48  TEX0.xy = TexCoord.xy - vec2(0.5 / SourceSize.x, 0.0) */
+  const float sh = 0.5f / tsx;
+  o_varying tu = o_varying_setup(0.f - sh, 1.f - sh, 1.f - sh, 0.f - sh, W, H, a->out_fmt);
+  o_varying tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  const float one_x = 1.0f / tsx;
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      float sy = 0.f, si = 0.f, sq = 0.f;
+      for (int c = 1; c <= 24; ++c) {
+        float off = (float)(c - 25);
+        o_vec4 p = o_sample(a->in, u + off * one_x, v);
+        o_vec4 n = o_sample(a->in, u + (-off) * one_x, v);
+        sy = sy + (p.x + n.x) * k_luma[c - 1];
+        si = si + (p.y + n.y) * k_chroma[c - 1];
+        sq = sq + (p.z + n.z) * k_chroma[c - 1];
+      }
+      o_vec4 m = o_sample(a->in, u, v);
+      sy = sy + m.x * k_luma[24];
+      si = si + m.y * k_chroma[24];
+      sq = sq + m.z * k_chroma[24];
+      /* yiq2rgb: signal * yiq2rgb_mat */
+      float r = sy * 1.0f + (si * 0.956f + sq * 0.6210f);
+      float g = sy * 1.0f + (si * -0.2720f + sq * -0.6474f);
+      float b = sy * 1.0f + (si * -1.1060f + sq * 1.7046f);
+      const float gm = 2.5f / 2.0f;
+      o_vec4 o = {o_pow(r, gm), o_pow(g, gm), o_pow(b, gm), 1.0f};
+      o_store_pixel(a, x, y, o);
+    }
+}
+void o_pass_ntsc_pass2_3phase_gamma(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  ntsc_pass2_body(a);
+  o_fp_leave(csr);
+}
+
+/* ----------------------------------------------------------------------------- xbr-lv3 -- */
+typedef struct { float v[4]; } f4;
+typedef struct { int v[4]; } b4;
+
+static inline f4 f4_df(f4 A, f4 B) { f4 r; for (int k = 0; k < 4; ++k) r.v[k] = fabsf(A.v[k] - B.v[k]); return r; }
+static inline b4 b4_lt(f4 A, float t) { b4 r; for (int k = 0; k < 4; ++k) r.v[k] = A.v[k] < t; return r; }
+static inline b4 b4_and(b4 A, b4 B) { b4 r; for (int k = 0; k < 4; ++k) r.v[k] = A.v[k] && B.v[k]; return r; }
+static inline b4 b4_or(b4 A, b4 B) { b4 r; for (int k = 0; k < 4; ++k) r.v[k] = A.v[k] || B.v[k]; return r; }
+static inline b4 b4_not(b4 A) { b4 r; for (int k = 0; k < 4; ++k) r.v[k] = !A.v[k]; return r; }
+static inline b4 b4_ne(f4 A, f4 B) { b4 r; for (int k = 0; k < 4; ++k) r.v[k] = A.v[k] != B.v[k]; return r; }
+static inline f4 sw(f4 A, int i0, int i1, int i2, int i3) { f4 r = {{A.v[i0], A.v[i1], A.v[i2], A.v[i3]}}; return r; }
+#define YZWX(A) sw(A, 1, 2, 3, 0)
+#define WXYZ(A) sw(A, 3, 0, 1, 2)
+#define ZWXY(A) sw(A, 2, 3, 0, 1)
+
+/* transpose(mat4x3(P0,P1,P2,P3)) * w  (FS :230-246) */
+static inline f4 lum4(o_vec4 p0, o_vec4 p1, o_vec4 p2, o_vec4 p3, const float* w) {
+  f4 r;
+  r.v[0] = (p0.x * w[0] + p0.y * w[1]) + p0.z * w[2];
+  r.v[1] = (p1.x * w[0] + p1.y * w[1]) + p1.z * w[2];
+  r.v[2] = (p2.x * w[0] + p2.y * w[1]) + p2.z * w[2];
+  r.v[3] = (p3.x * w[0] + p3.y * w[1]) + p3.z * w[2];
+  return r;
+}
+/* weighted_distance (FS :166-169).  The GLSL compiler rebalances the five-term sum into
+ * ((ab + ac) + (de + df)) + 4*gh (the only association of all 5-leaf trees that matches llvmpipe
+ * on a noise image; measured). */
+static inline f4 wd(f4 a, f4 b, f4 c, f4 d, f4 e, f4 f, f4 g, f4 h) {
+  f4 ab = f4_df(a, b), ac = f4_df(a, c), de = f4_df(d, e), dff = f4_df(d, f), gh = f4_df(g, h), r;
+  for (int k = 0; k < 4; ++k) r.v[k] = ((ab.v[k] + ac.v[k]) + (de.v[k] + dff.v[k])) + 4.0f * gh.v[k];
+  return r;
+}
+/* smoothstep(C - delta, C + delta, A*fp.y + B*fp.x) (FS :267-271, :302-306).  The edges fold to
+ * constants and the compiler moves the additive constant inward: the numerator is evaluated as
+ * (A*fy - e0) + B*fx (measured on every component of the five calls), except where A = B = -1
+ * (fx45.z), whose sum is first rewritten as -(fy + fx) and keeps the outer subtraction. */
+static inline f4 line_sstep(const float* A, const float* B, const float* C, float fy, float fx) {
+  f4 r;
+  for (int k = 0; k < 4; ++k) {
+    const float e0 = C[k] - 0.4f, e1 = C[k] + 0.4f;
+    float num;
+    if (A[k] == -1.0f && B[k] == -1.0f) num = (A[k] * fy + B[k] * fx) - e0;
+    else num = (A[k] * fy - e0) + B[k] * fx;
+    float t = num / (e1 - e0);
+    t = t > 0.0f ? t : 0.0f;
+    t = t < 1.0f ? t : 1.0f;
+    r.v[k] = t * (t * (3.0f - 2.0f * t));
+  }
+  return r;
+}
+static inline o_vec4 mix3(o_vec4 a, o_vec4 b, float t) {
+  o_vec4 r = {a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z), 1.0f};
+  return r;
+}
+static inline float c_df(o_vec4 a, o_vec4 b) {
+  return (fabsf(a.x - b.x) + fabsf(a.y - b.y)) + fabsf(a.z - b.z);
+}
+
+/* params: XBR_Y_WEIGHT, XBR_EQ_THRESHOLD, XBR_EQ_THRESHOLD2, XBR_LV2_COEFFICIENT, corner_type */
+static void xbr_lv3_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float yw = a->params[0], thr = a->params[1], thr2 = a->params[2], lv2 = a->params[3], corner = a->params[4];
+  const float tsx = (float)a->in->w, tsy = (float)a->in->h;
+  /* VS :82-99 */
+  const float dx = 1.0f / tsx, dy = 1.0f / tsy;
+  const float xoff[5] = {-2.0f * dx, -dx, 0.0f, dx, 2.0f * dx};
+  const float yoff[5] = {-2.0f * dy, -dy, 0.0f, dy, 2.0f * dy};
+  o_varying vx[5], vy[5];
+  for (int k = 0; k < 5; ++k) {
+    vx[k] = o_varying_setup(0.f + xoff[k], 1.f + xoff[k], 1.f + xoff[k], 0.f + xoff[k], W, H, a->out_fmt);
+    vy[k] = o_varying_setup(0.f + yoff[k], 0.f + yoff[k], 1.f + yoff[k], 1.f + yoff[k], W, H, a->out_fmt);
+  }
+  const float w[3] = {yw * 0.299f, yw * 0.587f, yw * 0.114f};
+  static const float Ao[4] = {1.0f, -1.0f, -1.0f, 1.0f}, Bo[4] = {1.0f, 1.0f, -1.0f, -1.0f}, Co[4] = {1.5f, 0.5f, -0.5f, 0.5f};
+  static const float Bx[4] = {0.5f, 2.0f, -0.5f, -2.0f}, Cx[4] = {1.0f, 1.0f, -0.5f, 0.0f};
+  static const float By[4] = {2.0f, 0.5f, -2.0f, -0.5f}, Cy[4] = {2.0f, 0.0f, -1.0f, 0.5f};
+  static const float Az[4] = {6.0f, -2.0f, -6.0f, 2.0f}, Bz[4] = {2.0f, 6.0f, -2.0f, -6.0f}, Cz[4] = {5.0f, 3.0f, -3.0f, -1.0f};
+  static const float Aw[4] = {2.0f, -6.0f, -2.0f, 6.0f}, Bw[4] = {6.0f, 2.0f, -6.0f, -2.0f}, Cw[4] = {5.0f, -1.0f, -3.0f, 3.0f};
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      float cx[5], cy[5];
+      for (int k = 0; k < 5; ++k) {
+        cx[k] = o_varying_at(&vx[k], x, y, lo);
+        cy[k] = o_varying_at(&vy[k], x, y, lo);
+      }
+      float fpx = cx[2] * tsx, fpy = cy[2] * tsy;
+      fpx = fpx - floorf(fpx);
+      fpy = fpy - floorf(fpy);
+#define T(i, j) o_sample(a->in, cx[i], cy[j])
+      o_vec4 A1 = T(1, 0), B1 = T(2, 0), C1 = T(3, 0);
+      o_vec4 A = T(1, 1), B = T(2, 1), C = T(3, 1);
+      o_vec4 D = T(1, 2), E = T(2, 2), F = T(3, 2);
+      o_vec4 G = T(1, 3), Hh = T(2, 3), I = T(3, 3);
+      o_vec4 G5 = T(1, 4), H5 = T(2, 4), I5 = T(3, 4);
+      o_vec4 A0 = T(0, 1), D0 = T(0, 2), G0 = T(0, 3);
+      o_vec4 C4 = T(4, 1), F4 = T(4, 2), I4 = T(4, 3);
+#undef T
+      f4 b = lum4(B, D, Hh, F, w), c = lum4(C, A, G, I, w), e = lum4(E, E, E, E, w);
+      f4 d = YZWX(b), f = WXYZ(b), g = ZWXY(c), h = ZWXY(b), i = WXYZ(c);
+      f4 i4 = lum4(I4, C1, A0, G5, w), i5 = lum4(I5, C4, A1, G0, w), h5 = lum4(H5, F4, B1, D0, w);
+      f4 f4_ = YZWX(h5), c1 = YZWX(i4), g0 = WXYZ(i5), b1 = ZWXY(h5), d0 = WXYZ(h5);
+      b4 r1;
+      b4 ne_ef_eh = b4_and(b4_ne(e, f), b4_ne(e, h));
+#define EQ(P, Q) b4_lt(f4_df(P, Q), thr)
+#define EQ2(P, Q) b4_lt(f4_df(P, Q), thr2)
+      if (corner == 1.0f) {
+        r1 = ne_ef_eh;
+      } else if (corner == 2.0f) {
+        b4 t = b4_and(b4_not(EQ(f, b)), b4_not(EQ(h, d)));
+        t = b4_or(t, EQ(e, i));
+        t = b4_and(t, b4_not(EQ(f, i4)));
+        t = b4_and(t, b4_not(EQ(h, i5)));
+        t = b4_or(t, EQ(e, g));
+        t = b4_or(t, EQ(e, c));
+        r1 = b4_and(ne_ef_eh, t);
+      } else {
+        b4 t1 = b4_or(b4_and(b4_not(EQ(f, b)), b4_not(EQ(f, c))), b4_and(b4_not(EQ(h, d)), b4_not(EQ(h, g))));
+        b4 t2 = b4_and(EQ(e, i), b4_or(b4_and(b4_not(EQ(f, f4_)), b4_not(EQ(f, i4))),
+                                       b4_and(b4_not(EQ(h, h5)), b4_not(EQ(h, i5)))));
+        b4 t3 = b4_or(EQ(e, g), EQ(e, c));
+        r1 = b4_and(ne_ef_eh, b4_or(t1, b4_or(t2, t3)));
+      }
+      b4 r2_left = b4_and(b4_ne(e, g), b4_ne(d, g));
+      b4 r2_up = b4_and(b4_ne(e, c), b4_ne(b, c));
+      b4 r3_left = b4_and(EQ2(g, g0), b4_not(EQ2(d0, g0)));
+      b4 r3_up = b4_and(EQ2(c, c1), b4_not(EQ2(b1, c1)));
+#undef EQ
+#undef EQ2
+      f4 fx45 = line_sstep(Ao, Bo, Co, fpy, fpx), fx30 = line_sstep(Ao, Bx, Cx, fpy, fpx);
+      f4 fx60 = line_sstep(Ao, By, Cy, fpy, fpx), fx15 = line_sstep(Az, Bz, Cz, fpy, fpx);
+      f4 fx75 = line_sstep(Aw, Bw, Cw, fpy, fpx);
+      f4 wd1 = wd(e, c, g, i, h5, f4_, h, f), wd2 = wd(h, d, i5, f, i4, b, e, i);
+      f4 dfg = f4_df(f, g), dhc = f4_df(h, c), def = f4_df(e, f), deh = f4_df(e, h);
+      b4 edr, edr_left, edr_up, px, nc45, nc30, nc60, nc15, nc75, nc;
+      float maximo[4];
+      for (int k = 0; k < 4; ++k) {
+        edr.v[k] = (wd1.v[k] < wd2.v[k]) && r1.v[k];
+        edr_left.v[k] = (lv2 * dfg.v[k] <= dhc.v[k]) && r2_left.v[k];
+        edr_up.v[k] = (dfg.v[k] >= lv2 * dhc.v[k]) && r2_up.v[k];
+        nc45.v[k] = edr.v[k] && (fx45.v[k] != 0.0f);
+        nc30.v[k] = edr.v[k] && edr_left.v[k] && (fx30.v[k] != 0.0f);
+        nc60.v[k] = edr.v[k] && edr_up.v[k] && (fx60.v[k] != 0.0f);
+        nc15.v[k] = edr.v[k] && edr_left.v[k] && r3_left.v[k] && (fx15.v[k] != 0.0f);
+        nc75.v[k] = edr.v[k] && edr_up.v[k] && r3_up.v[k] && (fx75.v[k] != 0.0f);
+        px.v[k] = def.v[k] <= deh.v[k];
+        nc.v[k] = nc75.v[k] || nc15.v[k] || nc30.v[k] || nc60.v[k] || nc45.v[k];
+        float f45 = (nc45.v[k] ? 1.0f : 0.0f) * fx45.v[k], f30 = (nc30.v[k] ? 1.0f : 0.0f) * fx30.v[k];
+        float f60 = (nc60.v[k] ? 1.0f : 0.0f) * fx60.v[k], f15 = (nc15.v[k] ? 1.0f : 0.0f) * fx15.v[k];
+        float f75 = (nc75.v[k] ? 1.0f : 0.0f) * fx75.v[k];
+        float m1 = f15 > f75 ? f15 : f75, m2 = f30 > f60 ? f30 : f60;
+        float m3 = m1 > m2 ? m1 : m2;
+        maximo[k] = m3 > f45 ? m3 : f45;
+      }
+      /* :335-343; with no rule firing the GLSL leaves pix/blend undefined: the compiler drops
+       * the select against the undefined value, i.e. the last arm is taken (its blend is 0) */
+      const o_vec4 pk[4] = {px.v[0] ? F : Hh, px.v[1] ? B : F, px.v[2] ? D : B, px.v[3] ? Hh : D};
+      int k1 = nc.v[0] ? 0 : nc.v[1] ? 1 : nc.v[2] ? 2 : 3;
+      int k2 = nc.v[3] ? 3 : nc.v[2] ? 2 : nc.v[1] ? 1 : 0;
+      o_vec4 res1 = mix3(E, pk[k1], maximo[k1]);
+      o_vec4 res2 = mix3(E, pk[k2], maximo[k2]);
+      /* mix(res1, res2, step(c_df(E,res1), c_df(E,res2))): a mix whose weight is a bool-to-float
+       * is compiled to a select, so res2 is taken exactly */
+      o_vec4 res = c_df(E, res2) < c_df(E, res1) ? res1 : res2;
+      res.w = 1.0f;
+      o_store_pixel(a, x, y, res);
+    }
+}
+void o_pass_xbr_lv3(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  xbr_lv3_body(a);
+  o_fp_leave(csr);
+}

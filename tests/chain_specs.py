@@ -10,6 +10,24 @@ PRESETS = {
                'shaders = "1"\nshader0 = "shaders/crt-pi.glsl"\nfilter_linear0 = "true"\n'
                'wrap_mode0 = "clamp_to_border"\nmipmap_input0 = "false"\nalias0 = ""\n'
                'float_framebuffer0 = "false"\nsrgb_framebuffer0 = "false"\n'),
+    # same keys / values as the reference's ntsc/ntsc-256px-svideo.glslp (its frame_count_mod0 line
+    # is dropped by the reference parser, quirk Q2) and xbr/xbr-lv3.glslp
+    "ntsc-256px-svideo": ("ntsc/ntsc-256px-svideo.glslp", """shaders = 2
+shader0 = shaders/ntsc-pass1-svideo-3phase.glsl
+shader1 = shaders/ntsc-pass2-3phase-gamma.glsl
+filter_linear0 = false
+filter_linear1 = false
+scale_type_x0 = absolute
+scale_type_y0 = source
+scale_x0 = 1024
+scale_y0 = 1.0
+frame_count_mod0 = 2
+float_framebuffer0 = true
+scale_type1 = source
+scale_x1 = 0.5
+scale_y1 = 1.0
+"""),
+    "xbr-lv3": ("xbr/xbr-lv3.glslp", 'shaders = 1\n\nshader0 = shaders/xbr-lv3.glsl\nfilter_linear0 = false\n'),
     "stock": ("stock.glslp", 'shaders = "1"\nshader0 = "stock.glsl"\nfilter_linear0 = "false"\n'),
     # Same keys / values as the reference's crt/crt-royale.glslp for the 12 passes, including the
     # three `"true" # comment` booleans that its parser reads as false; only the LUT that the
@@ -126,6 +144,13 @@ SHADERS = {
         "oracle": "crt_pi",
         "params": [("CURVATURE_X", 0.10), ("CURVATURE_Y", 0.15), ("MASK_BRIGHTNESS", 0.70), ("SCANLINE_WEIGHT", 6.0),
                    ("SCANLINE_GAP_BRIGHTNESS", 0.12), ("BLOOM_FACTOR", 1.5), ("INPUT_GAMMA", 2.4), ("OUTPUT_GAMMA", 2.2)],
+        "samplers": []},
+    "ntsc/shaders/ntsc-pass1-svideo-3phase.glsl": {"oracle": "ntsc_pass1_svideo_3phase", "params": [], "samplers": []},
+    "ntsc/shaders/ntsc-pass2-3phase-gamma.glsl": {"oracle": "ntsc_pass2_3phase_gamma", "params": [], "samplers": []},
+    "xbr/shaders/xbr-lv3.glsl": {
+        "oracle": "xbr_lv3",
+        "params": [("XBR_Y_WEIGHT", 48.0), ("XBR_EQ_THRESHOLD", 10.0), ("XBR_EQ_THRESHOLD2", 2.0),
+                   ("XBR_LV2_COEFFICIENT", 2.0), ("corner_type", 3.0)],
         "samplers": []},
     _R + "first-pass-linearize-crt-gamma-bob-fields.glsl": {"oracle": "royale_first", "params": [], "samplers": []},
     _R + "scanlines-vertical-interlacing.glsl": {"oracle": "royale_scan_v", "params": [], "samplers": []},

@@ -72,6 +72,9 @@ def run_case(name, preset, rgb, vw, vh, frames=1, luts=(), params=()):
         if r.returncode:
             raise RuntimeError(r.stderr)
         out = {"input_rgb": rgb, "viewport": np.array([vw, vh]), "frames": np.array(frames)}
+        if params:
+            out["param_names"] = np.array([k for k, _ in params])
+            out["param_values"] = np.array([v for _, v in params], np.float32)
         meta = open(os.path.join(d, "meta.txt")).read().splitlines()
         k = 0
         for line in meta:
@@ -158,7 +161,49 @@ def case_crt_royale_mask_active():
                  luts=luts)
 
 
-CASES = {"scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+def case_ntsc():
+    # BASELINE config 3: 2 passes, RGBA32F intermediate of absolute width 1024, frame_count_mod 2
+    run_case("ntsc_svideo_96x64_to_256x192", GLSL + "/ntsc/ntsc-256px-svideo.glslp", mixed(96, 64, 8), 256, 192,
+             frames=2)
+    run_case("ntsc_svideo_120x50_to_301x117", GLSL + "/ntsc/ntsc-256px-svideo.glslp", noise(120, 50, 9), 301, 117,
+             frames=3)
+
+
+def pixel_art(w, h, seed):
+    """Few-colour blocky image with diagonals and single-pixel features: the edge patterns
+    xBR's rules react to (noise alone almost never satisfies its equality tests)."""
+    rng = np.random.default_rng(seed)
+    pal = rng.integers(0, 256, (6, 3), dtype=np.uint8)
+    pal[0] = 0
+    pal[1] = 255
+    yy, xx = np.mgrid[0:h, 0:w]
+    idx = ((xx // 5 + yy // 3) % 3).astype(np.int64)
+    idx[(xx + yy) % 11 < 3] = 3
+    idx[(xx - 2 * yy) % 17 < 2] = 4
+    idx[((xx - w // 2) ** 2 + (yy - h // 2) ** 2) < (min(w, h) // 3) ** 2] = 5
+    idx[((xx - w // 2) ** 2 + (yy - h // 2) ** 2) < (min(w, h) // 5) ** 2] = 1
+    sp = rng.random((h, w)) < 0.03
+    idx[sp] = rng.integers(0, 6, sp.sum())
+    img = pal[idx]
+    img[:, : w // 6] = noise(w // 6, h, seed + 1)   # a noisy strip: near-equal colours
+    return img
+
+
+def case_xbr():
+    # BASELINE config 5: one pass, nearest, viewport-sized RGBA8 target
+    run_case("xbr_lv3_64x56_to_256x224", GLSL + "/xbr/xbr-lv3.glslp", pixel_art(64, 56, 10), 256, 224)
+    run_case("xbr_lv3_48x40_to_331x217", GLSL + "/xbr/xbr-lv3.glslp", pixel_art(48, 40, 11), 331, 217)
+    run_case("xbr_lv3_noise_40x36_to_240x216", GLSL + "/xbr/xbr-lv3.glslp", noise(40, 36, 14), 240, 216,
+             params=[("XBR_Y_WEIGHT", 30.0)])
+    # the other two corner rules and non-default thresholds (custom parameters, ShaderEngine.cpp:3264-3387)
+    run_case("xbr_lv3_corner1_40x36_to_200x180", GLSL + "/xbr/xbr-lv3.glslp", pixel_art(40, 36, 12), 200, 180,
+             params=[("corner_type", 1.0)])
+    run_case("xbr_lv3_corner2_40x36_to_240x216", GLSL + "/xbr/xbr-lv3.glslp", pixel_art(40, 36, 13), 240, 216,
+             params=[("corner_type", 2.0), ("XBR_EQ_THRESHOLD", 20.0), ("XBR_EQ_THRESHOLD2", 4.0),
+                     ("XBR_LV2_COEFFICIENT", 3.0), ("XBR_Y_WEIGHT", 30.0)])
+
+
+CASES = {"ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -19,6 +19,13 @@ CASES = {
     "crt_pi_80x60_to_250x190": "crt-pi",
     "crt_royale_160x120_to_320x240": "crt-royale",
     "crt_royale_128x96_to_400x300": "crt-royale",
+    "ntsc_svideo_96x64_to_256x192": "ntsc-256px-svideo",
+    "ntsc_svideo_120x50_to_301x117": "ntsc-256px-svideo",
+    "xbr_lv3_64x56_to_256x224": "xbr-lv3",
+    "xbr_lv3_48x40_to_331x217": "xbr-lv3",
+    "xbr_lv3_noise_40x36_to_240x216": "xbr-lv3",
+    "xbr_lv3_corner1_40x36_to_200x180": "xbr-lv3",
+    "xbr_lv3_corner2_40x36_to_240x216": "xbr-lv3",
     # the same preset as a GL that reads 0 from pass 6's unwritten varying renders it
     "crt_royale_maskon_160x120_to_320x240": "crt-royale",
     "crt_royale_maskon_96x128_to_512x384": "crt-royale",
@@ -28,7 +35,8 @@ CASES = {
 # crt-royale: every pass that stores to an sRGB8 target can differ from llvmpipe by 1 LSB in
 # ~0.3 % of the bytes, because llvmpipe's sRGB encode runs through the x86 RSQRTPS
 # approximation and is not monotone ("sRGB8 store"); RGBA8 passes must be exact.
-BAR = {"scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1)}
+BAR = {"scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1), "ntsc-256px-svideo": (1.0, 0),
+       "xbr-lv3": (1.0, 0)}
 
 
 def royale_luts():
@@ -52,9 +60,11 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
     flags = 1 if "maskon" in case else 0
     luts = royale_luts() if key == "crt-royale" else None
     golden = [g["pass%d" % i] for i in range(int(g["n_passes"]))]
+    custom = dict(zip([str(n) for n in g["param_names"]], [float(v) for v in g["param_values"]])) \
+        if "param_names" in g else None
     # every pass fed with the GOLDEN outputs of the passes before it (isolates each pass) ...
     outs = run_chain(passes, g["input_rgb"], vw, vh, frame_count=int(g["frames"]), luts=luts, flags=flags,
-                     given=golden)
+                     given=golden, custom=custom)
     assert len(outs) == int(g["n_passes"])
     floor, maxdiff = BAR[key]
     for i, o in enumerate(outs):
