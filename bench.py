@@ -28,6 +28,9 @@ WORKLOADS = {
     # key: (chain_specs preset key, source w, h, viewport w, h, description)
     "crt-royale": ("crt-royale", 1920, 1080, 1920, 1080, "crt/crt-royale.glslp 12-pass, 1920x1080 RGBA8 frames"),
     "crt-pi": ("crt-pi", 1920, 1080, 1920, 1080, "crt/crt-pi.glslp 1-pass, 1920x1080 RGBA8 frames"),
+    "ntsc": ("ntsc-256px-svideo", 1920, 1080, 1920, 1080,
+             "ntsc/ntsc-256px-svideo.glslp 2-pass (RGBA32F 1024x1080 intermediate), 1920x1080 RGBA8 frames"),
+    "xbr-lv3": ("xbr-lv3", 256, 224, 3840, 2160, "xbr/xbr-lv3.glslp 1-pass upscale 256x224 -> 3840x2160"),
     "scanline": ("scanline", 320, 240, 320, 240, "scanlines/shaders/scanline.glsl 1-pass, 320x240"),
 }
 
@@ -161,7 +164,9 @@ def main():
 
     value = aggregate([args.batch] * world, args.steps, dt)
     out = {
-        "metric": "1080p frames/sec, crt-royale 12-pass, 1/2/4/8 MI355X; % HBM roofline",
+        # BASELINE.json's metric for the default workload; other --workload values are side measurements
+        "metric": ("1080p frames/sec, crt-royale 12-pass, 1/2/4/8 MI355X; % HBM roofline" if wl == "crt-royale"
+                   else "frames/sec, %s; %% HBM roofline" % wl),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -17,6 +17,34 @@ void setupCrtPi(const PassGeometry& g, rcd::PassLaunch& L) {
   L.plane[1] = planeV(1.0001f, g.out_w, g.out_h, g.out_fmt);
 }
 
+// ntsc-pass1-svideo-3phase.glsl:69  pix_no = vTexCoord * SourceSize.xy * (outsize.xy / InputSize.xy)
+void setupNtscPass1(const PassGeometry& g, rcd::PassLaunch& L) {
+  const float tsx = (float)g.in_w, tsy = (float)g.in_h;
+  const float px1 = (1.0f * tsx) * ((float)g.out_w / tsx), py1 = (1.0f * tsy) * ((float)g.out_h / tsy);
+  L.plane[0] = planeU(1.0f, g.out_w, g.out_h, g.out_fmt);
+  L.plane[1] = planeV(1.0f, g.out_w, g.out_h, g.out_fmt);
+  L.plane[2] = makePlane(0.f, px1, px1, 0.f, g.out_w, g.out_h, g.out_fmt);
+  L.plane[3] = makePlane(0.f, 0.f, py1, py1, g.out_w, g.out_h, g.out_fmt);
+}
+
+// ntsc-pass2-3phase-gamma.glsl:48  TEX0.xy = TexCoord.xy - vec2(0.5 / SourceSize.x, 0.0)
+void setupNtscPass2(const PassGeometry& g, rcd::PassLaunch& L) {
+  const float sh = 0.5f / (float)g.in_w;
+  L.plane[0] = makePlane(0.f - sh, 1.f - sh, 1.f - sh, 0.f - sh, g.out_w, g.out_h, g.out_fmt);
+  L.plane[1] = planeV(1.0f, g.out_w, g.out_h, g.out_fmt);
+}
+
+// xbr-lv3.glsl:82-99  t1..t7 = TEX0 + multiples of one texel
+void setupXbrLv3(const PassGeometry& g, rcd::PassLaunch& L) {
+  const float dx = 1.0f / (float)g.in_w, dy = 1.0f / (float)g.in_h;
+  const float xo[5] = {-2.0f * dx, -dx, 0.0f, dx, 2.0f * dx};
+  const float yo[5] = {-2.0f * dy, -dy, 0.0f, dy, 2.0f * dy};
+  for (int k = 0; k < 5; ++k) {
+    L.plane[k] = makePlane(0.f + xo[k], 1.f + xo[k], 1.f + xo[k], 0.f + xo[k], g.out_w, g.out_h, g.out_fmt);
+    L.plane[5 + k] = makePlane(0.f + yo[k], 0.f + yo[k], 1.f + yo[k], 1.f + yo[k], g.out_w, g.out_h, g.out_fmt);
+  }
+}
+
 std::vector<KernelEntry> build() {
   std::vector<KernelEntry> r;
   r.push_back({"stock.glsl", "stock", {}, {}, rck::launch_stock, setupTexCoord, false});
@@ -36,6 +64,17 @@ std::vector<KernelEntry> build() {
                 {"INPUT_GAMMA", 2.4f, 0.0f, 5.0f, 0.01f, "Input gamma"},
                 {"OUTPUT_GAMMA", 2.2f, 0.0f, 5.0f, 0.01f, "Output gamma"}},
                {}, rck::launch_crt_pi, setupCrtPi, false});
+  r.push_back({"ntsc/shaders/ntsc-pass1-svideo-3phase.glsl", "ntsc-pass1-svideo-3phase", {}, {},
+               rck::launch_ntsc_pass1, setupNtscPass1, false});
+  r.push_back({"ntsc/shaders/ntsc-pass2-3phase-gamma.glsl", "ntsc-pass2-3phase-gamma", {}, {},
+               rck::launch_ntsc_pass2, setupNtscPass2, true});
+  r.push_back({"xbr/shaders/xbr-lv3.glsl", "xbr-lv3",
+               {{"XBR_Y_WEIGHT", 48.0f, 0.0f, 100.0f, 1.0f, "Y Weight"},
+                {"XBR_EQ_THRESHOLD", 10.0f, 0.0f, 50.0f, 1.0f, "EQ Threshold"},
+                {"XBR_EQ_THRESHOLD2", 2.0f, 0.0f, 4.0f, 1.0f, "EQ Threshold 2"},
+                {"XBR_LV2_COEFFICIENT", 2.0f, 1.0f, 3.0f, 1.0f, "Lv2 Coefficient"},
+                {"corner_type", 3.0f, 1.0f, 3.0f, 1.0f, "Corner Calculation"}},
+               {}, rck::launch_xbr_lv3, setupXbrLv3, true});
   registerRoyaleKernels(r);
   return r;
 }

@@ -1,0 +1,147 @@
+// Pass kernels for ntsc/ntsc-256px-svideo.glslp (arithmetic spec = the GLSL text):
+//   ntsc/shaders/ntsc-pass1-svideo-3phase.glsl   VS lines 64-70, FS lines 147-166
+//   ntsc/shaders/ntsc-pass2-3phase-gamma.glsl    VS lines 44-49, FS lines 215-281 (the file
+//     carries "#version 130", so the unrolled macro_loopz branch is the one that is compiled)
+// Operation order is the one Mesa's GLSL lowering produces: vec*mat is a dot per matrix column
+// evaluated x*c0 + (y*c1 + z*c2); mod(x,3) = x - 3*floor(x/3) with a true division.
+#include "pass_launch.h"
+
+using namespace rcd;
+
+namespace {
+
+// sin and cos of the same argument with one shared range reduction (same results as
+// sin_() / cos_(): both polynomials are evaluated once and each function selects its own).
+__device__ __forceinline__ void sincos_both(float x, float& s, float& c) {
+  const uint32_t xi = f2bits(x);
+  const float xa = bits2f(xi & 0x7fffffffu);
+  const uint32_t sign = xi & 0x80000000u;
+  const float y = xa * 1.27323954473516f;
+  int32_t j = (int32_t)y;
+  j = (j + 1) & ~1;
+  const float y2 = (float)j;
+  float x3 = fma_(y2, -0.78515625f, xa);
+  x3 = fma_(y2, -2.4187564849853515625e-4f, x3);
+  x3 = fma_(y2, -3.77489497744594108e-8f, x3);
+  const float z = x3 * x3;
+  float ys = fma_(-1.9515295891E-4f, z, 8.3321608736E-3f);
+  ys = fma_(ys, z, -1.6666654611E-1f);
+  ys = ys * z;
+  ys = fma_(ys, x3, x3);
+  float yc = fma_(2.443315711809948E-005f, z, -1.388731625493765E-003f);
+  yc = fma_(yc, z, 4.166664568298827E-002f);
+  yc = yc * z;
+  yc = yc * z;
+  yc = yc - z * 0.5f;
+  yc = yc + 1.0f;
+  const int32_t j2 = j - 2;
+  const float rs = (j & 2) == 0 ? ys : yc;
+  const float rc = (j2 & 2) == 0 ? ys : yc;
+  s = bits2f(f2bits(rs) ^ (sign ^ (((uint32_t)j & 4u) << 29)));
+  c = bits2f(f2bits(rc) ^ (((uint32_t)~j2 & 4u) << 29));
+}
+
+// plane[0], plane[1]: TEX0;  plane[2], plane[3]: pix_no
+template <int IN_FMT, int IN_LINEAR, int IN_WRAP, int OUT_FMT, bool GENERIC>
+__global__ void __launch_bounds__(256) k_ntsc_pass1(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  if (GENERIC || IN_FMT == FMT_SRGB8 || OUT_FMT == FMT_SRGB8) load_srgb_tables(lds);
+  const float k_phase = 0.6667f * 3.14159265f;
+  const float k_freq = 3.14159265f / 3.0f;
+  RC_TILE_LOOP_BEGIN
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float pnx = vary(L.plane[2], x, y, lo), pny = vary(L.plane[3], x, y, lo);
+  const uint8_t* img = frame_ptr(L.in, z);
+  const float4 col = GENERIC ? sample_rt(L.in, img, u, v, &lds) : sample<IN_FMT, IN_LINEAR, IN_WRAP>(L.in, img, u, v, &lds);
+  const float yy = col.x * 0.2989f + (col.y * 0.5870f + col.z * 0.1140f);
+  float ii = col.x * 0.5959f + (col.y * -0.2744f + col.z * -0.3216f);
+  float qq = col.x * 0.2115f + (col.y * -0.5229f + col.z * 0.3114f);
+  const float m3 = pny - 3.0f * __builtin_floorf(div_const_(pny, 3.0f, 1.0f / 3.0f));
+  const float fc = (float)(L.frame_count0 + z);
+  const float mod_phase = k_phase * (m3 + fc) + pnx * k_freq;
+  float i_mod, q_mod;
+  sincos_both(mod_phase, q_mod, i_mod);
+  ii *= i_mod;
+  qq *= q_mod;
+  ii *= 2.0f;
+  qq *= 2.0f;
+  ii *= i_mod;
+  qq *= q_mod;
+  const float4 o = make_float4(yy, ii, qq, 1.0f);
+  if (GENERIC) store_rt(L, z, x, y, o, &lds);
+  else store<OUT_FMT>(L, z, x, y, o, &lds);
+  RC_TILE_LOOP_END
+}
+
+__constant__ float k_luma[25] = {
+    -0.000012020f, -0.000022146f, -0.000013155f, -0.000012020f, -0.000049979f, -0.000113940f, -0.000122150f,
+    -0.000005612f, 0.000170516f,  0.000237199f,  0.000169640f,  0.000285688f,  0.000984574f,  0.002018683f,
+    0.002002275f,  -0.000909882f, -0.007049081f, -0.013222860f, -0.012606931f, 0.002460860f,  0.035868225f,
+    0.084016453f,  0.135563500f,  0.175261268f,  0.190176552f};
+__constant__ float k_chroma[25] = {
+    -0.000118847f, -0.000271306f, -0.000502642f, -0.000930833f, -0.001451013f, -0.002064744f, -0.002700432f,
+    -0.003241276f, -0.003524948f, -0.003350284f, -0.002491729f, -0.000721149f, 0.002164659f,  0.006313635f,
+    0.011789103f,  0.018545660f,  0.026414396f,  0.035100710f,  0.044196567f,  0.053207202f,  0.061590275f,
+    0.068803602f,  0.074356193f,  0.077856564f,  0.079052396f};
+
+// plane[0], plane[1]: TEX0 = TexCoord - (0.5 / SourceSize.x, 0)
+template <int IN_FMT, int IN_LINEAR, int IN_WRAP, int OUT_FMT, bool GENERIC>
+__global__ void __launch_bounds__(256) k_ntsc_pass2(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  if (GENERIC || IN_FMT == FMT_SRGB8 || OUT_FMT == FMT_SRGB8) load_srgb_tables(lds);
+  const float one_x = 1.0f / (float)L.in.w;
+  RC_TILE_LOOP_BEGIN
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const uint8_t* img = frame_ptr(L.in, z);
+  float sy = 0.f, si = 0.f, sq = 0.f;
+  constexpr int kUnroll = GENERIC ? 1 : 24;  // the run-time sampler switch is not worth 49 copies
+#pragma unroll kUnroll
+  for (int c = 1; c <= 24; ++c) {
+    const float off = (float)(c - 25);
+    const float4 p = GENERIC ? sample_rt(L.in, img, u + off * one_x, v, &lds)
+                             : sample<IN_FMT, IN_LINEAR, IN_WRAP>(L.in, img, u + off * one_x, v, &lds);
+    const float4 n = GENERIC ? sample_rt(L.in, img, u + (-off) * one_x, v, &lds)
+                             : sample<IN_FMT, IN_LINEAR, IN_WRAP>(L.in, img, u + (-off) * one_x, v, &lds);
+    sy = sy + (p.x + n.x) * k_luma[c - 1];
+    si = si + (p.y + n.y) * k_chroma[c - 1];
+    sq = sq + (p.z + n.z) * k_chroma[c - 1];
+  }
+  const float4 m = GENERIC ? sample_rt(L.in, img, u, v, &lds) : sample<IN_FMT, IN_LINEAR, IN_WRAP>(L.in, img, u, v, &lds);
+  sy = sy + m.x * k_luma[24];
+  si = si + m.y * k_chroma[24];
+  sq = sq + m.z * k_chroma[24];
+  const float r = sy + (si * 0.956f + sq * 0.6210f);
+  const float g = sy + (si * -0.2720f + sq * -0.6474f);
+  const float b = sy + (si * -1.1060f + sq * 1.7046f);
+  const float gm = 2.5f / 2.0f;
+  const float4 o = make_float4(pow_(r, gm), pow_(g, gm), pow_(b, gm), 1.0f);
+  if (GENERIC) store_rt(L, z, x, y, o, &lds);
+  else store<OUT_FMT>(L, z, x, y, o, &lds);
+  RC_TILE_LOOP_END
+}
+
+}  // namespace
+
+namespace rck {
+
+hipError_t launch_ntsc_pass1(const PassLaunch& L, hipStream_t s) {
+  // shipped preset: nearest on the RGB source frame, RGBA32F target
+  if (L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_F32)
+    hipLaunchKernelGGL((k_ntsc_pass1<FMT_RGBX8, 0, WRAP_EDGE, FMT_F32, false>), px_grid(L), px_block(), 0, s, L);
+  else if (L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_BORDER && L.out_fmt == FMT_F32)
+    hipLaunchKernelGGL((k_ntsc_pass1<FMT_RGBX8, 0, WRAP_BORDER, FMT_F32, false>), px_grid(L), px_block(), 0, s, L);
+  else
+    hipLaunchKernelGGL((k_ntsc_pass1<0, 0, 0, 0, true>), px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_ntsc_pass2(const PassLaunch& L, hipStream_t s) {
+  if (L.in.fmt == FMT_F32 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8)
+    hipLaunchKernelGGL((k_ntsc_pass2<FMT_F32, 0, WRAP_EDGE, FMT_RGBA8, false>), px_grid(L), px_block(), 0, s, L);
+  else if (L.in.fmt == FMT_F32 && !L.in.linear && L.in.wrap == WRAP_BORDER && L.out_fmt == FMT_RGBA8)
+    hipLaunchKernelGGL((k_ntsc_pass2<FMT_F32, 0, WRAP_BORDER, FMT_RGBA8, false>), px_grid(L), px_block(), 0, s, L);
+  else
+    hipLaunchKernelGGL((k_ntsc_pass2<0, 0, 0, 0, true>), px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+
+}  // namespace rck

@@ -1,0 +1,192 @@
+// Pass kernel for xbr/shaders/xbr-lv3.glsl (arithmetic spec = the GLSL text: VS lines 77-100,
+// FS lines 171-352).  Operation order is the one Mesa's GLSL compiler produces (measured, see
+// oracle/rc_passes_ntsc_xbr.c): mat*vec accumulates columns left to right; the five-term
+// weighted_distance sum is rebalanced to ((ab+ac)+(de+df))+4gh; the smoothstep numerators are
+// (A*fp.y - e0) + B*fp.x; a mix whose weight is step() is a select; with no rule firing the
+// undefined pix/blend resolve to the last arm of the if-chain (blend 0).
+//
+// plane[0..4]: TEX0.x + {-2dx,-dx,0,dx,2dx};  plane[5..9]: TEX0.y + {-2dy,-dy,0,dy,2dy}
+// params: XBR_Y_WEIGHT, XBR_EQ_THRESHOLD, XBR_EQ_THRESHOLD2, XBR_LV2_COEFFICIENT, corner_type
+#include "pass_launch.h"
+
+using namespace rcd;
+
+namespace {
+
+struct F4 { float v[4]; };
+struct B4 { bool v[4]; };
+
+__device__ __forceinline__ float lum(const float4 p, const float* w) { return (p.x * w[0] + p.y * w[1]) + p.z * w[2]; }
+__device__ __forceinline__ F4 lum4(const float4 a, const float4 b, const float4 c, const float4 d, const float* w) {
+  return F4{{lum(a, w), lum(b, w), lum(c, w), lum(d, w)}};
+}
+__device__ __forceinline__ F4 yzwx(const F4& a) { return F4{{a.v[1], a.v[2], a.v[3], a.v[0]}}; }
+__device__ __forceinline__ F4 wxyz(const F4& a) { return F4{{a.v[3], a.v[0], a.v[1], a.v[2]}}; }
+__device__ __forceinline__ F4 zwxy(const F4& a) { return F4{{a.v[2], a.v[3], a.v[0], a.v[1]}}; }
+__device__ __forceinline__ float df1(float a, float b) { return __builtin_fabsf(a - b); }
+__device__ __forceinline__ F4 wd(const F4& a, const F4& b, const F4& c, const F4& d, const F4& e, const F4& f,
+                                 const F4& g, const F4& h) {
+  F4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    r.v[k] = ((df1(a.v[k], b.v[k]) + df1(a.v[k], c.v[k])) + (df1(d.v[k], e.v[k]) + df1(d.v[k], f.v[k]))) +
+             4.0f * df1(g.v[k], h.v[k]);
+  return r;
+}
+// smoothstep(C - 0.4, C + 0.4, A*fy + B*fx) for one component
+__device__ __forceinline__ float line_sstep(float A, float B, float C, float fy, float fx) {
+  const float e0 = C - 0.4f, e1 = C + 0.4f;
+  const float num = (A == -1.0f && B == -1.0f) ? (A * fy + B * fx) - e0 : (A * fy - e0) + B * fx;
+  float t = num / (e1 - e0);
+  t = t > 0.0f ? t : 0.0f;
+  t = t < 1.0f ? t : 1.0f;
+  return t * (t * (3.0f - 2.0f * t));
+}
+__device__ __forceinline__ float4 mix3(const float4 a, const float4 b, float t) {
+  return make_float4(a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z), 1.0f);
+}
+__device__ __forceinline__ float c_df(const float4 a, const float4 b) {
+  return (__builtin_fabsf(a.x - b.x) + __builtin_fabsf(a.y - b.y)) + __builtin_fabsf(a.z - b.z);
+}
+
+template <int IN_FMT, int IN_WRAP, int OUT_FMT, bool GENERIC>
+__global__ void __launch_bounds__(256) k_xbr_lv3(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  if (GENERIC || IN_FMT == FMT_SRGB8 || OUT_FMT == FMT_SRGB8) load_srgb_tables(lds);
+  const float yw = L.params[0], thr = L.params[1], thr2 = L.params[2], lv2 = L.params[3], corner = L.params[4];
+  const float tsx = (float)L.in.w, tsy = (float)L.in.h;
+  const float w[3] = {yw * 0.299f, yw * 0.587f, yw * 0.114f};
+  RC_TILE_LOOP_BEGIN
+  float cx[5], cy[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    cx[k] = vary(L.plane[k], x, y, lo);
+    cy[k] = vary(L.plane[5 + k], x, y, lo);
+  }
+  float fpx = cx[2] * tsx, fpy = cy[2] * tsy;
+  fpx = fpx - __builtin_floorf(fpx);
+  fpy = fpy - __builtin_floorf(fpy);
+  const uint8_t* img = frame_ptr(L.in, z);
+#define T(i, j) (GENERIC ? sample_rt(L.in, img, cx[i], cy[j], &lds) : sample<IN_FMT, 0, IN_WRAP>(L.in, img, cx[i], cy[j], &lds))
+  const float4 A1 = T(1, 0), B1 = T(2, 0), C1 = T(3, 0);
+  const float4 A = T(1, 1), B = T(2, 1), C = T(3, 1);
+  const float4 D = T(1, 2), E = T(2, 2), F = T(3, 2);
+  const float4 G = T(1, 3), H = T(2, 3), I = T(3, 3);
+  const float4 G5 = T(1, 4), H5 = T(2, 4), I5 = T(3, 4);
+  const float4 A0 = T(0, 1), D0 = T(0, 2), G0 = T(0, 3);
+  const float4 C4 = T(4, 1), F4_ = T(4, 2), I4 = T(4, 3);
+#undef T
+  const F4 b = lum4(B, D, H, F, w), c = lum4(C, A, G, I, w);
+  const float le = lum(E, w);
+  const F4 e = F4{{le, le, le, le}};
+  const F4 d = yzwx(b), f = wxyz(b), g = zwxy(c), h = zwxy(b), i = wxyz(c);
+  const F4 i4 = lum4(I4, C1, A0, G5, w), i5 = lum4(I5, C4, A1, G0, w), h5 = lum4(H5, F4_, B1, D0, w);
+  const F4 f4 = yzwx(h5), c1 = yzwx(i4), g0 = wxyz(i5), b1 = zwxy(h5), d0 = wxyz(h5);
+  const F4 wd1 = wd(e, c, g, i, h5, f4, h, f), wd2 = wd(h, d, i5, f, i4, b, e, i);
+
+  const float Ao[4] = {1.0f, -1.0f, -1.0f, 1.0f}, Bo[4] = {1.0f, 1.0f, -1.0f, -1.0f}, Co[4] = {1.5f, 0.5f, -0.5f, 0.5f};
+  const float Bx[4] = {0.5f, 2.0f, -0.5f, -2.0f}, Cx[4] = {1.0f, 1.0f, -0.5f, 0.0f};
+  const float By[4] = {2.0f, 0.5f, -2.0f, -0.5f}, Cy[4] = {2.0f, 0.0f, -1.0f, 0.5f};
+  const float Az[4] = {6.0f, -2.0f, -6.0f, 2.0f}, Bz[4] = {2.0f, 6.0f, -2.0f, -6.0f}, Cz[4] = {5.0f, 3.0f, -3.0f, -1.0f};
+  const float Aw[4] = {2.0f, -6.0f, -2.0f, 6.0f}, Bw[4] = {6.0f, 2.0f, -6.0f, -2.0f}, Cw[4] = {5.0f, -1.0f, -3.0f, 3.0f};
+
+  bool nc[4], px[4];
+  float maximo[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#define EQ(P, Q) (df1(P.v[k], Q.v[k]) < thr)
+#define EQ2(P, Q) (df1(P.v[k], Q.v[k]) < thr2)
+    const bool ne = (e.v[k] != f.v[k]) && (e.v[k] != h.v[k]);
+    bool r1;
+    if (corner == 1.0f) {
+      r1 = ne;
+    } else if (corner == 2.0f) {
+      bool t = !EQ(f, b) && !EQ(h, d);
+      t = t || EQ(e, i);
+      t = t && !EQ(f, i4);
+      t = t && !EQ(h, i5);
+      t = t || EQ(e, g);
+      t = t || EQ(e, c);
+      r1 = ne && t;
+    } else {
+      const bool t1 = (!EQ(f, b) && !EQ(f, c)) || (!EQ(h, d) && !EQ(h, g));
+      const bool t2 = EQ(e, i) && ((!EQ(f, f4) && !EQ(f, i4)) || (!EQ(h, h5) && !EQ(h, i5)));
+      const bool t3 = EQ(e, g) || EQ(e, c);
+      r1 = ne && (t1 || (t2 || t3));
+    }
+    const bool r2_left = (e.v[k] != g.v[k]) && (d.v[k] != g.v[k]);
+    const bool r2_up = (e.v[k] != c.v[k]) && (b.v[k] != c.v[k]);
+    const bool r3_left = EQ2(g, g0) && !EQ2(d0, g0);
+    const bool r3_up = EQ2(c, c1) && !EQ2(b1, c1);
+#undef EQ
+#undef EQ2
+    const float dfg = df1(f.v[k], g.v[k]), dhc = df1(h.v[k], c.v[k]);
+    const bool edr = (wd1.v[k] < wd2.v[k]) && r1;
+    const bool edr_left = (lv2 * dfg <= dhc) && r2_left;
+    const bool edr_up = (dfg >= lv2 * dhc) && r2_up;
+    float m = 0.0f;
+    bool any = false;
+    if (edr) {  // every new-colour rule needs edr; without it all five finals are 0
+      const float fx45 = line_sstep(Ao[k], Bo[k], Co[k], fpy, fpx);
+      const bool nc45 = fx45 != 0.0f;
+      float f30 = 0.0f, f60 = 0.0f, f15 = 0.0f, f75 = 0.0f;
+      bool nc30 = false, nc60 = false, nc15 = false, nc75 = false;
+      if (edr_left) {
+        const float fx30 = line_sstep(Ao[k], Bx[k], Cx[k], fpy, fpx);
+        nc30 = fx30 != 0.0f;
+        f30 = nc30 ? fx30 : 0.0f;
+        if (r3_left) {
+          const float fx15 = line_sstep(Az[k], Bz[k], Cz[k], fpy, fpx);
+          nc15 = fx15 != 0.0f;
+          f15 = nc15 ? fx15 : 0.0f;
+        }
+      }
+      if (edr_up) {
+        const float fx60 = line_sstep(Ao[k], By[k], Cy[k], fpy, fpx);
+        nc60 = fx60 != 0.0f;
+        f60 = nc60 ? fx60 : 0.0f;
+        if (r3_up) {
+          const float fx75 = line_sstep(Aw[k], Bw[k], Cw[k], fpy, fpx);
+          nc75 = fx75 != 0.0f;
+          f75 = nc75 ? fx75 : 0.0f;
+        }
+      }
+      const float f45 = nc45 ? fx45 : 0.0f;
+      const float m1 = f15 > f75 ? f15 : f75, m2 = f30 > f60 ? f30 : f60;
+      const float m3 = m1 > m2 ? m1 : m2;
+      m = m3 > f45 ? m3 : f45;
+      any = nc75 || nc15 || nc30 || nc60 || nc45;
+    }
+    maximo[k] = m;
+    nc[k] = any;
+    px[k] = df1(e.v[k], f.v[k]) <= df1(e.v[k], h.v[k]);
+  }
+  const float4 pk0 = px[0] ? F : H, pk1 = px[1] ? B : F, pk2 = px[2] ? D : B, pk3 = px[3] ? H : D;
+  const float4 pix1 = nc[0] ? pk0 : nc[1] ? pk1 : nc[2] ? pk2 : pk3;
+  const float bl1 = nc[0] ? maximo[0] : nc[1] ? maximo[1] : nc[2] ? maximo[2] : maximo[3];
+  const float4 pix2 = nc[3] ? pk3 : nc[2] ? pk2 : nc[1] ? pk1 : pk0;
+  const float bl2 = nc[3] ? maximo[3] : nc[2] ? maximo[2] : nc[1] ? maximo[1] : maximo[0];
+  const float4 res1 = mix3(E, pix1, bl1), res2 = mix3(E, pix2, bl2);
+  float4 res = c_df(E, res2) < c_df(E, res1) ? res1 : res2;
+  res.w = 1.0f;
+  if (GENERIC) store_rt(L, z, x, y, res, &lds);
+  else store<OUT_FMT>(L, z, x, y, res, &lds);
+  RC_TILE_LOOP_END
+}
+
+}  // namespace
+
+namespace rck {
+
+hipError_t launch_xbr_lv3(const PassLaunch& L, hipStream_t s) {
+  // shipped preset: nearest on the RGB source frame, RGBA8 viewport-sized target
+  if (L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8)
+    hipLaunchKernelGGL((k_xbr_lv3<FMT_RGBX8, WRAP_EDGE, FMT_RGBA8, false>), px_grid(L), px_block(), 0, s, L);
+  else if (L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_BORDER && L.out_fmt == FMT_RGBA8)
+    hipLaunchKernelGGL((k_xbr_lv3<FMT_RGBX8, WRAP_BORDER, FMT_RGBA8, false>), px_grid(L), px_block(), 0, s, L);
+  else
+    hipLaunchKernelGGL((k_xbr_lv3<0, 0, 0, true>), px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+
+}  // namespace rck

@@ -34,7 +34,7 @@ struct Plane {
 };
 
 constexpr int kMaxExtra = 6;
-constexpr int kMaxPlanes = 8;
+constexpr int kMaxPlanes = 12;
 constexpr int kMaxParams = 48;
 
 struct PassLaunch {

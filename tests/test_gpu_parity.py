@@ -16,6 +16,13 @@ GOLDEN_CASES = {
     "scanline_64x48_to_160x100": "scanline",
     "crt_pi_96x64_to_192x128": "crt-pi",
     "crt_pi_80x60_to_250x190": "crt-pi",
+    "ntsc_svideo_96x64_to_256x192": "ntsc-256px-svideo",        # BASELINE config 3, RGBA32F intermediate
+    "ntsc_svideo_120x50_to_301x117": "ntsc-256px-svideo",
+    "xbr_lv3_64x56_to_256x224": "xbr-lv3",                      # BASELINE config 5
+    "xbr_lv3_48x40_to_331x217": "xbr-lv3",
+    "xbr_lv3_noise_40x36_to_240x216": "xbr-lv3",
+    "xbr_lv3_corner1_40x36_to_200x180": "xbr-lv3",
+    "xbr_lv3_corner2_40x36_to_240x216": "xbr-lv3",
 }
 
 
@@ -25,13 +32,18 @@ def test_engine_matches_golden(case, preset_tree, rc_lib):
     g = np.load(os.path.join(GOLD, case + ".npz"))
     vw, vh = [int(v) for v in g["viewport"]]
     e = make_engine(preset_tree[GOLDEN_CASES[case]], vw, vh)
-    final = run_engine(e, g["input_rgb"])
+    if "param_names" in g:
+        for name, v in zip(g["param_names"], g["param_values"]):
+            assert e.setShaderParameter(str(name), float(v))
+    for _ in range(int(g["frames"])):       # the golden run applied `frames` frames; the last one is kept
+        final = run_engine(e, g["input_rgb"])
     n = int(g["n_passes"])
     for i in range(n):
         got = e.readPass(i, 0)
         ref = g["pass%d" % i]
-        assert got.shape == ref.shape
-        assert np.array_equal(got, ref), "pass %d differs: %d bytes" % (i, int((got != ref).sum()))
+        assert got.shape == ref.shape and got.dtype == ref.dtype
+        same = got.view(np.uint32) == ref.view(np.uint32) if ref.dtype == np.float32 else got == ref
+        assert same.all(), "pass %d differs: %d values" % (i, int((~same).sum()))
     assert np.array_equal(final[0], g["pass%d" % (n - 1)])
     e.shutdown()
 
@@ -97,6 +109,11 @@ def test_royale_interlaced_source_and_batch(preset_tree, rc_lib):
     ("crt-pi", 100, 37, 301, 111),
     ("crt-pi", 1, 1, 5, 3),             # minimum size
     ("stock", 40, 30, 80, 60),
+    ("ntsc-256px-svideo", 70, 33, 140, 99),
+    ("ntsc-256px-svideo", 1, 1, 3, 2),
+    ("xbr-lv3", 37, 29, 259, 203),      # 7x, ragged
+    ("xbr-lv3", 2, 2, 9, 7),
+    ("xbr-lv3", 64, 56, 64, 56),        # 1:1
 ])
 def test_engine_matches_oracle(key, w, h, vw, vh, preset_tree, rc_lib):
     from gpu_util import make_engine, run_engine
@@ -110,6 +127,53 @@ def test_engine_matches_oracle(key, w, h, vw, vh, preset_tree, rc_lib):
         got = e.readPass(i, 0)
         assert np.array_equal(got, o), "pass %d: %d differing values" % (i, int((got != o).sum()))
     assert np.array_equal(final[0], want[-1])
+    e.shutdown()
+
+
+def test_ntsc_full_size_batch(preset_tree, rc_lib):
+    """BASELINE config 3 at full size: 1920x1080 source, 1024x1080 RGBA32F intermediate, 512x1080 output;
+    a batch of 3 frames (FrameCount 1..3 drives the chroma phase), every byte against the oracle."""
+    from gpu_util import make_engine, run_engine
+    from retrocapture_amd import engine as eng
+    import oracle_lib
+    oracle_lib.set_threads(8)
+    try:
+        rng = np.random.default_rng(31)
+        frames = rng.integers(0, 256, (3, 1080, 1920, 3), dtype=np.uint8)
+        passes = eng.preset_dump(preset_tree["ntsc-256px-svideo"])["passes"]
+        e = make_engine(preset_tree["ntsc-256px-svideo"], 1920, 1080, chunk=2)
+        final = run_engine(e, frames)
+        assert final.shape == (3, 1080, 512, 4)
+        for k in range(3):
+            want = run_chain(passes, frames[k], 1920, 1080, frame_count=k + 1)
+            assert want[0].shape == (1080, 1024, 4) and want[0].dtype == np.float32
+            assert np.array_equal(final[k], want[-1]), "frame %d: %d bytes" % (k, int((final[k] != want[-1]).sum()))
+        e.shutdown()
+    finally:
+        oracle_lib.set_threads(1)
+
+
+def test_xbr_full_size_properties(preset_tree, rc_lib):
+    """BASELINE config 5 at full size: 256x224 -> 3840x2160.  A 96-row band against the oracle,
+    determinism, batch-slot independence, opaque alpha, and the xBR invariant that a pixel no rule
+    fires on keeps its source colour (flat regions are copied)."""
+    from gpu_util import make_engine, run_engine
+    from oracle_lib import Tex, run_pass_rows
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_golden import pixel_art
+    frame = pixel_art(256, 224, 41)
+    frame[150:, 180:] = (9, 200, 77)                       # a flat block
+    e = make_engine(preset_tree["xbr-lv3"], 3840, 2160, chunk=2)
+    a = run_engine(e, np.stack([frame, frame[:, ::-1].copy(), frame]))
+    assert a.shape == (3, 2160, 3840, 4)
+    assert np.array_equal(a[0], a[2]) and (a[..., 3] == 255).all()
+    assert (a[0][1500:2100, 2800:3800, :3] == np.array([9, 200, 77], np.uint8)).all()
+    src = np.concatenate([frame, np.full((224, 256, 1), 255, np.uint8)], -1)
+    t = Tex(src, "rgbx8", False, "clamp_to_edge")
+    params = [d for _, d in chain_specs.SHADERS["xbr/shaders/xbr-lv3.glsl"]["params"]]
+    rows = run_pass_rows("xbr_lv3", t, 3840, 2160, 1000, 1096, params=params)
+    assert np.array_equal(a[0][1000:1096], rows)
     e.shutdown()
 
 
