@@ -145,6 +145,11 @@ void rc_engine_set_allow_missing_sources(rc_engine* e, int allow);
  * resized phosphor mask is rendered. */
 void rc_engine_set_undefined_varying_zero(rc_engine* e, int zero);
 
+/* Some passes have a specialised form next to their general one (e.g. xbr-lv3 evaluates its edge
+ * rules once per source pixel when the sampling pattern allows it).  Both forms give identical
+ * results; 1 forces the general form (diagnostics / tests).  Default 0. */
+void rc_engine_set_general_kernels_only(rc_engine* e, int general_only);
+
 const char* rc_last_error(void);
 const char* rc_version(void);
 /* Names of the registered kernels ("identity\n" list) for diagnostics. */

@@ -1,5 +1,8 @@
 #include "kernel_registry.h"
 
+#include <cmath>
+#include <cstring>
+
 #include "royale_setup.h"
 #include "varying.h"
 
@@ -34,6 +37,56 @@ void setupNtscPass2(const PassGeometry& g, rcd::PassLaunch& L) {
   L.plane[1] = planeV(1.0f, g.out_w, g.out_h, g.out_fmt);
 }
 
+// The device's vary() and GL_NEAREST index, evaluated on the host with the same operations.
+float hostVary(const rcd::Plane& p, int x, int y) { return std::fmaf(p.dy_lo, (float)y, std::fmaf(p.dx_lo, (float)x, p.a0_lo)); }
+int hostNearest(float s, int n) { return (int)std::floor(s * (float)n); }
+
+// xbr-lv3's rule tests depend only on the 21-texel neighbourhood of the source pixel a target
+// pixel falls in, PROVIDED the five columns (rows) it samples through five separately
+// interpolated coordinates are exactly centre-2 .. centre+2 (before wrapping).  Float rounding
+// breaks that where a sample position lands on a texel boundary (e.g. 224 -> 2160 rows: every
+// 135th half-row), so the actual planes are evaluated for every target column and row, with the
+// device's operations, and the irregular ones are listed: pass_xbr.hip evaluates the rules once
+// per source pixel and re-renders the listed rows / columns with the general per-pixel form.
+struct XbrPattern {
+  bool usable = false;
+  int n_rows = 0, n_cols = 0;
+  int rows[20], cols[20];
+};
+XbrPattern xbrPattern(const PassGeometry& g, const rcd::PassLaunch& L) {
+  XbrPattern p;
+  if (g.out_fmt != rcd::FMT_RGBA8) return p;  // one plane per varying only on the rectangle path
+  for (int k = 0; k < 5; ++k) {
+    const rcd::Plane &px = L.plane[k], &py = L.plane[5 + k];
+    if (px.dy_lo != 0.0f || py.dx_lo != 0.0f) return p;
+    if (px.a0_lo != px.a0_up || px.dx_lo != px.dx_up || py.a0_lo != py.a0_up || py.dy_lo != py.dy_up) return p;
+  }
+  for (int x = 0; x < g.out_w; ++x) {
+    const int c = hostNearest(hostVary(L.plane[2], x, 0), g.in_w);
+    if (c < 0 || c >= g.in_w) return p;
+    bool regular = true;
+    for (int k = 0; k < 5; ++k) regular = regular && hostNearest(hostVary(L.plane[k], x, 0), g.in_w) == c + k - 2;
+    if (!regular) {
+      if (p.n_cols == 20) return p;
+      p.cols[p.n_cols++] = x;
+    }
+  }
+  for (int y = 0; y < g.out_h; ++y) {
+    const int c = hostNearest(hostVary(L.plane[7], 0, y), g.in_h);
+    if (c < 0 || c >= g.in_h) return p;
+    bool regular = true;
+    for (int k = 0; k < 5; ++k) regular = regular && hostNearest(hostVary(L.plane[5 + k], 0, y), g.in_h) == c + k - 2;
+    if (!regular) {
+      if (p.n_rows == 20) return p;
+      p.rows[p.n_rows++] = y;
+    }
+  }
+  p.usable = true;
+  return p;
+}
+
+uint64_t scratchXbrLv3(const PassGeometry& g) { return (uint64_t)g.in_w * g.in_h * 4; }  // one rule record per source pixel
+
 // xbr-lv3.glsl:82-99  t1..t7 = TEX0 + multiples of one texel
 void setupXbrLv3(const PassGeometry& g, rcd::PassLaunch& L) {
   const float dx = 1.0f / (float)g.in_w, dy = 1.0f / (float)g.in_h;
@@ -42,6 +95,21 @@ void setupXbrLv3(const PassGeometry& g, rcd::PassLaunch& L) {
   for (int k = 0; k < 5; ++k) {
     L.plane[k] = makePlane(0.f + xo[k], 1.f + xo[k], 1.f + xo[k], 0.f + xo[k], g.out_w, g.out_h, g.out_fmt);
     L.plane[5 + k] = makePlane(0.f + yo[k], 0.f + yo[k], 1.f + yo[k], 1.f + yo[k], g.out_w, g.out_h, g.out_fmt);
+  }
+  // the check costs 5*(out_w+out_h) evaluations; geometry rarely changes between launches
+  static thread_local struct { int v[5]; XbrPattern pat; } memo = {{-1, -1, -1, -1, -1}, {}};
+  const int key[5] = {g.in_w, g.in_h, g.out_w, g.out_h, g.out_fmt};
+  if (std::memcmp(memo.v, key, sizeof(key)) != 0) {
+    std::memcpy(memo.v, key, sizeof(key));
+    memo.pat = xbrPattern(g, L);
+  }
+  if (memo.pat.usable) {
+    // ints travel as bit patterns in the float parameter block (pass_xbr.hip XBR_P_*)
+    L.flags |= rcd::RC_FLAG_XBR_REGULAR;
+    std::memcpy(&L.params[6], &memo.pat.n_rows, 4);
+    std::memcpy(&L.params[7], &memo.pat.n_cols, 4);
+    std::memcpy(&L.params[8], memo.pat.rows, sizeof(int) * (size_t)memo.pat.n_rows);
+    std::memcpy(&L.params[28], memo.pat.cols, sizeof(int) * (size_t)memo.pat.n_cols);
   }
 }
 
@@ -74,7 +142,7 @@ std::vector<KernelEntry> build() {
                 {"XBR_EQ_THRESHOLD2", 2.0f, 0.0f, 4.0f, 1.0f, "EQ Threshold 2"},
                 {"XBR_LV2_COEFFICIENT", 2.0f, 1.0f, 3.0f, 1.0f, "Lv2 Coefficient"},
                 {"corner_type", 3.0f, 1.0f, 3.0f, 1.0f, "Corner Calculation"}},
-               {}, rck::launch_xbr_lv3, setupXbrLv3, true});
+               {}, rck::launch_xbr_lv3, setupXbrLv3, true, true, nullptr, scratchXbrLv3});
   registerRoyaleKernels(r);
   return r;
 }

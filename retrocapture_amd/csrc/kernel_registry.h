@@ -43,6 +43,8 @@ struct KernelEntry {
   bool reads_input = true;              // false: the shader never samples its `Texture` input
   // Optional: returns an error text if the kernel cannot honour these parameter values
   const char* (*validate)(const float* params) = nullptr;
+  // Optional: bytes of device scratch the pass needs per frame (handed over in PassLaunch::scratch)
+  uint64_t (*scratch_bytes)(const PassGeometry& g) = nullptr;
 };
 
 const KernelEntry* findKernel(const std::string& shaderPath);

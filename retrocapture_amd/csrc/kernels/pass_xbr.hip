@@ -7,11 +7,17 @@
 //
 // plane[0..4]: TEX0.x + {-2dx,-dx,0,dx,2dx};  plane[5..9]: TEX0.y + {-2dy,-dy,0,dy,2dy}
 // params: XBR_Y_WEIGHT, XBR_EQ_THRESHOLD, XBR_EQ_THRESHOLD2, XBR_LV2_COEFFICIENT, corner_type
+#include <cstring>
+
 #include "pass_launch.h"
 
 using namespace rcd;
 
 namespace {
+
+// L.params layout beyond the five shader parameters (ints stored as bit patterns): the target rows
+// and columns whose five sampled source rows / columns are not centre-2..centre+2
+enum { XBR_P_NROWS = 6, XBR_P_NCOLS = 7, XBR_P_ROWS = 8, XBR_P_COLS = 28, XBR_MAX_IRREGULAR = 20 };
 
 struct F4 { float v[4]; };
 struct B4 { bool v[4]; };
@@ -49,14 +55,12 @@ __device__ __forceinline__ float c_df(const float4 a, const float4 b) {
   return (__builtin_fabsf(a.x - b.x) + __builtin_fabsf(a.y - b.y)) + __builtin_fabsf(a.z - b.z);
 }
 
-template <int IN_FMT, int IN_WRAP, int OUT_FMT, bool GENERIC>
-__global__ void __launch_bounds__(256) k_xbr_lv3(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  if (GENERIC || IN_FMT == FMT_SRGB8 || OUT_FMT == FMT_SRGB8) load_srgb_tables(lds);
+// One target pixel, general form: 21 samples through the five interpolated column / row coordinates.
+template <int IN_FMT, int IN_WRAP, bool GENERIC>
+__device__ __forceinline__ float4 xbr_pixel(const PassLaunch& L, const SrgbLds* lds_p, int x, int y, int z, bool lo) {
   const float yw = L.params[0], thr = L.params[1], thr2 = L.params[2], lv2 = L.params[3], corner = L.params[4];
   const float tsx = (float)L.in.w, tsy = (float)L.in.h;
   const float w[3] = {yw * 0.299f, yw * 0.587f, yw * 0.114f};
-  RC_TILE_LOOP_BEGIN
   float cx[5], cy[5];
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
@@ -67,7 +71,7 @@ __global__ void __launch_bounds__(256) k_xbr_lv3(const PassLaunch L) {
   fpx = fpx - __builtin_floorf(fpx);
   fpy = fpy - __builtin_floorf(fpy);
   const uint8_t* img = frame_ptr(L.in, z);
-#define T(i, j) (GENERIC ? sample_rt(L.in, img, cx[i], cy[j], &lds) : sample<IN_FMT, 0, IN_WRAP>(L.in, img, cx[i], cy[j], &lds))
+#define T(i, j) (GENERIC ? sample_rt(L.in, img, cx[i], cy[j], lds_p) : sample<IN_FMT, 0, IN_WRAP>(L.in, img, cx[i], cy[j], lds_p))
   const float4 A1 = T(1, 0), B1 = T(2, 0), C1 = T(3, 0);
   const float4 A = T(1, 1), B = T(2, 1), C = T(3, 1);
   const float4 D = T(1, 2), E = T(2, 2), F = T(3, 2);
@@ -169,8 +173,201 @@ __global__ void __launch_bounds__(256) k_xbr_lv3(const PassLaunch L) {
   const float4 res1 = mix3(E, pix1, bl1), res2 = mix3(E, pix2, bl2);
   float4 res = c_df(E, res2) < c_df(E, res1) ? res1 : res2;
   res.w = 1.0f;
+  return res;
+}
+
+template <int IN_FMT, int IN_WRAP, int OUT_FMT, bool GENERIC>
+__global__ void __launch_bounds__(256) k_xbr_lv3(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  if (GENERIC || IN_FMT == FMT_SRGB8 || OUT_FMT == FMT_SRGB8) load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float4 res = xbr_pixel<IN_FMT, IN_WRAP, GENERIC>(L, &lds, x, y, z, lo);
   if (GENERIC) store_rt(L, z, x, y, res, &lds);
   else store<OUT_FMT>(L, z, x, y, res, &lds);
+  RC_TILE_LOOP_END
+}
+
+// The general form on the few target rows / columns whose sampling pattern is irregular (listed in
+// L.params by the host, see below); launched after k_xbr_blend on the same stream.
+// grid.x = (rows * ceil(out_w/256) + cols * ceil(out_h/256)), grid.y = frames
+template <int IN_WRAP>
+__global__ void __launch_bounds__(256) k_xbr_fix(const PassLaunch L) {
+  const SrgbLds* none = nullptr;  // RGBX8 in, RGBA8 out: no sRGB tables involved
+  const int n_rows = __float_as_int(L.params[XBR_P_NROWS]), n_cols = __float_as_int(L.params[XBR_P_NCOLS]);
+  const int bx = (L.out_w + 255) >> 8, by = (L.out_h + 255) >> 8;
+  const int z = blockIdx.y;
+  int b = blockIdx.x, x, y;
+  if (b < n_rows * bx) {
+    y = __float_as_int(L.params[XBR_P_ROWS + b / bx]);
+    x = (b % bx) * 256 + threadIdx.x;
+  } else {
+    b -= n_rows * bx;
+    if (b >= n_cols * by) return;
+    x = __float_as_int(L.params[XBR_P_COLS + b / by]);
+    y = (b % by) * 256 + threadIdx.x;
+  }
+  if (x >= L.out_w || y >= L.out_h) return;
+  const float4 res = xbr_pixel<FMT_RGBX8, IN_WRAP, false>(L, none, x, y, z, lower_tri(x, y, L.out_w, L.out_h));
+  store<FMT_RGBA8>(L, z, x, y, res, none);
+}
+
+
+// ---- two-launch form --------------------------------------------------------------------------
+// Everything except the five smoothstep line tests depends only on the 21-texel neighbourhood of
+// the source pixel an output pixel falls in, not on where inside it the output pixel lies.  When
+// the host has checked (kernel_registry.cpp, xbrNeighbourhoodIsRegular) that for every target
+// column / row the five sampled columns / rows are exactly centre-2 .. centre+2, the rules are
+// evaluated once per SOURCE pixel into a 24-bit record (k_xbr_rules) and the per-target-pixel
+// kernel (k_xbr_blend) only evaluates the line tests of the rules that fired.  Same arithmetic,
+// same results; ~225x fewer rule evaluations at 15x magnification.
+//
+// record bits, k = 0..3: [k] edr, [4+k] edr && edr_left, [8+k] edr && edr_up,
+//   [12+k] edr && edr_left && lv3_left, [16+k] edr && edr_up && lv3_up, [20+k] px
+template <int IN_WRAP>
+__global__ void __launch_bounds__(256) k_xbr_rules(const PassLaunch L) {
+  const float yw = L.params[0], thr = L.params[1], thr2 = L.params[2], lv2 = L.params[3], corner = L.params[4];
+  const float w[3] = {yw * 0.299f, yw * 0.587f, yw * 0.114f};
+  const int W = L.in.w, n = L.in.w * L.in.h, total = n * L.n_frames;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int z = idx / n, r = idx - z * n, sy = r / W, sx = r - sy * W;
+    const uint8_t* img = frame_ptr(L.in, z);
+#define T(i, j) fetch_wrapped<FMT_RGBX8, IN_WRAP>(L.in, img, sx + (i) - 2, sy + (j) - 2, nullptr)
+    const float4 A1 = T(1, 0), B1 = T(2, 0), C1 = T(3, 0);
+    const float4 A = T(1, 1), B = T(2, 1), C = T(3, 1);
+    const float4 D = T(1, 2), E = T(2, 2), F = T(3, 2);
+    const float4 G = T(1, 3), H = T(2, 3), I = T(3, 3);
+    const float4 G5 = T(1, 4), H5 = T(2, 4), I5 = T(3, 4);
+    const float4 A0 = T(0, 1), D0 = T(0, 2), G0 = T(0, 3);
+    const float4 C4 = T(4, 1), F4_ = T(4, 2), I4 = T(4, 3);
+#undef T
+    const F4 b = lum4(B, D, H, F, w), c = lum4(C, A, G, I, w);
+    const float le = lum(E, w);
+    const F4 e = F4{{le, le, le, le}};
+    const F4 d = yzwx(b), f = wxyz(b), g = zwxy(c), h = zwxy(b), i = wxyz(c);
+    const F4 i4 = lum4(I4, C1, A0, G5, w), i5 = lum4(I5, C4, A1, G0, w), h5 = lum4(H5, F4_, B1, D0, w);
+    const F4 f4 = yzwx(h5), c1 = yzwx(i4), g0 = wxyz(i5), b1 = zwxy(h5), d0 = wxyz(h5);
+    const F4 wd1 = wd(e, c, g, i, h5, f4, h, f), wd2 = wd(h, d, i5, f, i4, b, e, i);
+    uint32_t rec = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#define EQ(P, Q) (df1(P.v[k], Q.v[k]) < thr)
+#define EQ2(P, Q) (df1(P.v[k], Q.v[k]) < thr2)
+      const bool ne = (e.v[k] != f.v[k]) && (e.v[k] != h.v[k]);
+      bool r1;
+      if (corner == 1.0f) {
+        r1 = ne;
+      } else if (corner == 2.0f) {
+        bool t = !EQ(f, b) && !EQ(h, d);
+        t = t || EQ(e, i);
+        t = t && !EQ(f, i4);
+        t = t && !EQ(h, i5);
+        t = t || EQ(e, g);
+        t = t || EQ(e, c);
+        r1 = ne && t;
+      } else {
+        const bool t1 = (!EQ(f, b) && !EQ(f, c)) || (!EQ(h, d) && !EQ(h, g));
+        const bool t2 = EQ(e, i) && ((!EQ(f, f4) && !EQ(f, i4)) || (!EQ(h, h5) && !EQ(h, i5)));
+        const bool t3 = EQ(e, g) || EQ(e, c);
+        r1 = ne && (t1 || (t2 || t3));
+      }
+      const bool r2_left = (e.v[k] != g.v[k]) && (d.v[k] != g.v[k]);
+      const bool r2_up = (e.v[k] != c.v[k]) && (b.v[k] != c.v[k]);
+      const bool r3_left = EQ2(g, g0) && !EQ2(d0, g0);
+      const bool r3_up = EQ2(c, c1) && !EQ2(b1, c1);
+#undef EQ
+#undef EQ2
+      const float dfg = df1(f.v[k], g.v[k]), dhc = df1(h.v[k], c.v[k]);
+      const bool edr = (wd1.v[k] < wd2.v[k]) && r1;
+      const bool el = edr && (lv2 * dfg <= dhc) && r2_left;
+      const bool eu = edr && (dfg >= lv2 * dhc) && r2_up;
+      const bool px = df1(e.v[k], f.v[k]) <= df1(e.v[k], h.v[k]);
+      rec |= (edr ? 1u : 0u) << k | (el ? 1u : 0u) << (4 + k) | (eu ? 1u : 0u) << (8 + k) |
+             ((el && r3_left) ? 1u : 0u) << (12 + k) | ((eu && r3_up) ? 1u : 0u) << (16 + k) | (px ? 1u : 0u) << (20 + k);
+    }
+    reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.scratch) + L.scratch_frame_stride * (uint64_t)z)[r] = rec;
+  }
+}
+
+// smoothstep(C - 0.4, C + 0.4, A*fy + B*fx) with compile-time A, B, C: the division by the folded
+// (e1 - e0) uses div_const_ (exhaustively checked exact for the four widths that occur)
+template <int K, int LINE>
+__device__ __forceinline__ float line_sstep_c(float fy, float fx) {
+  constexpr float A_[5][4] = {{1.0f, -1.0f, -1.0f, 1.0f}, {1.0f, -1.0f, -1.0f, 1.0f}, {1.0f, -1.0f, -1.0f, 1.0f},
+                              {6.0f, -2.0f, -6.0f, 2.0f}, {2.0f, -6.0f, -2.0f, 6.0f}};
+  constexpr float B_[5][4] = {{1.0f, 1.0f, -1.0f, -1.0f}, {0.5f, 2.0f, -0.5f, -2.0f}, {2.0f, 0.5f, -2.0f, -0.5f},
+                              {2.0f, 6.0f, -2.0f, -6.0f}, {6.0f, 2.0f, -6.0f, -2.0f}};
+  constexpr float C_[5][4] = {{1.5f, 0.5f, -0.5f, 0.5f}, {1.0f, 1.0f, -0.5f, 0.0f}, {2.0f, 0.0f, -1.0f, 0.5f},
+                              {5.0f, 3.0f, -3.0f, -1.0f}, {5.0f, -1.0f, -3.0f, 3.0f}};
+  constexpr float A = A_[LINE][K], B = B_[LINE][K], C = C_[LINE][K];
+  constexpr float e0 = C - 0.4f, e1 = C + 0.4f, d = e1 - e0, rd = 1.0f / d;
+  const float num = (A == -1.0f && B == -1.0f) ? (A * fy + B * fx) - e0 : (A * fy - e0) + B * fx;
+  float t = div_const_(num, d, rd);
+  t = t > 0.0f ? t : 0.0f;
+  t = t < 1.0f ? t : 1.0f;
+  return t * (t * (3.0f - 2.0f * t));
+}
+
+template <int K>
+__device__ __forceinline__ void blend_rule(uint32_t rec, float fpy, float fpx, float& m, bool& any) {
+  m = 0.0f;
+  any = false;
+  if (rec & (1u << K)) {
+    const float fx45 = line_sstep_c<K, 0>(fpy, fpx);
+    float f30 = 0.0f, f60 = 0.0f, f15 = 0.0f, f75 = 0.0f;
+    if (rec & (1u << (4 + K))) {
+      f30 = line_sstep_c<K, 1>(fpy, fpx);
+      if (rec & (1u << (12 + K))) f15 = line_sstep_c<K, 3>(fpy, fpx);
+    }
+    if (rec & (1u << (8 + K))) {
+      f60 = line_sstep_c<K, 2>(fpy, fpx);
+      if (rec & (1u << (16 + K))) f75 = line_sstep_c<K, 4>(fpy, fpx);
+    }
+    // final = float(nc) * fx with nc = rule && (fx != 0): equals fx itself (0 stays 0)
+    const float m1 = f15 > f75 ? f15 : f75, m2 = f30 > f60 ? f30 : f60;
+    const float m3 = m1 > m2 ? m1 : m2;
+    m = m3 > fx45 ? m3 : fx45;
+    any = (f75 != 0.0f) || (f15 != 0.0f) || (f30 != 0.0f) || (f60 != 0.0f) || (fx45 != 0.0f);
+  }
+}
+
+// plane[2] = TEX0.x, plane[7] = TEX0.y; RGBX8 nearest source, RGBA8 target
+template <int IN_WRAP>
+__global__ void __launch_bounds__(256) k_xbr_blend(const PassLaunch L) {
+  const float tsx = (float)L.in.w, tsy = (float)L.in.h;
+  RC_TILE_LOOP_BEGIN
+  const float ux = vary(L.plane[2], x, y, lo) * tsx, uy = vary(L.plane[7], x, y, lo) * tsy;
+  const float fx0 = __builtin_floorf(ux), fy0 = __builtin_floorf(uy);
+  const float fpx = ux - fx0, fpy = uy - fy0;
+  const int sx = (int)fx0, sy = (int)fy0;
+  const uint8_t* img = frame_ptr(L.in, z);
+  const uint32_t rec =
+      reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(L.scratch) + L.scratch_frame_stride * (uint64_t)z)[sy * L.in.w + sx];
+  uint32_t* dst = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z) + ((size_t)y * L.out_w + x);
+  if ((rec & 15u) == 0u) {
+    // no rule fires: both blends are 0 and the result is E itself; unorm8(k/255) = k
+    *dst = *reinterpret_cast<const uint32_t*>(img + ((size_t)sy * L.in.w + sx) * 4) | 0xff000000u;
+    continue;
+  }
+  float maximo[4];
+  bool nc[4];
+  blend_rule<0>(rec, fpy, fpx, maximo[0], nc[0]);
+  blend_rule<1>(rec, fpy, fpx, maximo[1], nc[1]);
+  blend_rule<2>(rec, fpy, fpx, maximo[2], nc[2]);
+  blend_rule<3>(rec, fpy, fpx, maximo[3], nc[3]);
+  const float4 E = texel<FMT_RGBX8>(L.in, img, sx, sy, nullptr);
+  const float4 B = fetch_wrapped<FMT_RGBX8, IN_WRAP>(L.in, img, sx, sy - 1, nullptr);
+  const float4 D = fetch_wrapped<FMT_RGBX8, IN_WRAP>(L.in, img, sx - 1, sy, nullptr);
+  const float4 F = fetch_wrapped<FMT_RGBX8, IN_WRAP>(L.in, img, sx + 1, sy, nullptr);
+  const float4 H = fetch_wrapped<FMT_RGBX8, IN_WRAP>(L.in, img, sx, sy + 1, nullptr);
+  const float4 pk0 = (rec >> 20) & 1u ? F : H, pk1 = (rec >> 21) & 1u ? B : F, pk2 = (rec >> 22) & 1u ? D : B,
+               pk3 = (rec >> 23) & 1u ? H : D;
+  const float4 pix1 = nc[0] ? pk0 : nc[1] ? pk1 : nc[2] ? pk2 : pk3;
+  const float bl1 = nc[0] ? maximo[0] : nc[1] ? maximo[1] : nc[2] ? maximo[2] : maximo[3];
+  const float4 pix2 = nc[3] ? pk3 : nc[2] ? pk2 : nc[1] ? pk1 : pk0;
+  const float bl2 = nc[3] ? maximo[3] : nc[2] ? maximo[2] : nc[1] ? maximo[1] : maximo[0];
+  const float4 res1 = mix3(E, pix1, bl1), res2 = mix3(E, pix2, bl2);
+  const float4 res = c_df(E, res2) < c_df(E, res1) ? res1 : res2;
+  *dst = unorm8(res.x) | (unorm8(res.y) << 8) | (unorm8(res.z) << 16) | 0xff000000u;
   RC_TILE_LOOP_END
 }
 
@@ -179,7 +376,27 @@ __global__ void __launch_bounds__(256) k_xbr_lv3(const PassLaunch L) {
 namespace rck {
 
 hipError_t launch_xbr_lv3(const PassLaunch& L, hipStream_t s) {
-  // shipped preset: nearest on the RGB source frame, RGBA8 viewport-sized target
+  const bool shipped = L.in.fmt == FMT_RGBX8 && !L.in.linear && L.out_fmt == FMT_RGBA8 &&
+                       (L.in.wrap == WRAP_EDGE || L.in.wrap == WRAP_BORDER);
+  if (shipped && (L.flags & RC_FLAG_XBR_REGULAR) && !(L.flags & RC_FLAG_GENERAL_ONLY) && L.scratch) {
+    const long n = (long)L.in.w * L.in.h * L.n_frames;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    int n_rows, n_cols;
+    std::memcpy(&n_rows, &L.params[XBR_P_NROWS], 4);
+    std::memcpy(&n_cols, &L.params[XBR_P_NCOLS], 4);
+    const unsigned fix_blocks = (unsigned)(n_rows * ((L.out_w + 255) / 256) + n_cols * ((L.out_h + 255) / 256));
+    if (L.in.wrap == WRAP_EDGE) {
+      hipLaunchKernelGGL((k_xbr_rules<WRAP_EDGE>), dim3(blocks ? blocks : 1), dim3(256), 0, s, L);
+      hipLaunchKernelGGL((k_xbr_blend<WRAP_EDGE>), px_grid(L), px_block(), 0, s, L);
+      if (fix_blocks) hipLaunchKernelGGL((k_xbr_fix<WRAP_EDGE>), dim3(fix_blocks, L.n_frames), dim3(256), 0, s, L);
+    } else {
+      hipLaunchKernelGGL((k_xbr_rules<WRAP_BORDER>), dim3(blocks ? blocks : 1), dim3(256), 0, s, L);
+      hipLaunchKernelGGL((k_xbr_blend<WRAP_BORDER>), px_grid(L), px_block(), 0, s, L);
+      if (fix_blocks) hipLaunchKernelGGL((k_xbr_fix<WRAP_BORDER>), dim3(fix_blocks, L.n_frames), dim3(256), 0, s, L);
+    }
+    return hipGetLastError();
+  }
+  // general form (any sampler state / target format, or an irregular sampling pattern): nearest on the RGB source frame, RGBA8 viewport-sized target
   if (L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8)
     hipLaunchKernelGGL((k_xbr_lv3<FMT_RGBX8, WRAP_EDGE, FMT_RGBA8, false>), px_grid(L), px_block(), 0, s, L);
   else if (L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_BORDER && L.out_fmt == FMT_RGBA8)

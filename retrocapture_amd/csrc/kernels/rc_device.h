@@ -33,6 +33,10 @@ struct Plane {
   float a0_lo, dx_lo, dy_lo, a0_up, dx_up, dy_up;
 };
 
+// PassLaunch::flags bits (bit 0 is crt-royale's RC_FLAG_UNDEF_VARYING_ZERO, kernels/royale_params.h)
+constexpr int RC_FLAG_GENERAL_ONLY = 1 << 16; // launchers must pick the general kernel form
+constexpr int RC_FLAG_XBR_REGULAR = 1 << 8;  // xbr: sampled columns/rows are centre-2..centre+2 for every target pixel
+
 constexpr int kMaxExtra = 6;
 constexpr int kMaxPlanes = 12;
 constexpr int kMaxParams = 48;
@@ -42,6 +46,8 @@ struct PassLaunch {
   Tex extra[kMaxExtra];   // PassPrev / alias / OrigTexture / LUT samplers, kernel specific
   void* out;
   uint64_t out_frame_stride;
+  void* scratch;                 // per-pass device scratch (KernelEntry::scratch_bytes per frame), or null
+  uint64_t scratch_frame_stride;
   int out_w, out_h, out_fmt;
   int src_w, src_h;       // OriginalSize
   int vp_w, vp_h;         // viewport

@@ -247,6 +247,9 @@ void rc_engine_set_chunk_frames(rc_engine* e, uint32_t n) {
 void rc_engine_set_undefined_varying_zero(rc_engine* e, int zero) {
   if (e) e->impl.setUndefinedVaryingZero(zero != 0);
 }
+void rc_engine_set_general_kernels_only(rc_engine* e, int general_only) {
+  if (e) e->impl.setGeneralKernelsOnly(general_only != 0);
+}
 void rc_engine_set_allow_missing_sources(rc_engine* e, int allow) {
   if (e) e->impl.setAllowMissingSources(allow != 0);
 }

@@ -86,8 +86,10 @@ void ShaderEngine::shutdown() {  // :62-86
 }
 
 void ShaderEngine::cleanupPresetPasses() {
-  for (auto& p : m_passes)
+  for (auto& p : m_passes) {
     if (p.target.ptr) (void)hipFree(p.target.ptr);
+    if (p.scratch.ptr) (void)hipFree(p.scratch.ptr);
+  }
   m_passes.clear();
 }
 
@@ -617,7 +619,13 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
         geo.chain_w[q] = (int)m_passes[(size_t)q].width;
         geo.chain_h[q] = (int)m_passes[(size_t)q].height;
       }
-      L.flags = m_undefVaryingZero ? 1 : 0;
+      L.flags = (m_undefVaryingZero ? 1 : 0) | (m_generalOnly ? rcd::RC_FLAG_GENERAL_ONLY : 0);
+      if (k.scratch_bytes) {
+        const uint64_t per_frame = k.scratch_bytes(geo);
+        if (!ensureBuffer(pd.scratch, per_frame * nFrames)) return false;
+        L.scratch = pd.scratch.ptr;
+        L.scratch_frame_stride = per_frame;
+      }
       if (k.setup) k.setup(geo, L);
       if (k.validate) {
         if (const char* why = k.validate(L.params)) {

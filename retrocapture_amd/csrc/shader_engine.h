@@ -38,6 +38,7 @@ struct ShaderPassData {  // reference ShaderEngine.h:19-40
   uint32_t width = 0, height = 0;
   int format = rcd::FMT_RGBA8;
   DeviceBuffer target;      // [chunk or batch][height][width] texels
+  DeviceBuffer scratch;     // kernel-private scratch, [chunk] frames (KernelEntry::scratch_bytes)
   size_t frameBytes = 0;
   std::map<std::string, float> extractedParameters;
   std::map<std::string, ShaderParameterInfo> parameterInfo;
@@ -102,6 +103,7 @@ class ShaderEngine {
   // fragment shader discards everything, as on Mesa llvmpipe; true: the varying reads 0, as on
   // GL drivers that zero undefined varyings, and the resized phosphor mask is rendered.
   void setUndefinedVaryingZero(bool zero) { m_undefVaryingZero = zero; }
+  void setGeneralKernelsOnly(bool on) { m_generalOnly = on; }
   uint32_t getChunkFrames() const { return m_chunk; }
   hipStream_t stream() const { return m_stream; }
   size_t passCount() const { return m_passes.size(); }
@@ -146,6 +148,7 @@ class ShaderEngine {
   bool m_singleShader = false;
   bool m_allowMissingSources = false;
   bool m_undefVaryingZero = false;
+  bool m_generalOnly = false;
   struct Vec4 { float x, y, z, w; };
   std::unordered_map<std::string, Vec4> m_uniforms;
   DeviceBuffer m_batchOutput;

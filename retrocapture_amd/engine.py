@@ -66,6 +66,7 @@ SYMBOLS = [
     ("rc_engine_set_chunk_frames", None, [C.c_void_p, C.c_uint32]),
     ("rc_engine_set_allow_missing_sources", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_undefined_varying_zero", None, [C.c_void_p, C.c_int]),
+    ("rc_engine_set_general_kernels_only", None, [C.c_void_p, C.c_int]),
     ("rc_last_error", C.c_char_p, []),
     ("rc_version", C.c_char_p, []),
     ("rc_kernel_list", C.c_size_t, [C.c_char_p, C.c_size_t]),
@@ -276,6 +277,9 @@ class ShaderEngine:
 
     def setUndefinedVaryingZero(self, zero):
         self._lib.rc_engine_set_undefined_varying_zero(self._need(), int(bool(zero)))
+
+    def setGeneralKernelsOnly(self, on):
+        self._lib.rc_engine_set_general_kernels_only(self._need(), int(bool(on)))
 
     def passCount(self):
         return self._lib.rc_engine_pass_count(self._need())

@@ -177,6 +177,28 @@ def test_xbr_full_size_properties(preset_tree, rc_lib):
     e.shutdown()
 
 
+@pytest.mark.parametrize("w,h,vw,vh", [(64, 56, 960, 840), (37, 29, 259, 203), (50, 40, 333, 217), (31, 17, 40, 23)])
+def test_xbr_general_and_per_source_pixel_forms_agree(w, h, vw, vh, preset_tree, rc_lib):
+    """xbr-lv3 runs as rules-per-source-pixel + blend when the host has verified the sampling
+    pattern; the general one-kernel form must give the same bytes, and both equal the oracle."""
+    from gpu_util import make_engine, run_engine
+    from retrocapture_amd import engine as eng
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_golden import pixel_art
+    frames = np.stack([pixel_art(w, h, 50 + w), np.random.default_rng(w).integers(0, 256, (h, w, 3), dtype=np.uint8)])
+    e = make_engine(preset_tree["xbr-lv3"], vw, vh)
+    fast = run_engine(e, frames)
+    e.setGeneralKernelsOnly(True)
+    general = run_engine(e, frames)
+    assert np.array_equal(fast, general)
+    passes = eng.preset_dump(preset_tree["xbr-lv3"])["passes"]
+    for k in range(2):
+        want = run_chain(passes, frames[k], vw, vh)
+        assert np.array_equal(general[k], want[-1]), "frame %d" % k
+    e.shutdown()
+
+
 def test_batch_equals_single_frames(preset_tree, rc_lib):
     """N frames in one call == N successive applyShader calls (FrameCount advances per frame)."""
     from gpu_util import make_engine, run_engine
