@@ -150,6 +150,12 @@ void rc_engine_set_undefined_varying_zero(rc_engine* e, int zero);
  * results; 1 forces the general form (diagnostics / tests).  Default 0. */
 void rc_engine_set_general_kernels_only(rc_engine* e, int general_only);
 
+/* Device self-test: the division shortcuts the kernels use (log2's mantissa division, the
+ * safe-range division, constant divisors) against IEEE division on the device's own reciprocal
+ * instruction: all 2^23 mantissas / 2^26 operand pairs / 6 x 2^24 quotients.  mismatches[0..2]
+ * receive the counts (all 0 on a conforming device).  Returns RC_OK or RC_ERR_DEVICE. */
+int rc_selftest_fastmath(int device, uint64_t mismatches[3]);
+
 const char* rc_last_error(void);
 const char* rc_version(void);
 /* Names of the registered kernels ("identity\n" list) for diagnostics. */

@@ -27,6 +27,8 @@ hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s);
 
+hipError_t launch_selftest(unsigned long long* d_counts, hipStream_t s);
+
 // 64x4 pixel tiles: one wave per row segment, so each wave stores 256 contiguous bytes of an
 // RGBA8 row.  A workgroup walks tiles grid-stride (tile index = frame, tile row, tile column),
 // which amortises its prologue (sRGB tables into LDS) over many tiles; the grid is capped at

@@ -30,12 +30,15 @@ struct S {
     return sample<FMT, LIN, WRAP>(t, img, s, v, l);
   }
   static bool matches(const Tex& t) { return t.fmt == FMT && (t.linear != 0) == (LIN != 0) && t.wrap == WRAP; }
+  // 8-bit texels: every sampled value is 0 or in [2^-40, 1], which is what div_safe_ needs
+  static constexpr bool kUnitRange = FMT != FMT_F32;
 };
 struct SRT {
   static __device__ __forceinline__ float4 get(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* l) {
     return sample_rt(t, img, s, v, l);
   }
   static bool matches(const Tex&) { return true; }
+  static constexpr bool kUnitRange = false;  // may be an RGBA32F texture with arbitrary values
 };
 template <int OUT>
 struct St {
@@ -101,11 +104,15 @@ __global__ void __launch_bounds__(256) k_royale_first(const PassLaunch L) {
 
 // ------------------------------------------------------------------------------- P1 ------
 // scanlines-vertical-interlacing.glsl FS 5982-6141; beam functions 4775-4998; gamma_impl 3907.
+template <bool SAFE>
+__device__ __forceinline__ float div_sel_(float n, float d) { return SAFE ? div_safe_(n, d) : n / d; }
+
+template <bool SAFE>
 __device__ __forceinline__ float gamma_impl1(float s, float s_inv) {
   const float g = 1.12906830989f, c0 = 0.8109119309638332633713423362694399653724431f;
   const float c1 = 0.4808354605142681877121661197951496120000040f, e = 2.71828182845904523536028747135266249775724709f;
   const float sph = s + 0.5f;
-  const float lanczos_sum = c0 + c1 / (s + 1.0f);
+  const float lanczos_sum = c0 + div_sel_<SAFE>(c1, s + 1.0f);  // s + 1 in [1.25, 1.5]
   // base is in [0.69, 0.78] for s = 1/beta in [1/4, 1/2]: a positive normal, no log2 edge cases
   const float base = div_const_(sph + g, e, 1.0f / e);
   return (exp2_(log2_core_(base) * sph) * lanczos_sum) * s_inv;
@@ -114,16 +121,19 @@ __device__ __forceinline__ float gamma_impl1(float s, float s_inv) {
 struct BeamShape {  // per (scanline colour, channel): everything that does not depend on dist
   float alpha_inv, beta, scale3;
 };
+template <bool SAFE>
 __device__ __forceinline__ BeamShape beam_shape(float color, float sigma_range, float shape_range) {
   const float lg = log2_(color);  // pow(color, p) = exp2(log2(color) * p) for both exponents
   const float sigma = 0.02f + sigma_range * exp2_(lg * (1.0f / 3.0f));
   const float alpha = 1.41421356237309504880f * sigma;  // sqrtf(2.0f)
   const float beta = 2.0f + shape_range * exp2_(lg * (1.0f / 4.0f));
   BeamShape b;
-  b.alpha_inv = 1.0f / alpha;
+  // SAFE (colour sampled from an 8-bit texture): operand ranges for div_safe_: alpha in [0.028, 0.43], beta in [2, 4], gamma_impl1 in [0.88, 3.7];
+  // color is 0 or >= 2^-13 (a filtered sRGB8 decode) so the numerator is 0 or >= 2^-14
+  b.alpha_inv = div_sel_<SAFE>(1.0f, alpha);
   b.beta = beta;
-  const float beta_inv = 1.0f / beta;
-  const float scale = color * beta * 0.5f * b.alpha_inv / gamma_impl1(beta_inv, beta);
+  const float beta_inv = div_sel_<SAFE>(1.0f, beta);
+  const float scale = div_sel_<SAFE>(color * beta * 0.5f * b.alpha_inv, gamma_impl1<SAFE>(beta_inv, beta));
   b.scale3 = div_const_(scale, 3.0f, 1.0f / 3.0f);
   return b;
 }
@@ -171,12 +181,12 @@ __global__ void __launch_bounds__(256, 8) k_royale_scan_v(const PassLaunch L) {
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
     const float d2 = dist - conv_y[ch];
-    const float k2 = beam_contrib(beam_shape(c2[ch], sigma_range, shape_range), d2, off);
+    const float k2 = beam_contrib(beam_shape<SI::kUnitRange>(c2[ch], sigma_range, shape_range), d2, off);
     // additive constants re-associated as the GL's compiler does: 1-(dist-c) -> (1+c)-dist, ...
-    const float k3 = beam_contrib(beam_shape(c3[ch], sigma_range, shape_range), __builtin_fabsf((1.0f + conv_y[ch]) - dist), off);
+    const float k3 = beam_contrib(beam_shape<SI::kUnitRange>(c3[ch], sigma_range, shape_range), __builtin_fabsf((1.0f + conv_y[ch]) - dist), off);
     float inten = k2 + k3;
     const float d14 = mix_rt(dist + (1.0f - conv_y[ch]), (2.0f + conv_y[ch]) - dist, dist_round);
-    inten += beam_contrib(beam_shape(co[ch], sigma_range, shape_range), d14, off);
+    inten += beam_contrib(beam_shape<SI::kUnitRange>(co[ch], sigma_range, shape_range), d14, off);
     out[ch] = inten * 0.5f;
   }
   SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);

@@ -80,6 +80,38 @@ RC_HD float exp2_(float x) {
   return e * fma_(odd, fp, even);
 }
 
+// num / den for the one division inside log2: num = m - 1 in [0,1), den = m + 1 in [2,3].  On the
+// device: reciprocal estimate, one Newton step, quotient, two fused corrections - no scaling or
+// fix-up is needed in this range.  Checked exhaustively against IEEE division for all 2^23 mantissas
+// with every reciprocal seed within 1 ulp (tests/test_fastmath.py repeats it on the real v_rcp_f32).
+RC_HD float div_log2_(float num, float den) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r = __builtin_amdgcn_rcpf(den);
+  r = fma_(fma_(-den, r, 1.0f), r, r);
+  const float q = num * r;
+  return fma_(fma_(-den, q, num), r, q);
+#else
+  return num / den;
+#endif
+}
+
+// n / d, correctly rounded, for operands away from the exponent extremes: n == 0 or 2^-60 <= |n| <=
+// 2^60, and 2^-60 <= |d| <= 2^60.  This is the compiler's own IEEE division sequence (reciprocal
+// estimate, Newton step, quotient, three fused corrections) without the v_div_scale / v_div_fixup /
+// denormal-mode bracketing, which only act on operands outside that range: same bits, about half
+// the issue slots.  Callers state why their operands qualify.
+RC_HD float div_safe_(float n, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r = __builtin_amdgcn_rcpf(d);
+  r = fma_(fma_(-d, r, 1.0f), r, r);
+  float q = n * r;
+  q = fma_(fma_(-d, q, n), r, q);
+  return fma_(fma_(-d, q, n), r, q);
+#else
+  return n / d;
+#endif
+}
+
 RC_HD float log2_(float x) {
   uint32_t i = f2bits(x);
   // zero / denormal -> -inf, negative -> NaN, +inf -> +inf (the GL's "safe" log2)
@@ -88,7 +120,7 @@ RC_HD float log2_(float x) {
   if (i == 0x7f800000u) return __builtin_inff();
   float logexp = (float)((int32_t)((i & 0x7f800000u) >> 23) - 127);
   float mant = bits2f((i & 0x007fffffu) | 0x3f800000u);
-  float y = (mant - 1.0f) / (mant + 1.0f);
+  float y = div_log2_(mant - 1.0f, mant + 1.0f);
   float z = y * y;
   float z2 = z * z;
   float even = fma_(z2, 0.406718052498846252698f, 0.577440339438736392009f);
@@ -104,7 +136,7 @@ RC_HD float log2_core_(float x) {
   uint32_t i = f2bits(x);
   float logexp = (float)((int32_t)((i & 0x7f800000u) >> 23) - 127);
   float mant = bits2f((i & 0x007fffffu) | 0x3f800000u);
-  float y = (mant - 1.0f) / (mant + 1.0f);
+  float y = div_log2_(mant - 1.0f, mant + 1.0f);
   float z = y * y;
   float z2 = z * z;
   float even = fma_(z2, 0.406718052498846252698f, 0.577440339438736392009f);

@@ -247,6 +247,20 @@ void rc_engine_set_chunk_frames(rc_engine* e, uint32_t n) {
 void rc_engine_set_undefined_varying_zero(rc_engine* e, int zero) {
   if (e) e->impl.setUndefinedVaryingZero(zero != 0);
 }
+int rc_selftest_fastmath(int device, uint64_t mismatches[3]) {
+  if (!mismatches) return RC_ERR_INVALID;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return RC_ERR_DEVICE;
+  unsigned long long* d = nullptr;
+  if (hipMalloc(&d, 3 * sizeof(unsigned long long)) != hipSuccess) return RC_ERR_DEVICE;
+  int rc = RC_OK;
+  unsigned long long h[3] = {0, 0, 0};
+  if (hipMemset(d, 0, sizeof(h)) != hipSuccess || rck::launch_selftest(d, nullptr) != hipSuccess ||
+      hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+    rc = RC_ERR_DEVICE;
+  (void)hipFree(d);
+  for (int i = 0; i < 3; ++i) mismatches[i] = h[i];
+  return rc;
+}
 void rc_engine_set_general_kernels_only(rc_engine* e, int general_only) {
   if (e) e->impl.setGeneralKernelsOnly(general_only != 0);
 }

@@ -67,6 +67,7 @@ SYMBOLS = [
     ("rc_engine_set_allow_missing_sources", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_undefined_varying_zero", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_general_kernels_only", None, [C.c_void_p, C.c_int]),
+    ("rc_selftest_fastmath", C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     ("rc_last_error", C.c_char_p, []),
     ("rc_version", C.c_char_p, []),
     ("rc_kernel_list", C.c_size_t, [C.c_char_p, C.c_size_t]),
@@ -126,6 +127,15 @@ def preset_dump(path):
 
 def shader_params(path):
     return _json_call(load_library().rc_shader_params_json, path)
+
+
+def selftest_fastmath(device=0):
+    """Mismatch counts (log2 division, safe-range division, constant divisors) of the device self-test."""
+    out = (C.c_uint64 * 3)()
+    rc = load_library().rc_selftest_fastmath(int(device), out)
+    if rc != 0:
+        raise RcError("rc_selftest_fastmath failed (%d)" % rc)
+    return list(out)
 
 
 def kernel_list():
