@@ -77,6 +77,66 @@ def cpu_baseline(key, w, h, vw, vh, tree, budget_s=15.0):
                       % (n, cores, dt)}
 
 
+def io_measurements(e, w, h, batch, reps):
+    """Side measurements: (1) the ingest / egress kernels alone, algorithmic bytes / event time;
+    (2) the whole host-to-host frame path the reference runs per frame (FrameProcessor upload ->
+    chain -> readback): pinned RGB24 in, H2D, ingest, chain, egress, D2H, pinned RGB24 out."""
+    import torch
+    from retrocapture_amd import engine as eng
+    res = {}
+    n = batch
+    px = w * h * n
+    src = {f: torch.randint(0, 256, (px * b,), dtype=torch.uint8, device="cuda")
+           for f, b in (("rgb24", 3), ("bgra", 4), ("yuyv422", 2))}
+    rgba = torch.empty(px * 4, dtype=torch.uint8, device="cuda")
+    rgb = torch.empty(px * 3, dtype=torch.uint8, device="cuda")
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e-3
+
+    st = torch.cuda.current_stream().cuda_stream
+    for f, b in (("rgb24", 3), ("bgra", 4), ("yuyv422", 2)):
+        t = timed(lambda: eng.ingest(src[f], f, w, h, n, rgba, stream=st))
+        res["ingest_" + f] = {"GB/s": px * (b + 4) / t / 1e9, "frac_of_8TBs": px * (b + 4) / t / 8e12, "frames": n, "w": w, "h": h}
+    t = timed(lambda: eng.egress_rgb24(rgba, w, h, n, rgb, stream=st))
+    res["egress_rgb24"] = {"GB/s": px * 7 / t / 1e9, "frac_of_8TBs": px * 7 / t / 8e12, "frames": n, "w": w, "h": h}
+
+    # host-to-host: the chain's own output size may differ from the input's
+    h_in = torch.randint(0, 256, (px * 3,), dtype=torch.uint8).pin_memory()
+    d_in = torch.empty(px * 3, dtype=torch.uint8, device="cuda")
+    e.applyShaderBatch(rgba.view(n, h, w, 4), n, w, h)
+    ow, oh = e.getOutputWidth(), e.getOutputHeight()
+    d_out = torch.empty(n * ow * oh * 3, dtype=torch.uint8, device="cuda")
+    h_out = torch.empty(n * ow * oh * 3, dtype=torch.uint8).pin_memory()
+
+    def frame_path():
+        d_in.copy_(h_in, non_blocking=True)
+        eng.ingest(d_in, "rgb24", w, h, n, rgba, stream=st)
+        ptr, _, _ = e.applyShaderBatch(rgba, n, w, h)
+        eng.egress_rgb24(ptr, ow, oh, n, d_out, stream=st)
+        h_out.copy_(d_out, non_blocking=True)
+
+    frame_path()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        frame_path()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    res["host_to_host"] = {"frames_per_s": n / dt, "bytes_in_per_frame": w * h * 3, "bytes_out_per_frame": ow * oh * 3,
+                           "pcie_GB/s": n * (w * h * 3 + ow * oh * 3) / dt / 1e9,
+                           "note": "one stream, copies not overlapped with compute; PCIe-inclusive, never `value`"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +146,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="frames per kernel launch (0 = engine default)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--io", action="store_true",
+                    help="also time the ingest / egress kernels and the whole host-to-host frame path (side "
+                         "measurements under \"io\"; never part of `value`)")
     args = ap.parse_args()
 
     import numpy as np
@@ -180,6 +243,8 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_per_launch},
         "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in prof],
     }
+    if args.io and rank == 0:
+        out["io"] = io_measurements(e, w, h, args.batch, max(3, args.steps))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(key, w, h, vw, vh, tree)

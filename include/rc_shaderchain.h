@@ -150,6 +150,20 @@ void rc_engine_set_undefined_varying_zero(rc_engine* e, int zero);
  * results; 1 forces the general form (diagnostics / tests).  Default 0. */
 void rc_engine_set_general_kernels_only(rc_engine* e, int general_only);
 
+/* ---- frame ingest / egress (device buffers; stream may be NULL) ------------------------------
+ * rc_ingest replaces the pixel-format handling of FrameProcessor::processFrame (reference
+ * src/processing/FrameProcessor.cpp:43-222: RGB24 upload, BGRA/RGBA swizzle, YUYV422 through
+ * libswscale) and produces the tightly packed RGBA8 frames rc_engine_apply takes (row 0 first,
+ * alpha 255).  rc_egress_rgb24 replaces the readback's alpha strip (reference
+ * src/core/FrameCapturePipeline.cpp:1060-1080): RGBA8 -> tightly packed RGB24, rows optionally
+ * reversed.  n frames are contiguous on both sides.  YUYV422 needs an even width. */
+typedef enum { RC_PIX_RGB24 = 0, RC_PIX_BGRA = 1, RC_PIX_RGBA = 2, RC_PIX_YUYV422 = 3 } rc_pixfmt;
+int rc_ingest(const void* d_src, int pixfmt, uint32_t width, uint32_t height, uint32_t n_frames, void* d_rgba8, void* stream);
+int rc_egress_rgb24(const void* d_rgba8, uint32_t width, uint32_t height, uint32_t n_frames, int flip_y, void* d_rgb24,
+                    void* stream);
+/* bytes per frame of a pixel format (0 for an unknown one) */
+size_t rc_pixfmt_frame_bytes(int pixfmt, uint32_t width, uint32_t height);
+
 /* Device self-test: the division shortcuts the kernels use (log2's mantissa division, the
  * safe-range division, constant divisors) against IEEE division on the device's own reciprocal
  * instruction: all 2^23 mantissas / 2^26 operand pairs / 6 x 2^24 quotients.  mismatches[0..2]

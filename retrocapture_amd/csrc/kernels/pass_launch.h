@@ -27,6 +27,9 @@ hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s);
 
+// frame_io.hip: pixel-format conversion either side of the chain (fmt: 0 RGB24, 1 BGRA, 2 RGBA, 3 YUYV422)
+hipError_t launch_ingest(const void* src, int fmt, uint32_t w, uint32_t h, uint32_t n, void* dst_rgba8, hipStream_t s);
+hipError_t launch_egress_rgb24(const void* src_rgba8, uint32_t w, uint32_t h, uint32_t n, int flip_y, void* dst, hipStream_t s);
 hipError_t launch_selftest(unsigned long long* d_counts, hipStream_t s);
 
 // 64x4 pixel tiles: one wave per row segment, so each wave stores 256 contiguous bytes of an

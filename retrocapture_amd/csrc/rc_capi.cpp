@@ -247,6 +247,27 @@ void rc_engine_set_chunk_frames(rc_engine* e, uint32_t n) {
 void rc_engine_set_undefined_varying_zero(rc_engine* e, int zero) {
   if (e) e->impl.setUndefinedVaryingZero(zero != 0);
 }
+int rc_ingest(const void* d_src, int pixfmt, uint32_t width, uint32_t height, uint32_t n_frames, void* d_rgba8, void* stream) {
+  if (!d_src || !d_rgba8 || pixfmt < 0 || pixfmt > 3 || (pixfmt == RC_PIX_YUYV422 && (width & 1u))) return RC_ERR_INVALID;
+  return rck::launch_ingest(d_src, pixfmt, width, height, n_frames, d_rgba8, static_cast<hipStream_t>(stream)) == hipSuccess
+             ? RC_OK : RC_ERR_DEVICE;
+}
+int rc_egress_rgb24(const void* d_rgba8, uint32_t width, uint32_t height, uint32_t n_frames, int flip_y, void* d_rgb24,
+                    void* stream) {
+  if (!d_rgba8 || !d_rgb24) return RC_ERR_INVALID;
+  return rck::launch_egress_rgb24(d_rgba8, width, height, n_frames, flip_y, d_rgb24, static_cast<hipStream_t>(stream)) == hipSuccess
+             ? RC_OK : RC_ERR_DEVICE;
+}
+size_t rc_pixfmt_frame_bytes(int pixfmt, uint32_t width, uint32_t height) {
+  const size_t px = (size_t)width * height;
+  switch (pixfmt) {
+    case RC_PIX_RGB24: return px * 3;
+    case RC_PIX_BGRA:
+    case RC_PIX_RGBA: return px * 4;
+    case RC_PIX_YUYV422: return px * 2;
+    default: return 0;
+  }
+}
 int rc_selftest_fastmath(int device, uint64_t mismatches[3]) {
   if (!mismatches) return RC_ERR_INVALID;
   if (device >= 0 && hipSetDevice(device) != hipSuccess) return RC_ERR_DEVICE;

@@ -67,6 +67,9 @@ SYMBOLS = [
     ("rc_engine_set_allow_missing_sources", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_undefined_varying_zero", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_general_kernels_only", None, [C.c_void_p, C.c_int]),
+    ("rc_ingest", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("rc_egress_rgb24", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
+    ("rc_pixfmt_frame_bytes", C.c_size_t, [C.c_int, C.c_uint32, C.c_uint32]),
     ("rc_selftest_fastmath", C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     ("rc_last_error", C.c_char_p, []),
     ("rc_version", C.c_char_p, []),
@@ -127,6 +130,25 @@ def preset_dump(path):
 
 def shader_params(path):
     return _json_call(load_library().rc_shader_params_json, path)
+
+
+PIXFMT = {"rgb24": 0, "bgra": 1, "rgba": 2, "yuyv422": 3}
+
+
+def ingest(src, pixfmt, width, height, n_frames, dst_rgba8, stream=None):
+    """Device-side pixel-format conversion into the chain's RGBA8 frames (FrameProcessor.cpp:43-222)."""
+    rc = load_library().rc_ingest(_ptr(src), PIXFMT[pixfmt], width, height, n_frames, _ptr(dst_rgba8),
+                                  C.c_void_p(stream) if stream else None)
+    if rc != 0:
+        raise RcError("rc_ingest failed (%d)" % rc)
+
+
+def egress_rgb24(src_rgba8, width, height, n_frames, dst_rgb24, flip_y=False, stream=None):
+    """RGBA8 -> RGB24 alpha strip of the readback (FrameCapturePipeline.cpp:1060-1080)."""
+    rc = load_library().rc_egress_rgb24(_ptr(src_rgba8), width, height, n_frames, int(bool(flip_y)), _ptr(dst_rgb24),
+                                        C.c_void_p(stream) if stream else None)
+    if rc != 0:
+        raise RcError("rc_egress_rgb24 failed (%d)" % rc)
 
 
 def selftest_fastmath(device=0):
