@@ -77,6 +77,28 @@ def cpu_baseline(key, w, h, vw, vh, tree, budget_s=15.0):
                       % (n, cores, dt)}
 
 
+def pmc_traffic(kernel_name, frames_per_launch):
+    """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary
+    (profiles/r*_royale_pmc.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, KiB).
+    Correction per /opt/skills/guides/MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the
+    bytes of coalesced streaming reads (re-checked here on the frame-I/O kernels, whose byte counts
+    are known: 4, 8, 12 and 16 B per lane all read exactly 1/2), WRITE_SIZE is exact.  Only valid
+    for the launch shape it was collected at (8 frames per launch); otherwise None."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_royale_pmc.csv")))
+    if not files or abs(frames_per_launch - 8.0) > 1e-6:
+        return None
+    want = "k_" + kernel_name.replace("-", "_")
+    alias = {"k_royale_scanlines_v": "k_royale_scan_v", "k_royale_scanlines_h": "k_royale_scan_h",
+             "k_royale_bloom_horizontal": "k_royale_bloom_h", "k_royale_bloom_vertical": "k_royale_bloom_v"}
+    want = alias.get(want, want)
+    for r in csv.DictReader(open(files[-1])):
+        if r["kernel"] == want and r.get("FETCH_SIZE_avg") and r.get("WRITE_SIZE_avg"):
+            return (2.0 * float(r["FETCH_SIZE_avg"]) + float(r["WRITE_SIZE_avg"])) * 1024.0
+    return None
+
+
 def io_measurements(e, w, h, batch, reps):
     """Side measurements: (1) the ingest / egress kernels alone, algorithmic bytes / event time;
     (2) the whole host-to-host frame path the reference runs per frame (FrameProcessor upload ->
@@ -238,7 +260,8 @@ def main():
                    "algorithmic_bytes_per_frame": chain_bytes,
                    "hbm_roofline_frac_whole_chain": value / world * chain_bytes / (HBM_PEAK_GBS * 1e9)},
         "roofline": {"bound": "hbm", "kernel": infos[dom]["kernel"], "pass": dom, "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic(infos[dom]["kernel"], frames_per_launch),
                      "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
         "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in prof],
