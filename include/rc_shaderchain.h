@@ -145,6 +145,13 @@ void rc_engine_set_allow_missing_sources(rc_engine* e, int allow);
  * resized phosphor mask is rendered. */
 void rc_engine_set_undefined_varying_zero(rc_engine* e, int zero);
 
+/* Frame history (reference ShaderEngine.h:140-143, .cpp:1735-1865): presets whose first pass samples
+ * PrevTexture / Prev<N>Texture keep a ring of at most 7 RGBA8 frames, newest first; such presets
+ * process the frames of a batch one after the other.  rc_engine_history_count returns the ring's
+ * length; rc_engine_read_history copies entry k to host memory (host may be NULL to query the size). */
+int rc_engine_history_count(rc_engine* e);
+int rc_engine_read_history(rc_engine* e, int k, uint32_t* width, uint32_t* height, void* host, size_t bytes);
+
 /* Some passes have a specialised form next to their general one (e.g. xbr-lv3 evaluates its edge
  * rules once per source pixel when the sampling pattern allows it).  Both forms give identical
  * results; 1 forces the general form (diagnostics / tests).  Default 0. */

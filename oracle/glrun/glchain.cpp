@@ -278,8 +278,10 @@ int main(int argc, char** argv) {
   // source texture: FrameProcessor.cpp:172-205 (GL_RGB internal format, RGB24 upload,
   // NEAREST); row 0 of the buffer is t = 0.
   std::string in = read_file(input_path);
-  if (in.size() != (size_t)W * H * 3) {
-    fprintf(stderr, "glchain: input must be %ux%u RGB24\n", W, H);
+  // one RGB24 frame (re-applied every frame) or `frames` frames back to back (a moving source)
+  const bool in_seq = frames > 1 && in.size() == (size_t)W * H * 3 * (size_t)frames;
+  if (!in_seq && in.size() != (size_t)W * H * 3) {
+    fprintf(stderr, "glchain: input must be %ux%u RGB24 (x1 or x frames)\n", W, H);
     return 6;
   }
   GLuint src_tex;
@@ -292,10 +294,21 @@ int main(int argc, char** argv) {
   TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
   TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
 
+  // frame history: ShaderEngine.h:140-143 (ring of at most 7 textures, newest first)
+  std::vector<GLuint> history;
+  std::vector<uint32_t> history_w, history_h;
+  GLuint copy_fbo = 0;
+  const size_t kMaxHistory = 7;
+
   float frame_count = 0.f, time_s = 0.f;
   for (int f = 0; f < frames; ++f) {
     frame_count += 1.0f;  // ShaderEngine.cpp:1688-1689
     time_s += 0.016f;
+    if (in_seq && f > 0) {  // FrameProcessor.cpp:177 glTexSubImage2D of the next captured frame
+      BindTexture(GL_TEXTURE_2D, src_tex);
+      PixelStorei(GL_UNPACK_ALIGNMENT, 1);
+      TexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, W, H, GL_RGB, GL_UNSIGNED_BYTE, in.data() + (size_t)f * W * H * 3);
+    }
     GLuint cur_tex = src_tex;
     uint32_t cw = W, ch = H;
     for (size_t i = 0; i < passes.size(); ++i) {
@@ -440,6 +453,26 @@ int main(int argc, char** argv) {
           break;
         }
       int unit = 1;
+      if (i == 0) {
+        // frame history for the first pass: ShaderEngine.cpp:1095-1159.  A Prev sampler is bound
+        // only when that much history exists; otherwise its uniform keeps its old value.
+        bool needs_history = false;
+        for (int k = 0; k < 7; ++k)
+          if (uloc(pr, k == 0 ? std::string("PrevTexture") : "Prev" + std::to_string(k) + "Texture") >= 0) needs_history = true;
+        for (int k = 0; k < 7; ++k) {
+          std::vector<std::string> names = {k == 0 ? std::string("PrevTexture") : "Prev" + std::to_string(k) + "Texture",
+                                            "PassPrev" + std::to_string(k) + "Texture"};
+          for (auto& nm : names)
+            if ((l = uloc(pr, nm)) >= 0) {
+              if (needs_history && (size_t)k < history.size() && history[k] != 0) {
+                ActiveTexture(GL_TEXTURE0 + unit);
+                BindTexture(GL_TEXTURE_2D, history[k]);
+                Uniform1i(l, unit++);
+              }
+              break;
+            }
+        }
+      }
       if (i > 0) {
         // previous passes: ShaderEngine.cpp:1163-1228
         for (size_t pp = 0; pp < i; ++pp) {
@@ -509,6 +542,60 @@ int main(int argc, char** argv) {
     }
     BindFramebuffer(GL_FRAMEBUFFER, 0);
     Disable(GL_FRAMEBUFFER_SRGB);
+    BindTexture(GL_TEXTURE_2D, 0);  // unit 0 is the active one after the last draw (cpp:1703-1704)
+    UseProgram(0);
+    // history push: the final output is re-drawn through pass 0's program, with pass 0's uniforms
+    // as they stand, into a history texture: ShaderEngine.cpp:1735-1865
+    if (cur_tex != 0 && cw > 0 && ch > 0) {
+      GLuint ht = 0;
+      if (history.size() < kMaxHistory) {
+        GenTextures(1, &ht);
+        BindTexture(GL_TEXTURE_2D, ht);
+        TexImage2D(GL_TEXTURE_2D, 0, GL_RGBA, cw, ch, 0, GL_RGBA, GL_UNSIGNED_BYTE, nullptr);
+        TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_LINEAR);
+        TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_LINEAR);
+        TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
+        TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
+        BindTexture(GL_TEXTURE_2D, 0);
+      } else {
+        ht = history.back();
+        history.pop_back();
+        history_w.pop_back();
+        history_h.pop_back();
+        if (history_w.empty() || history_w.back() != cw || history_h.back() != ch) {
+          BindTexture(GL_TEXTURE_2D, ht);
+          TexImage2D(GL_TEXTURE_2D, 0, GL_RGBA, cw, ch, 0, GL_RGBA, GL_UNSIGNED_BYTE, nullptr);
+          BindTexture(GL_TEXTURE_2D, 0);
+        }
+      }
+      if (!copy_fbo) GenFramebuffers(1, &copy_fbo);
+      BindFramebuffer(GL_FRAMEBUFFER, copy_fbo);
+      FramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, ht, 0);
+      if (CheckFramebufferStatus(GL_FRAMEBUFFER) == GL_FRAMEBUFFER_COMPLETE) {
+        Viewport(0, 0, cw, ch);
+        ClearColor(0.f, 0.f, 0.f, 1.f);
+        Clear(GL_COLOR_BUFFER_BIT);
+        if (passes[0].program) {
+          UseProgram(passes[0].program);
+          BindVertexArray(vao);
+          ActiveTexture(GL_TEXTURE0);
+          BindTexture(GL_TEXTURE_2D, cur_tex);
+          GLint tl = uloc(passes[0].program, "Texture");
+          if (tl < 0) tl = uloc(passes[0].program, "Source");
+          if (tl >= 0) Uniform1i(tl, 0);
+          EnableVertexAttribArray(0);
+          EnableVertexAttribArray(1);
+          DrawElements(GL_TRIANGLES, 6, GL_UNSIGNED_INT, nullptr);
+          BindVertexArray(0);
+          BindTexture(GL_TEXTURE_2D, 0);
+          UseProgram(0);
+        }
+      }
+      BindFramebuffer(GL_FRAMEBUFFER, 0);
+      history.insert(history.begin(), ht);
+      history_w.insert(history_w.begin(), cw);
+      history_h.insert(history_h.begin(), ch);
+    }
     Finish();
   }
 
@@ -536,6 +623,15 @@ int main(int argc, char** argv) {
          << p.info.filterLinear << " wrap=" << p.info.wrapMode << " alias=" << p.info.alias
          << " shader=" << p.info.shaderPath << "\n";
     for (auto& kv : p.params) meta << "  param " << kv.first << " " << kv.second << "\n";
+  }
+  for (size_t k = 0; k < history.size(); ++k) {
+    BindTexture(GL_TEXTURE_2D, history[k]);
+    std::vector<unsigned char> d((size_t)history_w[k] * history_h[k] * 4);
+    GetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, GL_UNSIGNED_BYTE, d.data());
+    FILE* fo = fopen((out_dir + "/history" + std::to_string(k) + ".bin").c_str(), "wb");
+    fwrite(d.data(), 1, d.size(), fo);
+    fclose(fo);
+    meta << "history " << k << " " << history_w[k] << " " << history_h[k] << "\n";
   }
   GLenum e = GetError();
   if (e) fprintf(stderr, "glchain: GL error 0x%x\n", e);

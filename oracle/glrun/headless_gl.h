@@ -65,7 +65,8 @@ GLRUN_FUNCS(X)
   X(void, DrawElements, (GLenum m, GLsizei c, GLenum t, const void* i), (m, c, t, i)) \
   X(void, ReadPixels, (GLint x, GLint y, GLsizei w, GLsizei h, GLenum f, GLenum t, void* d), (x, y, w, h, f, t, d)) \
   X(void, GetTexImage, (GLenum a, GLint l, GLenum f, GLenum t, void* d), (a, l, f, t, d)) \
-  X(void, TexImage2D, (GLenum a, GLint l, GLint i, GLsizei w, GLsizei h, GLint b, GLenum f, GLenum t, const void* d), (a, l, i, w, h, b, f, t, d))
+  X(void, TexImage2D, (GLenum a, GLint l, GLint i, GLsizei w, GLsizei h, GLint b, GLenum f, GLenum t, const void* d), (a, l, i, w, h, b, f, t, d)) \
+  X(void, TexSubImage2D, (GLenum a, GLint l, GLint x, GLint y, GLsizei w, GLsizei h, GLenum f, GLenum t, const void* d), (a, l, x, y, w, h, f, t, d))
 
 #define X(R, N, A, C) R N A;
 GLRUN_FUNCS1(X)

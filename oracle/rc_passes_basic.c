@@ -129,3 +129,26 @@ static void o_pass_crt_pi_body(const o_pass_args* a) {
       store_px(a, x, y, o);
     }
 }
+
+/* mix_frames  shaders/shaders_glsl/motionblur/shaders/mix_frames.glsl (VS :51-55, FS :94-107):
+ * 50:50 blend of the input with PrevTexture (extra[0]).  mix with the constant weight 0.5 is
+ * a*(1-0.5) + b*0.5.  TEX0 = TexCoord * 1.0001. */
+static void o_pass_mix_frames_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float k1 = 1.0001f;
+  o_varying tu = o_varying_setup(0.f * k1, 1.f * k1, 1.f * k1, 0.f * k1, W, H, a->out_fmt);
+  o_varying tv = o_varying_setup(0.f * k1, 0.f * k1, 1.f * k1, 1.f * k1, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      o_vec4 c = o_sample(a->in, u, v), p = o_sample(a->extra[0], u, v);
+      o_vec4 o = {c.x * 0.5f + p.x * 0.5f, c.y * 0.5f + p.y * 0.5f, c.z * 0.5f + p.z * 0.5f, 1.0f};
+      store_px(a, x, y, o);
+    }
+}
+void o_pass_mix_frames(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  o_pass_mix_frames_body(a);
+  o_fp_leave(csr);
+}

@@ -132,6 +132,8 @@ std::vector<KernelEntry> build() {
                 {"INPUT_GAMMA", 2.4f, 0.0f, 5.0f, 0.01f, "Input gamma"},
                 {"OUTPUT_GAMMA", 2.2f, 0.0f, 5.0f, 0.01f, "Output gamma"}},
                {}, rck::launch_crt_pi, setupCrtPi, false});
+  r.push_back({"motionblur/shaders/mix_frames.glsl", "mix-frames", {}, {"PrevTexture"}, rck::launch_mix_frames, setupCrtPi,
+               false, true, nullptr, nullptr, true});  // VS: TEX0 = TexCoord * 1.0001 (mix_frames.glsl:53)
   r.push_back({"ntsc/shaders/ntsc-pass1-svideo-3phase.glsl", "ntsc-pass1-svideo-3phase", {}, {},
                rck::launch_ntsc_pass1, setupNtscPass1, false});
   r.push_back({"ntsc/shaders/ntsc-pass2-3phase-gamma.glsl", "ntsc-pass2-3phase-gamma", {}, {},

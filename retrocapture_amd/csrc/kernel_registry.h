@@ -45,6 +45,10 @@ struct KernelEntry {
   const char* (*validate)(const float* params) = nullptr;
   // Optional: bytes of device scratch the pass needs per frame (handed over in PassLaunch::scratch)
   uint64_t (*scratch_bytes)(const PassGeometry& g) = nullptr;
+  // The shader reads no size uniform (TextureSize / InputSize / OutputSize / ...): its result depends
+  // only on the textures bound and the target size.  Needed for the frame-history re-draw, which runs
+  // pass 0's program with stale size uniforms (shader_engine.cpp pushHistory).
+  bool size_independent = false;
 };
 
 const KernelEntry* findKernel(const std::string& shaderPath);

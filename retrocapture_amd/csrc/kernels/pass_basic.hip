@@ -1,6 +1,7 @@
 // Pass kernels for three reference shader assets (arithmetic spec = the GLSL text):
 //   stock.glsl                         shaders/shaders_glsl/stock.glsl
 //   scanlines/shaders/scanline.glsl    VS line 50, FS lines 107-113
+//   motionblur/shaders/mix_frames.glsl VS lines 51-55, FS lines 94-107 (samples PrevTexture)
 //   crt/shaders/crt-pi.glsl            VS lines 96-103, FS lines 131-232
 //     (compile-time switches as shipped: SCANLINES, MULTISAMPLE, GAMMA, MASK_TYPE 1)
 // One thread per target pixel; blockIdx.z = frame of the batch.
@@ -33,6 +34,19 @@ __global__ void __launch_bounds__(256) k_scanline(const PassLaunch L) {
   const float d = comp_a * sin_(u * omega_x) + comp_b * sin_(v * omega_y);
   const float k = base + d;
   store_rt(L, z, x, y, make_float4(res.x * k, res.y * k, res.z * k, 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
+// extra[0] = PrevTexture; mix(colour, colourPrev, 0.5) with a constant weight = a*(1-0.5) + b*0.5
+// plane[0], plane[1]: TEX0 = TexCoord * 1.0001
+__global__ void __launch_bounds__(256) k_mix_frames(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+  const float4 p = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), u, v, &lds);
+  store_rt(L, z, x, y, make_float4(c.x * 0.5f + p.x * 0.5f, c.y * 0.5f + p.y * 0.5f, c.z * 0.5f + p.z * 0.5f, 1.0f), &lds);
   RC_TILE_LOOP_END
 }
 
@@ -99,6 +113,10 @@ namespace rck {
 
 hipError_t launch_stock(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_stock, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_mix_frames(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_mix_frames, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }
 hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {

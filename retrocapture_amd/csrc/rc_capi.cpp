@@ -282,6 +282,11 @@ int rc_selftest_fastmath(int device, uint64_t mismatches[3]) {
   for (int i = 0; i < 3; ++i) mismatches[i] = h[i];
   return rc;
 }
+int rc_engine_history_count(rc_engine* e) { return e ? (int)e->impl.historyCount() : 0; }
+int rc_engine_read_history(rc_engine* e, int k, uint32_t* width, uint32_t* height, void* host, size_t bytes) {
+  if (!e || k < 0) return RC_ERR_INVALID;
+  return e->impl.readHistory((size_t)k, width, height, host, bytes) ? RC_OK : RC_ERR_INVALID;
+}
 void rc_engine_set_general_kernels_only(rc_engine* e, int general_only) {
   if (e) e->impl.setGeneralKernelsOnly(general_only != 0);
 }

@@ -91,6 +91,11 @@ void ShaderEngine::cleanupPresetPasses() {
     if (p.scratch.ptr) (void)hipFree(p.scratch.ptr);
   }
   m_passes.clear();
+  for (auto& h : m_frameHistory)
+    if (h.buf.ptr) (void)hipFree(h.buf.ptr);
+  m_frameHistory.clear();
+  m_units.clear();
+  m_pass0Units.clear();
 }
 
 void ShaderEngine::cleanupTextureReferences() {
@@ -447,39 +452,107 @@ rcd::Tex ShaderEngine::passTexture(size_t p) const {
   return t;
 }
 
-// Which texture a sampler uniform of pass i is bound to (:1091-1415).
-rcd::Tex ShaderEngine::samplerFor(const std::string& name, size_t i, const rcd::Tex& inputTex,
-                                  const rcd::Tex& sourceTex) const {
-  // PassPrev<N>Texture / Prev[N]Texture -> output of pass i-N (:1163-1189); N > i -> the
-  // original input (:1234-1245)
-  if (name.rfind("PassPrev", 0) == 0 && name.size() > 15 && name.compare(name.size() - 7, 7, "Texture") == 0) {
-    const int n = std::atoi(name.substr(8, name.size() - 15).c_str());
-    if (n >= 1 && (size_t)n <= i) return passTexture(i - (size_t)n);
-    if (n > (int)i) return sourceTex;
+rcd::Tex ShaderEngine::lutTexture(const std::string& name) const {  // :1361-1415
+  rcd::Tex t;
+  std::memset(&t, 0, sizeof(t));
+  auto lut = m_textureReferences.find(name);
+  if (lut == m_textureReferences.end()) return t;
+  t.base = lut->second.data.ptr;
+  t.frame_stride = 0;
+  t.w = lut->second.width;
+  t.h = lut->second.height;
+  t.fmt = rcd::FMT_RGBA8;
+  t.linear = 1;
+  t.wrap = rcd::WRAP_EDGE;
+  auto st = m_preset.getTextures().find(name);
+  if (st != m_preset.getTextures().end()) {
+    t.linear = st->second.linear ? 1 : 0;
+    t.wrap = wrapFromString(st->second.wrapMode);
   }
-  if (name == "OrigTexture") return sourceTex;  // :1351-1358
-  for (size_t p = 0; p < i; ++p)                // aliases (:1251-1266)
-    if (!m_passes[p].passInfo.alias.empty() && m_passes[p].passInfo.alias == name) return passTexture(p);
-  auto lut = m_textureReferences.find(name);    // LUTs (:1361-1415)
-  if (lut != m_textureReferences.end()) {
-    rcd::Tex t;
-    t.base = lut->second.data.ptr;
-    t.frame_stride = 0;
-    t.w = lut->second.width;
-    t.h = lut->second.height;
-    t.fmt = rcd::FMT_RGBA8;
-    t.linear = 1;
-    t.wrap = rcd::WRAP_EDGE;
-    auto st = m_preset.getTextures().find(name);
-    if (st != m_preset.getTextures().end()) {
-      t.linear = st->second.linear ? 1 : 0;
-      t.wrap = wrapFromString(st->second.wrapMode);
+  return t;
+}
+
+namespace {
+std::string prevName(int k) { return k == 0 ? std::string("PrevTexture") : "Prev" + std::to_string(k) + "Texture"; }
+bool declares(const KernelEntry& k, const std::string& name) {
+  for (const char* s : k.samplers)
+    if (name == s) return true;
+  return false;
+}
+}  // namespace
+
+bool ShaderEngine::presetSamplesHistory() const {
+  if (m_passes.empty() || !m_passes[0].kernel) return false;
+  for (int k = 0; k < 7; ++k)
+    if (declares(*m_passes[0].kernel, prevName(k)) || declares(*m_passes[0].kernel, "PassPrev" + std::to_string(k) + "Texture"))
+      return true;
+  return false;
+}
+
+// The reference binds, in this order and on consecutive texture units starting at 1: frame history
+// (pass 0 only, and only as far as history exists, :1095-1159) or the outputs of earlier passes under
+// their PassPrev / Prev names (:1163-1228), the original input for PassPrev<N> with N beyond pass 0
+// (:1234-1245), earlier passes by alias (:1251-1277), OrigTexture (:1351-1358) and every preset LUT
+// (:1361-1415; a LUT takes a unit whether or not the program declares it).  A sampler uniform that
+// is not set keeps its value: 0 (= the pass input on unit 0) on a fresh program.
+void ShaderEngine::bindSamplers(size_t i, const KernelEntry& k, const rcd::Tex& inputTex, const rcd::Tex& sourceTex,
+                                rcd::PassLaunch* L) {
+  if (m_units.size() < 64) m_units.resize(64);
+  std::map<std::string, int> bound;
+  int unit = 1;
+  auto bind = [&](const std::string& name, const rcd::Tex& t) {
+    if (unit < (int)m_units.size()) m_units[(size_t)unit] = t;
+    bound[name] = unit++;
+  };
+  if (i == 0) {
+    for (int h = 0; h < 7; ++h) {
+      const std::string names[2] = {prevName(h), "PassPrev" + std::to_string(h) + "Texture"};
+      for (const std::string& n : names)
+        if (declares(k, n)) {
+          if ((size_t)h < m_frameHistory.size() && m_frameHistory[(size_t)h].buf.ptr) {
+            rcd::Tex t;
+            std::memset(&t, 0, sizeof(t));
+            t.base = m_frameHistory[(size_t)h].buf.ptr;
+            t.frame_stride = 0;
+            t.w = (int)m_frameHistory[(size_t)h].width;
+            t.h = (int)m_frameHistory[(size_t)h].height;
+            t.fmt = rcd::FMT_RGBA8;
+            t.linear = 1;  // creation state of a history texture, never changed (:1757-1761)
+            t.wrap = rcd::WRAP_EDGE;
+            bind(n, t);
+          }
+          break;
+        }
     }
-    return t;
+  } else {
+    for (size_t pp = 0; pp < i; ++pp) {
+      const std::string names[2] = {"PassPrev" + std::to_string(i - pp) + "Texture", prevName((int)pp)};
+      for (const std::string& n : names)
+        if (declares(k, n)) {
+          bind(n, passTexture(pp));
+          break;
+        }
+    }
+    for (size_t n = i + 1; n <= i + 12; ++n) {
+      const std::string name = "PassPrev" + std::to_string(n) + "Texture";
+      if (declares(k, name)) bind(name, sourceTex);
+    }
+    for (size_t pp = 0; pp < i; ++pp) {
+      const std::string& al = m_passes[pp].passInfo.alias;
+      if (!al.empty() && declares(k, al)) bind(al, passTexture(pp));
+    }
   }
-  // A sampler uniform that nothing binds keeps its default value 0 = the unit holding the
-  // pass input.
-  return inputTex;
+  if (declares(k, "OrigTexture")) bind("OrigTexture", sourceTex);
+  for (const auto& lt : m_preset.getTextures())  // std::map: by name
+    if (m_textureReferences.count(lt.first)) bind(lt.first, lutTexture(lt.first));
+  if (i == 0)
+    for (const auto& b : bound) m_pass0Units[b.first] = b.second;
+  const std::map<std::string, int>& units = (i == 0) ? m_pass0Units : bound;
+  for (size_t s = 0; s < k.samplers.size() && s < (size_t)rcd::kMaxExtra; ++s) {
+    auto it = units.find(k.samplers[s]);
+    const int u = it == units.end() ? 0 : it->second;
+    L->extra[s] = (u > 0 && u < (int)m_units.size()) ? m_units[(size_t)u] : inputTex;
+  }
 }
 
 const void* ShaderEngine::applyShader(const void* input, uint32_t width, uint32_t height) {
@@ -530,7 +603,10 @@ const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames,
   resolvePassSizes(pw, ph);
 
   // buffers: every pass holds `chunk` frames, except the last which holds the whole batch
-  const uint32_t chunk = std::min(m_chunk, nFrames);
+  // a preset whose first pass samples frame history is sequential: one frame per chunk, history
+  // pushed after each (frames of a batch are successive frames)
+  const bool history = presetSamplesHistory();
+  const uint32_t chunk = history ? 1u : std::min(m_chunk, nFrames);
   for (size_t i = 0; i + 1 < m_passes.size(); ++i)
     if (!ensureBuffer(m_passes[i].target, m_passes[i].frameBytes * chunk)) return inputs;
   ShaderPassData& lastPass = m_passes.back();
@@ -544,6 +620,16 @@ const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames,
     const uint8_t* in = static_cast<const uint8_t*>(inputs) + frameStride * f0;
     uint8_t* out = static_cast<uint8_t*>(lastPass.target.ptr) + lastPass.frameBytes * f0;
     if (!runChunk(in, frameStride, width, height, n, firstCount, out)) return inputs;
+    if (history) {
+      std::map<std::string, float> custom;
+      {
+        std::lock_guard<std::mutex> lock(m_paramMutex);
+        custom = m_customParameters;
+      }
+      rcd::Tex none;
+      std::memset(&none, 0, sizeof(none));
+      if (!pushHistory(out, firstCount, none, custom)) return inputs;
+    }
     for (uint32_t k = 0; k < n; ++k) {
       m_frameCount += 1.0f;
       m_time += 0.016f;
@@ -554,6 +640,90 @@ const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames,
   m_outputWidth = lastPass.width;
   m_outputHeight = lastPass.height;
   return lastPass.target.ptr;
+}
+
+void ShaderEngine::fillGeometry(size_t i, const rcd::Tex& inputTex, const rcd::PassLaunch& L, PassGeometry* geo) const {
+  geo->pass_index = (int)i;
+  geo->in_w = inputTex.w;
+  geo->in_h = inputTex.h;
+  geo->out_w = L.out_w;
+  geo->out_h = L.out_h;
+  geo->out_fmt = L.out_fmt;
+  geo->src_w = L.src_w;
+  geo->src_h = L.src_h;
+  geo->vp_w = L.vp_w;
+  geo->vp_h = L.vp_h;
+  geo->n_passes = (int)std::min<size_t>(m_passes.size(), 32);
+  for (int q = 0; q < geo->n_passes; ++q) {
+    geo->chain_w[q] = (int)m_passes[(size_t)q].width;
+    geo->chain_h[q] = (int)m_passes[(size_t)q].height;
+  }
+}
+
+// History push (:1735-1865).  The reference re-draws the final output through pass 0's PROGRAM -
+// sampler uniforms as pass 0's last draw left them, unit 0 = the final output (LINEAR, clamp to
+// edge: its creation state), every other unit as the frame's last draws left it - into an RGBA8
+// texture of the output size, and puts that at the front of the ring.  What Prev<N>Texture later
+// samples is therefore not the plain previous output but pass 0 applied to it again.  The size
+// uniforms of that draw are pass 0's stale ones, so only kernels that read none are accepted unless
+// all sizes coincide.
+bool ShaderEngine::pushHistory(const void* finalFrame, int frameCount, const rcd::Tex& sourceTex,
+                               const std::map<std::string, float>& custom) {
+  ShaderPassData& p0 = m_passes[0];
+  const ShaderPassData& lastPass = m_passes.back();
+  if (!p0.kernel) return true;
+  const KernelEntry& k = *p0.kernel;
+  const bool sameSizes = m_passes.size() == 1 && lastPass.width == m_sourceWidth && lastPass.height == m_sourceHeight;
+  if (!k.size_independent && !sameSizes) {
+    RC_LOG_ERROR(std::string("frame history: pass 0 kernel '") + k.name +
+                 "' reads size uniforms; its history re-draw is only supported at 1:1 single-pass geometry");
+    return false;
+  }
+  HistoryFrame hf;
+  if (m_frameHistory.size() >= kMaxFrameHistory) {  // reuse the oldest (:1764-1778)
+    hf = m_frameHistory.back();
+    m_frameHistory.pop_back();
+  }
+  const size_t bytes = (size_t)lastPass.width * lastPass.height * 4;
+  if (!ensureBuffer(hf.buf, bytes)) return false;
+  hf.width = lastPass.width;
+  hf.height = lastPass.height;
+
+  rcd::PassLaunch L;
+  std::memset(&L, 0, sizeof(L));
+  L.in = passTexture(m_passes.size() - 1);
+  L.in.base = finalFrame;
+  L.in.frame_stride = 0;
+  L.out = hf.buf.ptr;
+  L.out_frame_stride = bytes;
+  L.out_w = (int)lastPass.width;
+  L.out_h = (int)lastPass.height;
+  L.out_fmt = rcd::FMT_RGBA8;
+  L.src_w = (int)m_sourceWidth;
+  L.src_h = (int)m_sourceHeight;
+  L.vp_w = (int)m_viewportWidth;
+  L.vp_h = (int)m_viewportHeight;
+  L.frame_count0 = frameCount;
+  L.n_frames = 1;
+  L.flags = (m_undefVaryingZero ? 1 : 0) | (m_generalOnly ? rcd::RC_FLAG_GENERAL_ONLY : 0);
+  for (size_t s = 0; s < k.samplers.size() && s < (size_t)rcd::kMaxExtra; ++s) {
+    auto it = m_pass0Units.find(k.samplers[s]);
+    const int u = it == m_pass0Units.end() ? 0 : it->second;
+    L.extra[s] = (u > 0 && u < (int)m_units.size()) ? m_units[(size_t)u] : L.in;
+  }
+  for (size_t q = 0; q < k.params.size() && q < (size_t)rcd::kMaxParams; ++q) L.params[q] = effectiveParameter(p0, k.params[q], custom);
+  PassGeometry geo;
+  fillGeometry(0, L.in, L, &geo);
+  if (k.scratch_bytes) {
+    if (!ensureBuffer(p0.scratch, k.scratch_bytes(geo))) return false;
+    L.scratch = p0.scratch.ptr;
+    L.scratch_frame_stride = 0;
+  }
+  if (k.setup) k.setup(geo, L);
+  (void)sourceTex;
+  if (!hipOk(k.launch(L, m_stream), "history re-draw")) return false;
+  m_frameHistory.insert(m_frameHistory.begin(), hf);
+  return true;
 }
 
 bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t width, uint32_t height,
@@ -598,27 +768,12 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
       L.frame_count0 = firstFrameCount;
       L.n_frames = (int)nFrames;
       const KernelEntry& k = *pd.kernel;
-      for (size_t s = 0; s < k.samplers.size() && s < (size_t)rcd::kMaxExtra; ++s)
-        L.extra[s] = samplerFor(k.samplers[s], i, current, sourceTex);
+      bindSamplers(i, k, current, sourceTex, &L);
       for (size_t q = 0; q < k.params.size() && q < (size_t)rcd::kMaxParams; ++q) {
         L.params[q] = effectiveParameter(pd, k.params[q], custom);
       }
       PassGeometry geo;
-      geo.pass_index = (int)i;
-      geo.in_w = current.w;
-      geo.in_h = current.h;
-      geo.out_w = L.out_w;
-      geo.out_h = L.out_h;
-      geo.out_fmt = L.out_fmt;
-      geo.src_w = L.src_w;
-      geo.src_h = L.src_h;
-      geo.vp_w = L.vp_w;
-      geo.vp_h = L.vp_h;
-      geo.n_passes = (int)std::min<size_t>(m_passes.size(), 32);
-      for (int q = 0; q < geo.n_passes; ++q) {
-        geo.chain_w[q] = (int)m_passes[(size_t)q].width;
-        geo.chain_h[q] = (int)m_passes[(size_t)q].height;
-      }
+      fillGeometry(i, current, L, &geo);
       L.flags = (m_undefVaryingZero ? 1 : 0) | (m_generalOnly ? rcd::RC_FLAG_GENERAL_ONLY : 0);
       if (k.scratch_bytes) {
         const uint64_t per_frame = k.scratch_bytes(geo);
@@ -666,6 +821,18 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
     current = next;
   }
   return true;
+}
+
+bool ShaderEngine::readHistory(size_t k, uint32_t* width, uint32_t* height, void* host, size_t bytes) {
+  if (k >= m_frameHistory.size()) return false;
+  const HistoryFrame& h = m_frameHistory[k];
+  if (width) *width = h.width;
+  if (height) *height = h.height;
+  if (!host) return true;
+  const size_t need = (size_t)h.width * h.height * 4;
+  if (bytes < need) return false;
+  if (!hipOk(hipStreamSynchronize(m_stream), "sync")) return false;
+  return hipOk(hipMemcpy(host, h.buf.ptr, need, hipMemcpyDeviceToHost), "history readback");
 }
 
 void ShaderEngine::setProfiling(bool on) {

@@ -124,6 +124,9 @@ class ShaderEngine {
   // Algorithmic bytes one frame of pass i moves: each distinct texture it samples once at its
   // stored size, plus its target once (SURVEY.md section 8d convention).
   void passBytes(size_t i, uint64_t* readBytes, uint64_t* writeBytes) const;
+  // Frame-history ring (newest first); entries are RGBA8 at the output size they were pushed with.
+  size_t historyCount() const { return m_frameHistory.size(); }
+  bool readHistory(size_t k, uint32_t* width, uint32_t* height, void* host, size_t bytes);
 
  private:
   bool m_initialized = false;
@@ -171,8 +174,23 @@ class ShaderEngine {
   bool ensureBuffer(DeviceBuffer& b, size_t bytes);
   float effectiveParameter(const ShaderPassData& pass, const KernelParam& kp,
                            const std::map<std::string, float>& custom) const;
-  rcd::Tex samplerFor(const std::string& uniformName, size_t passIndex, const rcd::Tex& inputTex,
-                      const rcd::Tex& sourceTex) const;
+  // frame history (reference ShaderEngine.h:140-143: at most 7 textures of the processed output,
+  // newest first), the texture bound to every texture unit as the last draw left it, and the
+  // sampler uniforms of pass 0's program (a uniform keeps its value until it is set again)
+  struct HistoryFrame { DeviceBuffer buf; uint32_t width = 0, height = 0; };
+  std::vector<HistoryFrame> m_frameHistory;
+  std::vector<rcd::Tex> m_units;
+  std::map<std::string, int> m_pass0Units;
+  static constexpr size_t kMaxFrameHistory = 7;
+  bool presetSamplesHistory() const;
+  bool pushHistory(const void* finalFrame, int frameCount, const rcd::Tex& sourceTex,
+                   const std::map<std::string, float>& custom);
+  void fillGeometry(size_t passIndex, const rcd::Tex& inputTex, const rcd::PassLaunch& L, PassGeometry* geo) const;
+  rcd::Tex lutTexture(const std::string& name) const;
+  // Emulates the reference's sampler binding of pass i (:1095-1415): same order, same texture-unit
+  // numbering; fills L.extra for the kernel's declared samplers.
+  void bindSamplers(size_t passIndex, const KernelEntry& k, const rcd::Tex& inputTex, const rcd::Tex& sourceTex,
+                    rcd::PassLaunch* L);
   rcd::Tex passTexture(size_t passIndex) const;
   bool runChunk(const void* inputs, uint64_t inStride, uint32_t width, uint32_t height, uint32_t nFrames,
                 int firstFrameCount, void* finalOut);

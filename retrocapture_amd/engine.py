@@ -67,6 +67,9 @@ SYMBOLS = [
     ("rc_engine_set_allow_missing_sources", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_undefined_varying_zero", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_general_kernels_only", None, [C.c_void_p, C.c_int]),
+    ("rc_engine_history_count", C.c_int, [C.c_void_p]),
+    ("rc_engine_read_history", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p,
+                                         C.c_size_t]),
     ("rc_ingest", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("rc_egress_rgb24", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     ("rc_pixfmt_frame_bytes", C.c_size_t, [C.c_int, C.c_uint32, C.c_uint32]),
@@ -309,6 +312,20 @@ class ShaderEngine:
 
     def setUndefinedVaryingZero(self, zero):
         self._lib.rc_engine_set_undefined_varying_zero(self._need(), int(bool(zero)))
+
+    def historyCount(self):
+        return self._lib.rc_engine_history_count(self._need())
+
+    def readHistory(self, k):
+        """Host copy of entry k of the frame-history ring (0 = newest), (h, w, 4) uint8."""
+        import numpy as np
+        w, h = C.c_uint32(), C.c_uint32()
+        if self._lib.rc_engine_read_history(self._need(), int(k), C.byref(w), C.byref(h), None, 0) != 0:
+            raise RcError("readHistory(%d): no such entry" % k)
+        arr = np.empty((h.value, w.value, 4), np.uint8)
+        if self._lib.rc_engine_read_history(self._need(), int(k), C.byref(w), C.byref(h), arr.ctypes.data, arr.nbytes) != 0:
+            raise RcError("readHistory(%d) failed" % k)
+        return arr
 
     def setGeneralKernelsOnly(self, on):
         self._lib.rc_engine_set_general_kernels_only(self._need(), int(bool(on)))

@@ -28,6 +28,8 @@ scale_x1 = 0.5
 scale_y1 = 1.0
 """),
     "xbr-lv3": ("xbr/xbr-lv3.glslp", 'shaders = 1\n\nshader0 = shaders/xbr-lv3.glsl\nfilter_linear0 = false\n'),
+    # same keys / values as the reference's motionblur/mix_frames.glslp
+    "mix-frames": ("motionblur/mix_frames.glslp", 'shaders = "1"\n\nshader0 = "shaders/mix_frames.glsl"\nfilter_linear0 = "false"\n'),
     "stock": ("stock.glslp", 'shaders = "1"\nshader0 = "stock.glsl"\nfilter_linear0 = "false"\n'),
     # Same keys / values as the reference's crt/crt-royale.glslp for the 12 passes, including the
     # three `"true" # comment` booleans that its parser reads as false; only the LUT that the
@@ -145,6 +147,10 @@ SHADERS = {
         "params": [("CURVATURE_X", 0.10), ("CURVATURE_Y", 0.15), ("MASK_BRIGHTNESS", 0.70), ("SCANLINE_WEIGHT", 6.0),
                    ("SCANLINE_GAP_BRIGHTNESS", 0.12), ("BLOOM_FACTOR", 1.5), ("INPUT_GAMMA", 2.4), ("OUTPUT_GAMMA", 2.2)],
         "samplers": []},
+    # size_independent: reads no size uniform, so the history re-draw (which keeps pass 0's stale size
+    # uniforms, reference ShaderEngine.cpp:1805-1834) is well defined for any geometry
+    "motionblur/shaders/mix_frames.glsl": {"oracle": "mix_frames", "params": [], "samplers": ["PrevTexture"],
+                                           "size_independent": True},
     "ntsc/shaders/ntsc-pass1-svideo-3phase.glsl": {"oracle": "ntsc_pass1_svideo_3phase", "params": [], "samplers": []},
     "ntsc/shaders/ntsc-pass2-3phase-gamma.glsl": {"oracle": "ntsc_pass2_3phase_gamma", "params": [], "samplers": []},
     "xbr/shaders/xbr-lv3.glsl": {

@@ -58,7 +58,10 @@ def write_preset(d, text):
 
 
 def run_case(name, preset, rgb, vw, vh, frames=1, luts=(), params=()):
-    h, w, _ = rgb.shape
+    """rgb: (h, w, 3) applied `frames` times, or (frames, h, w, 3): a different source every frame."""
+    if rgb.ndim == 4:
+        frames = rgb.shape[0]
+    h, w, _ = rgb.shape[-3:]
     with tempfile.TemporaryDirectory() as d:
         rgb.tofile(os.path.join(d, "in.rgb"))
         cmd = [GLCHAIN, "--preset", preset, "--input", os.path.join(d, "in.rgb"), "--w", str(w), "--h", str(h),
@@ -86,6 +89,13 @@ def run_case(name, preset, rgb, vw, vh, frames=1, luts=(), params=()):
             out["pass%d" % k] = np.fromfile(os.path.join(d, "pass%s.bin" % i), dtype=dt).reshape(ph, pw, 4)
             out["pass%d_fmt" % k] = np.array(fmt)
             k += 1
+        nh = 0
+        for line in meta:
+            if line.startswith("history "):
+                _, i, pw, ph = line.split()[:4]
+                out["history%d" % nh] = np.fromfile(os.path.join(d, "history%s.bin" % i), dtype=np.uint8).reshape(int(ph), int(pw), 4)
+                nh += 1
+        out["n_history"] = np.array(nh)
         out["n_passes"] = np.array(k)
         out["sha256_last"] = np.array(hashlib.sha256(out["pass%d" % (k - 1)].tobytes()).hexdigest())
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
@@ -203,7 +213,26 @@ def case_xbr():
                      ("XBR_LV2_COEFFICIENT", 3.0), ("XBR_Y_WEIGHT", 30.0)])
 
 
-CASES = {"ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+def moving(w, h, n, seed):
+    """n frames: a noise background with a bright bar that moves 3 px per frame."""
+    base = noise(w, h, seed)
+    out = np.stack([base] * n)
+    for f in range(n):
+        x0 = (5 + 3 * f) % max(1, w - 6)
+        out[f, h // 4: h // 2, x0:x0 + 6] = (250, 240, 10)
+        out[f, :, :, 2] = np.roll(out[f, :, :, 2], f, axis=0)   # the whole blue plane scrolls
+    return out
+
+
+def case_mix_frames():
+    # frame history (reference ShaderEngine.cpp:1095-1159 binds it, :1735-1865 pushes it): one pass that
+    # samples PrevTexture.  3 frames exercise the first-frame rule and the recursion of the ring's
+    # content; 9 frames wrap the 7-deep ring.
+    run_case("mix_frames_72x40_to_72x40_f3", GLSL + "/motionblur/mix_frames.glslp", moving(72, 40, 3, 20), 72, 40)
+    run_case("mix_frames_48x36_to_120x90_f9", GLSL + "/motionblur/mix_frames.glslp", moving(48, 36, 9, 21), 120, 90)
+
+
+CASES = {"mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -46,18 +46,36 @@ def pass_sizes(passes, w, h, vw, vh):
     return out
 
 
+class ChainState:
+    """What the reference keeps between frames (ShaderEngine.h:140-143 and the GL objects' own state):
+    the frame-history ring (newest first, at most 7), the texture bound to every texture unit, and
+    the sampler uniforms of pass 0's program (a uniform keeps its value until set again)."""
+
+    def __init__(self):
+        self.history = []          # list of (h, w, 4) uint8 arrays
+        self.units = {}            # unit -> Tex
+        self.pass0_units = {}      # sampler name -> unit, as last set on pass 0's program
+        self.frame_count = 0
+
+
+def _history_tex(arr):
+    return Tex(arr, "rgba8", True, "clamp_to_edge")   # creation state, never changed (cpp:1757-1761)
+
+
 def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global_params=None, flags=0,
-              given=None):
+              given=None, state=None):
     """passes: list of dicts as produced by the preset dump (shader, filter_linear, wrap,
     alias, float_fb, srgb_fb, stx, sx, sty, sy).  rgb: (h, w, 3) uint8 source frame.
     luts: name -> (rgba array, linear, wrap).  given: optional list of per-pass arrays to feed forward
     instead of the oracle's own outputs (isolates each pass when checking against golden data).
+    state: a ChainState carried from frame to frame (frame history); None = stateless.
     Returns the list of per-pass outputs."""
     h, w, _ = rgb.shape
     src = np.concatenate([rgb, np.full((h, w, 1), 255, np.uint8)], -1)
     sizes = pass_sizes(passes, w, h, vw, vh)
     fmts = ["f32" if p["float_fb"] else ("srgb8" if p["srgb_fb"] else "rgba8") for p in passes]
     outs = []
+    units = state.units if state is not None else {}
 
     def tex_of_pass(k):
         nxt = passes[k + 1] if k + 1 < len(passes) else {"filter_linear": True, "wrap": "clamp_to_edge"}
@@ -65,24 +83,51 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
 
     source_tex = Tex(src, "rgbx8", passes[0]["filter_linear"], passes[0]["wrap"])
     cur = source_tex
+    pass0_call = None
     for i, p in enumerate(passes):
         spec = chain_specs.SHADERS[chain_specs.identity(p["shader"])]
-        extra = []
-        for name in spec["samplers"]:
-            t = None
-            if name.startswith("PassPrev") and name.endswith("Texture"):
-                n = int(name[8:-7])
-                t = tex_of_pass(i - n) if 1 <= n <= i else source_tex
-            elif name == "OrigTexture":
-                t = source_tex
-            else:
-                for k in range(i):
-                    if passes[k]["alias"] and passes[k]["alias"] == name:
-                        t = tex_of_pass(k)
-                if t is None and luts and name in luts:
-                    arr, linear, wrap = luts[name]
-                    t = Tex(arr, "rgba8", linear, wrap)
-            extra.append(t if t is not None else cur)
+        declared = spec["samplers"]
+        bound = {}                      # sampler name -> unit set in this draw
+        unit = 1
+
+        def bind(name, tex):
+            nonlocal unit
+            units[unit] = tex
+            bound[name] = unit
+            unit += 1
+
+        # the reference's binding order (ShaderEngine.cpp:1095-1415): history / previous passes,
+        # PassPrev<N> beyond pass 0, aliases, (PassFeedback: no registered shader), OrigTexture, LUTs
+        if i == 0:
+            hist = state.history if state is not None else []
+            for k in range(7):
+                for name in (("PrevTexture" if k == 0 else "Prev%dTexture" % k), "PassPrev%dTexture" % k):
+                    if name in declared:
+                        if k < len(hist):
+                            bind(name, _history_tex(hist[k]))
+                        break
+        else:
+            for pp in range(i):
+                for name in ("PassPrev%dTexture" % (i - pp), "PrevTexture" if pp == 0 else "Prev%dTexture" % pp):
+                    if name in declared:
+                        bind(name, tex_of_pass(pp))
+                        break
+            for n in range(i + 1, i + 13):
+                if "PassPrev%dTexture" % n in declared:
+                    bind("PassPrev%dTexture" % n, source_tex)
+            for pp in range(i):
+                al = passes[pp]["alias"]
+                if al and al in declared:
+                    bind(al, tex_of_pass(pp))
+        if "OrigTexture" in declared:
+            bind("OrigTexture", source_tex)
+        for name in sorted(luts or {}):
+            arr, linear, wrap = luts[name]
+            bind(name, Tex(arr, "rgba8", linear, wrap))
+        if i == 0 and state is not None:
+            state.pass0_units.update(bound)
+        sampler_units = dict(state.pass0_units) if (i == 0 and state is not None) else bound
+        extra = [units[sampler_units[name]] if sampler_units.get(name, 0) else cur for name in declared]
         params = []
         for name, default in spec["params"]:
             v = default
@@ -92,8 +137,25 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
                 v = global_params[name]
             params.append(v)
         ow, oh = sizes[i]
-        o = run_pass(spec["oracle"], cur, ow, oh, out_fmt=fmts[i], params=params, frame_count=frame_count,
-                     extra=extra, src_w=w, src_h=h, chain=sizes, pass_index=i, vp=(vw, vh), flags=flags)
+        call = dict(params=params, frame_count=frame_count, src_w=w, src_h=h, chain=sizes, pass_index=i, vp=(vw, vh),
+                    flags=flags)
+        if i == 0:
+            pass0_call = (spec, call)
+        o = run_pass(spec["oracle"], cur, ow, oh, out_fmt=fmts[i], extra=extra, **call)
         outs.append(o)
         cur = tex_of_pass(i)
+    if state is not None:
+        # history push (cpp:1735-1865): the final output drawn through pass 0's program - its sampler
+        # uniforms as they stand, unit 0 = the final output, every other unit as the frame left it -
+        # into an RGBA8 texture of the output size
+        spec, call = pass0_call
+        if not (spec.get("size_independent") or (len(passes) == 1 and sizes[-1] == (w, h))):
+            raise NotImplementedError("history re-draw with stale size uniforms")
+        final = cur
+        extra = [units[state.pass0_units[n]] if state.pass0_units.get(n, 0) else final for n in spec["samplers"]]
+        ow, oh = sizes[-1]
+        hist = run_pass(spec["oracle"], final, ow, oh, out_fmt="rgba8", extra=extra, **call)
+        state.history.insert(0, hist)
+        del state.history[7:]
+        state.frame_count += 1
     return outs

@@ -130,6 +130,29 @@ def test_engine_matches_oracle(key, w, h, vw, vh, preset_tree, rc_lib):
     e.shutdown()
 
 
+@pytest.mark.parametrize("case", ["mix_frames_72x40_to_72x40_f3", "mix_frames_48x36_to_120x90_f9"])
+@pytest.mark.parametrize("as_batch", [False, True])
+def test_frame_history_matches_golden(case, as_batch, preset_tree, rc_lib):
+    """A preset whose pass samples PrevTexture: output of the last frame and the whole history ring
+    (first-frame rule, recursion through pass 0's program, wrap of the 7-deep ring) against llvmpipe,
+    with the frames applied one call at a time and as one batch."""
+    from gpu_util import make_engine, run_engine
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    vw, vh = [int(v) for v in g["viewport"]]
+    frames = g["input_rgb"]
+    e = make_engine(preset_tree["mix-frames"], vw, vh)
+    if as_batch:
+        final = run_engine(e, frames)[-1]
+    else:
+        for f in range(frames.shape[0]):
+            final = run_engine(e, frames[f])[0]
+    assert np.array_equal(final, g["pass0"])
+    assert e.historyCount() == int(g["n_history"])
+    for k in range(e.historyCount()):
+        assert np.array_equal(e.readHistory(k), g["history%d" % k]), "history %d" % k
+    e.shutdown()
+
+
 def test_ntsc_full_size_batch(preset_tree, rc_lib):
     """BASELINE config 3 at full size: 1920x1080 source, 1024x1080 RGBA32F intermediate, 512x1080 output;
     a batch of 3 frames (FrameCount 1..3 drives the chroma phase), every byte against the oracle."""

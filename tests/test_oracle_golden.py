@@ -19,6 +19,8 @@ CASES = {
     "crt_pi_80x60_to_250x190": "crt-pi",
     "crt_royale_160x120_to_320x240": "crt-royale",
     "crt_royale_128x96_to_400x300": "crt-royale",
+    "mix_frames_72x40_to_72x40_f3": "mix-frames",
+    "mix_frames_48x36_to_120x90_f9": "mix-frames",
     "ntsc_svideo_96x64_to_256x192": "ntsc-256px-svideo",
     "ntsc_svideo_120x50_to_301x117": "ntsc-256px-svideo",
     "xbr_lv3_64x56_to_256x224": "xbr-lv3",
@@ -36,7 +38,7 @@ CASES = {
 # ~0.3 % of the bytes, because llvmpipe's sRGB encode runs through the x86 RSQRTPS
 # approximation and is not monotone ("sRGB8 store"); RGBA8 passes must be exact.
 BAR = {"scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1), "ntsc-256px-svideo": (1.0, 0),
-       "xbr-lv3": (1.0, 0)}
+       "xbr-lv3": (1.0, 0), "mix-frames": (1.0, 0)}
 
 
 def royale_luts():
@@ -51,7 +53,31 @@ def preset_passes(tmp_path, key):
     return engine.preset_dump(tree[key])["passes"]
 
 
-@pytest.mark.parametrize("case", sorted(CASES))
+def run_sequence(passes, frames_rgb, vw, vh, **kw):
+    """Frame-by-frame through the oracle with the reference's cross-frame state (history ring)."""
+    from oracle_chain import ChainState
+    st = ChainState()
+    outs = None
+    for f in range(frames_rgb.shape[0]):
+        outs = run_chain(passes, frames_rgb[f], vw, vh, frame_count=f + 1, state=st, **kw)
+    return outs, st
+
+
+@pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] == "mix-frames"))
+def test_oracle_frame_history_matches_llvmpipe(case, tmp_path, rc_lib):
+    """Presets that sample frame history: the last frame's output AND the ring's content after
+    3 / 9 frames (first-frame rule, recursion through pass 0's program, wrap of the 7-deep ring)."""
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    passes = preset_passes(tmp_path, CASES[case])
+    vw, vh = [int(v) for v in g["viewport"]]
+    outs, st = run_sequence(passes, g["input_rgb"], vw, vh)
+    assert np.array_equal(outs[-1], g["pass0"])
+    assert len(st.history) == int(g["n_history"]) == min(7, g["input_rgb"].shape[0])
+    for k, hk in enumerate(st.history):
+        assert np.array_equal(hk, g["history%d" % k]), "history %d" % k
+
+
+@pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] != "mix-frames"))
 def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
     g = np.load(os.path.join(GOLD, case + ".npz"))
     key = CASES[case]
