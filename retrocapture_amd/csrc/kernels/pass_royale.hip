@@ -9,6 +9,7 @@
 // operations and handed over in PassLaunch::params / planes; the kernels do the per-pixel part.
 // One thread per target pixel, 64x4 workgroups, blockIdx.z = frame.
 #include "pass_launch.h"
+#include "rc_vecmath.h"
 #include "royale_params.h"
 
 using namespace rcd;
@@ -104,52 +105,50 @@ __global__ void __launch_bounds__(256) k_royale_first(const PassLaunch L) {
 
 // ------------------------------------------------------------------------------- P1 ------
 // scanlines-vertical-interlacing.glsl FS 5982-6141; beam functions 4775-4998; gamma_impl 3907.
-template <bool SAFE>
-__device__ __forceinline__ float div_sel_(float n, float d) { return SAFE ? div_safe_(n, d) : n / d; }
+// The nine (scanline, channel) beam evaluations of a pixel are independent and identical, 250
+// float operations each: they run as four packed pairs plus one scalar (rc_vecmath.h).
+template <class F, bool SAFE>
+__device__ __forceinline__ F div_sel_(F n, F d) { return SAFE ? div_safe_v<F>(n, d) : n / d; }
 
-template <bool SAFE>
-__device__ __forceinline__ float gamma_impl1(float s, float s_inv) {
+template <class F, bool SAFE>
+__device__ __forceinline__ F gamma_impl1(F s, F s_inv) {
   const float g = 1.12906830989f, c0 = 0.8109119309638332633713423362694399653724431f;
   const float c1 = 0.4808354605142681877121661197951496120000040f, e = 2.71828182845904523536028747135266249775724709f;
-  const float sph = s + 0.5f;
-  const float lanczos_sum = c0 + div_sel_<SAFE>(c1, s + 1.0f);  // s + 1 in [1.25, 1.5]
+  const F sph = s + 0.5f;
+  const F lanczos_sum = c0 + div_sel_<F, SAFE>(F(c1), s + 1.0f);  // s + 1 in [1.25, 1.5]
   // base is in [0.69, 0.78] for s = 1/beta in [1/4, 1/2]: a positive normal, no log2 edge cases
-  const float base = div_const_(sph + g, e, 1.0f / e);
-  return (exp2_(log2_core_(base) * sph) * lanczos_sum) * s_inv;
+  const F base = div_const_v<F>(sph + g, e, 1.0f / e);
+  return (exp2_v<F, true>(log2_core_v<F>(base) * sph) * lanczos_sum) * s_inv;  // finite argument
 }
 
-struct BeamShape {  // per (scanline colour, channel): everything that does not depend on dist
-  float alpha_inv, beta, scale3;
-};
-template <bool SAFE>
-__device__ __forceinline__ BeamShape beam_shape(float color, float sigma_range, float shape_range) {
-  const float lg = log2_(color);  // pow(color, p) = exp2(log2(color) * p) for both exponents
-  const float sigma = 0.02f + sigma_range * exp2_(lg * (1.0f / 3.0f));
-  const float alpha = 1.41421356237309504880f * sigma;  // sqrtf(2.0f)
-  const float beta = 2.0f + shape_range * exp2_(lg * (1.0f / 4.0f));
-  BeamShape b;
-  // SAFE (colour sampled from an 8-bit texture): operand ranges for div_safe_: alpha in [0.028, 0.43], beta in [2, 4], gamma_impl1 in [0.88, 3.7];
-  // color is 0 or >= 2^-13 (a filtered sRGB8 decode) so the numerator is 0 or >= 2^-14
-  b.alpha_inv = div_sel_<SAFE>(1.0f, alpha);
-  b.beta = beta;
-  const float beta_inv = div_sel_<SAFE>(1.0f, beta);
-  const float scale = div_sel_<SAFE>(color * beta * 0.5f * b.alpha_inv, gamma_impl1<SAFE>(beta_inv, beta));
-  b.scale3 = div_const_(scale, 3.0f, 1.0f / 3.0f);
-  return b;
-}
-__device__ __forceinline__ float beam_contrib(const BeamShape& b, float dist, float off) {
-  const float d2 = dist + off, d3 = __builtin_fabsf(dist - off);
+// One scanline's contribution to one channel: scanline_contrib(dist, color, ...) of the GLSL, with
+// the three sub-pixel samples at dist, dist + off, |dist - off|.
+template <class F, bool SAFE>
+__device__ __forceinline__ F beam_k(F color, F dist, float off, float sigma_range, float shape_range) {
+  // SAFE also means: color is a non-negative number, so no exp2 argument below can be a NaN (log2 of
+  // 0 is -inf, every product with it stays -inf) and exp2's two clamps fold into one v_med3_f32
+  const F lg = log2_v(color);  // pow(color, p) = exp2(log2(color) * p) for both exponents
+  const F sigma = 0.02f + sigma_range * exp2_v<F, SAFE>(lg * (1.0f / 3.0f));
+  const F alpha = 1.41421356237309504880f * sigma;  // sqrtf(2.0f)
+  const F beta = 2.0f + shape_range * exp2_v<F, SAFE>(lg * (1.0f / 4.0f));
+  // SAFE (colour sampled from an 8-bit texture): operand ranges for div_safe_: alpha in [0.028, 0.43],
+  // beta in [2, 4], gamma_impl1 in [0.88, 3.7]; color is 0 or >= 2^-40, so the numerator is 0 or >= 2^-41
+  const F alpha_inv = div_sel_<F, SAFE>(F(1.0f), alpha);
+  const F beta_inv = div_sel_<F, SAFE>(F(1.0f), beta);
+  const F scale = div_sel_<F, SAFE>(color * beta * 0.5f * alpha_inv, gamma_impl1<F, SAFE>(beta_inv, beta));
+  const F scale3 = div_const_v<F>(scale, 3.0f, 1.0f / 3.0f);
+  const F d2 = dist + off, d3 = abs_v(dist - off);
   // pow(a, beta) with a >= 0 and beta in [2, 4]: for a zero or denormal `a` the full log2 returns
   // -inf and the core returns a value <= -126; times beta both are below exp2's clamp and give
   // exactly 0, so the edge-case selects of log2 are not needed here.
-  const float w1 = exp_(-exp2_(log2_core_(__builtin_fabsf(dist * b.alpha_inv)) * b.beta));
-  const float w2 = exp_(-exp2_(log2_core_(__builtin_fabsf(d2 * b.alpha_inv)) * b.beta));
-  const float w3 = exp_(-exp2_(log2_core_(__builtin_fabsf(d3 * b.alpha_inv)) * b.beta));
-  return b.scale3 * (w1 + w2 + w3);
+  const F w1 = exp_v<F, SAFE>(-exp2_v<F, SAFE>(log2_core_v<F>(abs_v(dist * alpha_inv)) * beta));
+  const F w2 = exp_v<F, SAFE>(-exp2_v<F, SAFE>(log2_core_v<F>(abs_v(d2 * alpha_inv)) * beta));
+  const F w3 = exp_v<F, SAFE>(-exp2_v<F, SAFE>(log2_core_v<F>(abs_v(d3 * alpha_inv)) * beta));
+  return scale3 * (w1 + w2 + w3);
 }
 
 template <class SI, class SO>
-__global__ void __launch_bounds__(256, 8) k_royale_scan_v(const PassLaunch L) {
+__global__ void __launch_bounds__(256, 4) k_royale_scan_v(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
   RC_TILE_LOOP_BEGIN
@@ -175,20 +174,26 @@ __global__ void __launch_bounds__(256, 8) k_royale_scan_v(const PassLaunch L) {
   const float off_y = mix_rt(-uv_step_y, 2.0f * uv_step_y, dist_round);
   const float4 so = SI::get(L.in, img, su + off_x, sv + off_y, &lds);
   const float off = ph / 3.0f;
-  const float c2[3] = {s2.x, s2.y, s2.z}, c3[3] = {s3.x, s3.y, s3.z}, co[3] = {so.x, so.y, so.z};
   const float conv_y[3] = {0.2f, 0.4f, 0.6f};
-  float out[3];
+  // colour and distance of the nine evaluations, index = scanline * 3 + channel
+  float col[9] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z, so.x, so.y, so.z}, dd[9], kk[9];
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
-    const float d2 = dist - conv_y[ch];
-    const float k2 = beam_contrib(beam_shape<SI::kUnitRange>(c2[ch], sigma_range, shape_range), d2, off);
+    dd[ch] = dist - conv_y[ch];
     // additive constants re-associated as the GL's compiler does: 1-(dist-c) -> (1+c)-dist, ...
-    const float k3 = beam_contrib(beam_shape<SI::kUnitRange>(c3[ch], sigma_range, shape_range), __builtin_fabsf((1.0f + conv_y[ch]) - dist), off);
-    float inten = k2 + k3;
-    const float d14 = mix_rt(dist + (1.0f - conv_y[ch]), (2.0f + conv_y[ch]) - dist, dist_round);
-    inten += beam_contrib(beam_shape<SI::kUnitRange>(co[ch], sigma_range, shape_range), d14, off);
-    out[ch] = inten * 0.5f;
+    dd[3 + ch] = __builtin_fabsf((1.0f + conv_y[ch]) - dist);
+    dd[6 + ch] = mix_rt(dist + (1.0f - conv_y[ch]), (2.0f + conv_y[ch]) - dist, dist_round);
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const v2f k = beam_k<v2f, SI::kUnitRange>(v2f{col[2 * j], col[2 * j + 1]}, v2f{dd[2 * j], dd[2 * j + 1]}, off, sigma_range, shape_range);
+    kk[2 * j] = k.x;
+    kk[2 * j + 1] = k.y;
+  }
+  kk[8] = beam_k<float, SI::kUnitRange>(col[8], dd[8], off, sigma_range, shape_range);
+  float out[3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) out[ch] = ((kk[ch] + kk[3 + ch]) + kk[6 + ch]) * 0.5f;
   SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
   RC_TILE_LOOP_END
 }
