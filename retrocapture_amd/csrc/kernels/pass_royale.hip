@@ -103,6 +103,32 @@ __global__ void __launch_bounds__(256) k_royale_first(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// Progressive source, 8-bit NEAREST clamp-to-edge input, 8-bit target (the shipped configuration):
+// the stored byte is a function of the source byte alone - encode(pow(byte/255, 2.5)) - so the
+// pass is a 256-entry byte map applied to the nearest texel.  Same results as k_royale_first.
+template <int OUT_FMT>
+__global__ void __launch_bounds__(256) k_royale_first_bytemap(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  __shared__ uint32_t map[256];
+  load_srgb_tables(lds);
+  {
+    const int t = threadIdx.y * 64 + threadIdx.x;
+    const float lin = pow_((float)t * (1.0f / 255.0f), 2.5f);
+    map[t] = OUT_FMT == FMT_SRGB8 ? srgb8(lin, &lds) : unorm8(lin);
+  }
+  __syncthreads();
+  RC_TILE_LOOP_BEGIN
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  // sample_nearest<., WRAP_EDGE>: texel index
+  const int sx = clampi((int)__builtin_floorf(u * (float)L.in.w), 0, L.in.w - 1);
+  const int sy = clampi((int)__builtin_floorf(v * (float)L.in.h), 0, L.in.h - 1);
+  const uint32_t p = *reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z) + ((size_t)sy * L.in.w + sx) * 4);
+  // alpha: the shader writes 1.0
+  const uint32_t o = map[p & 255u] | (map[(p >> 8) & 255u] << 8) | (map[(p >> 16) & 255u] << 16) | 0xff000000u;
+  *(reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z) + ((size_t)y * L.out_w + x)) = o;
+  RC_TILE_LOOP_END
+}
+
 // ------------------------------------------------------------------------------- P1 ------
 // scanlines-vertical-interlacing.glsl FS 5982-6141; beam functions 4775-4998; gamma_impl 3907.
 // The nine (scanline, channel) beam evaluations of a pixel are independent and identical, 250
@@ -493,7 +519,21 @@ namespace rck {
     hipLaunchKernelGGL(kernel, px_grid(L), px_block(), 0, s, L);      \
     return hipGetLastError();                                         \
   }
-RC_LAUNCH(launch_royale_first, k_royale_first)
+hipError_t launch_royale_first(const PassLaunch& L, hipStream_t s) {
+  const bool bytes_in = (L.in.fmt == FMT_RGBX8 || L.in.fmt == FMT_RGBA8) && !L.in.linear && L.in.wrap == WRAP_EDGE;
+  if (bytes_in && L.params[RP0_INTERLACED] == 0.0f && !(L.flags & RC_FLAG_GENERAL_ONLY)) {
+    if (L.out_fmt == FMT_SRGB8) {
+      hipLaunchKernelGGL(k_royale_first_bytemap<FMT_SRGB8>, px_grid(L), px_block(), 0, s, L);
+      return hipGetLastError();
+    }
+    if (L.out_fmt == FMT_RGBA8) {
+      hipLaunchKernelGGL(k_royale_first_bytemap<FMT_RGBA8>, px_grid(L), px_block(), 0, s, L);
+      return hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL(k_royale_first, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
 RC_LAUNCH(launch_royale_mask_v, k_royale_mask_v)
 RC_LAUNCH(launch_royale_mask_h, k_royale_mask_h)
 

@@ -86,6 +86,25 @@ def test_royale_matches_oracle_and_golden(case, preset_tree, rc_lib):
     e.shutdown()
 
 
+@pytest.mark.parametrize("w,h,vw,vh", [(160, 120, 320, 240), (96, 128, 517, 389), (300, 40, 300, 40)])
+def test_royale_specialised_and_general_forms_agree(w, h, vw, vh, preset_tree, rc_lib):
+    """Passes with a specialised form (P0: byte map of the nearest texel) must equal their general
+    form byte for byte on every pass."""
+    from gpu_util import make_engine, run_engine
+    frames = np.random.default_rng(w + vh).integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+    e = make_engine(preset_tree["crt-royale"], vw, vh)
+    e.setUndefinedVaryingZero(True)   # mask active: passes 7-10 carry signal
+    a = run_engine(e, frames)
+    pa = [e.readPass(i, 1) for i in range(12)]
+    e.setGeneralKernelsOnly(True)
+    b = run_engine(e, frames)
+    pb = [e.readPass(i, 1) for i in range(12)]
+    for i in range(12):
+        assert np.array_equal(pa[i], pb[i]), "pass %d" % i
+    assert np.array_equal(a, b)
+    e.shutdown()
+
+
 def test_royale_interlaced_source_and_batch(preset_tree, rc_lib):
     """A 480-line source is 'interlaced' for crt-royale (288.5 < lines < 576.5): pass 0 bobs fields
     and pass 1 doubles the scanline step, both depending on FrameCount.  Batch of 3 frames."""
