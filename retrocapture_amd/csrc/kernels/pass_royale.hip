@@ -504,10 +504,18 @@ __global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
   const float4 c = SI::get(L.in, frame_ptr(L.in, z), tu, tv, &lds);
   const float ex = minps(vu, 1.0f - vu) * geom_aspect_x, ey = minps(vv, 1.0f - vv) * geom_aspect_y;
   const float bx = maxps(border_size - ex, 0.0f), by = maxps(border_size - ey, 0.0f);
-  const float pen = __builtin_sqrtf(bx * bx + by * by) / border_size;
-  const float esc = maxps(1.0f - pen, 0.0f);
-  const float f = minps(pow_(esc, border_darkness) * maxps(1.0f, border_compress), 1.0f);
-  SO::put(L, z, x, y, make_float4(pow_(c.x * f, inv_gamma), pow_(c.y * f, inv_gamma), pow_(c.z * f, inv_gamma), 1.0f), &lds);
+  // Away from the border bx = by = 0: pen = sqrt(0)/size = 0, esc = 1, pow(1, d) = exp2(0*d) = 1 exactly
+  // (log2's polynomial is y*P with y = 0 at mantissa 1), and min(1 * max(1, compress), 1) = 1.
+  // (border_size = 0 would make pen 0/0: that case takes the full path)
+  float f = 1.0f;
+  if (bx != 0.0f || by != 0.0f || !(border_size > 0.0f)) {
+    const float pen = __builtin_sqrtf(bx * bx + by * by) / border_size;
+    const float esc = maxps(1.0f - pen, 0.0f);
+    f = minps(pow_(esc, border_darkness) * maxps(1.0f, border_compress), 1.0f);
+  }
+  // the three output-gamma pows: red and green as a packed pair (rc_vecmath.h), blue alone
+  const v2f rg = exp2_v<v2f>(log2_v(v2f{c.x * f, c.y * f}) * inv_gamma);
+  SO::put(L, z, x, y, make_float4(rg.x, rg.y, pow_(c.z * f, inv_gamma), 1.0f), &lds);
   RC_TILE_LOOP_END
 }
 
