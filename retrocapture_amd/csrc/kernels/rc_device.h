@@ -238,12 +238,17 @@ __device__ __forceinline__ int wrap_index(int i, int n) {
   return clampi(i, 0, n - 1);
 }
 
+// Byte offset of texel (x, y) inside one image: 32-bit arithmetic (the engine refuses frames of
+// 4 GiB or more), so the address is a uniform 64-bit base plus a 32-bit lane offset instead of a
+// 64-bit multiply-add per fetch.
+__device__ __forceinline__ uint32_t texel_off(int w, int x, int y, uint32_t bytes) { return ((uint32_t)y * (uint32_t)w + (uint32_t)x) * bytes; }
+
 template <int FMT>
 __device__ __forceinline__ float4 texel(const Tex& t, const uint8_t* img, int x, int y, const SrgbLds* lds) {
   if (FMT == FMT_F32) {
-    return *reinterpret_cast<const float4*>(img + ((size_t)y * t.w + x) * 16);
+    return *reinterpret_cast<const float4*>(img + texel_off(t.w, x, y, 16u));
   }
-  uint32_t p = *reinterpret_cast<const uint32_t*>(img + ((size_t)y * t.w + x) * 4);
+  uint32_t p = *reinterpret_cast<const uint32_t*>(img + texel_off(t.w, x, y, 4u));
   const float k = 1.0f / 255.0f;
   uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u, a = p >> 24;
   if (FMT == FMT_SRGB8) return make_float4(lds->dec[r], lds->dec[g], lds->dec[b], (float)a * k);
@@ -312,10 +317,10 @@ __device__ __forceinline__ float4 sample_linear_u8(const Tex& t, const uint8_t* 
   int wx = (int)__builtin_rintf((u - x0f) * 256.0f), wy = (int)__builtin_rintf((w - y0f) * 256.0f);
   int x0 = wrap_index<WRAP>((int)x0f, t.w), x1 = wrap_index<WRAP>((int)x0f + 1, t.w);
   int y0 = wrap_index<WRAP>((int)y0f, t.h), y1 = wrap_index<WRAP>((int)y0f + 1, t.h);
-  uint32_t p00 = *reinterpret_cast<const uint32_t*>(img + ((size_t)y0 * t.w + x0) * 4);
-  uint32_t p10 = *reinterpret_cast<const uint32_t*>(img + ((size_t)y0 * t.w + x1) * 4);
-  uint32_t p01 = *reinterpret_cast<const uint32_t*>(img + ((size_t)y1 * t.w + x0) * 4);
-  uint32_t p11 = *reinterpret_cast<const uint32_t*>(img + ((size_t)y1 * t.w + x1) * 4);
+  uint32_t p00 = *reinterpret_cast<const uint32_t*>(img + texel_off(t.w, x0, y0, 4u));
+  uint32_t p10 = *reinterpret_cast<const uint32_t*>(img + texel_off(t.w, x1, y0, 4u));
+  uint32_t p01 = *reinterpret_cast<const uint32_t*>(img + texel_off(t.w, x0, y1, 4u));
+  uint32_t p11 = *reinterpret_cast<const uint32_t*>(img + texel_off(t.w, x1, y1, 4u));
   float o[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -366,13 +371,13 @@ template <int OUT_FMT>
 __device__ __forceinline__ void store(const PassLaunch& L, int z, int x, int y, float4 c, const SrgbLds* t) {
   uint8_t* o = static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z;
   if (OUT_FMT == FMT_F32) {
-    *reinterpret_cast<float4*>(o + ((size_t)y * L.out_w + x) * 16) = c;
+    *reinterpret_cast<float4*>(o + texel_off(L.out_w, x, y, 16u)) = c;
   } else if (OUT_FMT == FMT_SRGB8) {
     uint32_t p = srgb8(c.x, t) | (srgb8(c.y, t) << 8) | (srgb8(c.z, t) << 16) | (unorm8(c.w) << 24);
-    *reinterpret_cast<uint32_t*>(o + ((size_t)y * L.out_w + x) * 4) = p;
+    *reinterpret_cast<uint32_t*>(o + texel_off(L.out_w, x, y, 4u)) = p;
   } else {
     uint32_t p = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (unorm8(c.w) << 24);
-    *reinterpret_cast<uint32_t*>(o + ((size_t)y * L.out_w + x) * 4) = p;
+    *reinterpret_cast<uint32_t*>(o + texel_off(L.out_w, x, y, 4u)) = p;
   }
 }
 

@@ -601,6 +601,16 @@ const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames,
     }
   }
   resolvePassSizes(pw, ph);
+  // the kernels address texels inside one frame with 32-bit byte offsets (rc_device.h texel_off)
+  {
+    const uint64_t limit = 1ull << 32;
+    bool ok = (uint64_t)width * height * 4 < limit;
+    for (const auto& p : m_passes) ok = ok && (uint64_t)p.frameBytes < limit;
+    if (!ok) {
+      RC_LOG_ERROR("applyShader: a frame or pass target of 4 GiB or more is not supported");
+      return inputs;
+    }
+  }
 
   // buffers: every pass holds `chunk` frames, except the last which holds the whole batch
   // a preset whose first pass samples frame history is sequential: one frame per chunk, history
