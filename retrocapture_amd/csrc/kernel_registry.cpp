@@ -20,6 +20,10 @@ void setupCrtPi(const PassGeometry& g, rcd::PassLaunch& L) {
   L.plane[1] = planeV(1.0001f, g.out_w, g.out_h, g.out_fmt);
 }
 
+// The device's vary() and GL_NEAREST index, evaluated on the host with the same operations.
+float hostVary(const rcd::Plane& p, int x, int y) { return std::fmaf(p.dy_lo, (float)y, std::fmaf(p.dx_lo, (float)x, p.a0_lo)); }
+int hostNearest(float s, int n) { return (int)std::floor(s * (float)n); }
+
 // ntsc-pass1-svideo-3phase.glsl:69  pix_no = vTexCoord * SourceSize.xy * (outsize.xy / InputSize.xy)
 void setupNtscPass1(const PassGeometry& g, rcd::PassLaunch& L) {
   const float tsx = (float)g.in_w, tsy = (float)g.in_h;
@@ -30,16 +34,44 @@ void setupNtscPass1(const PassGeometry& g, rcd::PassLaunch& L) {
   L.plane[3] = makePlane(0.f, 0.f, py1, py1, g.out_w, g.out_h, g.out_fmt);
 }
 
+// True when the 49 taps of ntsc pass 2 form, for every target column, the consecutive source columns
+// c(x) - 24 .. c(x) + 24 with c(x + 1) = c(x) + 2 (evaluated with the kernel's own float operations on
+// the actual plane): then pass_ntsc.hip may stage one row segment per wave instead of fetching per tap.
+bool ntscTapsAreRegular(const PassGeometry& g, const rcd::PassLaunch& L) {
+  if (g.out_fmt != rcd::FMT_RGBA8) return false;  // one plane per varying only on the rectangle path
+  const rcd::Plane &pu = L.plane[0], &pv = L.plane[1];
+  if (pu.dy_lo != 0.0f || pv.dx_lo != 0.0f || pu.a0_lo != pu.a0_up || pu.dx_lo != pu.dx_up || pv.a0_lo != pv.a0_up ||
+      pv.dy_lo != pv.dy_up)
+    return false;
+  const float one_x = 1.0f / (float)g.in_w;
+  int prev = 0;
+  for (int x = 0; x < g.out_w; ++x) {
+    const float u = hostVary(pu, x, 0);
+    const int c = hostNearest(u, g.in_w);
+    if (x > 0 && c != prev + 2) return false;
+    prev = c;
+    for (int k = 1; k <= 24; ++k) {
+      const float off = (float)(k - 25);
+      if (hostNearest(u + off * one_x, g.in_w) != c + (k - 25)) return false;
+      if (hostNearest(u + (-off) * one_x, g.in_w) != c - (k - 25)) return false;
+    }
+  }
+  return true;
+}
+
 // ntsc-pass2-3phase-gamma.glsl:48  TEX0.xy = TexCoord.xy - vec2(0.5 / SourceSize.x, 0.0)
 void setupNtscPass2(const PassGeometry& g, rcd::PassLaunch& L) {
   const float sh = 0.5f / (float)g.in_w;
   L.plane[0] = makePlane(0.f - sh, 1.f - sh, 1.f - sh, 0.f - sh, g.out_w, g.out_h, g.out_fmt);
   L.plane[1] = planeV(1.0f, g.out_w, g.out_h, g.out_fmt);
+  static thread_local struct { int v[5]; bool ok; } memo = {{-1, -1, -1, -1, -1}, false};
+  const int key[5] = {g.in_w, g.in_h, g.out_w, g.out_h, g.out_fmt};
+  if (std::memcmp(memo.v, key, sizeof(key)) != 0) {
+    std::memcpy(memo.v, key, sizeof(key));
+    memo.ok = ntscTapsAreRegular(g, L);
+  }
+  if (memo.ok) L.flags |= rcd::RC_FLAG_NTSC_REGULAR;
 }
-
-// The device's vary() and GL_NEAREST index, evaluated on the host with the same operations.
-float hostVary(const rcd::Plane& p, int x, int y) { return std::fmaf(p.dy_lo, (float)y, std::fmaf(p.dx_lo, (float)x, p.a0_lo)); }
-int hostNearest(float s, int n) { return (int)std::floor(s * (float)n); }
 
 // xbr-lv3's rule tests depend only on the 21-texel neighbourhood of the source pixel a target
 // pixel falls in, PROVIDED the five columns (rows) it samples through five separately

@@ -120,6 +120,77 @@ __global__ void __launch_bounds__(256) k_ntsc_pass2(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// ---- pass 2, row-staged form ------------------------------------------------------------------
+// The 49 taps of a pixel lie on one source row at consecutive columns, and the windows of the 64
+// pixels a wave computes overlap: 49 x 64 sixteen-byte fetches for 176 distinct texels.  When the
+// host has verified (kernel_registry.cpp, ntscTapsAreRegular: every tap of every target column,
+// evaluated with these very float operations) that tap k of column x reads source column
+// c(x) + k - 24 with c(x + 1) = c(x) + 2, each wave stages its row segment once - wrap applied while
+// staging, Y / I / Q split into planes and de-interleaved by column parity so that the 64 lanes of a
+// tap read 64 consecutive words - and every tap is three LDS reads at compile-time offsets.
+// Accumulation order and arithmetic are those of k_ntsc_pass2.
+constexpr int kNtscSeg = 176;                 // 2 * 63 + 49 columns, rounded up to even
+struct NtscRow { float y[2][kNtscSeg / 2], i[2][kNtscSeg / 2], q[2][kNtscSeg / 2]; };
+
+template <int IN_WRAP>
+__global__ void __launch_bounds__(256, 8) k_ntsc_pass2_rows(const PassLaunch L) {
+  __shared__ NtscRow rows[4];
+  const int tiles_x = (L.out_w + 63) >> 6, tiles_y = (L.out_h + 3) >> 2;
+  const int tiles_per_frame = tiles_x * tiles_y, n_tiles = tiles_per_frame * L.n_frames;
+  const int lane = threadIdx.x, wv = threadIdx.y;
+  NtscRow& row = rows[wv];
+  const float gm = 2.5f / 2.0f;
+  for (int tile_i = blockIdx.x; tile_i < n_tiles; tile_i += gridDim.x) {
+    const int z = tile_i / tiles_per_frame, rem = tile_i - z * tiles_per_frame;
+    const int tyi = rem / tiles_x, x0 = (rem - tyi * tiles_x) * 64;
+    const int x = x0 + lane, y = min(tyi * 4 + wv, L.out_h - 1);  // a row beyond the target recomputes the last one
+    const bool live = (tyi * 4 + wv) < L.out_h && x < L.out_w;
+    const uint8_t* img = frame_ptr(L.in, z);
+    // source row of this wave and first source column of its segment (rectangle-path planes: u depends on x only)
+    const float v = vary(L.plane[1], x0, y, false);
+    const int sy_raw = (int)__builtin_floorf(v * (float)L.in.h);
+    const int c_first = (int)__builtin_floorf(vary(L.plane[0], x0, y, false) * (float)L.in.w) - 24;
+    __syncthreads();  // every wave is done reading the previous tile's rows
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+      const int j = part * 64 + lane;  // segment column
+      if (j < kNtscSeg) {
+        const int sx_raw = c_first + j;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (IN_WRAP == WRAP_BORDER) {
+          if (sx_raw >= 0 && sx_raw < L.in.w && sy_raw >= 0 && sy_raw < L.in.h)
+            t = *reinterpret_cast<const float4*>(img + texel_off(L.in.w, sx_raw, sy_raw, 16u));
+        } else {
+          t = *reinterpret_cast<const float4*>(img + texel_off(L.in.w, clampi(sx_raw, 0, L.in.w - 1), clampi(sy_raw, 0, L.in.h - 1), 16u));
+        }
+        row.y[j & 1][j >> 1] = t.x;
+        row.i[j & 1][j >> 1] = t.y;
+        row.q[j & 1][j >> 1] = t.z;
+      }
+    }
+    __syncthreads();
+    // tap k (0..48) of lane l sits at segment column 2l + k
+    float sy = 0.f, si = 0.f, sq = 0.f;
+#pragma unroll
+    for (int c = 1; c <= 24; ++c) {
+      const int kp = c - 1, kn = 49 - c;  // offsets c - 25 and 25 - c
+      const float py = row.y[kp & 1][lane + (kp >> 1)], ny = row.y[kn & 1][lane + (kn >> 1)];
+      const float pi = row.i[kp & 1][lane + (kp >> 1)], ni = row.i[kn & 1][lane + (kn >> 1)];
+      const float pq = row.q[kp & 1][lane + (kp >> 1)], nq = row.q[kn & 1][lane + (kn >> 1)];
+      sy = sy + (py + ny) * k_luma[c - 1];
+      si = si + (pi + ni) * k_chroma[c - 1];
+      sq = sq + (pq + nq) * k_chroma[c - 1];
+    }
+    sy = sy + row.y[0][lane + 12] * k_luma[24];
+    si = si + row.i[0][lane + 12] * k_chroma[24];
+    sq = sq + row.q[0][lane + 12] * k_chroma[24];
+    const float r = sy + (si * 0.956f + sq * 0.6210f);
+    const float g = sy + (si * -0.2720f + sq * -0.6474f);
+    const float b = sy + (si * -1.1060f + sq * 1.7046f);
+    if (live) store<FMT_RGBA8>(L, z, x, tyi * 4 + wv, make_float4(pow_(r, gm), pow_(g, gm), pow_(b, gm), 1.0f), nullptr);
+  }
+}
+
 }  // namespace
 
 namespace rck {
@@ -135,6 +206,12 @@ hipError_t launch_ntsc_pass1(const PassLaunch& L, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_ntsc_pass2(const PassLaunch& L, hipStream_t s) {
+  if (L.in.fmt == FMT_F32 && !L.in.linear && L.out_fmt == FMT_RGBA8 && (L.flags & RC_FLAG_NTSC_REGULAR) &&
+      !(L.flags & RC_FLAG_GENERAL_ONLY) && (L.in.wrap == WRAP_EDGE || L.in.wrap == WRAP_BORDER)) {
+    if (L.in.wrap == WRAP_EDGE) hipLaunchKernelGGL((k_ntsc_pass2_rows<WRAP_EDGE>), px_grid(L), px_block(), 0, s, L);
+    else hipLaunchKernelGGL((k_ntsc_pass2_rows<WRAP_BORDER>), px_grid(L), px_block(), 0, s, L);
+    return hipGetLastError();
+  }
   if (L.in.fmt == FMT_F32 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8)
     hipLaunchKernelGGL((k_ntsc_pass2<FMT_F32, 0, WRAP_EDGE, FMT_RGBA8, false>), px_grid(L), px_block(), 0, s, L);
   else if (L.in.fmt == FMT_F32 && !L.in.linear && L.in.wrap == WRAP_BORDER && L.out_fmt == FMT_RGBA8)

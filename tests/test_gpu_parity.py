@@ -172,6 +172,22 @@ def test_frame_history_matches_golden(case, as_batch, preset_tree, rc_lib):
     e.shutdown()
 
 
+@pytest.mark.parametrize("w,h,vw,vh", [(96, 64, 256, 192), (33, 20, 100, 77), (640, 480, 640, 480)])
+def test_ntsc_row_staged_and_general_forms_agree(w, h, vw, vh, preset_tree, rc_lib):
+    """ntsc pass 2 stages one source row segment per wave when the host has verified the tap pattern;
+    the general per-tap form must give the same bytes."""
+    from gpu_util import make_engine, run_engine
+    frames = np.random.default_rng(w * 3 + vh).integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+    e = make_engine(preset_tree["ntsc-256px-svideo"], vw, vh)
+    a = run_engine(e, frames)
+    e2 = make_engine(preset_tree["ntsc-256px-svideo"], vw, vh)   # a fresh engine: same FrameCount sequence
+    e2.setGeneralKernelsOnly(True)
+    b = run_engine(e2, frames)
+    assert np.array_equal(a, b)
+    e.shutdown()
+    e2.shutdown()
+
+
 def test_ntsc_full_size_batch(preset_tree, rc_lib):
     """BASELINE config 3 at full size: 1920x1080 source, 1024x1080 RGBA32F intermediate, 512x1080 output;
     a batch of 3 frames (FrameCount 1..3 drives the chroma phase), every byte against the oracle."""
