@@ -37,6 +37,9 @@ namespace {
 struct Pass {
   ShaderPass info;
   GLuint program = 0, fbo = 0, tex = 0;
+  GLuint written_tex = 0;
+  GLuint fb_fbo = 0, fb_tex = 0;  // PassFeedback ping-pong partner (ShaderEngine.h feedbackTexture / feedbackFramebuffer)
+  bool feedback_enabled = false;
   uint32_t w = 0, h = 0;
   std::map<std::string, float> params;  // #pragma parameter defaults
 };
@@ -509,6 +512,41 @@ int main(int argc, char** argv) {
             Uniform4f(l, passes[pp].w, passes[pp].h, 1.f / passes[pp].w, 1.f / passes[pp].h);
         }
       }
+      // PassFeedback<N>: the previous frame's output of pass N <= i, second texture allocated on
+      // first sight (createFramebuffer, same size and format), swapped at the end of the frame:
+      // ShaderEngine.cpp:1285-1347
+      for (size_t fp = 0; fp <= i; ++fp) {
+        const std::string n = std::to_string(fp);
+        GLint tl = uloc(pr, "PassFeedback" + n);
+        if (tl < 0) tl = uloc(pr, "PassFeedback" + n + "Texture");
+        GLint sl = uloc(pr, "PassFeedback" + n + "Size");
+        if (sl < 0) sl = uloc(pr, "PassFeedback" + n + "TextureSize");
+        if (tl < 0 && sl < 0) continue;
+        Pass& t = passes[fp];
+        t.feedback_enabled = true;
+        if (t.fb_tex == 0 && t.w > 0 && t.h > 0) {
+          GenTextures(1, &t.fb_tex);
+          BindTexture(GL_TEXTURE_2D, t.fb_tex);
+          GLenum ifmt = t.info.floatFramebuffer ? GL_RGBA32F : t.info.srgbFramebuffer ? GL_SRGB8_ALPHA8 : GL_RGBA;
+          TexImage2D(GL_TEXTURE_2D, 0, ifmt, t.w, t.h, 0, GL_RGBA, t.info.floatFramebuffer ? GL_FLOAT : GL_UNSIGNED_BYTE, nullptr);
+          TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_LINEAR);
+          TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_LINEAR);
+          TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
+          TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
+          GenFramebuffers(1, &t.fb_fbo);
+          BindFramebuffer(GL_FRAMEBUFFER, t.fb_fbo);
+          FramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, t.fb_tex, 0);
+          CheckFramebufferStatus(GL_FRAMEBUFFER);
+          BindFramebuffer(GL_FRAMEBUFFER, 0);  // createFramebuffer leaves FBO 0 bound (cpp:2931-2932)
+          BindTexture(GL_TEXTURE_2D, 0);
+        }
+        if (tl >= 0 && t.fb_tex != 0) {
+          ActiveTexture(GL_TEXTURE0 + unit);
+          BindTexture(GL_TEXTURE_2D, t.fb_tex);
+          Uniform1i(tl, unit++);
+        }
+        if (sl >= 0) Uniform4f(sl, t.w, t.h, t.w > 0 ? 1.f / t.w : 0.f, t.h > 0 ? 1.f / t.h : 0.f);
+      }
       if ((l = uloc(pr, "OrigTexture")) >= 0) {  // cpp:1351-1358
         ActiveTexture(GL_TEXTURE0 + unit);
         BindTexture(GL_TEXTURE_2D, src_tex);
@@ -537,6 +575,7 @@ int main(int argc, char** argv) {
       DrawElements(GL_TRIANGLES, 6, GL_UNSIGNED_INT, nullptr);  // cpp:1448
       BindVertexArray(0);
       cur_tex = p.tex;
+      p.written_tex = p.tex;  // what this frame rendered into (the feedback swap below renames it)
       cw = ow;
       ch = oh;
     }
@@ -544,6 +583,11 @@ int main(int argc, char** argv) {
     Disable(GL_FRAMEBUFFER_SRGB);
     BindTexture(GL_TEXTURE_2D, 0);  // unit 0 is the active one after the last draw (cpp:1703-1704)
     UseProgram(0);
+    for (auto& fp : passes) {  // PassFeedback ping-pong swap: cpp:1710-1718
+      if (!fp.feedback_enabled || fp.fb_tex == 0) continue;
+      std::swap(fp.tex, fp.fb_tex);
+      std::swap(fp.fbo, fp.fb_fbo);
+    }
     // history push: the final output is re-drawn through pass 0's program, with pass 0's uniforms
     // as they stand, into a history texture: ShaderEngine.cpp:1735-1865
     if (cur_tex != 0 && cw > 0 && ch > 0) {
@@ -604,7 +648,7 @@ int main(int argc, char** argv) {
   PixelStorei(GL_PACK_ALIGNMENT, 1);
   for (size_t i = 0; i < passes.size(); ++i) {
     Pass& p = passes[i];
-    BindTexture(GL_TEXTURE_2D, p.tex);
+    BindTexture(GL_TEXTURE_2D, p.written_tex ? p.written_tex : p.tex);
     std::string fn = out_dir + "/pass" + std::to_string(i) + ".bin";
     FILE* fo = fopen(fn.c_str(), "wb");
     if (p.info.floatFramebuffer) {

@@ -100,6 +100,7 @@ typedef struct {
 void o_pass_stock(const o_pass_args* a);
 void o_pass_scanline(const o_pass_args* a);
 void o_pass_crt_pi(const o_pass_args* a);
+void o_pass_feedback_persist(const o_pass_args* a);   /* fixture; extra = PassFeedback0, PassFeedback1; 1 param */
 void o_pass_mix_frames(const o_pass_args* a);         /* extra[0] = PrevTexture (frame history) */
 /* crt-royale (shaders/shaders_glsl/crt/shaders/crt-royale/src/*.glsl, blurs/blur9fast-*.glsl) */
 void o_pass_royale_first(const o_pass_args* a);       /* P0  first-pass-linearize-crt-gamma-bob-fields */

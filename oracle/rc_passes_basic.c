@@ -152,3 +152,27 @@ void o_pass_mix_frames(const o_pass_args* a) {
   o_pass_mix_frames_body(a);
   o_fp_leave(csr);
 }
+
+/* Conformance fixture tests/fixtures/conformance/feedback-persist.glsl (this repository's own shader,
+ * FS main): max(cur*0.75 + old0*0.25, old1*PERSIST); extra[0] = PassFeedback0, extra[1] = PassFeedback1.
+ * params: PERSIST */
+static void o_pass_feedback_persist_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float persist = a->params[0];
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      o_vec4 c = o_sample(a->in, u, v), p0 = o_sample(a->extra[0], u, v), p1 = o_sample(a->extra[1], u, v);
+      float m0 = c.x * 0.75f + p0.x * 0.25f, m1 = c.y * 0.75f + p0.y * 0.25f, m2 = c.z * 0.75f + p0.z * 0.25f;
+      float q0 = p1.x * persist, q1 = p1.y * persist, q2 = p1.z * persist;
+      o_vec4 o = {m0 < q0 ? q0 : m0, m1 < q1 ? q1 : m1, m2 < q2 ? q2 : m2, 1.0f};
+      store_px(a, x, y, o);
+    }
+}
+void o_pass_feedback_persist(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  o_pass_feedback_persist_body(a);
+  o_fp_leave(csr);
+}

@@ -164,6 +164,10 @@ std::vector<KernelEntry> build() {
                 {"INPUT_GAMMA", 2.4f, 0.0f, 5.0f, 0.01f, "Input gamma"},
                 {"OUTPUT_GAMMA", 2.2f, 0.0f, 5.0f, 0.01f, "Output gamma"}},
                {}, rck::launch_crt_pi, setupCrtPi, false});
+  // conformance fixture of this repository (tests/fixtures/conformance/): pins PassFeedback, which no
+  // shader of the reference's tree declares
+  r.push_back({"conformance/feedback-persist.glsl", "feedback-persist", {{"PERSIST", 0.8f, 0.0f, 1.0f, 0.05f, "Persistence"}},
+               {"PassFeedback0", "PassFeedback1"}, rck::launch_feedback_persist, setupTexCoord, false});
   r.push_back({"motionblur/shaders/mix_frames.glsl", "mix-frames", {}, {"PrevTexture"}, rck::launch_mix_frames, setupCrtPi,
                false, true, nullptr, nullptr, true});  // VS: TEX0 = TexCoord * 1.0001 (mix_frames.glsl:53)
   r.push_back({"ntsc/shaders/ntsc-pass1-svideo-3phase.glsl", "ntsc-pass1-svideo-3phase", {}, {},

@@ -50,6 +50,23 @@ __global__ void __launch_bounds__(256) k_mix_frames(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// Conformance fixture tests/fixtures/conformance/feedback-persist.glsl (this repository's own shader):
+// max(cur*0.75 + old0*0.25, old1*PERSIST); extra[0] = PassFeedback0, extra[1] = PassFeedback1
+__global__ void __launch_bounds__(256) k_feedback_persist(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float persist = L.params[0];
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+  const float4 p0 = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), u, v, &lds);
+  const float4 p1 = sample_rt(L.extra[1], frame_ptr(L.extra[1], z), u, v, &lds);
+  const float m0 = c.x * 0.75f + p0.x * 0.25f, m1 = c.y * 0.75f + p0.y * 0.25f, m2 = c.z * 0.75f + p0.z * 0.25f;
+  const float q0 = p1.x * persist, q1 = p1.y * persist, q2 = p1.z * persist;
+  store_rt(L, z, x, y, make_float4(m0 < q0 ? q0 : m0, m1 < q1 ? q1 : m1, m2 < q2 ? q2 : m2, 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
 __device__ __forceinline__ float crtpi_weight(float dist, float sw, float gap) {
   float w = 1.0f - (dist * dist) * sw;
   return w > gap ? w : gap;
@@ -117,6 +134,10 @@ hipError_t launch_stock(const PassLaunch& L, hipStream_t s) {
 }
 hipError_t launch_mix_frames(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_mix_frames, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_feedback_persist, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }
 hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {

@@ -89,6 +89,8 @@ void ShaderEngine::cleanupPresetPasses() {
   for (auto& p : m_passes) {
     if (p.target.ptr) (void)hipFree(p.target.ptr);
     if (p.scratch.ptr) (void)hipFree(p.scratch.ptr);
+    if (p.feedback.ptr) (void)hipFree(p.feedback.ptr);
+    if (p.lastTarget.ptr) (void)hipFree(p.lastTarget.ptr);
   }
   m_passes.clear();
   for (auto& h : m_frameHistory)
@@ -495,8 +497,17 @@ bool ShaderEngine::presetSamplesHistory() const {
 // (:1234-1245), earlier passes by alias (:1251-1277), OrigTexture (:1351-1358) and every preset LUT
 // (:1361-1415; a LUT takes a unit whether or not the program declares it).  A sampler uniform that
 // is not set keeps its value: 0 (= the pass input on unit 0) on a fresh program.
-void ShaderEngine::bindSamplers(size_t i, const KernelEntry& k, const rcd::Tex& inputTex, const rcd::Tex& sourceTex,
-                                rcd::PassLaunch* L) {
+bool ShaderEngine::presetSamplesFeedback() const {
+  for (const auto& p : m_passes)
+    if (p.kernel)
+      for (const char* s : p.kernel->samplers)
+        if (std::strncmp(s, "PassFeedback", 12) == 0) return true;
+  return false;
+}
+
+bool ShaderEngine::bindSamplers(size_t i, const KernelEntry& k, const rcd::Tex& inputTex, const rcd::Tex& sourceTex,
+                                rcd::PassLaunch* L, bool* lostDraw) {
+  *lostDraw = false;
   if (m_units.size() < 64) m_units.resize(64);
   std::map<std::string, int> bound;
   int unit = 1;
@@ -542,6 +553,35 @@ void ShaderEngine::bindSamplers(size_t i, const KernelEntry& k, const rcd::Tex& 
       if (!al.empty() && declares(k, al)) bind(al, passTexture(pp));
     }
   }
+  // PassFeedback<fp> for fp <= i (:1285-1347): the partner texture of pass fp, created (zero-filled,
+  // LINEAR / clamp to edge) the first time any program asks for it.  createFramebuffer ends with
+  // framebuffer 0 bound (:2931), so the draw of the pass that triggered the creation does not reach
+  // its target, which keeps its clear colour - reproduced through *lostDraw.
+  for (size_t fp = 0; fp <= i && fp < m_passes.size(); ++fp) {
+    const std::string names[2] = {"PassFeedback" + std::to_string(fp), "PassFeedback" + std::to_string(fp) + "Texture"};
+    const std::string* hit = nullptr;
+    for (const std::string& n : names)
+      if (declares(k, n)) {
+        hit = &n;
+        break;
+      }
+    if (!hit) continue;
+    ShaderPassData& t = m_passes[fp];
+    t.feedbackEnabled = true;
+    if (!t.feedback.ptr && t.frameBytes > 0) {
+      if (!ensureBuffer(t.feedback, t.frameBytes)) return false;
+      if (!hipOk(hipMemsetAsync(t.feedback.ptr, 0, t.frameBytes, m_stream), "feedback clear")) return false;
+      t.feedbackLinear = 1;
+      t.feedbackWrap = rcd::WRAP_EDGE;
+      *lostDraw = true;
+    }
+    rcd::Tex ft = passTexture(fp);
+    ft.base = t.feedback.ptr;
+    ft.frame_stride = 0;
+    ft.linear = t.feedbackLinear;
+    ft.wrap = t.feedbackWrap;
+    bind(*hit, ft);
+  }
   if (declares(k, "OrigTexture")) bind("OrigTexture", sourceTex);
   for (const auto& lt : m_preset.getTextures())  // std::map: by name
     if (m_textureReferences.count(lt.first)) bind(lt.first, lutTexture(lt.first));
@@ -553,6 +593,7 @@ void ShaderEngine::bindSamplers(size_t i, const KernelEntry& k, const rcd::Tex& 
     const int u = it == units.end() ? 0 : it->second;
     L->extra[s] = (u > 0 && u < (int)m_units.size()) ? m_units[(size_t)u] : inputTex;
   }
+  return true;
 }
 
 const void* ShaderEngine::applyShader(const void* input, uint32_t width, uint32_t height) {
@@ -616,7 +657,12 @@ const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames,
   // a preset whose first pass samples frame history is sequential: one frame per chunk, history
   // pushed after each (frames of a batch are successive frames)
   const bool history = presetSamplesHistory();
-  const uint32_t chunk = history ? 1u : std::min(m_chunk, nFrames);
+  const bool feedback = presetSamplesFeedback();
+  if (history && feedback) {
+    RC_LOG_ERROR("applyShader: a preset that samples both frame history and PassFeedback is not supported");
+    return inputs;
+  }
+  const uint32_t chunk = (history || feedback) ? 1u : std::min(m_chunk, nFrames);
   for (size_t i = 0; i + 1 < m_passes.size(); ++i)
     if (!ensureBuffer(m_passes[i].target, m_passes[i].frameBytes * chunk)) return inputs;
   ShaderPassData& lastPass = m_passes.back();
@@ -630,6 +676,19 @@ const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames,
     const uint8_t* in = static_cast<const uint8_t*>(inputs) + frameStride * f0;
     uint8_t* out = static_cast<uint8_t*>(lastPass.target.ptr) + lastPass.frameBytes * f0;
     if (!runChunk(in, frameStride, width, height, n, firstCount, out)) return inputs;
+    if (feedback) {
+      // ping-pong swap (:1710-1718): what this frame wrote becomes next frame's "previous"; the texture
+      // object that held it keeps the sampler state its consumer set on it
+      for (size_t pi = 0; pi < m_passes.size(); ++pi) {
+        ShaderPassData& fp = m_passes[pi];
+        if (!fp.feedbackEnabled || !fp.feedback.ptr) continue;
+        const rcd::Tex written = passTexture(pi);
+        if (pi + 1 == m_passes.size()) std::swap(fp.lastTarget, fp.feedback);
+        else std::swap(fp.target, fp.feedback);
+        fp.feedbackLinear = written.linear;
+        fp.feedbackWrap = written.wrap;
+      }
+    }
     if (history) {
       std::map<std::string, float> custom;
       {
@@ -758,6 +817,12 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
     ShaderPassData& pd = m_passes[i];
     const bool last = (i + 1 == m_passes.size());
     void* target = last ? finalOut : pd.target.ptr;
+    if (last && pd.feedbackEnabled) {
+      // the last pass ping-pongs too: it renders into its own buffer, copied to the output below
+      if (!ensureBuffer(pd.lastTarget, pd.frameBytes * nFrames)) return false;
+      target = pd.lastTarget.ptr;
+    }
+    pd.lastWritten = target;
     if (!pd.kernel) {
       // A pass without a program is skipped after its target was cleared to (0,0,0,0); the
       // cleared target is the next pass's input (:959-975).
@@ -778,7 +843,25 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
       L.frame_count0 = firstFrameCount;
       L.n_frames = (int)nFrames;
       const KernelEntry& k = *pd.kernel;
-      bindSamplers(i, k, current, sourceTex, &L);
+      bool lostDraw = false;
+      if (!bindSamplers(i, k, current, sourceTex, &L, &lostDraw)) return false;
+      if (last && pd.feedbackEnabled && target == finalOut) {  // became enabled during this very binding
+        if (!ensureBuffer(pd.lastTarget, pd.frameBytes * nFrames)) return false;
+        target = pd.lastTarget.ptr;
+        pd.lastWritten = target;
+        L.out = target;
+      }
+      if (lostDraw) {
+        // the target was cleared (:953-957) and the draw went to framebuffer 0
+        if (!hipOk(hipMemsetAsync(target, 0, pd.frameBytes * nFrames, m_stream), "clear")) return false;
+        if (last && target != finalOut &&
+            !hipOk(hipMemcpyAsync(finalOut, target, pd.frameBytes * nFrames, hipMemcpyDeviceToDevice, m_stream), "copy"))
+          return false;
+        rcd::Tex nextLost = passTexture(i);
+        nextLost.base = target;
+        current = nextLost;
+        continue;
+      }
       for (size_t q = 0; q < k.params.size() && q < (size_t)rcd::kMaxParams; ++q) {
         L.params[q] = effectiveParameter(pd, k.params[q], custom);
       }
@@ -825,6 +908,9 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
         m_timed.push_back(tl);
       }
     }
+    if (last && target != finalOut &&
+        !hipOk(hipMemcpyAsync(finalOut, target, pd.frameBytes * nFrames, hipMemcpyDeviceToDevice, m_stream), "copy"))
+      return false;
     // this pass's output becomes the next pass's input
     rcd::Tex next = passTexture(i);
     next.base = target;
@@ -885,8 +971,8 @@ bool ShaderEngine::readPass(size_t i, uint32_t frame, void* host, size_t bytes) 
     index = frame - m_lastChunkFirst;
   }
   if (!hipOk(hipStreamSynchronize(m_stream), "sync")) return false;
-  return hipOk(hipMemcpy(host, static_cast<const uint8_t*>(pd.target.ptr) + pd.frameBytes * index, pd.frameBytes,
-                         hipMemcpyDeviceToHost),
+  const void* base = (!last && pd.lastWritten) ? pd.lastWritten : pd.target.ptr;
+  return hipOk(hipMemcpy(host, static_cast<const uint8_t*>(base) + pd.frameBytes * index, pd.frameBytes, hipMemcpyDeviceToHost),
                "readPass");
 }
 

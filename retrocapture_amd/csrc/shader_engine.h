@@ -39,6 +39,13 @@ struct ShaderPassData {  // reference ShaderEngine.h:19-40
   int format = rcd::FMT_RGBA8;
   DeviceBuffer target;      // [chunk or batch][height][width] texels
   DeviceBuffer scratch;     // kernel-private scratch, [chunk] frames (KernelEntry::scratch_bytes)
+  // PassFeedback ping-pong (reference ShaderEngine.h feedbackTexture / feedbackFramebuffer, .cpp:1285-1347,
+  // :1710-1718): the previous frame's output of this pass, allocated when a program first asks for it
+  DeviceBuffer feedback;
+  bool feedbackEnabled = false;
+  int feedbackLinear = 1, feedbackWrap = rcd::WRAP_EDGE;  // sampler state of the partner texture object
+  DeviceBuffer lastTarget;  // last pass only, when it takes part in feedback: its own render target
+  const void* lastWritten = nullptr;  // where the most recent chunk of this pass was rendered
   size_t frameBytes = 0;
   std::map<std::string, float> extractedParameters;
   std::map<std::string, ShaderParameterInfo> parameterInfo;
@@ -189,8 +196,11 @@ class ShaderEngine {
   rcd::Tex lutTexture(const std::string& name) const;
   // Emulates the reference's sampler binding of pass i (:1095-1415): same order, same texture-unit
   // numbering; fills L.extra for the kernel's declared samplers.
-  void bindSamplers(size_t passIndex, const KernelEntry& k, const rcd::Tex& inputTex, const rcd::Tex& sourceTex,
-                    rcd::PassLaunch* L);
+  // Returns false on a device error.  *lostDraw: a feedback partner was created during this binding,
+  // which in the reference leaves framebuffer 0 bound - the pass's draw misses its (cleared) target.
+  bool bindSamplers(size_t passIndex, const KernelEntry& k, const rcd::Tex& inputTex, const rcd::Tex& sourceTex,
+                    rcd::PassLaunch* L, bool* lostDraw);
+  bool presetSamplesFeedback() const;
   rcd::Tex passTexture(size_t passIndex) const;
   bool runChunk(const void* inputs, uint64_t inStride, uint32_t width, uint32_t height, uint32_t nFrames,
                 int firstFrameCount, void* finalOut);

@@ -30,6 +30,10 @@ scale_y1 = 1.0
     "xbr-lv3": ("xbr/xbr-lv3.glslp", 'shaders = 1\n\nshader0 = shaders/xbr-lv3.glsl\nfilter_linear0 = false\n'),
     # same keys / values as the reference's motionblur/mix_frames.glslp
     "mix-frames": ("motionblur/mix_frames.glslp", 'shaders = "1"\n\nshader0 = "shaders/mix_frames.glsl"\nfilter_linear0 = "false"\n'),
+    # PassFeedback conformance preset: the stock shader, then this repository's fixture shader
+    "feedback-persist": ("feedback-persist.glslp",
+                         'shaders = 2\nshader0 = stock.glsl\nfilter_linear0 = false\nscale_type0 = source\n'
+                         'shader1 = conformance/feedback-persist.glsl\nfilter_linear1 = true\n'),
     "stock": ("stock.glslp", 'shaders = "1"\nshader0 = "stock.glsl"\nfilter_linear0 = "false"\n'),
     # Same keys / values as the reference's crt/crt-royale.glslp for the 12 passes, including the
     # three `"true" # comment` booleans that its parser reads as false; only the LUT that the
@@ -149,6 +153,8 @@ SHADERS = {
         "samplers": []},
     # size_independent: reads no size uniform, so the history re-draw (which keeps pass 0's stale size
     # uniforms, reference ShaderEngine.cpp:1805-1834) is well defined for any geometry
+    "conformance/feedback-persist.glsl": {"oracle": "feedback_persist", "params": [("PERSIST", 0.8)],
+                                          "samplers": ["PassFeedback0", "PassFeedback1"]},
     "motionblur/shaders/mix_frames.glsl": {"oracle": "mix_frames", "params": [], "samplers": ["PrevTexture"],
                                            "size_independent": True},
     "ntsc/shaders/ntsc-pass1-svideo-3phase.glsl": {"oracle": "ntsc_pass1_svideo_3phase", "params": [], "samplers": []},

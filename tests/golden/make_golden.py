@@ -232,7 +232,20 @@ def case_mix_frames():
     run_case("mix_frames_48x36_to_120x90_f9", GLSL + "/motionblur/mix_frames.glslp", moving(48, 36, 9, 21), 120, 90)
 
 
-CASES = {"mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+def case_feedback():
+    # PassFeedback (reference ShaderEngine.cpp:1285-1347, swap :1710-1718): no shader in the reference's
+    # tree declares it, so the engine semantics are pinned with a fixture shader of this repository
+    # (tests/fixtures/conformance/feedback-persist.glsl) as pass 1 behind the reference's stock.glsl.
+    fixture = os.path.join(ROOT, "tests", "fixtures", "conformance", "feedback-persist.glsl")
+    with tempfile.TemporaryDirectory() as d:
+        p = write_preset(d, 'shaders = 2\nshader0 = %s/stock.glsl\nfilter_linear0 = false\nscale_type0 = source\n'
+                            'shader1 = %s\nfilter_linear1 = true\n' % (GLSL, fixture))
+        run_case("feedback_persist_64x40_to_64x40_f1", p, moving(64, 40, 1, 30), 64, 40)
+        run_case("feedback_persist_64x40_to_64x40_f2", p, moving(64, 40, 2, 30), 64, 40)
+        run_case("feedback_persist_64x40_to_150x90_f5", p, moving(64, 40, 5, 31), 150, 90, params=[("PERSIST", 0.6)])
+
+
+CASES = {"feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -56,6 +56,11 @@ class ChainState:
         self.units = {}            # unit -> Tex
         self.pass0_units = {}      # sampler name -> unit, as last set on pass 0's program
         self.frame_count = 0
+        # PassFeedback ping-pong (cpp:1285-1347, :1710-1718): per pass the partner texture (array or
+        # None), its sampler state, and whether any program asked for it
+        self.feedback = {}         # pass index -> array
+        self.feedback_state = {}   # pass index -> (linear, wrap)
+        self.feedback_enabled = set()
 
 
 def _history_tex(arr):
@@ -119,6 +124,24 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
                 al = passes[pp]["alias"]
                 if al and al in declared:
                     bind(al, tex_of_pass(pp))
+        lost_draw = False
+        for fp in range(i + 1):     # PassFeedback<fp>, cpp:1285-1347
+            name = next((n for n in ("PassFeedback%d" % fp, "PassFeedback%dTexture" % fp) if n in declared), None)
+            if name is None:
+                continue
+            if state is None:
+                raise ValueError("PassFeedback needs a ChainState")
+            state.feedback_enabled.add(fp)
+            if fp not in state.feedback:
+                # first sight: the partner texture is created now (zero-filled, creation sampler state).
+                # createFramebuffer leaves framebuffer 0 bound (cpp:2931), so THIS pass's draw misses its
+                # target, which keeps its clear colour (0,0,0,0)
+                fw, fh = sizes[fp]
+                state.feedback[fp] = np.zeros((fh, fw, 4), np.float32 if fmts[fp] == "f32" else np.uint8)
+                state.feedback_state[fp] = (True, "clamp_to_edge")
+                lost_draw = True
+            lin, wrap = state.feedback_state[fp]
+            bind(name, Tex(state.feedback[fp], fmts[fp], lin, wrap))
         if "OrigTexture" in declared:
             bind("OrigTexture", source_tex)
         for name in sorted(luts or {}):
@@ -141,9 +164,23 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
                     flags=flags)
         if i == 0:
             pass0_call = (spec, call)
-        o = run_pass(spec["oracle"], cur, ow, oh, out_fmt=fmts[i], extra=extra, **call)
+        if lost_draw:
+            o = np.zeros((oh, ow, 4), np.float32 if fmts[i] == "f32" else np.uint8)
+        else:
+            o = run_pass(spec["oracle"], cur, ow, oh, out_fmt=fmts[i], extra=extra, **call)
         outs.append(o)
         cur = tex_of_pass(i)
+    if state is not None and state.feedback_enabled:
+        # ping-pong swap (cpp:1710-1718): what was written becomes next frame's "previous"; the texture
+        # object keeps the sampler state its consumer set on it
+        for fp in sorted(state.feedback_enabled):
+            if fp in state.feedback:
+                nxt = passes[fp + 1] if fp + 1 < len(passes) else {"filter_linear": True, "wrap": "clamp_to_edge"}
+                state.feedback[fp] = outs[fp] if given is None else given[fp]
+                state.feedback_state[fp] = (nxt["filter_linear"], nxt["wrap"])
+        if any(n.startswith("Prev") or n.startswith("PassPrev0") for n in chain_specs.SHADERS[chain_specs.identity(passes[0]["shader"])]["samplers"]):
+            raise NotImplementedError("frame history together with PassFeedback")
+        return outs
     if state is not None:
         # history push (cpp:1735-1865): the final output drawn through pass 0's program - its sampler
         # uniforms as they stand, unit 0 = the final output, every other unit as the frame left it -

@@ -188,6 +188,33 @@ def test_ntsc_row_staged_and_general_forms_agree(w, h, vw, vh, preset_tree, rc_l
     e2.shutdown()
 
 
+@pytest.mark.parametrize("case", ["feedback_persist_64x40_to_64x40_f1", "feedback_persist_64x40_to_64x40_f2",
+                                  "feedback_persist_64x40_to_150x90_f5"])
+@pytest.mark.parametrize("as_batch", [False, True])
+def test_pass_feedback_matches_golden(case, as_batch, preset_tree, rc_lib):
+    """PassFeedback binding + ping-pong swap (fixture shader of this repository run on llvmpipe): the
+    frame that first creates a feedback texture loses the declaring pass's draw, later frames blend
+    with the previous frame's outputs of pass 0 and of the pass itself."""
+    from gpu_util import make_engine, run_engine
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    vw, vh = [int(v) for v in g["viewport"]]
+    frames = g["input_rgb"]
+    e = make_engine(preset_tree["feedback-persist"], vw, vh)
+    if "param_names" in g:
+        for name, v in zip(g["param_names"], g["param_values"]):
+            assert e.setShaderParameter(str(name), float(v))
+    if as_batch:
+        final = run_engine(e, frames)[-1]
+        last = frames.shape[0] - 1
+    else:
+        for f in range(frames.shape[0]):
+            final = run_engine(e, frames[f])[0]
+        last = 0
+    assert np.array_equal(final, g["pass1"])
+    assert np.array_equal(e.readPass(0, last), g["pass0"])
+    e.shutdown()
+
+
 def test_ntsc_full_size_batch(preset_tree, rc_lib):
     """BASELINE config 3 at full size: 1920x1080 source, 1024x1080 RGBA32F intermediate, 512x1080 output;
     a batch of 3 frames (FrameCount 1..3 drives the chroma phase), every byte against the oracle."""

@@ -19,6 +19,9 @@ CASES = {
     "crt_pi_80x60_to_250x190": "crt-pi",
     "crt_royale_160x120_to_320x240": "crt-royale",
     "crt_royale_128x96_to_400x300": "crt-royale",
+    "feedback_persist_64x40_to_64x40_f1": "feedback-persist",
+    "feedback_persist_64x40_to_64x40_f2": "feedback-persist",
+    "feedback_persist_64x40_to_150x90_f5": "feedback-persist",
     "mix_frames_72x40_to_72x40_f3": "mix-frames",
     "mix_frames_48x36_to_120x90_f9": "mix-frames",
     "ntsc_svideo_96x64_to_256x192": "ntsc-256px-svideo",
@@ -38,7 +41,7 @@ CASES = {
 # ~0.3 % of the bytes, because llvmpipe's sRGB encode runs through the x86 RSQRTPS
 # approximation and is not monotone ("sRGB8 store"); RGBA8 passes must be exact.
 BAR = {"scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1), "ntsc-256px-svideo": (1.0, 0),
-       "xbr-lv3": (1.0, 0), "mix-frames": (1.0, 0)}
+       "xbr-lv3": (1.0, 0), "mix-frames": (1.0, 0), "feedback-persist": (1.0, 0)}
 
 
 def royale_luts():
@@ -77,7 +80,20 @@ def test_oracle_frame_history_matches_llvmpipe(case, tmp_path, rc_lib):
         assert np.array_equal(hk, g["history%d" % k]), "history %d" % k
 
 
-@pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] != "mix-frames"))
+@pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] == "feedback-persist"))
+def test_oracle_pass_feedback_matches_llvmpipe(case, tmp_path, rc_lib):
+    """PassFeedback binding and ping-pong swap, pinned with this repository's fixture shader on
+    llvmpipe: the frame that first creates a feedback texture loses the declaring pass's draw."""
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    passes = preset_passes(tmp_path, CASES[case])
+    vw, vh = [int(v) for v in g["viewport"]]
+    custom = dict(zip([str(n) for n in g["param_names"]], [float(v) for v in g["param_values"]])) if "param_names" in g else None
+    outs, st = run_sequence(passes, g["input_rgb"], vw, vh, custom=custom)
+    for i in range(int(g["n_passes"])):
+        assert np.array_equal(outs[i], g["pass%d" % i]), "pass %d" % i
+
+
+@pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] not in ("mix-frames", "feedback-persist")))
 def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
     g = np.load(os.path.join(GOLD, case + ".npz"))
     key = CASES[case]

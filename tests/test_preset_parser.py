@@ -118,8 +118,11 @@ def test_quirk_expectations_come_from_the_reference(tmp_path):
 def test_pragma_parameters_of_config_shaders(rc_lib):
     from retrocapture_amd import engine
     import chain_specs
+    fixtures = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures")
     for ident, spec in chain_specs.SHADERS.items():
-        info = engine.shader_params(os.path.join(GLSL, ident))
+        # this repository's own conformance shaders live under tests/fixtures/, the rest in the reference tree
+        root = fixtures if ident.startswith("conformance/") else GLSL
+        info = engine.shader_params(os.path.join(root, ident))
         assert info["readable"], ident
         want = [n for n, _ in spec["params"]]
         assert [p["name"] for p in info["params"]] == want, ident
