@@ -303,6 +303,7 @@ int main(int argc, char** argv) {
   GLuint copy_fbo = 0;
   const size_t kMaxHistory = 7;
 
+  const bool force_f32 = getenv("GLCHAIN_F32") != nullptr;
   float frame_count = 0.f, time_s = 0.f;
   for (int f = 0; f < frames; ++f) {
     frame_count += 1.0f;  // ShaderEngine.cpp:1688-1689
@@ -334,10 +335,12 @@ int main(int argc, char** argv) {
         // createFramebuffer: ShaderEngine.cpp:2872-2923
         GenTextures(1, &p.tex);
         BindTexture(GL_TEXTURE_2D, p.tex);
-        GLenum ifmt = pi.floatFramebuffer ? GL_RGBA32F : pi.srgbFramebuffer ? GL_SRGB8_ALPHA8 : (getenv("GLCHAIN_RGBA8") ? GL_RGBA8 : GL_RGBA);
+        // GLCHAIN_F32=1: every pass renders to RGBA32F, so that the shaders' arithmetic can be compared
+        // at float precision (8-bit targets hide last-bit differences); not the reference's formats
+        const bool f32 = pi.floatFramebuffer || force_f32;
+        GLenum ifmt = f32 ? GL_RGBA32F : pi.srgbFramebuffer ? GL_SRGB8_ALPHA8 : (getenv("GLCHAIN_RGBA8") ? GL_RGBA8 : GL_RGBA);
         if (getenv("GLCHAIN_NODITHER")) Disable(GL_DITHER);
-        TexImage2D(GL_TEXTURE_2D, 0, ifmt, ow, oh, 0, GL_RGBA,
-                   pi.floatFramebuffer ? GL_FLOAT : GL_UNSIGNED_BYTE, nullptr);
+        TexImage2D(GL_TEXTURE_2D, 0, ifmt, ow, oh, 0, GL_RGBA, f32 ? GL_FLOAT : GL_UNSIGNED_BYTE, nullptr);
         TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_LINEAR);
         TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_LINEAR);
         TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
@@ -353,7 +356,7 @@ int main(int argc, char** argv) {
         p.h = oh;
       }
       BindFramebuffer(GL_FRAMEBUFFER, p.fbo);
-      if (pi.srgbFramebuffer) Enable(GL_FRAMEBUFFER_SRGB);  // ShaderEngine.cpp:944-952
+      if (pi.srgbFramebuffer && !force_f32) Enable(GL_FRAMEBUFFER_SRGB);  // ShaderEngine.cpp:944-952
       else Disable(GL_FRAMEBUFFER_SRGB);
       Viewport(0, 0, ow, oh);
       ColorMask(1, 1, 1, 1);
@@ -651,7 +654,7 @@ int main(int argc, char** argv) {
     BindTexture(GL_TEXTURE_2D, p.written_tex ? p.written_tex : p.tex);
     std::string fn = out_dir + "/pass" + std::to_string(i) + ".bin";
     FILE* fo = fopen(fn.c_str(), "wb");
-    if (p.info.floatFramebuffer) {
+    if (p.info.floatFramebuffer || force_f32) {
       std::vector<float> d((size_t)p.w * p.h * 4);
       GetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, GL_FLOAT, d.data());
       fwrite(d.data(), 4, d.size(), fo);
@@ -663,7 +666,7 @@ int main(int argc, char** argv) {
     }
     fclose(fo);
     meta << "pass " << i << " " << p.w << " " << p.h << " "
-         << (p.info.floatFramebuffer ? "f32" : p.info.srgbFramebuffer ? "srgb8" : "rgba8") << " lin="
+         << ((p.info.floatFramebuffer || force_f32) ? "f32" : p.info.srgbFramebuffer ? "srgb8" : "rgba8") << " lin="
          << p.info.filterLinear << " wrap=" << p.info.wrapMode << " alias=" << p.info.alias
          << " shader=" << p.info.shaderPath << "\n";
     for (auto& kv : p.params) meta << "  param " << kv.first << " " << kv.second << "\n";

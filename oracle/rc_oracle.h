@@ -63,7 +63,7 @@ uint8_t o_store_srgb8(float x);
 typedef struct { float a0_lo, dx_lo, dy_lo, a0_up, dx_up, dy_up; } o_varying;
 o_varying o_varying_setup(float a_bl, float a_br, float a_tr, float a_tl, int W, int H, int out_fmt);
 static inline int o_lower_tri(int x, int y, int W, int H) {
-  return ((double)y + 0.5) * (double)W < ((double)x + 0.5) * (double)H;
+  return ((double)y + 0.5) * (double)W <= ((double)x + 0.5) * (double)H;
 }
 float o_varying_at(const o_varying* v, int x, int y, int lower);
 
@@ -116,8 +116,17 @@ void o_pass_royale_bloom_v(const o_pass_args* a);     /* P9  bloom-vertical */
 void o_pass_royale_bloom_h(const o_pass_args* a);     /* P10 bloom-horizontal-reconstitute; extra = PassPrev3, PassPrev2, PassPrev6 */
 void o_pass_royale_last(const o_pass_args* a);        /* P11 geometry-aa-last-pass; 44 params */
 /* ntsc/ntsc-256px-svideo.glslp (2 passes) and xbr/xbr-lv3.glslp (1 pass) */
+/* the ntsc family: ntsc-pass1-{svideo,composite}-{2,3}phase.glsl, ntsc-pass2-{2,3}phase{,-gamma,-linear}.glsl */
 void o_pass_ntsc_pass1_svideo_3phase(const o_pass_args* a);
+void o_pass_ntsc_pass1_composite_3phase(const o_pass_args* a);
+void o_pass_ntsc_pass1_svideo_2phase(const o_pass_args* a);
+void o_pass_ntsc_pass1_composite_2phase(const o_pass_args* a);
 void o_pass_ntsc_pass2_3phase_gamma(const o_pass_args* a);
+void o_pass_ntsc_pass2_3phase_linear(const o_pass_args* a);
+void o_pass_ntsc_pass2_3phase(const o_pass_args* a);
+void o_pass_ntsc_pass2_2phase_gamma(const o_pass_args* a);
+void o_pass_ntsc_pass2_2phase_linear(const o_pass_args* a);
+void o_pass_ntsc_pass2_2phase(const o_pass_args* a);
 void o_pass_xbr_lv3(const o_pass_args* a);            /* 5 params */
 void o_store_pixel(const o_pass_args* a, int x, int y, o_vec4 c);
 

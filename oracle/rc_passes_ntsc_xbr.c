@@ -15,7 +15,10 @@
 #include "rc_oracle.h"
 
 /* ------------------------------------------------------------------------- ntsc pass 1 -- */
-static void ntsc_pass1_body(const o_pass_args* a) {
+/* The four pass-1 files differ only in two #defines (lines 3-4): COMPOSITE / SVIDEO select the
+ * cross-talk matrix mix_mat (lines 15-25, 118-124), TWO_PHASE / THREE_PHASE the chroma phase
+ * (lines 150-155) and CHROMA_MOD_FREQ (lines 9-13). */
+static void ntsc_pass1_body(const o_pass_args* a, int composite, int two_phase) {
   const int W = a->out_w, H = a->out_h;
   const float tsx = (float)a->in->w, tsy = (float)a->in->h; /* TextureSize == InputSize */
   /* VS :69  pix_no = vTexCoord * SourceSize.xy * (outsize.xy / InputSize.xy) */
@@ -24,8 +27,10 @@ static void ntsc_pass1_body(const o_pass_args* a) {
   o_varying tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
   o_varying pu = o_varying_setup(0.f, px1, px1, 0.f, W, H, a->out_fmt);
   o_varying pv = o_varying_setup(0.f, 0.f, py1, py1, W, H, a->out_fmt);
-  const float k_phase = 0.6667f * 3.14159265f;    /* folded constant */
-  const float k_freq = 3.14159265f / 3.0f;        /* CHROMA_MOD_FREQ */
+  const float pi = 3.14159265f;
+  const float k_phase = two_phase ? pi : 0.6667f * pi;              /* folded constants */
+  const float k_freq = two_phase ? (4.0f * pi) / 15.0f : pi / 3.0f; /* CHROMA_MOD_FREQ */
+  const float period = two_phase ? 2.0f : 3.0f;
   const float fc = (float)a->frame_count;
   for (int y = a->y0; y < a->y1; ++y)
     for (int x = 0; x < W; ++x) {
@@ -37,36 +42,62 @@ static void ntsc_pass1_body(const o_pass_args* a) {
       float yy = col.x * 0.2989f + (col.y * 0.5870f + col.z * 0.1140f);
       float ii = col.x * 0.5959f + (col.y * -0.2744f + col.z * -0.3216f);
       float qq = col.x * 0.2115f + (col.y * -0.5229f + col.z * 0.3114f);
-      float m3 = pny - 3.0f * floorf(pny / 3.0f);
-      float chroma_phase = k_phase * (m3 + fc);
+      float m = pny - period * floorf(pny / period);
+      float chroma_phase = k_phase * (m + fc);
       float mod_phase = chroma_phase + pnx * k_freq;
       float i_mod = o_cos(mod_phase), q_mod = o_sin(mod_phase);
       ii *= i_mod; qq *= q_mod;           /* modulate */
-      ii *= 2.0f; qq *= 2.0f;             /* mix_mat = diag(1, 2, 2) for SVIDEO */
-      ii *= i_mod; qq *= q_mod;           /* demodulate */
-      o_vec4 o = {yy, ii, qq, 1.0f};
+      /* yiq *= mix_mat: a dot per column, x*c0 + (y*c1 + z*c2); the factors 1, 2 and 0 are exact */
+      float my, mi, mq;
+      /* (composite, first column (1,1,1): ii and qq are products, so the plain addend yy joins the
+       * pending multiply-add's addend first: (yy + ii) + qq, float goldens) */
+      if (composite) { my = (yy + qq) + ii; mi = yy + (ii * 2.0f + 0.0f); mq = yy + (0.0f + qq * 2.0f); }
+      else { my = yy; mi = ii * 2.0f; mq = qq * 2.0f; }
+      mi *= i_mod; mq *= q_mod;           /* demodulate */
+      o_vec4 o = {my, mi, mq, 1.0f};
       o_store_pixel(a, x, y, o);
     }
 }
-void o_pass_ntsc_pass1_svideo_3phase(const o_pass_args* a) {
-  unsigned csr = o_fp_enter();
-  ntsc_pass1_body(a);
-  o_fp_leave(csr);
-}
+#define NTSC_P1(NAME, C, T)                              \
+  void o_pass_ntsc_pass1_##NAME(const o_pass_args* a) {  \
+    unsigned csr = o_fp_enter();                         \
+    ntsc_pass1_body(a, C, T);                            \
+    o_fp_leave(csr);                                     \
+  }
+NTSC_P1(svideo_3phase, 0, 0)
+NTSC_P1(composite_3phase, 1, 0)
+NTSC_P1(svideo_2phase, 0, 1)
+NTSC_P1(composite_2phase, 1, 1)
 
 /* ------------------------------------------------------------------------- ntsc pass 2 -- */
-static const float k_luma[25] = {
+/* ntsc-pass2-{2,3}phase{,-gamma,-linear}.glsl: symmetric FIR of 2*TAPS+1 taps (3-phase: TAPS 24,
+ * tables :87-137; 2-phase: TAPS 32, tables :116-182), then YIQ->RGB and pow(rgb, 2.5/2.0) (-gamma),
+ * pow(rgb, 2.4) (-linear) or nothing. */
+static const float k_luma3[25] = {
     -0.000012020f, -0.000022146f, -0.000013155f, -0.000012020f, -0.000049979f, -0.000113940f, -0.000122150f,
     -0.000005612f, 0.000170516f,  0.000237199f,  0.000169640f,  0.000285688f,  0.000984574f,  0.002018683f,
     0.002002275f,  -0.000909882f, -0.007049081f, -0.013222860f, -0.012606931f, 0.002460860f,  0.035868225f,
     0.084016453f,  0.135563500f,  0.175261268f,  0.190176552f};
-static const float k_chroma[25] = {
+static const float k_chroma3[25] = {
     -0.000118847f, -0.000271306f, -0.000502642f, -0.000930833f, -0.001451013f, -0.002064744f, -0.002700432f,
     -0.003241276f, -0.003524948f, -0.003350284f, -0.002491729f, -0.000721149f, 0.002164659f,  0.006313635f,
     0.011789103f,  0.018545660f,  0.026414396f,  0.035100710f,  0.044196567f,  0.053207202f,  0.061590275f,
     0.068803602f,  0.074356193f,  0.077856564f,  0.079052396f};
+static const float k_luma2[33] = {
+    -0.000174844f, -0.000205844f, -0.000149453f, -0.000051693f, 0.000000000f,  -0.000066171f, -0.000245058f,
+    -0.000432928f, -0.000472644f, -0.000252236f, 0.000198929f,  0.000687058f,  0.000944112f,  0.000803467f,
+    0.000363199f,  0.000013422f,  0.000253402f,  0.001339461f,  0.002932972f,  0.003983485f,  0.00302668f,
+    -0.001102056f, -0.008373026f, -0.016897700f, -0.022914480f, -0.021642347f, -0.008863273f, 0.017271957f,
+    0.054921920f,  0.098342579f,  0.139044281f,  0.168055832f,  0.178571429f};
+static const float k_chroma2[33] = {
+    0.001384762f, 0.001678312f, 0.002021715f, 0.002420562f, 0.002880460f, 0.003406879f, 0.004004985f,
+    0.004679445f, 0.005434218f, 0.006272332f, 0.007195654f, 0.008204665f, 0.009298238f, 0.010473450f,
+    0.011725413f, 0.013047155f, 0.014429548f, 0.015861306f, 0.017329037f, 0.018817382f, 0.020309220f,
+    0.021785952f, 0.023227857f, 0.024614500f, 0.025925203f, 0.027139546f, 0.028237893f, 0.029201910f,
+    0.030015081f, 0.030663170f, 0.031134640f, 0.031420995f, 0.031517031f};
 
-static void ntsc_pass2_body(const o_pass_args* a) {
+/* epilogue: 0 plain, 1 gamma (2.5/2.0), 2 linear (2.4) */
+static void ntsc_pass2_body(const o_pass_args* a, int taps, const float* luma, const float* chroma, int epilogue) {
   const int W = a->out_w, H = a->out_h;
   const float tsx = (float)a->in->w;
   /* VS :48  TEX0.xy = TexCoord.xy - vec2(0.5 / SourceSize.x, 0.0) */
@@ -79,32 +110,44 @@ static void ntsc_pass2_body(const o_pass_args* a) {
       int lo = o_lower_tri(x, y, W, H);
       float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
       float sy = 0.f, si = 0.f, sq = 0.f;
-      for (int c = 1; c <= 24; ++c) {
-        float off = (float)(c - 25);
+      for (int c = 1; c <= taps; ++c) {
+        float off = (float)(c - 1 - taps);
         o_vec4 p = o_sample(a->in, u + off * one_x, v);
         o_vec4 n = o_sample(a->in, u + (-off) * one_x, v);
-        sy = sy + (p.x + n.x) * k_luma[c - 1];
-        si = si + (p.y + n.y) * k_chroma[c - 1];
-        sq = sq + (p.z + n.z) * k_chroma[c - 1];
+        sy = sy + (p.x + n.x) * luma[c - 1];
+        si = si + (p.y + n.y) * chroma[c - 1];
+        sq = sq + (p.z + n.z) * chroma[c - 1];
       }
       o_vec4 m = o_sample(a->in, u, v);
-      sy = sy + m.x * k_luma[24];
-      si = si + m.y * k_chroma[24];
-      sq = sq + m.z * k_chroma[24];
-      /* yiq2rgb: signal * yiq2rgb_mat */
-      float r = sy * 1.0f + (si * 0.956f + sq * 0.6210f);
-      float g = sy * 1.0f + (si * -0.2720f + sq * -0.6474f);
-      float b = sy * 1.0f + (si * -1.1060f + sq * 1.7046f);
-      const float gm = 2.5f / 2.0f;
-      o_vec4 o = {o_pow(r, gm), o_pow(g, gm), o_pow(b, gm), 1.0f};
+      sy = sy + m.x * luma[taps];
+      si = si + m.y * chroma[taps];
+      sq = sq + m.z * chroma[taps];
+      /* yiq2rgb: signal * yiq2rgb_mat = a dot per column, x*1.0 + (y*c1 + z*c2).  With the first
+       * factor 1.0 the plain addend x meets the pending multiply-add y*c1 + (z*c2) and is added to its
+       * addend first (see rc_passes_royale.c blur9): (x + z*c2) + y*c1 (float goldens) */
+      float r = (sy + sq * 0.6210f) + si * 0.956f;
+      float g = (sy + sq * -0.6474f) + si * -0.2720f;
+      float b = (sy + sq * 1.7046f) + si * -1.1060f;
+      o_vec4 o = {r, g, b, 1.0f};
+      if (epilogue) {
+        const float gm = epilogue == 1 ? 2.5f / 2.0f : 2.4f;
+        o.x = o_pow(r, gm); o.y = o_pow(g, gm); o.z = o_pow(b, gm);
+      }
       o_store_pixel(a, x, y, o);
     }
 }
-void o_pass_ntsc_pass2_3phase_gamma(const o_pass_args* a) {
-  unsigned csr = o_fp_enter();
-  ntsc_pass2_body(a);
-  o_fp_leave(csr);
-}
+#define NTSC_P2(NAME, TAPS, L, C, E)                     \
+  void o_pass_ntsc_pass2_##NAME(const o_pass_args* a) {  \
+    unsigned csr = o_fp_enter();                         \
+    ntsc_pass2_body(a, TAPS, L, C, E);                   \
+    o_fp_leave(csr);                                     \
+  }
+NTSC_P2(3phase_gamma, 24, k_luma3, k_chroma3, 1)
+NTSC_P2(3phase_linear, 24, k_luma3, k_chroma3, 2)
+NTSC_P2(3phase, 24, k_luma3, k_chroma3, 0)
+NTSC_P2(2phase_gamma, 32, k_luma2, k_chroma2, 1)
+NTSC_P2(2phase_linear, 32, k_luma2, k_chroma2, 2)
+NTSC_P2(2phase, 32, k_luma2, k_chroma2, 0)
 
 /* ----------------------------------------------------------------------------- xbr-lv3 -- */
 typedef struct { float v[4]; } f4;

@@ -215,7 +215,9 @@ static void blur9(const o_pass_args* a, int horizontal) {
   const float denom_inv = 0.5f / (sigma * sigma);
   const float w0 = 1.0f, w1 = const_exp(-1.0f * denom_inv), w2 = const_exp(-4.0f * denom_inv);
   const float w3 = const_exp(-9.0f * denom_inv), w4 = const_exp(-16.0f * denom_inv);
-  const float weight_sum_inv = 1.0f / (w0 + 2.0f * (w1 + w2 + w3 + w4));
+  /* the weights fold at compile time; the four-term sum is rebalanced by the GLSL compiler (measured:
+   * weight_sum_inv read back from the GL is 1/(1 + 2*((w1+w2)+(w3+w4)))) */
+  const float weight_sum_inv = 1.0f / (w0 + 2.0f * ((w1 + w2) + (w3 + w4)));
   const float w12 = w1 + w2, w34 = w3 + w4;
   const float w12_ratio = w2 / w12, w34_ratio = w4 / w34;
   const float k34 = 3.0f + w34_ratio, k12 = 1.0f + w12_ratio;
@@ -233,12 +235,15 @@ static void blur9(const o_pass_args* a, int horizontal) {
       o_vec4 s2 = o_sample(a->in, u, v);
       o_vec4 s3 = o_sample(a->in, u + k12 * dx, v + k12 * dy);
       o_vec4 s4 = o_sample(a->in, u + k34 * dx, v + k34 * dy);
-      v3 sum = {0.0f, 0.0f, 0.0f};
-      sum.x += w34 * s0.x; sum.y += w34 * s0.y; sum.z += w34 * s0.z;
-      sum.x += w12 * s1.x; sum.y += w12 * s1.y; sum.z += w12 * s1.z;
-      sum.x += w0 * s2.x; sum.y += w0 * s2.y; sum.z += w0 * s2.z;
-      sum.x += w12 * s3.x; sum.y += w12 * s3.y; sum.z += w12 * s3.z;
-      sum.x += w34 * s4.x; sum.y += w34 * s4.y; sum.z += w34 * s4.z;
+      /* sum = w34*s0 + w12*s1 + 1.0*s2 + w12*s3 + w34*s4 as the GL evaluates it: every "+ product" is
+       * fused to a multiply-add, a plain addend met by a pending multiply-add is added to ITS addend
+       * first (fadd(x, ffma(a,b,c)) -> ffma(a,b, x + c)), then the fused operations are split again:
+       * ((((A + s2) + B) + D) + E) - the only association of all 5-leaf trees that matches the float
+       * goldens */
+      v3 sum;
+      sum.x = (((w34 * s0.x + s2.x) + w12 * s1.x) + w12 * s3.x) + w34 * s4.x;
+      sum.y = (((w34 * s0.y + s2.y) + w12 * s1.y) + w12 * s3.y) + w34 * s4.y;
+      sum.z = (((w34 * s0.z + s2.z) + w12 * s1.z) + w12 * s3.z) + w34 * s4.z;
       o_vec4 o = {sum.x * weight_sum_inv, sum.y * weight_sum_inv, sum.z * weight_sum_inv, 1.0f};
       o_store_pixel(a, x, y, o);
     }
@@ -537,13 +542,20 @@ static blur17_w blur17_weights(float sigma) {
 static v3 blur17(const o_tex* t, float u, float v, float dx, float dy, const blur17_w* b) {
   const float ks[9] = {-b->k78, -b->k56, -b->k34, -b->k12, 0.0f, b->k12, b->k34, b->k56, b->k78};
   const float ws[9] = {b->w78, b->w56, b->w34, b->w12, b->w0, b->w12, b->w34, b->w56, b->w78};
-  v3 sum = {0.f, 0.f, 0.f};
+  /* the nine terms are added in source order, except that the centre term - weight 1.0, so a plain
+   * addend, not a product - is added before the product that precedes it (same mechanism as blur9:
+   * fadd(x, ffma(a,b,c)) -> ffma(a,b, x + c)): (((A+B)+C) + centre) + D, then + E + F + G + H */
+  o_vec4 smp[9];
   for (int i = 0; i < 9; ++i) {
-    o_vec4 s;
-    if (i < 4) s = o_sample(t, u - (-ks[i]) * dx, v - (-ks[i]) * dy);
-    else if (i == 4) s = o_sample(t, u, v);
-    else s = o_sample(t, u + ks[i] * dx, v + ks[i] * dy);
-    sum.x += ws[i] * s.x; sum.y += ws[i] * s.y; sum.z += ws[i] * s.z;
+    if (i < 4) smp[i] = o_sample(t, u - (-ks[i]) * dx, v - (-ks[i]) * dy);
+    else if (i == 4) smp[i] = o_sample(t, u, v);
+    else smp[i] = o_sample(t, u + ks[i] * dx, v + ks[i] * dy);
+  }
+  static const int order[9] = {0, 1, 2, 4, 3, 5, 6, 7, 8};
+  v3 sum = {0.f, 0.f, 0.f};
+  for (int j = 0; j < 9; ++j) {
+    const int i = order[j];
+    sum.x += ws[i] * smp[i].x; sum.y += ws[i] * smp[i].y; sum.z += ws[i] * smp[i].z;
   }
   v3 r = {sum.x * b->sum_inv, sum.y * b->sum_inv, sum.z * b->sum_inv};
   return r;
@@ -603,7 +615,7 @@ void o_pass_royale_bloom_h(const o_pass_args* a) {
         float dimpass = i3[c] - b3[c];
         float phosphor_bloom = (dimpass + bl[c]) * mask_amplify * undim * 1.0f;
         float diffusion_color = 1.0f * h3[c];
-        out[c] = phosphor_bloom * (1.0f - diffusion) + diffusion_color * diffusion; /* lerp, constant t */
+        out[c] = phosphor_bloom + diffusion * (diffusion_color - phosphor_bloom); /* lerp, run-time t */
       }
       o_vec4 o = {out[0], out[1], out[2], 1.0f};
       o_store_pixel(a, x, y, o);

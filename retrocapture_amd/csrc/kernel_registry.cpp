@@ -37,7 +37,7 @@ void setupNtscPass1(const PassGeometry& g, rcd::PassLaunch& L) {
 // True when the 49 taps of ntsc pass 2 form, for every target column, the consecutive source columns
 // c(x) - 24 .. c(x) + 24 with c(x + 1) = c(x) + 2 (evaluated with the kernel's own float operations on
 // the actual plane): then pass_ntsc.hip may stage one row segment per wave instead of fetching per tap.
-bool ntscTapsAreRegular(const PassGeometry& g, const rcd::PassLaunch& L) {
+bool ntscTapsAreRegular(const PassGeometry& g, const rcd::PassLaunch& L, int taps) {
   if (g.out_fmt != rcd::FMT_RGBA8) return false;  // one plane per varying only on the rectangle path
   const rcd::Plane &pu = L.plane[0], &pv = L.plane[1];
   if (pu.dy_lo != 0.0f || pv.dx_lo != 0.0f || pu.a0_lo != pu.a0_up || pu.dx_lo != pu.dx_up || pv.a0_lo != pv.a0_up ||
@@ -50,28 +50,30 @@ bool ntscTapsAreRegular(const PassGeometry& g, const rcd::PassLaunch& L) {
     const int c = hostNearest(u, g.in_w);
     if (x > 0 && c != prev + 2) return false;
     prev = c;
-    for (int k = 1; k <= 24; ++k) {
-      const float off = (float)(k - 25);
-      if (hostNearest(u + off * one_x, g.in_w) != c + (k - 25)) return false;
-      if (hostNearest(u + (-off) * one_x, g.in_w) != c - (k - 25)) return false;
+    for (int k = 1; k <= taps; ++k) {
+      const float off = (float)(k - 1 - taps);
+      if (hostNearest(u + off * one_x, g.in_w) != c + (k - 1 - taps)) return false;
+      if (hostNearest(u + (-off) * one_x, g.in_w) != c - (k - 1 - taps)) return false;
     }
   }
   return true;
 }
 
 // ntsc-pass2-3phase-gamma.glsl:48  TEX0.xy = TexCoord.xy - vec2(0.5 / SourceSize.x, 0.0)
-void setupNtscPass2(const PassGeometry& g, rcd::PassLaunch& L) {
+void setupNtscPass2Taps(const PassGeometry& g, rcd::PassLaunch& L, int taps) {
   const float sh = 0.5f / (float)g.in_w;
   L.plane[0] = makePlane(0.f - sh, 1.f - sh, 1.f - sh, 0.f - sh, g.out_w, g.out_h, g.out_fmt);
   L.plane[1] = planeV(1.0f, g.out_w, g.out_h, g.out_fmt);
-  static thread_local struct { int v[5]; bool ok; } memo = {{-1, -1, -1, -1, -1}, false};
-  const int key[5] = {g.in_w, g.in_h, g.out_w, g.out_h, g.out_fmt};
+  static thread_local struct { int v[6]; bool ok; } memo = {{-1, -1, -1, -1, -1, -1}, false};
+  const int key[6] = {g.in_w, g.in_h, g.out_w, g.out_h, g.out_fmt, taps};
   if (std::memcmp(memo.v, key, sizeof(key)) != 0) {
     std::memcpy(memo.v, key, sizeof(key));
-    memo.ok = ntscTapsAreRegular(g, L);
+    memo.ok = ntscTapsAreRegular(g, L, taps);
   }
   if (memo.ok) L.flags |= rcd::RC_FLAG_NTSC_REGULAR;
 }
+void setupNtscPass2(const PassGeometry& g, rcd::PassLaunch& L) { setupNtscPass2Taps(g, L, 24); }
+void setupNtscPass2TwoPhase(const PassGeometry& g, rcd::PassLaunch& L) { setupNtscPass2Taps(g, L, 32); }
 
 // xbr-lv3's rule tests depend only on the 21-texel neighbourhood of the source pixel a target
 // pixel falls in, PROVIDED the five columns (rows) it samples through five separately
@@ -174,6 +176,23 @@ std::vector<KernelEntry> build() {
                rck::launch_ntsc_pass1, setupNtscPass1, false});
   r.push_back({"ntsc/shaders/ntsc-pass2-3phase-gamma.glsl", "ntsc-pass2-3phase-gamma", {}, {},
                rck::launch_ntsc_pass2, setupNtscPass2, true});
+  // the rest of the ntsc family (same kernels, other template arguments)
+  r.push_back({"ntsc/shaders/ntsc-pass1-composite-3phase.glsl", "ntsc-pass1-composite-3phase", {}, {},
+               rck::launch_ntsc_pass1_composite_3phase, setupNtscPass1, false});
+  r.push_back({"ntsc/shaders/ntsc-pass1-svideo-2phase.glsl", "ntsc-pass1-svideo-2phase", {}, {},
+               rck::launch_ntsc_pass1_svideo_2phase, setupNtscPass1, false});
+  r.push_back({"ntsc/shaders/ntsc-pass1-composite-2phase.glsl", "ntsc-pass1-composite-2phase", {}, {},
+               rck::launch_ntsc_pass1_composite_2phase, setupNtscPass1, false});
+  r.push_back({"ntsc/shaders/ntsc-pass2-3phase-linear.glsl", "ntsc-pass2-3phase-linear", {}, {},
+               rck::launch_ntsc_pass2_3phase_linear, setupNtscPass2, true});
+  r.push_back({"ntsc/shaders/ntsc-pass2-3phase.glsl", "ntsc-pass2-3phase", {}, {}, rck::launch_ntsc_pass2_3phase_plain,
+               setupNtscPass2, true});
+  r.push_back({"ntsc/shaders/ntsc-pass2-2phase-gamma.glsl", "ntsc-pass2-2phase-gamma", {}, {},
+               rck::launch_ntsc_pass2_2phase_gamma, setupNtscPass2TwoPhase, true});
+  r.push_back({"ntsc/shaders/ntsc-pass2-2phase-linear.glsl", "ntsc-pass2-2phase-linear", {}, {},
+               rck::launch_ntsc_pass2_2phase_linear, setupNtscPass2TwoPhase, true});
+  r.push_back({"ntsc/shaders/ntsc-pass2-2phase.glsl", "ntsc-pass2-2phase", {}, {}, rck::launch_ntsc_pass2_2phase_plain,
+               setupNtscPass2TwoPhase, true});
   r.push_back({"xbr/shaders/xbr-lv3.glsl", "xbr-lv3",
                {{"XBR_Y_WEIGHT", 48.0f, 0.0f, 100.0f, 1.0f, "Y Weight"},
                 {"XBR_EQ_THRESHOLD", 10.0f, 0.0f, 50.0f, 1.0f, "EQ Threshold"},

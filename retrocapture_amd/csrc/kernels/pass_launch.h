@@ -16,6 +16,14 @@ hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s);
 hipError_t launch_mix_frames(const PassLaunch& L, hipStream_t s);
 hipError_t launch_ntsc_pass1(const PassLaunch& L, hipStream_t s);
 hipError_t launch_ntsc_pass2(const PassLaunch& L, hipStream_t s);
+hipError_t launch_ntsc_pass1_composite_3phase(const PassLaunch& L, hipStream_t s);
+hipError_t launch_ntsc_pass1_svideo_2phase(const PassLaunch& L, hipStream_t s);
+hipError_t launch_ntsc_pass1_composite_2phase(const PassLaunch& L, hipStream_t s);
+hipError_t launch_ntsc_pass2_3phase_linear(const PassLaunch& L, hipStream_t s);
+hipError_t launch_ntsc_pass2_3phase_plain(const PassLaunch& L, hipStream_t s);
+hipError_t launch_ntsc_pass2_2phase_gamma(const PassLaunch& L, hipStream_t s);
+hipError_t launch_ntsc_pass2_2phase_linear(const PassLaunch& L, hipStream_t s);
+hipError_t launch_ntsc_pass2_2phase_plain(const PassLaunch& L, hipStream_t s);
 hipError_t launch_xbr_lv3(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_first(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s);

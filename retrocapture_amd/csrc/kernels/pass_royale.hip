@@ -253,12 +253,13 @@ __global__ void __launch_bounds__(256) k_blur9(const PassLaunch L) {
   const float4 s2 = SI::get(L.in, img, u, v, &lds);
   const float4 s3 = SI::get(L.in, img, u + k12 * dx, v + k12 * dy, &lds);
   const float4 s4 = SI::get(L.in, img, u + k34 * dx, v + k34 * dy, &lds);
-  float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-  sx += w34 * s0.x; sy += w34 * s0.y; sz += w34 * s0.z;
-  sx += w12 * s1.x; sy += w12 * s1.y; sz += w12 * s1.z;
-  sx += 1.0f * s2.x; sy += 1.0f * s2.y; sz += 1.0f * s2.z;
-  sx += w12 * s3.x; sy += w12 * s3.y; sz += w12 * s3.z;
-  sx += w34 * s4.x; sy += w34 * s4.y; sz += w34 * s4.z;
+  // w34*s0 + w12*s1 + 1.0*s2 + w12*s3 + w34*s4 as the GL evaluates it: the centre term is a plain
+  // addend (weight 1.0) and joins the running sum BEFORE the product that precedes it - the GL's
+  // compiler rewrites fadd(x, ffma(a,b,c)) to ffma(a,b, x + c) - measured on float render targets:
+  // ((((A + s2) + B) + D) + E) is the only association of all 5-leaf trees that matches
+  const float sx = (((w34 * s0.x + s2.x) + w12 * s1.x) + w12 * s3.x) + w34 * s4.x;
+  const float sy = (((w34 * s0.y + s2.y) + w12 * s1.y) + w12 * s3.y) + w34 * s4.y;
+  const float sz = (((w34 * s0.z + s2.z) + w12 * s1.z) + w12 * s3.z) + w34 * s4.z;
   SO::put(L, z, x, y, make_float4(sx * sum_inv, sy * sum_inv, sz * sum_inv, 1.0f), &lds);
   RC_TILE_LOOP_END
 }
@@ -427,15 +428,19 @@ __device__ __forceinline__ float4 blur17(const Tex& t, const uint8_t* img, float
                                         const SrgbLds* lds) {
   const float k[4] = {P[RPG_K78], P[RPG_K56], P[RPG_K34], P[RPG_K12]};
   const float w[4] = {P[RPG_W78], P[RPG_W56], P[RPG_W34], P[RPG_W12]};
+  // source order, except that the centre term (weight 1.0: a plain addend) is added before the
+  // product that precedes it, as in k_blur9: (((A+B)+C) + centre) + D, then the four right-hand taps
   float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 3; ++i) {
     const float4 s = SI::get(t, img, u - k[i] * dx, v - k[i] * dy, lds);
     sx += w[i] * s.x; sy += w[i] * s.y; sz += w[i] * s.z;
   }
   {
+    const float4 d = SI::get(t, img, u - k[3] * dx, v - k[3] * dy, lds);
     const float4 s = SI::get(t, img, u, v, lds);
     sx += 1.0f * s.x; sy += 1.0f * s.y; sz += 1.0f * s.z;
+    sx += w[3] * d.x; sy += w[3] * d.y; sz += w[3] * d.z;
   }
 #pragma unroll
   for (int i = 3; i >= 0; --i) {
@@ -478,7 +483,7 @@ __global__ void __launch_bounds__(256, 4) k_royale_bloom_h(const PassLaunch L) {
     const float dimpass = i3[c] - b3[c];
     const float phosphor_bloom = (dimpass + bl[c]) * mask_amplify * 2.0f * 1.0f;
     const float diffusion_color = 1.0f * h3[c];
-    out[c] = phosphor_bloom * (1.0f - 0.075f) + diffusion_color * 0.075f;
+    out[c] = phosphor_bloom + 0.075f * (diffusion_color - phosphor_bloom);  // lerp with a run-time weight (diffusion_weight is a uniform)
   }
   SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
   RC_TILE_LOOP_END

@@ -193,7 +193,9 @@ RC_HD float cos_(float x) { return sincos_<true>(x); }
 
 // ----------------------------------------------------------------------------- varyings ----
 __device__ __forceinline__ bool lower_tri(int x, int y, int W, int H) {
-  return (2 * y + 1) * W < (2 * x + 1) * H;  // pixel centre below the BL-TR diagonal
+  // pixel centre below the BL-TR diagonal; a centre exactly ON the diagonal belongs to the lower-right
+  // triangle (measured on float targets)
+  return (2 * y + 1) * W <= (2 * x + 1) * H;
 }
 __device__ __forceinline__ float vary(const Plane& p, int x, int y, bool lower) {
   float a0 = lower ? p.a0_lo : p.a0_up, dx = lower ? p.dx_lo : p.dx_up, dy = lower ? p.dy_lo : p.dy_up;

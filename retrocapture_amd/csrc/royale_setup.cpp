@@ -109,7 +109,8 @@ void setupBlur9(const PassGeometry& g, PassLaunch& L, bool horizontal) {
   L.params[RPB_W34] = w34;
   L.params[RPB_K12] = 1.0f + w2 / w12;
   L.params[RPB_K34] = 3.0f + w4 / w34;
-  L.params[RPB_SUM_INV] = 1.0f / (w0 + 2.0f * (w1 + w2 + w3 + w4));
+  // the GLSL compiler rebalances the four-term sum (value read back from the GL)
+  L.params[RPB_SUM_INV] = 1.0f / (w0 + 2.0f * ((w1 + w2) + (w3 + w4)));
   const float tsx = (float)g.in_w, tsy = (float)g.in_h;
   L.params[RPB_DX] = horizontal ? (tsx / (float)g.out_w) / tsx : 0.0f;
   L.params[RPB_DY] = horizontal ? 0.0f : (tsy / (float)g.out_h) / tsy;

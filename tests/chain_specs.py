@@ -2,6 +2,15 @@
 the description the oracle chain needs for each shader identity."""
 import os
 
+def _ntsc_preset(pass1, pass2, width):
+    """Same keys / values as the reference's ntsc/ntsc-{256,320}px*.glslp (their frame_count_mod0 line is
+    dropped by the reference parser, quirk Q2)."""
+    return ("shaders = 2\nshader0 = shaders/ntsc-pass1-%s.glsl\nshader1 = shaders/ntsc-pass2-%s.glsl\n"
+            "filter_linear0 = false\nfilter_linear1 = false\nscale_type_x0 = absolute\nscale_type_y0 = source\n"
+            "scale_x0 = %d\nscale_y0 = 1.0\nframe_count_mod0 = 2\nfloat_framebuffer0 = true\n"
+            "scale_type1 = source\nscale_x1 = 0.5\nscale_y1 = 1.0\n" % (pass1, pass2, width))
+
+
 # preset name -> (relative path below shaders_glsl/, text)
 PRESETS = {
     "scanline": ("scanlines/scanline.glslp",
@@ -27,6 +36,14 @@ scale_type1 = source
 scale_x1 = 0.5
 scale_y1 = 1.0
 """),
+    "ntsc-256px": ("ntsc/ntsc-256px.glslp", _ntsc_preset("composite-3phase", "3phase-gamma", 1024)),
+    "ntsc-320px": ("ntsc/ntsc-320px.glslp", _ntsc_preset("composite-2phase", "2phase-gamma", 1280)),
+    "ntsc-320px-svideo": ("ntsc/ntsc-320px-svideo.glslp", _ntsc_preset("svideo-2phase", "2phase-gamma", 1280)),
+    # synthesized: the -linear and plain pass-2 epilogues behind the shipped geometry
+    "ntsc-3phase-linear": ("ntsc/t-3phase-linear.glslp", _ntsc_preset("svideo-3phase", "3phase-linear", 1024)),
+    "ntsc-3phase-plain": ("ntsc/t-3phase-plain.glslp", _ntsc_preset("composite-3phase", "3phase", 1024)),
+    "ntsc-2phase-linear": ("ntsc/t-2phase-linear.glslp", _ntsc_preset("composite-2phase", "2phase-linear", 1280)),
+    "ntsc-2phase-plain": ("ntsc/t-2phase-plain.glslp", _ntsc_preset("svideo-2phase", "2phase", 1280)),
     "xbr-lv3": ("xbr/xbr-lv3.glslp", 'shaders = 1\n\nshader0 = shaders/xbr-lv3.glsl\nfilter_linear0 = false\n'),
     # same keys / values as the reference's motionblur/mix_frames.glslp
     "mix-frames": ("motionblur/mix_frames.glslp", 'shaders = "1"\n\nshader0 = "shaders/mix_frames.glsl"\nfilter_linear0 = "false"\n'),
@@ -157,8 +174,10 @@ SHADERS = {
                                           "samplers": ["PassFeedback0", "PassFeedback1"]},
     "motionblur/shaders/mix_frames.glsl": {"oracle": "mix_frames", "params": [], "samplers": ["PrevTexture"],
                                            "size_independent": True},
-    "ntsc/shaders/ntsc-pass1-svideo-3phase.glsl": {"oracle": "ntsc_pass1_svideo_3phase", "params": [], "samplers": []},
-    "ntsc/shaders/ntsc-pass2-3phase-gamma.glsl": {"oracle": "ntsc_pass2_3phase_gamma", "params": [], "samplers": []},
+    **{"ntsc/shaders/ntsc-pass1-%s.glsl" % n: {"oracle": "ntsc_pass1_" + n.replace("-", "_"), "params": [], "samplers": []}
+       for n in ("svideo-3phase", "composite-3phase", "svideo-2phase", "composite-2phase")},
+    **{"ntsc/shaders/ntsc-pass2-%s.glsl" % n: {"oracle": "ntsc_pass2_" + n.replace("-", "_"), "params": [], "samplers": []}
+       for n in ("3phase-gamma", "3phase-linear", "3phase", "2phase-gamma", "2phase-linear", "2phase")},
     "xbr/shaders/xbr-lv3.glsl": {
         "oracle": "xbr_lv3",
         "params": [("XBR_Y_WEIGHT", 48.0), ("XBR_EQ_THRESHOLD", 10.0), ("XBR_EQ_THRESHOLD2", 2.0),

@@ -57,7 +57,7 @@ def write_preset(d, text):
     return p
 
 
-def run_case(name, preset, rgb, vw, vh, frames=1, luts=(), params=()):
+def run_case(name, preset, rgb, vw, vh, frames=1, luts=(), params=(), f32=False):
     """rgb: (h, w, 3) applied `frames` times, or (frames, h, w, 3): a different source every frame."""
     if rgb.ndim == 4:
         frames = rgb.shape[0]
@@ -71,6 +71,10 @@ def run_case(name, preset, rgb, vw, vh, frames=1, luts=(), params=()):
         for k, v in params:
             cmd += ["--param", "%s=%g" % (k, v)]
         env = dict(os.environ, RETROCAPTURE_LOG_LEVEL="error")
+        if f32:
+            # every target RGBA32F: the stored values are the shaders' floats, so the oracle's arithmetic
+            # can be compared bit for bit (an 8-bit target hides last-bit differences)
+            env["GLCHAIN_F32"] = "1"
         r = subprocess.run(cmd, cwd=REF, env=env, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(r.stderr)
@@ -145,7 +149,7 @@ def case_crt_royale():
         run_case("crt_royale_128x96_to_400x300", GLSL + "/crt/crt-royale.glslp", noise(128, 96, 6), 400, 300, luts=luts)
 
 
-def case_crt_royale_mask_active():
+def case_crt_royale_mask_active(f32=False):
     """crt-royale as a GL driver that returns 0 for an unwritten varying would render it.
     Pass 6's fragment shader tests `max(tile_uv_wrap.x, tile_uv_wrap.y) <= mask_resize_num_tiles`
     on a varying its vertex shader never writes (the VS shadows it with a local).  Mesa llvmpipe
@@ -165,6 +169,10 @@ def case_crt_royale_mask_active():
         assert txt.count(needle) == 1
         open(f, "w").write(txt.replace(needle, "0.0 <= mask_resize_num_tiles"))
         luts = royale_luts(d)
+        if f32:
+            run_case("f32_crt_royale_maskon_64x48_to_128x96", dst + "/crt/crt-royale.glslp", mixed(64, 48, 5), 128, 96,
+                     luts=luts, f32=True)
+            return
         run_case("crt_royale_maskon_160x120_to_320x240", dst + "/crt/crt-royale.glslp", mixed(160, 120, 5), 320, 240,
                  luts=luts)
         run_case("crt_royale_maskon_96x128_to_512x384", dst + "/crt/crt-royale.glslp", noise(96, 128, 7), 512, 384,
@@ -177,6 +185,24 @@ def case_ntsc():
              frames=2)
     run_case("ntsc_svideo_120x50_to_301x117", GLSL + "/ntsc/ntsc-256px-svideo.glslp", noise(120, 50, 9), 301, 117,
              frames=3)
+
+
+def case_ntsc_family():
+    # the other members of the ntsc family: composite / 2-phase pass 1, 65-tap 2-phase pass 2, and the
+    # -linear / plain pass-2 epilogues (through synthesized two-pass presets with the shipped geometry)
+    run_case("ntsc_256px_composite_80x48_to_200x144", GLSL + "/ntsc/ntsc-256px.glslp", mixed(80, 48, 40), 200, 144, frames=2)
+    run_case("ntsc_320px_composite_72x40_to_320x120", GLSL + "/ntsc/ntsc-320px.glslp", mixed(72, 40, 41), 320, 120, frames=3)
+    run_case("ntsc_320px_svideo_64x36_to_161x77", GLSL + "/ntsc/ntsc-320px-svideo.glslp", noise(64, 36, 42), 161, 77)
+    with tempfile.TemporaryDirectory() as d:
+        for name, p1, p2, width in (("ntsc_3phase_linear", "svideo-3phase", "3phase-linear", 1024),
+                                    ("ntsc_3phase_plain", "composite-3phase", "3phase", 1024),
+                                    ("ntsc_2phase_linear", "composite-2phase", "2phase-linear", 1280),
+                                    ("ntsc_2phase_plain", "svideo-2phase", "2phase", 1280)):
+            p = write_preset(d, "shaders = 2\nshader0 = %s/ntsc/shaders/ntsc-pass1-%s.glsl\nshader1 = %s/ntsc/shaders/ntsc-pass2-%s.glsl\n"
+                                "filter_linear0 = false\nfilter_linear1 = false\nscale_type_x0 = absolute\nscale_type_y0 = source\n"
+                                "scale_x0 = %d\nscale_y0 = 1.0\nfloat_framebuffer0 = true\nscale_type1 = source\nscale_x1 = 0.5\nscale_y1 = 1.0\n"
+                             % (GLSL, p1, GLSL, p2, width))
+            run_case(name + "_56x30_to_140x66", p, mixed(56, 30, 43), 140, 66, frames=2)
 
 
 def pixel_art(w, h, seed):
@@ -245,7 +271,23 @@ def case_feedback():
         run_case("feedback_persist_64x40_to_150x90_f5", p, moving(64, 40, 5, 31), 150, 90, params=[("PERSIST", 0.6)])
 
 
-CASES = {"feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+def case_float():
+    """The same shaders with every render target forced to RGBA32F (not the reference's formats): pins
+    the arithmetic of every pass at float precision."""
+    with tempfile.TemporaryDirectory() as d:
+        p = write_preset(d, 'shaders = 1\nshader0 = %s/scanlines/shaders/scanline.glsl\n' % GLSL)
+        run_case("f32_scanline_64x48_to_160x100", p, mixed(64, 48, 2), 160, 100, f32=True)
+        run_case("f32_crt_pi_80x60_to_250x190", GLSL + "/crt/crt-pi.glslp", noise(80, 60, 4), 250, 190, f32=True)
+        run_case("f32_ntsc_svideo_96x64_to_256x192", GLSL + "/ntsc/ntsc-256px-svideo.glslp", mixed(96, 64, 8), 256, 192, frames=2, f32=True)
+        run_case("f32_ntsc_320px_72x40_to_320x120", GLSL + "/ntsc/ntsc-320px.glslp", mixed(72, 40, 41), 320, 120, f32=True)
+        run_case("f32_xbr_lv3_48x40_to_331x217", GLSL + "/xbr/xbr-lv3.glslp", pixel_art(48, 40, 11), 331, 217, f32=True)
+        run_case("f32_mix_frames_48x36_to_120x90_f3", GLSL + "/motionblur/mix_frames.glslp", moving(48, 36, 3, 21), 120, 90, f32=True)
+        luts = royale_luts(d)
+        run_case("f32_crt_royale_64x48_to_128x96", GLSL + "/crt/crt-royale.glslp", mixed(64, 48, 5), 128, 96, luts=luts, f32=True)
+    case_crt_royale_mask_active(f32=True)
+
+
+CASES = {"float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -68,17 +68,18 @@ def _history_tex(arr):
 
 
 def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global_params=None, flags=0,
-              given=None, state=None):
+              given=None, state=None, force_f32=False):
     """passes: list of dicts as produced by the preset dump (shader, filter_linear, wrap,
     alias, float_fb, srgb_fb, stx, sx, sty, sy).  rgb: (h, w, 3) uint8 source frame.
     luts: name -> (rgba array, linear, wrap).  given: optional list of per-pass arrays to feed forward
     instead of the oracle's own outputs (isolates each pass when checking against golden data).
     state: a ChainState carried from frame to frame (frame history); None = stateless.
+    force_f32: every pass target is RGBA32F (the float-precision goldens, not the reference's formats).
     Returns the list of per-pass outputs."""
     h, w, _ = rgb.shape
     src = np.concatenate([rgb, np.full((h, w, 1), 255, np.uint8)], -1)
     sizes = pass_sizes(passes, w, h, vw, vh)
-    fmts = ["f32" if p["float_fb"] else ("srgb8" if p["srgb_fb"] else "rgba8") for p in passes]
+    fmts = ["f32" if (p["float_fb"] or force_f32) else ("srgb8" if p["srgb_fb"] else "rgba8") for p in passes]
     outs = []
     units = state.units if state is not None else {}
 

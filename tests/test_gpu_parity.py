@@ -18,6 +18,13 @@ GOLDEN_CASES = {
     "crt_pi_80x60_to_250x190": "crt-pi",
     "ntsc_svideo_96x64_to_256x192": "ntsc-256px-svideo",        # BASELINE config 3, RGBA32F intermediate
     "ntsc_svideo_120x50_to_301x117": "ntsc-256px-svideo",
+    "ntsc_256px_composite_80x48_to_200x144": "ntsc-256px",     # the rest of the ntsc family
+    "ntsc_320px_composite_72x40_to_320x120": "ntsc-320px",
+    "ntsc_320px_svideo_64x36_to_161x77": "ntsc-320px-svideo",
+    "ntsc_3phase_linear_56x30_to_140x66": "ntsc-3phase-linear",
+    "ntsc_3phase_plain_56x30_to_140x66": "ntsc-3phase-plain",
+    "ntsc_2phase_linear_56x30_to_140x66": "ntsc-2phase-linear",
+    "ntsc_2phase_plain_56x30_to_140x66": "ntsc-2phase-plain",
     "xbr_lv3_64x56_to_256x224": "xbr-lv3",                      # BASELINE config 5
     "xbr_lv3_48x40_to_331x217": "xbr-lv3",
     "xbr_lv3_noise_40x36_to_240x216": "xbr-lv3",
@@ -129,6 +136,8 @@ def test_royale_interlaced_source_and_batch(preset_tree, rc_lib):
     ("crt-pi", 1, 1, 5, 3),             # minimum size
     ("stock", 40, 30, 80, 60),
     ("ntsc-256px-svideo", 70, 33, 140, 99),
+    ("ntsc-320px", 70, 33, 140, 99),
+    ("ntsc-2phase-plain", 31, 20, 60, 41),
     ("ntsc-256px-svideo", 1, 1, 3, 2),
     ("xbr-lv3", 37, 29, 259, 203),      # 7x, ragged
     ("xbr-lv3", 2, 2, 9, 7),
