@@ -514,7 +514,11 @@ void o_pass_royale_brightpass(const o_pass_args* a) {
         float pba = 1.0f * bl3[c];
         float max_area = maxps(pba - cw * intensity, 0.0f);
         float area_under = under * max_area;
-        float int_under = under * intensity;
+        /* bloom_underestimate_levels * (intensity_dim * undim * mask_amplify * levels_contrast): every
+         * factor but the sample is a compile-time constant in this file (no #pragma parameter, so
+         * PARAMETER_UNIFORM is undefined, brightpass.glsl ~2355), and the GL's compiler gathers constant
+         * factors of a product chain into one: in * (undim*mask_amplify*under) (float goldens) */
+        float int_under = in3[c] * ((undim * mask_amplify) * under);
         float ratio_temp = ((1.0f - area_under) / int_under - 1.0f) / (cw - 1.0f);
         float ratio = clampf(ratio_temp, 0.0f, 1.0f);
         out[c] = in3[c] * ratio; /* lerp(blur_ratio, 1, bloom_excess = 0) = blur_ratio */
@@ -613,9 +617,10 @@ void o_pass_royale_bloom_h(const o_pass_args* a) {
       float h3[3] = {hal.x, hal.y, hal.z}, out[3];
       for (int c = 0; c < 3; ++c) {
         float dimpass = i3[c] - b3[c];
-        float phosphor_bloom = (dimpass + bl[c]) * mask_amplify * undim * 1.0f;
-        float diffusion_color = 1.0f * h3[c];
-        out[c] = phosphor_bloom + diffusion * (diffusion_color - phosphor_bloom); /* lerp, run-time t */
+        /* lerp((dimpass + blurred) * mask_amplify * undim * contrast, contrast * halation, diffusion_weight):
+         * all parameters are compile-time constants here, the lerp is a*(1-t) + b*t and the constant
+         * factors of a*(1-t) are gathered into one: X * (mask_amplify*undim*(1-t)) + h * t (float goldens) */
+        out[c] = (dimpass + bl[c]) * ((mask_amplify * undim) * (1.0f - diffusion)) + h3[c] * diffusion;
       }
       o_vec4 o = {out[0], out[1], out[2], 1.0f};
       o_store_pixel(a, x, y, o);

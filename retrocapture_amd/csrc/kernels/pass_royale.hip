@@ -410,7 +410,9 @@ __global__ void __launch_bounds__(256) k_royale_brightpass(const PassLaunch L) {
       const float pba = 1.0f * bl3[c];
       const float max_area = maxps(pba - cw * intensity, 0.0f);
       const float area_under = 0.8f * max_area;
-      const float int_under = 0.8f * intensity;
+      // the GL's compiler gathers the constant factors of in*undim*mask_amplify*contrast*underestimate
+      // into one (all compile-time constants in this file): in * ((2*mask_amplify)*0.8)
+      const float int_under = in3[c] * ((2.0f * mask_amplify) * 0.8f);
       const float ratio_temp = ((1.0f - area_under) / int_under - 1.0f) / (cw - 1.0f);
       out[c] = in3[c] * clampf(ratio_temp, 0.0f, 1.0f);
     }
@@ -481,9 +483,9 @@ __global__ void __launch_bounds__(256, 4) k_royale_bloom_h(const PassLaunch L) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float dimpass = i3[c] - b3[c];
-    const float phosphor_bloom = (dimpass + bl[c]) * mask_amplify * 2.0f * 1.0f;
-    const float diffusion_color = 1.0f * h3[c];
-    out[c] = phosphor_bloom + 0.075f * (diffusion_color - phosphor_bloom);  // lerp with a run-time weight (diffusion_weight is a uniform)
+    // lerp(phosphor_bloom, diffusion_color, diffusion_weight) with compile-time parameters: a*(1-t) + b*t,
+    // the constant factors of a*(1-t) gathered into one by the GL's compiler (float goldens)
+    out[c] = (dimpass + bl[c]) * ((mask_amplify * 2.0f) * (1.0f - 0.075f)) + h3[c] * 0.075f;
   }
   SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
   RC_TILE_LOOP_END
