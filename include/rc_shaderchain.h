@@ -171,6 +171,29 @@ int rc_egress_rgb24(const void* d_rgba8, uint32_t width, uint32_t height, uint32
 /* bytes per frame of a pixel format (0 for an unknown one) */
 size_t rc_pixfmt_frame_bytes(int pixfmt, uint32_t width, uint32_t height);
 
+/* ---- host-to-host frame pipeline -----------------------------------------------------------
+ * The reference's per-frame path between a capture buffer and the encoder's RGB24 buffer:
+ * FrameProcessor upload (FrameProcessor.cpp:43-222) -> applyShader -> readback through double-
+ * buffered PBOs (PBOManager.cpp:86-170, FrameCapturePipeline.cpp:974-1084).  Here: a ring of `slots`
+ * (1..8) on three HIP streams (copy in / engine stream / copy out) linked by events, so the PCIe
+ * copies of neighbouring frames overlap the kernels.  submit() copies the caller's (unpinned) frame
+ * into pinned staging and queues H2D + rc_ingest + chain + rc_egress_rgb24 + D2H; receive() hands out
+ * the oldest finished frame (RGB24, row 0 first) in pipeline-owned pinned memory, valid until that
+ * slot is reused.  Frames return in submission order. */
+typedef struct rc_pipeline rc_pipeline;
+rc_pipeline* rc_pipeline_create(rc_engine* e, int slots);
+void rc_pipeline_destroy(rc_pipeline* p);
+/* RC_OK, RC_ERR_INVALID (bad arguments or no free slot: receive first) or RC_ERR_DEVICE */
+int rc_pipeline_submit(rc_pipeline* p, const void* host_frame, int pixfmt, uint32_t width, uint32_t height);
+/* RC_OK and *host_rgb24 / *width / *height; 1 if wait == 0 and the frame is not finished; < 0 on error
+ * or when nothing is in flight */
+int rc_pipeline_receive(rc_pipeline* p, const void** host_rgb24, uint32_t* width, uint32_t* height, int wait);
+/* Pinned staging memory of the slot the next submit will use (NULL if no slot is free): capture into
+ * it and pass the same pointer to rc_pipeline_submit to skip the host-side copy. */
+void* rc_pipeline_input_buffer(rc_pipeline* p, int pixfmt, uint32_t width, uint32_t height);
+int rc_pipeline_in_flight(rc_pipeline* p);
+void rc_pipeline_set_flip_y(rc_pipeline* p, int flip_y);
+
 /* Device self-test: the division shortcuts the kernels use (log2's mantissa division, the
  * safe-range division, constant divisors) against IEEE division on the device's own reciprocal
  * instruction: all 2^23 mantissas / 2^26 operand pairs / 6 x 2^24 quotients.  mismatches[0..2]

@@ -7,6 +7,7 @@
 
 #include "png_lut.h"
 #include "rc_log.h"
+#include "frame_pipeline.h"
 #include "shader_engine.h"
 
 struct rc_engine {
@@ -267,6 +268,36 @@ size_t rc_pixfmt_frame_bytes(int pixfmt, uint32_t width, uint32_t height) {
     case RC_PIX_YUYV422: return px * 2;
     default: return 0;
   }
+}
+struct rc_pipeline {
+  rc::FramePipeline impl;
+  rc_pipeline(rc::ShaderEngine* e, int slots) : impl(e, slots) {}
+};
+rc_pipeline* rc_pipeline_create(rc_engine* e, int slots) {
+  if (!e) return nullptr;
+  rc_pipeline* p = new rc_pipeline(&e->impl, slots);
+  if (!p->impl.ok()) {
+    delete p;
+    return nullptr;
+  }
+  return p;
+}
+void rc_pipeline_destroy(rc_pipeline* p) { delete p; }
+int rc_pipeline_submit(rc_pipeline* p, const void* host_frame, int pixfmt, uint32_t width, uint32_t height) {
+  if (!p || !host_frame) return RC_ERR_INVALID;
+  return p->impl.submit(host_frame, pixfmt, width, height) ? RC_OK : RC_ERR_INVALID;
+}
+int rc_pipeline_receive(rc_pipeline* p, const void** host_rgb24, uint32_t* width, uint32_t* height, int wait) {
+  if (!p || p->impl.inFlight() == 0) return RC_ERR_INVALID;
+  if (p->impl.receive(host_rgb24, width, height, wait != 0)) return RC_OK;
+  return wait ? RC_ERR_DEVICE : 1;
+}
+void* rc_pipeline_input_buffer(rc_pipeline* p, int pixfmt, uint32_t width, uint32_t height) {
+  return p ? p->impl.inputBuffer(pixfmt, width, height) : nullptr;
+}
+int rc_pipeline_in_flight(rc_pipeline* p) { return p ? p->impl.inFlight() : 0; }
+void rc_pipeline_set_flip_y(rc_pipeline* p, int flip_y) {
+  if (p) p->impl.setFlipY(flip_y != 0);
 }
 int rc_selftest_fastmath(int device, uint64_t mismatches[3]) {
   if (!mismatches) return RC_ERR_INVALID;

@@ -73,6 +73,13 @@ SYMBOLS = [
     ("rc_ingest", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("rc_egress_rgb24", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     ("rc_pixfmt_frame_bytes", C.c_size_t, [C.c_int, C.c_uint32, C.c_uint32]),
+    ("rc_pipeline_create", C.c_void_p, [C.c_void_p, C.c_int]),
+    ("rc_pipeline_destroy", None, [C.c_void_p]),
+    ("rc_pipeline_submit", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32]),
+    ("rc_pipeline_receive", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int]),
+    ("rc_pipeline_input_buffer", C.c_void_p, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32]),
+    ("rc_pipeline_in_flight", C.c_int, [C.c_void_p]),
+    ("rc_pipeline_set_flip_y", None, [C.c_void_p, C.c_int]),
     ("rc_selftest_fastmath", C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     ("rc_last_error", C.c_char_p, []),
     ("rc_version", C.c_char_p, []),
@@ -152,6 +159,59 @@ def egress_rgb24(src_rgba8, width, height, n_frames, dst_rgb24, flip_y=False, st
                                         C.c_void_p(stream) if stream else None)
     if rc != 0:
         raise RcError("rc_egress_rgb24 failed (%d)" % rc)
+
+
+class FramePipeline:
+    """Host-to-host frame path (upload, ingest, chain, egress, readback) pipelined over `slots` frames."""
+
+    def __init__(self, engine, slots=3):
+        self._lib = load_library()
+        self._engine = engine          # keeps the engine alive
+        self._h = self._lib.rc_pipeline_create(engine._need(), int(slots))
+        if not self._h:
+            raise RcError("rc_pipeline_create failed: " + self._lib.rc_last_error().decode())
+
+    def close(self):
+        if self._h:
+            self._lib.rc_pipeline_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, host_array, pixfmt, width, height):
+        """host_array: contiguous numpy uint8 array holding one frame.  False when every slot is busy."""
+        return self._lib.rc_pipeline_submit(self._h, host_array.ctypes.data, PIXFMT[pixfmt], width, height) == 0
+
+    def receive(self, wait=True):
+        """Oldest finished frame as an (h, w, 3) numpy view of pipeline-owned pinned memory (copy it if you
+        keep it past the next submits), or None."""
+        import numpy as np
+        ptr, w, h = C.c_void_p(), C.c_uint32(), C.c_uint32()
+        rc = self._lib.rc_pipeline_receive(self._h, C.byref(ptr), C.byref(w), C.byref(h), int(bool(wait)))
+        if rc != 0:
+            return None
+        buf = (C.c_uint8 * (w.value * h.value * 3)).from_address(ptr.value)
+        return np.frombuffer(buf, np.uint8).reshape(h.value, w.value, 3)
+
+    def inputBuffer(self, pixfmt, width, height):
+        """numpy view of the next slot's pinned staging memory (None if every slot is busy); fill it and
+        pass it to submit() to avoid the host-side copy."""
+        import numpy as np
+        ptr = self._lib.rc_pipeline_input_buffer(self._h, PIXFMT[pixfmt], width, height)
+        if not ptr:
+            return None
+        n = self._lib.rc_pixfmt_frame_bytes(PIXFMT[pixfmt], width, height)
+        return np.frombuffer((C.c_uint8 * n).from_address(ptr), np.uint8)
+
+    def inFlight(self):
+        return self._lib.rc_pipeline_in_flight(self._h)
+
+    def setFlipY(self, flip):
+        self._lib.rc_pipeline_set_flip_y(self._h, int(bool(flip)))
 
 
 def selftest_fastmath(device=0):

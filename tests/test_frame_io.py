@@ -100,3 +100,42 @@ def test_ingest_chain_egress_roundtrip(preset_tree, rc_lib):
     torch.cuda.synchronize()
     assert np.array_equal(d_out.cpu().numpy(), rgb)
     e.shutdown()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["rgb24", "bgra", "yuyv422"])
+def test_frame_pipeline_equals_direct_path(fmt, preset_tree, rc_lib):
+    """The pipelined host-to-host path (3 slots, 3 streams) returns, in order, exactly what ingest ->
+    chain -> egress gives frame by frame; crt-pi upscaling 2x, 7 frames through 3 slots."""
+    import torch
+    from gpu_util import make_engine
+    from retrocapture_amd import engine
+    w, h, vw, vh, n = 64, 48, 128, 96, 7
+    rng = np.random.default_rng(17)
+    frames = [rng.integers(0, 256, h * w * FMT[fmt][1], dtype=np.uint8) for _ in range(n)]
+    e = make_engine(preset_tree["crt-pi"], vw, vh)
+    want = []
+    d_rgba = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros(vh * vw * 3, dtype=torch.uint8, device="cuda")
+    for f in frames:
+        engine.ingest(torch.from_numpy(f).cuda(), fmt, w, h, 1, d_rgba)
+        ptr, ow, oh = e.applyShader(d_rgba, w, h)
+        engine.egress_rgb24(ptr, ow, oh, 1, d_out)
+        e.sync()
+        torch.cuda.synchronize()
+        want.append(d_out.cpu().numpy().reshape(oh, ow, 3).copy())
+    e2 = make_engine(preset_tree["crt-pi"], vw, vh)
+    pipe = engine.FramePipeline(e2, slots=3)
+    got = []
+    for f in frames:
+        while not pipe.submit(f, fmt, w, h):
+            got.append(pipe.receive(wait=True).copy())
+    while pipe.inFlight():
+        got.append(pipe.receive(wait=True).copy())
+    assert len(got) == n
+    for k in range(n):
+        assert np.array_equal(got[k], want[k]), "frame %d" % k
+    assert pipe.receive(wait=False) is None
+    pipe.close()
+    e.shutdown()
+    e2.shutdown()
