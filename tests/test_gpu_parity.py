@@ -422,3 +422,38 @@ def test_parameters_set_from_another_thread(preset_tree, rc_lib):
     for o in outs:                       # every frame used one of the two values, never a mixture
         assert np.array_equal(o, lo) or np.array_equal(o, hi)
     e.shutdown()
+
+
+_MATRIX_SHADERS = {"stock": "stock.glsl", "scanline": "scanlines/shaders/scanline.glsl", "crt-pi": "crt/shaders/crt-pi.glsl",
+                   "xbr": "xbr/shaders/xbr-lv3.glsl"}
+
+
+@pytest.mark.parametrize("shader", sorted(_MATRIX_SHADERS))
+@pytest.mark.parametrize("wrap", ["clamp_to_edge", "clamp_to_border", "repeat", "mirrored_repeat"])
+def test_sampler_state_and_target_format_matrix(shader, wrap, tmp_path, rc_lib):
+    """Every sampler state x target format reaches a kernel's general (run-time selected) form: a second
+    pass (stock) reads the first pass's target with filter / wrap under test, and the first pass's target
+    is RGBA8, sRGB8 or RGBA32F.  GPU == oracle for all of them."""
+    from gpu_util import make_engine, run_engine
+    from retrocapture_amd import engine as eng
+    root = tmp_path / "shaders_glsl"
+    root.mkdir()
+    rng = np.random.default_rng(len(shader) * 7 + len(wrap))
+    rgb = rng.integers(0, 256, (23, 31, 3), dtype=np.uint8)
+    for lin in ("false", "true"):
+        for fb in ("", "srgb_framebuffer0 = true\n", "float_framebuffer0 = true\n"):
+            text = ("shaders = 2\nshader0 = %s\nfilter_linear0 = %s\nwrap_mode0 = %s\nscale_type0 = source\nscale0 = 2.0\n%s"
+                    "shader1 = stock.glsl\nfilter_linear1 = %s\nwrap_mode1 = %s\n"
+                    % (_MATRIX_SHADERS[shader], lin, wrap, fb, lin, wrap))
+            p = root / ("m_%s_%s_%s.glslp" % (lin, wrap, "rgba8" if not fb else fb.split("_")[0]))
+            p.write_text(text)
+            passes = eng.preset_dump(str(p))["passes"]
+            want = run_chain(passes, rgb, 77, 51)
+            e = make_engine(str(p), 77, 51)
+            final = run_engine(e, rgb)
+            for i, o in enumerate(want):
+                got = e.readPass(i, 0)
+                same = got.view(np.uint32) == o.view(np.uint32) if o.dtype == np.float32 else got == o
+                assert same.all(), "%s pass %d: %d values differ" % (p.name, i, int((~same).sum()))
+            assert np.array_equal(final[0], want[-1])
+            e.shutdown()
