@@ -72,7 +72,9 @@ o_vec4 o_sample(const o_tex* t, float s, float v) {
     if (t->wrap == O_WRAP_REPEAT) { x = clampi(x, 0, t->w - 1); y = clampi(y, 0, t->h - 1); }
     return fetch_wrapped(t, x, y);
   }
-  int fixed = (t->fmt == O_FMT_RGBA8 || t->fmt == O_FMT_RGBX8) && t->wrap != O_WRAP_BORDER;
+  /* 8-bit fixed-point filter for RGBA8 / RGBX8 with clamp-to-edge or repeat; clamp-to-border and
+   * mirrored-repeat filter in float (measured: tests/golden/wrap_*, probes with random coordinates) */
+  int fixed = (t->fmt == O_FMT_RGBA8 || t->fmt == O_FMT_RGBX8) && t->wrap != O_WRAP_BORDER && t->wrap != O_WRAP_MIRROR;
   if (!fixed) {
     float u = linear_coord(s, t->w, t->wrap), w = linear_coord(v, t->h, t->wrap);
     float x0f = floorf(u), y0f = floorf(w);

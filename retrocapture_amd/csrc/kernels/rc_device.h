@@ -340,7 +340,9 @@ __device__ __forceinline__ float4 sample_linear_u8(const Tex& t, const uint8_t* 
 template <int FMT, int LINEAR, int WRAP>
 __device__ __forceinline__ float4 sample(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* lds) {
   if (!LINEAR) return sample_nearest<FMT, WRAP>(t, img, s, v, lds);
-  if ((FMT == FMT_RGBA8 || FMT == FMT_RGBX8) && WRAP != WRAP_BORDER) return sample_linear_u8<FMT, WRAP>(t, img, s, v);
+  // 8-bit fixed-point filter for RGBA8 / RGBX8 with clamp-to-edge or repeat; border and mirrored
+  // repeat filter in float (measured on the GL, tests/golden/wrap_*)
+  if ((FMT == FMT_RGBA8 || FMT == FMT_RGBX8) && WRAP != WRAP_BORDER && WRAP != WRAP_MIRROR) return sample_linear_u8<FMT, WRAP>(t, img, s, v);
   return sample_linear_f<FMT, WRAP>(t, img, s, v, lds);
 }
 

