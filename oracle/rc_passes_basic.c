@@ -35,9 +35,34 @@ void o_pass_stock(const o_pass_args* a) {
   o_pass_stock_body(a);
   o_fp_leave(csr);
 }
+/* llvmpipe executes a shader that only copies one RGBA8 texture to a plain RGBA8 target (clamp to
+ * edge) through its blit fast path (Mesa lp_linear_sampler.c), which steps the texture coordinate in
+ * 16.16 fixed point, re-anchored every 64 target pixels.  Measured on the GL (exact on every size
+ * tried, including ones full of samples that land exactly on texel boundaries such as 240 -> 1080):
+ *   D   = trunc(f32(d * T) * 65536)                       per-pixel step (d: plane slope, T: texture size)
+ *   S0  = trunc(f32(f32(f32(d * T) * j) + f32(a0 * T)) * 65536)   at the 64-pixel tile origin j
+ *   idx = clamp((S0 + (x - j) * D) >> 16, 0, T - 1)
+ * NEAREST only; the fast path's LINEAR filter is not restated (known gap). */
+static int blit_index(float a0, float d, int texsize, int x) {
+  const float T = (float)texsize, K = 65536.0f;
+  const float fd = d * T;
+  const int D = (int)(fd * K);
+  const int j = x & ~63;
+  const float s0 = fd * (float)j + a0 * T;
+  const int S0 = (int)(s0 * K);
+  int idx = (S0 + (x - j) * D) >> 16;
+  return idx < 0 ? 0 : (idx > texsize - 1 ? texsize - 1 : idx);
+}
+
 static void o_pass_stock_body(const o_pass_args* a) {
   const int W = a->out_w, H = a->out_h;
   o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  if (a->in->fmt == O_FMT_RGBA8 && !a->in->linear && a->in->wrap == O_WRAP_EDGE && a->out_fmt == O_FMT_RGBA8) {
+    for (int y = a->y0; y < a->y1; ++y)
+      for (int x = 0; x < W; ++x)
+        store_px(a, x, y, o_texel(a->in, blit_index(tu.a0_lo, tu.dx_lo, a->in->w, x), blit_index(tv.a0_lo, tv.dy_lo, a->in->h, y)));
+    return;
+  }
   for (int y = a->y0; y < a->y1; ++y)
     for (int x = 0; x < W; ++x) {
       int lo = o_lower_tri(x, y, W, H);

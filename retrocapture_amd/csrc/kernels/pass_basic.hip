@@ -11,6 +11,27 @@ using namespace rcd;
 
 namespace {
 
+// llvmpipe's blit fast path for a pure copy of an RGBA8 texture to a plain RGBA8 target with NEAREST
+// + clamp to edge: 16.16 fixed-point stepping of the texture coordinate, re-anchored every 64 target
+// pixels (formula measured on the GL, see oracle/rc_passes_basic.c blit_index).
+__device__ __forceinline__ int blit_index(float a0, float d, int texsize, int x) {
+  const float T = (float)texsize, K = 65536.0f;
+  const float fd = d * T;
+  const int D = (int)(fd * K);
+  const int j = x & ~63;
+  const float s0 = fd * (float)j + a0 * T;
+  const int S0 = (int)(s0 * K);
+  return clampi((S0 + (x - j) * D) >> 16, 0, texsize - 1);
+}
+__global__ void __launch_bounds__(256) k_stock_blit_nearest(const PassLaunch L) {
+  RC_TILE_LOOP_BEGIN
+  (void)lo;
+  const int sx = blit_index(L.plane[0].a0_lo, L.plane[0].dx_lo, L.in.w, x), sy = blit_index(L.plane[1].a0_lo, L.plane[1].dy_lo, L.in.h, y);
+  const uint32_t p = *reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z) + texel_off(L.in.w, sx, sy, 4u));
+  *reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z + texel_off(L.out_w, x, y, 4u)) = p;
+  RC_TILE_LOOP_END
+}
+
 __global__ void __launch_bounds__(256) k_stock(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
@@ -129,6 +150,10 @@ __global__ void __launch_bounds__(256) k_crt_pi(const PassLaunch L) {
 namespace rck {
 
 hipError_t launch_stock(const PassLaunch& L, hipStream_t s) {
+  if (L.in.fmt == FMT_RGBA8 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8) {
+    hipLaunchKernelGGL(k_stock_blit_nearest, px_grid(L), px_block(), 0, s, L);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_stock, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }

@@ -282,6 +282,11 @@ def case_sampler_matrix():
                                     "scale_type0 = source\nscale0 = 2.0\n%sshader1 = %s/stock.glsl\nfilter_linear1 = true\nwrap_mode1 = %s\n"
                                  % (GLSL, wrap, fb, GLSL, wrap))
                 run_case("wrap_%s_%s_40x30_to_97x71" % (wrap, tag), p, noise(40, 30, 50), 97, 71)
+        # llvmpipe's blit fast path: stock copying an RGBA8 target with NEAREST + clamp to edge, at a scale
+        # (4.5x) where every other sample row / column lands exactly on a texel boundary
+        p = write_preset(d, "shaders = 2\nshader0 = %s/crt/shaders/crt-pi.glsl\nfilter_linear0 = true\nscale_type0 = source\nscale0 = 2.0\n"
+                            "shader1 = %s/stock.glsl\nfilter_linear1 = false\nwrap_mode1 = clamp_to_edge\n" % (GLSL, GLSL))
+        run_case("blit_nearest_60x45_to_540x405", p, noise(60, 45, 51), 540, 405)
 
 
 def case_float():

@@ -482,3 +482,14 @@ def test_wrap_modes_match_llvmpipe_golden(wrap, tag, tmp_path, rc_lib):
         # end to end on the engine's own pass 0 (1 LSB off llvmpipe's non-monotone sRGB encode in ~0.3 %)
         assert d1.max() <= 2 and float((d1 == 0).mean()) >= 0.99
     e.shutdown()
+
+
+def test_blit_fast_path_nearest_matches_llvmpipe(tmp_path, rc_lib):
+    from gpu_util import make_engine, run_engine
+    from test_oracle_golden import blit_case_preset
+    g = np.load(os.path.join(GOLD, "blit_nearest_60x45_to_540x405.npz"))
+    e = make_engine(blit_case_preset(tmp_path), 540, 405)
+    final = run_engine(e, g["input_rgb"])
+    assert np.array_equal(e.readPass(0, 0), g["pass0"])
+    assert np.array_equal(final[0], g["pass1"])
+    e.shutdown()

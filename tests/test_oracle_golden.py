@@ -221,9 +221,29 @@ def test_oracle_wrap_modes_match_llvmpipe(case, tmp_path, rc_lib):
             assert d.max() <= 1 and float((d == 0).mean()) >= 0.995, "pass %d" % i
 
 
+def blit_case_preset(tmp_path):
+    root = tmp_path / "shaders_glsl"
+    root.mkdir(exist_ok=True)
+    p = root / "blit_nearest.glslp"
+    p.write_text("shaders = 2\nshader0 = crt/shaders/crt-pi.glsl\nfilter_linear0 = true\nscale_type0 = source\nscale0 = 2.0\n"
+                 "shader1 = stock.glsl\nfilter_linear1 = false\nwrap_mode1 = clamp_to_edge\n")
+    return str(p)
+
+
+def test_oracle_blit_fast_path_nearest(tmp_path, rc_lib):
+    """stock copying an RGBA8 target with NEAREST + clamp to edge goes through llvmpipe's blit fast path
+    (16.16 fixed-point coordinate stepping); at 4.5x every other sample sits exactly on a texel boundary."""
+    from retrocapture_amd import engine
+    g = np.load(os.path.join(GOLD, "blit_nearest_60x45_to_540x405.npz"))
+    passes = engine.preset_dump(blit_case_preset(tmp_path))["passes"]
+    outs = run_chain(passes, g["input_rgb"], 540, 405, given=[g["pass0"], g["pass1"]])
+    assert np.array_equal(outs[0], g["pass0"])
+    assert np.array_equal(outs[1], g["pass1"])
+
+
 def test_every_golden_file_has_a_case():
     names = {os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))} - {"llvmpipe_tables"}
     assert names <= set(CASES) | set(FLOAT_CASES) | set(WRAP_CASES) | EXTRA_GOLDEN
 
 
-EXTRA_GOLDEN = {"f32_mix_frames_48x36_to_120x90_f3"}
+EXTRA_GOLDEN = {"f32_mix_frames_48x36_to_120x90_f3", "blit_nearest_60x45_to_540x405"}
