@@ -42,25 +42,54 @@ void o_pass_stock(const o_pass_args* a) {
  *   D   = trunc(f32(d * T) * 65536)                       per-pixel step (d: plane slope, T: texture size)
  *   S0  = trunc(f32(f32(f32(d * T) * j) + f32(a0 * T)) * 65536)   at the 64-pixel tile origin j
  *   idx = clamp((S0 + (x - j) * D) >> 16, 0, T - 1)
- * NEAREST only; the fast path's LINEAR filter is not restated (known gap). */
-static int blit_index(float a0, float d, int texsize, int x) {
+ * LINEAR: the same coordinate minus half a texel (S - 32768); texel pair i = S >> 16 and i + 1 (clamped),
+ * weight w = (S >> 8) & 255, every lerp a + (((b - a) * w) >> 8) on bytes.  A 64x64 target tile whose
+ * samples need no clamping lerps horizontally first, then vertically; a tile that touches the texture
+ * edge does it the other way round (llvmpipe has a separate clamping fetch routine).  Fitted on the GL:
+ * 0 mismatches over 4.4e5 pixels of seven geometries. */
+static int blit_coord(float a0, float d, int texsize, int x) {
   const float T = (float)texsize, K = 65536.0f;
   const float fd = d * T;
   const int D = (int)(fd * K);
   const int j = x & ~63;
   const float s0 = fd * (float)j + a0 * T;
   const int S0 = (int)(s0 * K);
-  int idx = (S0 + (x - j) * D) >> 16;
-  return idx < 0 ? 0 : (idx > texsize - 1 ? texsize - 1 : idx);
+  return S0 + (x - j) * D;
+}
+static int clampidx(int i, int n) { return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); }
+static int blit_index(float a0, float d, int texsize, int x) { return clampidx(blit_coord(a0, d, texsize, x) >> 16, texsize); }
+static int lerp8(int a, int b, int w) { return a + (((b - a) * w) >> 8); }
+/* does the 64-pixel target tile holding x need clamping along this axis? */
+static int blit_tile_inside(float a0, float d, int texsize, int x, int extent) {
+  const int j = x & ~63, last = (j + 63 < extent - 1) ? j + 63 : extent - 1;   /* caller rounds the x extent up to 4: spans are 4 pixels wide */
+  const int lo = (blit_coord(a0, d, texsize, j) - 32768) >> 16, hi = (blit_coord(a0, d, texsize, last) - 32768) >> 16;
+  return lo >= 0 && hi + 1 <= texsize - 1;
 }
 
 static void o_pass_stock_body(const o_pass_args* a) {
   const int W = a->out_w, H = a->out_h;
   o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
-  if (a->in->fmt == O_FMT_RGBA8 && !a->in->linear && a->in->wrap == O_WRAP_EDGE && a->out_fmt == O_FMT_RGBA8) {
+  if (a->in->fmt == O_FMT_RGBA8 && a->in->wrap == O_WRAP_EDGE && a->out_fmt == O_FMT_RGBA8) {
+    const uint8_t* tex = (const uint8_t*)a->in->data;
+    const int TW = a->in->w, TH = a->in->h;
     for (int y = a->y0; y < a->y1; ++y)
-      for (int x = 0; x < W; ++x)
-        store_px(a, x, y, o_texel(a->in, blit_index(tu.a0_lo, tu.dx_lo, a->in->w, x), blit_index(tv.a0_lo, tv.dy_lo, a->in->h, y)));
+      for (int x = 0; x < W; ++x) {
+        uint8_t* dst = (uint8_t*)a->dst + ((size_t)y * W + x) * 4;
+        if (!a->in->linear) {
+          const uint8_t* t = tex + ((size_t)blit_index(tv.a0_lo, tv.dy_lo, TH, y) * TW + blit_index(tu.a0_lo, tu.dx_lo, TW, x)) * 4;
+          for (int c = 0; c < 4; ++c) dst[c] = t[c];
+          continue;
+        }
+        const int sx = blit_coord(tu.a0_lo, tu.dx_lo, TW, x) - 32768, sy = blit_coord(tv.a0_lo, tv.dy_lo, TH, y) - 32768;
+        const int x0 = clampidx(sx >> 16, TW), x1 = clampidx((sx >> 16) + 1, TW), wx = (sx >> 8) & 255;
+        const int y0 = clampidx(sy >> 16, TH), y1 = clampidx((sy >> 16) + 1, TH), wy = (sy >> 8) & 255;
+        const int inside = blit_tile_inside(tu.a0_lo, tu.dx_lo, TW, x, (W + 3) & ~3) && blit_tile_inside(tv.a0_lo, tv.dy_lo, TH, y, H);
+        for (int c = 0; c < 4; ++c) {
+          const int A = tex[((size_t)y0 * TW + x0) * 4 + c], B = tex[((size_t)y0 * TW + x1) * 4 + c];
+          const int Cc = tex[((size_t)y1 * TW + x0) * 4 + c], D = tex[((size_t)y1 * TW + x1) * 4 + c];
+          dst[c] = (uint8_t)(inside ? lerp8(lerp8(A, B, wx), lerp8(Cc, D, wx), wy) : lerp8(lerp8(A, Cc, wy), lerp8(B, D, wy), wx));
+        }
+      }
     return;
   }
   for (int y = a->y0; y < a->y1; ++y)

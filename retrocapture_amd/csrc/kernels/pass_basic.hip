@@ -11,24 +11,54 @@ using namespace rcd;
 
 namespace {
 
-// llvmpipe's blit fast path for a pure copy of an RGBA8 texture to a plain RGBA8 target with NEAREST
-// + clamp to edge: 16.16 fixed-point stepping of the texture coordinate, re-anchored every 64 target
-// pixels (formula measured on the GL, see oracle/rc_passes_basic.c blit_index).
-__device__ __forceinline__ int blit_index(float a0, float d, int texsize, int x) {
+// llvmpipe's blit fast path for a pure copy of an RGBA8 texture to a plain RGBA8 target with clamp to
+// edge: the texture coordinate is stepped in 16.16 fixed point, re-anchored every 64 target pixels;
+// LINEAR takes the texel pair and an 8-bit weight from the same coordinate minus half a texel, lerps
+// on bytes (a + (((b-a)*w) >> 8)), horizontally first in 64x64 target tiles that need no clamping and
+// vertically first in the others (formulas fitted on the GL, see oracle/rc_passes_basic.c).
+__device__ __forceinline__ int blit_coord(float a0, float d, int texsize, int x) {
   const float T = (float)texsize, K = 65536.0f;
   const float fd = d * T;
   const int D = (int)(fd * K);
   const int j = x & ~63;
   const float s0 = fd * (float)j + a0 * T;
   const int S0 = (int)(s0 * K);
-  return clampi((S0 + (x - j) * D) >> 16, 0, texsize - 1);
+  return S0 + (x - j) * D;
 }
-__global__ void __launch_bounds__(256) k_stock_blit_nearest(const PassLaunch L) {
+__device__ __forceinline__ bool blit_tile_inside(float a0, float d, int texsize, int x, int extent) {
+  const int j = x & ~63, last = min(j + 63, extent - 1);
+  const int lo = (blit_coord(a0, d, texsize, j) - 32768) >> 16, hi = (blit_coord(a0, d, texsize, last) - 32768) >> 16;
+  return lo >= 0 && hi + 1 <= texsize - 1;
+}
+__device__ __forceinline__ int lerp8(int a, int b, int w) { return a + (((b - a) * w) >> 8); }
+template <bool LINEAR>
+__global__ void __launch_bounds__(256) k_stock_blit(const PassLaunch L) {
   RC_TILE_LOOP_BEGIN
   (void)lo;
-  const int sx = blit_index(L.plane[0].a0_lo, L.plane[0].dx_lo, L.in.w, x), sy = blit_index(L.plane[1].a0_lo, L.plane[1].dy_lo, L.in.h, y);
-  const uint32_t p = *reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z) + texel_off(L.in.w, sx, sy, 4u));
-  *reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z + texel_off(L.out_w, x, y, 4u)) = p;
+  const uint8_t* img = frame_ptr(L.in, z);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z + texel_off(L.out_w, x, y, 4u));
+  const int cx = blit_coord(L.plane[0].a0_lo, L.plane[0].dx_lo, L.in.w, x), cy = blit_coord(L.plane[1].a0_lo, L.plane[1].dy_lo, L.in.h, y);
+  if (!LINEAR) {
+    *dst = *reinterpret_cast<const uint32_t*>(img + texel_off(L.in.w, clampi(cx >> 16, 0, L.in.w - 1), clampi(cy >> 16, 0, L.in.h - 1), 4u));
+    continue;
+  }
+  const int sx = cx - 32768, sy = cy - 32768;
+  const int x0 = clampi(sx >> 16, 0, L.in.w - 1), x1 = clampi((sx >> 16) + 1, 0, L.in.w - 1), wx = (sx >> 8) & 255;
+  const int y0 = clampi(sy >> 16, 0, L.in.h - 1), y1 = clampi((sy >> 16) + 1, 0, L.in.h - 1), wy = (sy >> 8) & 255;
+  const bool inside = blit_tile_inside(L.plane[0].a0_lo, L.plane[0].dx_lo, L.in.w, x, (L.out_w + 3) & ~3) &&   // spans are 4 px wide
+                      blit_tile_inside(L.plane[1].a0_lo, L.plane[1].dy_lo, L.in.h, y, L.out_h);
+  const uint32_t pa = *reinterpret_cast<const uint32_t*>(img + texel_off(L.in.w, x0, y0, 4u));
+  const uint32_t pb = *reinterpret_cast<const uint32_t*>(img + texel_off(L.in.w, x1, y0, 4u));
+  const uint32_t pc = *reinterpret_cast<const uint32_t*>(img + texel_off(L.in.w, x0, y1, 4u));
+  const uint32_t pd = *reinterpret_cast<const uint32_t*>(img + texel_off(L.in.w, x1, y1, 4u));
+  uint32_t o = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int A = (pa >> (8 * c)) & 255, B = (pb >> (8 * c)) & 255, Cc = (pc >> (8 * c)) & 255, D = (pd >> (8 * c)) & 255;
+    const int v = inside ? lerp8(lerp8(A, B, wx), lerp8(Cc, D, wx), wy) : lerp8(lerp8(A, Cc, wy), lerp8(B, D, wy), wx);
+    o |= (uint32_t)(v & 255) << (8 * c);
+  }
+  *dst = o;
   RC_TILE_LOOP_END
 }
 
@@ -150,8 +180,9 @@ __global__ void __launch_bounds__(256) k_crt_pi(const PassLaunch L) {
 namespace rck {
 
 hipError_t launch_stock(const PassLaunch& L, hipStream_t s) {
-  if (L.in.fmt == FMT_RGBA8 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8) {
-    hipLaunchKernelGGL(k_stock_blit_nearest, px_grid(L), px_block(), 0, s, L);
+  if (L.in.fmt == FMT_RGBA8 && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8) {
+    if (L.in.linear) hipLaunchKernelGGL(k_stock_blit<true>, px_grid(L), px_block(), 0, s, L);
+    else hipLaunchKernelGGL(k_stock_blit<false>, px_grid(L), px_block(), 0, s, L);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_stock, px_grid(L), px_block(), 0, s, L);

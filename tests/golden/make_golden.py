@@ -287,6 +287,12 @@ def case_sampler_matrix():
         p = write_preset(d, "shaders = 2\nshader0 = %s/crt/shaders/crt-pi.glsl\nfilter_linear0 = true\nscale_type0 = source\nscale0 = 2.0\n"
                             "shader1 = %s/stock.glsl\nfilter_linear1 = false\nwrap_mode1 = clamp_to_edge\n" % (GLSL, GLSL))
         run_case("blit_nearest_60x45_to_540x405", p, noise(60, 45, 51), 540, 405)
+        # ... and its LINEAR filter: several 64x64 target tiles (edge tiles lerp vertically first, inner
+        # tiles horizontally first), up- and down-scaled
+        p = write_preset(d, "shaders = 2\nshader0 = %s/crt/shaders/crt-pi.glsl\nfilter_linear0 = true\nscale_type0 = source\nscale0 = 2.0\n"
+                            "shader1 = %s/stock.glsl\nfilter_linear1 = true\nwrap_mode1 = clamp_to_edge\n" % (GLSL, GLSL))
+        run_case("blit_linear_60x45_to_540x405", p, noise(60, 45, 51), 540, 405)
+        run_case("blit_linear_160x120_to_233x150", p, noise(160, 120, 52), 233, 150)
 
 
 def case_float():

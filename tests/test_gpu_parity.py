@@ -463,8 +463,8 @@ def test_sampler_state_and_target_format_matrix(shader, wrap, tmp_path, rc_lib):
 @pytest.mark.parametrize("tag", ["rgba8", "srgb8"])
 def test_wrap_modes_match_llvmpipe_golden(wrap, tag, tmp_path, rc_lib):
     """All four wrap modes with LINEAR at chain level against llvmpipe (crt-pi then stock, both with the
-    wrap mode under test).  The one known gap - stock on a plain RGBA8 target with clamp-to-edge, llvmpipe's
-    blit fast path - is bounded instead of exact."""
+    wrap mode under test); stock on a plain RGBA8 target with clamp-to-edge goes through llvmpipe's blit
+    fast path, restated in k_stock_blit."""
     from gpu_util import make_engine, run_engine
     from test_oracle_golden import wrap_case_preset
     case = "wrap_%s_%s_40x30_to_97x71" % (wrap, tag)
@@ -476,7 +476,7 @@ def test_wrap_modes_match_llvmpipe_golden(wrap, tag, tmp_path, rc_lib):
     d1 = np.abs(final[0].astype(np.int32) - g["pass1"].astype(np.int32))
     if tag == "rgba8":
         assert d0.max() == 0
-        assert d1.max() == 0 if wrap != "clamp_to_edge" else d1.max() <= 4
+        assert d1.max() == 0      # clamp_to_edge: llvmpipe's blit fast path, restated
     else:
         assert d0.max() <= 1 and float((d0 == 0).mean()) >= 0.995
         # end to end on the engine's own pass 0 (1 LSB off llvmpipe's non-monotone sRGB encode in ~0.3 %)
@@ -484,11 +484,13 @@ def test_wrap_modes_match_llvmpipe_golden(wrap, tag, tmp_path, rc_lib):
     e.shutdown()
 
 
-def test_blit_fast_path_nearest_matches_llvmpipe(tmp_path, rc_lib):
+@pytest.mark.parametrize("case", ["blit_nearest_60x45_to_540x405", "blit_linear_60x45_to_540x405", "blit_linear_160x120_to_233x150"])
+def test_blit_fast_path_matches_llvmpipe(case, tmp_path, rc_lib):
     from gpu_util import make_engine, run_engine
-    from test_oracle_golden import blit_case_preset
-    g = np.load(os.path.join(GOLD, "blit_nearest_60x45_to_540x405.npz"))
-    e = make_engine(blit_case_preset(tmp_path), 540, 405)
+    from test_oracle_golden import blit_case_preset, BLIT_CASES
+    linear, vw, vh = BLIT_CASES[case]
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    e = make_engine(blit_case_preset(tmp_path, linear), vw, vh)
     final = run_engine(e, g["input_rgb"])
     assert np.array_equal(e.readPass(0, 0), g["pass0"])
     assert np.array_equal(final[0], g["pass1"])

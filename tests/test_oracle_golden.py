@@ -210,33 +210,35 @@ def test_oracle_wrap_modes_match_llvmpipe(case, tmp_path, rc_lib):
     outs = run_chain(passes, g["input_rgb"], vw, vh, given=golden)
     for i in range(2):
         d = np.abs(outs[i].astype(np.int32) - golden[i].astype(np.int32))
-        if case == "wrap_clamp_to_edge_rgba8_40x30_to_97x71" and i == 1:
-            # KNOWN GAP: a pure copy shader (stock.glsl) with RGBA8 source and target
-            # and clamp-to-edge takes llvmpipe's blit fast path (lp_linear), whose own fixed-point texture
-            # coordinate stepping and filter are not restated; LINEAR differs by a few levels there
-            assert d.max() <= 4
-        elif str(g["pass%d_fmt" % i]) == "rgba8":
+        if str(g["pass%d_fmt" % i]) == "rgba8":
             assert d.max() == 0, "pass %d: %d bytes differ" % (i, int((d != 0).sum()))
         else:   # sRGB8 store: llvmpipe's encode is not monotone
             assert d.max() <= 1 and float((d == 0).mean()) >= 0.995, "pass %d" % i
 
 
-def blit_case_preset(tmp_path):
+BLIT_CASES = {"blit_nearest_60x45_to_540x405": (False, 540, 405), "blit_linear_60x45_to_540x405": (True, 540, 405),
+              "blit_linear_160x120_to_233x150": (True, 233, 150)}
+
+
+def blit_case_preset(tmp_path, linear=False):
     root = tmp_path / "shaders_glsl"
     root.mkdir(exist_ok=True)
-    p = root / "blit_nearest.glslp"
+    p = root / ("blit_linear.glslp" if linear else "blit_nearest.glslp")
     p.write_text("shaders = 2\nshader0 = crt/shaders/crt-pi.glsl\nfilter_linear0 = true\nscale_type0 = source\nscale0 = 2.0\n"
-                 "shader1 = stock.glsl\nfilter_linear1 = false\nwrap_mode1 = clamp_to_edge\n")
+                 "shader1 = stock.glsl\nfilter_linear1 = %s\nwrap_mode1 = clamp_to_edge\n" % ("true" if linear else "false"))
     return str(p)
 
 
-def test_oracle_blit_fast_path_nearest(tmp_path, rc_lib):
-    """stock copying an RGBA8 target with NEAREST + clamp to edge goes through llvmpipe's blit fast path
-    (16.16 fixed-point coordinate stepping); at 4.5x every other sample sits exactly on a texel boundary."""
+@pytest.mark.parametrize("case", sorted(BLIT_CASES))
+def test_oracle_blit_fast_path(case, tmp_path, rc_lib):
+    """stock copying an RGBA8 target with clamp to edge goes through llvmpipe's blit fast path (16.16
+    fixed-point coordinate stepping, byte lerps); at 4.5x every other sample sits exactly on a texel
+    boundary."""
     from retrocapture_amd import engine
-    g = np.load(os.path.join(GOLD, "blit_nearest_60x45_to_540x405.npz"))
-    passes = engine.preset_dump(blit_case_preset(tmp_path))["passes"]
-    outs = run_chain(passes, g["input_rgb"], 540, 405, given=[g["pass0"], g["pass1"]])
+    linear, vw, vh = BLIT_CASES[case]
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    passes = engine.preset_dump(blit_case_preset(tmp_path, linear))["passes"]
+    outs = run_chain(passes, g["input_rgb"], vw, vh, given=[g["pass0"], g["pass1"]])
     assert np.array_equal(outs[0], g["pass0"])
     assert np.array_equal(outs[1], g["pass1"])
 
@@ -246,4 +248,4 @@ def test_every_golden_file_has_a_case():
     assert names <= set(CASES) | set(FLOAT_CASES) | set(WRAP_CASES) | EXTRA_GOLDEN
 
 
-EXTRA_GOLDEN = {"f32_mix_frames_48x36_to_120x90_f3", "blit_nearest_60x45_to_540x405"}
+EXTRA_GOLDEN = {"f32_mix_frames_48x36_to_120x90_f3"} | set(BLIT_CASES)
