@@ -99,6 +99,26 @@ def pmc_traffic(kernel_name, frames_per_launch):
     return None
 
 
+def copy_ceiling(torch, mib=1024, reps=20):
+    """Achieved stream-copy rate of this box (SURVEY.md section 8d asks for it beside the 8 TB/s vendor
+    peak): device-to-device copy of `mib` MiB, read + write bytes over the HIP-event time."""
+    n = mib << 20
+    a = torch.empty(n, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    a.fill_(7)
+    for _ in range(3):
+        b.copy_(a)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    t1.record()
+    torch.cuda.synchronize()
+    gbs = 2.0 * n * reps / (t0.elapsed_time(t1) * 1e-3) / 1e9
+    del a, b
+    return gbs
+
+
 def io_measurements(e, w, h, batch, reps):
     """Side measurements: (1) the ingest / egress kernels alone, algorithmic bytes / event time;
     (2) the whole host-to-host frame path the reference runs per frame (FrameProcessor upload ->
@@ -294,6 +314,7 @@ def main():
     chain_bytes = sum(q["read_bytes_per_frame"] + q["write_bytes_per_frame"] for q in prof)
 
     value = aggregate([args.batch] * world, args.steps, dt)
+    ceiling = copy_ceiling(torch)
     out = {
         # BASELINE.json's metric for the default workload; other --workload values are side measurements
         "metric": ("1080p frames/sec, crt-royale 12-pass, 1/2/4/8 MI355X; % HBM roofline" if wl == "crt-royale"
@@ -304,12 +325,15 @@ def main():
         "config": {"workload": desc, "frames_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
                    "chunk_frames": args.chunk or "default", "parallelism": "frames sharded, no collective",
                    "algorithmic_bytes_per_frame": chain_bytes,
-                   "hbm_roofline_frac_whole_chain": value / world * chain_bytes / (HBM_PEAK_GBS * 1e9)},
+                   "hbm_roofline_frac_whole_chain": value / world * chain_bytes / (HBM_PEAK_GBS * 1e9),
+                   "stream_copy_ceiling_GBs": ceiling,
+                   "copy_ceiling_frac_whole_chain": value / world * chain_bytes / (ceiling * 1e9)},
         "roofline": {"bound": "hbm", "kernel": infos[dom]["kernel"], "pass": dom, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(infos[dom]["kernel"], frames_per_launch),
                      "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch,
-                     "algorithmic_bytes_per_launch": bytes_per_launch},
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "frac_of_copy_ceiling": achieved / ceiling},
         "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in prof],
     }
     if args.io and rank == 0:

@@ -171,6 +171,43 @@ int rc_egress_rgb24(const void* d_rgba8, uint32_t width, uint32_t height, uint32
 /* bytes per frame of a pixel format (0 for an unknown one) */
 size_t rc_pixfmt_frame_bytes(int pixfmt, uint32_t width, uint32_t height);
 
+/* ---- OpenGLRenderer::renderTexture, off-screen ------------------------------------------------
+ * The reference draws one textured quad with a fixed program (reference
+ * src/renderer/OpenGLRenderer.cpp:378-470; program :141-158: rgb = (t.rgb * brightness - 0.5) * contrast
+ * + 0.5, alpha = t.a) in three places of the frame path; rc_present is that draw on device buffers:
+ *   pre-pass  NEAREST downscale to the logical capture size and overscan crop of the captured frame
+ *             into a GL_RGB target, through the viewport rc_overscan_viewport computes
+ *             (src/core/FrameCapturePipeline.cpp:160-250)          src_rgb 1, src_linear 0, RC_PRESENT_RGBX8
+ *   resize    shader output -> configured output resolution (:413-505)   src_linear 1, RC_PRESENT_RGBA8
+ *   bake      brightness / contrast into the frame for stream / recording (:739-804), same size
+ * `bake` != 0 runs a second draw (bake_brightness, bake_contrast) on the first one's RGBA8 result at the
+ * same size inside the same kernel - resize followed by bake as the reference chains them - and
+ * RC_PRESENT_RGB24 with out_flip_rows fuses the readback's alpha strip and row flip (:1060-1080).
+ * Source frames are RGBA8-sized (4 bytes per pixel; rc_ingest output or an engine output), n frames
+ * contiguous on both sides.  Target pixels outside the viewport receive `clear` (the reference clears
+ * to 0,0,0,0 before the resize and to 0,0,0,1 before the bake; its viewports always cover the target). */
+typedef enum { RC_PRESENT_RGBA8 = 0, RC_PRESENT_RGBX8 = 1, RC_PRESENT_RGB24 = 2 } rc_present_kind;
+typedef struct {
+  uint32_t src_w, src_h;
+  int src_rgb;               /* 1: GL_RGB source texture (alpha samples as 1.0) */
+  int src_linear;            /* the source texture's filter: 1 GL_LINEAR, 0 GL_NEAREST */
+  uint32_t dst_w, dst_h;
+  int dst_kind;              /* rc_present_kind */
+  int32_t vp_x, vp_y, vp_w, vp_h; /* glViewport; vp_w == 0: the whole target */
+  int flip_y;                /* the program's flipY uniform */
+  float brightness, contrast;
+  float clear[4];
+  int bake;
+  float bake_brightness, bake_contrast;
+  int out_flip_rows;         /* store rows bottom-up */
+} rc_present_desc;
+int rc_present(const void* d_src, void* d_dst, const rc_present_desc* desc, uint32_t n_frames, void* stream);
+/* bytes per frame of an rc_present target */
+size_t rc_present_frame_bytes(int dst_kind, uint32_t width, uint32_t height);
+/* glViewport of the pre-pass for an overscan crop of pct percent per side (clamped to 45):
+ * FrameCapturePipeline.cpp:205-216.  vp = x, y, w, h. */
+void rc_overscan_viewport(uint32_t fbo_w, uint32_t fbo_h, float pct_x, float pct_y, int32_t vp[4]);
+
 /* ---- host-to-host frame pipeline -----------------------------------------------------------
  * The reference's per-frame path between a capture buffer and the encoder's RGB24 buffer:
  * FrameProcessor upload (FrameProcessor.cpp:43-222) -> applyShader -> readback through double-
@@ -193,6 +230,14 @@ int rc_pipeline_receive(rc_pipeline* p, const void** host_rgb24, uint32_t* width
 void* rc_pipeline_input_buffer(rc_pipeline* p, int pixfmt, uint32_t width, uint32_t height);
 int rc_pipeline_in_flight(rc_pipeline* p);
 void rc_pipeline_set_flip_y(rc_pipeline* p, int flip_y);
+/* The frame path's optional stages either side of the chain, as FrameCapturePipeline applies them:
+ * source pre-pass (logical capture size smaller than the captured frame in both dimensions => NEAREST
+ * downscale; overscan percent per side > 0.001 => crop; FrameCapturePipeline.cpp:160-250; 0 = off),
+ * output resolution (:413-505; 0 = off) and image adjustments (:739-804; 1.0 = off).  They apply to
+ * frames submitted afterwards. */
+void rc_pipeline_set_source_prepass(rc_pipeline* p, uint32_t logical_w, uint32_t logical_h, float overscan_pct_x, float overscan_pct_y);
+void rc_pipeline_set_output_resolution(rc_pipeline* p, uint32_t width, uint32_t height);
+void rc_pipeline_set_image_adjust(rc_pipeline* p, float brightness, float contrast);
 
 /* Device self-test: the division shortcuts the kernels use (log2's mantissa division, the
  * safe-range division, constant divisors) against IEEE division on the device's own reciprocal

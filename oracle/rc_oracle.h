@@ -130,6 +130,21 @@ void o_pass_ntsc_pass2_2phase(const o_pass_args* a);
 void o_pass_xbr_lv3(const o_pass_args* a);            /* 5 params */
 void o_store_pixel(const o_pass_args* a, int x, int y, o_vec4 c);
 
+/* ---- OpenGLRenderer::renderTexture off-screen (rc_present.c) ------------------------------ */
+typedef struct {
+  const o_tex* src;      /* RGBX8 (captured frame, GL_RGB) or RGBA8 (shader output); wrap = edge */
+  int dst_w, dst_h;
+  int dst_fmt;           /* O_FMT_RGBX8 (GL_RGB target), O_FMT_RGBA8, O_FMT_F32 */
+  int vp_x, vp_y, vp_w, vp_h;
+  int flip_y;
+  float brightness, contrast;
+  o_vec4 clear;          /* what target pixels outside the viewport hold */
+  void* dst;
+} o_present_args;
+void o_present(const o_present_args* a);
+/* FrameCapturePipeline.cpp:205-216: the pre-pass viewport for an overscan crop, percent per side */
+void o_overscan_viewport(int fbo_w, int fbo_h, float pct_x, float pct_y, int vp[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "kernels/pass_launch.h"
+#include "present_setup.h"
 #include "rc_log.h"
 
 namespace rc {
@@ -48,6 +49,7 @@ FramePipeline::~FramePipeline() {
     if (s.hostOut) (void)hipHostFree(s.hostOut);
     if (s.devIn) (void)hipFree(s.devIn);
     if (s.devRgba) (void)hipFree(s.devRgba);
+    if (s.devPre) (void)hipFree(s.devPre);
     if (s.devOut) (void)hipFree(s.devOut);
     if (s.h2dDone) (void)hipEventDestroy(s.h2dDone);
     if (s.computeDone) (void)hipEventDestroy(s.computeDone);
@@ -81,15 +83,74 @@ bool FramePipeline::submit(const void* hostFrame, int pixfmt, uint32_t width, ui
       !hipOk(hipEventRecord(s.h2dDone, m_in), "event") || !hipOk(hipStreamWaitEvent(es, s.h2dDone, 0), "wait"))
     return false;
   if (!hipOk(rck::launch_ingest(s.devIn, pixfmt, width, height, 1, s.devRgba, es), "ingest")) return false;
-  const void* out = m_engine->applyShader(s.devRgba, width, height);
-  uint32_t ow = width, oh = height;
-  if (out != s.devRgba) {  // an inactive engine hands the input back (reference behaviour)
+  // source pre-pass (FrameCapturePipeline.cpp:160-250): only while a shader is active
+  const void* chainSrc = s.devRgba;
+  uint32_t cw = width, ch = height;
+  const bool needsOverscan = m_overscanX > 0.001f || m_overscanY > 0.001f;
+  const bool needsDownscale = m_logicalW > 0 && m_logicalH > 0 && m_logicalW < width && m_logicalH < height;
+  if (m_engine->isShaderActive() && (needsDownscale || needsOverscan)) {
+    PresentDesc d;
+    d.srcW = width;
+    d.srcH = height;
+    d.srcRgb = true;
+    d.srcLinear = false;   // the reference forces NEAREST on the source for this draw
+    d.dstW = needsDownscale ? m_logicalW : width;
+    d.dstH = needsDownscale ? m_logicalH : height;
+    d.dstKind = rck::PRESENT_RGBX8;
+    int vp[4];
+    overscanViewport(d.dstW, d.dstH, m_overscanX, m_overscanY, vp);
+    d.vpX = vp[0];
+    d.vpY = vp[1];
+    d.vpW = vp[2];
+    d.vpH = vp[3];
+    rck::PresentLaunch L;
+    if (!grow(&s.devPre, &s.devPreBytes, (size_t)d.dstW * d.dstH * 4, false) ||
+        !makePresentLaunch(d, s.devRgba, s.devPre, 1, &L) || !hipOk(rck::launch_present(L, es), "pre-pass"))
+      return false;
+    chainSrc = s.devPre;
+    cw = d.dstW;
+    ch = d.dstH;
+  }
+  const void* out = m_engine->applyShader(chainSrc, cw, ch);
+  uint32_t ow = cw, oh = ch;
+  const bool shaded = out != chainSrc;  // an inactive engine hands the input back (reference behaviour)
+  if (shaded) {
     ow = m_engine->getOutputWidth();
     oh = m_engine->getOutputHeight();
   }
-  const size_t outBytes = (size_t)ow * oh * 3;
+  // output resolution (:413-505) and image adjustments (:739-804), fused with the alpha strip
+  const bool resize = m_outW > 0 && m_outH > 0;
+  const bool adjust = m_brightness != 1.0f || m_contrast != 1.0f;
+  const uint32_t fw = resize ? m_outW : ow, fh = resize ? m_outH : oh;
+  const size_t outBytes = (size_t)fw * fh * 3;
   if (!grow(&s.devOut, &s.devOutBytes, outBytes, false) || !grow(&s.hostOut, &s.hostOutBytes, outBytes, true)) return false;
-  if (!hipOk(rck::launch_egress_rgb24(out, ow, oh, 1, m_flipY ? 1 : 0, s.devOut, es), "egress") ||
+  bool queued;
+  if (resize || adjust) {
+    PresentDesc d;
+    d.srcW = ow;
+    d.srcH = oh;
+    d.srcRgb = !shaded;      // the captured frame is a GL_RGB texture, NEAREST (FrameProcessor's default filter)
+    d.srcLinear = shaded;    // a render target's filter state as created (ShaderEngine.cpp:2896-2899)
+    d.dstW = fw;
+    d.dstH = fh;
+    d.dstKind = rck::PRESENT_RGB24;
+    d.outFlipRows = m_flipY;
+    if (resize) {
+      d.bake = adjust;
+      d.bakeBrightness = m_brightness;
+      d.bakeContrast = m_contrast;
+    } else {
+      d.brightness = m_brightness;
+      d.contrast = m_contrast;
+    }
+    rck::PresentLaunch L;
+    queued = makePresentLaunch(d, out, s.devOut, 1, &L) && hipOk(rck::launch_present(L, es), "present");
+  } else {
+    queued = hipOk(rck::launch_egress_rgb24(out, ow, oh, 1, m_flipY ? 1 : 0, s.devOut, es), "egress");
+  }
+  ow = fw;
+  oh = fh;
+  if (!queued ||
       !hipOk(hipEventRecord(s.computeDone, es), "event") || !hipOk(hipStreamWaitEvent(m_out, s.computeDone, 0), "wait") ||
       !hipOk(hipMemcpyAsync(s.hostOut, s.devOut, outBytes, hipMemcpyDeviceToHost, m_out), "D2H") ||
       !hipOk(hipEventRecord(s.d2hDone, m_out), "event"))

@@ -4,7 +4,8 @@
 // with its PBO double buffering (reference src/renderer/PBOManager.cpp:86-170, "lags one frame",
 // src/core/FrameCapturePipeline.cpp:974-1084) - as a ring of slots on three HIP streams:
 //   copy-in stream   pinned host frame  -> device        (hipMemcpyAsync H2D)
-//   engine stream    rc ingest kernel -> shader chain -> rc egress kernel
+//   engine stream    rc ingest kernel -> [source pre-pass] -> shader chain -> rc egress kernel
+//                    (or the fused resize / image-adjust / strip kernel, kernels/present.hip)
 //   copy-out stream  device RGB24 -> pinned host          (hipMemcpyAsync D2H)
 // linked by events, so the copies of frame n+1 / n-1 overlap the kernels of frame n.  Frames come
 // back in submission order.  Presets with frame history or PassFeedback stay correct: the engine
@@ -35,6 +36,23 @@ class FramePipeline {
   bool receive(const void** hostRgb24, uint32_t* width, uint32_t* height, bool wait);
   int inFlight() const { return m_inFlight; }
   void setFlipY(bool flip) { m_flipY = flip; }
+  // Optional stages of the reference's frame path (src/core/FrameCapturePipeline.cpp): NEAREST
+  // downscale to a logical capture size + overscan crop before the chain (:160-250), output
+  // resolution (:413-505) and brightness / contrast bake (:739-804) after it.
+  void setSourcePrepass(uint32_t logicalW, uint32_t logicalH, float overscanPctX, float overscanPctY) {
+    m_logicalW = logicalW;
+    m_logicalH = logicalH;
+    m_overscanX = overscanPctX;
+    m_overscanY = overscanPctY;
+  }
+  void setOutputResolution(uint32_t w, uint32_t h) {
+    m_outW = w;
+    m_outH = h;
+  }
+  void setImageAdjust(float brightness, float contrast) {
+    m_brightness = brightness;
+    m_contrast = contrast;
+  }
 
  private:
   struct Slot {
@@ -42,8 +60,9 @@ class FramePipeline {
     void* hostOut = nullptr;
     void* devIn = nullptr;
     void* devRgba = nullptr;
+    void* devPre = nullptr;   // pre-pass target (the chain's source when the pre-pass is on)
     void* devOut = nullptr;
-    size_t hostInBytes = 0, hostOutBytes = 0, devInBytes = 0, devRgbaBytes = 0, devOutBytes = 0;
+    size_t hostInBytes = 0, hostOutBytes = 0, devInBytes = 0, devRgbaBytes = 0, devPreBytes = 0, devOutBytes = 0;
     hipEvent_t h2dDone = nullptr, computeDone = nullptr, d2hDone = nullptr;
     uint32_t outW = 0, outH = 0;
   };
@@ -53,6 +72,8 @@ class FramePipeline {
   hipStream_t m_in = nullptr, m_out = nullptr;
   int m_head = 0, m_tail = 0, m_inFlight = 0;
   bool m_ok = false, m_flipY = false;
+  uint32_t m_logicalW = 0, m_logicalH = 0, m_outW = 0, m_outH = 0;
+  float m_overscanX = 0.0f, m_overscanY = 0.0f, m_brightness = 1.0f, m_contrast = 1.0f;
 };
 
 }  // namespace rc

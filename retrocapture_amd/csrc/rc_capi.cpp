@@ -8,6 +8,7 @@
 #include "png_lut.h"
 #include "rc_log.h"
 #include "frame_pipeline.h"
+#include "present_setup.h"
 #include "shader_engine.h"
 
 struct rc_engine {
@@ -259,6 +260,41 @@ int rc_egress_rgb24(const void* d_rgba8, uint32_t width, uint32_t height, uint32
   return rck::launch_egress_rgb24(d_rgba8, width, height, n_frames, flip_y, d_rgb24, static_cast<hipStream_t>(stream)) == hipSuccess
              ? RC_OK : RC_ERR_DEVICE;
 }
+int rc_present(const void* d_src, void* d_dst, const rc_present_desc* desc, uint32_t n_frames, void* stream) {
+  if (!d_src || !d_dst || !desc) return RC_ERR_INVALID;
+  rc::PresentDesc d;
+  d.srcW = desc->src_w;
+  d.srcH = desc->src_h;
+  d.srcRgb = desc->src_rgb != 0;
+  d.srcLinear = desc->src_linear != 0;
+  d.dstW = desc->dst_w;
+  d.dstH = desc->dst_h;
+  d.dstKind = desc->dst_kind;
+  d.vpX = desc->vp_x;
+  d.vpY = desc->vp_y;
+  d.vpW = desc->vp_w;
+  d.vpH = desc->vp_h;
+  d.flipY = desc->flip_y != 0;
+  d.brightness = desc->brightness;
+  d.contrast = desc->contrast;
+  for (int k = 0; k < 4; ++k) d.clear[k] = desc->clear[k];
+  d.bake = desc->bake != 0;
+  d.bakeBrightness = desc->bake_brightness;
+  d.bakeContrast = desc->bake_contrast;
+  d.outFlipRows = desc->out_flip_rows != 0;
+  rck::PresentLaunch L;
+  if (!rc::makePresentLaunch(d, d_src, d_dst, n_frames, &L)) return RC_ERR_INVALID;
+  return rck::launch_present(L, static_cast<hipStream_t>(stream)) == hipSuccess ? RC_OK : RC_ERR_DEVICE;
+}
+size_t rc_present_frame_bytes(int dst_kind, uint32_t width, uint32_t height) {
+  if (dst_kind < 0 || dst_kind > 2) return 0;
+  return (size_t)width * height * (dst_kind == RC_PRESENT_RGB24 ? 3 : 4);
+}
+void rc_overscan_viewport(uint32_t fbo_w, uint32_t fbo_h, float pct_x, float pct_y, int32_t vp[4]) {
+  int v[4];
+  rc::overscanViewport(fbo_w, fbo_h, pct_x, pct_y, v);
+  for (int k = 0; k < 4; ++k) vp[k] = v[k];
+}
 size_t rc_pixfmt_frame_bytes(int pixfmt, uint32_t width, uint32_t height) {
   const size_t px = (size_t)width * height;
   switch (pixfmt) {
@@ -298,6 +334,15 @@ void* rc_pipeline_input_buffer(rc_pipeline* p, int pixfmt, uint32_t width, uint3
 int rc_pipeline_in_flight(rc_pipeline* p) { return p ? p->impl.inFlight() : 0; }
 void rc_pipeline_set_flip_y(rc_pipeline* p, int flip_y) {
   if (p) p->impl.setFlipY(flip_y != 0);
+}
+void rc_pipeline_set_source_prepass(rc_pipeline* p, uint32_t logical_w, uint32_t logical_h, float overscan_pct_x, float overscan_pct_y) {
+  if (p) p->impl.setSourcePrepass(logical_w, logical_h, overscan_pct_x, overscan_pct_y);
+}
+void rc_pipeline_set_output_resolution(rc_pipeline* p, uint32_t width, uint32_t height) {
+  if (p) p->impl.setOutputResolution(width, height);
+}
+void rc_pipeline_set_image_adjust(rc_pipeline* p, float brightness, float contrast) {
+  if (p) p->impl.setImageAdjust(brightness, contrast);
 }
 int rc_selftest_fastmath(int device, uint64_t mismatches[3]) {
   if (!mismatches) return RC_ERR_INVALID;

@@ -28,6 +28,14 @@ class _RcPassInfo(C.Structure):
                 ("filter_linear", C.c_int), ("wrap", C.c_int), ("kernel", C.c_char * 48), ("alias", C.c_char * 48)]
 
 
+class _RcPresentDesc(C.Structure):
+    _fields_ = [("src_w", C.c_uint32), ("src_h", C.c_uint32), ("src_rgb", C.c_int), ("src_linear", C.c_int),
+                ("dst_w", C.c_uint32), ("dst_h", C.c_uint32), ("dst_kind", C.c_int),
+                ("vp_x", C.c_int32), ("vp_y", C.c_int32), ("vp_w", C.c_int32), ("vp_h", C.c_int32), ("flip_y", C.c_int),
+                ("brightness", C.c_float), ("contrast", C.c_float), ("clear", C.c_float * 4), ("bake", C.c_int),
+                ("bake_brightness", C.c_float), ("bake_contrast", C.c_float), ("out_flip_rows", C.c_int)]
+
+
 class _RcPassProfile(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("launches", C.c_uint64), ("frames", C.c_uint64),
                 ("read_bytes_per_frame", C.c_uint64), ("write_bytes_per_frame", C.c_uint64)]
@@ -73,6 +81,9 @@ SYMBOLS = [
     ("rc_ingest", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("rc_egress_rgb24", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     ("rc_pixfmt_frame_bytes", C.c_size_t, [C.c_int, C.c_uint32, C.c_uint32]),
+    ("rc_present", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_RcPresentDesc), C.c_uint32, C.c_void_p]),
+    ("rc_present_frame_bytes", C.c_size_t, [C.c_int, C.c_uint32, C.c_uint32]),
+    ("rc_overscan_viewport", None, [C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.POINTER(C.c_int32)]),
     ("rc_pipeline_create", C.c_void_p, [C.c_void_p, C.c_int]),
     ("rc_pipeline_destroy", None, [C.c_void_p]),
     ("rc_pipeline_submit", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32]),
@@ -80,6 +91,9 @@ SYMBOLS = [
     ("rc_pipeline_input_buffer", C.c_void_p, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32]),
     ("rc_pipeline_in_flight", C.c_int, [C.c_void_p]),
     ("rc_pipeline_set_flip_y", None, [C.c_void_p, C.c_int]),
+    ("rc_pipeline_set_source_prepass", None, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
+    ("rc_pipeline_set_output_resolution", None, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    ("rc_pipeline_set_image_adjust", None, [C.c_void_p, C.c_float, C.c_float]),
     ("rc_selftest_fastmath", C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     ("rc_last_error", C.c_char_p, []),
     ("rc_version", C.c_char_p, []),
@@ -161,6 +175,39 @@ def egress_rgb24(src_rgba8, width, height, n_frames, dst_rgb24, flip_y=False, st
         raise RcError("rc_egress_rgb24 failed (%d)" % rc)
 
 
+PRESENT_KIND = {"rgba8": 0, "rgbx8": 1, "rgb24": 2}
+
+
+def present(src, src_w, src_h, dst, dst_w, dst_h, n_frames=1, src_rgb=False, src_linear=True, dst_kind="rgba8",
+            viewport=None, flip_y=False, brightness=1.0, contrast=1.0, clear=(0.0, 0.0, 0.0, 0.0), bake=None,
+            out_flip_rows=False, stream=None):
+    """OpenGLRenderer::renderTexture off-screen (OpenGLRenderer.cpp:378-470) on device buffers: the source
+    pre-pass, the output-resolution resize and the brightness / contrast bake of FrameCapturePipeline.
+    bake = (brightness, contrast) of a second draw on the first one's result, fused."""
+    d = _RcPresentDesc()
+    d.src_w, d.src_h, d.src_rgb, d.src_linear = src_w, src_h, int(bool(src_rgb)), int(bool(src_linear))
+    d.dst_w, d.dst_h, d.dst_kind = dst_w, dst_h, PRESENT_KIND[dst_kind]
+    if viewport:
+        d.vp_x, d.vp_y, d.vp_w, d.vp_h = viewport
+    d.flip_y = int(bool(flip_y))
+    d.brightness, d.contrast = brightness, contrast
+    for k in range(4):
+        d.clear[k] = clear[k]
+    if bake:
+        d.bake, d.bake_brightness, d.bake_contrast = 1, bake[0], bake[1]
+    d.out_flip_rows = int(bool(out_flip_rows))
+    rc = load_library().rc_present(_ptr(src), _ptr(dst), C.byref(d), n_frames, C.c_void_p(stream) if stream else None)
+    if rc != 0:
+        raise RcError("rc_present failed (%d)" % rc)
+
+
+def overscan_viewport(fbo_w, fbo_h, pct_x, pct_y):
+    """glViewport (x, y, w, h) of the pre-pass for an overscan crop (FrameCapturePipeline.cpp:205-216).  No GPU needed."""
+    vp = (C.c_int32 * 4)()
+    load_library().rc_overscan_viewport(fbo_w, fbo_h, pct_x, pct_y, vp)
+    return tuple(vp)
+
+
 class FramePipeline:
     """Host-to-host frame path (upload, ingest, chain, egress, readback) pipelined over `slots` frames."""
 
@@ -212,6 +259,15 @@ class FramePipeline:
 
     def setFlipY(self, flip):
         self._lib.rc_pipeline_set_flip_y(self._h, int(bool(flip)))
+
+    def setSourcePrepass(self, logical_w=0, logical_h=0, overscan_pct_x=0.0, overscan_pct_y=0.0):
+        self._lib.rc_pipeline_set_source_prepass(self._h, logical_w, logical_h, overscan_pct_x, overscan_pct_y)
+
+    def setOutputResolution(self, width=0, height=0):
+        self._lib.rc_pipeline_set_output_resolution(self._h, width, height)
+
+    def setImageAdjust(self, brightness=1.0, contrast=1.0):
+        self._lib.rc_pipeline_set_image_adjust(self._h, brightness, contrast)
 
 
 def selftest_fastmath(device=0):

@@ -295,6 +295,76 @@ def case_sampler_matrix():
         run_case("blit_linear_160x120_to_233x150", p, noise(160, 120, 52), 233, 150)
 
 
+GLPRESENT = os.path.join(ROOT, "oracle", "_ref", "glpresent")
+
+
+def gl_present(src, filt, dw, dh, dfmt, vp=None, flip=0, b=1.0, c=1.0):
+    """One off-screen renderTexture draw on llvmpipe (oracle/glrun/glpresent.cpp)."""
+    sh, sw, ch = src.shape
+    vp = vp or (0, 0, dw, dh)
+    with tempfile.TemporaryDirectory() as d:
+        src.tofile(os.path.join(d, "in.raw"))
+        r = subprocess.run([GLPRESENT, os.path.join(d, "in.raw"), str(sw), str(sh), "rgb" if ch == 3 else "rgba", filt,
+                            str(dw), str(dh), dfmt] + [str(v) for v in vp] + [str(flip), repr(float(b)), repr(float(c))],
+                           capture_output=True)
+        if r.returncode or r.stderr:
+            raise RuntimeError(r.stderr.decode())
+    return np.frombuffer(r.stdout, np.float32 if dfmt == "f32" else np.uint8).reshape(dh, dw, 4).copy()
+
+
+def overscan_vp(fbo_w, fbo_h, pct_x, pct_y):
+    # FrameCapturePipeline.cpp:205-216 in float32
+    f = np.float32
+    ox = max(f(0), min(f(0.45), f(pct_x) / f(100))); oy = max(f(0), min(f(0.45), f(pct_y) / f(100)))
+    fx = f(1) - f(2) * ox; fy = f(1) - f(2) * oy
+    w = f(fbo_w) / fx; h = f(fbo_h) / fy
+    return (int((f(fbo_w) - w) / f(2)), int((f(fbo_h) - h) / f(2)), int(w), int(h))
+
+
+def case_present():
+    """OpenGLRenderer::renderTexture off-screen (OpenGLRenderer.cpp:378-470) as FrameCapturePipeline uses
+    it: source pre-pass (FCP.cpp:160-250), output resize (:413-505), brightness/contrast bake (:739-804)."""
+    def save(name, src, out, **meta):
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), src=src, out=out, **{k: np.array(v) for k, v in meta.items()})
+        print("wrote", name, src.shape, out.shape)
+
+    rgba = lambda w, h, seed: np.random.default_rng(seed).integers(0, 256, (h, w, 4), dtype=np.uint8)
+    # pre-pass: GL_RGB source, NEAREST, GL_RGB target
+    src = mixed(320, 240, 60)
+    save("present_prepass_down_320x240_to_256x224", src, gl_present(src, "nearest", 256, 224, "rgb"), filt="nearest", dst="rgbx8",
+         vp=(0, 0, 256, 224), overscan=(0.0, 0.0), b=1.0, c=1.0, flip=0)
+    vp = overscan_vp(256, 224, 5.0, 3.0)
+    save("present_prepass_overscan_down_320x240_to_256x224", src, gl_present(src, "nearest", 256, 224, "rgb", vp), filt="nearest",
+         dst="rgbx8", vp=vp, overscan=(5.0, 3.0), b=1.0, c=1.0, flip=0)
+    src = noise(161, 120, 61)
+    vp = overscan_vp(161, 120, 12.5, 0.0)
+    save("present_prepass_overscan_161x120", src, gl_present(src, "nearest", 161, 120, "rgb", vp), filt="nearest", dst="rgbx8",
+         vp=vp, overscan=(12.5, 0.0), b=1.0, c=1.0, flip=0)
+    # resize: RGBA8 source (a render target), LINEAR, GL_RGBA target
+    src = rgba(64, 48, 62)
+    save("present_resize_64x48_to_160x100", src, gl_present(src, "linear", 160, 100, "rgba"), filt="linear", dst="rgba8",
+         vp=(0, 0, 160, 100), b=1.0, c=1.0, flip=0)
+    src = rgba(160, 120, 63)
+    small = gl_present(src, "linear", 97, 71, "rgba")
+    save("present_resize_160x120_to_97x71", src, small, filt="linear", dst="rgba8", vp=(0, 0, 97, 71), b=1.0, c=1.0, flip=0)
+    # bake at the same size, then the reference's resize -> bake chain (two draws)
+    src = rgba(120, 90, 64)
+    save("present_bake_120x90", src, gl_present(src, "linear", 120, 90, "rgba", b=1.2, c=0.9), filt="linear", dst="rgba8",
+         vp=(0, 0, 120, 90), b=1.2, c=0.9, flip=0)
+    src = rgba(160, 120, 65)
+    mid = gl_present(src, "linear", 232, 150, "rgba")
+    save("present_resize_bake_160x120_to_232x150", src, gl_present(mid, "linear", 232, 150, "rgba", b=0.85, c=1.25), mid=mid,
+         filt="linear", dst="rgba8", vp=(0, 0, 232, 150), b=1.0, c=1.0, bake=(0.85, 1.25), flip=0)
+    # flipY uniform and a viewport inside the target (letterbox; the rest keeps the clear colour)
+    src = rgba(96, 54, 66)
+    save("present_flip_letterbox_96x54_to_120x100", src, gl_present(src, "nearest", 120, 100, "rgba", (0, 16, 120, 67), 1, 1.1, 1.1),
+         filt="nearest", dst="rgba8", vp=(0, 16, 120, 67), b=1.1, c=1.1, flip=1)
+    # float target: the program's arithmetic before the UNORM8 store
+    src = rgba(32, 32, 67)
+    save("present_f32_32x32", src, gl_present(src, "linear", 32, 32, "f32", b=0.7, c=1.45), filt="linear", dst="f32",
+         vp=(0, 0, 32, 32), b=0.7, c=1.45, flip=0)
+
+
 def case_float():
     """The same shaders with every render target forced to RGBA32F (not the reference's formats): pins
     the arithmetic of every pass at float precision."""
@@ -311,7 +381,7 @@ def case_float():
     case_crt_royale_mask_active(f32=True)
 
 
-CASES = {"sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -112,3 +112,41 @@ def run_pass_rows(name, tex, out_w, out_h, y0, y1, out_fmt="rgba8", params=(), f
     """Rows [y0, y1) of a pass rendered at full target size (for full-size spot checks)."""
     return _call(name, tex, out_w, out_h, y0, y1, out_fmt, params, frame_count, extra, src_w, src_h, chain,
                  pass_index, vp, flags, 1)[y0:y1].copy()
+
+
+class OVec4(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("w", C.c_float)]
+
+
+class OPresentArgs(C.Structure):
+    _fields_ = [("src", C.POINTER(OTex)), ("dst_w", C.c_int), ("dst_h", C.c_int), ("dst_fmt", C.c_int),
+                ("vp_x", C.c_int), ("vp_y", C.c_int), ("vp_w", C.c_int), ("vp_h", C.c_int), ("flip_y", C.c_int),
+                ("brightness", C.c_float), ("contrast", C.c_float), ("clear", OVec4), ("dst", C.c_void_p)]
+
+
+def present(tex, dst_w, dst_h, dst_fmt="rgba8", vp=None, flip_y=False, brightness=1.0, contrast=1.0,
+            clear=(0.0, 0.0, 0.0, 0.0)):
+    """OpenGLRenderer::renderTexture off-screen (oracle/rc_present.c); returns (dst_h, dst_w, 4)."""
+    L = lib()
+    L.o_present.restype = None
+    L.o_present.argtypes = [C.POINTER(OPresentArgs)]
+    dst = np.zeros((dst_h, dst_w, 4), np.float32 if dst_fmt == "f32" else np.uint8)
+    a = OPresentArgs()
+    a.src = C.pointer(tex.c)
+    a.dst_w, a.dst_h, a.dst_fmt = dst_w, dst_h, FMT[dst_fmt]
+    a.vp_x, a.vp_y, a.vp_w, a.vp_h = vp if vp else (0, 0, dst_w, dst_h)
+    a.flip_y = int(bool(flip_y))
+    a.brightness, a.contrast = brightness, contrast
+    a.clear = OVec4(*clear)
+    a.dst = dst.ctypes.data
+    L.o_present(C.byref(a))
+    return dst
+
+
+def overscan_viewport(fbo_w, fbo_h, pct_x, pct_y):
+    L = lib()
+    L.o_overscan_viewport.restype = None
+    L.o_overscan_viewport.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int)]
+    vp = (C.c_int * 4)()
+    L.o_overscan_viewport(fbo_w, fbo_h, pct_x, pct_y, vp)
+    return tuple(vp)
