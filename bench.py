@@ -151,6 +151,21 @@ def io_measurements(e, w, h, batch, reps):
     t = timed(lambda: eng.egress_rgb24(rgba, w, h, n, rgb, stream=st))
     res["egress_rgb24"] = {"GB/s": px * 7 / t / 1e9, "frac_of_8TBs": px * 7 / t / 8e12, "frames": n, "w": w, "h": h}
 
+    # rc_present (OpenGLRenderer::renderTexture off-screen): algorithmic bytes = source once + target once
+    dw, dh = w * 2 // 3, h * 2 // 3
+    small = torch.empty(n * dw * dh * 4, dtype=torch.uint8, device="cuda")
+    for name, kw, rd, wr in (
+            ("present_bake_rgba8", dict(dst_w=w, dst_h=h, brightness=1.1, contrast=0.9), 4, px * 4),
+            ("present_resize_bake_rgb24", dict(dst_w=dw, dst_h=dh, dst_kind="rgb24", bake=(1.1, 0.9), out_flip_rows=True), 4, n * dw * dh * 3),
+            ("present_prepass_nearest_rgbx8", dict(dst_w=dw, dst_h=dh, dst_kind="rgbx8", src_rgb=True, src_linear=False,
+                                                   viewport=eng.overscan_viewport(dw, dh, 5.0, 5.0)), 4, n * dw * dh * 4)):
+        dst = rgb if kw.get("dst_kind") == "rgb24" else (small if kw["dst_w"] != w else torch.empty_like(rgba))
+        kk = dict(kw)
+        tw, th = kk.pop("dst_w"), kk.pop("dst_h")
+        t = timed(lambda: eng.present(rgba, w, h, dst, tw, th, n_frames=n, stream=st, **kk))
+        res[name] = {"GB/s": (px * rd + wr) / t / 1e9, "frac_of_8TBs": (px * rd + wr) / t / 8e12, "frames": n,
+                     "src": [w, h], "dst": [tw, th], "us_per_frame": t / n * 1e6}
+
     # host-to-host: the chain's own output size may differ from the input's
     h_in = torch.randint(0, 256, (px * 3,), dtype=torch.uint8).pin_memory()
     d_in = torch.empty(px * 3, dtype=torch.uint8, device="cuda")
