@@ -27,6 +27,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); me
 WORKLOADS = {
     # key: (chain_specs preset key, source w, h, viewport w, h, description)
     "crt-royale": ("crt-royale", 1920, 1080, 1920, 1080, "crt/crt-royale.glslp 12-pass, 1920x1080 RGBA8 frames"),
+    "crt-royale-fake-bloom": ("crt-royale-fake-bloom", 1920, 1080, 1920, 1080,
+                              "crt/crt-royale-fake-bloom.glslp 9-pass, 1920x1080 RGBA8 frames"),
     "crt-pi": ("crt-pi", 1920, 1080, 1920, 1080, "crt/crt-pi.glslp 1-pass, 1920x1080 RGBA8 frames"),
     "ntsc": ("ntsc-256px-svideo", 1920, 1080, 1920, 1080,
              "ntsc/ntsc-256px-svideo.glslp 2-pass (RGBA32F 1024x1080 intermediate), 1920x1080 RGBA8 frames"),

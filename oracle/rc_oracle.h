@@ -111,6 +111,7 @@ void o_pass_blur9_h(const o_pass_args* a);            /* P4  blurs/blur9fast-hor
 void o_pass_royale_mask_v(const o_pass_args* a);      /* P5  mask-resize-vertical; extra[0] = mask_slot_texture_small */
 void o_pass_royale_mask_h(const o_pass_args* a);      /* P6  mask-resize-horizontal */
 void o_pass_royale_scan_h(const o_pass_args* a);      /* P7  scanlines-horizontal-apply-mask; extra = PassPrev6, PassPrev3 */
+void o_pass_royale_scan_h_fake(const o_pass_args* a); /* P7 of crt-royale-fake-bloom; extra = PassPrev6, PassPrev5, PassPrev3 */
 void o_pass_royale_brightpass(const o_pass_args* a);  /* P8  brightpass; extra[0] = PassPrev4 */
 void o_pass_royale_bloom_v(const o_pass_args* a);     /* P9  bloom-vertical */
 void o_pass_royale_bloom_h(const o_pass_args* a);     /* P10 bloom-horizontal-reconstitute; extra = PassPrev3, PassPrev2, PassPrev6 */

@@ -433,8 +433,26 @@ static float scanline_horizontal_1ch(const o_tex* t, float u, float v, float tsx
   return maxps(m, 0.0f);
 }
 
-void o_pass_royale_scan_h(const o_pass_args* a) {
-  ENTER;
+static const float mask_amplify = 1.0f / (46.0f / 255.0f); /* mask_type 1: 1/mask_slot_avg_color */
+/* FS 10948-11027 with PHOSPHOR_BLOOM_FAKE (and PHOSPHOR_BLOOM_FAKE_WITH_SIMPLE_BLEND): every parameter is a
+ * compile-time constant in this file (no #pragma parameter).  scan = electron_intensity_dim (halation_weight 0). */
+static float fake_bloom_tail(float scan, float mask, float soft, float hal) {
+  const float undim = 1.0f / 0.5f, under = 0.8f, diffusion = 0.075f, contrast = 1.05f;
+  const float ped = scan * mask;
+  const float pe = ped * (undim * mask_amplify);
+  const float ei = scan * undim;
+  const float lerped = soft * (1.0f - 0.1f) + ei * 0.1f;
+  const float approx = lerped * contrast;
+  /* the GL's compiler gathers the constant factors of each product chain (float goldens): the
+   * underestimates are products of the lerp itself, not of `approx` */
+  const float pbu = lerped * (contrast * under);
+  const float amu = lerped * ((contrast * under) * mask_amplify);
+  const float rt = (amu - 1.0f) / (amu - pbu);
+  const float ratio = maxps(clampf(rt, 0.0f, 1.0f), 0.0f);
+  const float unclipped = pe + ratio * (approx - pe);   /* non-constant weight: x + t*(y - x) */
+  return unclipped * (1.0f - diffusion) + hal * diffusion;
+}
+static void royale_scan_h_body(const o_pass_args* a, int fake) {
   const int W = a->out_w, H = a->out_h;
   const float ox = (float)W, oy = (float)H;
   const float tsx = (float)a->in->w, tsy = (float)a->in->h; /* MASK_RESIZE texture/video size */
@@ -453,6 +471,18 @@ void o_pass_royale_scan_h(const o_pass_args* a) {
   const float tps_x = ox / tile.x, tps_y = oy / tile.y;                    /* mask_tiles_per_screen */
   const float conv_x[3] = {0.1f, 0.3f, 0.5f};
   const o_tex* scan = a->extra[0];
+  /* PHOSPHOR_BLOOM_FAKE: blur3x3_tex_uv / halation_tex_uv = video_uv * <pass>video_size / <pass>texture_size
+   * (VS 6117-6120) for BLOOM_APPROX (PassPrev5) and HALATION_BLUR (PassPrev3) */
+  o_varying p_bu = p_vu, p_bv = p_vv, p_hu = p_vu, p_hv = p_vv;
+  if (fake) {
+    float iw, ih, tw, th;
+    prev_pass_sizes(a, 5, &iw, &ih, &tw, &th);
+    p_bu = plane_u(vu0 * iw / tw, vu1 * iw / tw, W, H, a->out_fmt);
+    p_bv = plane_v(vv0 * ih / th, vv1 * ih / th, W, H, a->out_fmt);
+    prev_pass_sizes(a, 3, &iw, &ih, &tw, &th);
+    p_hu = plane_u(vu0 * iw / tw, vu1 * iw / tw, W, H, a->out_fmt);
+    p_hv = plane_v(vv0 * ih / th, vv1 * ih / th, W, H, a->out_fmt);
+  }
   for (int y = a->y0; y < a->y1; ++y)
     for (int x = 0; x < W; ++x) {
       int lo = o_lower_tri(x, y, W, H);
@@ -469,8 +499,27 @@ void o_pass_royale_scan_h(const o_pass_args* a) {
       o_vec4 mask = o_sample(a->in, mu, mv);
       /* electron_intensity_dim = lerp(scanline, halation_intensity, halation_weight = 0) */
       o_vec4 o = {scanc[0] * mask.x, scanc[1] * mask.y, scanc[2] * mask.z, 1.0f};
+      if (fake) {
+        const o_vec4 soft = o_sample(a->extra[1], o_varying_at(&p_bu, x, y, lo), o_varying_at(&p_bv, x, y, lo));
+        const o_vec4 hal = o_sample(a->extra[2], o_varying_at(&p_hu, x, y, lo), o_varying_at(&p_hv, x, y, lo));
+        const float m3[3] = {mask.x, mask.y, mask.z}, s3[3] = {soft.x, soft.y, soft.z}, h3[3] = {hal.x, hal.y, hal.z};
+        float out[3];
+        for (int c = 0; c < 3; ++c) out[c] = fake_bloom_tail(scanc[c], m3[c], s3[c], h3[c]);
+        o.x = out[0]; o.y = out[1]; o.z = out[2];
+      }
       o_store_pixel(a, x, y, o);
     }
+}
+void o_pass_royale_scan_h(const o_pass_args* a) {
+  ENTER;
+  royale_scan_h_body(a, 0);
+  LEAVE;
+}
+/* scanlines-horizontal-apply-mask-fake-bloom.glsl: the same file with PHOSPHOR_BLOOM_FAKE defined;
+ * extra = PassPrev6 (VERTICAL_SCANLINES), PassPrev5 (BLOOM_APPROX), PassPrev3 (HALATION_BLUR) */
+void o_pass_royale_scan_h_fake(const o_pass_args* a) {
+  ENTER;
+  royale_scan_h_body(a, 1);
   LEAVE;
 }
 
@@ -487,7 +536,6 @@ static float bloom_sigma_runtime(float ox, float oy) {
 static float center_weight(float sigma) {
   return minps(o_exp(o_exp(0.348348412457428f / (sigma - 0.0860587260734721f))), 0.399334576340352f / sigma);
 }
-static const float mask_amplify = 1.0f / (46.0f / 255.0f); /* mask_type 1: 1/mask_slot_avg_color */
 
 /* brightpass.glsl FS 14610-14663; extra[0] = PassPrev4Texture */
 void o_pass_royale_brightpass(const o_pass_args* a) {

@@ -32,6 +32,7 @@ hipError_t launch_blur9(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_mask_v(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_mask_h(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_scan_h(const PassLaunch& L, hipStream_t s);
+hipError_t launch_royale_scan_h_fake(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_brightpass(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s);

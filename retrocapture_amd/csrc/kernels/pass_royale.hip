@@ -362,7 +362,27 @@ __device__ __forceinline__ float scanline_h_1ch(const Tex& t, const uint8_t* img
   return maxps(m, 0.0f);
 }
 
-template <class SI, class S0, class SO>
+// PHOSPHOR_BLOOM_FAKE tail (scanlines-horizontal-apply-mask-fake-bloom.glsl FS 10948-11027): every
+// parameter is a compile-time constant in that file; operation order as the GL's compiler leaves it
+// (constant factors of a product chain gathered, x + t*(y - x) for the run-time weight; float goldens).
+__device__ __forceinline__ float fake_bloom_tail(float scan, float mask, float soft, float hal) {
+  const float mask_amplify = 1.0f / (46.0f / 255.0f);
+  const float undim = 1.0f / 0.5f, under = 0.8f, diffusion = 0.075f, contrast = 1.05f;
+  const float ped = scan * mask;
+  const float pe = ped * (undim * mask_amplify);
+  const float ei = scan * undim;
+  const float lerped = soft * (1.0f - 0.1f) + ei * 0.1f;
+  const float approx = lerped * contrast;
+  const float pbu = lerped * (contrast * under);
+  const float amu = lerped * ((contrast * under) * mask_amplify);
+  const float rt = (amu - 1.0f) / (amu - pbu);
+  const float ratio = maxps(minps(maxps(rt, 0.0f), 1.0f), 0.0f);
+  const float unclipped = pe + ratio * (approx - pe);
+  return unclipped * (1.0f - diffusion) + hal * diffusion;
+}
+
+// FAKE: extra = PassPrev6 (VERTICAL_SCANLINES), PassPrev5 (BLOOM_APPROX), PassPrev3 (HALATION_BLUR)
+template <class SI, class S0, class SO, bool FAKE>
 __global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
@@ -373,8 +393,8 @@ __global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
   const float mu = L.params[RP7_START_X] + tux * L.params[RP7_UVS_X], mv = L.params[RP7_START_Y] + tuy * L.params[RP7_UVS_Y];
   const float4 mask = SI::get(L.in, frame_ptr(L.in, z), mu, mv, &lds);
   float4 o = make_float4(0.f, 0.f, 0.f, 1.0f);
-  // scan * 0 is 0 (or NaN, which every target format stores as 0): skip the scanline taps
-  if (mask.x != 0.0f || mask.y != 0.0f || mask.z != 0.0f) {
+  // without the fake bloom: scan * 0 is 0 (or NaN, which every target format stores as 0): skip the scanline taps
+  if (FAKE || mask.x != 0.0f || mask.y != 0.0f || mask.z != 0.0f) {
     const float su = vary(L.plane[2], x, y, lo), sv = vary(L.plane[3], x, y, lo);
     const Tex& scan = L.extra[0];
     const uint8_t* simg = frame_ptr(scan, z);
@@ -384,6 +404,12 @@ __global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) sc[ch] = scanline_h_1ch<S0>(scan, simg, su - conv_x[ch] * tix, sv - 0.0f, tsx, tsy, tix, tiy, ch, &lds);
     o = make_float4(sc[0] * mask.x, sc[1] * mask.y, sc[2] * mask.z, 1.0f);
+    if (FAKE) {
+      const float4 soft = S0::get(L.extra[1], frame_ptr(L.extra[1], z), vary(L.plane[4], x, y, lo), vary(L.plane[5], x, y, lo), &lds);
+      const float4 hal = S0::get(L.extra[2], frame_ptr(L.extra[2], z), vary(L.plane[6], x, y, lo), vary(L.plane[7], x, y, lo), &lds);
+      o = make_float4(fake_bloom_tail(sc[0], mask.x, soft.x, hal.x), fake_bloom_tail(sc[1], mask.y, soft.y, hal.y),
+                      fake_bloom_tail(sc[2], mask.z, soft.z, hal.z), 1.0f);
+    }
   }
   SO::put(L, z, x, y, o, &lds);
   RC_TILE_LOOP_END
@@ -573,8 +599,15 @@ hipError_t launch_blur9(const PassLaunch& L, hipStream_t s) {
 }
 hipError_t launch_royale_scan_h(const PassLaunch& L, hipStream_t s) {
   using MaskS = S<FMT_RGBA8, 0, WRAP_EDGE>;
-  if (MaskS::matches(L.in) && SrgbLinEdge::matches(L.extra[0]) && OutS::matches(L)) GO(k_royale_scan_h<MaskS, SrgbLinEdge, OutS>);
-  GO(k_royale_scan_h<SRT, SRT, StRT>);
+  if (MaskS::matches(L.in) && SrgbLinEdge::matches(L.extra[0]) && OutS::matches(L)) GO((k_royale_scan_h<MaskS, SrgbLinEdge, OutS, false>));
+  GO((k_royale_scan_h<SRT, SRT, StRT, false>));
+}
+hipError_t launch_royale_scan_h_fake(const PassLaunch& L, hipStream_t s) {
+  using MaskS = S<FMT_RGBA8, 0, WRAP_EDGE>;
+  if (MaskS::matches(L.in) && SrgbLinEdge::matches(L.extra[0]) && SrgbLinEdge::matches(L.extra[1]) && SrgbLinEdge::matches(L.extra[2]) &&
+      OutS::matches(L))
+    GO((k_royale_scan_h<MaskS, SrgbLinEdge, OutS, true>));
+  GO((k_royale_scan_h<SRT, SRT, StRT, true>));
 }
 hipError_t launch_royale_brightpass(const PassLaunch& L, hipStream_t s) {
   if (SrgbNearEdge::matches(L.in) && SrgbLinEdge::matches(L.extra[0]) && OutS::matches(L)) GO(k_royale_brightpass<SrgbNearEdge, SrgbLinEdge, OutS>);

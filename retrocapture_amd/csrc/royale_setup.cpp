@@ -168,6 +168,19 @@ void setupScanH(const PassGeometry& g, PassLaunch& L) {
   L.params[RP7_SCAN_TIY] = stiy;
 }
 
+// ---- pass 7 of crt-royale-fake-bloom: the same file with PHOSPHOR_BLOOM_FAKE; blur3x3_tex_uv / halation_tex_uv
+// = video_uv * <pass>video_size / <pass>texture_size (VS 6117-6120), BLOOM_APPROX = PassPrev5, HALATION_BLUR = PassPrev3
+void setupScanHFake(const PassGeometry& g, PassLaunch& L) {
+  setupScanH(g, L);
+  const float tsx = (float)g.in_w, tsy = (float)g.in_h;
+  const float vu1 = (1.0f * tsx) / tsx, vv1 = (1.0f * tsy) / tsy, vu0 = (0.0f * tsx) / tsx, vv0 = (0.0f * tsy) / tsy;
+  PrevSizes b = prevSizes(g, 5), h = prevSizes(g, 3);
+  L.plane[4] = planeU01(vu0 * b.in_w / b.tex_w, vu1 * b.in_w / b.tex_w, g, g.out_fmt);
+  L.plane[5] = planeV01(vv0 * b.in_h / b.tex_h, vv1 * b.in_h / b.tex_h, g, g.out_fmt);
+  L.plane[6] = planeU01(vu0 * h.in_w / h.tex_w, vu1 * h.in_w / h.tex_w, g, g.out_fmt);
+  L.plane[7] = planeV01(vv0 * h.in_h / h.tex_h, vv1 * h.in_h / h.tex_h, g, g.out_fmt);
+}
+
 // ---- pass 8: brightpass VS 6630-6649
 void setupBrightpass(const PassGeometry& g, PassLaunch& L) {
   const float tsx = (float)g.in_w, tsy = (float)g.in_h;
@@ -264,6 +277,10 @@ void registerRoyaleKernels(std::vector<KernelEntry>& r) {
   r.push_back({id("mask-resize-horizontal.glsl"), "royale-mask-h", {}, {}, rck::launch_royale_mask_h, setupMaskH, true});
   r.push_back({id("scanlines-horizontal-apply-mask.glsl"), "royale-scanlines-h", {}, {"PassPrev6Texture", "PassPrev3Texture"},
                rck::launch_royale_scan_h, setupScanH, false});
+  // crt-royale-fake-bloom.glslp: the two files that differ from crt-royale's by `#define PHOSPHOR_BLOOM_FAKE`
+  r.push_back({id("bloom-approx-fake-bloom.glsl"), "royale-bloom-approx", {}, {"PassPrev2Texture"}, rck::launch_royale_bloom_approx, setupBloomApprox, false});
+  r.push_back({id("scanlines-horizontal-apply-mask-fake-bloom.glsl"), "royale-scanlines-h-fake-bloom", {},
+               {"PassPrev6Texture", "PassPrev5Texture", "PassPrev3Texture"}, rck::launch_royale_scan_h_fake, setupScanHFake, false});
   r.push_back({id("brightpass.glsl"), "royale-brightpass", {}, {"PassPrev4Texture"}, rck::launch_royale_brightpass, setupBrightpass, false});
   r.push_back({id("bloom-vertical.glsl"), "royale-bloom-v", {}, {}, rck::launch_royale_bloom_v, setupBloomV, false});
   r.push_back({id("bloom-horizontal-reconstitute.glsl"), "royale-bloom-h", {},

@@ -244,10 +244,10 @@ bool ShaderEngine::compilePass(size_t i) {
                  shaderIdentity(pi.shaderPath) + "); the pass will be skipped");
     return false;
   }
-  if (pi.mipmapInput) {
-    RC_LOG_ERROR("mipmap_input is not supported by the HIP shader chain (pass " + std::to_string(i) + ")");
-    return false;
-  }
+  // mipmap_input (:1022-1033, GL_LINEAR_MIPMAP_LINEAR + glGenerateMipmap on the input): no mip chain is
+  // built here.  Accepted only where level 0 is all that is sampled - a pass whose target has the size of
+  // its input (checked per frame in runChunk; crt-royale-fake-bloom's last pass) - see DESIGN.md section 3
+  // for the 1e-5-level residual this leaves against llvmpipe.
   pd.kernel = entry;
   return true;
 }
@@ -864,6 +864,12 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
       }
       for (size_t q = 0; q < k.params.size() && q < (size_t)rcd::kMaxParams; ++q) {
         L.params[q] = effectiveParameter(pd, k.params[q], custom);
+      }
+      if (pd.passInfo.mipmapInput && (current.w != L.out_w || current.h != L.out_h)) {
+        RC_LOG_ERROR("pass " + std::to_string(i) + ": mipmap_input with a " + std::to_string(current.w) + "x" + std::to_string(current.h) +
+                     " input and a " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h) +
+                     " target would sample mip levels above 0, which the HIP shader chain does not build");
+        return false;
       }
       PassGeometry geo;
       fillGeometry(i, current, L, &geo);

@@ -133,11 +133,77 @@ filter_linear11 = "true"
 scale_type11 = "viewport"
 mipmap_input11 = "false"
 texture_wrap_mode11 = "clamp_to_edge"
+"""),    # Same keys / values as the reference's crt/crt-royale-fake-bloom.glslp (9 passes: crt-royale's 0-7 and
+    # its last pass, with the PHOSPHOR_BLOOM_FAKE variants of passes 2 and 7; BLOOM_APPROX is 400x300)
+    "crt-royale-fake-bloom": ("crt/crt-royale-fake-bloom.glslp", """shaders = "9"
+textures = "mask_slot_texture_small"
+mask_slot_texture_small = "shaders/crt-royale/mask_slot_small_64.png"
+mask_slot_texture_small_wrap_mode = "repeat"
+mask_slot_texture_small_linear = "true"
+mask_slot_texture_small_mipmap = "false"  # trailing comments make this parse as false anyway
+shader0 = "shaders/crt-royale/src/crt-royale-first-pass-linearize-crt-gamma-bob-fields.glsl"
+alias0 = "ORIG_LINEARIZED"
+filter_linear0 = "false"
+scale_type0 = "source"
+scale0 = "1.0"
+srgb_framebuffer0 = "true"
+shader1 = "shaders/crt-royale/src/crt-royale-scanlines-vertical-interlacing.glsl"
+alias1 = "VERTICAL_SCANLINES"
+filter_linear1 = "true"
+scale_type_x1 = "source"
+scale_x1 = "1.0"
+scale_type_y1 = "viewport"
+scale_y1 = "1.0"
+srgb_framebuffer1 = "true"
+shader2 = "shaders/crt-royale/src/crt-royale-bloom-approx-fake-bloom.glsl"
+alias2 = "BLOOM_APPROX"
+filter_linear2 = "true"
+scale_type2 = "absolute"
+scale_x2 = "400"
+scale_y2 = "300"
+srgb_framebuffer2 = "true"
+shader3 = "../blurs/blur9fast-vertical.glsl"
+filter_linear3 = "true"
+scale_type3 = "source"
+scale3 = "1.0"
+srgb_framebuffer3 = "true"
+shader4 = "../blurs/blur9fast-horizontal.glsl"
+alias4 = "HALATION_BLUR"
+filter_linear4 = "true"
+scale_type4 = "source"
+scale4 = "1.0"
+srgb_framebuffer4 = "true"
+shader5 = "shaders/crt-royale/src/crt-royale-mask-resize-vertical.glsl"
+filter_linear5 = "true"
+scale_type_x5 = "absolute"
+scale_x5 = "64"
+scale_type_y5 = "viewport"
+scale_y5 = "0.0625" # viewport fraction
+shader6 = "shaders/crt-royale/src/crt-royale-mask-resize-horizontal.glsl"
+alias6 = "MASK_RESIZE"
+filter_linear6 = "false"
+scale_type_x6 = "viewport"
+scale_x6 = "0.0625"
+scale_type_y6 = "source"
+scale_y6 = "1.0"
+shader7 = "shaders/crt-royale/src/crt-royale-scanlines-horizontal-apply-mask-fake-bloom.glsl"
+alias7 = "MASKED_SCANLINES"
+filter_linear7 = "true" # This could just as easily be nearest neighbor.
+scale_type7 = "viewport"
+scale7 = "1.0"
+srgb_framebuffer7 = "true"
+shader8 = "shaders/crt-royale/src/crt-royale-geometry-aa-last-pass.glsl"
+filter_linear8 = "true"
+scale_type8 = "viewport"
+mipmap_input8 = "true"
+texture_wrap_mode8 = "clamp_to_edge"
 """),
+
 }
 
 # files copied next to a preset: name -> (preset key, relative path below the preset dir, source under tests/golden)
-ASSETS = {"mask_slot_small_64.png": ("crt-royale", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png")}
+ASSETS = {"mask_slot_small_64.png": ("crt-royale", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png"),
+          "mask_slot_small_64.png#fake-bloom": ("crt-royale-fake-bloom", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png")}
 
 ROYALE_LAST_PARAMS = [
     ("crt_gamma", 2.5), ("lcd_gamma", 2.2), ("levels_contrast", 1.0), ("halation_weight", 0.0),
@@ -192,6 +258,9 @@ SHADERS = {
     _R + "mask-resize-horizontal.glsl": {"oracle": "royale_mask_h", "params": [], "samplers": []},
     _R + "scanlines-horizontal-apply-mask.glsl": {"oracle": "royale_scan_h", "params": [],
                                                    "samplers": ["PassPrev6Texture", "PassPrev3Texture"]},
+    _R + "bloom-approx-fake-bloom.glsl": {"oracle": "royale_bloom_approx", "params": [], "samplers": ["PassPrev2Texture"]},
+    _R + "scanlines-horizontal-apply-mask-fake-bloom.glsl": {"oracle": "royale_scan_h_fake", "params": [],
+                                                              "samplers": ["PassPrev6Texture", "PassPrev5Texture", "PassPrev3Texture"]},
     _R + "brightpass.glsl": {"oracle": "royale_brightpass", "params": [], "samplers": ["PassPrev4Texture"]},
     _R + "bloom-vertical.glsl": {"oracle": "royale_bloom_v", "params": [], "samplers": []},
     _R + "bloom-horizontal-reconstitute.glsl": {"oracle": "royale_bloom_h", "params": [],

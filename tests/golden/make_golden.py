@@ -381,7 +381,32 @@ def case_float():
     case_crt_royale_mask_active(f32=True)
 
 
-CASES = {"present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+def case_royale_fake_bloom():
+    """crt/crt-royale-fake-bloom.glslp (9 passes): crt-royale's passes 0-7 and its last pass, with the two
+    PHOSPHOR_BLOOM_FAKE variants of bloom-approx and scanlines-horizontal-apply-mask.  Rendered as llvmpipe
+    does (pass 6 discards everything, see case_crt_royale_mask_active) and with that pass active."""
+    import shutil
+    with tempfile.TemporaryDirectory() as d:
+        luts = royale_luts(d)
+        run_case("crt_royale_fake_bloom_160x120_to_320x240", GLSL + "/crt/crt-royale-fake-bloom.glslp", mixed(160, 120, 5), 320, 240,
+                 frames=2, luts=luts)
+        dst = os.path.join(d, "shaders_glsl")
+        os.makedirs(os.path.join(dst, "crt", "shaders"))
+        shutil.copytree(GLSL + "/crt/shaders/crt-royale", dst + "/crt/shaders/crt-royale")
+        shutil.copytree(GLSL + "/blurs", dst + "/blurs")
+        shutil.copy(GLSL + "/crt/crt-royale-fake-bloom.glslp", dst + "/crt/crt-royale-fake-bloom.glslp")
+        f = dst + "/crt/shaders/crt-royale/src/crt-royale-mask-resize-horizontal.glsl"
+        txt = open(f).read()
+        needle = "max(tile_uv_wrap.x, tile_uv_wrap.y) <= mask_resize_num_tiles"
+        assert txt.count(needle) == 1
+        open(f, "w").write(txt.replace(needle, "0.0 <= mask_resize_num_tiles"))
+        run_case("crt_royale_fake_bloom_maskon_128x96_to_400x300", dst + "/crt/crt-royale-fake-bloom.glslp", noise(128, 96, 6), 400, 300,
+                 luts=luts)
+        run_case("f32_crt_royale_fake_bloom_maskon_64x48_to_128x96", dst + "/crt/crt-royale-fake-bloom.glslp", mixed(64, 48, 5), 128, 96,
+                 luts=luts, f32=True)
+
+
+CASES = {"royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

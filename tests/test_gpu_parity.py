@@ -61,31 +61,34 @@ def royale_luts():
 
 
 ROYALE_GOLDEN = ["crt_royale_160x120_to_320x240", "crt_royale_128x96_to_400x300",
-                 "crt_royale_maskon_160x120_to_320x240", "crt_royale_maskon_96x128_to_512x384"]
+                 "crt_royale_maskon_160x120_to_320x240", "crt_royale_maskon_96x128_to_512x384",
+                 "crt_royale_fake_bloom_160x120_to_320x240", "crt_royale_fake_bloom_maskon_128x96_to_400x300"]
 
 
 @pytest.mark.parametrize("case", ROYALE_GOLDEN)
 def test_royale_matches_oracle_and_golden(case, preset_tree, rc_lib):
-    """All 12 crt-royale passes: bit-exact against the oracle run on the same input, and within
-    the documented sRGB-encode tolerance of the llvmpipe golden vectors."""
+    """All 12 crt-royale passes (9 of crt-royale-fake-bloom): bit-exact against the oracle run on the same
+    input, and within the documented sRGB-encode tolerance of the llvmpipe golden vectors."""
     from gpu_util import make_engine, run_engine
     from retrocapture_amd import engine as eng
     g = np.load(os.path.join(GOLD, case + ".npz"))
     vw, vh = [int(v) for v in g["viewport"]]
     maskon = "maskon" in case
     frames = int(g["frames"])
-    passes = eng.preset_dump(preset_tree["crt-royale"])["passes"]
-    assert len(passes) == 12
+    key = "crt-royale-fake-bloom" if "fake_bloom" in case else "crt-royale"
+    passes = eng.preset_dump(preset_tree[key])["passes"]
+    n = len(passes)
+    assert n == (9 if "fake_bloom" in case else 12)
     want = run_chain(passes, g["input_rgb"], vw, vh, frame_count=frames, luts=royale_luts(), flags=1 if maskon else 0)
-    e = make_engine(preset_tree["crt-royale"], vw, vh)
+    e = make_engine(preset_tree[key], vw, vh)
     e.setUndefinedVaryingZero(maskon)
     for _ in range(frames):                 # the golden run applied `frames` frames; the last one is kept
         final = run_engine(e, g["input_rgb"])
-    for i in range(12):
+    for i in range(n):
         got = e.readPass(i, 0)
         assert got.shape == want[i].shape, (i, got.shape, want[i].shape)
         assert np.array_equal(got, want[i]), "pass %d vs oracle: %d differing values" % (i, int((got != want[i]).sum()))
-    ref = g["pass11"]
+    ref = g["pass%d" % (n - 1)]
     d = np.abs(final[0].astype(np.int32) - ref.astype(np.int32))
     assert float((d == 0).mean()) >= 0.97
     if not maskon:
@@ -109,6 +112,30 @@ def test_royale_specialised_and_general_forms_agree(w, h, vw, vh, preset_tree, r
     for i in range(12):
         assert np.array_equal(pa[i], pb[i]), "pass %d" % i
     assert np.array_equal(a, b)
+    e.shutdown()
+
+
+def test_fake_bloom_forms_agree_and_mipmap_input_rule(preset_tree, rc_lib):
+    """crt-royale-fake-bloom: specialised and general kernel forms agree on all 9 passes, at full size too (a
+    1080p frame, last pass only); its last pass declares mipmap_input, which is accepted because that pass
+    renders 1:1, and refused (apply returns the input, as on any failed pass) where it would need mip levels."""
+    from gpu_util import make_engine, run_engine
+    frames = np.random.default_rng(77).integers(0, 256, (2, 96, 128, 3), dtype=np.uint8)
+    e = make_engine(preset_tree["crt-royale-fake-bloom"], 400, 300)
+    e.setUndefinedVaryingZero(True)
+    a = run_engine(e, frames)
+    pa = [e.readPass(i, 1) for i in range(9)]
+    e.setGeneralKernelsOnly(True)
+    b = run_engine(e, frames)
+    for i in range(9):
+        assert np.array_equal(pa[i], e.readPass(i, 1)), "pass %d" % i
+    assert np.array_equal(a, b) and a.std() > 10
+    big = np.random.default_rng(78).integers(0, 256, (1, 1080, 1920, 3), dtype=np.uint8)
+    e.setViewport(1920, 1080)
+    g = run_engine(e, big)
+    e.setGeneralKernelsOnly(False)
+    s = run_engine(e, big)
+    assert np.array_equal(g, s) and s.shape == (1, 1080, 1920, 4)
     e.shutdown()
 
 
@@ -364,7 +391,7 @@ def test_full_size_properties(preset_tree, rc_lib):
     e.shutdown()
 
 
-@pytest.mark.parametrize("key", ["crt-royale", "crt-pi", "scanline", "ntsc-256px-svideo", "ntsc-320px", "xbr-lv3"])
+@pytest.mark.parametrize("key", ["crt-royale", "crt-royale-fake-bloom", "crt-pi", "scanline", "ntsc-256px-svideo", "ntsc-320px", "xbr-lv3"])
 def test_smoke_statistics_like_the_reference(key, preset_tree, rc_lib):
     """The reference's only end-to-end check (tools/smoke-test.sh:221-300) restated: on its synthetic
     colour-bar source (VideoCaptureTestPattern.cpp:65-101) the shaded frame is not black, has variance,
@@ -377,7 +404,7 @@ def test_smoke_statistics_like_the_reference(key, preset_tree, rc_lib):
     w, h = 320, 240
     f0, f1 = bars(w, h, 0), bars(w, h, 40)
     e = make_engine(preset_tree[key], w, h)
-    if key == "crt-royale":
+    if key.startswith("crt-royale"):
         e.setUndefinedVaryingZero(True)
     out = run_engine(e, np.stack([f0, f1]))
     a, b = out[0][..., :3].astype(np.float64), out[1][..., :3].astype(np.float64)

@@ -38,6 +38,8 @@ CASES = {
     "xbr_lv3_noise_40x36_to_240x216": "xbr-lv3",
     "xbr_lv3_corner1_40x36_to_200x180": "xbr-lv3",
     "xbr_lv3_corner2_40x36_to_240x216": "xbr-lv3",
+    "crt_royale_fake_bloom_160x120_to_320x240": "crt-royale-fake-bloom",
+    "crt_royale_fake_bloom_maskon_128x96_to_400x300": "crt-royale-fake-bloom",
     # the same preset as a GL that reads 0 from pass 6's unwritten varying renders it
     "crt_royale_maskon_160x120_to_320x240": "crt-royale",
     "crt_royale_maskon_96x128_to_512x384": "crt-royale",
@@ -47,7 +49,7 @@ CASES = {
 # crt-royale: every pass that stores to an sRGB8 target can differ from llvmpipe by 1 LSB in
 # ~0.3 % of the bytes, because llvmpipe's sRGB encode runs through the x86 RSQRTPS
 # approximation and is not monotone ("sRGB8 store"); RGBA8 passes must be exact.
-BAR = {"scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1), "ntsc-256px-svideo": (1.0, 0),
+BAR = {"scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1), "crt-royale-fake-bloom": (0.995, 1), "ntsc-256px-svideo": (1.0, 0),
        "xbr-lv3": (1.0, 0), "mix-frames": (1.0, 0), "feedback-persist": (1.0, 0)}
 
 
@@ -107,7 +109,7 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
     passes = preset_passes(tmp_path, key)
     vw, vh = [int(v) for v in g["viewport"]]
     flags = 1 if "maskon" in case else 0
-    luts = royale_luts() if key == "crt-royale" else None
+    luts = royale_luts() if key.startswith("crt-royale") else None
     golden = [g["pass%d" % i] for i in range(int(g["n_passes"]))]
     custom = dict(zip([str(n) for n in g["param_names"]], [float(v) for v in g["param_values"]])) \
         if "param_names" in g else None
@@ -123,13 +125,17 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
             d = np.abs(o.astype(np.int32) - ref.astype(np.int32))
             exact = float((d == 0).mean())
             fmt = str(g["pass%d_fmt" % i])
-            if fmt == "rgba8":
+            if fmt == "rgba8" and passes[i]["mipmap"]:
+                # mipmap_input at 1:1 (crt-royale-fake-bloom's last pass): llvmpipe blends a 1e-7 share of mip
+                # level 1 into some pixel quads; no mip chain is built here
+                assert d.max() <= 1 and exact >= 0.9999, "pass %d: exact %.6f max %d" % (i, exact, d.max())
+            elif fmt == "rgba8":
                 assert d.max() == 0, "RGBA8 pass %d must be bit-exact: exact %.5f max %d" % (i, exact, d.max())
             assert d.max() <= maxdiff and exact >= floor, "pass %d: exact %.5f max %d" % (i, exact, d.max())
         else:
             assert np.array_equal(o.view(np.uint32), ref.view(np.uint32)) or np.allclose(o, ref, rtol=1e-6, atol=1e-7)
     # ... and the whole chain end to end on the oracle's own intermediates
-    if key == "crt-royale":
+    if key.startswith("crt-royale"):
         own = run_chain(passes, g["input_rgb"], vw, vh, frame_count=int(g["frames"]), luts=luts, flags=flags)
         d = np.abs(own[-1].astype(np.int32) - golden[-1].astype(np.int32))
         exact = float((d == 0).mean())
@@ -153,6 +159,10 @@ FLOAT_CASES = {
     "f32_xbr_lv3_48x40_to_331x217": ("xbr-lv3", {0: 0.999}),
     "f32_crt_royale_64x48_to_128x96": ("crt-royale", {1: 0.99}),          # P1: <= 3 ulp on 0.5 % of components (values < 1e-3)
     "f32_crt_royale_maskon_64x48_to_128x96": ("crt-royale", {1: 0.99}),
+    # pass 8 (the last pass, mipmap_input = true at 1:1): llvmpipe's trilinear LOD is a hair above 0 on some
+    # pixel quads and blends a 1e-7 share of mip level 1 into the sample - 1 ulp on 11 % of the floats, 1 LSB on
+    # <= 2e-5 of the stored bytes; no mip chain is built here
+    "f32_crt_royale_fake_bloom_maskon_64x48_to_128x96": ("crt-royale-fake-bloom", {1: 0.99, 8: 0.88}),
 }
 
 
@@ -165,12 +175,15 @@ def test_oracle_arithmetic_at_float_precision(case, tmp_path, rc_lib):
     n = int(g["n_passes"])
     golden = [g["pass%d" % i] for i in range(n)]
     outs = run_chain(passes, g["input_rgb"], vw, vh, frame_count=int(g["frames"]),
-                     luts=royale_luts() if key == "crt-royale" else None, flags=1 if "maskon" in case else 0,
+                     luts=royale_luts() if key.startswith("crt-royale") else None, flags=1 if "maskon" in case else 0,
                      given=golden, force_f32=True)
     for i, (o, r) in enumerate(zip(outs, golden)):
         same = (o.view(np.uint32) == r.view(np.uint32)) | (np.isnan(o) & np.isnan(r))
         frac = float(same[..., :3].mean())
         assert frac >= floors.get(i, 1.0), "pass %d: %.5f of the float components bit-identical" % (i, frac)
+        if passes[i]["mipmap"]:   # see the comment at the case: a 1e-7 share of mip level 1, then the output gamma
+            assert float(np.abs(o - r)[..., :3].max()) <= 1e-3, "pass %d" % i
+            continue
         ulp = np.abs(o.view(np.int32).astype(np.int64) - r.view(np.int32).astype(np.int64))[..., :3][~same[..., :3]]
         assert ulp.size == 0 or ulp.max() <= 9000, "pass %d: max %d ulp" % (i, int(ulp.max()))
 
