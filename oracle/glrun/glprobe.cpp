@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
   std::string vs =
       "#version 330\nin vec4 P;\nin vec2 TexCoord;\nout vec2 TC;\nvoid main(){ gl_Position = P; TC = TexCoord; }\n";
   std::string fs =
-      "#version 330\nuniform sampler2D T;\nuniform sampler2D S;\nuniform vec2 Size;\nuniform vec2 SSize;\nin vec2 TC;\nout vec4 O;\n" + bs.str() +
+      "#version 330\n#extension GL_ARB_texture_query_lod : enable\nuniform sampler2D T;\nuniform sampler2D S;\nuniform vec2 Size;\nuniform vec2 SSize;\nin vec2 TC;\nout vec4 O;\n" + bs.str() +
       "\nvoid main(){ O = f(texelFetch(T, ivec2(gl_FragCoord.xy), 0)); }\n";
   GLuint prog = CreateProgram();
   AttachShader(prog, compile(GL_VERTEX_SHADER, vs));
@@ -107,9 +107,27 @@ int main(int argc, char** argv) {
     else
       TexImage2D(GL_TEXTURE_2D, 0, tf == "srgb8" ? GL_SRGB8_ALPHA8 : GL_RGBA, TW, TH, 0, GL_RGBA,
                  GL_UNSIGNED_BYTE, td.data());
-    GLenum fl = filt == "linear" ? GL_LINEAR : GL_NEAREST;
+    // "trilinear" / "mipnearest": the state ShaderEngine sets for mipmap_input (ShaderEngine.cpp:1022-1033)
+    const bool mip = filt == "trilinear" || filt == "mipnearest";
+    GLenum fl = (filt == "linear" || filt == "trilinear") ? GL_LINEAR : GL_NEAREST;
     TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, fl);
     TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, fl);
+    if (mip) {
+      TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, filt == "trilinear" ? GL_LINEAR_MIPMAP_LINEAR : GL_NEAREST_MIPMAP_NEAREST);
+      GenerateMipmap(GL_TEXTURE_2D);
+      if (const char* dump = getenv("GLPROBE_DUMP_LEVELS")) {   // every generated level, raw stored bytes / floats
+        FILE* df = fopen(dump, "wb");
+        for (int lv = 0, lw = TW, lh = TH;; ++lv) {
+          std::vector<char> buf((size_t)lw * lh * (tf == "f32" ? 16 : 4));
+          GetTexImage(GL_TEXTURE_2D, lv, GL_RGBA, tf == "f32" ? GL_FLOAT : GL_UNSIGNED_BYTE, buf.data());
+          fwrite(buf.data(), 1, buf.size(), df);
+          if (lw == 1 && lh == 1) break;
+          lw = lw > 1 ? lw / 2 : 1;
+          lh = lh > 1 ? lh / 2 : 1;
+        }
+        fclose(df);
+      }
+    }
     GLenum wr = wrap == "border" ? GL_CLAMP_TO_BORDER
                 : wrap == "repeat" ? GL_REPEAT
                 : wrap == "mirror" ? GL_MIRRORED_REPEAT

@@ -49,7 +49,22 @@ typedef struct {
   int fmt;
   int linear; /* filter: 1 = GL_LINEAR, 0 = GL_NEAREST */
   int wrap;
+  /* mipmap_input (ShaderEngine.cpp:1022-1033: GL_LINEAR_MIPMAP_LINEAR + glGenerateMipmap): levels 1.. of the
+   * chain, level k is max(1, w >> k) x max(1, h >> k); n_levels = 0 or 1: not mip-mapped */
+  int n_levels;
+  const void* mip[15]; /* mip[k] = level k (mip[0] = data) */
 } o_tex;
+#define O_MAX_LEVELS 15
+/* number of levels of a full chain, and llvmpipe's glGenerateMipmap: every level is a LINEAR blit of the
+ * one above (sRGB8: decoded, averaged and re-encoded; F32: plain); dst[k] must hold level k (k >= 1) */
+int o_mip_levels(int w, int h);
+void o_gen_mipmaps(const void* level0, int w, int h, int fmt, void* const* dst, int n_levels);
+/* texture() on a mip-mapped texture: the coordinate at this pixel and at its horizontal / vertical
+ * neighbour inside the 2x2 quad (llvmpipe takes per-pixel differences, rc_sampler.c) */
+o_vec4 o_sample_quad(const o_tex* t, float s, float v, float s_dx0, float s_dx1, float v_dx0, float v_dx1,
+                     float s_dy0, float s_dy1, float v_dy0, float v_dy1);
+float o_lod_from_quad(const o_tex* t, float s_dx0, float s_dx1, float v_dx0, float v_dx1,
+                      float s_dy0, float s_dy1, float v_dy0, float v_dy1);
 
 o_vec4 o_texel(const o_tex* t, int x, int y); /* decoded texel, no wrap */
 o_vec4 o_sample(const o_tex* t, float s, float v);
@@ -129,6 +144,13 @@ void o_pass_ntsc_pass2_2phase_gamma(const o_pass_args* a);
 void o_pass_ntsc_pass2_2phase_linear(const o_pass_args* a);
 void o_pass_ntsc_pass2_2phase(const o_pass_args* a);
 void o_pass_xbr_lv3(const o_pass_args* a);            /* 5 params */
+/* crt/crt-hyllian-glow.glslp (rc_passes_glow.c) */
+void o_pass_glow_linearize(const o_pass_args* a);     /* 1 param */
+void o_pass_crt_hyllian_glow(const o_pass_args* a);   /* 10 params */
+void o_pass_glow_threshold(const o_pass_args* a);     /* 2 params */
+void o_pass_glow_blur_h(const o_pass_args* a);        /* mip-mapped input */
+void o_pass_glow_blur_v(const o_pass_args* a);
+void o_pass_hyllian_resolve2(const o_pass_args* a);   /* 4 params; extra[0] = PassPrev4Texture */
 void o_store_pixel(const o_pass_args* a, int x, int y, o_vec4 c);
 
 /* ---- OpenGLRenderer::renderTexture off-screen (rc_present.c) ------------------------------ */

@@ -13,6 +13,11 @@
  *     weights rint(frac(u)*256), lerp = a + ((w*(b-a) + 128) >> 8) on bytes, x then y,
  *     result k * (1/255f).
  *   - store: UNORM8 = rint(clamp(x,0,1) * 255) (ties to even); sRGB8: monotone table.
+ *   - mip-mapped (GL_LINEAR_MIPMAP_LINEAR, measured with textureQueryLOD and level dumps):
+ *     rho^2 = max((dsdx*W)^2 + (dtdx*H)^2, (dsdy*W)^2 + (dtdy*H)^2) from per-pixel coordinate differences
+ *     inside the 2x2 quad; lod = max(0, 0.5 * (exponent(rho^2) + mantissa(rho^2) - 1)) (a linear "fast
+ *     log2"), clamped to the last level; result = fma(frac(lod), S(l+1) - S(l), S(l)) with S = the LINEAR
+ *     sample of a level.  glGenerateMipmap = one LINEAR blit per level (sRGB8 decoded / re-encoded).
  */
 #include <math.h>
 
@@ -116,6 +121,62 @@ o_vec4 o_sample(const o_tex* t, float s, float v) {
     out[c] = (float)r * (1.0f / 255.0f);
   }
   return v4(out[0], out[1], out[2], out[3]);
+}
+
+/* ---- mip-mapped sampling -------------------------------------------------------------------- */
+int o_mip_levels(int w, int h) {
+  int n = 1;
+  while (w > 1 || h > 1) { w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1; ++n; }
+  return n < O_MAX_LEVELS ? n : O_MAX_LEVELS;
+}
+
+static float fast_log2(float x) {
+  union { float f; uint32_t u; } b = {x};
+  const int e = (int)((b.u >> 23) & 255u) - 127;
+  b.u = (b.u & 0x7fffffu) | 0x3f800000u;
+  return (float)e + (b.f - 1.0f);
+}
+
+float o_lod_from_quad(const o_tex* t, float s_dx0, float s_dx1, float v_dx0, float v_dx1,
+                      float s_dy0, float s_dy1, float v_dy0, float v_dy1) {
+  const float fw = (float)t->w, fh = (float)t->h;
+  const float ax = (s_dx1 - s_dx0) * fw, bx = (v_dx1 - v_dx0) * fh;
+  const float ay = (s_dy1 - s_dy0) * fw, by = (v_dy1 - v_dy0) * fh;
+  const float rx = ax * ax + bx * bx, ry = ay * ay + by * by;
+  const float rho2 = rx > ry ? rx : ry;
+  float lod = 0.5f * fast_log2(rho2);
+  if (!(lod > 0.0f)) lod = 0.0f;
+  const float last = (float)(t->n_levels - 1);
+  return lod > last ? last : lod;
+}
+
+o_vec4 o_sample_quad(const o_tex* t, float s, float v, float s_dx0, float s_dx1, float v_dx0, float v_dx1,
+                     float s_dy0, float s_dy1, float v_dy0, float v_dy1) {
+  if (t->n_levels <= 1) return o_sample(t, s, v);
+  const float lod = o_lod_from_quad(t, s_dx0, s_dx1, v_dx0, v_dx1, s_dy0, s_dy1, v_dy0, v_dy1);
+  const float fl = floorf(lod), w = lod - fl;
+  int l0 = (int)fl, l1 = l0 + 1;
+  if (l1 > t->n_levels - 1) l1 = t->n_levels - 1;
+  o_tex a = *t, b = *t;
+  a.data = t->mip[l0]; a.w = t->w >> l0 ? t->w >> l0 : 1; a.h = t->h >> l0 ? t->h >> l0 : 1; a.n_levels = 0;
+  b.data = t->mip[l1]; b.w = t->w >> l1 ? t->w >> l1 : 1; b.h = t->h >> l1 ? t->h >> l1 : 1; b.n_levels = 0;
+  const o_vec4 c0 = o_sample(&a, s, v), c1 = o_sample(&b, s, v);
+  return v4(fmaf(w, c1.x - c0.x, c0.x), fmaf(w, c1.y - c0.y, c0.y), fmaf(w, c1.z - c0.z, c0.z), fmaf(w, c1.w - c0.w, c0.w));
+}
+
+void o_gen_mipmaps(const void* level0, int w, int h, int fmt, void* const* dst, int n_levels) {
+  const void* src = level0;
+  for (int k = 1; k < n_levels; ++k) {
+    const int sw = (w >> (k - 1)) ? (w >> (k - 1)) : 1, sh = (h >> (k - 1)) ? (h >> (k - 1)) : 1;
+    const int dw = (w >> k) ? (w >> k) : 1, dh = (h >> k) ? (h >> k) : 1;
+    o_tex t = {0};
+    t.data = src; t.w = sw; t.h = sh; t.fmt = fmt; t.linear = 1; t.wrap = O_WRAP_EDGE;
+    o_pass_args a = {0};
+    a.in = &t; a.src_w = sw; a.src_h = sh; a.out_w = dw; a.out_h = dh; a.out_fmt = fmt; a.dst = dst[k];
+    a.y0 = 0; a.y1 = dh; a.n_passes = 1; a.vp_w = dw; a.vp_h = dh;
+    o_pass_stock(&a);
+    src = dst[k];
+  }
 }
 
 uint8_t o_store_unorm8(float x) {

@@ -20,6 +20,39 @@ void setupCrtPi(const PassGeometry& g, rcd::PassLaunch& L) {
   L.plane[1] = planeV(1.0001f, g.out_w, g.out_h, g.out_fmt);
 }
 
+// glow/blur_{horiz,vert}.glsl: the nine weights exp(-0.35 i^2) and their sum.  The loop is unrolled by the GL's
+// compiler and exp() of a constant folded with a correctly rounded exp, not the run-time polynomial.
+void setupGlowBlur(const PassGeometry& g, rcd::PassLaunch& L) {
+  setupTexCoord(g, L);
+  float total = 0.0f;
+  for (int i = -4; i <= 4; ++i) {
+    const float fi = (float)i;
+    const float k = (float)std::exp((double)(-0.35f * fi * fi));
+    L.params[i + 4] = k;
+    total += k;
+  }
+  L.params[9] = total;
+}
+
+// crt-hyllian-glow.glsl: invX from HFILTER_SHARPNESS (FS 157-165) and the beam profile (FS 174-187)
+void setupHyllianGlow(const PassGeometry& g, rcd::PassLaunch& L) {
+  setupTexCoord(g, L);
+  const float* P = L.params;
+  float bp[4] = {P[3], P[1], P[2], P[4]};
+  static const float prof[6][4] = {{0.40f, 1.00f, 1.00f, 1.00f}, {0.72f, 1.00f, 1.00f, 1.25f}, {0.60f, 0.50f, 1.00f, 1.25f},
+                                   {0.60f, 0.72f, 1.00f, 1.25f}, {0.68f, 0.68f, 1.00f, 1.25f}, {0.70f, 0.50f, 1.00f, 1.80f}};
+  for (int k = 1; k <= 6; ++k)
+    if (P[0] == (float)k)
+      for (int c = 0; c < 4; ++c) bp[c] = prof[k - 1][c];
+  const float B = 1.0f - P[5], C = P[5] * 0.5f;
+  const float m[16] = {(-B - 6.0f * C) / 6.0f, (12.0f - 9.0f * B - 6.0f * C) / 6.0f, -(12.0f - 9.0f * B - 6.0f * C) / 6.0f, (B + 6.0f * C) / 6.0f,
+                       (3.0f * B + 12.0f * C) / 6.0f, (-18.0f + 12.0f * B + 6.0f * C) / 6.0f, (18.0f - 15.0f * B - 12.0f * C) / 6.0f, -C,
+                       (-3.0f * B - 6.0f * C) / 6.0f, 0.0f, (3.0f * B + 6.0f * C) / 6.0f, 0.0f,
+                       B / 6.0f, (6.0f - 2.0f * B) / 6.0f, B / 6.0f, 0.0f};
+  for (int k = 0; k < 16; ++k) L.params[16 + k] = m[k];
+  for (int k = 0; k < 4; ++k) L.params[32 + k] = bp[k];
+}
+
 // The device's vary() and GL_NEAREST index, evaluated on the host with the same operations.
 float hostVary(const rcd::Plane& p, int x, int y) { return std::fmaf(p.dy_lo, (float)y, std::fmaf(p.dx_lo, (float)x, p.a0_lo)); }
 int hostNearest(float s, int n) { return (int)std::floor(s * (float)n); }
@@ -166,6 +199,46 @@ std::vector<KernelEntry> build() {
                 {"INPUT_GAMMA", 2.4f, 0.0f, 5.0f, 0.01f, "Input gamma"},
                 {"OUTPUT_GAMMA", 2.2f, 0.0f, 5.0f, 0.01f, "Output gamma"}},
                {}, rck::launch_crt_pi, setupCrtPi, false});
+  // crt/crt-hyllian-glow.glslp, the reference's smoke-test default preset (kernels/pass_glow.hip)
+  r.push_back({"crt/shaders/glow/linearize.glsl", "glow-linearize", {{"INPUT_GAMMA", 2.4f, 2.0f, 2.6f, 0.02f, "Input Gamma"}}, {},
+               rck::launch_glow_linearize, setupTexCoord, false});
+  r.push_back({"crt/shaders/hyllian/crt-hyllian-glow/crt-hyllian-glow.glsl", "crt-hyllian-glow",
+               {{"BEAM_PROFILE", 0.0f, 0.0f, 6.0f, 1.0f, "BEAM PROFILE (BP)"},
+                {"BEAM_MIN_WIDTH", 0.86f, 0.0f, 1.0f, 0.02f, "  Custom [If   BP=0.00] MIN BEAM WIDTH"},
+                {"BEAM_MAX_WIDTH", 1.0f, 0.0f, 1.0f, 0.02f, "  Custom [If   BP=0.00] MAX BEAM WIDTH"},
+                {"SCANLINES_STRENGTH", 0.58f, 0.0f, 1.0f, 0.02f, "  Custom [If   BP=0.00] SCANLINES STRENGTH"},
+                {"COLOR_BOOST", 1.25f, 1.0f, 2.0f, 0.05f, "  Custom [If   BP=0.00] COLOR BOOST"},
+                {"HFILTER_SHARPNESS", 1.0f, 0.0f, 1.0f, 0.02f, "HORIZONTAL FILTER SHARPNESS"},
+                {"CRT_ANTI_RINGING", 1.0f, 0.0f, 1.0f, 0.1f, "ANTI RINGING"},
+                {"InputGamma", 2.4f, 0.0f, 5.0f, 0.1f, "INPUT GAMMA"},
+                {"OutputGamma", 2.2f, 0.0f, 5.0f, 0.1f, "OUTPUT GAMMA"},
+                {"VSCANLINES", 0.0f, 0.0f, 1.0f, 1.0f, "SCANLINES DIRECTION"}},
+               {}, rck::launch_crt_hyllian_glow, setupHyllianGlow, false});
+  r.push_back({"crt/shaders/glow/threshold.glsl", "glow-threshold",
+               {{"GLOW_WHITEPOINT", 1.0f, 0.5f, 1.1f, 0.02f, "Glow Whitepoint"}, {"GLOW_ROLLOFF", 3.0f, 1.2f, 6.0f, 0.1f, "Glow Rolloff"}}, {},
+               rck::launch_glow_threshold, setupTexCoord, false});
+  {
+    KernelEntry e{"crt/shaders/glow/blur_horiz.glsl", "glow-blur-h", {}, {}, rck::launch_glow_blur_h, setupGlowBlur, false};
+    e.mip_aware = true;
+    e.ignores_texture_height = true;   // FS 87: dx = 4.0 * SourceSize.z only
+    r.push_back(e);
+  }
+  r.push_back({"crt/shaders/glow/blur_vert.glsl", "glow-blur-v", {}, {}, rck::launch_glow_blur_v, setupGlowBlur, false});
+  {
+    KernelEntry e{"crt/shaders/hyllian/crt-hyllian-glow/resolve2.glsl", "hyllian-resolve2",
+                  {{"BLOOM_STRENGTH", 0.45f, 0.0f, 0.8f, 0.05f, "Glow Strength"},
+                   {"OUTPUT_GAMMA", 2.2f, 1.8f, 2.6f, 0.02f, "Monitor Gamma"},
+                   {"PHOSPHOR_LAYOUT", 4.0f, 0.0f, 19.0f, 1.0f, "PHOSPHOR LAYOUT"},
+                   {"MASK_INTENSITY", 0.5f, 0.0f, 1.0f, 0.1f, "MASK INTENSITY"}},
+                  {"PassPrev4Texture"}, rck::launch_hyllian_resolve2, setupTexCoord, false};
+    e.validate = [](const float* p) -> const char* {
+      const int layout = (int)p[2];
+      return (layout == 0 || layout == 1 || layout == 2 || layout == 4 || layout == 5)
+                 ? nullptr
+                 : "resolve2.glsl: only PHOSPHOR_LAYOUT 0, 1, 2, 4 and 5 are restated";
+    };
+    r.push_back(e);
+  }
   // conformance fixture of this repository (tests/fixtures/conformance/): pins PassFeedback, which no
   // shader of the reference's tree declares
   r.push_back({"conformance/feedback-persist.glsl", "feedback-persist", {{"PERSIST", 0.8f, 0.0f, 1.0f, 0.05f, "Persistence"}},

@@ -49,6 +49,12 @@ struct KernelEntry {
   // only on the textures bound and the target size.  Needed for the frame-history re-draw, which runs
   // pass 0's program with stale size uniforms (shader_engine.cpp pushHistory).
   bool size_independent = false;
+  // The kernel samples its input as llvmpipe samples a mip-mapped texture (mipmap_input of its pass:
+  // GL_LINEAR_MIPMAP_LINEAR + glGenerateMipmap, ShaderEngine.cpp:1022-1033); the engine then builds the chain.
+  bool mip_aware = false;
+  // The shader never reads TextureSize.y, so the reference's override of that uniform for pass index 3
+  // (ShaderEngine.cpp:2418-2421) cannot change its result.
+  bool ignores_texture_height = false;
 };
 
 const KernelEntry* findKernel(const std::string& shaderPath);

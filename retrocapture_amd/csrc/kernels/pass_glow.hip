@@ -1,0 +1,233 @@
+// crt/crt-hyllian-glow.glslp - the reference's smoke-test default preset - 6 passes:
+//   P0 crt/shaders/glow/linearize.glsl                              FS 88-93
+//   P1 crt/shaders/hyllian/crt-hyllian-glow/crt-hyllian-glow.glsl   FS 146-247
+//   P2 crt/shaders/glow/threshold.glsl                              FS 90-96
+//   P3 crt/shaders/glow/blur_horiz.glsl (mip-mapped input)          FS 84-98
+//   P4 crt/shaders/glow/blur_vert.glsl                              FS 84-98
+//   P5 crt/shaders/hyllian/crt-hyllian-glow/resolve2.glsl           FS 129-189, 408-424
+// Operation order as in oracle/rc_passes_glow.c (pinned by the float-precision goldens).  These
+// passes use the run-time selected samplers: they are small next to crt-royale's and HBM-light
+// (P3 / P4 work at 1/16 of the pixels).
+#include "pass_launch.h"
+
+using namespace rcd;
+
+namespace {
+
+__device__ __forceinline__ float minps(float a, float b) { return a < b ? a : b; }  // SSE minps: NaN -> b
+__device__ __forceinline__ float maxps(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float mix_rt_(float a, float b, float t) { return a + t * (b - a); }
+__device__ __forceinline__ float clamp_ps(float x, float lo, float hi) { return minps(maxps(x, lo), hi); }
+
+// params: INPUT_GAMMA
+__global__ void __launch_bounds__(256) k_glow_linearize(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float g = L.params[0];
+  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
+  store_rt(L, z, x, y, make_float4(pow_(c.x, g), pow_(c.y, g), pow_(c.z, g), 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
+// params: GLOW_WHITEPOINT, GLOW_ROLLOFF
+__global__ void __launch_bounds__(256) k_glow_threshold(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float wp = L.params[0], roll = L.params[1];
+  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
+  store_rt(L, z, x, y,
+           make_float4(pow_(clamp_ps((1.15f * c.x) / wp, 0.0f, 1.0f), roll), pow_(clamp_ps((1.15f * c.y) / wp, 0.0f, 1.0f), roll),
+                       pow_(clamp_ps((1.15f * c.z) / wp, 0.0f, 1.0f), roll), 1.0f),
+           &lds);
+  RC_TILE_LOOP_END
+}
+
+// texture() on a mip-mapped input (GL_LINEAR_MIPMAP_LINEAR, ShaderEngine.cpp:1022-1033) as llvmpipe evaluates
+// it: rho^2 from per-pixel coordinate differences inside the 2x2 quad, lod = 0.5 * (exponent + mantissa - 1)
+// of rho^2, the two nearest levels filtered LINEAR and blended with fma (oracle/rc_sampler.c).
+__device__ __forceinline__ float fast_log2_(float x) {
+  const uint32_t b = f2bits(x);
+  const int e = (int)((b >> 23) & 255u) - 127;
+  return (float)e + (bits2f((b & 0x7fffffu) | 0x3f800000u) - 1.0f);
+}
+__device__ __forceinline__ Tex mip_level(const Tex& t, int z, int level, const uint8_t** img) {
+  Tex l = t;
+  if (level == 0) {
+    *img = frame_ptr(t, z);
+    return l;
+  }
+  uint64_t off = 0;
+  for (int k = 1; k < level; ++k) off += (uint64_t)max(t.w >> k, 1) * (uint64_t)max(t.h >> k, 1) * (uint64_t)texel_bytes(t.fmt);
+  l.w = max(t.w >> level, 1);
+  l.h = max(t.h >> level, 1);
+  *img = static_cast<const uint8_t*>(t.mip_base) + t.mip_frame_stride * (uint64_t)z + off;
+  return l;
+}
+__device__ __forceinline__ float4 sample_mip(const Tex& t, int z, float s, float v, float lod, const SrgbLds* lds) {
+  const float fl = __builtin_floorf(lod), w = lod - fl;
+  const int l0 = (int)fl, l1 = min(l0 + 1, t.n_levels - 1);
+  const uint8_t *i0, *i1;
+  const Tex t0 = mip_level(t, z, l0, &i0), t1 = mip_level(t, z, l1, &i1);
+  const float4 c0 = sample_rt(t0, i0, s, v, lds), c1 = sample_rt(t1, i1, s, v, lds);
+  return make_float4(fma_(w, c1.x - c0.x, c0.x), fma_(w, c1.y - c0.y, c0.y), fma_(w, c1.z - c0.z, c0.z), fma_(w, c1.w - c0.w, c0.w));
+}
+
+// 9 taps, weights exp(-0.35 i^2) folded by the GL's compiler with a correctly rounded exp (params[0..8]) and
+// their sum (params[9]); HORIZ steps 4 texels on a mip-mapped input, else 1 texel vertically
+template <bool HORIZ>
+__global__ void __launch_bounds__(256) k_glow_blur(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float step = HORIZ ? 4.0f * (1.0f / (float)L.in.w) : 1.0f / (float)L.in.h;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const bool mip = HORIZ && L.in.n_levels > 1;
+  const int x0 = x & ~1, y0 = y & ~1;
+  // the quad's coordinates as this pixel's triangle extrapolates them
+  const float ux0 = vary(L.plane[0], x0, y, lo), ux1 = vary(L.plane[0], x0 + 1, y, lo);
+  const float vx0 = vary(L.plane[1], x0, y, lo), vx1 = vary(L.plane[1], x0 + 1, y, lo);
+  const float uy0 = vary(L.plane[0], x, y0, lo), uy1 = vary(L.plane[0], x, y0 + 1, lo);
+  const float vy0 = vary(L.plane[1], x, y0, lo), vy1 = vary(L.plane[1], x, y0 + 1, lo);
+  const uint8_t* img = frame_ptr(L.in, z);
+  float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+  for (int i = -4; i <= 4; ++i) {
+    const float off = (float)i * step;
+    const float su = HORIZ ? u + off : u + 0.0f, sv = HORIZ ? v + 0.0f : v + off;
+    float4 c;
+    if (mip) {
+      const float fw = (float)L.in.w, fh = (float)L.in.h;
+      const float ax = ((ux1 + off) - (ux0 + off)) * fw, bx = ((vx1 + 0.0f) - (vx0 + 0.0f)) * fh;
+      const float ay = ((uy1 + off) - (uy0 + off)) * fw, by = ((vy1 + 0.0f) - (vy0 + 0.0f)) * fh;
+      const float rx = ax * ax + bx * bx, ry = ay * ay + by * by;
+      float lod = 0.5f * fast_log2_(rx > ry ? rx : ry);
+      if (!(lod > 0.0f)) lod = 0.0f;
+      lod = fminf(lod, (float)(L.in.n_levels - 1));
+      c = sample_mip(L.in, z, su, sv, lod, &lds);
+    } else {
+      c = sample_rt(L.in, img, su, sv, &lds);
+    }
+    const float k = L.params[i + 4];
+    c0 += k * c.x;
+    c1 += k * c.y;
+    c2 += k * c.z;
+  }
+  const float kt = L.params[9];
+  store_rt(L, z, x, y, make_float4(c0 / kt, c1 / kt, c2 / kt, 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
+// params[0..9]: BEAM_PROFILE, BEAM_MIN_WIDTH, BEAM_MAX_WIDTH, SCANLINES_STRENGTH, COLOR_BOOST, HFILTER_SHARPNESS,
+// CRT_ANTI_RINGING, InputGamma, OutputGamma, VSCANLINES; params[16..31]: invX (column c, row r at 16 + 4c + r),
+// params[32..35]: the beam profile in effect (scanlines strength, min width, max width, colour boost) (host)
+__global__ void __launch_bounds__(256) k_crt_hyllian_glow(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float anti = L.params[6], gin = L.params[7], gout = L.params[8], vs = L.params[9];
+  const float* m = &L.params[16];
+  const float scan = 4.0f * L.params[32], bmin = L.params[33], bmax = L.params[34], boost = L.params[35];
+  const float tsx = (float)L.in.w, tsy = (float)L.in.h;
+  const float dxx = mix_rt_(1.0f / tsx, 0.0f, vs), dxy = mix_rt_(0.0f, 1.0f / tsy, vs);
+  const float dyx = mix_rt_(0.0f, 1.0f / tsx, vs), dyy = mix_rt_(1.0f / tsy, 0.0f, vs);
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float pcx = u * tsx + -0.5f, pcy = v * tsy + 0.5f;
+  const float flx = __builtin_floorf(pcx), fly = __builtin_floorf(pcy);
+  const float tcx = mix_rt_((flx + 0.5f) / tsx, (flx + 1.0f) / tsx, vs);
+  const float tcy = mix_rt_((fly + 0.5f) / tsy, (fly + -0.5f) / tsy, vs);
+  const float frx = pcx - flx, fry = pcy - fly;
+  const float fpx = mix_rt_(frx, fry, vs), fpy = mix_rt_(fry, frx, vs);
+  const uint8_t* img = frame_ptr(L.in, z);
+  float c[2][4][4];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float kx = (float)(k - 1);
+      float su = tcx + kx * dxx, sv = tcy + kx * dxy;
+      if (r == 0) {
+        su -= dyx;
+        sv -= dyy;
+      }
+      const float4 t = sample_rt(L.in, img, su, sv, &lds);
+      c[r][k][0] = pow_(t.x, gin);
+      c[r][k][1] = pow_(t.y, gin);
+      c[r][k][2] = pow_(t.z, gin);
+      c[r][k][3] = pow_(t.w, gin);
+    }
+  const float l0 = fpx * fpx * fpx, l1 = fpx * fpx, l2 = fpx;
+  float ip[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ip[r] = ((m[r] * l0 + m[4 + r] * l1) + m[8 + r] * l2) + m[12 + r] * 1.0f;
+  const float pos0 = fpy, pos1 = 1.0f - fpy;
+  float out[4];
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch) {
+    float col[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float v0 = ((c[r][0][ch] * ip[0] + c[r][1][ch] * ip[1]) + c[r][2][ch] * ip[2]) + c[r][3][ch] * ip[3];
+      const float mn = minps(c[r][1][ch], c[r][2][ch]), mx = maxps(c[r][1][ch], c[r][2][ch]);
+      col[r] = mix_rt_(v0, clamp_ps(v0, mn, mx), anti);
+    }
+    const float lum0 = mix_rt_(bmin, bmax, col[0]), lum1 = mix_rt_(bmin, bmax, col[1]);
+    float d0 = (scan * pos0) / (lum0 + 0.0000001f), d1 = (scan * pos1) / (lum1 + 0.0000001f);
+    d0 = exp_(-d0 * d0);
+    d1 = exp_(-d1 * d1);
+    out[ch] = pow_(boost * (col[0] * d0 + col[1] * d1), 1.0f / gout);
+  }
+  store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], out[3]), &lds);
+  RC_TILE_LOOP_END
+}
+
+// params: BLOOM_STRENGTH, OUTPUT_GAMMA, PHOSPHOR_LAYOUT, MASK_INTENSITY; extra[0] = PassPrev4Texture.
+// Phosphor layouts 0, 1, 2, 4, 5 (host validates).
+__global__ void __launch_bounds__(256) k_hyllian_resolve2(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float strength = L.params[0], gamma = L.params[1], intensity = L.params[3];
+  const int layout = (int)L.params[2];
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float4 s = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), u, v, &lds);
+  const float4 b = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+  const float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+  const float mx = __builtin_floorf(fx - 2.0f * __builtin_floorf(fx / 2.0f)), my = __builtin_floorf(fy - 2.0f * __builtin_floorf(fy / 2.0f));
+  const float on = 1.0f, off = 1.0f - intensity;
+  float w3[3] = {1.0f, 1.0f, 1.0f};
+  if (layout != 0) {
+    const bool rgb = layout == 1 || layout == 2;   // magenta / green columns; else yellow / blue
+    const float a3[3] = {on, rgb ? off : on, rgb ? on : off}, b3[3] = {off, rgb ? on : off, rgb ? off : on};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float ap = a3[k] + mx * (b3[k] - a3[k]);
+      w3[k] = ap;
+      if (layout == 2 || layout == 5) {
+        const float inv = b3[k] + mx * (a3[k] - b3[k]);
+        w3[k] = ap + my * (inv - ap);
+      }
+    }
+  }
+  const float s3[3] = {s.x, s.y, s.z}, bl[3] = {b.x, b.y, b.z};
+  float out[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) out[k] = pow_(clamp_ps((1.15f * s3[k] + strength * bl[k]) * w3[k], 0.0f, 1.0f), 1.0f / gamma);
+  store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
+}  // namespace
+
+namespace rck {
+#define GOK(K)                                                         \
+  hipLaunchKernelGGL(K, px_grid(L), px_block(), 0, s, L);              \
+  return hipGetLastError()
+hipError_t launch_glow_linearize(const PassLaunch& L, hipStream_t s) { GOK(k_glow_linearize); }
+hipError_t launch_glow_threshold(const PassLaunch& L, hipStream_t s) { GOK(k_glow_threshold); }
+hipError_t launch_glow_blur_h(const PassLaunch& L, hipStream_t s) { GOK(k_glow_blur<true>); }
+hipError_t launch_glow_blur_v(const PassLaunch& L, hipStream_t s) { GOK(k_glow_blur<false>); }
+hipError_t launch_crt_hyllian_glow(const PassLaunch& L, hipStream_t s) { GOK(k_crt_hyllian_glow); }
+hipError_t launch_hyllian_resolve2(const PassLaunch& L, hipStream_t s) { GOK(k_hyllian_resolve2); }
+}  // namespace rck

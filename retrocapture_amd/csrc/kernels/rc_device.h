@@ -26,6 +26,11 @@ struct Tex {
   uint64_t frame_stride; // bytes between consecutive frames (0: one image shared by all)
   int w, h;
   int fmt, linear, wrap;
+  // mipmap_input (ShaderEngine.cpp:1022-1033): levels 1..n_levels-1 of the chain, packed one after the
+  // other per frame (level k is max(1, w >> k) x max(1, h >> k)); n_levels <= 1: not mip-mapped
+  int n_levels = 0;
+  const void* mip_base = nullptr;
+  uint64_t mip_frame_stride = 0;
 };
 
 // Plane equation of one varying for the two triangles of the quad (see host varying.cpp).

@@ -1,6 +1,7 @@
 // ShaderEngine on HIP.  Section references are to the reference implementation
 // (src/shader/ShaderEngine.cpp) whose observable behaviour each block keeps.
 #include "shader_engine.h"
+#include "varying.h"
 
 #include <algorithm>
 #include <cmath>
@@ -451,7 +452,65 @@ rcd::Tex ShaderEngine::passTexture(size_t p) const {
     t.linear = 1;
     t.wrap = rcd::WRAP_EDGE;
   }
+  if (pd.mipLevels > 1 && pd.mips.ptr) {
+    t.n_levels = pd.mipLevels;
+    t.mip_base = pd.mips.ptr;
+    t.mip_frame_stride = pd.mipFrameBytes;
+  }
   return t;
+}
+
+// glGenerateMipmap as llvmpipe does it (measured, oracle/rc_sampler.c): every level is a LINEAR,
+// clamp-to-edge blit of the level above in the texture's own format - the stock kernel.
+bool ShaderEngine::buildMipChain(size_t p, const void* level0, uint32_t nFrames) {
+  ShaderPassData& pd = m_passes[p];
+  const uint32_t bpp = texelBytes(pd.format);
+  int levels = 1;
+  size_t bytes = 0;
+  for (uint32_t w = pd.width, h = pd.height; w > 1 || h > 1;) {
+    w = std::max(1u, w >> 1);
+    h = std::max(1u, h >> 1);
+    bytes += (size_t)w * h * bpp;
+    if (++levels == 15) break;
+  }
+  pd.mipLevels = levels;
+  pd.mipFrameBytes = bytes;
+  if (levels <= 1) return true;
+  if (!ensureBuffer(pd.mips, bytes * nFrames)) return false;
+  rcd::Tex src;
+  src.base = level0;
+  src.frame_stride = pd.frameBytes;
+  src.w = (int)pd.width;
+  src.h = (int)pd.height;
+  src.fmt = pd.format;
+  src.linear = 1;
+  src.wrap = rcd::WRAP_EDGE;
+  size_t off = 0;
+  for (int k = 1; k < levels; ++k) {
+    const int dw = std::max(1, (int)pd.width >> k), dh = std::max(1, (int)pd.height >> k);
+    rcd::PassLaunch L;
+    std::memset(static_cast<void*>(&L), 0, sizeof(L));
+    L.in = src;
+    L.out = static_cast<uint8_t*>(pd.mips.ptr) + off;
+    L.out_frame_stride = bytes;
+    L.out_w = dw;
+    L.out_h = dh;
+    L.out_fmt = pd.format;
+    L.src_w = src.w;
+    L.src_h = src.h;
+    L.vp_w = dw;
+    L.vp_h = dh;
+    L.n_frames = (int)nFrames;
+    L.plane[0] = makePlane(0.f, 1.f, 1.f, 0.f, dw, dh, pd.format);
+    L.plane[1] = makePlane(0.f, 0.f, 1.f, 1.f, dw, dh, pd.format);
+    if (!hipOk(rck::launch_stock(L, m_stream), "mip level")) return false;
+    src.base = L.out;
+    src.frame_stride = bytes;
+    src.w = dw;
+    src.h = dh;
+    off += (size_t)dw * dh * bpp;
+  }
+  return true;
 }
 
 rcd::Tex ShaderEngine::lutTexture(const std::string& name) const {  // :1361-1415
@@ -865,10 +924,26 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
       for (size_t q = 0; q < k.params.size() && q < (size_t)rcd::kMaxParams; ++q) {
         L.params[q] = effectiveParameter(pd, k.params[q], custom);
       }
-      if (pd.passInfo.mipmapInput && (current.w != L.out_w || current.h != L.out_h)) {
+      if (pd.passInfo.mipmapInput && k.mip_aware) {
+        if (current.n_levels <= 1 && (current.w > 1 || current.h > 1)) {
+          RC_LOG_ERROR("pass " + std::to_string(i) + ": mipmap_input needs an sRGB8 or float render target as input "
+                       "(llvmpipe's mip generation is restated for those formats only)");
+          return false;
+        }
+      } else if (pd.passInfo.mipmapInput && (current.w != L.out_w || current.h != L.out_h)) {
         RC_LOG_ERROR("pass " + std::to_string(i) + ": mipmap_input with a " + std::to_string(current.w) + "x" + std::to_string(current.h) +
                      " input and a " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h) +
                      " target would sample mip levels above 0, which the HIP shader chain does not build");
+        return false;
+      }
+      if (i == 3 && current.h != L.out_h && !k.size_independent && !k.ignores_texture_height) {
+        // The reference hands pass index 3 TextureSize.y = the TARGET's height whenever that differs from the
+        // input's (ShaderEngine.cpp:2418-2421, written for interlacing.glsl) while InputSize and the texture keep
+        // the real height.  No registered kernel restates its shader under that mismatch, so refuse rather
+        // than render something the reference would not (e.g. crt-royale-ntsc-*.glslp, whose pass 3 is
+        // scanlines-vertical-interlacing).
+        RC_LOG_ERROR("pass 3 scales its height (" + std::to_string(current.h) + " -> " + std::to_string(L.out_h) +
+                     "): the reference's TextureSize.y override for pass index 3 is not restated for this shader");
         return false;
       }
       PassGeometry geo;
@@ -917,6 +992,12 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
     if (last && target != finalOut &&
         !hipOk(hipMemcpyAsync(finalOut, target, pd.frameBytes * nFrames, hipMemcpyDeviceToDevice, m_stream), "copy"))
       return false;
+    // mipmap_input of the next pass: the reference generates the chain when that pass binds this texture
+    pd.mipLevels = 0;
+    if (!last && m_passes[i + 1].kernel && m_passes[i + 1].kernel->mip_aware && m_passes[i + 1].passInfo.mipmapInput &&
+        m_passes[i + 1].passInfo.filterLinear && (pd.format == rcd::FMT_SRGB8 || pd.format == rcd::FMT_F32)) {
+      if (!buildMipChain(i, target, nFrames)) return false;
+    }
     // this pass's output becomes the next pass's input
     rcd::Tex next = passTexture(i);
     next.base = target;

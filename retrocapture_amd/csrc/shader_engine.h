@@ -39,6 +39,11 @@ struct ShaderPassData {  // reference ShaderEngine.h:19-40
   int format = rcd::FMT_RGBA8;
   DeviceBuffer target;      // [chunk or batch][height][width] texels
   DeviceBuffer scratch;     // kernel-private scratch, [chunk] frames (KernelEntry::scratch_bytes)
+  // mip levels 1.. of the target, [chunk] frames, built after the pass when the next pass declares
+  // mipmap_input and its kernel samples mip-mapped (glGenerateMipmap at bind time, .cpp:1022-1033)
+  DeviceBuffer mips;
+  int mipLevels = 0;        // levels of the chain including level 0; 0: none
+  size_t mipFrameBytes = 0;
   // PassFeedback ping-pong (reference ShaderEngine.h feedbackTexture / feedbackFramebuffer, .cpp:1285-1347,
   // :1710-1718): the previous frame's output of this pass, allocated when a program first asks for it
   DeviceBuffer feedback;
@@ -202,6 +207,7 @@ class ShaderEngine {
                     rcd::PassLaunch* L, bool* lostDraw);
   bool presetSamplesFeedback() const;
   rcd::Tex passTexture(size_t passIndex) const;
+  bool buildMipChain(size_t passIndex, const void* level0, uint32_t nFrames);
   bool runChunk(const void* inputs, uint64_t inStride, uint32_t width, uint32_t height, uint32_t nFrames,
                 int firstFrameCount, void* finalOut);
 };

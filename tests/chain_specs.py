@@ -51,6 +51,38 @@ scale_y1 = 1.0
     "feedback-persist": ("feedback-persist.glslp",
                          'shaders = 2\nshader0 = stock.glsl\nfilter_linear0 = false\nscale_type0 = source\n'
                          'shader1 = conformance/feedback-persist.glsl\nfilter_linear1 = true\n'),
+    # same keys / values as the reference's crt/crt-hyllian-glow.glslp (its smoke-test default preset)
+    "crt-hyllian-glow": ("crt/crt-hyllian-glow.glslp", """shaders = 6
+
+shader0 = shaders/glow/linearize.glsl
+filter_linear0 = false
+srgb_framebuffer0 = true
+
+shader1 = shaders/hyllian/crt-hyllian-glow/crt-hyllian-glow.glsl
+filter_linear1 = false
+scale_type1 = viewport
+scale1 = 1.0
+srgb_framebuffer1 = true
+alias1 = CRT_PASS
+
+shader2 = shaders/glow/threshold.glsl
+filter_linear2 = false
+srgb_framebuffer2 = true
+
+shader3 = shaders/glow/blur_horiz.glsl
+mipmap_input3 = true
+filter_linear3 = true
+scale_type3 = source
+scale3 = 0.25
+srgb_framebuffer3 = true
+
+shader4 = shaders/glow/blur_vert.glsl
+filter_linear4 = true
+srgb_framebuffer4 = true
+
+shader5 = shaders/hyllian/crt-hyllian-glow/resolve2.glsl
+filter_linear5 = true
+"""),
     "stock": ("stock.glslp", 'shaders = "1"\nshader0 = "stock.glsl"\nfilter_linear0 = "false"\n'),
     # Same keys / values as the reference's crt/crt-royale.glslp for the 12 passes, including the
     # three `"true" # comment` booleans that its parser reads as false; only the LUT that the
@@ -249,6 +281,21 @@ SHADERS = {
         "params": [("XBR_Y_WEIGHT", 48.0), ("XBR_EQ_THRESHOLD", 10.0), ("XBR_EQ_THRESHOLD2", 2.0),
                    ("XBR_LV2_COEFFICIENT", 2.0), ("corner_type", 3.0)],
         "samplers": []},
+    "crt/shaders/glow/linearize.glsl": {"oracle": "glow_linearize", "params": [("INPUT_GAMMA", 2.4)], "samplers": []},
+    "crt/shaders/hyllian/crt-hyllian-glow/crt-hyllian-glow.glsl": {
+        "oracle": "crt_hyllian_glow",
+        "params": [("BEAM_PROFILE", 0.0), ("BEAM_MIN_WIDTH", 0.86), ("BEAM_MAX_WIDTH", 1.0), ("SCANLINES_STRENGTH", 0.58),
+                   ("COLOR_BOOST", 1.25), ("HFILTER_SHARPNESS", 1.0), ("CRT_ANTI_RINGING", 1.0), ("InputGamma", 2.4),
+                   ("OutputGamma", 2.2), ("VSCANLINES", 0.0)],
+        "samplers": []},
+    "crt/shaders/glow/threshold.glsl": {"oracle": "glow_threshold", "params": [("GLOW_WHITEPOINT", 1.0), ("GLOW_ROLLOFF", 3.0)],
+                                         "samplers": []},
+    "crt/shaders/glow/blur_horiz.glsl": {"oracle": "glow_blur_h", "params": [], "samplers": []},
+    "crt/shaders/glow/blur_vert.glsl": {"oracle": "glow_blur_v", "params": [], "samplers": []},
+    "crt/shaders/hyllian/crt-hyllian-glow/resolve2.glsl": {
+        "oracle": "hyllian_resolve2",
+        "params": [("BLOOM_STRENGTH", 0.45), ("OUTPUT_GAMMA", 2.2), ("PHOSPHOR_LAYOUT", 4.0), ("MASK_INTENSITY", 0.5)],
+        "samplers": ["PassPrev4Texture"]},
     _R + "first-pass-linearize-crt-gamma-bob-fields.glsl": {"oracle": "royale_first", "params": [], "samplers": []},
     _R + "scanlines-vertical-interlacing.glsl": {"oracle": "royale_scan_v", "params": [], "samplers": []},
     _R + "bloom-approx.glsl": {"oracle": "royale_bloom_approx", "params": [], "samplers": ["PassPrev2Texture"]},

@@ -406,7 +406,20 @@ def case_royale_fake_bloom():
                  luts=luts, f32=True)
 
 
-CASES = {"royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+def case_hyllian_glow():
+    """crt/crt-hyllian-glow.glslp: the reference's smoke-test default (6 passes, mip-mapped input on pass 3)."""
+    P = GLSL + "/crt/crt-hyllian-glow.glslp"
+    run_case("crt_hyllian_glow_96x64_to_256x192", P, mixed(96, 64, 70), 256, 192)
+    run_case("crt_hyllian_glow_80x60_to_250x190", P, noise(80, 60, 71), 250, 190)      # viewport / 4 is not integral
+    run_case("crt_hyllian_glow_params_64x48_to_200x150", P, mixed(64, 48, 72), 200, 150,
+             params=[("BEAM_PROFILE", 3.0), ("HFILTER_SHARPNESS", 0.6), ("CRT_ANTI_RINGING", 0.5), ("PHOSPHOR_LAYOUT", 2.0),
+                     ("MASK_INTENSITY", 0.7), ("GLOW_ROLLOFF", 2.2), ("BLOOM_STRENGTH", 0.6)])
+    run_case("f32_crt_hyllian_glow_64x48_to_160x120", P, mixed(64, 48, 73), 160, 120, f32=True)
+    run_case("f32_crt_hyllian_glow_64x48_to_150x110", P, noise(64, 48, 74), 150, 110, f32=True,
+             params=[("HFILTER_SHARPNESS", 0.7), ("CRT_ANTI_RINGING", 0.6), ("MASK_INTENSITY", 0.7), ("PHOSPHOR_LAYOUT", 5.0)])
+
+
+CASES = {"hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

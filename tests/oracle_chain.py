@@ -83,9 +83,16 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
     outs = []
     units = state.units if state is not None else {}
 
+    mip_cache = {}
+
     def tex_of_pass(k):
         nxt = passes[k + 1] if k + 1 < len(passes) else {"filter_linear": True, "wrap": "clamp_to_edge"}
-        return Tex(given[k] if given is not None else outs[k], fmts[k], nxt["filter_linear"], nxt["wrap"])
+        # mipmap_input of the consuming pass (ShaderEngine.cpp:1022-1033): the chain is generated when that pass
+        # binds its input and stays on the texture (as does the min filter) for later PassPrev reads
+        mip = bool(nxt.get("mipmap")) and nxt["filter_linear"]
+        if k not in mip_cache:
+            mip_cache[k] = Tex(given[k] if given is not None else outs[k], fmts[k], nxt["filter_linear"], nxt["wrap"], mipmap=mip)
+        return mip_cache[k]
 
     source_tex = Tex(src, "rgbx8", passes[0]["filter_linear"], passes[0]["wrap"])
     cur = source_tex

@@ -20,7 +20,7 @@ WRAP = {"clamp_to_edge": 0, "clamp_to_border": 1, "repeat": 2, "mirrored_repeat"
 
 class OTex(C.Structure):
     _fields_ = [("data", C.c_void_p), ("w", C.c_int), ("h", C.c_int), ("fmt", C.c_int),
-                ("linear", C.c_int), ("wrap", C.c_int)]
+                ("linear", C.c_int), ("wrap", C.c_int), ("n_levels", C.c_int), ("mip", C.c_void_p * 15)]
 
 
 class OPassArgs(C.Structure):
@@ -50,11 +50,33 @@ def lib():
 class Tex:
     """A texture as a pass sees it: array + format + the sampler state set on it."""
 
-    def __init__(self, arr, fmt, linear, wrap):
+    def __init__(self, arr, fmt, linear, wrap, mipmap=False):
         self.arr = np.ascontiguousarray(arr)
         self.c = OTex(self.arr.ctypes.data, self.arr.shape[1], self.arr.shape[0], FMT[fmt],
                       int(bool(linear)), WRAP.get(wrap, 0))
         self.fmt = fmt
+        self.levels = [self.arr]
+        if mipmap:      # mipmap_input: the chain llvmpipe's glGenerateMipmap builds (oracle/rc_sampler.c)
+            self.levels = gen_mipmaps(self.arr, fmt)
+            self.c.n_levels = len(self.levels)
+            for k, l in enumerate(self.levels):
+                self.c.mip[k] = l.ctypes.data
+
+
+def gen_mipmaps(level0, fmt):
+    """[level 0, level 1, ...] as o_gen_mipmaps builds them (sRGB8 / F32 textures)."""
+    L = lib()
+    h, w = level0.shape[:2]
+    L.o_mip_levels.restype = C.c_int
+    n = L.o_mip_levels(w, h)
+    levels = [np.ascontiguousarray(level0)]
+    for k in range(1, n):
+        levels.append(np.zeros((max(1, h >> k), max(1, w >> k), 4), level0.dtype))
+    ptrs = (C.c_void_p * n)(*[l.ctypes.data for l in levels])
+    L.o_gen_mipmaps.restype = None
+    L.o_gen_mipmaps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int]
+    L.o_gen_mipmaps(levels[0].ctypes.data, w, h, FMT[fmt], ptrs, n)
+    return levels
 
 
 def _call(name, tex, out_w, out_h, y0, y1, out_fmt, params, frame_count, extra, src_w, src_h, chain, pass_index,

@@ -115,6 +115,56 @@ def test_royale_specialised_and_general_forms_agree(w, h, vw, vh, preset_tree, r
     e.shutdown()
 
 
+HYLLIAN_GOLDEN = ["crt_hyllian_glow_96x64_to_256x192", "crt_hyllian_glow_80x60_to_250x190", "crt_hyllian_glow_params_64x48_to_200x150"]
+
+
+@pytest.mark.parametrize("case", HYLLIAN_GOLDEN)
+def test_hyllian_glow_matches_oracle_and_golden(case, preset_tree, rc_lib):
+    """crt/crt-hyllian-glow.glslp (the reference's smoke-test default): all 6 passes bit-exact against the oracle on
+    the same input - including pass 3, which samples a mip-mapped input (chain built on the device, trilinear LOD
+    from the pixel quad) - and the final RGBA8 pass against the llvmpipe golden within the sRGB-encode residual
+    of the passes before it."""
+    from gpu_util import make_engine, run_engine
+    from retrocapture_amd import engine as eng
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    vw, vh = [int(v) for v in g["viewport"]]
+    passes = eng.preset_dump(preset_tree["crt-hyllian-glow"])["passes"]
+    custom = dict(zip([str(x) for x in g["param_names"]], [float(v) for v in g["param_values"]])) if "param_names" in g else {}
+    want = run_chain(passes, g["input_rgb"], vw, vh, frame_count=1, custom=custom)
+    e = make_engine(preset_tree["crt-hyllian-glow"], vw, vh)
+    for k, v in custom.items():
+        assert e.setShaderParameter(k, v)
+    final = run_engine(e, g["input_rgb"])
+    for i in range(6):
+        got = e.readPass(i, 0)
+        assert got.shape == want[i].shape, (i, got.shape, want[i].shape)
+        assert np.array_equal(got, want[i]), "pass %d vs oracle: %d differing values" % (i, int((got != want[i]).sum()))
+    # end to end against llvmpipe: its non-monotone sRGB encode (DESIGN.md section 3) flips 0.3 % of pass 0's bytes by
+    # one level, which the two gamma curves amplify at isolated dark pixels (the oracle alone shows the same: max 8,
+    # 99.3 % exact; with golden inputs per pass the final pass is exact, tests/test_oracle_golden.py)
+    d = np.abs(final[0].astype(np.int32) - g["pass5"].astype(np.int32))
+    assert d.max() <= 16 and float((d == 0).mean()) >= 0.99 and float((d > 1).mean()) <= 1e-3
+    e.shutdown()
+
+
+def test_hyllian_glow_1080p_batch_and_unsupported_layout(preset_tree, rc_lib):
+    """Full size (1080p, 3 frames in one launch per pass; rows of the final pass spot-checked against the oracle
+    through golden-free properties: frames are processed independently, so each frame of the batch equals the
+    same frame run alone) and the parameter the kernel does not restate is refused, not mis-rendered."""
+    from gpu_util import make_engine, run_engine, to_device_rgba
+    frames = np.random.default_rng(31).integers(0, 256, (3, 270, 480, 3), dtype=np.uint8)
+    e = make_engine(preset_tree["crt-hyllian-glow"], 1920, 1080)
+    out = run_engine(e, frames)
+    assert out.shape == (3, 1080, 1920, 4) and out[..., :3].std() > 10
+    for k in range(3):
+        assert np.array_equal(run_engine(e, frames[k:k + 1])[0], out[k]), k
+    assert e.setShaderParameter("PHOSPHOR_LAYOUT", 7.0)
+    from retrocapture_amd.engine import RcError
+    with pytest.raises(RcError, match="PHOSPHOR_LAYOUT"):      # refused loudly, not mis-rendered
+        e.applyShader(to_device_rgba(frames[:1]), 480, 270)
+    e.shutdown()
+
+
 def test_fake_bloom_forms_agree_and_mipmap_input_rule(preset_tree, rc_lib):
     """crt-royale-fake-bloom: specialised and general kernel forms agree on all 9 passes, at full size too (a
     1080p frame, last pass only); its last pass declares mipmap_input, which is accepted because that pass
