@@ -710,7 +710,22 @@ void o_pass_royale_last(const o_pass_args* a) {
       float fu = u * (tsx * vsix), fv = v * (tsy * vsiy);          /* flat_video_uv */
       float vu = (fu - 0.5f) / osx + 0.5f, vv = (fv - 0.5f) / osy + 0.5f; /* video_uv */
       float tu = vu * (tsx * tsix), tv = vv * (tsy * tsiy);
-      o_vec4 c = o_sample(a->in, tu, tv);
+      o_vec4 c;
+      if (a->in->n_levels > 1) {
+        /* mipmap_input (crt-royale-fake-bloom's last pass): the sample coordinate of the quad's pixels as this
+         * pixel's triangle extrapolates them (rc_sampler.c, o_sample_quad) */
+        const int x0 = x & ~1, y0 = y & ~1;
+        float qu[4], qv[4];
+        const int qx[4] = {x0, x0 + 1, x, x}, qy[4] = {y, y, y0, y0 + 1};
+        for (int k = 0; k < 4; ++k) {
+          const float uu = o_varying_at(&tc.u, qx[k], qy[k], lo), vq = o_varying_at(&tc.v, qx[k], qy[k], lo);
+          qu[k] = ((uu * (tsx * vsix) - 0.5f) / osx + 0.5f) * (tsx * tsix);
+          qv[k] = ((vq * (tsy * vsiy) - 0.5f) / osy + 0.5f) * (tsy * tsiy);
+        }
+        c = o_sample_quad(a->in, tu, tv, qu[0], qu[1], qv[0], qv[1], qu[2], qu[3], qv[2], qv[3]);
+      } else {
+        c = o_sample(a->in, tu, tv);
+      }
       /* get_border_dim_factor */
       float ex = minps(vu, 1.0f - vu) * geom_aspect_x, ey = minps(vv, 1.0f - vv) * geom_aspect_y;
       float bx = maxps(border_size - ex, 0.0f), by = maxps(border_size - ey, 0.0f);

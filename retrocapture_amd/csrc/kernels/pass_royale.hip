@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(256, 4) k_royale_bloom_h(const PassLaunch L) {
 
 // ------------------------------------------------------------------------------ P11 ------
 // geometry-aa-last-pass.glsl FS 5451-5531 (flat geometry path), get_border_dim_factor 5250.
-template <class SI, class SO>
+template <class SI, class SO, bool MIP>
 __global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
@@ -534,7 +534,23 @@ __global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
   const float fu = u * (tsx * vsix), fv = v * (tsy * vsiy);
   const float vu = (fu - 0.5f) / osx + 0.5f, vv = (fv - 0.5f) / osy + 0.5f;
   const float tu = vu * (tsx * vsix), tv = vv * (tsy * vsiy);
-  const float4 c = SI::get(L.in, frame_ptr(L.in, z), tu, tv, &lds);
+  float4 c;
+  if (MIP) {
+    // mipmap_input (crt-royale-fake-bloom's last pass): the sample coordinate at the quad's pixels as this pixel's
+    // triangle extrapolates them; on a 1:1 pass the LOD is 0 or a hair above it (rc_device.h, mip-mapped sampling)
+    const int x0 = x & ~1, y0 = y & ~1;
+    const int qx[4] = {x0, x0 + 1, x, x}, qy[4] = {y, y, y0, y0 + 1};
+    float qu[4], qv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      qu[k] = ((vary(L.plane[0], qx[k], qy[k], lo) * (tsx * vsix) - 0.5f) / osx + 0.5f) * (tsx * vsix);
+      qv[k] = ((vary(L.plane[1], qx[k], qy[k], lo) * (tsy * vsiy) - 0.5f) / osy + 0.5f) * (tsy * vsiy);
+    }
+    const float lod = lod_from_quad(L.in, qu[0], qu[1], qv[0], qv[1], qu[2], qu[3], qv[2], qv[3]);
+    c = lod > 0.0f ? sample_mip(L.in, z, tu, tv, lod, &lds) : SI::get(L.in, frame_ptr(L.in, z), tu, tv, &lds);
+  } else {
+    c = SI::get(L.in, frame_ptr(L.in, z), tu, tv, &lds);
+  }
   const float ex = minps(vu, 1.0f - vu) * geom_aspect_x, ey = minps(vv, 1.0f - vv) * geom_aspect_y;
   const float bx = maxps(border_size - ex, 0.0f), by = maxps(border_size - ey, 0.0f);
   // Away from the border bx = by = 0: pen = sqrt(0)/size = 0, esc = 1, pow(1, d) = exp2(0*d) = 1 exactly
@@ -624,7 +640,11 @@ hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
   GO(k_royale_bloom_h<SRT, SRT, SRT, SRT, StRT>);
 }
 hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
-  if (SrgbLinEdge::matches(L.in) && St<FMT_RGBA8>::matches(L)) GO(k_royale_last<SrgbLinEdge, St<FMT_RGBA8>>);
-  GO(k_royale_last<SRT, StRT>);
+  if (L.in.n_levels > 1) {
+    if (SrgbLinEdge::matches(L.in) && St<FMT_RGBA8>::matches(L)) GO((k_royale_last<SrgbLinEdge, St<FMT_RGBA8>, true>));
+    GO((k_royale_last<SRT, StRT, true>));
+  }
+  if (SrgbLinEdge::matches(L.in) && St<FMT_RGBA8>::matches(L)) GO((k_royale_last<SrgbLinEdge, St<FMT_RGBA8>, false>));
+  GO((k_royale_last<SRT, StRT, false>));
 }
 }  // namespace rck

@@ -437,4 +437,45 @@ __device__ __forceinline__ void store_rt(const PassLaunch& L, int z, int x, int 
   else if (L.out_fmt == FMT_SRGB8) store<FMT_SRGB8>(L, z, x, y, c, t);
   else store<FMT_RGBA8>(L, z, x, y, c, t);
 }
+// ------------------------------------------------------------------- mip-mapped sampling ----
+// texture() on a mip-mapped input (GL_LINEAR_MIPMAP_LINEAR, ShaderEngine.cpp:1022-1033) as llvmpipe evaluates
+// it: rho^2 from per-pixel coordinate differences inside the 2x2 quad, lod = 0.5 * (exponent + mantissa - 1)
+// of rho^2, the two nearest levels filtered LINEAR and blended with fma (oracle/rc_sampler.c).
+__device__ __forceinline__ float fast_log2_(float x) {
+  const uint32_t b = f2bits(x);
+  const int e = (int)((b >> 23) & 255u) - 127;
+  return (float)e + (bits2f((b & 0x7fffffu) | 0x3f800000u) - 1.0f);
+}
+__device__ __forceinline__ Tex mip_level(const Tex& t, int z, int level, const uint8_t** img) {
+  Tex l = t;
+  if (level == 0) {
+    *img = frame_ptr(t, z);
+    return l;
+  }
+  uint64_t off = 0;
+  for (int k = 1; k < level; ++k) off += (uint64_t)max(t.w >> k, 1) * (uint64_t)max(t.h >> k, 1) * (uint64_t)texel_bytes(t.fmt);
+  l.w = max(t.w >> level, 1);
+  l.h = max(t.h >> level, 1);
+  *img = static_cast<const uint8_t*>(t.mip_base) + t.mip_frame_stride * (uint64_t)z + off;
+  return l;
+}
+__device__ __forceinline__ float lod_from_quad(const Tex& t, float s_dx0, float s_dx1, float v_dx0, float v_dx1, float s_dy0,
+                                               float s_dy1, float v_dy0, float v_dy1) {
+  const float fw = (float)t.w, fh = (float)t.h;
+  const float ax = (s_dx1 - s_dx0) * fw, bx = (v_dx1 - v_dx0) * fh;
+  const float ay = (s_dy1 - s_dy0) * fw, by = (v_dy1 - v_dy0) * fh;
+  const float rx = ax * ax + bx * bx, ry = ay * ay + by * by;
+  float lod = 0.5f * fast_log2_(rx > ry ? rx : ry);
+  if (!(lod > 0.0f)) lod = 0.0f;
+  return fminf(lod, (float)(t.n_levels - 1));
+}
+__device__ __forceinline__ float4 sample_mip(const Tex& t, int z, float s, float v, float lod, const SrgbLds* lds) {
+  const float fl = __builtin_floorf(lod), w = lod - fl;
+  const int l0 = (int)fl, l1 = min(l0 + 1, t.n_levels - 1);
+  const uint8_t *i0, *i1;
+  const Tex t0 = mip_level(t, z, l0, &i0), t1 = mip_level(t, z, l1, &i1);
+  const float4 c0 = sample_rt(t0, i0, s, v, lds), c1 = sample_rt(t1, i1, s, v, lds);
+  return make_float4(fma_(w, c1.x - c0.x, c0.x), fma_(w, c1.y - c0.y, c0.y), fma_(w, c1.z - c0.z, c0.z), fma_(w, c1.w - c0.w, c0.w));
+}
+
 }  // namespace rcd

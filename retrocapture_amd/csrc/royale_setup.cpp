@@ -332,6 +332,7 @@ void registerRoyaleKernels(std::vector<KernelEntry>& r) {
                 {"interlace_1080i", 0.0f, 0.0f, 1.0f, 1.0f, "Interlace - Detect 1080i"}},
                {}, rck::launch_royale_last, setupLast, false});
   r.back().validate = validateLast;
+  r.back().mip_aware = true;   // mipmap_input (crt-royale-fake-bloom): LOD from the pixel quad, chain built by the engine
   for (auto& e : r) {
     const std::string n = e.name;
     if (n == "royale-bloom-approx" || n == "royale-mask-v") e.reads_input = false;
