@@ -30,6 +30,31 @@ __global__ void __launch_bounds__(256) k_glow_linearize(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// 8-bit NEAREST clamp-to-edge input and an 8-bit target (the shipped preset): both passes are per-channel
+// functions of the source byte - a 256-entry byte map applied to the nearest texel (as crt-royale's first
+// pass, pass_royale.hip).  OP 0: linearize, OP 1: threshold.  Same bytes as the general kernels (tested).
+template <int OP>
+__global__ void __launch_bounds__(256) k_glow_bytemap(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  __shared__ uint32_t map[256];
+  load_srgb_tables(lds);
+  {
+    const int t = threadIdx.y * 64 + threadIdx.x;
+    const float c = L.in.fmt == FMT_SRGB8 ? lds.dec[t] : (float)t * (1.0f / 255.0f);
+    const float r = OP == 0 ? pow_(c, L.params[0]) : pow_(clamp_ps((1.15f * c) / L.params[0], 0.0f, 1.0f), L.params[1]);
+    map[t] = L.out_fmt == FMT_SRGB8 ? srgb8(r, &lds) : unorm8(r);
+  }
+  __syncthreads();
+  RC_TILE_LOOP_BEGIN
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const int sx = clampi((int)__builtin_floorf(u * (float)L.in.w), 0, L.in.w - 1);
+  const int sy = clampi((int)__builtin_floorf(v * (float)L.in.h), 0, L.in.h - 1);
+  const uint32_t p = *reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z) + texel_off(L.in.w, sx, sy, 4u));
+  const uint32_t o = map[p & 255u] | (map[(p >> 8) & 255u] << 8) | (map[(p >> 16) & 255u] << 16) | 0xff000000u;
+  *reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z + texel_off(L.out_w, x, y, 4u)) = o;
+  RC_TILE_LOOP_END
+}
+
 // params: GLOW_WHITEPOINT, GLOW_ROLLOFF
 __global__ void __launch_bounds__(256) k_glow_threshold(const PassLaunch L) {
   __shared__ SrgbLds lds;
@@ -86,9 +111,20 @@ __global__ void __launch_bounds__(256) k_glow_blur(const PassLaunch L) {
 // params[0..9]: BEAM_PROFILE, BEAM_MIN_WIDTH, BEAM_MAX_WIDTH, SCANLINES_STRENGTH, COLOR_BOOST, HFILTER_SHARPNESS,
 // CRT_ANTI_RINGING, InputGamma, OutputGamma, VSCANLINES; params[16..31]: invX (column c, row r at 16 + 4c + r),
 // params[32..35]: the beam profile in effect (scanlines strength, min width, max width, colour boost) (host)
+// TEXEL_LUT: 8-bit NEAREST clamp-to-edge input - GAMMA_IN(texel) is a function of the texel's bytes, so the 32
+// pows per pixel become lookups in two 256-entry tables (colour channels, alpha) built once per workgroup.
+template <bool TEXEL_LUT>
 __global__ void __launch_bounds__(256) k_crt_hyllian_glow(const PassLaunch L) {
   __shared__ SrgbLds lds;
+  __shared__ float gin_rgb[TEXEL_LUT ? 256 : 1], gin_a[TEXEL_LUT ? 256 : 1];
   load_srgb_tables(lds);
+  if (TEXEL_LUT) {
+    const int t = threadIdx.y * 64 + threadIdx.x;
+    const float k = (float)t * (1.0f / 255.0f);
+    gin_rgb[t] = pow_(L.in.fmt == FMT_SRGB8 ? lds.dec[t] : k, L.params[7]);
+    gin_a[t] = pow_(L.in.fmt == FMT_RGBX8 ? 1.0f : k, L.params[7]);
+    __syncthreads();
+  }
   RC_TILE_LOOP_BEGIN
   const float anti = L.params[6], gin = L.params[7], gout = L.params[8], vs = L.params[9];
   const float* m = &L.params[16];
@@ -115,11 +151,20 @@ __global__ void __launch_bounds__(256) k_crt_hyllian_glow(const PassLaunch L) {
         su -= dyx;
         sv -= dyy;
       }
-      const float4 t = sample_rt(L.in, img, su, sv, &lds);
-      c[r][k][0] = pow_(t.x, gin);
-      c[r][k][1] = pow_(t.y, gin);
-      c[r][k][2] = pow_(t.z, gin);
-      c[r][k][3] = pow_(t.w, gin);
+      if (TEXEL_LUT) {
+        const int sx = clampi((int)__builtin_floorf(su * tsx), 0, L.in.w - 1), sy = clampi((int)__builtin_floorf(sv * tsy), 0, L.in.h - 1);
+        const uint32_t p = *reinterpret_cast<const uint32_t*>(img + texel_off(L.in.w, sx, sy, 4u));
+        c[r][k][0] = gin_rgb[p & 255u];
+        c[r][k][1] = gin_rgb[(p >> 8) & 255u];
+        c[r][k][2] = gin_rgb[(p >> 16) & 255u];
+        c[r][k][3] = gin_a[p >> 24];
+      } else {
+        const float4 t = sample_rt(L.in, img, su, sv, &lds);
+        c[r][k][0] = pow_(t.x, gin);
+        c[r][k][1] = pow_(t.y, gin);
+        c[r][k][2] = pow_(t.z, gin);
+        c[r][k][3] = pow_(t.w, gin);
+      }
     }
   const float l0 = fpx * fpx * fpx, l1 = fpx * fpx, l2 = fpx;
   float ip[4];
@@ -188,10 +233,25 @@ namespace rck {
 #define GOK(K)                                                         \
   hipLaunchKernelGGL(K, px_grid(L), px_block(), 0, s, L);              \
   return hipGetLastError()
-hipError_t launch_glow_linearize(const PassLaunch& L, hipStream_t s) { GOK(k_glow_linearize); }
-hipError_t launch_glow_threshold(const PassLaunch& L, hipStream_t s) { GOK(k_glow_threshold); }
+static bool bytes_nearest_edge(const rcd::Tex& t) {
+  return (t.fmt == FMT_SRGB8 || t.fmt == FMT_RGBA8 || t.fmt == FMT_RGBX8) && !t.linear && t.wrap == WRAP_EDGE && t.n_levels <= 1;
+}
+static bool bytemap_ok(const PassLaunch& L) {
+  return bytes_nearest_edge(L.in) && (L.out_fmt == FMT_SRGB8 || L.out_fmt == FMT_RGBA8) && !(L.flags & RC_FLAG_GENERAL_ONLY);
+}
+hipError_t launch_glow_linearize(const PassLaunch& L, hipStream_t s) {
+  if (bytemap_ok(L)) { GOK(k_glow_bytemap<0>); }
+  GOK(k_glow_linearize);
+}
+hipError_t launch_glow_threshold(const PassLaunch& L, hipStream_t s) {
+  if (bytemap_ok(L)) { GOK(k_glow_bytemap<1>); }
+  GOK(k_glow_threshold);
+}
 hipError_t launch_glow_blur_h(const PassLaunch& L, hipStream_t s) { GOK(k_glow_blur<true>); }
 hipError_t launch_glow_blur_v(const PassLaunch& L, hipStream_t s) { GOK(k_glow_blur<false>); }
-hipError_t launch_crt_hyllian_glow(const PassLaunch& L, hipStream_t s) { GOK(k_crt_hyllian_glow); }
+hipError_t launch_crt_hyllian_glow(const PassLaunch& L, hipStream_t s) {
+  if (bytes_nearest_edge(L.in) && !(L.flags & RC_FLAG_GENERAL_ONLY)) { GOK(k_crt_hyllian_glow<true>); }
+  GOK(k_crt_hyllian_glow<false>);
+}
 hipError_t launch_hyllian_resolve2(const PassLaunch& L, hipStream_t s) { GOK(k_hyllian_resolve2); }
 }  // namespace rck

@@ -147,6 +147,22 @@ def test_hyllian_glow_matches_oracle_and_golden(case, preset_tree, rc_lib):
     e.shutdown()
 
 
+@pytest.mark.parametrize("w,h,vw,vh", [(96, 64, 256, 192), (80, 60, 250, 190), (320, 240, 1366, 768)])
+def test_hyllian_glow_specialised_and_general_forms_agree(w, h, vw, vh, preset_tree, rc_lib):
+    """The byte-map forms of passes 0 and 2 and the texel-LUT form of pass 1 against their general forms, every pass."""
+    from gpu_util import make_engine, run_engine
+    frames = np.random.default_rng(w + vw).integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+    e = make_engine(preset_tree["crt-hyllian-glow"], vw, vh)
+    a = run_engine(e, frames)
+    pa = [e.readPass(i, 1) for i in range(6)]
+    e.setGeneralKernelsOnly(True)
+    b = run_engine(e, frames)
+    for i in range(6):
+        assert np.array_equal(pa[i], e.readPass(i, 1)), "pass %d" % i
+    assert np.array_equal(a, b)
+    e.shutdown()
+
+
 def test_hyllian_glow_1080p_batch_and_unsupported_layout(preset_tree, rc_lib):
     """Full size (1080p, 3 frames in one launch per pass; rows of the final pass spot-checked against the oracle
     through golden-free properties: frames are processed independently, so each frame of the batch equals the
