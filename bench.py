@@ -35,6 +35,7 @@ WORKLOADS = {
     "ntsc": ("ntsc-256px-svideo", 1920, 1080, 1920, 1080,
              "ntsc/ntsc-256px-svideo.glslp 2-pass (RGBA32F 1024x1080 intermediate), 1920x1080 RGBA8 frames"),
     "xbr-lv3": ("xbr-lv3", 256, 224, 3840, 2160, "xbr/xbr-lv3.glslp 1-pass upscale 256x224 -> 3840x2160"),
+    "xbr-lv2": ("xbr-lv2", 256, 224, 3840, 2160, "xbr/xbr-lv2.glslp 1-pass upscale 256x224 -> 3840x2160"),
     "scanline": ("scanline", 320, 240, 320, 240, "scanlines/shaders/scanline.glsl 1-pass, 320x240"),
 }
 

@@ -144,6 +144,7 @@ void o_pass_ntsc_pass2_2phase_gamma(const o_pass_args* a);
 void o_pass_ntsc_pass2_2phase_linear(const o_pass_args* a);
 void o_pass_ntsc_pass2_2phase(const o_pass_args* a);
 void o_pass_xbr_lv3(const o_pass_args* a);            /* 5 params */
+void o_pass_xbr_lv2(const o_pass_args* a);            /* 5 params (small_details < 0.5 only) */
 /* crt/crt-hyllian-glow.glslp (rc_passes_glow.c) */
 void o_pass_glow_linearize(const o_pass_args* a);     /* 1 param */
 void o_pass_crt_hyllian_glow(const o_pass_args* a);   /* 10 params */

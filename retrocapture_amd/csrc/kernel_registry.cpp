@@ -180,6 +180,17 @@ void setupXbrLv3(const PassGeometry& g, rcd::PassLaunch& L) {
   }
 }
 
+// xbr-lv2.glsl:111-117: the same coordinate set as xbr-lv3
+void setupXbrLv2(const PassGeometry& g, rcd::PassLaunch& L) {
+  const float dx = 1.0f / (float)g.in_w, dy = 1.0f / (float)g.in_h;
+  const float xo[5] = {-2.0f * dx, -dx, 0.0f, dx, 2.0f * dx};
+  const float yo[5] = {-2.0f * dy, -dy, 0.0f, dy, 2.0f * dy};
+  for (int k = 0; k < 5; ++k) {
+    L.plane[k] = makePlane(0.f + xo[k], 1.f + xo[k], 1.f + xo[k], 0.f + xo[k], g.out_w, g.out_h, g.out_fmt);
+    L.plane[5 + k] = makePlane(0.f + yo[k], 0.f + yo[k], 1.f + yo[k], 1.f + yo[k], g.out_w, g.out_h, g.out_fmt);
+  }
+}
+
 std::vector<KernelEntry> build() {
   std::vector<KernelEntry> r;
   r.push_back({"stock.glsl", "stock", {}, {}, rck::launch_stock, setupTexCoord, false});
@@ -273,6 +284,21 @@ std::vector<KernelEntry> build() {
                 {"XBR_LV2_COEFFICIENT", 2.0f, 1.0f, 3.0f, 1.0f, "Lv2 Coefficient"},
                 {"corner_type", 3.0f, 1.0f, 3.0f, 1.0f, "Corner Calculation"}},
                {}, rck::launch_xbr_lv3, setupXbrLv3, true, true, nullptr, scratchXbrLv3});
+  {
+    // parity "partial": the shader reads an unassigned variable (oracle/rc_passes_ntsc_xbr.c)
+    KernelEntry e{"xbr/shaders/xbr-lv2.glsl", "xbr-lv2",
+                  {{"XBR_SCALE", 3.0f, 1.0f, 5.0f, 1.0f, "xBR Scale"},   // `//#pragma parameter ...`: the reference's scan is not comment-aware
+                   {"XBR_Y_WEIGHT", 48.0f, 0.0f, 100.0f, 1.0f, "Y Weight"},
+                   {"XBR_EQ_THRESHOLD", 15.0f, 0.0f, 50.0f, 1.0f, "Eq Threshold"},
+                   {"XBR_LV1_COEFFICIENT", 0.5f, 0.0f, 30.0f, 0.5f, "Lv1 Coefficient"},
+                   {"XBR_LV2_COEFFICIENT", 2.0f, 1.0f, 3.0f, 0.1f, "Lv2 Coefficient"},
+                   {"small_details", 0.0f, 0.0f, 1.0f, 1.0f, "Preserve Small Details"}},
+                  {}, rck::launch_xbr_lv2, setupXbrLv2, true};
+    e.validate = [](const float* p) -> const char* {
+      return p[5] < 0.5f ? nullptr : "xbr-lv2.glsl: only the small_details = 0 branch is restated";
+    };
+    r.push_back(e);
+  }
   registerRoyaleKernels(r);
   return r;
 }

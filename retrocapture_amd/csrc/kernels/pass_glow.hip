@@ -87,7 +87,6 @@ __global__ void __launch_bounds__(256) k_glow_blur(const PassLaunch L) {
   const float vy0 = vary(L.plane[1], x, y0, lo), vy1 = vary(L.plane[1], x, y0 + 1, lo);
   const uint8_t* img = frame_ptr(L.in, z);
   float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-#pragma unroll
   for (int i = -4; i <= 4; ++i) {
     const float off = (float)i * step;
     const float su = HORIZ ? u + off : u + 0.0f, sv = HORIZ ? v + 0.0f : v + off;
@@ -141,9 +140,7 @@ __global__ void __launch_bounds__(256) k_crt_hyllian_glow(const PassLaunch L) {
   const float fpx = mix_rt_(frx, fry, vs), fpy = mix_rt_(fry, frx, vs);
   const uint8_t* img = frame_ptr(L.in, z);
   float c[2][4][4];
-#pragma unroll
   for (int r = 0; r < 2; ++r)
-#pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float kx = (float)(k - 1);
       float su = tcx + kx * dxx, sv = tcy + kx * dxy;

@@ -187,6 +187,95 @@ __global__ void __launch_bounds__(256) k_xbr_lv3(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// ----------------------------------------------------------------------------- xbr-lv2 ------
+// xbr/shaders/xbr-lv2.glsl FS 260-361 (CORNER_C, SMOOTH_TIPS, small_details < 0.5), same 5x5 coordinate set.
+// Restated as in oracle/rc_passes_ntsc_xbr.c, including what llvmpipe makes of the shader's unassigned `f4`
+// (reads as `i` in wd1; eq(f, f4) true) - parity "partial", see there.
+// params: XBR_SCALE (unused: a commented-out pragma the reference's scan still lists), XBR_Y_WEIGHT, XBR_EQ_THRESHOLD,
+// XBR_LV1_COEFFICIENT, XBR_LV2_COEFFICIENT, small_details
+__device__ __forceinline__ float lv2_line(float A, float B, float dl, float C, float ci, float fy, float fx) {
+  float num = ((A * fy + B * fx) + dl) - C;
+  if (ci != 0.0f) num = num - ci;
+  float t = num / (2.0f * dl);
+  t = t > 0.0f ? t : 0.0f;
+  return t < 1.0f ? t : 1.0f;
+}
+__device__ __forceinline__ float dot_rgbw(const float4 p) { return p.x * 14.352f + (p.y * 28.176f + p.z * 5.472f); }
+
+// GENERIC false: RGBX8 / RGBA8 NEAREST clamp-to-edge source and a plain RGBA8 target (the shipped preset)
+template <int IN_FMT, bool GENERIC>
+__global__ void __launch_bounds__(256) k_xbr_lv2(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  if (GENERIC) load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float thr = L.params[2], lv2 = L.params[4];
+  const float tsx = (float)L.in.w, tsy = (float)L.in.h;
+  float cx[5], cy[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    cx[k] = vary(L.plane[k], x, y, lo);
+    cy[k] = vary(L.plane[5 + k], x, y, lo);
+  }
+  float fpx = cx[2] * tsx, fpy = cy[2] * tsy;
+  fpx = fpx - __builtin_floorf(fpx);
+  fpy = fpy - __builtin_floorf(fpy);
+  const uint8_t* img = frame_ptr(L.in, z);
+#define T(i, j) (GENERIC ? sample_rt(L.in, img, cx[i], cy[j], &lds) : sample<IN_FMT, 0, WRAP_EDGE>(L.in, img, cx[i], cy[j], &lds))
+  const float4 A1 = T(1, 0), C1 = T(3, 0);
+  const float4 A = T(1, 1), B = T(2, 1), C = T(3, 1);
+  const float4 D = T(1, 2), E = T(2, 2), F = T(3, 2);
+  const float4 G = T(1, 3), H = T(2, 3), I = T(3, 3);
+  const float4 G5 = T(1, 4), H5 = T(2, 4), I5 = T(3, 4);
+  const float4 A0 = T(0, 1), D0 = T(0, 2), G0 = T(0, 3);
+  const float4 C4 = T(4, 1), F4_ = T(4, 2), I4 = T(4, 3), B1 = T(2, 0);
+#undef T
+  const F4 b = F4{{dot_rgbw(B), dot_rgbw(D), dot_rgbw(H), dot_rgbw(F)}}, c = F4{{dot_rgbw(C), dot_rgbw(A), dot_rgbw(G), dot_rgbw(I)}};
+  const float le = dot_rgbw(E);
+  const F4 e = F4{{le, le, le, le}};
+  const F4 d = yzwx(b), f = wxyz(b), g = zwxy(c), h = zwxy(b), i = wxyz(c);
+  const F4 i4 = F4{{dot_rgbw(I4), dot_rgbw(C1), dot_rgbw(A0), dot_rgbw(G5)}}, i5 = F4{{dot_rgbw(I5), dot_rgbw(C4), dot_rgbw(A1), dot_rgbw(G0)}};
+  const F4 h5 = F4{{dot_rgbw(H5), dot_rgbw(F4_), dot_rgbw(B1), dot_rgbw(D0)}};
+  const F4 wd1 = wd(e, c, g, i, h5, i, h, f), wd2 = wd(h, d, i5, f, i4, b, e, i);
+  const float Ao[4] = {1.0f, -1.0f, -1.0f, 1.0f}, Bo[4] = {1.0f, 1.0f, -1.0f, -1.0f}, Co[4] = {1.5f, 0.5f, -0.5f, 0.5f};
+  const float Bx[4] = {0.5f, 2.0f, -0.5f, -2.0f}, Cx[4] = {1.0f, 1.0f, -0.5f, 0.0f};
+  const float By[4] = {2.0f, 0.5f, -2.0f, -0.5f}, Cy[4] = {2.0f, 0.0f, -1.0f, 0.5f};
+  const float third = 1.0f / 3.0f, sixth = 0.5f / 3.0f;
+  const float dl[4] = {sixth, third, sixth, third}, du[4] = {third, sixth, third, sixth};
+  float maximos[4];
+  bool px[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#define EQ(p, q) (df1(p.v[k], q.v[k]) <= thr)
+    const bool ne = e.v[k] != f.v[k] && e.v[k] != h.v[k];
+    const bool t1 = (!EQ(f, b) && !EQ(f, c)) || (!EQ(h, d) && !EQ(h, g));
+    const bool t2 = EQ(e, i) && (!EQ(h, h5) && !EQ(h, i5));
+    const bool t3 = EQ(e, g) || EQ(e, c);
+#undef EQ
+    const bool r1 = ne && (t1 || t2 || t3);
+    const bool r2l = e.v[k] != g.v[k] && d.v[k] != g.v[k], r2u = e.v[k] != c.v[k] && b.v[k] != c.v[k];
+    const float dfg = df1(f.v[k], g.v[k]), dhc = df1(h.v[k], c.v[k]);
+    const bool edri = wd1.v[k] <= wd2.v[k] && ne;
+    const bool edr = wd1.v[k] + 0.1f <= wd2.v[k] && r1;
+    const bool edr_l = lv2 * dfg <= dhc && r2l && edr, edr_u = lv2 * dhc <= dfg && r2u && edr;
+    const float f45 = edr ? lv2_line(Ao[k], Bo[k], third, Co[k], 0.0f, fpy, fpx) : 0.0f;
+    const float f45i = edri ? lv2_line(Ao[k], Bo[k], third, Co[k], 0.25f, fpy, fpx) : 0.0f;
+    const float f30 = edr_l ? lv2_line(Ao[k], Bx[k], dl[k], Cx[k], 0.0f, fpy, fpx) : 0.0f;
+    const float f60 = edr_u ? lv2_line(Ao[k], By[k], du[k], Cy[k], 0.0f, fpy, fpx) : 0.0f;
+    px[k] = df1(e.v[k], f.v[k]) <= df1(e.v[k], h.v[k]);
+    const float m1 = f30 > f60 ? f30 : f60, m2 = f45 > f45i ? f45 : f45i;
+    maximos[k] = m1 > m2 ? m1 : m2;
+  }
+  float4 res1 = mix3(E, px[0] ? F : H, maximos[0]);
+  res1 = mix3(res1, px[2] ? D : B, maximos[2]);
+  float4 res2 = mix3(E, px[1] ? B : F, maximos[1]);
+  res2 = mix3(res2, px[3] ? H : D, maximos[3]);
+  float4 res = c_df(E, res2) < c_df(E, res1) ? res1 : res2;
+  res.w = 0.0f;   // FragColor.xyz only: alpha is never written and comes out 0 on llvmpipe
+  if (GENERIC) store_rt(L, z, x, y, res, &lds);
+  else store<FMT_RGBA8>(L, z, x, y, res, &lds);
+  RC_TILE_LOOP_END
+}
+
 // The general form on the few target rows / columns whose sampling pattern is irregular (listed in
 // L.params by the host, see below); launched after k_xbr_blend on the same stream.
 // grid.x = (rows * ceil(out_w/256) + cols * ceil(out_h/256)), grid.y = frames
@@ -375,6 +464,13 @@ __global__ void __launch_bounds__(256) k_xbr_blend(const PassLaunch L) {
 
 namespace rck {
 
+hipError_t launch_xbr_lv2(const PassLaunch& L, hipStream_t s) {
+  const bool fast = !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8 && !(L.flags & RC_FLAG_GENERAL_ONLY);
+  if (fast && L.in.fmt == FMT_RGBX8) hipLaunchKernelGGL((k_xbr_lv2<FMT_RGBX8, false>), px_grid(L), px_block(), 0, s, L);
+  else if (fast && L.in.fmt == FMT_RGBA8) hipLaunchKernelGGL((k_xbr_lv2<FMT_RGBA8, false>), px_grid(L), px_block(), 0, s, L);
+  else hipLaunchKernelGGL((k_xbr_lv2<FMT_RGBA8, true>), px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
 hipError_t launch_xbr_lv3(const PassLaunch& L, hipStream_t s) {
   const bool shipped = L.in.fmt == FMT_RGBX8 && !L.in.linear && L.out_fmt == FMT_RGBA8 &&
                        (L.in.wrap == WRAP_EDGE || L.in.wrap == WRAP_BORDER);

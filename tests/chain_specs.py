@@ -45,6 +45,7 @@ scale_y1 = 1.0
     "ntsc-2phase-linear": ("ntsc/t-2phase-linear.glslp", _ntsc_preset("composite-2phase", "2phase-linear", 1280)),
     "ntsc-2phase-plain": ("ntsc/t-2phase-plain.glslp", _ntsc_preset("svideo-2phase", "2phase", 1280)),
     "xbr-lv3": ("xbr/xbr-lv3.glslp", 'shaders = 1\n\nshader0 = shaders/xbr-lv3.glsl\nfilter_linear0 = false\n'),
+    "xbr-lv2": ("xbr/xbr-lv2.glslp", 'shaders = 1\n\nshader0 = shaders/xbr-lv2.glsl\nfilter_linear0 = false\n'),
     # same keys / values as the reference's motionblur/mix_frames.glslp
     "mix-frames": ("motionblur/mix_frames.glslp", 'shaders = "1"\n\nshader0 = "shaders/mix_frames.glsl"\nfilter_linear0 = "false"\n'),
     # PassFeedback conformance preset: the stock shader, then this repository's fixture shader
@@ -296,6 +297,11 @@ SHADERS = {
         "oracle": "hyllian_resolve2",
         "params": [("BLOOM_STRENGTH", 0.45), ("OUTPUT_GAMMA", 2.2), ("PHOSPHOR_LAYOUT", 4.0), ("MASK_INTENSITY", 0.5)],
         "samplers": ["PassPrev4Texture"]},
+    "xbr/shaders/xbr-lv2.glsl": {
+        "oracle": "xbr_lv2",
+        "params": [("XBR_SCALE", 3.0), ("XBR_Y_WEIGHT", 48.0), ("XBR_EQ_THRESHOLD", 15.0), ("XBR_LV1_COEFFICIENT", 0.5),
+                   ("XBR_LV2_COEFFICIENT", 2.0), ("small_details", 0.0)],
+        "samplers": []},
     _R + "first-pass-linearize-crt-gamma-bob-fields.glsl": {"oracle": "royale_first", "params": [], "samplers": []},
     _R + "scanlines-vertical-interlacing.glsl": {"oracle": "royale_scan_v", "params": [], "samplers": []},
     _R + "bloom-approx.glsl": {"oracle": "royale_bloom_approx", "params": [], "samplers": ["PassPrev2Texture"]},

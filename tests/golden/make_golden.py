@@ -419,7 +419,15 @@ def case_hyllian_glow():
              params=[("HFILTER_SHARPNESS", 0.7), ("CRT_ANTI_RINGING", 0.6), ("MASK_INTENSITY", 0.7), ("PHOSPHOR_LAYOUT", 5.0)])
 
 
-CASES = {"hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+def case_xbr_lv2():
+    P = GLSL + "/xbr/xbr-lv2.glslp"
+    run_case("xbr_lv2_64x56_to_256x224", P, mixed(64, 56, 80), 256, 224)
+    run_case("xbr_lv2_noise_40x36_to_240x216", P, noise(40, 36, 81), 240, 216)
+    run_case("xbr_lv2_params_48x40_to_331x217", P, mixed(48, 40, 82), 331, 217, params=[("XBR_EQ_THRESHOLD", 25.0), ("XBR_LV2_COEFFICIENT", 1.4)])
+    run_case("f32_xbr_lv2_48x40_to_331x217", P, mixed(48, 40, 83), 331, 217, f32=True)
+
+
+CASES = {"xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

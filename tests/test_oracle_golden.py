@@ -38,6 +38,9 @@ CASES = {
     "xbr_lv3_noise_40x36_to_240x216": "xbr-lv3",
     "xbr_lv3_corner1_40x36_to_200x180": "xbr-lv3",
     "xbr_lv3_corner2_40x36_to_240x216": "xbr-lv3",
+    "xbr_lv2_64x56_to_256x224": "xbr-lv2",
+    "xbr_lv2_noise_40x36_to_240x216": "xbr-lv2",
+    "xbr_lv2_params_48x40_to_331x217": "xbr-lv2",
     "crt_hyllian_glow_96x64_to_256x192": "crt-hyllian-glow",
     "crt_hyllian_glow_80x60_to_250x190": "crt-hyllian-glow",         # pass 3 is 63x48: not viewport / 4, fractional mip LOD
     "crt_hyllian_glow_params_64x48_to_200x150": "crt-hyllian-glow",
@@ -52,7 +55,7 @@ CASES = {
 # crt-royale: every pass that stores to an sRGB8 target can differ from llvmpipe by 1 LSB in
 # ~0.3 % of the bytes, because llvmpipe's sRGB encode runs through the x86 RSQRTPS
 # approximation and is not monotone ("sRGB8 store"); RGBA8 passes must be exact.
-BAR = {"scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1), "crt-royale-fake-bloom": (0.995, 1), "crt-hyllian-glow": (0.98, 1), "ntsc-256px-svideo": (1.0, 0),
+BAR = {"xbr-lv2": (0.999, 1), "scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1), "crt-royale-fake-bloom": (0.995, 1), "crt-hyllian-glow": (0.98, 1), "ntsc-256px-svideo": (1.0, 0),
        "xbr-lv3": (1.0, 0), "mix-frames": (1.0, 0), "feedback-persist": (1.0, 0)}
 
 
@@ -128,7 +131,11 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
             d = np.abs(o.astype(np.int32) - ref.astype(np.int32))
             exact = float((d == 0).mean())
             fmt = str(g["pass%d_fmt" % i])
-            if fmt == "rgba8":
+            if key == "xbr-lv2":
+                # parity "partial" (oracle/rc_passes_ntsc_xbr.c): the shader reads an unassigned variable and the
+                # association of its line-equation sums is not pinned; alpha (never written by the shader) is exact
+                assert d.max() <= 1 and exact >= 0.999, "pass %d: exact %.5f max %d" % (i, exact, d.max())
+            elif fmt == "rgba8":
                 assert d.max() == 0, "RGBA8 pass %d must be bit-exact: exact %.5f max %d" % (i, exact, d.max())
             assert d.max() <= maxdiff and exact >= floor, "pass %d: exact %.5f max %d" % (i, exact, d.max())
         else:
@@ -164,6 +171,7 @@ FLOAT_CASES = {
     # crt-hyllian-glow: passes 0, 2 and 5 bit-identical; the residuals of pass 1 (<= 3e-6 absolute), of the two
     # blurs (1 ulp: the association of the nine-term sum is not pinned) and of the mip-mapped pass 3 are far below
     # an 8-bit step - the 8-bit goldens of every pass match at the sRGB-encode residual and the final pass exactly
+    "f32_xbr_lv2_48x40_to_331x217": ("xbr-lv2", {0: 0.96}),   # parity "partial", see above
     "f32_crt_hyllian_glow_64x48_to_160x120": ("crt-hyllian-glow", {1: 0.93, 3: 0.5, 4: 0.93}),
     "f32_crt_hyllian_glow_64x48_to_150x110": ("crt-hyllian-glow", {1: 0.80, 3: 0.4, 4: 0.93}),
 }
