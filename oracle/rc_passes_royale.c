@@ -140,11 +140,15 @@ static float beam_contrib(float dist, float color, float ph, float sigma_range, 
 void o_pass_royale_scan_v(const o_pass_args* a) {
   ENTER;
   const int W = a->out_w, H = a->out_h;
-  const float tsx = (float)a->in->w, tsy = (float)a->in->h;
+  /* texture_size = TextureSize, video_size = InputSize (glsl :38-39).  They differ in one case: the reference
+   * hands pass index 3 TextureSize.y = the target's height when that is not the input's (ShaderEngine.cpp:
+   * 2418-2421) - which is where this shader sits in crt/crt-royale-ntsc-*.glslp */
+  const float vsy = (float)a->in->h;
+  const float tsx = (float)a->in->w, tsy = (a->pass_index == 3 && H != a->in->h) ? (float)H : vsy;
   uvplanes tc = texcoord_planes(1.0f, W, H, a->out_fmt);
-  const float y_step = 1.0f + (is_interlaced(tsy) ? 1.0f : 0.0f);
+  const float y_step = 1.0f + (is_interlaced(vsy) ? 1.0f : 0.0f);
   const float uv_step_y = y_step / tsy;
-  const float ph = (tsy / (float)H) / y_step;
+  const float ph = (vsy / (float)H) / y_step;
   const float tix = 1.0f / tsx, tiy = 1.0f / tsy;
   const float sigma_range = maxps(beam_max_sigma, beam_min_sigma) - beam_min_sigma;
   const float shape_range = maxps(beam_max_shape, beam_min_shape) - beam_min_shape;

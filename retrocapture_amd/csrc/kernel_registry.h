@@ -55,6 +55,8 @@ struct KernelEntry {
   // The shader never reads TextureSize.y, so the reference's override of that uniform for pass index 3
   // (ShaderEngine.cpp:2418-2421) cannot change its result.
   bool ignores_texture_height = false;
+  // ... or the kernel restates its shader under that override (its setup reads PassGeometry::pass_index).
+  bool texture_height_override = false;
 };
 
 const KernelEntry* findKernel(const std::string& shaderPath);

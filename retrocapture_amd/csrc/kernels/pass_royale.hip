@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256, 4) k_royale_scan_v(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
   RC_TILE_LOOP_BEGIN
-  const float tsx = (float)L.in.w, tsy = (float)L.in.h;
+  const float tsx = (float)L.in.w, tsy = L.params[RP1_TSY];   // TextureSize.y as the reference sets it (royale_setup.cpp)
   const float y_step = L.params[RP1_Y_STEP], uv_step_y = L.params[RP1_UV_STEP_Y], ph = L.params[RP1_PH];
   const float tix = 1.0f / tsx, tiy = 1.0f / tsy;
   const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;

@@ -6,7 +6,7 @@ enum {  // pass 0
   RP0_INTERLACED = 0,
 };
 enum {  // pass 1
-  RP1_Y_STEP = 0, RP1_UV_STEP_Y, RP1_PH,
+  RP1_Y_STEP = 0, RP1_UV_STEP_Y, RP1_PH, RP1_TSY,
 };
 enum {  // blur9 (passes 3, 4)
   RPB_W12 = 0, RPB_W34, RPB_K12, RPB_K34, RPB_SUM_INV, RPB_DX, RPB_DY,

@@ -80,11 +80,16 @@ void setupFirst(const PassGeometry& g, PassLaunch& L) {
 // ---- pass 1: VS 5912-5938
 void setupScanV(const PassGeometry& g, PassLaunch& L) {
   setupTexCoord(g, L, 1.0f);
-  const float tsy = (float)g.in_h;
-  const float y_step = 1.0f + (isInterlaced(tsy) ? 1.0f : 0.0f);
+  // texture_size = TextureSize, video_size = InputSize (glsl :38-39); the reference hands pass index 3
+  // TextureSize.y = the target's height when that differs from the input's (ShaderEngine.cpp:2418-2421),
+  // which is where this shader sits in crt/crt-royale-ntsc-*.glslp
+  const float vsy = (float)g.in_h;
+  const float tsy = (g.pass_index == 3 && g.out_h != g.in_h) ? (float)g.out_h : vsy;
+  const float y_step = 1.0f + (isInterlaced(vsy) ? 1.0f : 0.0f);
   L.params[RP1_Y_STEP] = y_step;
   L.params[RP1_UV_STEP_Y] = y_step / tsy;
-  L.params[RP1_PH] = (tsy / (float)g.out_h) / y_step;
+  L.params[RP1_PH] = (vsy / (float)g.out_h) / y_step;
+  L.params[RP1_TSY] = tsy;
 }
 
 // ---- pass 2: VS 5926-5932
@@ -270,6 +275,7 @@ void registerRoyaleKernels(std::vector<KernelEntry>& r) {
   ids.reserve(16);
   r.push_back({id("first-pass-linearize-crt-gamma-bob-fields.glsl"), "royale-first", {}, {}, rck::launch_royale_first, setupFirst, false});
   r.push_back({id("scanlines-vertical-interlacing.glsl"), "royale-scanlines-v", {}, {}, rck::launch_royale_scan_v, setupScanV, false});
+  r.back().texture_height_override = true;
   r.push_back({id("bloom-approx.glsl"), "royale-bloom-approx", {}, {"PassPrev2Texture"}, rck::launch_royale_bloom_approx, setupBloomApprox, false});
   r.push_back({"blurs/blur9fast-vertical.glsl", "blur9fast-v", {}, {}, rck::launch_blur9, setupBlur9V, false});
   r.push_back({"blurs/blur9fast-horizontal.glsl", "blur9fast-h", {}, {}, rck::launch_blur9, setupBlur9H, false});

@@ -936,7 +936,7 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
                      " target would sample mip levels above 0, which the HIP shader chain does not build");
         return false;
       }
-      if (i == 3 && current.h != L.out_h && !k.size_independent && !k.ignores_texture_height) {
+      if (i == 3 && current.h != L.out_h && !k.size_independent && !k.ignores_texture_height && !k.texture_height_override) {
         // The reference hands pass index 3 TextureSize.y = the TARGET's height whenever that differs from the
         // input's (ShaderEngine.cpp:2418-2421, written for interlacing.glsl) while InputSize and the texture keep
         // the real height.  No registered kernel restates its shader under that mismatch, so refuse rather

@@ -234,9 +234,28 @@ texture_wrap_mode8 = "clamp_to_edge"
 
 }
 
+def _royale_ntsc(pass1, pass2, width):
+    """crt/crt-royale-ntsc-*.glslp: two ntsc passes in front of crt-royale's twelve (same keys / values as the
+    reference's files; frame_count_mod0 is there too - the reference's parser ignores it)."""
+    body = PRESETS["crt-royale"][1]
+    body = re.sub(r'^(\w+?)(\d+) = ', lambda m: "%s%d = " % (m.group(1), int(m.group(2)) + 2), body, flags=re.M)
+    body = body.replace('shaders = "12"\n', "").replace('mipmap_input13 = "false"', 'mipmap_input13 = "true"')
+    head = ('shaders = "14"\nshader0 = "../ntsc/shaders/ntsc-pass1-%s.glsl"\nshader1 = "../ntsc/shaders/ntsc-pass2-%s.glsl"\n'
+            'filter_linear0 = false\nfilter_linear1 = false\nscale_type_x0 = absolute\nscale_type_y0 = source\nscale_x0 = %d\n'
+            'scale_y0 = 1.0\nframe_count_mod0 = 2\nfloat_framebuffer0 = true\nscale_type1 = source\nscale_x1 = 0.5\nscale_y1 = 1.0\n'
+            % (pass1, pass2, width))
+    return head + body
+
+
+import re
+PRESETS["crt-royale-ntsc-256px-svideo"] = ("crt/crt-royale-ntsc-256px-svideo.glslp", _royale_ntsc("svideo-3phase", "3phase", 1536))
+PRESETS["crt-royale-ntsc-320px-composite"] = ("crt/crt-royale-ntsc-320px-composite.glslp", _royale_ntsc("composite-2phase", "2phase", 1280))
+
 # files copied next to a preset: name -> (preset key, relative path below the preset dir, source under tests/golden)
 ASSETS = {"mask_slot_small_64.png": ("crt-royale", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png"),
-          "mask_slot_small_64.png#fake-bloom": ("crt-royale-fake-bloom", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png")}
+          "mask_slot_small_64.png#fake-bloom": ("crt-royale-fake-bloom", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png"),
+          "mask_slot_small_64.png#ntsc-256": ("crt-royale-ntsc-256px-svideo", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png"),
+          "mask_slot_small_64.png#ntsc-320": ("crt-royale-ntsc-320px-composite", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png")}
 
 ROYALE_LAST_PARAMS = [
     ("crt_gamma", 2.5), ("lcd_gamma", 2.2), ("levels_contrast", 1.0), ("halation_weight", 0.0),

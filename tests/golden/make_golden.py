@@ -427,7 +427,18 @@ def case_xbr_lv2():
     run_case("f32_xbr_lv2_48x40_to_331x217", P, mixed(48, 40, 83), 331, 217, f32=True)
 
 
-CASES = {"xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+def case_royale_ntsc():
+    """crt/crt-royale-ntsc-*.glslp (14 passes): the scanlines-vertical pass sits at pass index 3, where the reference
+    overrides TextureSize.y with the target's height (ShaderEngine.cpp:2418-2421); the last pass has mipmap_input."""
+    with tempfile.TemporaryDirectory() as d:
+        luts = royale_luts(d)
+        run_case("crt_royale_ntsc_256px_svideo_96x64_to_320x240", GLSL + "/crt/crt-royale-ntsc-256px-svideo.glslp", mixed(96, 64, 90), 320, 240,
+                 frames=2, luts=luts)
+        run_case("crt_royale_ntsc_320px_composite_80x56_to_300x200", GLSL + "/crt/crt-royale-ntsc-320px-composite.glslp", noise(80, 56, 91), 300, 200,
+                 luts=luts)
+
+
+CASES = {"royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -62,7 +62,8 @@ def royale_luts():
 
 ROYALE_GOLDEN = ["crt_royale_160x120_to_320x240", "crt_royale_128x96_to_400x300",
                  "crt_royale_maskon_160x120_to_320x240", "crt_royale_maskon_96x128_to_512x384",
-                 "crt_royale_fake_bloom_160x120_to_320x240", "crt_royale_fake_bloom_maskon_128x96_to_400x300"]
+                 "crt_royale_fake_bloom_160x120_to_320x240", "crt_royale_fake_bloom_maskon_128x96_to_400x300",
+                 "crt_royale_ntsc_256px_svideo_96x64_to_320x240", "crt_royale_ntsc_320px_composite_80x56_to_300x200"]
 
 
 @pytest.mark.parametrize("case", ROYALE_GOLDEN)
@@ -75,10 +76,11 @@ def test_royale_matches_oracle_and_golden(case, preset_tree, rc_lib):
     vw, vh = [int(v) for v in g["viewport"]]
     maskon = "maskon" in case
     frames = int(g["frames"])
-    key = "crt-royale-fake-bloom" if "fake_bloom" in case else "crt-royale"
+    key = ("crt-royale-fake-bloom" if "fake_bloom" in case else "crt-royale-ntsc-256px-svideo" if "ntsc_256px" in case
+           else "crt-royale-ntsc-320px-composite" if "ntsc_320px" in case else "crt-royale")
     passes = eng.preset_dump(preset_tree[key])["passes"]
     n = len(passes)
-    assert n == (9 if "fake_bloom" in case else 12)
+    assert n == (9 if "fake_bloom" in case else 14 if "ntsc" in case else 12)
     want = run_chain(passes, g["input_rgb"], vw, vh, frame_count=frames, luts=royale_luts(), flags=1 if maskon else 0)
     e = make_engine(preset_tree[key], vw, vh)
     e.setUndefinedVaryingZero(maskon)

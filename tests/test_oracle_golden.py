@@ -38,6 +38,10 @@ CASES = {
     "xbr_lv3_noise_40x36_to_240x216": "xbr-lv3",
     "xbr_lv3_corner1_40x36_to_200x180": "xbr-lv3",
     "xbr_lv3_corner2_40x36_to_240x216": "xbr-lv3",
+    # 14 passes: two ntsc passes, then crt-royale with its scanlines-vertical pass at pass index 3, where the
+    # reference overrides TextureSize.y (ShaderEngine.cpp:2418-2421), and a mip-mapped last pass
+    "crt_royale_ntsc_256px_svideo_96x64_to_320x240": "crt-royale-ntsc-256px-svideo",
+    "crt_royale_ntsc_320px_composite_80x56_to_300x200": "crt-royale-ntsc-320px-composite",
     "xbr_lv2_64x56_to_256x224": "xbr-lv2",
     "xbr_lv2_noise_40x36_to_240x216": "xbr-lv2",
     "xbr_lv2_params_48x40_to_331x217": "xbr-lv2",
@@ -55,7 +59,8 @@ CASES = {
 # crt-royale: every pass that stores to an sRGB8 target can differ from llvmpipe by 1 LSB in
 # ~0.3 % of the bytes, because llvmpipe's sRGB encode runs through the x86 RSQRTPS
 # approximation and is not monotone ("sRGB8 store"); RGBA8 passes must be exact.
-BAR = {"xbr-lv2": (0.999, 1), "scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1), "crt-royale-fake-bloom": (0.995, 1), "crt-hyllian-glow": (0.98, 1), "ntsc-256px-svideo": (1.0, 0),
+BAR = {"xbr-lv2": (0.999, 1), "scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1), "crt-royale-fake-bloom": (0.995, 1), "crt-hyllian-glow": (0.98, 1),
+       "crt-royale-ntsc-256px-svideo": (0.995, 1), "crt-royale-ntsc-320px-composite": (0.995, 1), "ntsc-256px-svideo": (1.0, 0),
        "xbr-lv3": (1.0, 0), "mix-frames": (1.0, 0), "feedback-persist": (1.0, 0)}
 
 
