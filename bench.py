@@ -104,6 +104,26 @@ def pmc_traffic(kernel_name, frames_per_launch):
     return None
 
 
+def pmc_valu(kernel_name, frames_per_launch, avg_launch_ms):
+    """The dominant kernel's real limiter when it is not HBM: VALU wave-instructions per launch from the same
+    committed PMC summary (SQ_INSTS_VALU) over the live launch time, per SIMD (256 CUs x 4), against the issue rate
+    a dependence-free FMA loop reaches on this device (0.53 G/s/SIMD)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_royale_pmc.csv")))
+    if not files or abs(frames_per_launch - 8.0) > 1e-6 or avg_launch_ms <= 0:
+        return None
+    want = {"royale-scanlines-v": "k_royale_scan_v", "royale-bloom-h": "k_royale_bloom_h"}.get(kernel_name, "k_" + kernel_name.replace("-", "_"))
+    for r in csv.DictReader(open(files[-1])):
+        if r["kernel"] == want and r.get("SQ_INSTS_VALU_avg"):
+            insts = float(r["SQ_INSTS_VALU_avg"])
+            rate = insts / (avg_launch_ms * 1e-3) / (256 * 4) / 1e9
+            return {"wave_insts_per_launch": insts, "G_wave_insts_per_s_per_simd": rate, "issue_ceiling_G_per_s_per_simd": 0.53,
+                    "frac_of_issue_ceiling": rate / 0.53,
+                    "note": "this kernel is VALU-issue-bound (bit-exact polynomial pow/exp of the reference GL), not HBM-bound"}
+    return None
+
+
 def copy_ceiling(torch, mib=1024, reps=20):
     """Achieved stream-copy rate of this box (SURVEY.md section 8d asks for it beside the 8 TB/s vendor
     peak): device-to-device copy of `mib` MiB, read + write bytes over the HIP-event time."""
@@ -353,7 +373,8 @@ def main():
                      "traffic": pmc_traffic(infos[dom]["kernel"], frames_per_launch),
                      "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "frac_of_copy_ceiling": achieved / ceiling},
+                     "frac_of_copy_ceiling": achieved / ceiling,
+                     "valu": pmc_valu(infos[dom]["kernel"], frames_per_launch, avg_ms)},
         "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in prof],
     }
     if args.io and rank == 0:

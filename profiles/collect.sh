@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for the default bench workload on the GPU box (run through gpurun from the repo
+# root): per-kernel time statistics, then hardware counters in separate --pmc passes (never combined with other trace
+# domains).  Raw output goes to gpurun_out/prof/, the summaries judged live in profiles/ (profiles/summarize.py).
+set -e
+REPO="${GRAFT_REPO_ROOT:-$(pwd)}"
+OUT="$REPO/gpurun_out/prof"
+rm -rf "$OUT" && mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o royale -- python3 "$REPO/bench.py" --no-cpu-baseline > "$OUT/bench_stats.json" 2> "$OUT/stats.err"
+echo "stats done"
+i=0
+for CTRS in "SQ_WAVES SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i + 1))
+  rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d "$OUT/pmc$i" -o royale -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_pmc$i.json" 2> "$OUT/pmc$i.err"
+  echo "pmc pass $i ($CTRS) done"
+done
+python3 "$REPO/profiles/summarize.py" "$OUT" "$OUT"
