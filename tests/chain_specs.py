@@ -84,6 +84,11 @@ srgb_framebuffer4 = true
 shader5 = shaders/hyllian/crt-hyllian-glow/resolve2.glsl
 filter_linear5 = true
 """),
+    # same keys / values as the reference's interpolation/sharp-bilinear-2x-prescale.glslp and bilinear.glslp
+    "sharp-bilinear-2x": ("interpolation/sharp-bilinear-2x-prescale.glslp",
+                          'shaders = 2\nshader0 = ../stock.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 2.0\n'
+                          'shader1 = ../stock.glsl\nfilter_linear1 = true'),
+    "bilinear": ("bilinear.glslp", 'shaders = 1\n\nshader0 = stock.glsl\nfilter_linear0 = true\n'),
     "stock": ("stock.glslp", 'shaders = "1"\nshader0 = "stock.glsl"\nfilter_linear0 = "false"\n'),
     # Same keys / values as the reference's crt/crt-royale.glslp for the 12 passes, including the
     # three `"true" # comment` booleans that its parser reads as false; only the LUT that the

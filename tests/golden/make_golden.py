@@ -438,7 +438,15 @@ def case_royale_ntsc():
                  luts=luts)
 
 
-CASES = {"royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+def case_stock_presets():
+    """The reference's presets built from stock.glsl alone: bilinear (GL_RGB source, LINEAR) and
+    sharp-bilinear-2x-prescale (NEAREST 2x, then a LINEAR copy of an RGBA8 target: llvmpipe's blit fast path)."""
+    run_case("bilinear_64x48_to_237x171", GLSL + "/bilinear.glslp", mixed(64, 48, 95), 237, 171)
+    run_case("sharp_bilinear_2x_64x48_to_300x210", GLSL + "/interpolation/sharp-bilinear-2x-prescale.glslp", mixed(64, 48, 96), 300, 210)
+    run_case("sharp_bilinear_2x_120x90_to_160x100", GLSL + "/interpolation/sharp-bilinear-2x-prescale.glslp", noise(120, 90, 97), 160, 100)
+
+
+CASES = {"stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -145,6 +145,23 @@ def test_xbr_lv2_matches_oracle_and_golden(case, preset_tree, rc_lib):
     e.shutdown()
 
 
+@pytest.mark.parametrize("case,key", [("bilinear_64x48_to_237x171", "bilinear"), ("sharp_bilinear_2x_64x48_to_300x210", "sharp-bilinear-2x"),
+                                      ("sharp_bilinear_2x_120x90_to_160x100", "sharp-bilinear-2x")])
+def test_stock_presets_match_llvmpipe_golden(case, key, preset_tree, rc_lib):
+    """The reference's presets made of stock.glsl alone, every pass bit-exact against llvmpipe (the second pass of
+    sharp-bilinear-2x-prescale is a LINEAR copy of an RGBA8 target: llvmpipe's blit fast path)."""
+    from gpu_util import make_engine, run_engine
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    vw, vh = [int(v) for v in g["viewport"]]
+    e = make_engine(preset_tree[key], vw, vh)
+    final = run_engine(e, g["input_rgb"])
+    n = int(g["n_passes"])
+    for i in range(n):
+        assert np.array_equal(e.readPass(i, 0), g["pass%d" % i]), "pass %d" % i
+    assert np.array_equal(final[0], g["pass%d" % (n - 1)])
+    e.shutdown()
+
+
 HYLLIAN_GOLDEN = ["crt_hyllian_glow_96x64_to_256x192", "crt_hyllian_glow_80x60_to_250x190", "crt_hyllian_glow_params_64x48_to_200x150"]
 
 

@@ -42,6 +42,9 @@ CASES = {
     # reference overrides TextureSize.y (ShaderEngine.cpp:2418-2421), and a mip-mapped last pass
     "crt_royale_ntsc_256px_svideo_96x64_to_320x240": "crt-royale-ntsc-256px-svideo",
     "crt_royale_ntsc_320px_composite_80x56_to_300x200": "crt-royale-ntsc-320px-composite",
+    "bilinear_64x48_to_237x171": "bilinear",
+    "sharp_bilinear_2x_64x48_to_300x210": "sharp-bilinear-2x",
+    "sharp_bilinear_2x_120x90_to_160x100": "sharp-bilinear-2x",
     "xbr_lv2_64x56_to_256x224": "xbr-lv2",
     "xbr_lv2_noise_40x36_to_240x216": "xbr-lv2",
     "xbr_lv2_params_48x40_to_331x217": "xbr-lv2",
