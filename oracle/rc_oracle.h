@@ -117,7 +117,7 @@ void o_pass_scanline(const o_pass_args* a);
 void o_pass_crt_pi(const o_pass_args* a);
 void o_pass_feedback_persist(const o_pass_args* a);   /* fixture; extra = PassFeedback0, PassFeedback1; 1 param */
 void o_pass_mix_frames(const o_pass_args* a);         /* extra[0] = PrevTexture (frame history) */
-/* crt-royale (shaders/shaders_glsl/crt/shaders/crt-royale/src/*.glsl, blurs/blur9fast-*.glsl) */
+/* crt-royale (shaders/shaders_glsl/crt/shaders/crt-royale/src/ and blurs/blur9fast-{vertical,horizontal}.glsl) */
 void o_pass_royale_first(const o_pass_args* a);       /* P0  first-pass-linearize-crt-gamma-bob-fields */
 void o_pass_royale_scan_v(const o_pass_args* a);      /* P1  scanlines-vertical-interlacing */
 void o_pass_royale_bloom_approx(const o_pass_args* a);/* P2  bloom-approx; extra[0] = PassPrev2Texture */

@@ -65,7 +65,7 @@ static o_varying plane_v(float at0, float at1, int W, int H, int fmt) { return o
 void o_pass_royale_first(const o_pass_args* a) {
   ENTER;
   const int W = a->out_w, H = a->out_h;
-  const float tsx = (float)a->in->w, tsy = (float)a->in->h; /* texture_size == video_size */
+  const float tsy = (float)a->in->h; /* texture_size == video_size */
   uvplanes tc = texcoord_planes(1.00001f, W, H, a->out_fmt);
   const float uv_step_y = 1.0f / tsy;
   const float interlaced = is_interlaced(tsy) ? 1.0f : 0.0f;
