@@ -230,3 +230,45 @@ void o_pass_feedback_persist(const o_pass_args* a) {
   o_pass_feedback_persist_body(a);
   o_fp_leave(csr);
 }
+
+/* crt/shaders/zfast_crt.glsl (crt/zfast-crt.glslp), FINEMASK as the file defines it; VS 101-108, FS 168-198.
+ * params: BLURSCALEX, LOWLUMSCAN, HILUMSCAN, BRIGHTBOOST, MASK_DARK, MASK_FADE - the six names the reference
+ * overwrites with fixed values after the pragma parameters (ShaderEngine.cpp:2260-2294), so they always arrive as
+ * 0.30, 6, 8, 1.25, 0.25, 0.8 whatever the user or the preset says. */
+static void o_pass_zfast_crt_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float blur = a->params[0], lowlum = a->params[1], hilum = a->params[2], boost = a->params[3], mdark = a->params[4], mfade = a->params[5];
+  const float tsx = (float)a->in->w, tsy = (float)a->in->h;
+  o_varying tu = o_varying_setup(0.f * 1.0001f, 1.f * 1.0001f, 1.f * 1.0001f, 0.f * 1.0001f, W, H, a->out_fmt);
+  o_varying tv = o_varying_setup(0.f * 1.0001f, 0.f * 1.0001f, 1.f * 1.0001f, 1.f * 1.0001f, W, H, a->out_fmt);
+  const float mask_fade = 0.3333f * mfade, idx = 1.0f / tsx, idy = 1.0f / tsy;
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      const float px = u * tsx, py = v * tsy;
+      const float ix = floorf(px) + 0.5f, iy = floorf(py) + 0.5f;
+      const float fx = px - ix, fy = py - iy;
+      float qx = (ix + ((4.0f * fx) * fx) * fx) * idx;
+      const float qy = (iy + ((4.0f * fy) * fy) * fy) * idy;
+      qx = qx + blur * (u - qx);
+      const float Y = fy * fy, YY = Y * Y;
+      const float wm0 = floorf((u * (float)W) * -0.4999f);
+      const float whichmask = wm0 - floorf(wm0);
+      const float mask = 1.0f + (whichmask < 0.5f ? 1.0f : 0.0f) * -mdark;
+      const o_vec4 c = o_sample(a->in, qx, qy);
+      const float slw = boost - lowlum * (Y - 2.05f * YY);
+      const float slwb = 1.0f - hilum * (YY - (2.8f * YY) * Y);
+      /* dot(colour, vec3(maskFade)): the splat factor is pulled out of the sum, a*m + (b*m + c*m) -> (a + (b + c))*m */
+      const float d = (c.x + (c.y + c.z)) * mask_fade;
+      const float m0 = slw * mask;
+      const float w = m0 + d * (slwb - m0);
+      const o_vec4 o = {c.x * w, c.y * w, c.z * w, 1.0f};
+      store_px(a, x, y, o);
+    }
+}
+void o_pass_zfast_crt(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  o_pass_zfast_crt_body(a);
+  o_fp_leave(csr);
+}

@@ -210,6 +210,15 @@ std::vector<KernelEntry> build() {
                 {"INPUT_GAMMA", 2.4f, 0.0f, 5.0f, 0.01f, "Input gamma"},
                 {"OUTPUT_GAMMA", 2.2f, 0.0f, 5.0f, 0.01f, "Output gamma"}},
                {}, rck::launch_crt_pi, setupCrtPi, false});
+  // crt/zfast-crt.glslp: the six parameters are the names the reference overwrites with fixed values (shader_engine.cpp)
+  r.push_back({"crt/shaders/zfast_crt.glsl", "zfast-crt",
+               {{"BLURSCALEX", 0.30f, 0.0f, 1.0f, 0.05f, "Blur Amount X-Axis"},
+                {"LOWLUMSCAN", 6.0f, 0.0f, 10.0f, 0.5f, "Scanline Darkness - Low"},
+                {"HILUMSCAN", 8.0f, 0.0f, 50.0f, 1.0f, "Scanline Darkness - High"},
+                {"BRIGHTBOOST", 1.25f, 0.5f, 1.5f, 0.05f, "Dark Pixel Brightness Boost"},
+                {"MASK_DARK", 0.25f, 0.0f, 1.0f, 0.05f, "Mask Effect Amount"},
+                {"MASK_FADE", 0.8f, 0.0f, 1.0f, 0.05f, "Mask/Scanline Fade"}},
+               {}, rck::launch_zfast_crt, setupCrtPi, false});
   // crt/crt-hyllian-glow.glslp, the reference's smoke-test default preset (kernels/pass_glow.hip)
   r.push_back({"crt/shaders/glow/linearize.glsl", "glow-linearize", {{"INPUT_GAMMA", 2.4f, 2.0f, 2.6f, 0.02f, "Input Gamma"}}, {},
                rck::launch_glow_linearize, setupTexCoord, false});

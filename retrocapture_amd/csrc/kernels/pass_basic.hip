@@ -118,6 +118,41 @@ __global__ void __launch_bounds__(256) k_feedback_persist(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// crt/shaders/zfast_crt.glsl (FINEMASK), VS 101-108, FS 168-198; plane[0], plane[1]: TEX0 = TexCoord * 1.0001.
+// params: BLURSCALEX, LOWLUMSCAN, HILUMSCAN, BRIGHTBOOST, MASK_DARK, MASK_FADE (always the reference's fixed values,
+// ShaderEngine.cpp:2260-2294)
+// GENERIC false: GL_RGB source (RGBX8) LINEAR clamp-to-edge and a plain RGBA8 target - the shipped single-pass preset
+template <bool GENERIC>
+__global__ void __launch_bounds__(256) k_zfast_crt(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  if (GENERIC) load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float blur = L.params[0], lowlum = L.params[1], hilum = L.params[2], boost = L.params[3], mdark = L.params[4];
+  const float mask_fade = 0.3333f * L.params[5];
+  const float tsx = (float)L.in.w, tsy = (float)L.in.h, idx = 1.0f / tsx, idy = 1.0f / tsy;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float px = u * tsx, py = v * tsy;
+  const float ix = __builtin_floorf(px) + 0.5f, iy = __builtin_floorf(py) + 0.5f;
+  const float fx = px - ix, fy = py - iy;
+  float qx = (ix + ((4.0f * fx) * fx) * fx) * idx;
+  const float qy = (iy + ((4.0f * fy) * fy) * fy) * idy;
+  qx = qx + blur * (u - qx);
+  const float Y = fy * fy, YY = Y * Y;
+  const float wm0 = __builtin_floorf((u * (float)L.out_w) * -0.4999f);
+  const float whichmask = wm0 - __builtin_floorf(wm0);
+  const float mask = 1.0f + (whichmask < 0.5f ? 1.0f : 0.0f) * -mdark;
+  const float4 c = GENERIC ? sample_rt(L.in, frame_ptr(L.in, z), qx, qy, &lds)
+                           : sample<FMT_RGBX8, 1, WRAP_EDGE>(L.in, frame_ptr(L.in, z), qx, qy, &lds);
+  const float slw = boost - lowlum * (Y - 2.05f * YY);
+  const float slwb = 1.0f - hilum * (YY - (2.8f * YY) * Y);
+  const float d = (c.x + (c.y + c.z)) * mask_fade;
+  const float m0 = slw * mask;
+  const float w = m0 + d * (slwb - m0);
+  if (GENERIC) store_rt(L, z, x, y, make_float4(c.x * w, c.y * w, c.z * w, 1.0f), &lds);
+  else store<FMT_RGBA8>(L, z, x, y, make_float4(c.x * w, c.y * w, c.z * w, 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
 __device__ __forceinline__ float crtpi_weight(float dist, float sw, float gap) {
   float w = 1.0f - (dist * dist) * sw;
   return w > gap ? w : gap;
@@ -198,6 +233,13 @@ hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s) {
 }
 hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_scanline, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_zfast_crt(const PassLaunch& L, hipStream_t s) {
+  const bool fast = L.in.fmt == FMT_RGBX8 && L.in.linear && L.in.wrap == WRAP_EDGE && L.in.n_levels <= 1 && L.out_fmt == FMT_RGBA8 &&
+                    !(L.flags & RC_FLAG_GENERAL_ONLY);
+  if (fast) hipLaunchKernelGGL(k_zfast_crt<false>, px_grid(L), px_block(), 0, s, L);
+  else hipLaunchKernelGGL(k_zfast_crt<true>, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }
 hipError_t launch_crt_pi(const PassLaunch& L, hipStream_t s) {

@@ -329,17 +329,18 @@ __device__ __forceinline__ float4 sample_linear_u8(const Tex& t, const uint8_t* 
   uint32_t p10 = *reinterpret_cast<const uint32_t*>(img + texel_off(t.w, x1, y0, 4u));
   uint32_t p01 = *reinterpret_cast<const uint32_t*>(img + texel_off(t.w, x0, y1, 4u));
   uint32_t p11 = *reinterpret_cast<const uint32_t*>(img + texel_off(t.w, x1, y1, 4u));
-  float o[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    int a = (p00 >> (8 * c)) & 255, b = (p10 >> (8 * c)) & 255, cc = (p01 >> (8 * c)) & 255, d = (p11 >> (8 * c)) & 255;
-    if (c == 3 && FMT == FMT_RGBX8) a = b = cc = d = 255;
-    int top = (a + ((wx * (b - a) + 128) >> 8)) & 255;
-    int bot = (cc + ((wx * (d - cc) + 128) >> 8)) & 255;
-    int r = (top + ((wy * (bot - top) + 128) >> 8)) & 255;
-    o[c] = (float)r * (1.0f / 255.0f);
-  }
-  return make_float4(o[0], o[1], o[2], o[3]);
+  // a + ((w*(b - a) + 128) >> 8) == (a*(256 - w) + b*w + 128) >> 8 with every term non-negative and at most
+  // 255*256 + 128 < 2^16: two channels are filtered per 32-bit operation (red|blue and green|alpha lanes).
+  const uint32_t ux = (uint32_t)wx, uy = (uint32_t)wy, M = 0x00ff00ffu, R = 0x00800080u;
+  const uint32_t top_rb = (((p00 & M) * (256u - ux) + (p10 & M) * ux + R) >> 8) & M;
+  const uint32_t bot_rb = (((p01 & M) * (256u - ux) + (p11 & M) * ux + R) >> 8) & M;
+  const uint32_t rb = ((top_rb * (256u - uy) + bot_rb * uy + R) >> 8) & M;
+  const uint32_t top_ga = ((((p00 >> 8) & M) * (256u - ux) + ((p10 >> 8) & M) * ux + R) >> 8) & M;
+  const uint32_t bot_ga = ((((p01 >> 8) & M) * (256u - ux) + ((p11 >> 8) & M) * ux + R) >> 8) & M;
+  const uint32_t ga = ((top_ga * (256u - uy) + bot_ga * uy + R) >> 8) & M;
+  const float k = 1.0f / 255.0f;
+  return make_float4((float)(rb & 255u) * k, (float)(ga & 255u) * k, (float)(rb >> 16) * k,
+                     FMT == FMT_RGBX8 ? 1.0f : (float)(ga >> 16) * k);
 }
 
 template <int FMT, int LINEAR, int WRAP>

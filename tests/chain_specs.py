@@ -89,6 +89,7 @@ filter_linear5 = true
                           'shaders = 2\nshader0 = ../stock.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 2.0\n'
                           'shader1 = ../stock.glsl\nfilter_linear1 = true'),
     "bilinear": ("bilinear.glslp", 'shaders = 1\n\nshader0 = stock.glsl\nfilter_linear0 = true\n'),
+    "zfast-crt": ("crt/zfast-crt.glslp", 'shaders = 1\n\nshader0 = shaders/zfast_crt.glsl\nfilter_linear0 = true'),
     "stock": ("stock.glslp", 'shaders = "1"\nshader0 = "stock.glsl"\nfilter_linear0 = "false"\n'),
     # Same keys / values as the reference's crt/crt-royale.glslp for the 12 passes, including the
     # three `"true" # comment` booleans that its parser reads as false; only the LUT that the
@@ -305,6 +306,11 @@ SHADERS = {
         "oracle": "xbr_lv3",
         "params": [("XBR_Y_WEIGHT", 48.0), ("XBR_EQ_THRESHOLD", 10.0), ("XBR_EQ_THRESHOLD2", 2.0),
                    ("XBR_LV2_COEFFICIENT", 2.0), ("corner_type", 3.0)],
+        "samplers": []},
+    "crt/shaders/zfast_crt.glsl": {
+        "oracle": "zfast_crt",
+        "params": [("BLURSCALEX", 0.30), ("LOWLUMSCAN", 6.0), ("HILUMSCAN", 8.0), ("BRIGHTBOOST", 1.25), ("MASK_DARK", 0.25),
+                   ("MASK_FADE", 0.8)],
         "samplers": []},
     "crt/shaders/glow/linearize.glsl": {"oracle": "glow_linearize", "params": [("INPUT_GAMMA", 2.4)], "samplers": []},
     "crt/shaders/hyllian/crt-hyllian-glow/crt-hyllian-glow.glsl": {

@@ -446,7 +446,16 @@ def case_stock_presets():
     run_case("sharp_bilinear_2x_120x90_to_160x100", GLSL + "/interpolation/sharp-bilinear-2x-prescale.glslp", noise(120, 90, 97), 160, 100)
 
 
-CASES = {"stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+def case_zfast():
+    """crt/zfast-crt.glslp; its six parameters are the ones the reference hard-codes (ShaderEngine.cpp:2260-2294), so a
+    value set by the user must not show (second case)."""
+    P = GLSL + "/crt/zfast-crt.glslp"
+    run_case("zfast_crt_96x64_to_301x217", P, mixed(96, 64, 100), 301, 217)
+    run_case("zfast_crt_custom_ignored_80x60_to_320x240", P, noise(80, 60, 101), 320, 240, params=[("BLURSCALEX", 0.9), ("MASK_DARK", 0.6)])
+    run_case("f32_zfast_crt_64x48_to_200x150", P, mixed(64, 48, 102), 200, 150, f32=True)
+
+
+CASES = {"zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -46,6 +46,10 @@ def pass_sizes(passes, w, h, vw, vh):
     return out
 
 
+# ShaderEngine.cpp:2260-2294: uniforms the reference overwrites with fixed values on every draw
+HARD_CODED = {"BLURSCALEX": 0.30, "LOWLUMSCAN": 6.0, "HILUMSCAN": 8.0, "BRIGHTBOOST": 1.25, "MASK_DARK": 0.25, "MASK_FADE": 0.8}
+
+
 class ChainState:
     """What the reference keeps between frames (ShaderEngine.h:140-143 and the GL objects' own state):
     the frame-history ring (newest first, at most 7), the texture bound to every texture unit, and
@@ -164,6 +168,8 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
             v = default
             if custom and name in custom:
                 v = custom[name]
+            if name in HARD_CODED:          # written after the pragma parameters, whatever they were
+                v = HARD_CODED[name]
             if global_params and name in global_params:
                 v = global_params[name]
             params.append(v)

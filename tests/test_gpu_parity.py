@@ -145,7 +145,8 @@ def test_xbr_lv2_matches_oracle_and_golden(case, preset_tree, rc_lib):
     e.shutdown()
 
 
-@pytest.mark.parametrize("case,key", [("bilinear_64x48_to_237x171", "bilinear"), ("sharp_bilinear_2x_64x48_to_300x210", "sharp-bilinear-2x"),
+@pytest.mark.parametrize("case,key", [("zfast_crt_96x64_to_301x217", "zfast-crt"), ("zfast_crt_custom_ignored_80x60_to_320x240", "zfast-crt"),
+                                      ("bilinear_64x48_to_237x171", "bilinear"), ("sharp_bilinear_2x_64x48_to_300x210", "sharp-bilinear-2x"),
                                       ("sharp_bilinear_2x_120x90_to_160x100", "sharp-bilinear-2x")])
 def test_stock_presets_match_llvmpipe_golden(case, key, preset_tree, rc_lib):
     """The reference's presets made of stock.glsl alone, every pass bit-exact against llvmpipe (the second pass of
@@ -154,11 +155,16 @@ def test_stock_presets_match_llvmpipe_golden(case, key, preset_tree, rc_lib):
     g = np.load(os.path.join(GOLD, case + ".npz"))
     vw, vh = [int(v) for v in g["viewport"]]
     e = make_engine(preset_tree[key], vw, vh)
+    if "param_names" in g:   # zfast-crt: the reference overwrites these uniforms after the user's values (ShaderEngine.cpp:2260-2294)
+        for k, v in zip(g["param_names"], g["param_values"]):
+            assert e.setShaderParameter(str(k), float(v))
     final = run_engine(e, g["input_rgb"])
     n = int(g["n_passes"])
     for i in range(n):
         assert np.array_equal(e.readPass(i, 0), g["pass%d" % i]), "pass %d" % i
     assert np.array_equal(final[0], g["pass%d" % (n - 1)])
+    e.setGeneralKernelsOnly(True)     # the run-time-sampler forms give the same bytes
+    assert np.array_equal(run_engine(e, g["input_rgb"])[0], final[0])
     e.shutdown()
 
 
@@ -504,7 +510,7 @@ def test_full_size_properties(preset_tree, rc_lib):
     e.shutdown()
 
 
-@pytest.mark.parametrize("key", ["crt-hyllian-glow", "crt-royale", "crt-royale-fake-bloom", "crt-pi", "scanline", "ntsc-256px-svideo", "ntsc-320px", "xbr-lv3"])
+@pytest.mark.parametrize("key", ["zfast-crt", "crt-hyllian-glow", "crt-royale", "crt-royale-fake-bloom", "crt-pi", "scanline", "ntsc-256px-svideo", "ntsc-320px", "xbr-lv3"])
 def test_smoke_statistics_like_the_reference(key, preset_tree, rc_lib):
     """The reference's only end-to-end check (tools/smoke-test.sh:221-300) restated: on its synthetic
     colour-bar source (VideoCaptureTestPattern.cpp:65-101) the shaded frame is not black, has variance,
