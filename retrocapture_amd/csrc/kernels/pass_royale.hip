@@ -224,6 +224,72 @@ __global__ void __launch_bounds__(256, 4) k_royale_scan_v(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// One pixel's inputs to the nine beam evaluations: colours and distances, index = scanline * 3 + channel.
+template <class SI>
+__device__ __forceinline__ void scan_v_gather(const PassLaunch& L, const SrgbLds& lds, int x, int y, int z, float* col, float* dd) {
+  const bool lo = rcd::lower_tri(x, y, L.out_w, L.out_h);
+  const float tsx = (float)L.in.w, tsy = L.params[RP1_TSY];
+  const float y_step = L.params[RP1_Y_STEP], uv_step_y = L.params[RP1_UV_STEP_Y];
+  const float tix = 1.0f / tsx, tiy = 1.0f / tsy;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float frame_count = (float)(L.frame_count0 + z);
+  const float field_offset = __builtin_floorf(y_step * 0.75f) * mod_glsl(frame_count + 0.0f, 2.0f);
+  const float ctx = u * tsx, cty = v * tsy;
+  const float ptx = __builtin_floorf(ctx - kUnderHalf), pty = __builtin_floorf(cty - kUnderHalf);
+  const float wrong_field = mod_glsl(pty + field_offset, y_step);
+  const float stx = (ptx - 0.0f) + 0.5f, sty = (pty - wrong_field) + 0.5f;
+  const float su = stx * tix, sv = sty * tiy;
+  const float dist = (cty - sty) / y_step;
+  const uint8_t* img = frame_ptr(L.in, z);
+  const float4 s2 = SI::get(L.in, img, su, sv, &lds);
+  const float4 s3 = SI::get(L.in, img, su + 0.0f, sv + uv_step_y, &lds);
+  const float dist_round = __builtin_rintf(dist);
+  const float off_x = mix_rt(-0.0f, 2.0f * 0.0f, dist_round);
+  const float off_y = mix_rt(-uv_step_y, 2.0f * uv_step_y, dist_round);
+  const float4 so = SI::get(L.in, img, su + off_x, sv + off_y, &lds);
+  const float conv_y[3] = {0.2f, 0.4f, 0.6f};
+  col[0] = s2.x; col[1] = s2.y; col[2] = s2.z; col[3] = s3.x; col[4] = s3.y; col[5] = s3.z; col[6] = so.x; col[7] = so.y; col[8] = so.z;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    dd[ch] = dist - conv_y[ch];
+    dd[3 + ch] = __builtin_fabsf((1.0f + conv_y[ch]) - dist);
+    dd[6 + ch] = mix_rt(dist + (1.0f - conv_y[ch]), (2.0f + conv_y[ch]) - dist, dist_round);
+  }
+}
+
+// Two vertically adjacent pixels per thread: the nine evaluations of one pixel leave one scalar evaluation next to
+// four packed pairs; pairing evaluation j of the upper pixel with evaluation j of the lower one makes all nine packed
+// (rc_vecmath.h).  Tiles are 64 x 8; a wave still stores 256 contiguous bytes per row.  Same results as k_royale_scan_v.
+template <class SI, class SO>
+__global__ void __launch_bounds__(256, 4) k_royale_scan_v2(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  const int tiles_x = (L.out_w + 63) >> 6, tiles_y = (L.out_h + 7) >> 3;
+  const int tiles_per_frame = tiles_x * tiles_y, n_tiles = tiles_per_frame * L.n_frames;
+  const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
+  const float off = L.params[RP1_PH] / 3.0f;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int z = tile / tiles_per_frame, rem = tile - z * tiles_per_frame;
+    const int ty = rem / tiles_x;
+    const int x = (rem - ty * tiles_x) * 64 + (int)threadIdx.x, y0 = ty * 8 + (int)threadIdx.y * 2;
+    if (x >= L.out_w || y0 >= L.out_h) continue;
+    const bool two = y0 + 1 < L.out_h;
+    float ca[9], da[9], cb[9], db[9];
+    scan_v_gather<SI>(L, lds, x, y0, z, ca, da);
+    scan_v_gather<SI>(L, lds, x, two ? y0 + 1 : y0, z, cb, db);
+    float ka[9], kb[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const v2f k = beam_k<v2f, SI::kUnitRange>(v2f{ca[j], cb[j]}, v2f{da[j], db[j]}, off, sigma_range, shape_range);
+      ka[j] = k.x;
+      kb[j] = k.y;
+    }
+    SO::put(L, z, x, y0, make_float4(((ka[0] + ka[3]) + ka[6]) * 0.5f, ((ka[1] + ka[4]) + ka[7]) * 0.5f, ((ka[2] + ka[5]) + ka[8]) * 0.5f, 1.0f), &lds);
+    if (two)
+      SO::put(L, z, x, y0 + 1, make_float4(((kb[0] + kb[3]) + kb[6]) * 0.5f, ((kb[1] + kb[4]) + kb[7]) * 0.5f, ((kb[2] + kb[5]) + kb[8]) * 0.5f, 1.0f), &lds);
+  }
+}
+
 // ------------------------------------------------------------------------------- P2 ------
 // bloom-approx.glsl FS 14053-14184: the only live statement samples extra[0] at tex_uv.
 template <class S0, class SO>
@@ -602,7 +668,13 @@ RC_LAUNCH(launch_royale_mask_h, k_royale_mask_h)
 using OutS = St<FMT_SRGB8>;
 
 hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s) {
-  if (SrgbLinEdge::matches(L.in) && OutS::matches(L)) GO(k_royale_scan_v<SrgbLinEdge, OutS>);
+  if (SrgbLinEdge::matches(L.in) && OutS::matches(L)) {
+    if (L.flags & RC_FLAG_GENERAL_ONLY) GO((k_royale_scan_v<SrgbLinEdge, OutS>));
+    // two rows per thread: 64 x 8 tiles
+    const long tiles = (long)((L.out_w + 63) / 64) * ((L.out_h + 7) / 8) * L.n_frames;
+    hipLaunchKernelGGL((k_royale_scan_v2<SrgbLinEdge, OutS>), dim3((unsigned)(tiles < 2048 ? (tiles > 0 ? tiles : 1) : 2048)), px_block(), 0, s, L);
+    return hipGetLastError();
+  }
   GO(k_royale_scan_v<SRT, StRT>);
 }
 hipError_t launch_royale_bloom_approx(const PassLaunch& L, hipStream_t s) {
