@@ -99,8 +99,10 @@ def pmc_traffic(kernel_name, frames_per_launch):
     alias = {"k_royale_scanlines_v": "k_royale_scan_v", "k_royale_scanlines_h": "k_royale_scan_h",
              "k_royale_bloom_horizontal": "k_royale_bloom_h", "k_royale_bloom_vertical": "k_royale_bloom_v"}
     want = alias.get(want, want)
-    for r in csv.DictReader(open(files[-1])):
-        if r["kernel"] == want and r.get("FETCH_SIZE_avg") and r.get("WRITE_SIZE_avg"):
+    rows = {r["kernel"]: r for r in csv.DictReader(open(files[-1]))}
+    for name in (want + "2", want):      # k_royale_scan_v2: the two-rows-per-thread form the fast path launches
+        r = rows.get(name)
+        if r and r.get("FETCH_SIZE_avg") and r.get("WRITE_SIZE_avg"):
             return (2.0 * float(r["FETCH_SIZE_avg"]) + float(r["WRITE_SIZE_avg"])) * 1024.0
     return None
 
@@ -115,8 +117,10 @@ def pmc_valu(kernel_name, frames_per_launch, avg_launch_ms):
     if not files or abs(frames_per_launch - 8.0) > 1e-6 or avg_launch_ms <= 0:
         return None
     want = {"royale-scanlines-v": "k_royale_scan_v", "royale-bloom-h": "k_royale_bloom_h"}.get(kernel_name, "k_" + kernel_name.replace("-", "_"))
-    for r in csv.DictReader(open(files[-1])):
-        if r["kernel"] == want and r.get("SQ_INSTS_VALU_avg"):
+    rows = {r["kernel"]: r for r in csv.DictReader(open(files[-1]))}
+    for name in (want + "2", want):
+        r = rows.get(name)
+        if r and r.get("SQ_INSTS_VALU_avg"):
             insts = float(r["SQ_INSTS_VALU_avg"])
             rate = insts / (avg_launch_ms * 1e-3) / (256 * 4) / 1e9
             return {"wave_insts_per_launch": insts, "G_wave_insts_per_s_per_simd": rate, "issue_ceiling_G_per_s_per_simd": 0.53,
