@@ -227,6 +227,9 @@ def test_hyllian_glow_1080p_batch_and_unsupported_layout(preset_tree, rc_lib):
     assert out.shape == (3, 1080, 1920, 4) and out[..., :3].std() > 10
     for k in range(3):
         assert np.array_equal(run_engine(e, frames[k:k + 1])[0], out[k]), k
+    e2 = make_engine(preset_tree["crt-hyllian-glow"], 1920, 1080, chunk=2)     # two launches per pass: 2 + 1 frames, own mip chains
+    assert np.array_equal(run_engine(e2, frames), out)
+    e2.shutdown()
     assert e.setShaderParameter("PHOSPHOR_LAYOUT", 7.0)
     from retrocapture_amd.engine import RcError
     with pytest.raises(RcError, match="PHOSPHOR_LAYOUT"):      # refused loudly, not mis-rendered
