@@ -333,19 +333,24 @@ void o_pass_xbr_lv3(const o_pass_args* a) {
  * The shader reads a variable it never assigns: `f4` (declared FS 295; xbr-lv3 has f4 = h5.yzwx).  What llvmpipe makes
  * of the two uses was fitted on the goldens: in the weighted distance wd1 it reads as `i`, and eq(f, f4) in the
  * CORNER_C rule comes out true.  PARITY: "partial" for this shader - with those two choices the 8-bit output matches
- * llvmpipe in 99.93 % of the bytes with a maximum difference of 1 (float target: 97 % bit-identical, <= 4e-7): the
- * association of the line-equation sums is not pinned. */
+ * llvmpipe in 99.99 % of the bytes with a maximum difference of 1 (float target: 99.3 % bit-identical, <= 3e-7): the
+ * association of the line-equation sums is fitted, not fully pinned. */
 static inline float dot_rgbw(o_vec4 p) { return p.x * 14.352f + (p.y * 28.176f + p.z * 5.472f); }
 static inline f4 lumc(o_vec4 p0, o_vec4 p1, o_vec4 p2, o_vec4 p3) {
   f4 r = {{dot_rgbw(p0), dot_rgbw(p1), dot_rgbw(p2), dot_rgbw(p3)}};
   return r;
 }
-/* clamp(((A*fp.y + B*fp.x + delta) - C [- Ci]) / (2*delta), 0, 1): `delta` is a mutable global, so nothing is folded */
+/* clamp((A*fp.y + B*fp.x + delta - C [- Ci]) / (2*delta), 0, 1).  `delta` is a mutable global, so nothing is
+ * folded; the order of the additions follows the compiler's multiply-add fusing (as in rc_passes_royale.c): where
+ * B*fp.x is a real product (|B| != 1: the 30 and 60 degree lines) the plain addends gather first,
+ * B*fx + ((A*fy + delta) - C); where A and B are +-1 (the 45 degree lines) ((A*fy + delta) + B*fx) - C fits best */
 static inline f4 line_clamp(const float* A, const float* B, const float* dl, const float* C, float ci, float fy, float fx) {
   f4 r;
   for (int k = 0; k < 4; ++k) {
-    float num = ((A[k] * fy + B[k] * fx) + dl[k]) - C[k];
-    if (ci != 0.0f) num = num - ci;
+    float num;
+    const float cc = ci != 0.0f ? C[k] + ci : C[k];   /* the two constants fold: (x - Co) - Ci -> x - (Co + Ci) */
+    if (fabsf(B[k]) != 1.0f) num = B[k] * fx + ((A[k] * fy + dl[k]) - cc);
+    else num = ((A[k] * fy + dl[k]) + B[k] * fx) - cc;
     float t = num / (2.0f * dl[k]);
     t = t > 0.0f ? t : 0.0f;
     r.v[k] = t < 1.0f ? t : 1.0f;

@@ -194,8 +194,9 @@ __global__ void __launch_bounds__(256) k_xbr_lv3(const PassLaunch L) {
 // params: XBR_SCALE (unused: a commented-out pragma the reference's scan still lists), XBR_Y_WEIGHT, XBR_EQ_THRESHOLD,
 // XBR_LV1_COEFFICIENT, XBR_LV2_COEFFICIENT, small_details
 __device__ __forceinline__ float lv2_line(float A, float B, float dl, float C, float ci, float fy, float fx) {
-  float num = ((A * fy + B * fx) + dl) - C;
-  if (ci != 0.0f) num = num - ci;
+  // addition order as in oracle/rc_passes_ntsc_xbr.c (line_clamp)
+  const float cc = ci != 0.0f ? C + ci : C;
+  const float num = __builtin_fabsf(B) != 1.0f ? B * fx + ((A * fy + dl) - cc) : ((A * fy + dl) + B * fx) - cc;
   float t = num / (2.0f * dl);
   t = t > 0.0f ? t : 0.0f;
   return t < 1.0f ? t : 1.0f;

@@ -64,7 +64,7 @@ CASES = {
 # crt-royale: every pass that stores to an sRGB8 target can differ from llvmpipe by 1 LSB in
 # ~0.3 % of the bytes, because llvmpipe's sRGB encode runs through the x86 RSQRTPS
 # approximation and is not monotone ("sRGB8 store"); RGBA8 passes must be exact.
-BAR = {"xbr-lv2": (0.999, 1), "scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1), "crt-royale-fake-bloom": (0.995, 1), "crt-hyllian-glow": (0.98, 1),
+BAR = {"xbr-lv2": (0.9998, 1), "scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1), "crt-royale-fake-bloom": (0.995, 1), "crt-hyllian-glow": (0.98, 1),
        "crt-royale-ntsc-256px-svideo": (0.995, 1), "crt-royale-ntsc-320px-composite": (0.995, 1), "ntsc-256px-svideo": (1.0, 0),
        "xbr-lv3": (1.0, 0), "mix-frames": (1.0, 0), "feedback-persist": (1.0, 0)}
 
@@ -144,7 +144,7 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
             if key == "xbr-lv2":
                 # parity "partial" (oracle/rc_passes_ntsc_xbr.c): the shader reads an unassigned variable and the
                 # association of its line-equation sums is not pinned; alpha (never written by the shader) is exact
-                assert d.max() <= 1 and exact >= 0.999, "pass %d: exact %.5f max %d" % (i, exact, d.max())
+                assert d.max() <= 1 and exact >= 0.9998, "pass %d: exact %.5f max %d" % (i, exact, d.max())
             elif fmt == "rgba8":
                 assert d.max() == 0, "RGBA8 pass %d must be bit-exact: exact %.5f max %d" % (i, exact, d.max())
             assert d.max() <= maxdiff and exact >= floor, "pass %d: exact %.5f max %d" % (i, exact, d.max())
@@ -182,7 +182,7 @@ FLOAT_CASES = {
     # blurs (1 ulp: the association of the nine-term sum is not pinned) and of the mip-mapped pass 3 are far below
     # an 8-bit step - the 8-bit goldens of every pass match at the sRGB-encode residual and the final pass exactly
     "f32_zfast_crt_64x48_to_200x150": ("zfast-crt", {}),
-    "f32_xbr_lv2_48x40_to_331x217": ("xbr-lv2", {0: 0.96}),   # parity "partial", see above
+    "f32_xbr_lv2_48x40_to_331x217": ("xbr-lv2", {0: 0.99}),   # parity "partial", see above
     "f32_crt_hyllian_glow_64x48_to_160x120": ("crt-hyllian-glow", {1: 0.93, 3: 0.5, 4: 0.93}),
     "f32_crt_hyllian_glow_64x48_to_150x110": ("crt-hyllian-glow", {1: 0.80, 3: 0.4, 4: 0.93}),
 }
