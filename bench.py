@@ -31,6 +31,7 @@ WORKLOADS = {
                               "crt/crt-royale-fake-bloom.glslp 9-pass, 1920x1080 RGBA8 frames"),
     "crt-hyllian-glow": ("crt-hyllian-glow", 1920, 1080, 1920, 1080,
                          "crt/crt-hyllian-glow.glslp 6-pass (the reference's smoke-test default), 1920x1080 RGBA8 frames"),
+    "crt-easymode": ("crt-easymode", 1920, 1080, 1920, 1080, "crt/crt-easymode.glslp 1-pass, 1920x1080 RGBA8 frames"),
     "zfast-crt": ("zfast-crt", 1920, 1080, 1920, 1080, "crt/zfast-crt.glslp 1-pass, 1920x1080 RGBA8 frames"),
     "crt-pi": ("crt-pi", 1920, 1080, 1920, 1080, "crt/crt-pi.glslp 1-pass, 1920x1080 RGBA8 frames"),
     "ntsc": ("ntsc-256px-svideo", 1920, 1080, 1920, 1080,

@@ -272,3 +272,97 @@ void o_pass_zfast_crt(const o_pass_args* a) {
   o_pass_zfast_crt_body(a);
   o_fp_leave(csr);
 }
+
+/* crt/shaders/crt-easymode.glsl (crt/crt-easymode.glslp), ENABLE_LANCZOS 1; FS 159-268.  17 params in pragma order:
+ * SHARPNESS_H, SHARPNESS_V, MASK_STRENGTH, MASK_DOT_WIDTH, MASK_DOT_HEIGHT, MASK_STAGGER, MASK_SIZE, SCANLINE_STRENGTH,
+ * SCANLINE_BEAM_WIDTH_MIN, SCANLINE_BEAM_WIDTH_MAX, SCANLINE_BRIGHT_MIN, SCANLINE_BRIGHT_MAX, SCANLINE_CUTOFF,
+ * GAMMA_INPUT, GAMMA_OUTPUT, BRIGHT_BOOST, DILATION */
+static float em_curve(float x, float sharp) {
+  const float x_step = x < 0.5f ? 0.0f : 1.0f;
+  const float h = 0.5f - x;
+  const float sg = h > 0.0f ? 1.0f : (h < 0.0f ? -1.0f : 0.0f);
+  const float curve = 0.5f - sqrtf(0.25f - (x - x_step) * (x - x_step)) * sg;
+  return x + sharp * (curve - x);
+}
+static o_vec4 em_tex(const o_tex* t, float u, float v, float dil) {
+  const o_vec4 c = o_sample(t, u, v);
+  const o_vec4 r = {c.x * (1.0f + dil * (c.x - 1.0f)), c.y * (1.0f + dil * (c.y - 1.0f)), c.z * (1.0f + dil * (c.z - 1.0f)),
+                    c.w * (1.0f + dil * (c.w - 1.0f))};
+  return r;
+}
+static void em_lanczos(const o_tex* t, float u, float v, float dx, const float* k, float dil, float* out3) {
+  const o_vec4 m0 = em_tex(t, u - dx, v - 0.0f, dil), m1 = em_tex(t, u, v, dil), m2 = em_tex(t, u + dx, v + 0.0f, dil);
+  const o_vec4 m3 = em_tex(t, u + 2.0f * dx, v + 2.0f * 0.0f, dil);
+  const float* p0 = &m0.x; const float* p1 = &m1.x; const float* p2 = &m2.x; const float* p3 = &m3.x;
+  for (int c = 0; c < 3; ++c) {
+    const float col = ((p0[c] * k[0] + p1[c] * k[1]) + p2[c] * k[2]) + p3[c] * k[3];
+    const float mn = p1[c] < p2[c] ? p1[c] : p2[c], mx = p1[c] > p2[c] ? p1[c] : p2[c];
+    const float lo = col > mn ? col : mn;
+    out3[c] = lo < mx ? lo : mx;
+  }
+}
+static void o_pass_crt_easymode_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float* P = a->params;
+  const float sh = P[0], sv = P[1], mstr = P[2], mdw = P[3], mdh = P[4], mstag = P[5], msize = P[6], sstr = P[7];
+  const float bwmin = P[8], bwmax = P[9], brmin = P[10], brmax = P[11], cutoff = P[12], gin = P[13], gout = P[14], boost = P[15], dil = P[16];
+  const float tsx = (float)a->in->w, tsy = (float)a->in->h; /* TextureSize == InputSize */
+  const float idx = 1.0f / tsx, idy = 1.0f / tsy;
+  const float pi = 3.141592653589f;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      const float pcx = u * tsx - 0.5f, pcy = v * tsy - 0.5f;
+      const float tcx = (floorf(pcx) + 0.5f) * idx, tcy = (floorf(pcy) + 0.5f) * idy;
+      const float dsx = pcx - floorf(pcx), dsy = pcy - floorf(pcy);
+      const float cx = em_curve(dsx, sh * sh);
+      float k[4] = {pi * (1.0f + cx), pi * cx, pi * (1.0f - cx), pi * (2.0f - cx)};
+      for (int q = 0; q < 4; ++q) {
+        float c = fabsf(k[q]);
+        c = c > 1e-5f ? c : 1e-5f;
+        k[q] = ((2.0f * o_sin(c)) * o_sin(c * 0.5f)) / (c * c);
+      }
+      const float ksum = k[0] + (k[1] + (k[2] + k[3]));   /* dot(coeffs, vec4(1.0)) */
+      for (int q = 0; q < 4; ++q) k[q] = k[q] / ksum;
+      float c1[3], c2[3], col[3];
+      em_lanczos(a->in, tcx, tcy, idx, k, dil, c1);
+      em_lanczos(a->in, tcx + 0.0f, tcy + idy, idx, k, dil, c2);
+      const float cy = em_curve(dsy, sv);
+      const float ge = gin / (dil + 1.0f);
+      for (int c = 0; c < 3; ++c) col[c] = o_pow(c1[c] + cy * (c2[c] - c1[c]), ge);
+      const float luma = 0.2126f * col[0] + (0.7152f * col[1] + 0.0722f * col[2]);
+      const float gb = col[1] > col[2] ? col[1] : col[2];
+      const float mxc = col[0] > gb ? col[0] : gb;
+      const float bright = (mxc + luma) * 0.5f;
+      float scan_bright = bright > brmin ? bright : brmin;
+      scan_bright = scan_bright < brmax ? scan_bright : brmax;
+      float scan_beam = bright * bwmax;
+      scan_beam = scan_beam > bwmin ? scan_beam : bwmin;
+      scan_beam = scan_beam < bwmax ? scan_beam : bwmax;
+      const float ang = ((v * 2.0f) * pi) * tsy;
+      float scan_weight = 1.0f - o_pow(o_cos(ang) * 0.5f + 0.5f, scan_beam) * sstr;
+      const float mask = 1.0f - mstr;
+      const float mfx = floorf(((u * (float)W) * tsx) / (tsx * msize)), mfy = floorf(((v * (float)H) * tsy) / (tsy * (mdh * msize)));
+      const float m2 = mfy - 2.0f * floorf(mfy / 2.0f);
+      const float q = (mfx + m2 * mstag) / mdw;
+      const int dot_no = (int)(q - 3.0f * floorf(q / 3.0f));
+      const float mw[3] = {dot_no == 0 ? 1.0f : mask, dot_no == 1 ? 1.0f : mask, (dot_no != 0 && dot_no != 1) ? 1.0f : mask};
+      if (tsy >= cutoff) scan_weight = 1.0f;
+      float out[3];
+      for (int c = 0; c < 3; ++c) {
+        const float c0 = col[c] * scan_weight;
+        float r = c0 + scan_bright * (col[c] - c0);
+        r = r * mw[c];
+        out[c] = o_pow(r, 1.0f / gout) * boost;
+      }
+      const o_vec4 o = {out[0], out[1], out[2], 1.0f};
+      store_px(a, x, y, o);
+    }
+}
+void o_pass_crt_easymode(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  o_pass_crt_easymode_body(a);
+  o_fp_leave(csr);
+}

@@ -210,6 +210,25 @@ std::vector<KernelEntry> build() {
                 {"INPUT_GAMMA", 2.4f, 0.0f, 5.0f, 0.01f, "Input gamma"},
                 {"OUTPUT_GAMMA", 2.2f, 0.0f, 5.0f, 0.01f, "Output gamma"}},
                {}, rck::launch_crt_pi, setupCrtPi, false});
+  r.push_back({"crt/shaders/crt-easymode.glsl", "crt-easymode",
+               {{"SHARPNESS_H", 0.5f, 0.0f, 1.0f, 0.05f, "Sharpness Horizontal"},
+                {"SHARPNESS_V", 1.0f, 0.0f, 1.0f, 0.05f, "Sharpness Vertical"},
+                {"MASK_STRENGTH", 0.3f, 0.0f, 1.0f, 0.01f, "Mask Strength"},
+                {"MASK_DOT_WIDTH", 1.0f, 1.0f, 100.0f, 1.0f, "Mask Dot Width"},
+                {"MASK_DOT_HEIGHT", 1.0f, 1.0f, 100.0f, 1.0f, "Mask Dot Height"},
+                {"MASK_STAGGER", 0.0f, 0.0f, 100.0f, 1.0f, "Mask Stagger"},
+                {"MASK_SIZE", 1.0f, 1.0f, 100.0f, 1.0f, "Mask Size"},
+                {"SCANLINE_STRENGTH", 1.0f, 0.0f, 1.0f, 0.05f, "Scanline Strength"},
+                {"SCANLINE_BEAM_WIDTH_MIN", 1.5f, 0.5f, 5.0f, 0.5f, "Scanline Beam Width Min."},
+                {"SCANLINE_BEAM_WIDTH_MAX", 1.5f, 0.5f, 5.0f, 0.5f, "Scanline Beam Width Max."},
+                {"SCANLINE_BRIGHT_MIN", 0.35f, 0.0f, 1.0f, 0.05f, "Scanline Brightness Min."},
+                {"SCANLINE_BRIGHT_MAX", 0.65f, 0.0f, 1.0f, 0.05f, "Scanline Brightness Max."},
+                {"SCANLINE_CUTOFF", 400.0f, 1.0f, 1000.0f, 1.0f, "Scanline Cutoff"},
+                {"GAMMA_INPUT", 2.0f, 0.1f, 5.0f, 0.1f, "Gamma Input"},
+                {"GAMMA_OUTPUT", 1.8f, 0.1f, 5.0f, 0.1f, "Gamma Output"},
+                {"BRIGHT_BOOST", 1.2f, 1.0f, 2.0f, 0.01f, "Brightness Boost"},
+                {"DILATION", 1.0f, 0.0f, 1.0f, 1.0f, "Dilation"}},
+               {}, rck::launch_crt_easymode, setupTexCoord, false});
   // crt/zfast-crt.glslp: the six parameters are the names the reference overwrites with fixed values (shader_engine.cpp)
   r.push_back({"crt/shaders/zfast_crt.glsl", "zfast-crt",
                {{"BLURSCALEX", 0.30f, 0.0f, 1.0f, 0.05f, "Blur Amount X-Axis"},

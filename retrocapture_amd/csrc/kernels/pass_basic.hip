@@ -153,6 +153,97 @@ __global__ void __launch_bounds__(256) k_zfast_crt(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// crt/shaders/crt-easymode.glsl (ENABLE_LANCZOS 1), FS 159-268; 17 params in pragma order (oracle/rc_passes_basic.c).
+__device__ __forceinline__ float em_curve(float x, float sharp) {
+  const float x_step = x < 0.5f ? 0.0f : 1.0f;
+  const float h = 0.5f - x;
+  const float sg = h > 0.0f ? 1.0f : (h < 0.0f ? -1.0f : 0.0f);
+  const float curve = 0.5f - __builtin_sqrtf(0.25f - (x - x_step) * (x - x_step)) * sg;
+  return x + sharp * (curve - x);
+}
+__device__ __forceinline__ void em_lanczos(const Tex& t, const uint8_t* img, float u, float v, float dx, const float* k, float dil,
+                                            const SrgbLds* lds, float* out3) {
+  float m[4][3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float su = q == 0 ? u - dx : (q == 1 ? u : (q == 2 ? u + dx : u + 2.0f * dx));
+    const float sv = q == 0 ? v - 0.0f : (q == 1 ? v : (q == 2 ? v + 0.0f : v + 2.0f * 0.0f));
+    const float4 c = sample_rt(t, img, su, sv, lds);
+    m[q][0] = c.x * (1.0f + dil * (c.x - 1.0f));
+    m[q][1] = c.y * (1.0f + dil * (c.y - 1.0f));
+    m[q][2] = c.z * (1.0f + dil * (c.z - 1.0f));
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float col = ((m[0][c] * k[0] + m[1][c] * k[1]) + m[2][c] * k[2]) + m[3][c] * k[3];
+    const float mn = m[1][c] < m[2][c] ? m[1][c] : m[2][c], mx = m[1][c] > m[2][c] ? m[1][c] : m[2][c];
+    const float lo = col > mn ? col : mn;
+    out3[c] = lo < mx ? lo : mx;
+  }
+}
+__global__ void __launch_bounds__(256) k_crt_easymode(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float* P = L.params;
+  const float sh = P[0], sv = P[1], mstr = P[2], mdw = P[3], mdh = P[4], mstag = P[5], msize = P[6], sstr = P[7];
+  const float bwmin = P[8], bwmax = P[9], brmin = P[10], brmax = P[11], cutoff = P[12], gin = P[13], gout = P[14], boost = P[15], dil = P[16];
+  const float tsx = (float)L.in.w, tsy = (float)L.in.h, idx = 1.0f / tsx, idy = 1.0f / tsy;
+  const float pi = 3.141592653589f;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float pcx = u * tsx - 0.5f, pcy = v * tsy - 0.5f;
+  const float flx = __builtin_floorf(pcx), fly = __builtin_floorf(pcy);
+  const float tcx = (flx + 0.5f) * idx, tcy = (fly + 0.5f) * idy;
+  const float dsx = pcx - flx, dsy = pcy - fly;
+  const float cx = em_curve(dsx, sh * sh);
+  float k[4] = {pi * (1.0f + cx), pi * cx, pi * (1.0f - cx), pi * (2.0f - cx)};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float c = __builtin_fabsf(k[q]);
+    c = c > 1e-5f ? c : 1e-5f;
+    k[q] = ((2.0f * sin_(c)) * sin_(c * 0.5f)) / (c * c);
+  }
+  const float ksum = k[0] + (k[1] + (k[2] + k[3]));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) k[q] = k[q] / ksum;
+  const uint8_t* img = frame_ptr(L.in, z);
+  float c1[3], c2[3], col[3];
+  em_lanczos(L.in, img, tcx, tcy, idx, k, dil, &lds, c1);
+  em_lanczos(L.in, img, tcx + 0.0f, tcy + idy, idx, k, dil, &lds, c2);
+  const float cy = em_curve(dsy, sv);
+  const float ge = gin / (dil + 1.0f);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) col[c] = pow_(c1[c] + cy * (c2[c] - c1[c]), ge);
+  const float luma = 0.2126f * col[0] + (0.7152f * col[1] + 0.0722f * col[2]);
+  const float gb = col[1] > col[2] ? col[1] : col[2];
+  const float mxc = col[0] > gb ? col[0] : gb;
+  const float bright = (mxc + luma) * 0.5f;
+  float scan_bright = bright > brmin ? bright : brmin;
+  scan_bright = scan_bright < brmax ? scan_bright : brmax;
+  float scan_beam = bright * bwmax;
+  scan_beam = scan_beam > bwmin ? scan_beam : bwmin;
+  scan_beam = scan_beam < bwmax ? scan_beam : bwmax;
+  const float ang = ((v * 2.0f) * pi) * tsy;
+  float scan_weight = 1.0f - pow_(cos_(ang) * 0.5f + 0.5f, scan_beam) * sstr;
+  const float mask = 1.0f - mstr;
+  const float mfx = __builtin_floorf(((u * (float)L.out_w) * tsx) / (tsx * msize));
+  const float mfy = __builtin_floorf(((v * (float)L.out_h) * tsy) / (tsy * (mdh * msize)));
+  const float m2 = mfy - 2.0f * __builtin_floorf(mfy / 2.0f);
+  const float qd = (mfx + m2 * mstag) / mdw;
+  const int dot_no = (int)(qd - 3.0f * __builtin_floorf(qd / 3.0f));
+  const float mw[3] = {dot_no == 0 ? 1.0f : mask, dot_no == 1 ? 1.0f : mask, (dot_no != 0 && dot_no != 1) ? 1.0f : mask};
+  if (tsy >= cutoff) scan_weight = 1.0f;
+  float out[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float c0 = col[c] * scan_weight;
+    const float r = (c0 + scan_bright * (col[c] - c0)) * mw[c];
+    out[c] = pow_(r, 1.0f / gout) * boost;
+  }
+  store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
 __device__ __forceinline__ float crtpi_weight(float dist, float sw, float gap) {
   float w = 1.0f - (dist * dist) * sw;
   return w > gap ? w : gap;
@@ -233,6 +324,10 @@ hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s) {
 }
 hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_scanline, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_crt_easymode(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_crt_easymode, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }
 hipError_t launch_zfast_crt(const PassLaunch& L, hipStream_t s) {

@@ -89,6 +89,7 @@ filter_linear5 = true
                           'shaders = 2\nshader0 = ../stock.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 2.0\n'
                           'shader1 = ../stock.glsl\nfilter_linear1 = true'),
     "bilinear": ("bilinear.glslp", 'shaders = 1\n\nshader0 = stock.glsl\nfilter_linear0 = true\n'),
+    "crt-easymode": ("crt/crt-easymode.glslp", 'shaders = 1\n\nshader0 = shaders/crt-easymode.glsl\nfilter_linear0 = false\n'),
     "zfast-crt": ("crt/zfast-crt.glslp", 'shaders = 1\n\nshader0 = shaders/zfast_crt.glsl\nfilter_linear0 = true'),
     "stock": ("stock.glslp", 'shaders = "1"\nshader0 = "stock.glsl"\nfilter_linear0 = "false"\n'),
     # Same keys / values as the reference's crt/crt-royale.glslp for the 12 passes, including the
@@ -306,6 +307,13 @@ SHADERS = {
         "oracle": "xbr_lv3",
         "params": [("XBR_Y_WEIGHT", 48.0), ("XBR_EQ_THRESHOLD", 10.0), ("XBR_EQ_THRESHOLD2", 2.0),
                    ("XBR_LV2_COEFFICIENT", 2.0), ("corner_type", 3.0)],
+        "samplers": []},
+    "crt/shaders/crt-easymode.glsl": {
+        "oracle": "crt_easymode",
+        "params": [("SHARPNESS_H", 0.5), ("SHARPNESS_V", 1.0), ("MASK_STRENGTH", 0.3), ("MASK_DOT_WIDTH", 1.0), ("MASK_DOT_HEIGHT", 1.0),
+                   ("MASK_STAGGER", 0.0), ("MASK_SIZE", 1.0), ("SCANLINE_STRENGTH", 1.0), ("SCANLINE_BEAM_WIDTH_MIN", 1.5),
+                   ("SCANLINE_BEAM_WIDTH_MAX", 1.5), ("SCANLINE_BRIGHT_MIN", 0.35), ("SCANLINE_BRIGHT_MAX", 0.65),
+                   ("SCANLINE_CUTOFF", 400.0), ("GAMMA_INPUT", 2.0), ("GAMMA_OUTPUT", 1.8), ("BRIGHT_BOOST", 1.2), ("DILATION", 1.0)],
         "samplers": []},
     "crt/shaders/zfast_crt.glsl": {
         "oracle": "zfast_crt",

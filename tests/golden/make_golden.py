@@ -455,7 +455,16 @@ def case_zfast():
     run_case("f32_zfast_crt_64x48_to_200x150", P, mixed(64, 48, 102), 200, 150, f32=True)
 
 
-CASES = {"zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+def case_easymode():
+    P = GLSL + "/crt/crt-easymode.glslp"
+    run_case("crt_easymode_96x64_to_301x217", P, mixed(96, 64, 110), 301, 217)
+    run_case("crt_easymode_params_80x60_to_320x240", P, noise(80, 60, 111), 320, 240,
+             params=[("SHARPNESS_H", 0.8), ("SHARPNESS_V", 0.6), ("MASK_DOT_WIDTH", 2.0), ("MASK_STAGGER", 3.0), ("MASK_SIZE", 2.0),
+                     ("SCANLINE_BEAM_WIDTH_MIN", 1.0), ("SCANLINE_BEAM_WIDTH_MAX", 2.5), ("DILATION", 0.0), ("SCANLINE_STRENGTH", 0.7)])
+    run_case("f32_crt_easymode_64x48_to_200x150", P, mixed(64, 48, 112), 200, 150, f32=True)
+
+
+CASES = {"easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":
