@@ -161,6 +161,7 @@ __device__ __forceinline__ float em_curve(float x, float sharp) {
   const float curve = 0.5f - __builtin_sqrtf(0.25f - (x - x_step) * (x - x_step)) * sg;
   return x + sharp * (curve - x);
 }
+template <bool GENERIC>
 __device__ __forceinline__ void em_lanczos(const Tex& t, const uint8_t* img, float u, float v, float dx, const float* k, float dil,
                                             const SrgbLds* lds, float* out3) {
   float m[4][3];
@@ -168,7 +169,7 @@ __device__ __forceinline__ void em_lanczos(const Tex& t, const uint8_t* img, flo
   for (int q = 0; q < 4; ++q) {
     const float su = q == 0 ? u - dx : (q == 1 ? u : (q == 2 ? u + dx : u + 2.0f * dx));
     const float sv = q == 0 ? v - 0.0f : (q == 1 ? v : (q == 2 ? v + 0.0f : v + 2.0f * 0.0f));
-    const float4 c = sample_rt(t, img, su, sv, lds);
+    const float4 c = GENERIC ? sample_rt(t, img, su, sv, lds) : sample<FMT_RGBX8, 0, WRAP_EDGE>(t, img, su, sv, lds);
     m[q][0] = c.x * (1.0f + dil * (c.x - 1.0f));
     m[q][1] = c.y * (1.0f + dil * (c.y - 1.0f));
     m[q][2] = c.z * (1.0f + dil * (c.z - 1.0f));
@@ -181,9 +182,11 @@ __device__ __forceinline__ void em_lanczos(const Tex& t, const uint8_t* img, flo
     out3[c] = lo < mx ? lo : mx;
   }
 }
+// GENERIC false: GL_RGB source (RGBX8) NEAREST clamp-to-edge and a plain RGBA8 target - the shipped single-pass preset
+template <bool GENERIC>
 __global__ void __launch_bounds__(256) k_crt_easymode(const PassLaunch L) {
   __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  if (GENERIC) load_srgb_tables(lds);
   RC_TILE_LOOP_BEGIN
   const float* P = L.params;
   const float sh = P[0], sv = P[1], mstr = P[2], mdw = P[3], mdh = P[4], mstag = P[5], msize = P[6], sstr = P[7];
@@ -208,8 +211,8 @@ __global__ void __launch_bounds__(256) k_crt_easymode(const PassLaunch L) {
   for (int q = 0; q < 4; ++q) k[q] = k[q] / ksum;
   const uint8_t* img = frame_ptr(L.in, z);
   float c1[3], c2[3], col[3];
-  em_lanczos(L.in, img, tcx, tcy, idx, k, dil, &lds, c1);
-  em_lanczos(L.in, img, tcx + 0.0f, tcy + idy, idx, k, dil, &lds, c2);
+  em_lanczos<GENERIC>(L.in, img, tcx, tcy, idx, k, dil, &lds, c1);
+  em_lanczos<GENERIC>(L.in, img, tcx + 0.0f, tcy + idy, idx, k, dil, &lds, c2);
   const float cy = em_curve(dsy, sv);
   const float ge = gin / (dil + 1.0f);
 #pragma unroll
@@ -240,7 +243,8 @@ __global__ void __launch_bounds__(256) k_crt_easymode(const PassLaunch L) {
     const float r = (c0 + scan_bright * (col[c] - c0)) * mw[c];
     out[c] = pow_(r, 1.0f / gout) * boost;
   }
-  store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+  if (GENERIC) store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+  else store<FMT_RGBA8>(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
   RC_TILE_LOOP_END
 }
 
@@ -327,7 +331,10 @@ hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_crt_easymode(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_crt_easymode, px_grid(L), px_block(), 0, s, L);
+  const bool fast = L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.in.n_levels <= 1 && L.out_fmt == FMT_RGBA8 &&
+                    !(L.flags & RC_FLAG_GENERAL_ONLY);
+  if (fast) hipLaunchKernelGGL(k_crt_easymode<false>, px_grid(L), px_block(), 0, s, L);
+  else hipLaunchKernelGGL(k_crt_easymode<true>, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }
 hipError_t launch_zfast_crt(const PassLaunch& L, hipStream_t s) {
