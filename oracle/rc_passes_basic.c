@@ -366,3 +366,37 @@ void o_pass_crt_easymode(const o_pass_args* a) {
   o_pass_crt_easymode_body(a);
   o_fp_leave(csr);
 }
+
+/* crt/shaders/crt-nes-mini.glsl (crt/crt-nes-mini.glslp), VS 38-43, FS 94-105.  params: SCANTHICK, INTENSITY, BRIGHTBOOST;
+ * BRIGHTBOOST is one of the names the reference overwrites on every draw (ShaderEngine.cpp:2278-2282): it always
+ * arrives as 1.25, not the shader's 0.15. */
+static void o_pass_crt_nes_mini_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float thick = a->params[0], inten = a->params[1], boost = a->params[2];
+  const float tsy = (float)a->in->h;
+  o_varying tu = o_varying_setup(0.f * 1.00001f, 1.f * 1.00001f, 1.f * 1.00001f, 0.f * 1.00001f, W, H, a->out_fmt);
+  o_varying tv = o_varying_setup(0.f * 1.00001f, 0.f * 1.00001f, 1.f * 1.00001f, 1.f * 1.00001f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      const o_vec4 t = o_sample(a->in, u, v);
+      const float sy0 = (v * thick) * tsy;
+      const float sel = sy0 - 2.0f * floorf(sy0 / 2.0f);
+      const float hi = sel < 1.0f ? 0.0f : 1.0f, lw = 1.0f - hi;
+      const float t3[3] = {t.x, t.y, t.z};
+      float out[3];
+      for (int c = 0; c < 3; ++c) {
+        const float ph = ((1.0f + boost) - 0.2f * t3[c]) * t3[c];
+        const float pl = ((1.0f - inten) + 0.1f * t3[c]) * t3[c];
+        out[c] = lw * pl + hi * ph;
+      }
+      const o_vec4 o = {out[0], out[1], out[2], 1.0f};
+      store_px(a, x, y, o);
+    }
+}
+void o_pass_crt_nes_mini(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  o_pass_crt_nes_mini_body(a);
+  o_fp_leave(csr);
+}

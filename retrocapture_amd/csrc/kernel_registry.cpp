@@ -14,6 +14,12 @@ void setupTexCoord(const PassGeometry& g, rcd::PassLaunch& L) {
   L.plane[1] = planeV(1.0f, g.out_w, g.out_h, g.out_fmt);
 }
 
+void setupNesMini(const PassGeometry& g, rcd::PassLaunch& L) {
+  // VS: TEX0 = TexCoord * 1.00001 (crt-nes-mini.glsl:42)
+  L.plane[0] = planeU(1.00001f, g.out_w, g.out_h, g.out_fmt);
+  L.plane[1] = planeV(1.00001f, g.out_w, g.out_h, g.out_fmt);
+}
+
 void setupCrtPi(const PassGeometry& g, rcd::PassLaunch& L) {
   // VS: TEX0 = TexCoord * 1.0001 (crt-pi.glsl:101)
   L.plane[0] = planeU(1.0001f, g.out_w, g.out_h, g.out_fmt);
@@ -210,6 +216,11 @@ std::vector<KernelEntry> build() {
                 {"INPUT_GAMMA", 2.4f, 0.0f, 5.0f, 0.01f, "Input gamma"},
                 {"OUTPUT_GAMMA", 2.2f, 0.0f, 5.0f, 0.01f, "Output gamma"}},
                {}, rck::launch_crt_pi, setupCrtPi, false});
+  r.push_back({"crt/shaders/crt-nes-mini.glsl", "crt-nes-mini",
+               {{"SCANTHICK", 2.0f, 2.0f, 4.0f, 2.0f, "Scanline Thickness"},
+                {"INTENSITY", 0.15f, 0.0f, 1.0f, 0.01f, "Scanline Intensity"},
+                {"BRIGHTBOOST", 0.15f, 0.0f, 1.0f, 0.01f, "Luminance Boost"}},
+               {}, rck::launch_crt_nes_mini, setupNesMini, false});
   r.push_back({"crt/shaders/crt-easymode.glsl", "crt-easymode",
                {{"SHARPNESS_H", 0.5f, 0.0f, 1.0f, 0.05f, "Sharpness Horizontal"},
                 {"SHARPNESS_V", 1.0f, 0.0f, 1.0f, 0.05f, "Sharpness Vertical"},

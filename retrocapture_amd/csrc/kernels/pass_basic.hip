@@ -153,6 +153,30 @@ __global__ void __launch_bounds__(256) k_zfast_crt(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// crt/shaders/crt-nes-mini.glsl, VS 38-43, FS 94-105; plane[0], plane[1]: TEX0 = TexCoord * 1.00001.
+// params: SCANTHICK, INTENSITY, BRIGHTBOOST (the last always 1.25: one of the uniforms the reference overwrites)
+__global__ void __launch_bounds__(256) k_crt_nes_mini(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float thick = L.params[0], inten = L.params[1], boost = L.params[2];
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float4 t = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+  const float sy0 = (v * thick) * (float)L.in.h;
+  const float sel = sy0 - 2.0f * __builtin_floorf(sy0 / 2.0f);
+  const float hi = sel < 1.0f ? 0.0f : 1.0f, lw = 1.0f - hi;
+  const float t3[3] = {t.x, t.y, t.z};
+  float out[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float ph = ((1.0f + boost) - 0.2f * t3[c]) * t3[c];
+    const float pl = ((1.0f - inten) + 0.1f * t3[c]) * t3[c];
+    out[c] = lw * pl + hi * ph;
+  }
+  store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
 // crt/shaders/crt-easymode.glsl (ENABLE_LANCZOS 1), FS 159-268; 17 params in pragma order (oracle/rc_passes_basic.c).
 __device__ __forceinline__ float em_curve(float x, float sharp) {
   const float x_step = x < 0.5f ? 0.0f : 1.0f;
@@ -328,6 +352,10 @@ hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s) {
 }
 hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_scanline, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_crt_nes_mini(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_crt_nes_mini, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }
 hipError_t launch_crt_easymode(const PassLaunch& L, hipStream_t s) {

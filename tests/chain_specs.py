@@ -90,6 +90,7 @@ filter_linear5 = true
                           'shader1 = ../stock.glsl\nfilter_linear1 = true'),
     "bilinear": ("bilinear.glslp", 'shaders = 1\n\nshader0 = stock.glsl\nfilter_linear0 = true\n'),
     "crt-easymode": ("crt/crt-easymode.glslp", 'shaders = 1\n\nshader0 = shaders/crt-easymode.glsl\nfilter_linear0 = false\n'),
+    "crt-nes-mini": ("crt/crt-nes-mini.glslp", 'shaders = 1\n\nshader0 = shaders/crt-nes-mini.glsl\n'),
     "zfast-crt": ("crt/zfast-crt.glslp", 'shaders = 1\n\nshader0 = shaders/zfast_crt.glsl\nfilter_linear0 = true'),
     "stock": ("stock.glslp", 'shaders = "1"\nshader0 = "stock.glsl"\nfilter_linear0 = "false"\n'),
     # Same keys / values as the reference's crt/crt-royale.glslp for the 12 passes, including the
@@ -315,6 +316,8 @@ SHADERS = {
                    ("SCANLINE_BEAM_WIDTH_MAX", 1.5), ("SCANLINE_BRIGHT_MIN", 0.35), ("SCANLINE_BRIGHT_MAX", 0.65),
                    ("SCANLINE_CUTOFF", 400.0), ("GAMMA_INPUT", 2.0), ("GAMMA_OUTPUT", 1.8), ("BRIGHT_BOOST", 1.2), ("DILATION", 1.0)],
         "samplers": []},
+    "crt/shaders/crt-nes-mini.glsl": {"oracle": "crt_nes_mini",
+                                      "params": [("SCANTHICK", 2.0), ("INTENSITY", 0.15), ("BRIGHTBOOST", 0.15)], "samplers": []},
     "crt/shaders/zfast_crt.glsl": {
         "oracle": "zfast_crt",
         "params": [("BLURSCALEX", 0.30), ("LOWLUMSCAN", 6.0), ("HILUMSCAN", 8.0), ("BRIGHTBOOST", 1.25), ("MASK_DARK", 0.25),

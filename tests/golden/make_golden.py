@@ -464,7 +464,14 @@ def case_easymode():
     run_case("f32_crt_easymode_64x48_to_200x150", P, mixed(64, 48, 112), 200, 150, f32=True)
 
 
-CASES = {"easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+def case_nes_mini():
+    P = GLSL + "/crt/crt-nes-mini.glslp"
+    run_case("crt_nes_mini_96x64_to_301x217", P, mixed(96, 64, 120), 301, 217)
+    run_case("crt_nes_mini_params_80x60_to_320x240", P, noise(80, 60, 121), 320, 240, params=[("SCANTHICK", 4.0), ("INTENSITY", 0.4), ("BRIGHTBOOST", 0.5)])
+    run_case("f32_crt_nes_mini_64x48_to_200x150", P, mixed(64, 48, 122), 200, 150, f32=True)
+
+
+CASES = {"nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":
