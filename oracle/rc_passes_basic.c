@@ -400,3 +400,44 @@ void o_pass_crt_nes_mini(const o_pass_args* a) {
   o_pass_crt_nes_mini_body(a);
   o_fp_leave(csr);
 }
+
+/* interpolation/shaders/quilez.glsl (FS 87-102) and interpolation/shaders/sharp-bilinear.glsl (FS 104-121; params
+ * SHARP_BILINEAR_PRE_SCALE, AUTO_PRESCALE): a modified coordinate, then one sample with the input's own filter. */
+static void o_pass_interp_body(const o_pass_args* a, int sharp) {
+  const int W = a->out_w, H = a->out_h;
+  const float tsx = (float)a->in->w, tsy = (float)a->in->h, idx = 1.0f / tsx, idy = 1.0f / tsy;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  float scale = 1.0f, range = 0.0f;
+  if (sharp) {
+    scale = a->params[1] > 0.5f ? floorf((float)H / tsy + 0.01f) : a->params[0];   /* InputSize.y == TextureSize.y */
+    range = 0.5f - 0.5f / scale;
+  }
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      float qx, qy;
+      if (!sharp) {
+        const float px = u * tsx + 0.5f, py = v * tsy + 0.5f;
+        const float ix = floorf(px), iy = floorf(py);
+        float fx = px - ix, fy = py - iy;
+        fx = ((fx * fx) * fx) * (fx * (fx * 6.0f - 15.0f) + 10.0f);
+        fy = ((fy * fy) * fy) * (fy * (fy * 6.0f - 15.0f) + 10.0f);
+        qx = ((ix + fx) - 0.5f) * idx;
+        qy = ((iy + fy) - 0.5f) * idy;
+      } else {
+        const float tx = u * tsx, ty = v * tsy;
+        const float flx = floorf(tx), fly = floorf(ty);
+        const float cdx = (tx - flx) - 0.5f, cdy = (ty - fly) - 0.5f;
+        const float clx = fminf(fmaxf(cdx, -range), range), cly = fminf(fmaxf(cdy, -range), range);
+        const float fx = (cdx - clx) * scale + 0.5f, fy = (cdy - cly) * scale + 0.5f;
+        qx = (flx + fx) / tsx;
+        qy = (fly + fy) / tsy;
+      }
+      o_vec4 c = o_sample(a->in, qx, qy);
+      if (sharp) c.w = 1.0f;
+      store_px(a, x, y, c);
+    }
+}
+void o_pass_quilez(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_interp_body(a, 0); o_fp_leave(csr); }
+void o_pass_sharp_bilinear(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_interp_body(a, 1); o_fp_leave(csr); }

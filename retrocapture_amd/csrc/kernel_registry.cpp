@@ -216,6 +216,11 @@ std::vector<KernelEntry> build() {
                 {"INPUT_GAMMA", 2.4f, 0.0f, 5.0f, 0.01f, "Input gamma"},
                 {"OUTPUT_GAMMA", 2.2f, 0.0f, 5.0f, 0.01f, "Output gamma"}},
                {}, rck::launch_crt_pi, setupCrtPi, false});
+  r.push_back({"interpolation/shaders/quilez.glsl", "quilez", {}, {}, rck::launch_quilez, setupTexCoord, true});
+  r.push_back({"interpolation/shaders/sharp-bilinear.glsl", "sharp-bilinear",
+               {{"SHARP_BILINEAR_PRE_SCALE", 4.0f, 1.0f, 10.0f, 1.0f, "Sharp Bilinear Prescale"},
+                {"AUTO_PRESCALE", 1.0f, 0.0f, 1.0f, 1.0f, "Automatic Prescale"}},
+               {}, rck::launch_sharp_bilinear, setupTexCoord, true});
   r.push_back({"crt/shaders/crt-nes-mini.glsl", "crt-nes-mini",
                {{"SCANTHICK", 2.0f, 2.0f, 4.0f, 2.0f, "Scanline Thickness"},
                 {"INTENSITY", 0.15f, 0.0f, 1.0f, 0.01f, "Scanline Intensity"},

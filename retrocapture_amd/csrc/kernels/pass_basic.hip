@@ -153,6 +153,40 @@ __global__ void __launch_bounds__(256) k_zfast_crt(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// interpolation/shaders/quilez.glsl (FS 87-102) and interpolation/shaders/sharp-bilinear.glsl (FS 104-121; params
+// SHARP_BILINEAR_PRE_SCALE, AUTO_PRESCALE): a modified coordinate, then one sample with the input's own filter.
+template <bool SHARP>
+__global__ void __launch_bounds__(256) k_interp(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float tsx = (float)L.in.w, tsy = (float)L.in.h, idx = 1.0f / tsx, idy = 1.0f / tsy;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  float qx, qy;
+  if (!SHARP) {
+    const float px = u * tsx + 0.5f, py = v * tsy + 0.5f;
+    const float ix = __builtin_floorf(px), iy = __builtin_floorf(py);
+    float fx = px - ix, fy = py - iy;
+    fx = ((fx * fx) * fx) * (fx * (fx * 6.0f - 15.0f) + 10.0f);
+    fy = ((fy * fy) * fy) * (fy * (fy * 6.0f - 15.0f) + 10.0f);
+    qx = ((ix + fx) - 0.5f) * idx;
+    qy = ((iy + fy) - 0.5f) * idy;
+  } else {
+    const float scale = L.params[1] > 0.5f ? __builtin_floorf((float)L.out_h / tsy + 0.01f) : L.params[0];
+    const float range = 0.5f - 0.5f / scale;
+    const float tx = u * tsx, ty = v * tsy;
+    const float flx = __builtin_floorf(tx), fly = __builtin_floorf(ty);
+    const float cdx = (tx - flx) - 0.5f, cdy = (ty - fly) - 0.5f;
+    const float clx = fminf(fmaxf(cdx, -range), range), cly = fminf(fmaxf(cdy, -range), range);
+    qx = (flx + ((cdx - clx) * scale + 0.5f)) / tsx;
+    qy = (fly + ((cdy - cly) * scale + 0.5f)) / tsy;
+  }
+  float4 c = sample_rt(L.in, frame_ptr(L.in, z), qx, qy, &lds);
+  if (SHARP) c.w = 1.0f;
+  store_rt(L, z, x, y, c, &lds);
+  RC_TILE_LOOP_END
+}
+
 // crt/shaders/crt-nes-mini.glsl, VS 38-43, FS 94-105; plane[0], plane[1]: TEX0 = TexCoord * 1.00001.
 // params: SCANTHICK, INTENSITY, BRIGHTBOOST (the last always 1.25: one of the uniforms the reference overwrites)
 __global__ void __launch_bounds__(256) k_crt_nes_mini(const PassLaunch L) {
@@ -352,6 +386,14 @@ hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s) {
 }
 hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_scanline, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_quilez(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_interp<false>, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_sharp_bilinear(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_interp<true>, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }
 hipError_t launch_crt_nes_mini(const PassLaunch& L, hipStream_t s) {

@@ -471,7 +471,16 @@ def case_nes_mini():
     run_case("f32_crt_nes_mini_64x48_to_200x150", P, mixed(64, 48, 122), 200, 150, f32=True)
 
 
-CASES = {"nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+def case_interp():
+    run_case("quilez_64x48_to_237x171", GLSL + "/interpolation/quilez.glslp", mixed(64, 48, 130), 237, 171)
+    run_case("f32_quilez_64x48_to_200x150", GLSL + "/interpolation/quilez.glslp", noise(64, 48, 131), 200, 150, f32=True)
+    P = GLSL + "/interpolation/sharp-bilinear.glslp"
+    run_case("sharp_bilinear_64x48_to_237x171", P, mixed(64, 48, 132), 237, 171)
+    run_case("sharp_bilinear_manual_80x60_to_400x300", P, noise(80, 60, 133), 400, 300, params=[("AUTO_PRESCALE", 0.0), ("SHARP_BILINEAR_PRE_SCALE", 3.0)])
+    run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
+
+
+CASES = {"interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -42,6 +42,9 @@ CASES = {
     # reference overrides TextureSize.y (ShaderEngine.cpp:2418-2421), and a mip-mapped last pass
     "crt_royale_ntsc_256px_svideo_96x64_to_320x240": "crt-royale-ntsc-256px-svideo",
     "crt_royale_ntsc_320px_composite_80x56_to_300x200": "crt-royale-ntsc-320px-composite",
+    "quilez_64x48_to_237x171": "quilez",
+    "sharp_bilinear_64x48_to_237x171": "sharp-bilinear",
+    "sharp_bilinear_manual_80x60_to_400x300": "sharp-bilinear",
     "crt_nes_mini_96x64_to_301x217": "crt-nes-mini",
     "crt_nes_mini_params_80x60_to_320x240": "crt-nes-mini",   # BRIGHTBOOST set by the user: overwritten with 1.25 by the reference
     "crt_easymode_96x64_to_301x217": "crt-easymode",
@@ -187,6 +190,8 @@ FLOAT_CASES = {
     # an 8-bit step - the 8-bit goldens of every pass match at the sRGB-encode residual and the final pass exactly
     "f32_zfast_crt_64x48_to_200x150": ("zfast-crt", {}),
     "f32_crt_nes_mini_64x48_to_200x150": ("crt-nes-mini", {}),
+    "f32_quilez_64x48_to_200x150": ("quilez", {}),
+    "f32_sharp_bilinear_64x48_to_200x150": ("sharp-bilinear", {}),
     "f32_crt_easymode_64x48_to_200x150": ("crt-easymode", {0: 0.95}),   # 8-bit goldens exact; <= 3e-7 in float
     "f32_xbr_lv2_48x40_to_331x217": ("xbr-lv2", {0: 0.99}),   # parity "partial", see above
     "f32_crt_hyllian_glow_64x48_to_160x120": ("crt-hyllian-glow", {1: 0.93, 3: 0.5, 4: 0.93}),
