@@ -408,7 +408,7 @@ static void o_pass_interp_body(const o_pass_args* a, int sharp) {
   const float tsx = (float)a->in->w, tsy = (float)a->in->h, idx = 1.0f / tsx, idy = 1.0f / tsy;
   o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
   float scale = 1.0f, range = 0.0f;
-  if (sharp) {
+  if (sharp == 1) {
     scale = a->params[1] > 0.5f ? floorf((float)H / tsy + 0.01f) : a->params[0];   /* InputSize.y == TextureSize.y */
     range = 0.5f - 0.5f / scale;
   }
@@ -417,12 +417,17 @@ static void o_pass_interp_body(const o_pass_args* a, int sharp) {
       const int lo = o_lower_tri(x, y, W, H);
       const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
       float qx, qy;
-      if (!sharp) {
+      if (sharp != 1) {
         const float px = u * tsx + 0.5f, py = v * tsy + 0.5f;
         const float ix = floorf(px), iy = floorf(py);
         float fx = px - ix, fy = py - iy;
-        fx = ((fx * fx) * fx) * (fx * (fx * 6.0f - 15.0f) + 10.0f);
-        fy = ((fy * fy) * fy) * (fy * (fy * 6.0f - 15.0f) + 10.0f);
+        if (sharp == 2) {   /* smootheststep.glsl FS 104: f*f*f*f*(f*(f*(-20 f + 70) - 84) + 35) */
+          fx = (((fx * fx) * fx) * fx) * (fx * (fx * (-20.0f * fx + 70.0f) - 84.0f) + 35.0f);
+          fy = (((fy * fy) * fy) * fy) * (fy * (fy * (-20.0f * fy + 70.0f) - 84.0f) + 35.0f);
+        } else {
+          fx = ((fx * fx) * fx) * (fx * (fx * 6.0f - 15.0f) + 10.0f);
+          fy = ((fy * fy) * fy) * (fy * (fy * 6.0f - 15.0f) + 10.0f);
+        }
         qx = ((ix + fx) - 0.5f) * idx;
         qy = ((iy + fy) - 0.5f) * idy;
       } else {
@@ -435,9 +440,10 @@ static void o_pass_interp_body(const o_pass_args* a, int sharp) {
         qy = (fly + fy) / tsy;
       }
       o_vec4 c = o_sample(a->in, qx, qy);
-      if (sharp) c.w = 1.0f;
+      if (sharp != 0) c.w = 1.0f;   /* quilez writes vec4(texture), the other two vec4(rgb, 1.0) */
       store_px(a, x, y, c);
     }
 }
 void o_pass_quilez(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_interp_body(a, 0); o_fp_leave(csr); }
+void o_pass_smootheststep(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_interp_body(a, 2); o_fp_leave(csr); }
 void o_pass_sharp_bilinear(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_interp_body(a, 1); o_fp_leave(csr); }

@@ -217,6 +217,7 @@ std::vector<KernelEntry> build() {
                 {"OUTPUT_GAMMA", 2.2f, 0.0f, 5.0f, 0.01f, "Output gamma"}},
                {}, rck::launch_crt_pi, setupCrtPi, false});
   r.push_back({"interpolation/shaders/quilez.glsl", "quilez", {}, {}, rck::launch_quilez, setupTexCoord, true});
+  r.push_back({"interpolation/shaders/smootheststep.glsl", "smootheststep", {}, {}, rck::launch_smootheststep, setupTexCoord, true});
   r.push_back({"interpolation/shaders/sharp-bilinear.glsl", "sharp-bilinear",
                {{"SHARP_BILINEAR_PRE_SCALE", 4.0f, 1.0f, 10.0f, 1.0f, "Sharp Bilinear Prescale"},
                 {"AUTO_PRESCALE", 1.0f, 0.0f, 1.0f, 1.0f, "Automatic Prescale"}},

@@ -155,7 +155,8 @@ __global__ void __launch_bounds__(256) k_zfast_crt(const PassLaunch L) {
 
 // interpolation/shaders/quilez.glsl (FS 87-102) and interpolation/shaders/sharp-bilinear.glsl (FS 104-121; params
 // SHARP_BILINEAR_PRE_SCALE, AUTO_PRESCALE): a modified coordinate, then one sample with the input's own filter.
-template <bool SHARP>
+// MODE 0: quilez, 1: sharp-bilinear, 2: smootheststep (interpolation/shaders/smootheststep.glsl FS 87-112)
+template <int MODE>
 __global__ void __launch_bounds__(256) k_interp(const PassLaunch L) {
   __shared__ SrgbLds lds;
   load_srgb_tables(lds);
@@ -163,12 +164,17 @@ __global__ void __launch_bounds__(256) k_interp(const PassLaunch L) {
   const float tsx = (float)L.in.w, tsy = (float)L.in.h, idx = 1.0f / tsx, idy = 1.0f / tsy;
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
   float qx, qy;
-  if (!SHARP) {
+  if (MODE != 1) {
     const float px = u * tsx + 0.5f, py = v * tsy + 0.5f;
     const float ix = __builtin_floorf(px), iy = __builtin_floorf(py);
     float fx = px - ix, fy = py - iy;
-    fx = ((fx * fx) * fx) * (fx * (fx * 6.0f - 15.0f) + 10.0f);
-    fy = ((fy * fy) * fy) * (fy * (fy * 6.0f - 15.0f) + 10.0f);
+    if (MODE == 2) {
+      fx = (((fx * fx) * fx) * fx) * (fx * (fx * (-20.0f * fx + 70.0f) - 84.0f) + 35.0f);
+      fy = (((fy * fy) * fy) * fy) * (fy * (fy * (-20.0f * fy + 70.0f) - 84.0f) + 35.0f);
+    } else {
+      fx = ((fx * fx) * fx) * (fx * (fx * 6.0f - 15.0f) + 10.0f);
+      fy = ((fy * fy) * fy) * (fy * (fy * 6.0f - 15.0f) + 10.0f);
+    }
     qx = ((ix + fx) - 0.5f) * idx;
     qy = ((iy + fy) - 0.5f) * idy;
   } else {
@@ -182,7 +188,7 @@ __global__ void __launch_bounds__(256) k_interp(const PassLaunch L) {
     qy = (fly + ((cdy - cly) * scale + 0.5f)) / tsy;
   }
   float4 c = sample_rt(L.in, frame_ptr(L.in, z), qx, qy, &lds);
-  if (SHARP) c.w = 1.0f;
+  if (MODE != 0) c.w = 1.0f;   // quilez writes vec4(texture), the other two vec4(rgb, 1.0)
   store_rt(L, z, x, y, c, &lds);
   RC_TILE_LOOP_END
 }
@@ -389,11 +395,15 @@ hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_quilez(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_interp<false>, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_interp<0>, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }
 hipError_t launch_sharp_bilinear(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_interp<true>, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_interp<1>, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_smootheststep(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_interp<2>, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }
 hipError_t launch_crt_nes_mini(const PassLaunch& L, hipStream_t s) {

@@ -92,6 +92,7 @@ filter_linear5 = true
     "crt-easymode": ("crt/crt-easymode.glslp", 'shaders = 1\n\nshader0 = shaders/crt-easymode.glsl\nfilter_linear0 = false\n'),
     "crt-nes-mini": ("crt/crt-nes-mini.glslp", 'shaders = 1\n\nshader0 = shaders/crt-nes-mini.glsl\n'),
     "quilez": ("interpolation/quilez.glslp", 'shaders = 1\n\nshader0 = shaders/quilez.glsl\nfilter_linear0 = true'),
+    "smootheststep": ("interpolation/smootheststep.glslp", 'shaders = 1\n\nshader0 = shaders/smootheststep.glsl\nfilter_linear0 = true'),
     "sharp-bilinear": ("interpolation/sharp-bilinear.glslp", 'shaders = 1\n\nshader0 = shaders/sharp-bilinear.glsl\nfilter_linear0 = true'),
     "zfast-crt": ("crt/zfast-crt.glslp", 'shaders = 1\n\nshader0 = shaders/zfast_crt.glsl\nfilter_linear0 = true'),
     "stock": ("stock.glslp", 'shaders = "1"\nshader0 = "stock.glsl"\nfilter_linear0 = "false"\n'),
@@ -321,6 +322,7 @@ SHADERS = {
     "crt/shaders/crt-nes-mini.glsl": {"oracle": "crt_nes_mini",
                                       "params": [("SCANTHICK", 2.0), ("INTENSITY", 0.15), ("BRIGHTBOOST", 0.15)], "samplers": []},
     "interpolation/shaders/quilez.glsl": {"oracle": "quilez", "params": [], "samplers": []},
+    "interpolation/shaders/smootheststep.glsl": {"oracle": "smootheststep", "params": [], "samplers": []},
     "interpolation/shaders/sharp-bilinear.glsl": {"oracle": "sharp_bilinear",
                                                   "params": [("SHARP_BILINEAR_PRE_SCALE", 4.0), ("AUTO_PRESCALE", 1.0)], "samplers": []},
     "crt/shaders/zfast_crt.glsl": {

@@ -474,6 +474,8 @@ def case_nes_mini():
 def case_interp():
     run_case("quilez_64x48_to_237x171", GLSL + "/interpolation/quilez.glslp", mixed(64, 48, 130), 237, 171)
     run_case("f32_quilez_64x48_to_200x150", GLSL + "/interpolation/quilez.glslp", noise(64, 48, 131), 200, 150, f32=True)
+    run_case("smootheststep_64x48_to_237x171", GLSL + "/interpolation/smootheststep.glslp", mixed(64, 48, 135), 237, 171)
+    run_case("f32_smootheststep_64x48_to_200x150", GLSL + "/interpolation/smootheststep.glslp", noise(64, 48, 136), 200, 150, f32=True)
     P = GLSL + "/interpolation/sharp-bilinear.glslp"
     run_case("sharp_bilinear_64x48_to_237x171", P, mixed(64, 48, 132), 237, 171)
     run_case("sharp_bilinear_manual_80x60_to_400x300", P, noise(80, 60, 133), 400, 300, params=[("AUTO_PRESCALE", 0.0), ("SHARP_BILINEAR_PRE_SCALE", 3.0)])

@@ -43,6 +43,7 @@ CASES = {
     "crt_royale_ntsc_256px_svideo_96x64_to_320x240": "crt-royale-ntsc-256px-svideo",
     "crt_royale_ntsc_320px_composite_80x56_to_300x200": "crt-royale-ntsc-320px-composite",
     "quilez_64x48_to_237x171": "quilez",
+    "smootheststep_64x48_to_237x171": "smootheststep",
     "sharp_bilinear_64x48_to_237x171": "sharp-bilinear",
     "sharp_bilinear_manual_80x60_to_400x300": "sharp-bilinear",
     "crt_nes_mini_96x64_to_301x217": "crt-nes-mini",
@@ -191,6 +192,7 @@ FLOAT_CASES = {
     "f32_zfast_crt_64x48_to_200x150": ("zfast-crt", {}),
     "f32_crt_nes_mini_64x48_to_200x150": ("crt-nes-mini", {}),
     "f32_quilez_64x48_to_200x150": ("quilez", {}),
+    "f32_smootheststep_64x48_to_200x150": ("smootheststep", {}),
     "f32_sharp_bilinear_64x48_to_200x150": ("sharp-bilinear", {}),
     "f32_crt_easymode_64x48_to_200x150": ("crt-easymode", {0: 0.95}),   # 8-bit goldens exact; <= 3e-7 in float
     "f32_xbr_lv2_48x40_to_331x217": ("xbr-lv2", {0: 0.99}),   # parity "partial", see above
