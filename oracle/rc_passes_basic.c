@@ -447,3 +447,30 @@ static void o_pass_interp_body(const o_pass_args* a, int sharp) {
 void o_pass_quilez(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_interp_body(a, 0); o_fp_leave(csr); }
 void o_pass_smootheststep(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_interp_body(a, 2); o_fp_leave(csr); }
 void o_pass_sharp_bilinear(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_interp_body(a, 1); o_fp_leave(csr); }
+
+/* scalenx/shaders/epx.glsl (scalenx/epx.glslp: NEAREST, source x 2), FS 97-136: EPX / Scale2x selection rules. */
+static int epx_same(o_vec4 a, o_vec4 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+static void o_pass_epx_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float tsx = (float)a->in->w, tsy = (float)a->in->h, idx = 1.0f / tsx, idy = 1.0f / tsy;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      const o_vec4 P = o_sample(a->in, u + 0.0f * idx, v + 0.0f * idy);
+      const o_vec4 A = o_sample(a->in, u + 0.0f * idx, v + 1.0f * idy), B = o_sample(a->in, u + 1.0f * idx, v + 0.0f * idy);
+      const o_vec4 D = o_sample(a->in, u + 0.0f * idx, v + -1.0f * idy), C = o_sample(a->in, u + -1.0f * idx, v + 0.0f * idy);
+      const o_vec4 one = (epx_same(C, D) && !epx_same(C, A) && !epx_same(C, B)) ? C : P;
+      const o_vec4 two = (epx_same(D, B) && !epx_same(D, C) && !epx_same(D, A)) ? D : P;
+      const o_vec4 three = (epx_same(A, C) && !epx_same(A, B) && !epx_same(A, D)) ? A : P;
+      const o_vec4 four = (epx_same(B, A) && !epx_same(B, D) && !epx_same(B, C)) ? B : P;
+      float pxx = u * tsx, pxy = v * tsy;
+      pxx = pxx - floorf(pxx);
+      pxy = pxy - floorf(pxy);
+      o_vec4 o = pxx < 0.5f ? (pxy < 0.5f ? one : three) : (pxy < 0.5f ? two : four);
+      o.w = 1.0f;
+      store_px(a, x, y, o);
+    }
+}
+void o_pass_epx(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_epx_body(a); o_fp_leave(csr); }

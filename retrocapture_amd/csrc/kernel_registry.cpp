@@ -216,6 +216,7 @@ std::vector<KernelEntry> build() {
                 {"INPUT_GAMMA", 2.4f, 0.0f, 5.0f, 0.01f, "Input gamma"},
                 {"OUTPUT_GAMMA", 2.2f, 0.0f, 5.0f, 0.01f, "Output gamma"}},
                {}, rck::launch_crt_pi, setupCrtPi, false});
+  r.push_back({"scalenx/shaders/epx.glsl", "epx", {}, {}, rck::launch_epx, setupTexCoord, true});
   r.push_back({"interpolation/shaders/quilez.glsl", "quilez", {}, {}, rck::launch_quilez, setupTexCoord, true});
   r.push_back({"interpolation/shaders/smootheststep.glsl", "smootheststep", {}, {}, rck::launch_smootheststep, setupTexCoord, true});
   r.push_back({"interpolation/shaders/sharp-bilinear.glsl", "sharp-bilinear",

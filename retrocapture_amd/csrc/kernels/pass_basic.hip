@@ -153,6 +153,31 @@ __global__ void __launch_bounds__(256) k_zfast_crt(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// scalenx/shaders/epx.glsl (scalenx/epx.glslp: NEAREST, source x 2), FS 97-136: EPX / Scale2x selection rules.
+__device__ __forceinline__ bool epx_same(const float4 a, const float4 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+__global__ void __launch_bounds__(256) k_epx(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float tsx = (float)L.in.w, tsy = (float)L.in.h, idx = 1.0f / tsx, idy = 1.0f / tsy;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const uint8_t* img = frame_ptr(L.in, z);
+  const float4 P = sample_rt(L.in, img, u + 0.0f * idx, v + 0.0f * idy, &lds);
+  const float4 A = sample_rt(L.in, img, u + 0.0f * idx, v + 1.0f * idy, &lds), B = sample_rt(L.in, img, u + 1.0f * idx, v + 0.0f * idy, &lds);
+  const float4 D = sample_rt(L.in, img, u + 0.0f * idx, v + -1.0f * idy, &lds), C = sample_rt(L.in, img, u + -1.0f * idx, v + 0.0f * idy, &lds);
+  const float4 one = (epx_same(C, D) && !epx_same(C, A) && !epx_same(C, B)) ? C : P;
+  const float4 two = (epx_same(D, B) && !epx_same(D, C) && !epx_same(D, A)) ? D : P;
+  const float4 three = (epx_same(A, C) && !epx_same(A, B) && !epx_same(A, D)) ? A : P;
+  const float4 four = (epx_same(B, A) && !epx_same(B, D) && !epx_same(B, C)) ? B : P;
+  float pxx = u * tsx, pxy = v * tsy;
+  pxx = pxx - __builtin_floorf(pxx);
+  pxy = pxy - __builtin_floorf(pxy);
+  float4 o = pxx < 0.5f ? (pxy < 0.5f ? one : three) : (pxy < 0.5f ? two : four);
+  o.w = 1.0f;
+  store_rt(L, z, x, y, o, &lds);
+  RC_TILE_LOOP_END
+}
+
 // interpolation/shaders/quilez.glsl (FS 87-102) and interpolation/shaders/sharp-bilinear.glsl (FS 104-121; params
 // SHARP_BILINEAR_PRE_SCALE, AUTO_PRESCALE): a modified coordinate, then one sample with the input's own filter.
 // MODE 0: quilez, 1: sharp-bilinear, 2: smootheststep (interpolation/shaders/smootheststep.glsl FS 87-112)
@@ -392,6 +417,10 @@ hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s) {
 }
 hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_scanline, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_epx(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_epx, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }
 hipError_t launch_quilez(const PassLaunch& L, hipStream_t s) {

@@ -42,6 +42,8 @@ CASES = {
     # reference overrides TextureSize.y (ShaderEngine.cpp:2418-2421), and a mip-mapped last pass
     "crt_royale_ntsc_256px_svideo_96x64_to_320x240": "crt-royale-ntsc-256px-svideo",
     "crt_royale_ntsc_320px_composite_80x56_to_300x200": "crt-royale-ntsc-320px-composite",
+    "epx_80x56_to_300x200": "epx",          # the only pass is source x 2.0: 160x112 whatever the viewport
+    "epx_mixed_64x48_to_64x48": "epx",
     "quilez_64x48_to_237x171": "quilez",
     "smootheststep_64x48_to_237x171": "smootheststep",
     "sharp_bilinear_64x48_to_237x171": "sharp-bilinear",
