@@ -474,3 +474,27 @@ static void o_pass_epx_body(const o_pass_args* a) {
     }
 }
 void o_pass_epx(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_epx_body(a); o_fp_leave(csr); }
+
+/* handheld/shaders/lcd3x.glsl (handheld/lcd3x.glslp), FS 95-110.  params: brighten_scanlines, brighten_lcd */
+static void o_pass_lcd3x_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float bs = a->params[0], bl = a->params[1];
+  const float pi = 3.141592654f;
+  const float off[3] = {pi * (1.0f / 2.0f), pi * (1.0f / 2.0f - 2.0f / 3.0f), pi * (1.0f / 2.0f - 4.0f / 3.0f)};
+  const float omx = (pi * 2.0f) * (float)a->in->w, omy = (pi * 2.0f) * (float)a->in->h;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      const o_vec4 r = o_sample(a->in, u, v);
+      const float ax = u * omx, ay = v * omy;
+      const float yf = (bs + o_sin(ay)) / (bs + 1.0f);
+      const float r3[3] = {r.x, r.y, r.z};
+      float out[3];
+      for (int c = 0; c < 3; ++c) out[c] = (yf * ((bl + o_sin(ax + off[c])) / (bl + 1.0f))) * r3[c];
+      const o_vec4 o = {out[0], out[1], out[2], 1.0f};
+      store_px(a, x, y, o);
+    }
+}
+void o_pass_lcd3x(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_lcd3x_body(a); o_fp_leave(csr); }

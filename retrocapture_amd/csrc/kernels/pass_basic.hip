@@ -153,6 +153,27 @@ __global__ void __launch_bounds__(256) k_zfast_crt(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// handheld/shaders/lcd3x.glsl (handheld/lcd3x.glslp), FS 95-110.  params: brighten_scanlines, brighten_lcd
+__global__ void __launch_bounds__(256) k_lcd3x(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float bs = L.params[0], bl = L.params[1];
+  const float pi = 3.141592654f;
+  const float off[3] = {pi * (1.0f / 2.0f), pi * (1.0f / 2.0f - 2.0f / 3.0f), pi * (1.0f / 2.0f - 4.0f / 3.0f)};
+  const float omx = (pi * 2.0f) * (float)L.in.w, omy = (pi * 2.0f) * (float)L.in.h;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float4 r = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+  const float ax = u * omx, ay = v * omy;
+  const float yf = (bs + sin_(ay)) / (bs + 1.0f);
+  const float r3[3] = {r.x, r.y, r.z};
+  float out[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[c] = (yf * ((bl + sin_(ax + off[c])) / (bl + 1.0f))) * r3[c];
+  store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
 // scalenx/shaders/epx.glsl (scalenx/epx.glslp: NEAREST, source x 2), FS 97-136: EPX / Scale2x selection rules.
 __device__ __forceinline__ bool epx_same(const float4 a, const float4 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
 __global__ void __launch_bounds__(256) k_epx(const PassLaunch L) {
@@ -417,6 +438,10 @@ hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s) {
 }
 hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_scanline, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_lcd3x(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_lcd3x, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }
 hipError_t launch_epx(const PassLaunch& L, hipStream_t s) {

@@ -479,6 +479,13 @@ def case_epx():
     run_case("epx_mixed_64x48_to_64x48", GLSL + "/scalenx/epx.glslp", mixed(64, 48, 141), 64, 48)
 
 
+def case_lcd3x():
+    P = GLSL + "/handheld/lcd3x.glslp"
+    run_case("lcd3x_64x48_to_192x144", P, mixed(64, 48, 150), 192, 144)
+    run_case("lcd3x_params_80x60_to_301x217", P, noise(80, 60, 151), 301, 217, params=[("brighten_scanlines", 4.0), ("brighten_lcd", 1.5)])
+    run_case("f32_lcd3x_64x48_to_200x150", P, noise(64, 48, 152), 200, 150, f32=True)
+
+
 def case_interp():
     run_case("quilez_64x48_to_237x171", GLSL + "/interpolation/quilez.glslp", mixed(64, 48, 130), 237, 171)
     run_case("f32_quilez_64x48_to_200x150", GLSL + "/interpolation/quilez.glslp", noise(64, 48, 131), 200, 150, f32=True)
@@ -490,7 +497,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -42,6 +42,8 @@ CASES = {
     # reference overrides TextureSize.y (ShaderEngine.cpp:2418-2421), and a mip-mapped last pass
     "crt_royale_ntsc_256px_svideo_96x64_to_320x240": "crt-royale-ntsc-256px-svideo",
     "crt_royale_ntsc_320px_composite_80x56_to_300x200": "crt-royale-ntsc-320px-composite",
+    "lcd3x_64x48_to_192x144": "lcd3x",
+    "lcd3x_params_80x60_to_301x217": "lcd3x",
     "epx_80x56_to_300x200": "epx",          # the only pass is source x 2.0: 160x112 whatever the viewport
     "epx_mixed_64x48_to_64x48": "epx",
     "quilez_64x48_to_237x171": "quilez",
@@ -194,6 +196,7 @@ FLOAT_CASES = {
     "f32_zfast_crt_64x48_to_200x150": ("zfast-crt", {}),
     "f32_crt_nes_mini_64x48_to_200x150": ("crt-nes-mini", {}),
     "f32_quilez_64x48_to_200x150": ("quilez", {}),
+    "f32_lcd3x_64x48_to_200x150": ("lcd3x", {}),
     "f32_smootheststep_64x48_to_200x150": ("smootheststep", {}),
     "f32_sharp_bilinear_64x48_to_200x150": ("sharp-bilinear", {}),
     "f32_crt_easymode_64x48_to_200x150": ("crt-easymode", {0: 0.95}),   # 8-bit goldens exact; <= 3e-7 in float
