@@ -498,3 +498,29 @@ static void o_pass_lcd3x_body(const o_pass_args* a) {
     }
 }
 void o_pass_lcd3x(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_lcd3x_body(a); o_fp_leave(csr); }
+
+/* dithering/shaders/bayer-matrix-dithering.glsl (dithering/bayer-matrix-dithering.glslp), FS 99-141: 8x8 ordered
+ * dithering of every channel to 0 / 1.  params: animate, dither_size; FrameCount is an int uniform. */
+static const int k_bayer8[8][8] = {{0, 32, 8, 40, 2, 34, 10, 42}, {48, 16, 56, 24, 50, 18, 58, 26}, {12, 44, 4, 36, 14, 46, 6, 38},
+                                   {60, 28, 52, 20, 62, 30, 54, 22}, {3, 35, 11, 43, 1, 33, 9, 41}, {51, 19, 59, 27, 49, 17, 57, 25},
+                                   {15, 47, 7, 39, 13, 45, 5, 37}, {63, 31, 55, 23, 61, 29, 53, 21}};
+static void o_pass_bayer_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float animate = a->params[0], dsize = a->params[1];
+  const float fc2 = 2.0f * (float)a->frame_count;
+  const float scale = (3.0f + (fc2 - 32.0f * floorf(fc2 / 32.0f)) * animate) + dsize;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      const o_vec4 c = o_sample(a->in, u, v);
+      const float xx = (u * (float)W) * scale, yy = (v * (float)H) * scale;
+      const int ix = (int)(xx - 8.0f * floorf(xx / 8.0f)), iy = (int)(yy - 8.0f * floorf(yy / 8.0f));
+      float limit = 0.0f;
+      if (ix < 8) limit = (float)(k_bayer8[ix & 7][iy & 7] + 1) / 64.0f;
+      const o_vec4 o = {c.x < limit ? 0.0f : 1.0f, c.y < limit ? 0.0f : 1.0f, c.z < limit ? 0.0f : 1.0f, 1.0f};
+      store_px(a, x, y, o);
+    }
+}
+void o_pass_bayer(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_bayer_body(a); o_fp_leave(csr); }

@@ -153,6 +153,26 @@ __global__ void __launch_bounds__(256) k_zfast_crt(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// dithering/shaders/bayer-matrix-dithering.glsl, FS 99-141: 8x8 ordered dithering of every channel to 0 / 1.
+// params: animate, dither_size; FrameCount is an int uniform.
+__constant__ int k_bayer8[64] = {0, 32, 8, 40, 2, 34, 10, 42, 48, 16, 56, 24, 50, 18, 58, 26, 12, 44, 4, 36, 14, 46, 6, 38, 60, 28, 52, 20, 62, 30, 54, 22,
+                                 3, 35, 11, 43, 1, 33, 9, 41, 51, 19, 59, 27, 49, 17, 57, 25, 15, 47, 7, 39, 13, 45, 5, 37, 63, 31, 55, 23, 61, 29, 53, 21};
+__global__ void __launch_bounds__(256) k_bayer(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float fc2 = 2.0f * (float)(L.frame_count0 + z);
+  const float scale = (3.0f + (fc2 - 32.0f * __builtin_floorf(fc2 / 32.0f)) * L.params[0]) + L.params[1];
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+  const float xx = (u * (float)L.out_w) * scale, yy = (v * (float)L.out_h) * scale;
+  const int ix = (int)(xx - 8.0f * __builtin_floorf(xx / 8.0f)), iy = (int)(yy - 8.0f * __builtin_floorf(yy / 8.0f));
+  float limit = 0.0f;
+  if (ix < 8) limit = (float)(k_bayer8[(ix & 7) * 8 + (iy & 7)] + 1) / 64.0f;
+  store_rt(L, z, x, y, make_float4(c.x < limit ? 0.0f : 1.0f, c.y < limit ? 0.0f : 1.0f, c.z < limit ? 0.0f : 1.0f, 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
 // handheld/shaders/lcd3x.glsl (handheld/lcd3x.glslp), FS 95-110.  params: brighten_scanlines, brighten_lcd
 __global__ void __launch_bounds__(256) k_lcd3x(const PassLaunch L) {
   __shared__ SrgbLds lds;
@@ -438,6 +458,10 @@ hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s) {
 }
 hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_scanline, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_bayer(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_bayer, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }
 hipError_t launch_lcd3x(const PassLaunch& L, hipStream_t s) {

@@ -93,6 +93,7 @@ filter_linear5 = true
     "crt-nes-mini": ("crt/crt-nes-mini.glslp", 'shaders = 1\n\nshader0 = shaders/crt-nes-mini.glsl\n'),
     "epx": ("scalenx/epx.glslp", 'shaders = 1\n\nshader0 = shaders/epx.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 2.0\n'),
     "lcd3x": ("handheld/lcd3x.glslp", 'shaders = 1\n\nshader0 = shaders/lcd3x.glsl\nfilter_linear0 = false'),
+    "bayer": ("dithering/bayer-matrix-dithering.glslp", 'shaders = 1\n\nshader0 = shaders/bayer-matrix-dithering.glsl\nfilter_linear0 = false'),
     "quilez": ("interpolation/quilez.glslp", 'shaders = 1\n\nshader0 = shaders/quilez.glsl\nfilter_linear0 = true'),
     "smootheststep": ("interpolation/smootheststep.glslp", 'shaders = 1\n\nshader0 = shaders/smootheststep.glsl\nfilter_linear0 = true'),
     "sharp-bilinear": ("interpolation/sharp-bilinear.glslp", 'shaders = 1\n\nshader0 = shaders/sharp-bilinear.glsl\nfilter_linear0 = true'),
@@ -325,6 +326,7 @@ SHADERS = {
                                       "params": [("SCANTHICK", 2.0), ("INTENSITY", 0.15), ("BRIGHTBOOST", 0.15)], "samplers": []},
     "scalenx/shaders/epx.glsl": {"oracle": "epx", "params": [], "samplers": []},
     "handheld/shaders/lcd3x.glsl": {"oracle": "lcd3x", "params": [("brighten_scanlines", 16.0), ("brighten_lcd", 4.0)], "samplers": []},
+    "dithering/shaders/bayer-matrix-dithering.glsl": {"oracle": "bayer", "params": [("animate", 0.0), ("dither_size", 0.0)], "samplers": []},
     "interpolation/shaders/quilez.glsl": {"oracle": "quilez", "params": [], "samplers": []},
     "interpolation/shaders/smootheststep.glsl": {"oracle": "smootheststep", "params": [], "samplers": []},
     "interpolation/shaders/sharp-bilinear.glsl": {"oracle": "sharp_bilinear",

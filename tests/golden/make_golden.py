@@ -486,6 +486,12 @@ def case_lcd3x():
     run_case("f32_lcd3x_64x48_to_200x150", P, noise(64, 48, 152), 200, 150, f32=True)
 
 
+def case_bayer():
+    P = GLSL + "/dithering/bayer-matrix-dithering.glslp"
+    run_case("bayer_64x48_to_237x171", P, mixed(64, 48, 160), 237, 171)
+    run_case("bayer_animated_80x60_to_320x240_f3", P, noise(80, 60, 161), 320, 240, frames=3, params=[("animate", 1.0), ("dither_size", 0.35)])
+
+
 def case_interp():
     run_case("quilez_64x48_to_237x171", GLSL + "/interpolation/quilez.glslp", mixed(64, 48, 130), 237, 171)
     run_case("f32_quilez_64x48_to_200x150", GLSL + "/interpolation/quilez.glslp", noise(64, 48, 131), 200, 150, f32=True)
@@ -497,7 +503,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -145,7 +145,8 @@ def test_xbr_lv2_matches_oracle_and_golden(case, preset_tree, rc_lib):
     e.shutdown()
 
 
-@pytest.mark.parametrize("case,key", [("lcd3x_64x48_to_192x144", "lcd3x"), ("lcd3x_params_80x60_to_301x217", "lcd3x"), ("epx_80x56_to_300x200", "epx"), ("epx_mixed_64x48_to_64x48", "epx"), ("quilez_64x48_to_237x171", "quilez"), ("smootheststep_64x48_to_237x171", "smootheststep"), ("sharp_bilinear_64x48_to_237x171", "sharp-bilinear"),
+@pytest.mark.parametrize("case,key", [("bayer_64x48_to_237x171", "bayer"), ("bayer_animated_80x60_to_320x240_f3", "bayer"),
+                                      ("lcd3x_64x48_to_192x144", "lcd3x"), ("lcd3x_params_80x60_to_301x217", "lcd3x"), ("epx_80x56_to_300x200", "epx"), ("epx_mixed_64x48_to_64x48", "epx"), ("quilez_64x48_to_237x171", "quilez"), ("smootheststep_64x48_to_237x171", "smootheststep"), ("sharp_bilinear_64x48_to_237x171", "sharp-bilinear"),
                                       ("sharp_bilinear_manual_80x60_to_400x300", "sharp-bilinear"),
                                       ("crt_nes_mini_96x64_to_301x217", "crt-nes-mini"), ("crt_nes_mini_params_80x60_to_320x240", "crt-nes-mini"),
                                       ("crt_easymode_96x64_to_301x217", "crt-easymode"), ("crt_easymode_params_80x60_to_320x240", "crt-easymode"),
@@ -162,13 +163,15 @@ def test_stock_presets_match_llvmpipe_golden(case, key, preset_tree, rc_lib):
     if "param_names" in g:   # zfast-crt: the reference overwrites these uniforms after the user's values (ShaderEngine.cpp:2260-2294)
         for k, v in zip(g["param_names"], g["param_values"]):
             assert e.setShaderParameter(str(k), float(v))
-    final = run_engine(e, g["input_rgb"])
+    for _ in range(int(g["frames"])):       # the golden run applied `frames` frames (FrameCount 1, 2, ...); the last one is kept
+        final = run_engine(e, g["input_rgb"])
     n = int(g["n_passes"])
     for i in range(n):
         assert np.array_equal(e.readPass(i, 0), g["pass%d" % i]), "pass %d" % i
     assert np.array_equal(final[0], g["pass%d" % (n - 1)])
-    e.setGeneralKernelsOnly(True)     # the run-time-sampler forms give the same bytes
-    assert np.array_equal(run_engine(e, g["input_rgb"])[0], final[0])
+    if int(g["frames"]) == 1:
+        e.setGeneralKernelsOnly(True)     # the run-time-sampler forms give the same bytes
+        assert np.array_equal(run_engine(e, g["input_rgb"])[0], final[0])
     e.shutdown()
 
 

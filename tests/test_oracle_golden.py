@@ -42,6 +42,8 @@ CASES = {
     # reference overrides TextureSize.y (ShaderEngine.cpp:2418-2421), and a mip-mapped last pass
     "crt_royale_ntsc_256px_svideo_96x64_to_320x240": "crt-royale-ntsc-256px-svideo",
     "crt_royale_ntsc_320px_composite_80x56_to_300x200": "crt-royale-ntsc-320px-composite",
+    "bayer_64x48_to_237x171": "bayer",
+    "bayer_animated_80x60_to_320x240_f3": "bayer",     # animate = 1: the pattern scale follows FrameCount (3 frames applied)
     "lcd3x_64x48_to_192x144": "lcd3x",
     "lcd3x_params_80x60_to_301x217": "lcd3x",
     "epx_80x56_to_300x200": "epx",          # the only pass is source x 2.0: 160x112 whatever the viewport
