@@ -119,6 +119,7 @@ void o_pass_crt_easymode(const o_pass_args* a);        /* 17 params */
 void o_pass_crt_nes_mini(const o_pass_args* a);        /* 3 params */
 void o_pass_bayer(const o_pass_args* a);               /* 2 params; reads FrameCount */
 void o_pass_epx(const o_pass_args* a);
+void o_pass_lcd1x(const o_pass_args* a);               /* 2 params */
 void o_pass_lcd3x(const o_pass_args* a);               /* 2 params */
 void o_pass_quilez(const o_pass_args* a);
 void o_pass_smootheststep(const o_pass_args* a);

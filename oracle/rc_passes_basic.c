@@ -524,3 +524,26 @@ static void o_pass_bayer_body(const o_pass_args* a) {
     }
 }
 void o_pass_bayer(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_bayer_body(a); o_fp_leave(csr); }
+
+/* handheld/shaders/lcd1x.glsl (handheld/lcd1x.glslp: NEAREST, clamp_to_border), FS 104-121.
+ * params: BRIGHTEN_SCANLINES, BRIGHTEN_LCD */
+static void o_pass_lcd1x_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float bs = a->params[0], bl = a->params[1];
+  const float two_pi = 2.0f * 3.141592654f;
+  const float tsx = (float)a->in->w, tsy = (float)a->in->h;
+  o_varying tu = o_varying_setup(0.f * 1.0001f, 1.f * 1.0001f, 1.f * 1.0001f, 0.f * 1.0001f, W, H, a->out_fmt);
+  o_varying tv = o_varying_setup(0.f * 1.0001f, 0.f * 1.0001f, 1.f * 1.0001f, 1.f * 1.0001f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      const float ax = two_pi * (u * tsx - 0.25f), ay = two_pi * (v * tsy - 0.25f);
+      const float yf = (bs + o_sin(ay)) / (bs + 1.0f), xf = (bl + o_sin(ax)) / (bl + 1.0f);
+      const o_vec4 c = o_sample(a->in, u, v);
+      const float k = yf * xf;
+      const o_vec4 o = {k * c.x, k * c.y, k * c.z, 1.0f};
+      store_px(a, x, y, o);
+    }
+}
+void o_pass_lcd1x(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_lcd1x_body(a); o_fp_leave(csr); }

@@ -219,6 +219,9 @@ std::vector<KernelEntry> build() {
   r.push_back({"dithering/shaders/bayer-matrix-dithering.glsl", "bayer-matrix-dithering",
                {{"animate", 0.0f, 0.0f, 1.0f, 1.0f, "Dithering Animation"}, {"dither_size", 0.0f, 0.0f, 0.95f, 0.05f, "Dither Size"}},
                {}, rck::launch_bayer, setupTexCoord, false});
+  r.push_back({"handheld/shaders/lcd1x.glsl", "lcd1x",
+               {{"BRIGHTEN_SCANLINES", 16.0f, 1.0f, 32.0f, 0.5f, "Brighten Scanlines"}, {"BRIGHTEN_LCD", 4.0f, 1.0f, 12.0f, 0.1f, "Brighten LCD"}},
+               {}, rck::launch_lcd1x, setupCrtPi, true});   // same TEX0 = TexCoord * 1.0001 as crt-pi
   r.push_back({"handheld/shaders/lcd3x.glsl", "lcd3x",
                {{"brighten_scanlines", 16.0f, 1.0f, 32.0f, 0.5f, "Brighten Scanlines"}, {"brighten_lcd", 4.0f, 1.0f, 12.0f, 0.1f, "Brighten LCD"}},
                {}, rck::launch_lcd3x, setupTexCoord, true});

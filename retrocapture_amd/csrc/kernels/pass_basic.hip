@@ -153,6 +153,22 @@ __global__ void __launch_bounds__(256) k_zfast_crt(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// handheld/shaders/lcd1x.glsl (handheld/lcd1x.glslp), FS 104-121; plane[0], plane[1]: TEX0 = TexCoord * 1.0001.
+// params: BRIGHTEN_SCANLINES, BRIGHTEN_LCD
+__global__ void __launch_bounds__(256) k_lcd1x(const PassLaunch L) {
+  __shared__ SrgbLds lds;
+  load_srgb_tables(lds);
+  RC_TILE_LOOP_BEGIN
+  const float bs = L.params[0], bl = L.params[1];
+  const float two_pi = 2.0f * 3.141592654f;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float ax = two_pi * (u * (float)L.in.w - 0.25f), ay = two_pi * (v * (float)L.in.h - 0.25f);
+  const float k = ((bs + sin_(ay)) / (bs + 1.0f)) * ((bl + sin_(ax)) / (bl + 1.0f));
+  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+  store_rt(L, z, x, y, make_float4(k * c.x, k * c.y, k * c.z, 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
 // dithering/shaders/bayer-matrix-dithering.glsl, FS 99-141: 8x8 ordered dithering of every channel to 0 / 1.
 // params: animate, dither_size; FrameCount is an int uniform.
 __constant__ int k_bayer8[64] = {0, 32, 8, 40, 2, 34, 10, 42, 48, 16, 56, 24, 50, 18, 58, 26, 12, 44, 4, 36, 14, 46, 6, 38, 60, 28, 52, 20, 62, 30, 54, 22,
@@ -458,6 +474,10 @@ hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s) {
 }
 hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_scanline, px_grid(L), px_block(), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_lcd1x(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_lcd1x, px_grid(L), px_block(), 0, s, L);
   return hipGetLastError();
 }
 hipError_t launch_bayer(const PassLaunch& L, hipStream_t s) {

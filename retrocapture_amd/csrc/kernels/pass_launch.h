@@ -18,6 +18,7 @@ hipError_t launch_crt_nes_mini(const PassLaunch& L, hipStream_t s);
 hipError_t launch_quilez(const PassLaunch& L, hipStream_t s);
 hipError_t launch_epx(const PassLaunch& L, hipStream_t s);
 hipError_t launch_lcd3x(const PassLaunch& L, hipStream_t s);
+hipError_t launch_lcd1x(const PassLaunch& L, hipStream_t s);
 hipError_t launch_bayer(const PassLaunch& L, hipStream_t s);
 hipError_t launch_smootheststep(const PassLaunch& L, hipStream_t s);
 hipError_t launch_sharp_bilinear(const PassLaunch& L, hipStream_t s);

@@ -92,6 +92,8 @@ filter_linear5 = true
     "crt-easymode": ("crt/crt-easymode.glslp", 'shaders = 1\n\nshader0 = shaders/crt-easymode.glsl\nfilter_linear0 = false\n'),
     "crt-nes-mini": ("crt/crt-nes-mini.glslp", 'shaders = 1\n\nshader0 = shaders/crt-nes-mini.glsl\n'),
     "epx": ("scalenx/epx.glslp", 'shaders = 1\n\nshader0 = shaders/epx.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 2.0\n'),
+    "lcd1x": ("handheld/lcd1x.glslp", 'shaders = "1"\n\nshader0 = "shaders/lcd1x.glsl"\n\nfilter_linear0 = "false"\nwrap_mode0 = "clamp_to_border"\n'
+                                      'mipmap_input0 = "false"\nalias0 = ""\nfloat_framebuffer0 = "false"\nsrgb_framebuffer0 = "false"\n'),
     "lcd3x": ("handheld/lcd3x.glslp", 'shaders = 1\n\nshader0 = shaders/lcd3x.glsl\nfilter_linear0 = false'),
     "bayer": ("dithering/bayer-matrix-dithering.glslp", 'shaders = 1\n\nshader0 = shaders/bayer-matrix-dithering.glsl\nfilter_linear0 = false'),
     "quilez": ("interpolation/quilez.glslp", 'shaders = 1\n\nshader0 = shaders/quilez.glsl\nfilter_linear0 = true'),
@@ -325,6 +327,7 @@ SHADERS = {
     "crt/shaders/crt-nes-mini.glsl": {"oracle": "crt_nes_mini",
                                       "params": [("SCANTHICK", 2.0), ("INTENSITY", 0.15), ("BRIGHTBOOST", 0.15)], "samplers": []},
     "scalenx/shaders/epx.glsl": {"oracle": "epx", "params": [], "samplers": []},
+    "handheld/shaders/lcd1x.glsl": {"oracle": "lcd1x", "params": [("BRIGHTEN_SCANLINES", 16.0), ("BRIGHTEN_LCD", 4.0)], "samplers": []},
     "handheld/shaders/lcd3x.glsl": {"oracle": "lcd3x", "params": [("brighten_scanlines", 16.0), ("brighten_lcd", 4.0)], "samplers": []},
     "dithering/shaders/bayer-matrix-dithering.glsl": {"oracle": "bayer", "params": [("animate", 0.0), ("dither_size", 0.0)], "samplers": []},
     "interpolation/shaders/quilez.glsl": {"oracle": "quilez", "params": [], "samplers": []},

@@ -480,6 +480,10 @@ def case_epx():
 
 
 def case_lcd3x():
+    Q = GLSL + "/handheld/lcd1x.glslp"
+    run_case("lcd1x_64x48_to_192x144", Q, mixed(64, 48, 153), 192, 144)
+    run_case("lcd1x_params_80x60_to_301x217", Q, noise(80, 60, 154), 301, 217, params=[("BRIGHTEN_SCANLINES", 3.0), ("BRIGHTEN_LCD", 1.5)])
+    run_case("f32_lcd1x_64x48_to_200x150", Q, noise(64, 48, 155), 200, 150, f32=True)
     P = GLSL + "/handheld/lcd3x.glslp"
     run_case("lcd3x_64x48_to_192x144", P, mixed(64, 48, 150), 192, 144)
     run_case("lcd3x_params_80x60_to_301x217", P, noise(80, 60, 151), 301, 217, params=[("brighten_scanlines", 4.0), ("brighten_lcd", 1.5)])

@@ -146,6 +146,7 @@ def test_xbr_lv2_matches_oracle_and_golden(case, preset_tree, rc_lib):
 
 
 @pytest.mark.parametrize("case,key", [("bayer_64x48_to_237x171", "bayer"), ("bayer_animated_80x60_to_320x240_f3", "bayer"),
+                                      ("lcd1x_64x48_to_192x144", "lcd1x"), ("lcd1x_params_80x60_to_301x217", "lcd1x"),
                                       ("lcd3x_64x48_to_192x144", "lcd3x"), ("lcd3x_params_80x60_to_301x217", "lcd3x"), ("epx_80x56_to_300x200", "epx"), ("epx_mixed_64x48_to_64x48", "epx"), ("quilez_64x48_to_237x171", "quilez"), ("smootheststep_64x48_to_237x171", "smootheststep"), ("sharp_bilinear_64x48_to_237x171", "sharp-bilinear"),
                                       ("sharp_bilinear_manual_80x60_to_400x300", "sharp-bilinear"),
                                       ("crt_nes_mini_96x64_to_301x217", "crt-nes-mini"), ("crt_nes_mini_params_80x60_to_320x240", "crt-nes-mini"),

@@ -44,6 +44,8 @@ CASES = {
     "crt_royale_ntsc_320px_composite_80x56_to_300x200": "crt-royale-ntsc-320px-composite",
     "bayer_64x48_to_237x171": "bayer",
     "bayer_animated_80x60_to_320x240_f3": "bayer",     # animate = 1: the pattern scale follows FrameCount (3 frames applied)
+    "lcd1x_64x48_to_192x144": "lcd1x",
+    "lcd1x_params_80x60_to_301x217": "lcd1x",
     "lcd3x_64x48_to_192x144": "lcd3x",
     "lcd3x_params_80x60_to_301x217": "lcd3x",
     "epx_80x56_to_300x200": "epx",          # the only pass is source x 2.0: 160x112 whatever the viewport
@@ -199,6 +201,7 @@ FLOAT_CASES = {
     "f32_crt_nes_mini_64x48_to_200x150": ("crt-nes-mini", {}),
     "f32_quilez_64x48_to_200x150": ("quilez", {}),
     "f32_lcd3x_64x48_to_200x150": ("lcd3x", {}),
+    "f32_lcd1x_64x48_to_200x150": ("lcd1x", {}),
     "f32_smootheststep_64x48_to_200x150": ("smootheststep", {}),
     "f32_sharp_bilinear_64x48_to_200x150": ("sharp-bilinear", {}),
     "f32_crt_easymode_64x48_to_200x150": ("crt-easymode", {0: 0.95}),   # 8-bit goldens exact; <= 3e-7 in float
