@@ -244,6 +244,13 @@ void rc_pipeline_set_image_adjust(rc_pipeline* p, float brightness, float contra
  * instruction: all 2^23 mantissas / 2^26 operand pairs / 6 x 2^24 quotients.  mismatches[0..2]
  * receive the counts (all 0 on a conforming device).  Returns RC_OK or RC_ERR_DEVICE. */
 int rc_selftest_fastmath(int device, uint64_t mismatches[3]);
+/* The sRGB8 encode of an sRGB render target (GL_FRAMEBUFFER_SRGB, reference ShaderEngine.cpp:944-952; the
+ * conversion is the GL's: Mesa llvmpipe's RSQRTPS-based lp_build_linear_to_srgb, restated exactly in
+ * csrc/srgb_encode.cpp) applied to a flat array of floats: with the host-side per-run table the kernels
+ * use (host pointers), and by the device function every pass kernel stores through (device pointers).
+ * For tests: both must equal the oracle's byte for every float. */
+int rc_selftest_srgb8_host(const float* src, uint8_t* dst, size_t n);
+int rc_selftest_srgb8_device(int device, const float* d_src, uint8_t* d_dst, size_t n, void* stream);
 
 const char* rc_last_error(void);
 const char* rc_version(void);

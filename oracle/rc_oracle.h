@@ -71,6 +71,8 @@ o_vec4 o_sample(const o_tex* t, float s, float v);
 extern const float o_srgb_decode_table[256];
 uint8_t o_store_unorm8(float x);
 uint8_t o_store_srgb8(float x);
+/* bulk form for the exhaustive probe and the tests: dst[i] = o_store_srgb8(src[i]) */
+void o_store_srgb8_array(const float* src, uint8_t* dst, size_t n);
 
 /* ---- varyings (rc_varying.c) --------------------------------------------------------- */
 /* A varying written by the vertex shader, as the rasteriser hands it to pixel (x, y) of a

@@ -22,6 +22,7 @@
 #include <math.h>
 
 #include "rc_oracle.h"
+#include <string.h>
 #include "rc_tables.inc"
 
 static inline o_vec4 v4(float x, float y, float z, float w) { o_vec4 r = {x, y, z, w}; return r; }
@@ -185,13 +186,36 @@ uint8_t o_store_unorm8(float x) {
   return (uint8_t)rintf(x * 255.0f);
 }
 
+/* RSQRTPS of a positive normal float (oracle/rc_rsqrt_table.inc) */
+#include "rc_rsqrt_table.inc"
+static float rsqrtps_(float x) {
+  uint32_t b;
+  memcpy(&b, &x, 4);
+  const int E = (int)(b >> 23);
+  const int k = (E & 1) ? (E - 127) / 2 : (E - 128) / 2;
+  const uint32_t rb = (((uint32_t)o_rsqrtps_table[(b >> 13) & 0x7ffu] + 0x7e000u) << 11) - ((uint32_t)k << 23);
+  float r;
+  memcpy(&r, &rb, 4);
+  return r;
+}
+
+/* llvmpipe's linear -> sRGB8 conversion (Mesa 23.2.1 gallivm lp_bld_format_srgb.c, lp_build_linear_to_srgb with
+ * the fast rsqrt available): clamp to [0,1] (NaN -> 0); x <= 0.0031308: x * (12.92 * 255); else
+ * a * x^0.375 + (b * x^0.5 + c) with x^0.5 = x * rsqrt(x), x^0.375 = rsqrt(rsqrt(x * x^0.5)), the b/c term fused;
+ * round to nearest even.  Verified against the GL for EVERY float in [0,1] and samples outside it
+ * (oracle/probes/srgb_encode_sweep.py): the stored byte is this function of the float, bit for bit. */
 uint8_t o_store_srgb8(float x) {
-  if (!(x > 0.0f)) return 0;
-  /* number of thresholds <= x */
-  int lo = 0, hi = 255;
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (o_srgb_encode_thresholds[mid] <= x) lo = mid + 1; else hi = mid;
-  }
-  return (uint8_t)lo;
+  if (!(x > 0.0f)) return 0; /* also NaN */
+  if (x > 1.0f) x = 1.0f;
+  if (x <= 0.0031308f) return (uint8_t)rintf(x * (12.92f * 255.0f));
+  const float x05 = x * rsqrtps_(x);
+  const float t = x05 * x;
+  const float x0375 = rsqrtps_(rsqrtps_(t));
+  const float a = (float)(0.675f * 1.0622 * 255.0f), b = (float)(0.325f * 1.0622 * 255.0f), c = -0.0620f * 255.0f;
+  const float y = a * x0375 + fmaf(b, x05, c);
+  return (uint8_t)rintf(y);
+}
+
+void o_store_srgb8_array(const float* src, uint8_t* dst, size_t n) {
+  for (size_t i = 0; i < n; ++i) dst[i] = o_store_srgb8(src[i]);
 }

@@ -63,8 +63,7 @@ __global__ void __launch_bounds__(256) k_stock_blit(const PassLaunch L) {
 }
 
 __global__ void __launch_bounds__(256) k_stock(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
   store_rt(L, z, x, y, sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds), &lds);
@@ -73,8 +72,7 @@ __global__ void __launch_bounds__(256) k_stock(const PassLaunch L) {
 
 // params: SCANLINE_BASE_BRIGHTNESS, SCANLINE_SINE_COMP_A, SCANLINE_SINE_COMP_B, size
 __global__ void __launch_bounds__(256) k_scanline(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float base = L.params[0], comp_a = L.params[1], comp_b = L.params[2], size = L.params[3];
   const float pi = 3.141592654f;
@@ -91,8 +89,7 @@ __global__ void __launch_bounds__(256) k_scanline(const PassLaunch L) {
 // extra[0] = PrevTexture; mix(colour, colourPrev, 0.5) with a constant weight = a*(1-0.5) + b*0.5
 // plane[0], plane[1]: TEX0 = TexCoord * 1.0001
 __global__ void __launch_bounds__(256) k_mix_frames(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
   const float4 c = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
@@ -104,8 +101,7 @@ __global__ void __launch_bounds__(256) k_mix_frames(const PassLaunch L) {
 // Conformance fixture tests/fixtures/conformance/feedback-persist.glsl (this repository's own shader):
 // max(cur*0.75 + old0*0.25, old1*PERSIST); extra[0] = PassFeedback0, extra[1] = PassFeedback1
 __global__ void __launch_bounds__(256) k_feedback_persist(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float persist = L.params[0];
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
@@ -124,8 +120,7 @@ __global__ void __launch_bounds__(256) k_feedback_persist(const PassLaunch L) {
 // GENERIC false: GL_RGB source (RGBX8) LINEAR clamp-to-edge and a plain RGBA8 target - the shipped single-pass preset
 template <bool GENERIC>
 __global__ void __launch_bounds__(256) k_zfast_crt(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  if (GENERIC) load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float blur = L.params[0], lowlum = L.params[1], hilum = L.params[2], boost = L.params[3], mdark = L.params[4];
   const float mask_fade = 0.3333f * L.params[5];
@@ -156,8 +151,7 @@ __global__ void __launch_bounds__(256) k_zfast_crt(const PassLaunch L) {
 // handheld/shaders/lcd1x.glsl (handheld/lcd1x.glslp), FS 104-121; plane[0], plane[1]: TEX0 = TexCoord * 1.0001.
 // params: BRIGHTEN_SCANLINES, BRIGHTEN_LCD
 __global__ void __launch_bounds__(256) k_lcd1x(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float bs = L.params[0], bl = L.params[1];
   const float two_pi = 2.0f * 3.141592654f;
@@ -174,8 +168,7 @@ __global__ void __launch_bounds__(256) k_lcd1x(const PassLaunch L) {
 __constant__ int k_bayer8[64] = {0, 32, 8, 40, 2, 34, 10, 42, 48, 16, 56, 24, 50, 18, 58, 26, 12, 44, 4, 36, 14, 46, 6, 38, 60, 28, 52, 20, 62, 30, 54, 22,
                                  3, 35, 11, 43, 1, 33, 9, 41, 51, 19, 59, 27, 49, 17, 57, 25, 15, 47, 7, 39, 13, 45, 5, 37, 63, 31, 55, 23, 61, 29, 53, 21};
 __global__ void __launch_bounds__(256) k_bayer(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float fc2 = 2.0f * (float)(L.frame_count0 + z);
   const float scale = (3.0f + (fc2 - 32.0f * __builtin_floorf(fc2 / 32.0f)) * L.params[0]) + L.params[1];
@@ -191,8 +184,7 @@ __global__ void __launch_bounds__(256) k_bayer(const PassLaunch L) {
 
 // handheld/shaders/lcd3x.glsl (handheld/lcd3x.glslp), FS 95-110.  params: brighten_scanlines, brighten_lcd
 __global__ void __launch_bounds__(256) k_lcd3x(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float bs = L.params[0], bl = L.params[1];
   const float pi = 3.141592654f;
@@ -213,8 +205,7 @@ __global__ void __launch_bounds__(256) k_lcd3x(const PassLaunch L) {
 // scalenx/shaders/epx.glsl (scalenx/epx.glslp: NEAREST, source x 2), FS 97-136: EPX / Scale2x selection rules.
 __device__ __forceinline__ bool epx_same(const float4 a, const float4 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
 __global__ void __launch_bounds__(256) k_epx(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float tsx = (float)L.in.w, tsy = (float)L.in.h, idx = 1.0f / tsx, idy = 1.0f / tsy;
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
@@ -240,8 +231,7 @@ __global__ void __launch_bounds__(256) k_epx(const PassLaunch L) {
 // MODE 0: quilez, 1: sharp-bilinear, 2: smootheststep (interpolation/shaders/smootheststep.glsl FS 87-112)
 template <int MODE>
 __global__ void __launch_bounds__(256) k_interp(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float tsx = (float)L.in.w, tsy = (float)L.in.h, idx = 1.0f / tsx, idy = 1.0f / tsy;
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
@@ -278,8 +268,7 @@ __global__ void __launch_bounds__(256) k_interp(const PassLaunch L) {
 // crt/shaders/crt-nes-mini.glsl, VS 38-43, FS 94-105; plane[0], plane[1]: TEX0 = TexCoord * 1.00001.
 // params: SCANTHICK, INTENSITY, BRIGHTBOOST (the last always 1.25: one of the uniforms the reference overwrites)
 __global__ void __launch_bounds__(256) k_crt_nes_mini(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float thick = L.params[0], inten = L.params[1], boost = L.params[2];
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
@@ -331,8 +320,7 @@ __device__ __forceinline__ void em_lanczos(const Tex& t, const uint8_t* img, flo
 // GENERIC false: GL_RGB source (RGBX8) NEAREST clamp-to-edge and a plain RGBA8 target - the shipped single-pass preset
 template <bool GENERIC>
 __global__ void __launch_bounds__(256) k_crt_easymode(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  if (GENERIC) load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float* P = L.params;
   const float sh = P[0], sv = P[1], mstr = P[2], mdw = P[3], mdh = P[4], mstag = P[5], msize = P[6], sstr = P[7];
@@ -404,8 +392,7 @@ __device__ __forceinline__ float crtpi_weight(float dist, float sw, float gap) {
 // plane[0], plane[1]: TEX0 = TexCoord * 1.0001
 template <int IN_FMT, int IN_LINEAR, int IN_WRAP, int OUT_FMT, bool GENERIC>
 __global__ void __launch_bounds__(256) k_crt_pi(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  if (GENERIC || IN_FMT == FMT_SRGB8 || OUT_FMT == FMT_SRGB8) load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float mask_b = L.params[2], sw = L.params[3], gap = L.params[4], bloom = L.params[5];
   const float in_gamma = L.params[6], out_gamma = L.params[7];
@@ -457,78 +444,78 @@ namespace rck {
 
 hipError_t launch_stock(const PassLaunch& L, hipStream_t s) {
   if (L.in.fmt == FMT_RGBA8 && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8) {
-    if (L.in.linear) hipLaunchKernelGGL(k_stock_blit<true>, px_grid(L), px_block(), 0, s, L);
-    else hipLaunchKernelGGL(k_stock_blit<false>, px_grid(L), px_block(), 0, s, L);
+    if (L.in.linear) hipLaunchKernelGGL(k_stock_blit<true>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+    else hipLaunchKernelGGL(k_stock_blit<false>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(k_stock, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_stock, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_mix_frames(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_mix_frames, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_mix_frames, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_feedback_persist, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_feedback_persist, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_scanline(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_scanline, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_scanline, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_lcd1x(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_lcd1x, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_lcd1x, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_bayer(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_bayer, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_bayer, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_lcd3x(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_lcd3x, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_lcd3x, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_epx(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_epx, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_epx, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_quilez(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_interp<0>, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_interp<0>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_sharp_bilinear(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_interp<1>, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_interp<1>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_smootheststep(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_interp<2>, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_interp<2>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_crt_nes_mini(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL(k_crt_nes_mini, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_crt_nes_mini, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_crt_easymode(const PassLaunch& L, hipStream_t s) {
   const bool fast = L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.in.n_levels <= 1 && L.out_fmt == FMT_RGBA8 &&
                     !(L.flags & RC_FLAG_GENERAL_ONLY);
-  if (fast) hipLaunchKernelGGL(k_crt_easymode<false>, px_grid(L), px_block(), 0, s, L);
-  else hipLaunchKernelGGL(k_crt_easymode<true>, px_grid(L), px_block(), 0, s, L);
+  if (fast) hipLaunchKernelGGL(k_crt_easymode<false>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  else hipLaunchKernelGGL(k_crt_easymode<true>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_zfast_crt(const PassLaunch& L, hipStream_t s) {
   const bool fast = L.in.fmt == FMT_RGBX8 && L.in.linear && L.in.wrap == WRAP_EDGE && L.in.n_levels <= 1 && L.out_fmt == FMT_RGBA8 &&
                     !(L.flags & RC_FLAG_GENERAL_ONLY);
-  if (fast) hipLaunchKernelGGL(k_zfast_crt<false>, px_grid(L), px_block(), 0, s, L);
-  else hipLaunchKernelGGL(k_zfast_crt<true>, px_grid(L), px_block(), 0, s, L);
+  if (fast) hipLaunchKernelGGL(k_zfast_crt<false>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  else hipLaunchKernelGGL(k_zfast_crt<true>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_crt_pi(const PassLaunch& L, hipStream_t s) {
   // the shipped preset's configuration (crt/crt-pi.glslp: linear, clamp_to_border, RGBA8 out,
   // on the RGB source frame) gets a specialised instantiation
   if (L.in.fmt == FMT_RGBX8 && L.in.linear && L.in.wrap == WRAP_BORDER && L.out_fmt == FMT_RGBA8)
-    hipLaunchKernelGGL((k_crt_pi<FMT_RGBX8, 1, WRAP_BORDER, FMT_RGBA8, false>), px_grid(L), px_block(), 0, s, L);
+    hipLaunchKernelGGL((k_crt_pi<FMT_RGBX8, 1, WRAP_BORDER, FMT_RGBA8, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   else
-    hipLaunchKernelGGL((k_crt_pi<0, 0, 0, 0, true>), px_grid(L), px_block(), 0, s, L);
+    hipLaunchKernelGGL((k_crt_pi<0, 0, 0, 0, true>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 

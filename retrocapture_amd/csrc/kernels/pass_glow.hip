@@ -21,8 +21,7 @@ __device__ __forceinline__ float clamp_ps(float x, float lo, float hi) { return 
 
 // params: INPUT_GAMMA
 __global__ void __launch_bounds__(256) k_glow_linearize(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float g = L.params[0];
   const float4 c = sample_rt(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
@@ -35,9 +34,8 @@ __global__ void __launch_bounds__(256) k_glow_linearize(const PassLaunch L) {
 // pass, pass_royale.hip).  OP 0: linearize, OP 1: threshold.  Same bytes as the general kernels (tested).
 template <int OP>
 __global__ void __launch_bounds__(256) k_glow_bytemap(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  __shared__ uint32_t map[256];
-  load_srgb_tables(lds);
+    __shared__ uint32_t map[256];
+  RC_SRGB_LDS(lds, L);
   {
     const int t = threadIdx.y * 64 + threadIdx.x;
     const float c = L.in.fmt == FMT_SRGB8 ? lds.dec[t] : (float)t * (1.0f / 255.0f);
@@ -57,8 +55,7 @@ __global__ void __launch_bounds__(256) k_glow_bytemap(const PassLaunch L) {
 
 // params: GLOW_WHITEPOINT, GLOW_ROLLOFF
 __global__ void __launch_bounds__(256) k_glow_threshold(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float wp = L.params[0], roll = L.params[1];
   const float4 c = sample_rt(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
@@ -73,8 +70,7 @@ __global__ void __launch_bounds__(256) k_glow_threshold(const PassLaunch L) {
 // their sum (params[9]); HORIZ steps 4 texels on a mip-mapped input, else 1 texel vertically
 template <bool HORIZ>
 __global__ void __launch_bounds__(256) k_glow_blur(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float step = HORIZ ? 4.0f * (1.0f / (float)L.in.w) : 1.0f / (float)L.in.h;
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
@@ -114,9 +110,8 @@ __global__ void __launch_bounds__(256) k_glow_blur(const PassLaunch L) {
 // pows per pixel become lookups in two 256-entry tables (colour channels, alpha) built once per workgroup.
 template <bool TEXEL_LUT>
 __global__ void __launch_bounds__(256) k_crt_hyllian_glow(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  __shared__ float gin_rgb[TEXEL_LUT ? 256 : 1], gin_a[TEXEL_LUT ? 256 : 1];
-  load_srgb_tables(lds);
+    __shared__ float gin_rgb[TEXEL_LUT ? 256 : 1], gin_a[TEXEL_LUT ? 256 : 1];
+  RC_SRGB_LDS(lds, L);
   if (TEXEL_LUT) {
     const int t = threadIdx.y * 64 + threadIdx.x;
     const float k = (float)t * (1.0f / 255.0f);
@@ -191,8 +186,7 @@ __global__ void __launch_bounds__(256) k_crt_hyllian_glow(const PassLaunch L) {
 // params: BLOOM_STRENGTH, OUTPUT_GAMMA, PHOSPHOR_LAYOUT, MASK_INTENSITY; extra[0] = PassPrev4Texture.
 // Phosphor layouts 0, 1, 2, 4, 5 (host validates).
 __global__ void __launch_bounds__(256) k_hyllian_resolve2(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float strength = L.params[0], gamma = L.params[1], intensity = L.params[3];
   const int layout = (int)L.params[2];
@@ -228,7 +222,7 @@ __global__ void __launch_bounds__(256) k_hyllian_resolve2(const PassLaunch L) {
 
 namespace rck {
 #define GOK(K)                                                         \
-  hipLaunchKernelGGL(K, px_grid(L), px_block(), 0, s, L);              \
+  hipLaunchKernelGGL(K, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);              \
   return hipGetLastError()
 static bool bytes_nearest_edge(const rcd::Tex& t) {
   return (t.fmt == FMT_SRGB8 || t.fmt == FMT_RGBA8 || t.fmt == FMT_RGBX8) && !t.linear && t.wrap == WRAP_EDGE && t.n_levels <= 1;

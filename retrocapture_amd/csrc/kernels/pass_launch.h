@@ -59,6 +59,7 @@ hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s);
 hipError_t launch_ingest(const void* src, int fmt, uint32_t w, uint32_t h, uint32_t n, void* dst_rgba8, hipStream_t s);
 hipError_t launch_egress_rgb24(const void* src_rgba8, uint32_t w, uint32_t h, uint32_t n, int flip_y, void* dst, hipStream_t s);
 hipError_t launch_selftest(unsigned long long* d_counts, hipStream_t s);
+hipError_t launch_selftest_srgb8(const float* d_src, uint8_t* d_dst, size_t n, const uint32_t* table, hipStream_t s);
 
 // 64x4 pixel tiles: one wave per row segment, so each wave stores 256 contiguous bytes of an
 // RGBA8 row.  A workgroup walks tiles grid-stride (tile index = frame, tile row, tile column),

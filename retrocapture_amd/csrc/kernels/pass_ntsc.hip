@@ -46,8 +46,7 @@ __device__ __forceinline__ void sincos_both(float x, float& s, float& c) {
 // TWO_PHASE / THREE_PHASE (chroma phase and CHROMA_MOD_FREQ).
 template <int IN_FMT, int IN_LINEAR, int IN_WRAP, int OUT_FMT, bool GENERIC, bool COMPOSITE, bool TWO_PHASE>
 __global__ void __launch_bounds__(256) k_ntsc_pass1(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  if (GENERIC || IN_FMT == FMT_SRGB8 || OUT_FMT == FMT_SRGB8) load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   const float k_phase = TWO_PHASE ? 3.14159265f : 0.6667f * 3.14159265f;
   const float k_freq = TWO_PHASE ? (4.0f * 3.14159265f) / 15.0f : 3.14159265f / 3.0f;
   RC_TILE_LOOP_BEGIN
@@ -119,8 +118,7 @@ __device__ __forceinline__ float4 ntsc_epilogue(float r, float g, float b) {
 // plane[0], plane[1]: TEX0 = TexCoord - (0.5 / SourceSize.x, 0)
 template <int IN_FMT, int IN_LINEAR, int IN_WRAP, int OUT_FMT, bool GENERIC, int TAPS, int EPI>
 __global__ void __launch_bounds__(256) k_ntsc_pass2(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  if (GENERIC || IN_FMT == FMT_SRGB8 || OUT_FMT == FMT_SRGB8) load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   const float one_x = 1.0f / (float)L.in.w;
   RC_TILE_LOOP_BEGIN
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
@@ -232,27 +230,27 @@ template <bool COMPOSITE, bool TWO_PHASE>
 hipError_t launch_pass1(const PassLaunch& L, hipStream_t s) {
   // shipped presets: nearest on the RGB source frame, RGBA32F target
   if (L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_F32)
-    hipLaunchKernelGGL((k_ntsc_pass1<FMT_RGBX8, 0, WRAP_EDGE, FMT_F32, false, COMPOSITE, TWO_PHASE>), px_grid(L), px_block(), 0, s, L);
+    hipLaunchKernelGGL((k_ntsc_pass1<FMT_RGBX8, 0, WRAP_EDGE, FMT_F32, false, COMPOSITE, TWO_PHASE>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   else if (L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_BORDER && L.out_fmt == FMT_F32)
-    hipLaunchKernelGGL((k_ntsc_pass1<FMT_RGBX8, 0, WRAP_BORDER, FMT_F32, false, COMPOSITE, TWO_PHASE>), px_grid(L), px_block(), 0, s, L);
+    hipLaunchKernelGGL((k_ntsc_pass1<FMT_RGBX8, 0, WRAP_BORDER, FMT_F32, false, COMPOSITE, TWO_PHASE>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   else
-    hipLaunchKernelGGL((k_ntsc_pass1<0, 0, 0, 0, true, COMPOSITE, TWO_PHASE>), px_grid(L), px_block(), 0, s, L);
+    hipLaunchKernelGGL((k_ntsc_pass1<0, 0, 0, 0, true, COMPOSITE, TWO_PHASE>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 template <int TAPS, int EPI>
 hipError_t launch_pass2(const PassLaunch& L, hipStream_t s) {
   if (L.in.fmt == FMT_F32 && !L.in.linear && L.out_fmt == FMT_RGBA8 && (L.flags & RC_FLAG_NTSC_REGULAR) &&
       !(L.flags & RC_FLAG_GENERAL_ONLY) && (L.in.wrap == WRAP_EDGE || L.in.wrap == WRAP_BORDER)) {
-    if (L.in.wrap == WRAP_EDGE) hipLaunchKernelGGL((k_ntsc_pass2_rows<WRAP_EDGE, TAPS, EPI>), px_grid(L), px_block(), 0, s, L);
-    else hipLaunchKernelGGL((k_ntsc_pass2_rows<WRAP_BORDER, TAPS, EPI>), px_grid(L), px_block(), 0, s, L);
+    if (L.in.wrap == WRAP_EDGE) hipLaunchKernelGGL((k_ntsc_pass2_rows<WRAP_EDGE, TAPS, EPI>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+    else hipLaunchKernelGGL((k_ntsc_pass2_rows<WRAP_BORDER, TAPS, EPI>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
     return hipGetLastError();
   }
   if (L.in.fmt == FMT_F32 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8)
-    hipLaunchKernelGGL((k_ntsc_pass2<FMT_F32, 0, WRAP_EDGE, FMT_RGBA8, false, TAPS, EPI>), px_grid(L), px_block(), 0, s, L);
+    hipLaunchKernelGGL((k_ntsc_pass2<FMT_F32, 0, WRAP_EDGE, FMT_RGBA8, false, TAPS, EPI>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   else if (L.in.fmt == FMT_F32 && !L.in.linear && L.in.wrap == WRAP_BORDER && L.out_fmt == FMT_RGBA8)
-    hipLaunchKernelGGL((k_ntsc_pass2<FMT_F32, 0, WRAP_BORDER, FMT_RGBA8, false, TAPS, EPI>), px_grid(L), px_block(), 0, s, L);
+    hipLaunchKernelGGL((k_ntsc_pass2<FMT_F32, 0, WRAP_BORDER, FMT_RGBA8, false, TAPS, EPI>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   else
-    hipLaunchKernelGGL((k_ntsc_pass2<0, 0, 0, 0, true, TAPS, EPI>), px_grid(L), px_block(), 0, s, L);
+    hipLaunchKernelGGL((k_ntsc_pass2<0, 0, 0, 0, true, TAPS, EPI>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_ntsc_pass1(const PassLaunch& L, hipStream_t s) { return launch_pass1<false, false>(L, s); }

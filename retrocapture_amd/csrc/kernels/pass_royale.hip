@@ -59,9 +59,8 @@ constexpr float kUnderHalf = 0.4995f;
 // first-pass-linearize-crt-gamma-bob-fields.glsl FS 4850-4884.  The source texel is a byte per
 // channel, so pow(texel, crt_gamma = 2.5) takes 256 values: tabulated once per workgroup.
 __global__ void __launch_bounds__(256) k_royale_first(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  __shared__ float lin[256];
-  load_srgb_tables(lds);
+    __shared__ float lin[256];
+  RC_SRGB_LDS(lds, L);
   {
     const int t = threadIdx.y * 64 + threadIdx.x;
     lin[t] = pow_((float)t * (1.0f / 255.0f), 2.5f);
@@ -108,9 +107,8 @@ __global__ void __launch_bounds__(256) k_royale_first(const PassLaunch L) {
 // pass is a 256-entry byte map applied to the nearest texel.  Same results as k_royale_first.
 template <int OUT_FMT>
 __global__ void __launch_bounds__(256) k_royale_first_bytemap(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  __shared__ uint32_t map[256];
-  load_srgb_tables(lds);
+    __shared__ uint32_t map[256];
+  RC_SRGB_LDS(lds, L);
   {
     const int t = threadIdx.y * 64 + threadIdx.x;
     const float lin = pow_((float)t * (1.0f / 255.0f), 2.5f);
@@ -175,8 +173,7 @@ __device__ __forceinline__ F beam_k(F color, F dist, float off, float sigma_rang
 
 template <class SI, class SO>
 __global__ void __launch_bounds__(256, 4) k_royale_scan_v(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float tsx = (float)L.in.w, tsy = L.params[RP1_TSY];   // TextureSize.y as the reference sets it (royale_setup.cpp)
   const float y_step = L.params[RP1_Y_STEP], uv_step_y = L.params[RP1_UV_STEP_Y], ph = L.params[RP1_PH];
@@ -262,8 +259,7 @@ __device__ __forceinline__ void scan_v_gather(const PassLaunch& L, const SrgbLds
 // (rc_vecmath.h).  Tiles are 64 x 8; a wave still stores 256 contiguous bytes per row.  Same results as k_royale_scan_v.
 template <class SI, class SO>
 __global__ void __launch_bounds__(256, 4) k_royale_scan_v2(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   const int tiles_x = (L.out_w + 63) >> 6, tiles_y = (L.out_h + 7) >> 3;
   const int tiles_per_frame = tiles_x * tiles_y, n_tiles = tiles_per_frame * L.n_frames;
   const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
@@ -294,8 +290,7 @@ __global__ void __launch_bounds__(256, 4) k_royale_scan_v2(const PassLaunch L) {
 // bloom-approx.glsl FS 14053-14184: the only live statement samples extra[0] at tex_uv.
 template <class S0, class SO>
 __global__ void __launch_bounds__(256) k_royale_bloom_approx(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
   SO::put(L, z, x, y, S0::get(L.extra[0], frame_ptr(L.extra[0], z), u, v, &lds), &lds);
@@ -307,8 +302,7 @@ __global__ void __launch_bounds__(256) k_royale_bloom_approx(const PassLaunch L)
 // folded by the host (royale_setup.cpp) the way the GL's compiler folds them.
 template <class SI, class SO>
 __global__ void __launch_bounds__(256) k_blur9(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float w12 = L.params[RPB_W12], w34 = L.params[RPB_W34], k12 = L.params[RPB_K12], k34 = L.params[RPB_K34];
   const float sum_inv = L.params[RPB_SUM_INV], dx = L.params[RPB_DX], dy = L.params[RPB_DY];
@@ -373,8 +367,7 @@ __device__ __forceinline__ float4 sinc_tiled(const Tex& t, const uint8_t* img, f
 }
 
 __global__ void __launch_bounds__(256) k_royale_mask_v(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float wu = vary(L.plane[0], x, y, lo), wv = vary(L.plane[1], x, y, lo);
   uint8_t* o = static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z;
@@ -389,8 +382,7 @@ __global__ void __launch_bounds__(256) k_royale_mask_v(const PassLaunch L) {
 }
 
 __global__ void __launch_bounds__(256) k_royale_mask_h(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   uint8_t* o = static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z;
   if (!(L.flags & RC_FLAG_UNDEF_VARYING_ZERO)) {
@@ -450,8 +442,7 @@ __device__ __forceinline__ float fake_bloom_tail(float scan, float mask, float s
 // FAKE: extra = PassPrev6 (VERTICAL_SCANLINES), PassPrev5 (BLOOM_APPROX), PassPrev3 (HALATION_BLUR)
 template <class SI, class S0, class SO, bool FAKE>
 __global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float vu = vary(L.plane[0], x, y, lo), vv = vary(L.plane[1], x, y, lo);
   const float twx = vu * L.params[RP7_TPS_X], twy = vv * L.params[RP7_TPS_Y];
@@ -485,8 +476,7 @@ __global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
 // brightpass.glsl FS 14610-14663; extra[0] = PassPrev4Texture.
 template <class SI, class S0, class SO>
 __global__ void __launch_bounds__(256) k_royale_brightpass(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float4 idim = SI::get(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
   float4 o = make_float4(0.f, 0.f, 0.f, 1.0f);
@@ -547,8 +537,7 @@ __device__ __forceinline__ float4 blur17(const Tex& t, const uint8_t* img, float
 
 template <class SI, class SO>
 __global__ void __launch_bounds__(256) k_royale_bloom_v(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float4 c = blur17<SI>(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), 0.0f, L.params[RPG_DXY],
                           L.params, &lds);
@@ -560,8 +549,7 @@ __global__ void __launch_bounds__(256) k_royale_bloom_v(const PassLaunch L) {
 // extra[0] = PassPrev3 (MASKED_SCANLINES), extra[1] = PassPrev2 (BRIGHTPASS), extra[2] = PassPrev6 (HALATION_BLUR)
 template <class SI, class S0, class S1, class S2, class SO>
 __global__ void __launch_bounds__(256, 4) k_royale_bloom_h(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float4 blurred = blur17<SI>(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), L.params[RPG_DXY], 0.0f,
                                 L.params, &lds);
@@ -587,8 +575,7 @@ __global__ void __launch_bounds__(256, 4) k_royale_bloom_h(const PassLaunch L) {
 // geometry-aa-last-pass.glsl FS 5451-5531 (flat geometry path), get_border_dim_factor 5250.
 template <class SI, class SO, bool MIP>
 __global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float tsx = (float)L.in.w, tsy = (float)L.in.h;
   const float* P = L.params;
@@ -639,22 +626,22 @@ __global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
 namespace rck {
 #define RC_LAUNCH(fn, kernel)                                         \
   hipError_t fn(const PassLaunch& L, hipStream_t s) {                 \
-    hipLaunchKernelGGL(kernel, px_grid(L), px_block(), 0, s, L);      \
+    hipLaunchKernelGGL(kernel, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);      \
     return hipGetLastError();                                         \
   }
 hipError_t launch_royale_first(const PassLaunch& L, hipStream_t s) {
   const bool bytes_in = (L.in.fmt == FMT_RGBX8 || L.in.fmt == FMT_RGBA8) && !L.in.linear && L.in.wrap == WRAP_EDGE;
   if (bytes_in && L.params[RP0_INTERLACED] == 0.0f && !(L.flags & RC_FLAG_GENERAL_ONLY)) {
     if (L.out_fmt == FMT_SRGB8) {
-      hipLaunchKernelGGL(k_royale_first_bytemap<FMT_SRGB8>, px_grid(L), px_block(), 0, s, L);
+      hipLaunchKernelGGL(k_royale_first_bytemap<FMT_SRGB8>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
       return hipGetLastError();
     }
     if (L.out_fmt == FMT_RGBA8) {
-      hipLaunchKernelGGL(k_royale_first_bytemap<FMT_RGBA8>, px_grid(L), px_block(), 0, s, L);
+      hipLaunchKernelGGL(k_royale_first_bytemap<FMT_RGBA8>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
       return hipGetLastError();
     }
   }
-  hipLaunchKernelGGL(k_royale_first, px_grid(L), px_block(), 0, s, L);
+  hipLaunchKernelGGL(k_royale_first, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 RC_LAUNCH(launch_royale_mask_v, k_royale_mask_v)
@@ -662,7 +649,7 @@ RC_LAUNCH(launch_royale_mask_h, k_royale_mask_h)
 
 #define GO(...)                                                                 \
   do {                                                                          \
-    hipLaunchKernelGGL((__VA_ARGS__), px_grid(L), px_block(), 0, s, L);          \
+    hipLaunchKernelGGL((__VA_ARGS__), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);          \
     return hipGetLastError();                                                   \
   } while (0)
 using OutS = St<FMT_SRGB8>;
@@ -672,7 +659,7 @@ hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s) {
     if (L.flags & RC_FLAG_GENERAL_ONLY) GO((k_royale_scan_v<SrgbLinEdge, OutS>));
     // two rows per thread: 64 x 8 tiles
     const long tiles = (long)((L.out_w + 63) / 64) * ((L.out_h + 7) / 8) * L.n_frames;
-    hipLaunchKernelGGL((k_royale_scan_v2<SrgbLinEdge, OutS>), dim3((unsigned)(tiles < 2048 ? (tiles > 0 ? tiles : 1) : 2048)), px_block(), 0, s, L);
+    hipLaunchKernelGGL((k_royale_scan_v2<SrgbLinEdge, OutS>), dim3((unsigned)(tiles < 2048 ? (tiles > 0 ? tiles : 1) : 2048)), px_block(), rcd::srgb_lds_bytes(L), s, L);
     return hipGetLastError();
   }
   GO(k_royale_scan_v<SRT, StRT>);

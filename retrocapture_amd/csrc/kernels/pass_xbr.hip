@@ -178,8 +178,7 @@ __device__ __forceinline__ float4 xbr_pixel(const PassLaunch& L, const SrgbLds* 
 
 template <int IN_FMT, int IN_WRAP, int OUT_FMT, bool GENERIC>
 __global__ void __launch_bounds__(256) k_xbr_lv3(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  if (GENERIC || IN_FMT == FMT_SRGB8 || OUT_FMT == FMT_SRGB8) load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float4 res = xbr_pixel<IN_FMT, IN_WRAP, GENERIC>(L, &lds, x, y, z, lo);
   if (GENERIC) store_rt(L, z, x, y, res, &lds);
@@ -206,8 +205,7 @@ __device__ __forceinline__ float dot_rgbw(const float4 p) { return p.x * 14.352f
 // GENERIC false: RGBX8 / RGBA8 NEAREST clamp-to-edge source and a plain RGBA8 target (the shipped preset)
 template <int IN_FMT, bool GENERIC>
 __global__ void __launch_bounds__(256) k_xbr_lv2(const PassLaunch L) {
-  __shared__ SrgbLds lds;
-  if (GENERIC) load_srgb_tables(lds);
+  RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
   const float thr = L.params[2], lv2 = L.params[4];
   const float tsx = (float)L.in.w, tsy = (float)L.in.h;
@@ -467,9 +465,9 @@ namespace rck {
 
 hipError_t launch_xbr_lv2(const PassLaunch& L, hipStream_t s) {
   const bool fast = !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8 && !(L.flags & RC_FLAG_GENERAL_ONLY);
-  if (fast && L.in.fmt == FMT_RGBX8) hipLaunchKernelGGL((k_xbr_lv2<FMT_RGBX8, false>), px_grid(L), px_block(), 0, s, L);
-  else if (fast && L.in.fmt == FMT_RGBA8) hipLaunchKernelGGL((k_xbr_lv2<FMT_RGBA8, false>), px_grid(L), px_block(), 0, s, L);
-  else hipLaunchKernelGGL((k_xbr_lv2<FMT_RGBA8, true>), px_grid(L), px_block(), 0, s, L);
+  if (fast && L.in.fmt == FMT_RGBX8) hipLaunchKernelGGL((k_xbr_lv2<FMT_RGBX8, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  else if (fast && L.in.fmt == FMT_RGBA8) hipLaunchKernelGGL((k_xbr_lv2<FMT_RGBA8, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  else hipLaunchKernelGGL((k_xbr_lv2<FMT_RGBA8, true>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_xbr_lv3(const PassLaunch& L, hipStream_t s) {
@@ -483,23 +481,23 @@ hipError_t launch_xbr_lv3(const PassLaunch& L, hipStream_t s) {
     std::memcpy(&n_cols, &L.params[XBR_P_NCOLS], 4);
     const unsigned fix_blocks = (unsigned)(n_rows * ((L.out_w + 255) / 256) + n_cols * ((L.out_h + 255) / 256));
     if (L.in.wrap == WRAP_EDGE) {
-      hipLaunchKernelGGL((k_xbr_rules<WRAP_EDGE>), dim3(blocks ? blocks : 1), dim3(256), 0, s, L);
-      hipLaunchKernelGGL((k_xbr_blend<WRAP_EDGE>), px_grid(L), px_block(), 0, s, L);
-      if (fix_blocks) hipLaunchKernelGGL((k_xbr_fix<WRAP_EDGE>), dim3(fix_blocks, L.n_frames), dim3(256), 0, s, L);
+      hipLaunchKernelGGL((k_xbr_rules<WRAP_EDGE>), dim3(blocks ? blocks : 1), dim3(256), rcd::srgb_lds_bytes(L), s, L);
+      hipLaunchKernelGGL((k_xbr_blend<WRAP_EDGE>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+      if (fix_blocks) hipLaunchKernelGGL((k_xbr_fix<WRAP_EDGE>), dim3(fix_blocks, L.n_frames), dim3(256), rcd::srgb_lds_bytes(L), s, L);
     } else {
-      hipLaunchKernelGGL((k_xbr_rules<WRAP_BORDER>), dim3(blocks ? blocks : 1), dim3(256), 0, s, L);
-      hipLaunchKernelGGL((k_xbr_blend<WRAP_BORDER>), px_grid(L), px_block(), 0, s, L);
-      if (fix_blocks) hipLaunchKernelGGL((k_xbr_fix<WRAP_BORDER>), dim3(fix_blocks, L.n_frames), dim3(256), 0, s, L);
+      hipLaunchKernelGGL((k_xbr_rules<WRAP_BORDER>), dim3(blocks ? blocks : 1), dim3(256), rcd::srgb_lds_bytes(L), s, L);
+      hipLaunchKernelGGL((k_xbr_blend<WRAP_BORDER>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+      if (fix_blocks) hipLaunchKernelGGL((k_xbr_fix<WRAP_BORDER>), dim3(fix_blocks, L.n_frames), dim3(256), rcd::srgb_lds_bytes(L), s, L);
     }
     return hipGetLastError();
   }
   // general form (any sampler state / target format, or an irregular sampling pattern): nearest on the RGB source frame, RGBA8 viewport-sized target
   if (L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8)
-    hipLaunchKernelGGL((k_xbr_lv3<FMT_RGBX8, WRAP_EDGE, FMT_RGBA8, false>), px_grid(L), px_block(), 0, s, L);
+    hipLaunchKernelGGL((k_xbr_lv3<FMT_RGBX8, WRAP_EDGE, FMT_RGBA8, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   else if (L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_BORDER && L.out_fmt == FMT_RGBA8)
-    hipLaunchKernelGGL((k_xbr_lv3<FMT_RGBX8, WRAP_BORDER, FMT_RGBA8, false>), px_grid(L), px_block(), 0, s, L);
+    hipLaunchKernelGGL((k_xbr_lv3<FMT_RGBX8, WRAP_BORDER, FMT_RGBA8, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   else
-    hipLaunchKernelGGL((k_xbr_lv3<0, 0, 0, true>), px_grid(L), px_block(), 0, s, L);
+    hipLaunchKernelGGL((k_xbr_lv3<0, 0, 0, true>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 

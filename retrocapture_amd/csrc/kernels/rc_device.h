@@ -60,6 +60,7 @@ struct PassLaunch {
   int frame_count0;       // FrameCount of frame 0 of this launch; frame z sees frame_count0+z
   int n_frames;
   int flags;              // kernel specific (e.g. RC_FLAG_UNDEF_VARYING_ZERO)
+  const uint32_t* srgb_enc;  // per-run table of the sRGB8 encode in device memory (srgb_encode.cpp); needed when out_fmt is sRGB8
   Plane plane[kMaxPlanes];
   float params[kMaxParams];
 };
@@ -208,26 +209,38 @@ __device__ __forceinline__ float vary(const Plane& p, int x, int y, bool lower) 
 }
 
 // ------------------------------------------------------------------------------- tables ----
-// sRGB8 -> linear float as the texture unit decodes it, and the thresholds of the sRGB8
-// encode (tables measured on the GL; the same numbers as oracle/rc_tables.inc
-// but owned by the product).
-#include "rc_tables_device.inc"  // k_srgb_decode[256], k_srgb_encode_thr[256] ([255] = +inf)
+// sRGB8 -> linear float as the texture unit decodes it (table measured on the GL; the
+// same numbers as oracle/rc_tables.inc but owned by the product), and the sRGB8 encode of an sRGB
+// render target: llvmpipe's RSQRTPS-based conversion, re-tabulated per RSQRTPS run of the argument
+// (srgb_encode.cpp): byte = entry >> 16, plus one from offset (entry & 0xffff) of the run on.
+#include "rc_tables_device.inc"  // k_srgb_decode[256]
 
+constexpr float kSrgbLinMax = 0.0031308f;          // linear segment up to here: byte = rint(x * kSrgbLinScale)
+constexpr float kSrgbLinScale = 12.92f * 255.0f;
+constexpr uint32_t kSrgbRun0 = 0x3b4d2e1cu >> 13;  // run (float bits >> 13) that contains kSrgbLinMax
+constexpr uint32_t kSrgbRuns = (0x3f7fffffu >> 13) - kSrgbRun0 + 1u;  // 8599, up to the last float below 1
+
+// Both tables live in dynamic LDS (the launch passes srgb_lds_bytes(L)): 1 KiB for the decode table,
+// plus 34 KiB for the encode table only when the pass stores to an sRGB8 target.
 struct SrgbLds {
-  float dec[256];
-  float thr[256];
-  uint32_t coarse[kSrgbCoarseWords];
+  const float* dec;
+  const uint32_t* enc;
 };
-// Every thread of the block must call this before sampling sRGB textures / storing sRGB.
-__device__ __forceinline__ void load_srgb_tables(SrgbLds& t) {
-  for (int i = threadIdx.y * blockDim.x + threadIdx.x; i < 256; i += blockDim.x * blockDim.y) {
-    t.dec[i] = k_srgb_decode[i];
-    t.thr[i] = k_srgb_encode_thr[i];
-  }
-  for (int i = threadIdx.y * blockDim.x + threadIdx.x; i < kSrgbCoarseWords; i += blockDim.x * blockDim.y)
-    t.coarse[i] = k_srgb_encode_coarse[i];
+inline unsigned srgb_lds_bytes(const PassLaunch& L) { return 1024u + (L.out_fmt == FMT_SRGB8 ? kSrgbRuns * 4u : 0u); }
+// Every thread of the block must call this (RC_SRGB_LDS) before sampling sRGB textures / storing sRGB.
+__device__ __forceinline__ SrgbLds load_srgb_tables(uint32_t* dyn, const PassLaunch& L) {
+  float* dec = reinterpret_cast<float*>(dyn);
+  uint32_t* enc = dyn + 256;
+  const int nt = blockDim.x * blockDim.y, t0 = threadIdx.y * blockDim.x + threadIdx.x;
+  for (int i = t0; i < 256; i += nt) dec[i] = k_srgb_decode[i];
+  if (L.out_fmt == FMT_SRGB8)
+    for (int i = t0; i < (int)kSrgbRuns; i += nt) enc[i] = L.srgb_enc[i];
   __syncthreads();
+  return SrgbLds{dec, enc};
 }
+#define RC_SRGB_LDS(name, L)                  \
+  extern __shared__ uint32_t rc_dyn_lds_[];   \
+  const rcd::SrgbLds name = rcd::load_srgb_tables(rc_dyn_lds_, (L))
 
 // ------------------------------------------------------------------------------ sampling ----
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -363,19 +376,14 @@ __device__ __forceinline__ uint32_t unorm8(float x) {
   x = x > 1.0f ? 1.0f : x;
   return (uint32_t)__builtin_rintf(x * 255.0f);
 }
-// sRGB8 encode = number of thresholds <= x (255 ascending thresholds + an inf sentinel).
-// A coarse table indexed by the float's upper bits gives the count at the bucket's lower bound;
-// at most two more thresholds lie inside a bucket.
+// sRGB8 encode (see the tables section): one LDS entry per RSQRTPS run of x.
 __device__ __forceinline__ uint32_t srgb8(float x, const SrgbLds* t) {
   if (!(x > 0.0f)) return 0u;  // also NaN
   if (x >= 1.0f) return 255u;
+  if (x <= kSrgbLinMax) return (uint32_t)__builtin_rintf(x * kSrgbLinScale);
   const uint32_t b = f2bits(x);
-  if (b < 0x39000000u) return 0u;  // below 2^-13 < first threshold
-  const uint32_t idx = (b - 0x39000000u) >> 15;
-  uint32_t k = (t->coarse[idx >> 2] >> ((idx & 3u) * 8u)) & 255u;
-  k += (t->thr[k] <= x) ? 1u : 0u;
-  k += (t->thr[k] <= x) ? 1u : 0u;
-  return k;
+  const uint32_t e = t->enc[(b >> 13) - kSrgbRun0];
+  return (e >> 16) + ((b & 0x1fffu) >= (e & 0xffffu) ? 1u : 0u);
 }
 
 template <int OUT_FMT>

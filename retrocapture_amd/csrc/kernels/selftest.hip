@@ -45,9 +45,22 @@ __global__ void __launch_bounds__(256) k_selftest(unsigned long long* counts) {
   if (bad2) atomicAdd(&counts[2], bad2);
 }
 
+// the sRGB8 store of every pass kernel (rc_device.h srgb8) on a flat array of floats
+__global__ void __launch_bounds__(256) k_selftest_srgb8(const float* src, uint8_t* dst, size_t n, const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = (uint8_t)srgb8(src[i], &lds);
+}
+
 }  // namespace
 
 namespace rck {
+hipError_t launch_selftest_srgb8(const float* d_src, uint8_t* d_dst, size_t n, const uint32_t* table, hipStream_t s) {
+  PassLaunch L = {};
+  L.out_fmt = FMT_SRGB8;
+  L.srgb_enc = table;
+  hipLaunchKernelGGL(k_selftest_srgb8, dim3(1024), dim3(256), rcd::srgb_lds_bytes(L), s, d_src, d_dst, n, L);
+  return hipGetLastError();
+}
 hipError_t launch_selftest(unsigned long long* d_counts, hipStream_t s) {
   hipLaunchKernelGGL(k_selftest, dim3(4096), dim3(256), 0, s, d_counts);
   return hipGetLastError();

@@ -10,6 +10,7 @@
 #include "frame_pipeline.h"
 #include "present_setup.h"
 #include "shader_engine.h"
+#include "srgb_encode.h"
 
 struct rc_engine {
   rc::ShaderEngine impl;
@@ -123,6 +124,7 @@ int rc_engine_apply_batch(rc_engine* e, const void* d_in, uint32_t n, uint32_t w
                           const void** d_out, uint32_t* ow, uint32_t* oh) {
   if (!e || !d_out) return RC_ERR_INVALID;
   return guarded([&] {
+    rc::clear_last_error();  // the status below must reflect THIS call only
     const void* out = e->impl.applyShaderBatch(d_in, n, w, h, stride);
     *d_out = out;
     if (!out) return (int)RC_ERR_INVALID;
@@ -357,6 +359,24 @@ int rc_selftest_fastmath(int device, uint64_t mismatches[3]) {
   (void)hipFree(d);
   for (int i = 0; i < 3; ++i) mismatches[i] = h[i];
   return rc;
+}
+int rc_selftest_srgb8_host(const float* src, uint8_t* dst, size_t n) {
+  if (!src || !dst) return RC_ERR_INVALID;
+  return guarded([&] {
+    std::vector<uint32_t> table;
+    if (!rc::buildSrgbRunTable(&table)) return (int)RC_ERR_INVALID;
+    for (size_t i = 0; i < n; ++i) dst[i] = rc::srgb8EncodeByRunTable(src[i], table.data());
+    return (int)RC_OK;
+  });
+}
+int rc_selftest_srgb8_device(int device, const float* d_src, uint8_t* d_dst, size_t n, void* stream) {
+  if (!d_src || !d_dst) return RC_ERR_INVALID;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return RC_ERR_DEVICE;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return RC_ERR_DEVICE;
+  const uint32_t* table = rc::deviceSrgbRunTable(dev);
+  if (!table) return RC_ERR_DEVICE;
+  return rck::launch_selftest_srgb8(d_src, d_dst, n, table, static_cast<hipStream_t>(stream)) == hipSuccess ? RC_OK : RC_ERR_DEVICE;
 }
 int rc_engine_history_count(rc_engine* e) { return e ? (int)e->impl.historyCount() : 0; }
 int rc_engine_read_history(rc_engine* e, int k, uint32_t* width, uint32_t* height, void* host, size_t bytes) {

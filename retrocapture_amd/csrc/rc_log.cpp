@@ -32,4 +32,5 @@ void log(LogLevel level, const std::string& msg) {
 }
 
 const std::string& last_error() { return t_last_error; }
+void clear_last_error() { t_last_error.clear(); }
 }  // namespace rc

@@ -9,6 +9,7 @@ namespace rc {
 enum class LogLevel { Debug = 0, Info = 1, Warn = 2, Error = 3 };
 void log(LogLevel level, const std::string& msg);
 const std::string& last_error();
+void clear_last_error();  // the C ABI clears it on entry of calls whose status depends on it
 }  // namespace rc
 
 #define RC_LOG_DEBUG(m) ::rc::log(::rc::LogLevel::Debug, (m))

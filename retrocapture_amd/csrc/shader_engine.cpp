@@ -10,6 +10,7 @@
 
 #include "png_lut.h"
 #include "rc_log.h"
+#include "srgb_encode.h"
 
 namespace fs = std::filesystem;
 
@@ -72,6 +73,11 @@ bool ShaderEngine::init(int device, hipStream_t stream) {  // :22-60
       RC_LOG_WARN(std::string("ShaderEngine: kernels are built for gfx950, device is ") + prop.gcnArchName);
   }
   m_stream = stream;
+  m_srgbEnc = deviceSrgbRunTable(m_device);
+  if (!m_srgbEnc) {
+    RC_LOG_ERROR("ShaderEngine: could not create the sRGB8 encode table on the device");
+    return false;
+  }
   m_initialized = true;
   return true;
 }
@@ -490,6 +496,7 @@ bool ShaderEngine::buildMipChain(size_t p, const void* level0, uint32_t nFrames)
     const int dw = std::max(1, (int)pd.width >> k), dh = std::max(1, (int)pd.height >> k);
     rcd::PassLaunch L;
     std::memset(static_cast<void*>(&L), 0, sizeof(L));
+    L.srgb_enc = m_srgbEnc;
     L.in = src;
     L.out = static_cast<uint8_t*>(pd.mips.ptr) + off;
     L.out_frame_stride = bytes;
@@ -819,6 +826,7 @@ bool ShaderEngine::pushHistory(const void* finalFrame, int frameCount, const rcd
 
   rcd::PassLaunch L;
   std::memset(&L, 0, sizeof(L));
+  L.srgb_enc = m_srgbEnc;
   L.in = passTexture(m_passes.size() - 1);
   L.in.base = finalFrame;
   L.in.frame_stride = 0;
@@ -889,6 +897,7 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
     } else {
       rcd::PassLaunch L;
       std::memset(&L, 0, sizeof(L));
+      L.srgb_enc = m_srgbEnc;
       L.in = current;
       L.out = target;
       L.out_frame_stride = pd.frameBytes;

@@ -145,6 +145,7 @@ class ShaderEngine {
   bool m_shaderActive = false;
   int m_device = -1;
   hipStream_t m_stream = nullptr;
+  const uint32_t* m_srgbEnc = nullptr;  // sRGB8 encode table of this device (srgb_encode.cpp)
 
   ShaderPreset m_preset;
   std::string m_presetPath;

@@ -95,6 +95,8 @@ SYMBOLS = [
     ("rc_pipeline_set_output_resolution", None, [C.c_void_p, C.c_uint32, C.c_uint32]),
     ("rc_pipeline_set_image_adjust", None, [C.c_void_p, C.c_float, C.c_float]),
     ("rc_selftest_fastmath", C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
+    ("rc_selftest_srgb8_host", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("rc_selftest_srgb8_device", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("rc_last_error", C.c_char_p, []),
     ("rc_version", C.c_char_p, []),
     ("rc_kernel_list", C.c_size_t, [C.c_char_p, C.c_size_t]),
@@ -277,6 +279,24 @@ def selftest_fastmath(device=0):
     if rc != 0:
         raise RcError("rc_selftest_fastmath failed (%d)" % rc)
     return list(out)
+
+
+def srgb8_encode_host(values):
+    """The sRGB8 store of the pass kernels, evaluated on the host through the same per-run table (numpy float32 in)."""
+    import numpy as np
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    out = np.empty(v.size, dtype=np.uint8)
+    rc = load_library().rc_selftest_srgb8_host(v.ctypes.data, out.ctypes.data, v.size)
+    if rc != 0:
+        raise RcError("rc_selftest_srgb8_host failed (%d)" % rc)
+    return out.reshape(v.shape)
+
+
+def srgb8_encode_device(d_values, d_out, n, device=0, stream=0):
+    """The same on the device: d_values (float32) / d_out (uint8) are device pointers or torch tensors."""
+    rc = load_library().rc_selftest_srgb8_device(int(device), _ptr(d_values), _ptr(d_out), int(n), C.c_void_p(int(stream)))
+    if rc != 0:
+        raise RcError("rc_selftest_srgb8_device failed (%d)" % rc)
 
 
 def kernel_list():

@@ -80,9 +80,13 @@ CASES = {
 # crt-royale: every pass that stores to an sRGB8 target can differ from llvmpipe by 1 LSB in
 # ~0.3 % of the bytes, because llvmpipe's sRGB encode runs through the x86 RSQRTPS
 # approximation and is not monotone ("sRGB8 store"); RGBA8 passes must be exact.
-BAR = {"xbr-lv2": (0.9998, 1), "scanline": (1.0, 0), "crt-pi": (1.0, 0), "crt-royale": (0.995, 1), "crt-royale-fake-bloom": (0.995, 1), "crt-hyllian-glow": (0.98, 1),
-       "crt-royale-ntsc-256px-svideo": (0.995, 1), "crt-royale-ntsc-320px-composite": (0.995, 1), "ntsc-256px-svideo": (1.0, 0),
-       "xbr-lv3": (1.0, 0), "mix-frames": (1.0, 0), "feedback-persist": (1.0, 0)}
+# Every preset is bit-exact against llvmpipe, its sRGB8 passes included (the sRGB8 encode is llvmpipe's own
+# RSQRTPS-based conversion, verified for every float in [0,1]: oracle/probes/srgb_encode_sweep.py), except:
+#  - xbr-lv2 (parity "partial": the shader reads an unassigned variable),
+#  - pass 3 of the crt-hyllian-glow case whose mip-mapped input is sampled at a fractional LOD (63x48 target):
+#    2 of 12 096 bytes differ by 1 (float residual of the two-level blend).
+BAR = {"xbr-lv2": (0.9998, 1)}
+CASE_PASS_BAR = {("crt_hyllian_glow_80x60_to_250x190", 3): (0.9998, 1)}
 
 
 def royale_luts():
@@ -149,8 +153,8 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
     outs = run_chain(passes, g["input_rgb"], vw, vh, frame_count=int(g["frames"]), luts=luts, flags=flags,
                      given=golden, custom=custom)
     assert len(outs) == int(g["n_passes"])
-    floor, maxdiff = BAR.get(key, (1.0, 0))
     for i, o in enumerate(outs):
+        floor, maxdiff = CASE_PASS_BAR.get((case, i), BAR.get(key, (1.0, 0)))
         ref = g["pass%d" % i]
         assert o.shape == ref.shape, (i, o.shape, ref.shape)
         if ref.dtype == np.uint8:
@@ -169,14 +173,8 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
     # ... and the whole chain end to end on the oracle's own intermediates
     if key.startswith("crt-royale"):
         own = run_chain(passes, g["input_rgb"], vw, vh, frame_count=int(g["frames"]), luts=luts, flags=flags)
-        d = np.abs(own[-1].astype(np.int32) - golden[-1].astype(np.int32))
-        exact = float((d == 0).mean())
-        # With the mask active, pass 8's brightpass ratio is discontinuous in its inputs, so a 1-LSB
-        # sRGB-encode difference upstream can flip isolated output pixels by a large amount; only the
-        # match rate is bounded there.  In the default mode the chain is smooth: max 2 LSB.
-        assert exact >= 0.97, "end to end: exact %.5f max %d" % (exact, d.max())
-        if not flags:
-            assert d.max() <= 2, "end to end: exact %.5f max %d" % (exact, d.max())
+        for i in range(len(golden)):
+            assert np.array_equal(own[i], golden[i]), "end to end, pass %d" % i
 
 
 # Float-precision goldens: the same shaders with every render target forced to RGBA32F on llvmpipe
