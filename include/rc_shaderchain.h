@@ -251,6 +251,13 @@ int rc_selftest_fastmath(int device, uint64_t mismatches[3]);
  * For tests: both must equal the oracle's byte for every float. */
 int rc_selftest_srgb8_host(const float* src, uint8_t* dst, size_t n);
 int rc_selftest_srgb8_device(int device, const float* d_src, uint8_t* d_dst, size_t n, void* stream);
+/* crt-royale's scanline pass (crt-royale-scanlines-vertical-interlacing.glsl) runs, at 1:1 geometry, from an
+ * expansion table of the beam function around its possible colours with a certified remainder bound
+ * (csrc/kernels/pass_royale_scan.hip).  This returns the host-built part of that table for sub-pixel offset
+ * `off` so that tests can check the bound against exact evaluations: A = [9][nodes][4] floats (0, dK/dc,
+ * d2K/dc2 / 2, dK/ddist), B = [9][nodes][2] words (bound as float bits, node colour as float bits), index
+ * 9 = scanline * 3 + channel.  Returns the node count (also with null pointers), negative on error. */
+int rc_selftest_royale_scan_tables(float off, float* A, uint32_t* B, size_t a_floats, size_t b_words);
 
 const char* rc_last_error(void);
 const char* rc_version(void);

@@ -73,6 +73,8 @@ uint8_t o_store_unorm8(float x);
 uint8_t o_store_srgb8(float x);
 /* bulk form for the exhaustive probe and the tests: dst[i] = o_store_srgb8(src[i]) */
 void o_store_srgb8_array(const float* src, uint8_t* dst, size_t n);
+/* crt-royale pass 1: one scanline's contribution to one channel, on arrays (rc_passes_royale.c) */
+void o_royale_beam_array(const float* dist, const float* color, float ph, float* out, size_t n);
 
 /* ---- varyings (rc_varying.c) --------------------------------------------------------- */
 /* A varying written by the vertex shader, as the rasteriser hands it to pixel (x, y) of a

@@ -137,6 +137,16 @@ static float beam_contrib(float dist, float color, float ph, float sigma_range, 
   return scale / 3.0f * (w1 + w2 + w3);
 }
 
+/* beam_contrib on arrays (calibration of the scanline kernel's table form and its tests): out[i] =
+ * beam_contrib(dist[i], color[i], ph) with the pass's static sigma / shape ranges */
+void o_royale_beam_array(const float* dist, const float* color, float ph, float* out, size_t n) {
+  ENTER;
+  const float sigma_range = maxps(beam_max_sigma, beam_min_sigma) - beam_min_sigma;
+  const float shape_range = maxps(beam_max_shape, beam_min_shape) - beam_min_shape;
+  for (size_t i = 0; i < n; ++i) out[i] = beam_contrib(dist[i], color[i], ph, sigma_range, shape_range);
+  LEAVE;
+}
+
 void o_pass_royale_scan_v(const o_pass_args* a) {
   ENTER;
   const int W = a->out_w, H = a->out_h;

@@ -8,52 +8,12 @@
 // uv scales) is computed once per launch on the host (royale_setup.cpp) with the same float
 // operations and handed over in PassLaunch::params / planes; the kernels do the per-pixel part.
 // One thread per target pixel, 64x4 workgroups, blockIdx.z = frame.
-#include "pass_launch.h"
-#include "rc_vecmath.h"
-#include "royale_params.h"
+#include "royale_common.h"
 
 using namespace rcd;
+using namespace rcroyale;
 
 namespace {
-
-__device__ __forceinline__ float minps(float a, float b) { return a < b ? a : b; }  // NaN -> b
-__device__ __forceinline__ float maxps(float a, float b) { return a > b ? a : b; }
-__device__ __forceinline__ float clampf(float x, float lo, float hi) { return minps(maxps(x, lo), hi); }
-__device__ __forceinline__ float fractf(float x) { return x - __builtin_floorf(x); }
-__device__ __forceinline__ float mod_glsl(float x, float y) { return x - y * __builtin_floorf(x / y); }
-__device__ __forceinline__ float mix_rt(float a, float b, float t) { return a + t * (b - a); }
-
-// Sampler / store policies: the shipped preset's texture formats and sampler states get
-// compile-time specialised kernels; any other configuration runs the run-time selected ones.
-template <int FMT, int LIN, int WRAP>
-struct S {
-  static __device__ __forceinline__ float4 get(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* l) {
-    return sample<FMT, LIN, WRAP>(t, img, s, v, l);
-  }
-  static bool matches(const Tex& t) { return t.fmt == FMT && (t.linear != 0) == (LIN != 0) && t.wrap == WRAP; }
-  // 8-bit texels: every sampled value is 0 or in [2^-40, 1], which is what div_safe_ needs
-  static constexpr bool kUnitRange = FMT != FMT_F32;
-};
-struct SRT {
-  static __device__ __forceinline__ float4 get(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* l) {
-    return sample_rt(t, img, s, v, l);
-  }
-  static bool matches(const Tex&) { return true; }
-  static constexpr bool kUnitRange = false;  // may be an RGBA32F texture with arbitrary values
-};
-template <int OUT>
-struct St {
-  static __device__ __forceinline__ void put(const PassLaunch& L, int z, int x, int y, float4 c, const SrgbLds* l) { store<OUT>(L, z, x, y, c, l); }
-  static bool matches(const PassLaunch& L) { return L.out_fmt == OUT; }
-};
-struct StRT {
-  static __device__ __forceinline__ void put(const PassLaunch& L, int z, int x, int y, float4 c, const SrgbLds* l) { store_rt(L, z, x, y, c, l); }
-  static bool matches(const PassLaunch&) { return true; }
-};
-using SrgbLinEdge = S<FMT_SRGB8, 1, WRAP_EDGE>;
-using SrgbNearEdge = S<FMT_SRGB8, 0, WRAP_EDGE>;
-
-constexpr float kUnderHalf = 0.4995f;
 
 // ------------------------------------------------------------------------------- P0 ------
 // first-pass-linearize-crt-gamma-bob-fields.glsl FS 4850-4884.  The source texel is a byte per
@@ -125,165 +85,6 @@ __global__ void __launch_bounds__(256) k_royale_first_bytemap(const PassLaunch L
   const uint32_t o = map[p & 255u] | (map[(p >> 8) & 255u] << 8) | (map[(p >> 16) & 255u] << 16) | 0xff000000u;
   *(reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z) + ((size_t)y * L.out_w + x)) = o;
   RC_TILE_LOOP_END
-}
-
-// ------------------------------------------------------------------------------- P1 ------
-// scanlines-vertical-interlacing.glsl FS 5982-6141; beam functions 4775-4998; gamma_impl 3907.
-// The nine (scanline, channel) beam evaluations of a pixel are independent and identical, 250
-// float operations each: they run as four packed pairs plus one scalar (rc_vecmath.h).
-template <class F, bool SAFE>
-__device__ __forceinline__ F div_sel_(F n, F d) { return SAFE ? div_safe_v<F>(n, d) : n / d; }
-
-template <class F, bool SAFE>
-__device__ __forceinline__ F gamma_impl1(F s, F s_inv) {
-  const float g = 1.12906830989f, c0 = 0.8109119309638332633713423362694399653724431f;
-  const float c1 = 0.4808354605142681877121661197951496120000040f, e = 2.71828182845904523536028747135266249775724709f;
-  const F sph = s + 0.5f;
-  const F lanczos_sum = c0 + div_sel_<F, SAFE>(F(c1), s + 1.0f);  // s + 1 in [1.25, 1.5]
-  // base is in [0.69, 0.78] for s = 1/beta in [1/4, 1/2]: a positive normal, no log2 edge cases
-  const F base = div_const_v<F>(sph + g, e, 1.0f / e);
-  return (exp2_v<F, true>(log2_core_v<F>(base) * sph) * lanczos_sum) * s_inv;  // finite argument
-}
-
-// One scanline's contribution to one channel: scanline_contrib(dist, color, ...) of the GLSL, with
-// the three sub-pixel samples at dist, dist + off, |dist - off|.
-template <class F, bool SAFE>
-__device__ __forceinline__ F beam_k(F color, F dist, float off, float sigma_range, float shape_range) {
-  // SAFE also means: color is a non-negative number, so no exp2 argument below can be a NaN (log2 of
-  // 0 is -inf, every product with it stays -inf) and exp2's two clamps fold into one v_med3_f32
-  const F lg = log2_v(color);  // pow(color, p) = exp2(log2(color) * p) for both exponents
-  const F sigma = 0.02f + sigma_range * exp2_v<F, SAFE>(lg * (1.0f / 3.0f));
-  const F alpha = 1.41421356237309504880f * sigma;  // sqrtf(2.0f)
-  const F beta = 2.0f + shape_range * exp2_v<F, SAFE>(lg * (1.0f / 4.0f));
-  // SAFE (colour sampled from an 8-bit texture): operand ranges for div_safe_: alpha in [0.028, 0.43],
-  // beta in [2, 4], gamma_impl1 in [0.88, 3.7]; color is 0 or >= 2^-40, so the numerator is 0 or >= 2^-41
-  const F alpha_inv = div_sel_<F, SAFE>(F(1.0f), alpha);
-  const F beta_inv = div_sel_<F, SAFE>(F(1.0f), beta);
-  const F scale = div_sel_<F, SAFE>(color * beta * 0.5f * alpha_inv, gamma_impl1<F, SAFE>(beta_inv, beta));
-  const F scale3 = div_const_v<F>(scale, 3.0f, 1.0f / 3.0f);
-  const F d2 = dist + off, d3 = abs_v(dist - off);
-  // pow(a, beta) with a >= 0 and beta in [2, 4]: for a zero or denormal `a` the full log2 returns
-  // -inf and the core returns a value <= -126; times beta both are below exp2's clamp and give
-  // exactly 0, so the edge-case selects of log2 are not needed here.
-  const F w1 = exp_v<F, SAFE>(-exp2_v<F, SAFE>(log2_core_v<F>(abs_v(dist * alpha_inv)) * beta));
-  const F w2 = exp_v<F, SAFE>(-exp2_v<F, SAFE>(log2_core_v<F>(abs_v(d2 * alpha_inv)) * beta));
-  const F w3 = exp_v<F, SAFE>(-exp2_v<F, SAFE>(log2_core_v<F>(abs_v(d3 * alpha_inv)) * beta));
-  return scale3 * (w1 + w2 + w3);
-}
-
-template <class SI, class SO>
-__global__ void __launch_bounds__(256, 4) k_royale_scan_v(const PassLaunch L) {
-  RC_SRGB_LDS(lds, L);
-  RC_TILE_LOOP_BEGIN
-  const float tsx = (float)L.in.w, tsy = L.params[RP1_TSY];   // TextureSize.y as the reference sets it (royale_setup.cpp)
-  const float y_step = L.params[RP1_Y_STEP], uv_step_y = L.params[RP1_UV_STEP_Y], ph = L.params[RP1_PH];
-  const float tix = 1.0f / tsx, tiy = 1.0f / tsy;
-  const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
-  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
-  // get_last_scanline_uv
-  const float frame_count = (float)(L.frame_count0 + z);
-  const float field_offset = __builtin_floorf(y_step * 0.75f) * mod_glsl(frame_count + 0.0f, 2.0f);
-  const float ctx = u * tsx, cty = v * tsy;
-  const float ptx = __builtin_floorf(ctx - kUnderHalf), pty = __builtin_floorf(cty - kUnderHalf);
-  const float wrong_field = mod_glsl(pty + field_offset, y_step);
-  const float stx = (ptx - 0.0f) + 0.5f, sty = (pty - wrong_field) + 0.5f;
-  const float su = stx * tix, sv = sty * tiy;
-  const float dist = (cty - sty) / y_step;
-  const uint8_t* img = frame_ptr(L.in, z);
-  const float4 s2 = SI::get(L.in, img, su, sv, &lds);
-  const float4 s3 = SI::get(L.in, img, su + 0.0f, sv + uv_step_y, &lds);
-  const float dist_round = __builtin_rintf(dist);
-  const float off_x = mix_rt(-0.0f, 2.0f * 0.0f, dist_round);
-  const float off_y = mix_rt(-uv_step_y, 2.0f * uv_step_y, dist_round);
-  const float4 so = SI::get(L.in, img, su + off_x, sv + off_y, &lds);
-  const float off = ph / 3.0f;
-  const float conv_y[3] = {0.2f, 0.4f, 0.6f};
-  // colour and distance of the nine evaluations, index = scanline * 3 + channel
-  float col[9] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z, so.x, so.y, so.z}, dd[9], kk[9];
-#pragma unroll
-  for (int ch = 0; ch < 3; ++ch) {
-    dd[ch] = dist - conv_y[ch];
-    // additive constants re-associated as the GL's compiler does: 1-(dist-c) -> (1+c)-dist, ...
-    dd[3 + ch] = __builtin_fabsf((1.0f + conv_y[ch]) - dist);
-    dd[6 + ch] = mix_rt(dist + (1.0f - conv_y[ch]), (2.0f + conv_y[ch]) - dist, dist_round);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const v2f k = beam_k<v2f, SI::kUnitRange>(v2f{col[2 * j], col[2 * j + 1]}, v2f{dd[2 * j], dd[2 * j + 1]}, off, sigma_range, shape_range);
-    kk[2 * j] = k.x;
-    kk[2 * j + 1] = k.y;
-  }
-  kk[8] = beam_k<float, SI::kUnitRange>(col[8], dd[8], off, sigma_range, shape_range);
-  float out[3];
-#pragma unroll
-  for (int ch = 0; ch < 3; ++ch) out[ch] = ((kk[ch] + kk[3 + ch]) + kk[6 + ch]) * 0.5f;
-  SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
-  RC_TILE_LOOP_END
-}
-
-// One pixel's inputs to the nine beam evaluations: colours and distances, index = scanline * 3 + channel.
-template <class SI>
-__device__ __forceinline__ void scan_v_gather(const PassLaunch& L, const SrgbLds& lds, int x, int y, int z, float* col, float* dd) {
-  const bool lo = rcd::lower_tri(x, y, L.out_w, L.out_h);
-  const float tsx = (float)L.in.w, tsy = L.params[RP1_TSY];
-  const float y_step = L.params[RP1_Y_STEP], uv_step_y = L.params[RP1_UV_STEP_Y];
-  const float tix = 1.0f / tsx, tiy = 1.0f / tsy;
-  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
-  const float frame_count = (float)(L.frame_count0 + z);
-  const float field_offset = __builtin_floorf(y_step * 0.75f) * mod_glsl(frame_count + 0.0f, 2.0f);
-  const float ctx = u * tsx, cty = v * tsy;
-  const float ptx = __builtin_floorf(ctx - kUnderHalf), pty = __builtin_floorf(cty - kUnderHalf);
-  const float wrong_field = mod_glsl(pty + field_offset, y_step);
-  const float stx = (ptx - 0.0f) + 0.5f, sty = (pty - wrong_field) + 0.5f;
-  const float su = stx * tix, sv = sty * tiy;
-  const float dist = (cty - sty) / y_step;
-  const uint8_t* img = frame_ptr(L.in, z);
-  const float4 s2 = SI::get(L.in, img, su, sv, &lds);
-  const float4 s3 = SI::get(L.in, img, su + 0.0f, sv + uv_step_y, &lds);
-  const float dist_round = __builtin_rintf(dist);
-  const float off_x = mix_rt(-0.0f, 2.0f * 0.0f, dist_round);
-  const float off_y = mix_rt(-uv_step_y, 2.0f * uv_step_y, dist_round);
-  const float4 so = SI::get(L.in, img, su + off_x, sv + off_y, &lds);
-  const float conv_y[3] = {0.2f, 0.4f, 0.6f};
-  col[0] = s2.x; col[1] = s2.y; col[2] = s2.z; col[3] = s3.x; col[4] = s3.y; col[5] = s3.z; col[6] = so.x; col[7] = so.y; col[8] = so.z;
-#pragma unroll
-  for (int ch = 0; ch < 3; ++ch) {
-    dd[ch] = dist - conv_y[ch];
-    dd[3 + ch] = __builtin_fabsf((1.0f + conv_y[ch]) - dist);
-    dd[6 + ch] = mix_rt(dist + (1.0f - conv_y[ch]), (2.0f + conv_y[ch]) - dist, dist_round);
-  }
-}
-
-// Two vertically adjacent pixels per thread: the nine evaluations of one pixel leave one scalar evaluation next to
-// four packed pairs; pairing evaluation j of the upper pixel with evaluation j of the lower one makes all nine packed
-// (rc_vecmath.h).  Tiles are 64 x 8; a wave still stores 256 contiguous bytes per row.  Same results as k_royale_scan_v.
-template <class SI, class SO>
-__global__ void __launch_bounds__(256, 4) k_royale_scan_v2(const PassLaunch L) {
-  RC_SRGB_LDS(lds, L);
-  const int tiles_x = (L.out_w + 63) >> 6, tiles_y = (L.out_h + 7) >> 3;
-  const int tiles_per_frame = tiles_x * tiles_y, n_tiles = tiles_per_frame * L.n_frames;
-  const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
-  const float off = L.params[RP1_PH] / 3.0f;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int z = tile / tiles_per_frame, rem = tile - z * tiles_per_frame;
-    const int ty = rem / tiles_x;
-    const int x = (rem - ty * tiles_x) * 64 + (int)threadIdx.x, y0 = ty * 8 + (int)threadIdx.y * 2;
-    if (x >= L.out_w || y0 >= L.out_h) continue;
-    const bool two = y0 + 1 < L.out_h;
-    float ca[9], da[9], cb[9], db[9];
-    scan_v_gather<SI>(L, lds, x, y0, z, ca, da);
-    scan_v_gather<SI>(L, lds, x, two ? y0 + 1 : y0, z, cb, db);
-    float ka[9], kb[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const v2f k = beam_k<v2f, SI::kUnitRange>(v2f{ca[j], cb[j]}, v2f{da[j], db[j]}, off, sigma_range, shape_range);
-      ka[j] = k.x;
-      kb[j] = k.y;
-    }
-    SO::put(L, z, x, y0, make_float4(((ka[0] + ka[3]) + ka[6]) * 0.5f, ((ka[1] + ka[4]) + ka[7]) * 0.5f, ((ka[2] + ka[5]) + ka[8]) * 0.5f, 1.0f), &lds);
-    if (two)
-      SO::put(L, z, x, y0 + 1, make_float4(((kb[0] + kb[3]) + kb[6]) * 0.5f, ((kb[1] + kb[4]) + kb[7]) * 0.5f, ((kb[2] + kb[5]) + kb[8]) * 0.5f, 1.0f), &lds);
-  }
 }
 
 // ------------------------------------------------------------------------------- P2 ------
@@ -654,16 +455,6 @@ RC_LAUNCH(launch_royale_mask_h, k_royale_mask_h)
   } while (0)
 using OutS = St<FMT_SRGB8>;
 
-hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s) {
-  if (SrgbLinEdge::matches(L.in) && OutS::matches(L)) {
-    if (L.flags & RC_FLAG_GENERAL_ONLY) GO((k_royale_scan_v<SrgbLinEdge, OutS>));
-    // two rows per thread: 64 x 8 tiles
-    const long tiles = (long)((L.out_w + 63) / 64) * ((L.out_h + 7) / 8) * L.n_frames;
-    hipLaunchKernelGGL((k_royale_scan_v2<SrgbLinEdge, OutS>), dim3((unsigned)(tiles < 2048 ? (tiles > 0 ? tiles : 1) : 2048)), px_block(), rcd::srgb_lds_bytes(L), s, L);
-    return hipGetLastError();
-  }
-  GO(k_royale_scan_v<SRT, StRT>);
-}
 hipError_t launch_royale_bloom_approx(const PassLaunch& L, hipStream_t s) {
   if (SrgbLinEdge::matches(L.extra[0]) && OutS::matches(L)) GO(k_royale_bloom_approx<SrgbLinEdge, OutS>);
   GO(k_royale_bloom_approx<SRT, StRT>);

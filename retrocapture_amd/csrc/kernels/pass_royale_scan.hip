@@ -1,0 +1,628 @@
+// crt-royale pass 1 (scanlines-vertical-interlacing.glsl): the general per-pixel kernels, and the table form
+// that runs the shipped 1:1 configuration.
+//
+// Per pixel the shader evaluates nine generalized-Gaussian beam profiles (3 scanlines x 3 channels), each
+// a function K(colour, distance) of ~280 float operations (5 log2, 9 exp2, 4 divisions of the GL's
+// polynomial / IEEE kind), sums three per channel, halves, and stores to an sRGB8 target.  At 1:1 geometry
+// (source lines = target lines, progressive) the structure is far simpler than the arithmetic:
+//   * the three scanlines of target row y are source rows y, y+1, y-1, sampled at texel centres up to float
+//     rounding: the bilinear weights are 0 or a few 2^-13 (or 1 minus that), `dist` is 0 or +-2^-14 at most;
+//   * so every colour that reaches K is a decoded sRGB8 byte plus a perturbation delta of at most 2.6e-4,
+//     and every distance is one of nine constants plus `dist`;
+//   * the pass output is a BYTE: encode(((K0 + K1) + K2) * 0.5).
+// k_royale_scan_v_tab therefore evaluates K from a table: the exact float value T of K at the node (computed by
+// the very beam_k code of the general kernel, on the device), corrected by a second-order expansion in delta and
+// a first-order one in dist whose coefficients come from the closed-form K in double precision, together with a
+// bound on everything the expansion leaves out (remainder of the expansion per node, sampled in double
+// precision with a safety factor; float rounding noise of the exact evaluation, measured and bounded by 5e-6 K).
+// If the sRGB8 byte is the same over the whole interval [S - B, S + B] the byte is certain and is stored;
+// otherwise (about 0.6 % of the pixels on uniform noise) the pixel goes to a per-tile list and is recomputed
+// with the general form by otherwise idle lanes.  The result is bit-identical to the general kernel whenever
+// the bound holds; tests/test_gpu_parity.py compares both forms on full-size noise and natural-like frames, and
+// tests/test_royale_scan_table.py checks the bound itself against the oracle's exact K on the CPU.
+// Colours below 2^-8 (where K is strongly non-linear in colour) use log-spaced nodes, 8 per octave, instead of
+// the byte nodes, so the relative perturbation stays below 4.6 %.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "royale_common.h"
+
+using namespace rcd;
+using namespace rcroyale;
+
+namespace {
+
+// ------------------------------------------------------------------------------- P1 ------
+// scanlines-vertical-interlacing.glsl FS 5982-6141; beam functions 4775-4998; gamma_impl 3907.
+// The nine (scanline, channel) beam evaluations of a pixel are independent and identical, 250
+// float operations each: they run as four packed pairs plus one scalar (rc_vecmath.h).
+template <class F, bool SAFE>
+__device__ __forceinline__ F div_sel_(F n, F d) { return SAFE ? div_safe_v<F>(n, d) : n / d; }
+
+template <class F, bool SAFE>
+__device__ __forceinline__ F gamma_impl1(F s, F s_inv) {
+  const float g = 1.12906830989f, c0 = 0.8109119309638332633713423362694399653724431f;
+  const float c1 = 0.4808354605142681877121661197951496120000040f, e = 2.71828182845904523536028747135266249775724709f;
+  const F sph = s + 0.5f;
+  const F lanczos_sum = c0 + div_sel_<F, SAFE>(F(c1), s + 1.0f);  // s + 1 in [1.25, 1.5]
+  // base is in [0.69, 0.78] for s = 1/beta in [1/4, 1/2]: a positive normal, no log2 edge cases
+  const F base = div_const_v<F>(sph + g, e, 1.0f / e);
+  return (exp2_v<F, true>(log2_core_v<F>(base) * sph) * lanczos_sum) * s_inv;  // finite argument
+}
+
+// One scanline's contribution to one channel: scanline_contrib(dist, color, ...) of the GLSL, with
+// the three sub-pixel samples at dist, dist + off, |dist - off|.
+template <class F, bool SAFE>
+__device__ __forceinline__ F beam_k(F color, F dist, float off, float sigma_range, float shape_range) {
+  // SAFE also means: color is a non-negative number, so no exp2 argument below can be a NaN (log2 of
+  // 0 is -inf, every product with it stays -inf) and exp2's two clamps fold into one v_med3_f32
+  const F lg = log2_v(color);  // pow(color, p) = exp2(log2(color) * p) for both exponents
+  const F sigma = 0.02f + sigma_range * exp2_v<F, SAFE>(lg * (1.0f / 3.0f));
+  const F alpha = 1.41421356237309504880f * sigma;  // sqrtf(2.0f)
+  const F beta = 2.0f + shape_range * exp2_v<F, SAFE>(lg * (1.0f / 4.0f));
+  // SAFE (colour sampled from an 8-bit texture): operand ranges for div_safe_: alpha in [0.028, 0.43],
+  // beta in [2, 4], gamma_impl1 in [0.88, 3.7]; color is 0 or >= 2^-40, so the numerator is 0 or >= 2^-41
+  const F alpha_inv = div_sel_<F, SAFE>(F(1.0f), alpha);
+  const F beta_inv = div_sel_<F, SAFE>(F(1.0f), beta);
+  const F scale = div_sel_<F, SAFE>(color * beta * 0.5f * alpha_inv, gamma_impl1<F, SAFE>(beta_inv, beta));
+  const F scale3 = div_const_v<F>(scale, 3.0f, 1.0f / 3.0f);
+  const F d2 = dist + off, d3 = abs_v(dist - off);
+  // pow(a, beta) with a >= 0 and beta in [2, 4]: for a zero or denormal `a` the full log2 returns
+  // -inf and the core returns a value <= -126; times beta both are below exp2's clamp and give
+  // exactly 0, so the edge-case selects of log2 are not needed here.
+  const F w1 = exp_v<F, SAFE>(-exp2_v<F, SAFE>(log2_core_v<F>(abs_v(dist * alpha_inv)) * beta));
+  const F w2 = exp_v<F, SAFE>(-exp2_v<F, SAFE>(log2_core_v<F>(abs_v(d2 * alpha_inv)) * beta));
+  const F w3 = exp_v<F, SAFE>(-exp2_v<F, SAFE>(log2_core_v<F>(abs_v(d3 * alpha_inv)) * beta));
+  return scale3 * (w1 + w2 + w3);
+}
+
+template <class SI, class SO>
+__global__ void __launch_bounds__(256, 4) k_royale_scan_v(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  const float tsx = (float)L.in.w, tsy = L.params[RP1_TSY];   // TextureSize.y as the reference sets it (royale_setup.cpp)
+  const float y_step = L.params[RP1_Y_STEP], uv_step_y = L.params[RP1_UV_STEP_Y], ph = L.params[RP1_PH];
+  const float tix = 1.0f / tsx, tiy = 1.0f / tsy;
+  const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  // get_last_scanline_uv
+  const float frame_count = (float)(L.frame_count0 + z);
+  const float field_offset = __builtin_floorf(y_step * 0.75f) * mod_glsl(frame_count + 0.0f, 2.0f);
+  const float ctx = u * tsx, cty = v * tsy;
+  const float ptx = __builtin_floorf(ctx - kUnderHalf), pty = __builtin_floorf(cty - kUnderHalf);
+  const float wrong_field = mod_glsl(pty + field_offset, y_step);
+  const float stx = (ptx - 0.0f) + 0.5f, sty = (pty - wrong_field) + 0.5f;
+  const float su = stx * tix, sv = sty * tiy;
+  const float dist = (cty - sty) / y_step;
+  const uint8_t* img = frame_ptr(L.in, z);
+  const float4 s2 = SI::get(L.in, img, su, sv, &lds);
+  const float4 s3 = SI::get(L.in, img, su + 0.0f, sv + uv_step_y, &lds);
+  const float dist_round = __builtin_rintf(dist);
+  const float off_x = mix_rt(-0.0f, 2.0f * 0.0f, dist_round);
+  const float off_y = mix_rt(-uv_step_y, 2.0f * uv_step_y, dist_round);
+  const float4 so = SI::get(L.in, img, su + off_x, sv + off_y, &lds);
+  const float off = ph / 3.0f;
+  const float conv_y[3] = {0.2f, 0.4f, 0.6f};
+  // colour and distance of the nine evaluations, index = scanline * 3 + channel
+  float col[9] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z, so.x, so.y, so.z}, dd[9], kk[9];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    dd[ch] = dist - conv_y[ch];
+    // additive constants re-associated as the GL's compiler does: 1-(dist-c) -> (1+c)-dist, ...
+    dd[3 + ch] = __builtin_fabsf((1.0f + conv_y[ch]) - dist);
+    dd[6 + ch] = mix_rt(dist + (1.0f - conv_y[ch]), (2.0f + conv_y[ch]) - dist, dist_round);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const v2f k = beam_k<v2f, SI::kUnitRange>(v2f{col[2 * j], col[2 * j + 1]}, v2f{dd[2 * j], dd[2 * j + 1]}, off, sigma_range, shape_range);
+    kk[2 * j] = k.x;
+    kk[2 * j + 1] = k.y;
+  }
+  kk[8] = beam_k<float, SI::kUnitRange>(col[8], dd[8], off, sigma_range, shape_range);
+  float out[3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) out[ch] = ((kk[ch] + kk[3 + ch]) + kk[6 + ch]) * 0.5f;
+  SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
+// One pixel's inputs to the nine beam evaluations: colours and distances, index = scanline * 3 + channel.
+template <class SI>
+__device__ __forceinline__ void scan_v_gather(const PassLaunch& L, const SrgbLds& lds, int x, int y, int z, float* col, float* dd) {
+  const bool lo = rcd::lower_tri(x, y, L.out_w, L.out_h);
+  const float tsx = (float)L.in.w, tsy = L.params[RP1_TSY];
+  const float y_step = L.params[RP1_Y_STEP], uv_step_y = L.params[RP1_UV_STEP_Y];
+  const float tix = 1.0f / tsx, tiy = 1.0f / tsy;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float frame_count = (float)(L.frame_count0 + z);
+  const float field_offset = __builtin_floorf(y_step * 0.75f) * mod_glsl(frame_count + 0.0f, 2.0f);
+  const float ctx = u * tsx, cty = v * tsy;
+  const float ptx = __builtin_floorf(ctx - kUnderHalf), pty = __builtin_floorf(cty - kUnderHalf);
+  const float wrong_field = mod_glsl(pty + field_offset, y_step);
+  const float stx = (ptx - 0.0f) + 0.5f, sty = (pty - wrong_field) + 0.5f;
+  const float su = stx * tix, sv = sty * tiy;
+  const float dist = (cty - sty) / y_step;
+  const uint8_t* img = frame_ptr(L.in, z);
+  const float4 s2 = SI::get(L.in, img, su, sv, &lds);
+  const float4 s3 = SI::get(L.in, img, su + 0.0f, sv + uv_step_y, &lds);
+  const float dist_round = __builtin_rintf(dist);
+  const float off_x = mix_rt(-0.0f, 2.0f * 0.0f, dist_round);
+  const float off_y = mix_rt(-uv_step_y, 2.0f * uv_step_y, dist_round);
+  const float4 so = SI::get(L.in, img, su + off_x, sv + off_y, &lds);
+  const float conv_y[3] = {0.2f, 0.4f, 0.6f};
+  col[0] = s2.x; col[1] = s2.y; col[2] = s2.z; col[3] = s3.x; col[4] = s3.y; col[5] = s3.z; col[6] = so.x; col[7] = so.y; col[8] = so.z;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    dd[ch] = dist - conv_y[ch];
+    dd[3 + ch] = __builtin_fabsf((1.0f + conv_y[ch]) - dist);
+    dd[6 + ch] = mix_rt(dist + (1.0f - conv_y[ch]), (2.0f + conv_y[ch]) - dist, dist_round);
+  }
+}
+
+// Two vertically adjacent pixels per thread: the nine evaluations of one pixel leave one scalar evaluation next to
+// four packed pairs; pairing evaluation j of the upper pixel with evaluation j of the lower one makes all nine packed
+// (rc_vecmath.h).  Tiles are 64 x 8; a wave still stores 256 contiguous bytes per row.  Same results as k_royale_scan_v.
+template <class SI, class SO>
+__global__ void __launch_bounds__(256, 4) k_royale_scan_v2(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const int tiles_x = (L.out_w + 63) >> 6, tiles_y = (L.out_h + 7) >> 3;
+  const int tiles_per_frame = tiles_x * tiles_y, n_tiles = tiles_per_frame * L.n_frames;
+  const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
+  const float off = L.params[RP1_PH] / 3.0f;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int z = tile / tiles_per_frame, rem = tile - z * tiles_per_frame;
+    const int ty = rem / tiles_x;
+    const int x = (rem - ty * tiles_x) * 64 + (int)threadIdx.x, y0 = ty * 8 + (int)threadIdx.y * 2;
+    if (x >= L.out_w || y0 >= L.out_h) continue;
+    const bool two = y0 + 1 < L.out_h;
+    float ca[9], da[9], cb[9], db[9];
+    scan_v_gather<SI>(L, lds, x, y0, z, ca, da);
+    scan_v_gather<SI>(L, lds, x, two ? y0 + 1 : y0, z, cb, db);
+    float ka[9], kb[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const v2f k = beam_k<v2f, SI::kUnitRange>(v2f{ca[j], cb[j]}, v2f{da[j], db[j]}, off, sigma_range, shape_range);
+      ka[j] = k.x;
+      kb[j] = k.y;
+    }
+    SO::put(L, z, x, y0, make_float4(((ka[0] + ka[3]) + ka[6]) * 0.5f, ((ka[1] + ka[4]) + ka[7]) * 0.5f, ((ka[2] + ka[5]) + ka[8]) * 0.5f, 1.0f), &lds);
+    if (two)
+      SO::put(L, z, x, y0 + 1, make_float4(((kb[0] + kb[3]) + kb[6]) * 0.5f, ((kb[1] + kb[4]) + kb[7]) * 0.5f, ((kb[2] + kb[5]) + kb[8]) * 0.5f, 1.0f), &lds);
+  }
+}
+
+// ------------------------------------------------------------------------ table form ------
+constexpr int kLogNodes = 192;               // colours in [2^-32, 2^-8): 8 nodes per octave (top 3 mantissa bits), node = bucket midpoint
+constexpr int kNodes = kLogNodes + 256;      // then one node per sRGB8 byte; node kLogNodes + 0 is the zero colour
+constexpr uint32_t kLogBits0 = 0x2f800000u;  // 2^-32
+constexpr float kLogMax = 0.00390625f;       // 2^-8
+constexpr float kMaxDelta = 2.6e-4f;         // byte nodes: largest |colour - node| the bounds are computed for
+constexpr float kMaxWeight = 1.25e-4f;       // largest off-centre bilinear weight per axis (2 * kMaxWeight * 1.0 < kMaxDelta)
+constexpr float kMaxDist = 6.103515625e-05f; // 2^-14: largest |dist| the bounds are computed for
+constexpr int kStripRows = 8;                // target rows one thread walks
+constexpr int kWinRows = kStripRows + 4;     // source rows it needs: two above, two below
+constexpr int kTabWaves = 16;                // 1024 threads: one workgroup per CU (the tables fill its LDS)
+constexpr int kTabThreads = kTabWaves * 64;
+constexpr int kFallbackPixels = kTabThreads / 9;  // pixels re-evaluated per fallback round (9 evaluations each)
+
+// dynamic LDS layout, in dwords (after the 256-entry decode table and the sRGB8 encode table of RC_SRGB_LDS)
+constexpr int kLdsA = (256 + (int)kSrgbRuns + 3) & ~3;        // float4 A[9][kNodes]: T, dK/dc, d2K/dc2 / 2, dK/ddist
+constexpr int kLdsB = kLdsA + 9 * kNodes * 4;                 // uint2 B[9][kNodes]: bound of the expansion at this node, node colour
+constexpr int kLdsFail = kLdsB + 9 * kNodes * 2;              // uint16 fails[kTabThreads * kStripRows]
+constexpr int kLdsK = kLdsFail + kTabThreads * kStripRows / 2;
+constexpr int kLdsCnt = kLdsK + kTabThreads;
+constexpr int kLdsTotal = kLdsCnt + 4;
+
+struct ScanRow {  // per target row, the same for every pixel of the row except `dist` (one value per triangle)
+  float dist_lo, dist_up;
+  float wy[3];     // bilinear weight between the two source rows of scanline s2 / s3 / so
+  uint32_t up;     // bit j: that pair starts one row above the scanline's own row (weight 1 - tiny)
+  uint32_t pad[2];
+};
+
+__device__ __forceinline__ float scan_dd(int j, int ch, float dist, float dist_round) {
+  const float conv_y[3] = {0.2f, 0.4f, 0.6f};
+  if (j == 0) return dist - conv_y[ch];
+  if (j == 1) return __builtin_fabsf((1.0f + conv_y[ch]) - dist);
+  return mix_rt(dist + (1.0f - conv_y[ch]), (2.0f + conv_y[ch]) - dist, dist_round);
+}
+
+// T of every node: the general kernel's own beam_k at the node colour and the role's distance for dist = 0
+__global__ void __launch_bounds__(256) k_scan_tab_nodes(float4* A, const uint2* B, float off) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 9 * kNodes) return;
+  const int jc = i / kNodes;
+  const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
+  const float c = bits2f(B[i].y);
+  A[i].x = beam_k<float, true>(c, scan_dd(jc / 3, jc % 3, 0.0f, 0.0f), off, sigma_range, shape_range);
+}
+
+// Where the samples of every target row / column land, evaluated with the operations of scan_v_gather and of the
+// LINEAR clamp-to-edge sampler; *bad is set if the geometry is not the regular 1:1 one the table form assumes.
+__global__ void __launch_bounds__(256) k_scan_geometry(const PassLaunch L, ScanRow* rows, float* cols, uint32_t* bad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float tsx = (float)L.in.w, tsy = L.params[RP1_TSY], uv_step_y = L.params[RP1_UV_STEP_Y];
+  const float tix = 1.0f / tsx, tiy = 1.0f / tsy;
+  bool ok = true;
+  if (i < L.out_h) {
+    ScanRow r = {};
+    if (i >= 2 && i < L.out_h - 2) {
+      float sv = 0.f;
+      for (int side = 0; side < 2; ++side) {
+        const float v = vary(L.plane[1], 0, i, side == 0);
+        const float cty = v * tsy, pty = __builtin_floorf(cty - kUnderHalf);
+        const float sty = (pty - 0.0f) + 0.5f;   // progressive: wrong_field = 0
+        const float dist = (cty - sty) / 1.0f;
+        ok = ok && pty == (float)i && __builtin_rintf(dist) == 0.0f && __builtin_fabsf(dist) <= kMaxDist;
+        (side == 0 ? r.dist_lo : r.dist_up) = dist;
+        sv = sty * tiy;
+      }
+      const float svr[3] = {sv, sv + uv_step_y, sv + mix_rt(-uv_step_y, 2.0f * uv_step_y, 0.0f)};
+      const int roff[3] = {0, 1, -1};
+      for (int j = 0; j < 3; ++j) {
+        const float w = linear_coord<WRAP_EDGE>(svr[j], L.in.h);
+        const float y0 = __builtin_floorf(w);
+        r.wy[j] = w - y0;
+        const float want = (float)(i + roff[j]);
+        // the pair's weight towards the scanline's own row is 1 up to kMaxWeight, so that |colour - node| <= kMaxDelta
+        if (y0 == want - 1.0f) {
+          r.up |= 1u << j;
+          ok = ok && 1.0f - r.wy[j] <= kMaxWeight;
+        } else {
+          ok = ok && y0 == want && r.wy[j] <= kMaxWeight;
+        }
+      }
+    }
+    rows[i] = r;
+  }
+  if (i < L.out_w) {
+    float wx = 0.f;
+    for (int side = 0; side < 2; ++side) {
+      const float u = vary(L.plane[0], i, 0, side == 0);
+      const float ctx = u * tsx, ptx = __builtin_floorf(ctx - kUnderHalf);
+      const float su = ((ptx - 0.0f) + 0.5f) * tix;
+      const float w = linear_coord<WRAP_EDGE>(su, L.in.w);
+      const float x0 = __builtin_floorf(w);
+      wx = w - x0;
+      ok = ok && ptx == (float)i && x0 == (float)i && wx >= 0.0f && wx <= kMaxWeight;
+    }
+    cols[i] = wx;
+  }
+  if (!ok) atomicOr(bad, 1u);
+}
+
+// Is the sRGB8 byte the same for every value in [s - b, s + b]?  Returns the byte; *ok tells whether it is certain.
+// Certain means: the interval lies inside the linear segment (monotone) and both ends round to the same byte, or
+// it lies inside ONE RSQRTPS run of the power segment - where the byte is monotone, one LDS entry - and both
+// ends are on the same side of the run's crossing.  Anything else (0.2 % of the values) is left to the exact path.
+__device__ __forceinline__ uint32_t srgb8_interval(float s, float b, const SrgbLds& t, bool* ok) {
+  const float lo = s - b, hi = s + b;
+  // power segment
+  const uint32_t bl = f2bits(__builtin_amdgcn_fmed3f(lo, 0.00313080009f, 0.99999994f)), bh = f2bits(hi);
+  const uint32_t e = t.enc[(bl >> 13) - kSrgbRun0];
+  const uint32_t cross = e & 0xffffu;
+  const bool pl = (bl & 0x1fffu) >= cross, ph = (bh & 0x1fffu) >= cross;
+  const bool ok_pow = lo > kSrgbLinMax && hi < 1.0f && ((bl ^ bh) >> 13) == 0u && pl == ph;
+  const uint32_t byte_pow = (e >> 16) + (pl ? 1u : 0u);
+  // linear segment
+  const float ll = __builtin_rintf((lo > 0.0f ? lo : 0.0f) * kSrgbLinScale), lh = __builtin_rintf(hi * kSrgbLinScale);
+  const bool lin = hi <= kSrgbLinMax;
+  *ok = lin ? (ll == lh && hi >= 0.0f) : ok_pow;
+  return lin ? (uint32_t)ll : byte_pow;
+}
+
+template <class SI, class SO>
+__global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLaunch L, const float4* __restrict__ gA, const uint2* __restrict__ gB,
+                                                                  const ScanRow* __restrict__ rows, const float* __restrict__ cols) {
+  RC_SRGB_LDS(lds, L);
+  float4* A = reinterpret_cast<float4*>(rc_dyn_lds_ + kLdsA);
+  uint2* B = reinterpret_cast<uint2*>(rc_dyn_lds_ + kLdsB);
+  uint16_t* fails = reinterpret_cast<uint16_t*>(rc_dyn_lds_ + kLdsFail);
+  float* kbuf = reinterpret_cast<float*>(rc_dyn_lds_ + kLdsK);
+  uint32_t* cnt = rc_dyn_lds_ + kLdsCnt;
+  const int tid = (int)threadIdx.x;
+  for (int i = tid; i < 9 * kNodes; i += kTabThreads) {
+    A[i] = gA[i];
+    B[i] = gB[i];
+  }
+  if (tid == 0) *cnt = 0u;
+  __syncthreads();
+  const int W = L.out_w, H = L.out_h;
+  const int cgs = (W + 63) >> 6, rss = (H + kStripRows - 1) / kStripRows;
+  const int strips_per_frame = cgs * rss, n_strips = strips_per_frame * L.n_frames;
+  const int n_tiles = (n_strips + kTabWaves - 1) / kTabWaves;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
+  const float off = L.params[RP1_PH] / 3.0f;
+  for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+    const int strip = tile * kTabWaves + wave;
+    if (strip < n_strips) {
+      const int z = strip / strips_per_frame, rem = strip - z * strips_per_frame;
+      const int rs = rem / cgs, x = (rem - rs * cgs) * 64 + lane, ys = rs * kStripRows;
+      if (x < W) {
+        const uint32_t* img = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
+        const float wx = cols[x];
+        const int xr = x + 1 < W ? x + 1 : W - 1;
+        uint32_t t[kWinRows];
+        float crow[kWinRows][3];
+#pragma unroll
+        for (int i = 0; i < kWinRows; ++i) {
+          const int r = clampi(ys - 2 + i, 0, H - 1);
+          t[i] = img[r * W + x];
+          const uint32_t tr = img[r * W + xr];
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const float d = lds.dec[(t[i] >> (8 * ch)) & 255u], dr = lds.dec[(tr >> (8 * ch)) & 255u];
+            crow[i][ch] = fma_(wx, dr - d, d);   // the sampler's horizontal lerp, exactly
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kStripRows; ++k) {
+          const int y = ys + k;
+          if (y >= H) break;
+          const ScanRow ri = rows[y];
+          const bool lo = rcd::lower_tri(x, y, W, H);
+          const float dist = lo ? ri.dist_lo : ri.dist_up;
+          bool fail = y < 2 || y >= H - 2;
+          uint32_t px = 0xff000000u;
+          if (!fail) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+              float kj[3], bj[3];
+#pragma unroll
+              for (int j = 0; j < 3; ++j) {
+                const int wi = k + 2 + (j == 0 ? 0 : (j == 1 ? 1 : -1));
+                const bool up = (ri.up >> j) & 1u;
+                const float lowc = up ? crow[wi - 1][ch] : crow[wi][ch], highc = up ? crow[wi][ch] : crow[wi + 1][ch];
+                const float c = fma_(ri.wy[j], highc - lowc, lowc);   // ... and its vertical lerp: the sampled colour
+                const uint32_t cb = f2bits(c);
+                const uint32_t byte = (t[wi] >> (8 * ch)) & 255u;
+                uint32_t idx = (uint32_t)kLogNodes + byte;
+                if (c < kLogMax) idx = cb >= kLogBits0 ? (cb - kLogBits0) >> 20 : (uint32_t)kLogNodes;
+                const uint32_t e = (uint32_t)((j * 3 + ch) * kNodes) + idx;
+                const float4 a = A[e];
+                const uint2 bb = B[e];
+                const float delta = c - bits2f(bb.y);   // at most kMaxDelta (byte nodes: k_scan_geometry bounds the weights) or half a bucket
+                kj[j] = fma_(delta, fma_(delta, a.z, a.y), fma_(a.w, dist, a.x));
+                bj[j] = bits2f(bb.x);
+              }
+              const float s = ((kj[0] + kj[1]) + kj[2]) * 0.5f;
+              const float b = fma_(5e-7f, s, 0.5f * ((bj[0] + bj[1]) + bj[2]));
+              bool ok;
+              const uint32_t byte = srgb8_interval(s, b, lds, &ok);
+              fail = fail || !ok;
+              px |= byte << (8 * ch);
+            }
+          }
+          if (!fail) {
+            *(reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z) + ((size_t)y * W + x)) = px;
+          } else {
+            const uint32_t slot = atomicAdd(cnt, 1u);
+            fails[slot] = (uint16_t)((wave << 9) | (k << 6) | lane);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // pixels whose byte was not certain: the general form, nine evaluations per pixel spread over the lanes
+    const int n_fail = (int)*cnt;
+    for (int base = 0; base < n_fail; base += kFallbackPixels) {
+      const int p = base + tid / 9, e = tid % 9;
+      if (tid < kFallbackPixels * 9 && p < n_fail) {
+        const uint32_t id = fails[p];
+        const int strip2 = tile * kTabWaves + (int)(id >> 9);
+        const int z = strip2 / strips_per_frame, rem = strip2 - z * strips_per_frame;
+        const int rs = rem / cgs, x = (rem - rs * cgs) * 64 + (int)(id & 63u), y = rs * kStripRows + (int)((id >> 6) & 7u);
+        float col[9], dd[9];
+        scan_v_gather<SI>(L, lds, x, y, z, col, dd);
+        float c = col[0], d = dd[0];
+#pragma unroll
+        for (int q = 1; q < 9; ++q)
+          if (e == q) {
+            c = col[q];
+            d = dd[q];
+          }
+        kbuf[tid] = beam_k<float, SI::kUnitRange>(c, d, off, sigma_range, shape_range);
+      }
+      __syncthreads();
+      if (tid < kFallbackPixels && base + tid < n_fail) {
+        const uint32_t id = fails[base + tid];
+        const int strip2 = tile * kTabWaves + (int)(id >> 9);
+        const int z = strip2 / strips_per_frame, rem = strip2 - z * strips_per_frame;
+        const int rs = rem / cgs, x = (rem - rs * cgs) * 64 + (int)(id & 63u), y = rs * kStripRows + (int)((id >> 6) & 7u);
+        const float* kk = kbuf + tid * 9;
+        SO::put(L, z, x, y, make_float4(((kk[0] + kk[3]) + kk[6]) * 0.5f, ((kk[1] + kk[4]) + kk[7]) * 0.5f, ((kk[2] + kk[5]) + kk[8]) * 0.5f, 1.0f), &lds);
+      }
+      __syncthreads();
+    }
+    if (tid == 0) *cnt = 0u;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------- host side of the table form ------
+// K(colour, distance) in closed form and double precision (the GLSL's formulas, libm instead of the GL's
+// polynomials): used for the expansion coefficients and the remainder bounds only, never for a stored value.
+struct BeamModel {
+  double off;
+  double K(double c, double dd) const {
+    if (!(c > 0.0)) return 0.0;
+    const double sigma = 0.02 + 0.28 * std::cbrt(c), alpha = std::sqrt(2.0) * sigma, beta = 2.0 + 2.0 * std::pow(c, 0.25);
+    const double s = 1.0 / beta, g = 1.12906830989, c0 = 0.8109119309638332633713423362694399653724431,
+                 c1 = 0.4808354605142681877121661197951496120000040;
+    const double gam = std::pow((s + 0.5 + g) / 2.71828182845904523536, s + 0.5) * (c0 + c1 / (s + 1.0)) * beta;
+    const double scale = c * beta * 0.5 / alpha / gam;
+    const double d1 = std::fabs(dd), d2 = std::fabs(dd + off), d3 = std::fabs(std::fabs(dd - off));
+    const double w = std::exp(-std::pow(d1 / alpha, beta)) + std::exp(-std::pow(d2 / alpha, beta)) + std::exp(-std::pow(d3 / alpha, beta));
+    return scale / 3.0 * w;
+  }
+};
+double modelDd(int j, int ch, double dist) {
+  const double conv[3] = {(double)0.2f, (double)0.4f, (double)0.6f};
+  if (j == 0) return dist - conv[ch];
+  if (j == 1) return std::fabs((1.0 + conv[ch]) - dist);
+  return dist + (1.0 - conv[ch]);
+}
+float nodeColour(int n) {
+  return n < kLogNodes ? bits2f(kLogBits0 + ((uint32_t)n << 20) + (1u << 19)) : k_srgb_decode_host[n - kLogNodes];
+}
+
+void buildScanTablesHost(float off, std::vector<float>* A, std::vector<uint32_t>* B) {
+  A->assign((size_t)9 * kNodes * 4, 0.0f);
+  B->assign((size_t)9 * kNodes * 2, 0u);
+  const BeamModel M{(double)off};
+  const double dm = (double)kMaxDist;
+  for (int jc = 0; jc < 9; ++jc) {
+    const int j = jc / 3, ch = jc % 3;
+    const double D0 = modelDd(j, ch, 0.0);
+    for (int n = 0; n < kNodes; ++n) {
+      const size_t i = (size_t)jc * kNodes + n;
+      const float cf = nodeColour(n);
+      (*B)[i * 2 + 1] = f2bits(cf);
+      const double c0 = (double)cf;
+      if (!(c0 > 0.0)) {  // the zero colour: K = 0; also takes colours below 2^-32, where K < 1e-8
+        (*B)[i * 2] = f2bits(1.5e-8f);
+        continue;
+      }
+      double dmax;  // largest |colour - node| this node is used for
+      if (n < kLogNodes) dmax = std::ldexp(1.0, std::ilogb(c0)) / 16.0 * 1.0001;
+      else if (c0 + (double)kMaxDelta < (double)kLogMax) {  // byte node below the log range: never selected
+        (*B)[i * 2] = f2bits(1e30f);
+        continue;
+      } else dmax = (double)kMaxDelta;
+      const double h = 1e-4 * c0;
+      const double k0 = M.K(c0, D0), kp = M.K(c0 + h, D0), km = M.K(c0 - h, D0);
+      const double Tc = (kp - km) / (2.0 * h), Tcc2 = 0.5 * (kp - 2.0 * k0 + km) / (h * h);
+      const double Td = (M.K(c0, modelDd(j, ch, 1e-6)) - M.K(c0, modelDd(j, ch, -1e-6))) / 2e-6;
+      double rmax = 0.0;  // largest remainder of the expansion over this node's colour range and |dist| <= kMaxDist
+      const int G = 32;
+      const double dists[5] = {-dm, -0.5 * dm, 0.0, 0.5 * dm, dm};
+      for (int g = -G; g <= G; ++g) {
+        const double d = dmax * g / G, c = c0 + d > 0.0 ? c0 + d : 0.0, dc = c - c0;
+        const double quad = k0 + Tc * dc + Tcc2 * dc * dc;
+        for (double dist : dists) rmax = std::fmax(rmax, std::fabs(M.K(c, modelDd(j, ch, dist)) - (quad + Td * dist)));
+      }
+      // safety factor 2 on the sampled remainder; 5e-6 K + 2e-9: rounding noise of the exact float evaluation
+      // (measured: <= 1.6e-6 K, tests/test_royale_scan_table.py)
+      const double bound = 2.0 * rmax + 5e-6 * std::fabs(k0) + 2e-9;
+      (*A)[i * 4 + 1] = (float)Tc;
+      (*A)[i * 4 + 2] = (float)Tcc2;
+      (*A)[i * 4 + 3] = (float)Td;
+      (*B)[i * 2] = f2bits((float)(bound * 1.0000002));
+    }
+  }
+}
+
+struct ScanTables {
+  float4* A = nullptr;
+  uint2* B = nullptr;
+  ScanRow* rows = nullptr;
+  float* cols = nullptr;
+  bool usable = false;
+};
+struct ScanKey {
+  int device, in_w, in_h, out_w, out_h;
+  float planes[12], params[4];
+  bool operator<(const ScanKey& o) const { return std::memcmp(this, &o, sizeof(ScanKey)) < 0; }
+};
+
+// Tables for this launch's geometry on the current device, built on first use (two small kernels on `s` and one
+// synchronisation to learn whether the geometry is the regular one); nullptr when the table form does not apply.
+const ScanTables* scanTablesFor(const PassLaunch& L, hipStream_t s) {
+  if (L.in.w != L.out_w || L.in.h != L.out_h || L.out_h < 8 || L.params[RP1_Y_STEP] != 1.0f || L.params[RP1_TSY] != (float)L.in.h) return nullptr;
+  const Plane &pu = L.plane[0], &pv = L.plane[1];
+  if (pu.dy_lo != 0.0f || pu.dy_up != 0.0f || pv.dx_lo != 0.0f || pv.dx_up != 0.0f) return nullptr;
+  ScanKey key;
+  std::memset(&key, 0, sizeof(key));
+  if (hipGetDevice(&key.device) != hipSuccess) return nullptr;
+  key.in_w = L.in.w; key.in_h = L.in.h; key.out_w = L.out_w; key.out_h = L.out_h;
+  std::memcpy(key.planes, &L.plane[0], sizeof(float) * 12);
+  for (int i = 0; i < 4; ++i) key.params[i] = L.params[i];
+  static std::mutex mu;
+  static std::map<ScanKey, ScanTables> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second.usable ? &it->second : nullptr;
+  if (cache.size() > 64) return nullptr;  // geometries keep changing (e.g. a window being resized): stay with the general form
+  ScanTables T;
+  std::vector<float> hA;
+  std::vector<uint32_t> hB;
+  buildScanTablesHost(L.params[RP1_PH] / 3.0f, &hA, &hB);
+  uint32_t* bad = nullptr;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&T.A), hA.size() * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&T.B), hB.size() * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&T.rows), sizeof(ScanRow) * (size_t)L.out_h) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&T.cols), sizeof(float) * (size_t)L.out_w) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&bad), 4) == hipSuccess;
+  uint32_t hbad = 1;
+  if (ok) {
+    ok = hipMemcpyAsync(T.A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(T.B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemsetAsync(bad, 0, 4, s) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(k_scan_tab_nodes, dim3((9 * kNodes + 255) / 256), dim3(256), 0, s, T.A, T.B, L.params[RP1_PH] / 3.0f);
+      const int n = L.out_w > L.out_h ? L.out_w : L.out_h;
+      hipLaunchKernelGGL(k_scan_geometry, dim3((n + 255) / 256), dim3(256), 0, s, L, T.rows, T.cols, bad);
+      // hA / hB must outlive the asynchronous copies: the synchronising copy below orders that
+      ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+           hipStreamSynchronize(s) == hipSuccess;
+    }
+  }
+  if (bad) (void)hipFree(bad);
+  T.usable = ok && hbad == 0;
+  if (!T.usable) {
+    if (T.A) (void)hipFree(T.A);
+    if (T.B) (void)hipFree(T.B);
+    if (T.rows) (void)hipFree(T.rows);
+    if (T.cols) (void)hipFree(T.cols);
+    T = ScanTables();
+  }
+  auto ins = cache.emplace(key, T);
+  return ins.first->second.usable ? &ins.first->second : nullptr;
+}
+
+}  // namespace
+
+namespace rck {
+// for tests/test_royale_scan_table.py: the host-built part of the tables (A: 0, dK/dc, d2K/dc2 / 2, dK/ddist; B: bound, node colour)
+void royale_scan_tables_host(float off, float* A, uint32_t* B) {
+  std::vector<float> a;
+  std::vector<uint32_t> b;
+  buildScanTablesHost(off, &a, &b);
+  std::memcpy(A, a.data(), a.size() * sizeof(float));
+  std::memcpy(B, b.data(), b.size() * sizeof(uint32_t));
+}
+int royale_scan_table_nodes() { return kNodes; }
+
+#define GO(...)                                                                              \
+  do {                                                                                       \
+    hipLaunchKernelGGL((__VA_ARGS__), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L); \
+    return hipGetLastError();                                                                \
+  } while (0)
+using OutS = St<FMT_SRGB8>;
+
+hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s) {
+  if (SrgbLinEdge::matches(L.in) && OutS::matches(L)) {
+    if (L.flags & RC_FLAG_GENERAL_ONLY) GO((k_royale_scan_v<SrgbLinEdge, OutS>));
+    if (const ScanTables* T = scanTablesFor(L, s)) {
+      auto kernel = k_royale_scan_v_tab<SrgbLinEdge, OutS>;
+      static bool attr = false;
+      if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal * 4) != hipSuccess)
+          return hipGetLastError();
+        attr = true;
+      }
+      const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kStripRows - 1) / kStripRows) * L.n_frames;
+      const long tiles = (strips + kTabWaves - 1) / kTabWaves;
+      hipLaunchKernelGGL(kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(kTabThreads), kLdsTotal * 4, s, L, T->A, T->B, T->rows, T->cols);
+      return hipGetLastError();
+    }
+    // two rows per thread: 64 x 8 tiles
+    const long tiles = (long)((L.out_w + 63) / 64) * ((L.out_h + 7) / 8) * L.n_frames;
+    hipLaunchKernelGGL((k_royale_scan_v2<SrgbLinEdge, OutS>), dim3((unsigned)(tiles < 2048 ? (tiles > 0 ? tiles : 1) : 2048)), px_block(), rcd::srgb_lds_bytes(L), s, L);
+    return hipGetLastError();
+  }
+  GO(k_royale_scan_v<SRT, StRT>);
+}
+}  // namespace rck

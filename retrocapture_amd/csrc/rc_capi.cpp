@@ -378,6 +378,15 @@ int rc_selftest_srgb8_device(int device, const float* d_src, uint8_t* d_dst, siz
   if (!table) return RC_ERR_DEVICE;
   return rck::launch_selftest_srgb8(d_src, d_dst, n, table, static_cast<hipStream_t>(stream)) == hipSuccess ? RC_OK : RC_ERR_DEVICE;
 }
+int rc_selftest_royale_scan_tables(float off, float* A, uint32_t* B, size_t a_floats, size_t b_words) {
+  const size_t n = (size_t)rck::royale_scan_table_nodes();
+  if (!A || !B) return (int)n;
+  if (a_floats < 9 * n * 4 || b_words < 9 * n * 2) return RC_ERR_INVALID;
+  return guarded([&] {
+    rck::royale_scan_tables_host(off, A, B);
+    return (int)n;
+  });
+}
 int rc_engine_history_count(rc_engine* e) { return e ? (int)e->impl.historyCount() : 0; }
 int rc_engine_read_history(rc_engine* e, int k, uint32_t* width, uint32_t* height, void* host, size_t bytes) {
   if (!e || k < 0) return RC_ERR_INVALID;

@@ -96,6 +96,7 @@ SYMBOLS = [
     ("rc_pipeline_set_image_adjust", None, [C.c_void_p, C.c_float, C.c_float]),
     ("rc_selftest_fastmath", C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     ("rc_selftest_srgb8_host", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("rc_selftest_royale_scan_tables", C.c_int, [C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     ("rc_selftest_srgb8_device", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("rc_last_error", C.c_char_p, []),
     ("rc_version", C.c_char_p, []),
@@ -297,6 +298,19 @@ def srgb8_encode_device(d_values, d_out, n, device=0, stream=0):
     rc = load_library().rc_selftest_srgb8_device(int(device), _ptr(d_values), _ptr(d_out), int(n), C.c_void_p(int(stream)))
     if rc != 0:
         raise RcError("rc_selftest_srgb8_device failed (%d)" % rc)
+
+
+def royale_scan_tables(off):
+    """Host-built expansion tables of crt-royale's scanline pass: (A [9, nodes, 4] float32, bound [9, nodes] float32,
+    node colour [9, nodes] float32)."""
+    import numpy as np
+    lib = load_library()
+    n = lib.rc_selftest_royale_scan_tables(C.c_float(off), None, None, 0, 0)
+    A = np.zeros((9, n, 4), np.float32)
+    B = np.zeros((9, n, 2), np.uint32)
+    if lib.rc_selftest_royale_scan_tables(C.c_float(off), A.ctypes.data, B.ctypes.data, A.size, B.size) != n:
+        raise RcError("rc_selftest_royale_scan_tables failed")
+    return A, B[..., 0].copy().view(np.float32), B[..., 1].copy().view(np.float32)
 
 
 def kernel_list():

@@ -1,0 +1,103 @@
+"""The headline configuration as users run it: crt/crt-royale.glslp, 1920x1080 source, 1920x1080 viewport
+(BASELINE config 4), in both behaviours of pass 6's unwritten varying (llvmpipe's: mask discarded; and the
+GPU drivers': mask rendered).  Every pass of the engine is compared, over the whole frame, with the oracle
+fed the engine's own output of the passes before it; the specialised kernel forms (pass 0's byte map, pass 1's
+expansion-table form with its exact fallback, ...) are compared with the general per-pixel forms; frames are
+uniform noise (every texel pair differs: the worst case for the table form), a smooth natural-like frame and
+the reference's test-pattern bars."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_chain import run_chain
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+W, H = 1920, 1080
+
+
+def royale_luts():
+    lut = np.load(os.path.join(GOLD, "lut_mask_slot_small_64.npy"))
+    return {"mask_slot_texture_small": (lut, True, "repeat")}
+
+
+def bars(w, h, f):
+    """The reference's synthetic source (VideoCaptureTestPattern.cpp:65-101): eight bars and a moving marker."""
+    cols = np.array([[255, 255, 255], [255, 255, 0], [0, 255, 255], [0, 255, 0], [255, 0, 255], [255, 0, 0], [0, 0, 255],
+                     [16, 16, 16]], np.uint8)
+    img = cols[np.minimum(np.arange(w) // (w // 8), 7)][None].repeat(h, 0).copy()
+    x0 = f % w
+    img[: h // 8, x0:x0 + 8] = 0
+    return img
+
+
+def smooth(w, h, seed):
+    rng = np.random.default_rng(seed)
+    low = rng.integers(0, 256, (h // 24 + 2, w // 24 + 2, 3)).astype(np.float32)
+    yy, xx = np.arange(h)[:, None] / 24.0, np.arange(w)[None, :] / 24.0
+    y0, x0 = yy.astype(int), xx.astype(int)
+    fy, fx = (yy - y0)[..., None], (xx - x0)[..., None]
+    img = (low[y0, x0] * (1 - fy) * (1 - fx) + low[y0, x0 + 1] * (1 - fy) * fx + low[y0 + 1, x0] * fy * (1 - fx)
+           + low[y0 + 1, x0 + 1] * fy * fx)
+    return np.clip(img + rng.normal(0, 1.5, img.shape), 0, 255).astype(np.uint8)
+
+
+def frames3():
+    noise = np.random.default_rng(4).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    return np.stack([noise, smooth(W, H, 9), bars(W, H, 1234)])
+
+
+@pytest.mark.parametrize("mask_rendered", [False, True])
+def test_crt_royale_1080p_every_pass_against_the_oracle(mask_rendered, preset_tree, rc_lib):
+    from gpu_util import make_engine, run_engine
+    from retrocapture_amd import engine as eng
+    oracle_lib.set_threads(min(16, os.cpu_count() or 1))
+    passes = eng.preset_dump(preset_tree["crt-royale"])["passes"]
+    frames = frames3()
+    e = make_engine(preset_tree["crt-royale"], W, H)
+    e.setUndefinedVaryingZero(mask_rendered)
+    final = run_engine(e, frames)
+    assert final.shape == (3, H, W, 4)
+    assert e.passInfo(1)["kernel"] == "royale-scanlines-v"
+    mine = [[e.readPass(i, k) for i in range(12)] for k in range(3)]
+    # the general per-pixel forms give the same bytes on every pass
+    e.setGeneralKernelsOnly(True)
+    final_g = run_engine(e, frames)
+    for k in range(3):
+        for i in range(12):
+            assert np.array_equal(e.readPass(i, k), mine[k][i]), "frame %d pass %d: specialised vs general form" % (k, i)
+    assert np.array_equal(final, final_g)
+    e.shutdown()
+    # every pass against the oracle, fed the engine's own previous passes (FrameCount of frame k = k + 1)
+    for k in range(3):
+        want = run_chain(passes, frames[k], W, H, frame_count=k + 1, luts=royale_luts(), flags=1 if mask_rendered else 0,
+                         given=mine[k])
+        for i in range(12):
+            assert want[i].shape == mine[k][i].shape
+            bad = int((want[i] != mine[k][i]).sum())
+            assert bad == 0, "frame %d pass %d: %d bytes differ from the oracle" % (k, i, bad)
+        assert np.array_equal(final[k], want[11])
+    if mask_rendered:
+        assert final[0][..., :3].std() > 10      # the mask path carries signal
+
+
+def test_scanline_table_form_fallback_share(preset_tree, rc_lib):
+    """Geometry that is not the regular 1:1 one (here 1080 -> 1000 lines) must take the general form: same bytes
+    as the oracle on a band."""
+    from gpu_util import make_engine, run_engine
+    from retrocapture_amd import engine as eng
+    from oracle_lib import Tex, run_pass_rows
+    passes = eng.preset_dump(preset_tree["crt-royale"])["passes"]
+    frame = np.random.default_rng(5).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    e = make_engine(preset_tree["crt-royale"], W, 1000)
+    run_engine(e, frame)
+    p0, p1 = e.readPass(0, 0), e.readPass(1, 0)
+    e.shutdown()
+    assert p1.shape == (1000, W, 4)
+    from oracle_chain import pass_sizes
+    sizes = pass_sizes(passes, W, H, W, 1000)
+    rows = run_pass_rows("royale_scan_v", Tex(p0, "srgb8", True, "clamp_to_edge"), W, 1000, 470, 534, out_fmt="srgb8",
+                         src_w=W, src_h=H, chain=sizes, pass_index=1, vp=(W, 1000))
+    assert np.array_equal(rows, p1[470:534])
