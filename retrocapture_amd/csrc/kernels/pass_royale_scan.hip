@@ -23,6 +23,8 @@
 // Colours below 2^-8 (where K is strongly non-linear in colour) use log-spaced nodes, 8 per octave, instead of
 // the byte nodes, so the relative perturbation stays below 4.6 %.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -203,23 +205,28 @@ constexpr float kMaxDelta = 2.6e-4f;         // byte nodes: largest |colour - no
 constexpr float kMaxWeight = 1.25e-4f;       // largest off-centre bilinear weight per axis (2 * kMaxWeight * 1.0 < kMaxDelta)
 constexpr float kMaxDist = 6.103515625e-05f; // 2^-14: largest |dist| the bounds are computed for
 constexpr int kStripRows = 8;                // target rows one thread walks
-constexpr int kWinRows = kStripRows + 4;     // source rows it needs: two above, two below
 constexpr int kTabWaves = 16;                // 1024 threads: one workgroup per CU (the tables fill its LDS)
 constexpr int kTabThreads = kTabWaves * 64;
-constexpr int kFallbackPixels = kTabThreads / 9;  // pixels re-evaluated per fallback round (9 evaluations each)
 
 // dynamic LDS layout, in dwords (after the 256-entry decode table and the sRGB8 encode table of RC_SRGB_LDS)
 constexpr int kLdsA = (256 + (int)kSrgbRuns + 3) & ~3;        // float4 A[9][kNodes]: T, dK/dc, d2K/dc2 / 2, dK/ddist
 constexpr int kLdsB = kLdsA + 9 * kNodes * 4;                 // uint2 B[9][kNodes]: bound of the expansion at this node, node colour
-constexpr int kLdsFail = kLdsB + 9 * kNodes * 2;              // uint16 fails[kTabThreads * kStripRows]
-constexpr int kLdsK = kLdsFail + kTabThreads * kStripRows / 2;
-constexpr int kLdsCnt = kLdsK + kTabThreads;
+constexpr int kLdsFail = kLdsB + 9 * kNodes * 2;              // uint16 fails[kTabThreads * kStripRows]: tile-local ids of uncertain pixels
+constexpr int kLdsCnt = kLdsFail + kTabThreads * kStripRows / 2;  // their count, and the base of the tile's range in the global list
 constexpr int kLdsTotal = kLdsCnt + 4;
+
+// Pixels whose byte the table form could not certify are collected per tile in LDS and appended (one global atomic
+// per tile) to a list in the pass's scratch buffer (PassLaunch::scratch: a counter, then entries
+// (frame * H + y) * W + x); k_royale_scan_v_fix renders them with the general form.
+constexpr uint32_t kFixHeader = 256;  // bytes reserved for the counter (the registry sizes the scratch: header + 4 bytes per pixel, per frame)
+__device__ __forceinline__ uint32_t* fix_counter(const PassLaunch& L) { return static_cast<uint32_t*>(L.scratch); }
+__device__ __forceinline__ uint32_t* fix_list(const PassLaunch& L) { return reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.scratch) + kFixHeader); }
 
 struct ScanRow {  // per target row, the same for every pixel of the row except `dist` (one value per triangle)
   float dist_lo, dist_up;
   float wy[3];     // bilinear weight between the two source rows of scanline s2 / s3 / so
-  uint32_t up;     // bit j: that pair starts one row above the scanline's own row (weight 1 - tiny)
+  uint32_t up;     // bit j: that pair starts one row above the scanline's own row (weight 1 - tiny);
+                   // bit 8 / 9: |dist_lo| / |dist_up| is beyond kMaxDist: those pixels take the exact path
   uint32_t pad[2];
 };
 
@@ -246,7 +253,7 @@ __global__ void __launch_bounds__(256) k_scan_geometry(const PassLaunch L, ScanR
   const int i = blockIdx.x * 256 + threadIdx.x;
   const float tsx = (float)L.in.w, tsy = L.params[RP1_TSY], uv_step_y = L.params[RP1_UV_STEP_Y];
   const float tix = 1.0f / tsx, tiy = 1.0f / tsy;
-  bool ok = true;
+  uint32_t why = 0u;  // reasons the geometry is not the regular one (bit set), for diagnostics
   if (i < L.out_h) {
     ScanRow r = {};
     if (i >= 2 && i < L.out_h - 2) {
@@ -256,7 +263,10 @@ __global__ void __launch_bounds__(256) k_scan_geometry(const PassLaunch L, ScanR
         const float cty = v * tsy, pty = __builtin_floorf(cty - kUnderHalf);
         const float sty = (pty - 0.0f) + 0.5f;   // progressive: wrong_field = 0
         const float dist = (cty - sty) / 1.0f;
-        ok = ok && pty == (float)i && __builtin_rintf(dist) == 0.0f && __builtin_fabsf(dist) <= kMaxDist;
+        if (!(pty == (float)i)) why |= 2u;
+        if (!(__builtin_rintf(dist) == 0.0f)) why |= 4u;
+        // a row whose dist exceeds the range of the bounds (2 of 1080 rows at 1080p, one triangle each) takes the exact path
+        if (!(__builtin_fabsf(dist) <= kMaxDist)) r.up |= 256u << side;
         (side == 0 ? r.dist_lo : r.dist_up) = dist;
         sv = sty * tiy;
       }
@@ -270,9 +280,10 @@ __global__ void __launch_bounds__(256) k_scan_geometry(const PassLaunch L, ScanR
         // the pair's weight towards the scanline's own row is 1 up to kMaxWeight, so that |colour - node| <= kMaxDelta
         if (y0 == want - 1.0f) {
           r.up |= 1u << j;
-          ok = ok && 1.0f - r.wy[j] <= kMaxWeight;
+          if (!(1.0f - r.wy[j] <= kMaxWeight)) why |= 8u;
         } else {
-          ok = ok && y0 == want && r.wy[j] <= kMaxWeight;
+          if (!(y0 == want)) why |= 16u;
+          if (!(r.wy[j] <= kMaxWeight)) why |= 32u;
         }
       }
     }
@@ -287,26 +298,33 @@ __global__ void __launch_bounds__(256) k_scan_geometry(const PassLaunch L, ScanR
       const float w = linear_coord<WRAP_EDGE>(su, L.in.w);
       const float x0 = __builtin_floorf(w);
       wx = w - x0;
-      ok = ok && ptx == (float)i && x0 == (float)i && wx >= 0.0f && wx <= kMaxWeight;
+      if (!(ptx == (float)i && x0 == (float)i)) why |= 64u;
+      if (!(wx >= 0.0f && wx <= kMaxWeight)) why |= 128u;
     }
     cols[i] = wx;
   }
-  if (!ok) atomicOr(bad, 1u);
+  if (why) atomicOr(bad, why);
 }
 
 // Is the sRGB8 byte the same for every value in [s - b, s + b]?  Returns the byte; *ok tells whether it is certain.
 // Certain means: the interval lies inside the linear segment (monotone) and both ends round to the same byte, or
-// it lies inside ONE RSQRTPS run of the power segment - where the byte is monotone, one LDS entry - and both
-// ends are on the same side of the run's crossing.  Anything else (0.2 % of the values) is left to the exact path.
+// inside ONE RSQRTPS run of the power segment - where the byte is monotone - with both ends on the same side of
+// the run's crossing, or inside two neighbouring runs with no crossing between the ends and the same byte either
+// side of the run boundary (flag bit 14 of the table entry; the encode is not monotone across run boundaries).
 __device__ __forceinline__ uint32_t srgb8_interval(float s, float b, const SrgbLds& t, bool* ok) {
   const float lo = s - b, hi = s + b;
   // power segment
   const uint32_t bl = f2bits(__builtin_amdgcn_fmed3f(lo, 0.00313080009f, 0.99999994f)), bh = f2bits(hi);
-  const uint32_t e = t.enc[(bl >> 13) - kSrgbRun0];
-  const uint32_t cross = e & 0xffffu;
-  const bool pl = (bl & 0x1fffu) >= cross, ph = (bh & 0x1fffu) >= cross;
-  const bool ok_pow = lo > kSrgbLinMax && hi < 1.0f && ((bl ^ bh) >> 13) == 0u && pl == ph;
-  const uint32_t byte_pow = (e >> 16) + (pl ? 1u : 0u);
+  const uint32_t ri = (bl >> 13) - kSrgbRun0;
+  const uint32_t el = t.enc[ri], eh = t.enc[ri + 1u];   // (the table has a spare entry after the last run)
+  const uint32_t cl = el & 0x3fffu, ch = eh & 0x3fffu;
+  const uint32_t ol = bl & 0x1fffu, oh = bh & 0x1fffu;
+  const bool pl = ol >= cl;
+  const uint32_t dr = (bh >> 13) - (bl >> 13);
+  const bool same = dr == 0u && pl == (oh >= cl);
+  const bool next = dr == 1u && (el & 0x4000u) && (pl || cl == 8192u) && oh < ch;
+  const bool ok_pow = lo > kSrgbLinMax && hi < 1.0f && (same || next);
+  const uint32_t byte_pow = (el >> 16) + (pl ? 1u : 0u);
   // linear segment
   const float ll = __builtin_rintf((lo > 0.0f ? lo : 0.0f) * kSrgbLinScale), lh = __builtin_rintf(hi * kSrgbLinScale);
   const bool lin = hi <= kSrgbLinMax;
@@ -320,23 +338,20 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
   RC_SRGB_LDS(lds, L);
   float4* A = reinterpret_cast<float4*>(rc_dyn_lds_ + kLdsA);
   uint2* B = reinterpret_cast<uint2*>(rc_dyn_lds_ + kLdsB);
-  uint16_t* fails = reinterpret_cast<uint16_t*>(rc_dyn_lds_ + kLdsFail);
-  float* kbuf = reinterpret_cast<float*>(rc_dyn_lds_ + kLdsK);
-  uint32_t* cnt = rc_dyn_lds_ + kLdsCnt;
   const int tid = (int)threadIdx.x;
   for (int i = tid; i < 9 * kNodes; i += kTabThreads) {
     A[i] = gA[i];
     B[i] = gB[i];
   }
-  if (tid == 0) *cnt = 0u;
+  uint16_t* fails = reinterpret_cast<uint16_t*>(rc_dyn_lds_ + kLdsFail);
+  uint32_t* cnt = rc_dyn_lds_ + kLdsCnt;
+  if (tid == 0) cnt[0] = 0u;
   __syncthreads();
   const int W = L.out_w, H = L.out_h;
   const int cgs = (W + 63) >> 6, rss = (H + kStripRows - 1) / kStripRows;
   const int strips_per_frame = cgs * rss, n_strips = strips_per_frame * L.n_frames;
   const int n_tiles = (n_strips + kTabWaves - 1) / kTabWaves;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
-  const float off = L.params[RP1_PH] / 3.0f;
   for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
     const int strip = tile * kTabWaves + wave;
     if (strip < n_strips) {
@@ -344,102 +359,125 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
       const int rs = rem / cgs, x = (rem - rs * cgs) * 64 + lane, ys = rs * kStripRows;
       if (x < W) {
         const uint32_t* img = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
+        uint32_t* out = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z);
         const float wx = cols[x];
         const int xr = x + 1 < W ? x + 1 : W - 1;
-        uint32_t t[kWinRows];
-        float crow[kWinRows][3];
-#pragma unroll
-        for (int i = 0; i < kWinRows; ++i) {
-          const int r = clampi(ys - 2 + i, 0, H - 1);
-          t[i] = img[r * W + x];
-          const uint32_t tr = img[r * W + xr];
+        // rolling window of five source rows (y-2 .. y+2 of the current target row): the texel (its bytes select the
+        // nodes) and, per channel, the sampler's horizontal lerp of that row, exactly as the GL evaluates it
+        uint32_t t[5];
+        float crow[5][3];
+        auto decode_row = [&](uint32_t tc, uint32_t tr, int slot) {
+          t[slot] = tc;
 #pragma unroll
           for (int ch = 0; ch < 3; ++ch) {
-            const float d = lds.dec[(t[i] >> (8 * ch)) & 255u], dr = lds.dec[(tr >> (8 * ch)) & 255u];
-            crow[i][ch] = fma_(wx, dr - d, d);   // the sampler's horizontal lerp, exactly
+            const float d = lds.dec[(tc >> (8 * ch)) & 255u], dr = lds.dec[(tr >> (8 * ch)) & 255u];
+            crow[slot][ch] = fma_(wx, dr - d, d);
           }
-        }
+        };
 #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = clampi(ys - 2 + i, 0, H - 1);
+          decode_row(img[r * W + x], img[r * W + xr], i);
+        }
+        int rn = clampi(ys + 2, 0, H - 1);
+        uint32_t nc = img[rn * W + x], nr = img[rn * W + xr];   // row y+2 of the first target row, in flight
+#pragma unroll 1
         for (int k = 0; k < kStripRows; ++k) {
           const int y = ys + k;
           if (y >= H) break;
+          decode_row(nc, nr, 4);
+          rn = clampi(y + 3, 0, H - 1);
+          nc = img[rn * W + x];   // next iteration's row
+          nr = img[rn * W + xr];
           const ScanRow ri = rows[y];
           const bool lo = rcd::lower_tri(x, y, W, H);
           const float dist = lo ? ri.dist_lo : ri.dist_up;
-          bool fail = y < 2 || y >= H - 2;
+          uint32_t fail = (y < 2 || y >= H - 2) ? 1u : ((ri.up >> (lo ? 8 : 9)) & 1u);
           uint32_t px = 0xff000000u;
-          if (!fail) {
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-              float kj[3], bj[3];
+          for (int ch = 0; ch < 3; ++ch) {
+            float kj[3], bj[3];
 #pragma unroll
-              for (int j = 0; j < 3; ++j) {
-                const int wi = k + 2 + (j == 0 ? 0 : (j == 1 ? 1 : -1));
-                const bool up = (ri.up >> j) & 1u;
-                const float lowc = up ? crow[wi - 1][ch] : crow[wi][ch], highc = up ? crow[wi][ch] : crow[wi + 1][ch];
-                const float c = fma_(ri.wy[j], highc - lowc, lowc);   // ... and its vertical lerp: the sampled colour
-                const uint32_t cb = f2bits(c);
-                const uint32_t byte = (t[wi] >> (8 * ch)) & 255u;
-                uint32_t idx = (uint32_t)kLogNodes + byte;
-                if (c < kLogMax) idx = cb >= kLogBits0 ? (cb - kLogBits0) >> 20 : (uint32_t)kLogNodes;
-                const uint32_t e = (uint32_t)((j * 3 + ch) * kNodes) + idx;
-                const float4 a = A[e];
-                const uint2 bb = B[e];
-                const float delta = c - bits2f(bb.y);   // at most kMaxDelta (byte nodes: k_scan_geometry bounds the weights) or half a bucket
-                kj[j] = fma_(delta, fma_(delta, a.z, a.y), fma_(a.w, dist, a.x));
-                bj[j] = bits2f(bb.x);
-              }
-              const float s = ((kj[0] + kj[1]) + kj[2]) * 0.5f;
-              const float b = fma_(5e-7f, s, 0.5f * ((bj[0] + bj[1]) + bj[2]));
-              bool ok;
-              const uint32_t byte = srgb8_interval(s, b, lds, &ok);
-              fail = fail || !ok;
-              px |= byte << (8 * ch);
+            for (int j = 0; j < 3; ++j) {
+              const int wi = 2 + (j == 0 ? 0 : (j == 1 ? 1 : -1));
+              const bool up = (ri.up >> j) & 1u;
+              const float lowc = up ? crow[wi - 1][ch] : crow[wi][ch], highc = up ? crow[wi][ch] : crow[wi + 1][ch];
+              const float c = fma_(ri.wy[j], highc - lowc, lowc);   // ... and its vertical lerp: the sampled colour
+              const uint32_t cb = f2bits(c);
+              const uint32_t byte = (t[wi] >> (8 * ch)) & 255u;
+              uint32_t idx = (uint32_t)kLogNodes + byte;
+              if (c < kLogMax) idx = cb >= kLogBits0 ? (cb - kLogBits0) >> 20 : (uint32_t)kLogNodes;
+              const uint32_t e = (uint32_t)((j * 3 + ch) * kNodes) + idx;
+              const float4 a = A[e];
+              const uint2 bb = B[e];
+              const float delta = c - bits2f(bb.y);   // at most kMaxDelta (byte nodes: k_scan_geometry bounds the weights) or half a bucket
+              kj[j] = fma_(delta, fma_(delta, a.z, a.y), fma_(a.w, dist, a.x));
+              bj[j] = bits2f(bb.x);
             }
+            const float s = ((kj[0] + kj[1]) + kj[2]) * 0.5f;
+            const float b = fma_(5e-7f, s, 0.5f * ((bj[0] + bj[1]) + bj[2]));
+            bool ok;
+            const uint32_t byte = srgb8_interval(s, b, lds, &ok);
+            fail |= ok ? 0u : 1u;
+            px |= byte << (8 * ch);
           }
-          if (!fail) {
-            *(reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z) + ((size_t)y * W + x)) = px;
-          } else {
-            const uint32_t slot = atomicAdd(cnt, 1u);
-            fails[slot] = (uint16_t)((wave << 9) | (k << 6) | lane);
+          if (fail == 0u) out[(size_t)y * W + x] = px;
+          else fails[atomicAdd(cnt, 1u)] = (uint16_t)((wave << 9) | (k << 6) | lane);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            t[i] = t[i + 1];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) crow[i][ch] = crow[i + 1][ch];
           }
         }
       }
     }
+    // this tile's uncertain pixels: one range of the global list, reserved by one atomic
     __syncthreads();
-    // pixels whose byte was not certain: the general form, nine evaluations per pixel spread over the lanes
-    const int n_fail = (int)*cnt;
-    for (int base = 0; base < n_fail; base += kFallbackPixels) {
-      const int p = base + tid / 9, e = tid % 9;
-      if (tid < kFallbackPixels * 9 && p < n_fail) {
-        const uint32_t id = fails[p];
+    const uint32_t n_fail = cnt[0];
+    if (n_fail) {   // uniform
+      if (tid == 0) cnt[1] = atomicAdd(fix_counter(L), n_fail);
+      __syncthreads();
+      const uint32_t base = cnt[1];
+      for (uint32_t i = (uint32_t)tid; i < n_fail; i += kTabThreads) {
+        const uint32_t id = fails[i];
         const int strip2 = tile * kTabWaves + (int)(id >> 9);
         const int z = strip2 / strips_per_frame, rem = strip2 - z * strips_per_frame;
         const int rs = rem / cgs, x = (rem - rs * cgs) * 64 + (int)(id & 63u), y = rs * kStripRows + (int)((id >> 6) & 7u);
-        float col[9], dd[9];
-        scan_v_gather<SI>(L, lds, x, y, z, col, dd);
-        float c = col[0], d = dd[0];
-#pragma unroll
-        for (int q = 1; q < 9; ++q)
-          if (e == q) {
-            c = col[q];
-            d = dd[q];
-          }
-        kbuf[tid] = beam_k<float, SI::kUnitRange>(c, d, off, sigma_range, shape_range);
+        fix_list(L)[base + i] = (uint32_t)((z * H + y) * W + x);
       }
       __syncthreads();
-      if (tid < kFallbackPixels && base + tid < n_fail) {
-        const uint32_t id = fails[base + tid];
-        const int strip2 = tile * kTabWaves + (int)(id >> 9);
-        const int z = strip2 / strips_per_frame, rem = strip2 - z * strips_per_frame;
-        const int rs = rem / cgs, x = (rem - rs * cgs) * 64 + (int)(id & 63u), y = rs * kStripRows + (int)((id >> 6) & 7u);
-        const float* kk = kbuf + tid * 9;
-        SO::put(L, z, x, y, make_float4(((kk[0] + kk[3]) + kk[6]) * 0.5f, ((kk[1] + kk[4]) + kk[7]) * 0.5f, ((kk[2] + kk[5]) + kk[8]) * 0.5f, 1.0f), &lds);
-      }
+      if (tid == 0) cnt[0] = 0u;
       __syncthreads();
     }
-    if (tid == 0) *cnt = 0u;
-    __syncthreads();
+  }
+}
+
+// The listed pixels in the general form (k_royale_scan_v's arithmetic: four packed pairs and one scalar evaluation).
+template <class SI, class SO>
+__global__ void __launch_bounds__(256) k_royale_scan_v_fix(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
+  const float off = L.params[RP1_PH] / 3.0f;
+  const uint32_t stride = gridDim.x * 256u;
+  {
+    const uint32_t n = *fix_counter(L);
+    const uint32_t* list = fix_list(L);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
+      const uint32_t p = list[i];
+      const uint32_t row = p / (uint32_t)L.out_w;
+      const int x = (int)(p - row * (uint32_t)L.out_w), z = (int)(row / (uint32_t)L.out_h), y = (int)(row - (uint32_t)z * (uint32_t)L.out_h);
+      float col[9], dd[9], kk[9];
+      scan_v_gather<SI>(L, lds, x, y, z, col, dd);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const v2f k = beam_k<v2f, SI::kUnitRange>(v2f{col[2 * j], col[2 * j + 1]}, v2f{dd[2 * j], dd[2 * j + 1]}, off, sigma_range, shape_range);
+        kk[2 * j] = k.x;
+        kk[2 * j + 1] = k.y;
+      }
+      kk[8] = beam_k<float, SI::kUnitRange>(col[8], dd[8], off, sigma_range, shape_range);
+      SO::put(L, z, x, y, make_float4(((kk[0] + kk[3]) + kk[6]) * 0.5f, ((kk[1] + kk[4]) + kk[7]) * 0.5f, ((kk[2] + kk[5]) + kk[8]) * 0.5f, 1.0f), &lds);
+    }
   }
 }
 
@@ -571,6 +609,7 @@ const ScanTables* scanTablesFor(const PassLaunch& L, hipStream_t s) {
   }
   if (bad) (void)hipFree(bad);
   T.usable = ok && hbad == 0;
+  if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc scan] tables for %dx%d: hip ok %d, geometry flags %u\n", L.out_w, L.out_h, (int)ok, hbad);
   if (!T.usable) {
     if (T.A) (void)hipFree(T.A);
     if (T.B) (void)hipFree(T.B);
@@ -605,7 +644,10 @@ using OutS = St<FMT_SRGB8>;
 hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s) {
   if (SrgbLinEdge::matches(L.in) && OutS::matches(L)) {
     if (L.flags & RC_FLAG_GENERAL_ONLY) GO((k_royale_scan_v<SrgbLinEdge, OutS>));
-    if (const ScanTables* T = scanTablesFor(L, s)) {
+    const bool room = L.scratch && L.scratch_frame_stride >= (uint64_t)kFixHeader + (uint64_t)L.out_w * L.out_h * 4u &&
+                      (uint64_t)L.n_frames * L.out_w * L.out_h < (1ull << 32);
+    const ScanTables* T = room ? scanTablesFor(L, s) : nullptr;
+    if (T) {
       auto kernel = k_royale_scan_v_tab<SrgbLinEdge, OutS>;
       static bool attr = false;
       if (!attr) {
@@ -615,7 +657,9 @@ hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s) {
       }
       const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kStripRows - 1) / kStripRows) * L.n_frames;
       const long tiles = (strips + kTabWaves - 1) / kTabWaves;
+      if (hipMemsetAsync(L.scratch, 0, kFixHeader, s) != hipSuccess) return hipGetLastError();
       hipLaunchKernelGGL(kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(kTabThreads), kLdsTotal * 4, s, L, T->A, T->B, T->rows, T->cols);
+      hipLaunchKernelGGL((k_royale_scan_v_fix<SrgbLinEdge, OutS>), dim3(512), dim3(256), rcd::srgb_lds_bytes(L), s, L);
       return hipGetLastError();
     }
     // two rows per thread: 64 x 8 tiles

@@ -212,13 +212,14 @@ __device__ __forceinline__ float vary(const Plane& p, int x, int y, bool lower) 
 // sRGB8 -> linear float as the texture unit decodes it (table measured on the GL; the
 // same numbers as oracle/rc_tables.inc but owned by the product), and the sRGB8 encode of an sRGB
 // render target: llvmpipe's RSQRTPS-based conversion, re-tabulated per RSQRTPS run of the argument
-// (srgb_encode.cpp): byte = entry >> 16, plus one from offset (entry & 0xffff) of the run on.
+// (srgb_encode.cpp): byte = entry >> 16, plus one from offset (entry & 0x3fff) of the run on (bit 14: flag for
+// interval tests across a run boundary).
 #include "rc_tables_device.inc"  // k_srgb_decode[256]
 
 constexpr float kSrgbLinMax = 0.0031308f;          // linear segment up to here: byte = rint(x * kSrgbLinScale)
 constexpr float kSrgbLinScale = 12.92f * 255.0f;
 constexpr uint32_t kSrgbRun0 = 0x3b4d2e1cu >> 13;  // run (float bits >> 13) that contains kSrgbLinMax
-constexpr uint32_t kSrgbRuns = (0x3f7fffffu >> 13) - kSrgbRun0 + 1u;  // 8599, up to the last float below 1
+constexpr uint32_t kSrgbRuns = (0x3f7fffffu >> 13) - kSrgbRun0 + 2u;  // 8599 runs up to the last float below 1, and a spare entry (255 << 16) for the run of 1.0
 
 // Both tables live in dynamic LDS (the launch passes srgb_lds_bytes(L)): 1 KiB for the decode table,
 // plus 34 KiB for the encode table only when the pass stores to an sRGB8 target.
@@ -383,7 +384,7 @@ __device__ __forceinline__ uint32_t srgb8(float x, const SrgbLds* t) {
   if (x <= kSrgbLinMax) return (uint32_t)__builtin_rintf(x * kSrgbLinScale);
   const uint32_t b = f2bits(x);
   const uint32_t e = t->enc[(b >> 13) - kSrgbRun0];
-  return (e >> 16) + ((b & 0x1fffu) >= (e & 0xffffu) ? 1u : 0u);
+  return (e >> 16) + ((b & 0x1fffu) >= (e & 0x3fffu) ? 1u : 0u);
 }
 
 template <int OUT_FMT>

@@ -274,7 +274,15 @@ void registerRoyaleKernels(std::vector<KernelEntry>& r) {
   };
   ids.reserve(16);
   r.push_back({id("first-pass-linearize-crt-gamma-bob-fields.glsl"), "royale-first", {}, {}, rck::launch_royale_first, setupFirst, false});
-  r.push_back({id("scanlines-vertical-interlacing.glsl"), "royale-scanlines-v", {}, {}, rck::launch_royale_scan_v, setupScanV, false});
+  {
+    KernelEntry e{id("scanlines-vertical-interlacing.glsl"), "royale-scanlines-v", {}, {}, rck::launch_royale_scan_v, setupScanV, false};
+    // 1:1 geometry runs the expansion-table form (kernels/pass_royale_scan.hip), which lists the pixels it leaves to the
+    // general form in this scratch: 256 bytes of counters and one 4-byte entry per pixel, per frame
+    e.scratch_bytes = [](const PassGeometry& g) -> uint64_t {
+      return (g.in_w == g.out_w && g.in_h == g.out_h) ? 256u + (uint64_t)g.out_w * (uint64_t)g.out_h * 4u : 0u;
+    };
+    r.push_back(e);
+  }
   r.back().texture_height_override = true;
   r.push_back({id("bloom-approx.glsl"), "royale-bloom-approx", {}, {"PassPrev2Texture"}, rck::launch_royale_bloom_approx, setupBloomApprox, false});
   r.push_back({"blurs/blur9fast-vertical.glsl", "blur9fast-v", {}, {}, rck::launch_blur9, setupBlur9V, false});

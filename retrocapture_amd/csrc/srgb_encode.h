@@ -9,7 +9,8 @@ namespace rc {
 // the byte an sRGB8 render target stores for x (host evaluation of the full algorithm)
 uint8_t srgb8Encode(float x);
 // per-run table the kernels use (rcd::kSrgbRuns entries: byte at the run's start << 16 | offset of the
-// crossing inside the run, 8192 = none); false if the measured structure does not hold
+// crossing inside the run, 8192 = none; bit 14: the next run starts with the byte this one ends with); false if
+// the measured structure does not hold
 bool buildSrgbRunTable(std::vector<uint32_t>* table);
 uint8_t srgb8EncodeByRunTable(float x, const uint32_t* table);
 // the table in device memory of `device` (current device must be `device`); created on first use
