@@ -305,73 +305,6 @@ __global__ void __launch_bounds__(256) k_royale_brightpass(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
-// ------------------------------------------------------------------------ P9 / P10 ------
-// tex2Dblur17fast (bloom-vertical.glsl 7132-7176); the nine (offset, weight) pairs come from
-// the host, evaluated with the run-time sigma exactly as the fragment shader would.
-template <class SI>
-__device__ __forceinline__ float4 blur17(const Tex& t, const uint8_t* img, float u, float v, float dx, float dy, const float* P,
-                                        const SrgbLds* lds) {
-  const float k[4] = {P[RPG_K78], P[RPG_K56], P[RPG_K34], P[RPG_K12]};
-  const float w[4] = {P[RPG_W78], P[RPG_W56], P[RPG_W34], P[RPG_W12]};
-  // source order, except that the centre term (weight 1.0: a plain addend) is added before the
-  // product that precedes it, as in k_blur9: (((A+B)+C) + centre) + D, then the four right-hand taps
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const float4 s = SI::get(t, img, u - k[i] * dx, v - k[i] * dy, lds);
-    sx += w[i] * s.x; sy += w[i] * s.y; sz += w[i] * s.z;
-  }
-  {
-    const float4 d = SI::get(t, img, u - k[3] * dx, v - k[3] * dy, lds);
-    const float4 s = SI::get(t, img, u, v, lds);
-    sx += 1.0f * s.x; sy += 1.0f * s.y; sz += 1.0f * s.z;
-    sx += w[3] * d.x; sy += w[3] * d.y; sz += w[3] * d.z;
-  }
-#pragma unroll
-  for (int i = 3; i >= 0; --i) {
-    const float4 s = SI::get(t, img, u + k[i] * dx, v + k[i] * dy, lds);
-    sx += w[i] * s.x; sy += w[i] * s.y; sz += w[i] * s.z;
-  }
-  const float si = P[RPG_SUM_INV];
-  return make_float4(sx * si, sy * si, sz * si, 1.0f);
-}
-
-template <class SI, class SO>
-__global__ void __launch_bounds__(256) k_royale_bloom_v(const PassLaunch L) {
-  RC_SRGB_LDS(lds, L);
-  RC_TILE_LOOP_BEGIN
-  const float4 c = blur17<SI>(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), 0.0f, L.params[RPG_DXY],
-                          L.params, &lds);
-  SO::put(L, z, x, y, c, &lds);
-  RC_TILE_LOOP_END
-}
-
-// bloom-horizontal-reconstitute.glsl FS 11407-11439.
-// extra[0] = PassPrev3 (MASKED_SCANLINES), extra[1] = PassPrev2 (BRIGHTPASS), extra[2] = PassPrev6 (HALATION_BLUR)
-template <class SI, class S0, class S1, class S2, class SO>
-__global__ void __launch_bounds__(256, 4) k_royale_bloom_h(const PassLaunch L) {
-  RC_SRGB_LDS(lds, L);
-  RC_TILE_LOOP_BEGIN
-  const float4 blurred = blur17<SI>(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), L.params[RPG_DXY], 0.0f,
-                                L.params, &lds);
-  const float4 idim = S0::get(L.extra[0], frame_ptr(L.extra[0], z), vary(L.plane[2], x, y, lo), vary(L.plane[3], x, y, lo), &lds);
-  const float4 bright = S1::get(L.extra[1], frame_ptr(L.extra[1], z), vary(L.plane[4], x, y, lo), vary(L.plane[5], x, y, lo), &lds);
-  const float4 hal = S2::get(L.extra[2], frame_ptr(L.extra[2], z), vary(L.plane[6], x, y, lo), vary(L.plane[7], x, y, lo), &lds);
-  const float mask_amplify = L.params[RPG_MASK_AMPLIFY];
-  const float i3[3] = {idim.x, idim.y, idim.z}, b3[3] = {bright.x, bright.y, bright.z}, bl[3] = {blurred.x, blurred.y, blurred.z};
-  const float h3[3] = {hal.x, hal.y, hal.z};
-  float out[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float dimpass = i3[c] - b3[c];
-    // lerp(phosphor_bloom, diffusion_color, diffusion_weight) with compile-time parameters: a*(1-t) + b*t,
-    // the constant factors of a*(1-t) gathered into one by the GL's compiler (float goldens)
-    out[c] = (dimpass + bl[c]) * ((mask_amplify * 2.0f) * (1.0f - 0.075f)) + h3[c] * 0.075f;
-  }
-  SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
-  RC_TILE_LOOP_END
-}
-
 // ------------------------------------------------------------------------------ P11 ------
 // geometry-aa-last-pass.glsl FS 5451-5531 (flat geometry path), get_border_dim_factor 5250.
 template <class SI, class SO, bool MIP>
@@ -478,16 +411,6 @@ hipError_t launch_royale_scan_h_fake(const PassLaunch& L, hipStream_t s) {
 hipError_t launch_royale_brightpass(const PassLaunch& L, hipStream_t s) {
   if (SrgbNearEdge::matches(L.in) && SrgbLinEdge::matches(L.extra[0]) && OutS::matches(L)) GO(k_royale_brightpass<SrgbNearEdge, SrgbLinEdge, OutS>);
   GO(k_royale_brightpass<SRT, SRT, StRT>);
-}
-hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s) {
-  if (SrgbNearEdge::matches(L.in) && OutS::matches(L)) GO(k_royale_bloom_v<SrgbNearEdge, OutS>);
-  GO(k_royale_bloom_v<SRT, StRT>);
-}
-hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
-  if (SrgbLinEdge::matches(L.in) && SrgbNearEdge::matches(L.extra[0]) && SrgbNearEdge::matches(L.extra[1]) &&
-      SrgbLinEdge::matches(L.extra[2]) && OutS::matches(L))
-    GO(k_royale_bloom_h<SrgbLinEdge, SrgbNearEdge, SrgbNearEdge, SrgbLinEdge, OutS>);
-  GO(k_royale_bloom_h<SRT, SRT, SRT, SRT, StRT>);
 }
 hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
   if (L.in.n_levels > 1) {

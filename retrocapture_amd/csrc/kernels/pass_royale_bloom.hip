@@ -1,0 +1,388 @@
+// crt-royale passes 9 and 10 (bloom-vertical.glsl, bloom-horizontal-reconstitute.glsl): the general per-pixel
+// kernels, and the strip forms that run separable geometry (royale_strip.h) - the shipped preset at any size.
+#include <cstdio>
+#include <cstdlib>
+
+#include "royale_strip.h"
+
+using namespace rcd;
+using namespace rcroyale;
+using namespace rcstrip;
+
+namespace {
+
+// ------------------------------------------------------------------------ P9 / P10 ------
+// tex2Dblur17fast (bloom-vertical.glsl 7132-7176); the nine (offset, weight) pairs come from
+// the host, evaluated with the run-time sigma exactly as the fragment shader would.
+template <class SI>
+__device__ __forceinline__ float4 blur17(const Tex& t, const uint8_t* img, float u, float v, float dx, float dy, const float* P,
+                                        const SrgbLds* lds) {
+  const float k[4] = {P[RPG_K78], P[RPG_K56], P[RPG_K34], P[RPG_K12]};
+  const float w[4] = {P[RPG_W78], P[RPG_W56], P[RPG_W34], P[RPG_W12]};
+  // source order, except that the centre term (weight 1.0: a plain addend) is added before the
+  // product that precedes it, as in k_blur9: (((A+B)+C) + centre) + D, then the four right-hand taps
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float4 s = SI::get(t, img, u - k[i] * dx, v - k[i] * dy, lds);
+    sx += w[i] * s.x; sy += w[i] * s.y; sz += w[i] * s.z;
+  }
+  {
+    const float4 d = SI::get(t, img, u - k[3] * dx, v - k[3] * dy, lds);
+    const float4 s = SI::get(t, img, u, v, lds);
+    sx += 1.0f * s.x; sy += 1.0f * s.y; sz += 1.0f * s.z;
+    sx += w[3] * d.x; sy += w[3] * d.y; sz += w[3] * d.z;
+  }
+#pragma unroll
+  for (int i = 3; i >= 0; --i) {
+    const float4 s = SI::get(t, img, u + k[i] * dx, v + k[i] * dy, lds);
+    sx += w[i] * s.x; sy += w[i] * s.y; sz += w[i] * s.z;
+  }
+  const float si = P[RPG_SUM_INV];
+  return make_float4(sx * si, sy * si, sz * si, 1.0f);
+}
+
+template <class SI, class SO>
+__global__ void __launch_bounds__(256) k_royale_bloom_v(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  const float4 c = blur17<SI>(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), 0.0f, L.params[RPG_DXY],
+                          L.params, &lds);
+  SO::put(L, z, x, y, c, &lds);
+  RC_TILE_LOOP_END
+}
+
+// bloom-horizontal-reconstitute.glsl FS 11407-11439.
+// extra[0] = PassPrev3 (MASKED_SCANLINES), extra[1] = PassPrev2 (BRIGHTPASS), extra[2] = PassPrev6 (HALATION_BLUR)
+template <class SI, class S0, class S1, class S2, class SO>
+__global__ void __launch_bounds__(256, 4) k_royale_bloom_h(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  const float4 blurred = blur17<SI>(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), L.params[RPG_DXY], 0.0f,
+                                L.params, &lds);
+  const float4 idim = S0::get(L.extra[0], frame_ptr(L.extra[0], z), vary(L.plane[2], x, y, lo), vary(L.plane[3], x, y, lo), &lds);
+  const float4 bright = S1::get(L.extra[1], frame_ptr(L.extra[1], z), vary(L.plane[4], x, y, lo), vary(L.plane[5], x, y, lo), &lds);
+  const float4 hal = S2::get(L.extra[2], frame_ptr(L.extra[2], z), vary(L.plane[6], x, y, lo), vary(L.plane[7], x, y, lo), &lds);
+  const float mask_amplify = L.params[RPG_MASK_AMPLIFY];
+  const float i3[3] = {idim.x, idim.y, idim.z}, b3[3] = {bright.x, bright.y, bright.z}, bl[3] = {blurred.x, blurred.y, blurred.z};
+  const float h3[3] = {hal.x, hal.y, hal.z};
+  float out[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float dimpass = i3[c] - b3[c];
+    // lerp(phosphor_bloom, diffusion_color, diffusion_weight) with compile-time parameters: a*(1-t) + b*t,
+    // the constant factors of a*(1-t) gathered into one by the GL's compiler (float goldens)
+    out[c] = (dimpass + bl[c]) * ((mask_amplify * 2.0f) * (1.0f - 0.075f)) + h3[c] * 0.075f;
+  }
+  SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
+// ----------------------------------------------------------------- P10, strip form ------
+// One wave renders 64 columns x kBhRows rows.  The nine blur taps of a pixel read a row of the input texture
+// (pass 9's sRGB8 target) through a LINEAR sampler at horizontal offsets of up to 7.x texels: the wave decodes each
+// source row ONCE into a segment of floats in LDS (its 64 columns + 10 either side, indices clamped like the
+// sampler clamps them) and the taps read decoded neighbours from there.  Per tap a thread holds (first texel, weight)
+// of its column - for both triangles - in registers (k_bloomh_geometry).  A row whose vertical weight is exactly 0
+// (the usual case at 1:1) filters one source row, any other row the pair the sampler would fetch.
+constexpr int kBhRows = 8;
+constexpr int kBhWaves = 4;
+constexpr int kBhSeg = 84;      // staged columns: 10 + 64 + 10
+constexpr int kBhSegLeft = 10;
+constexpr int kBhRingDwords = 3 * kBhSeg * 4;   // per wave: three rows of float4
+enum { BH_DX = 0, BH_WX = 9, BH_IDIM_X = 18, BH_BRIGHT_X = 19, BH_HAL_X0 = 20, BH_HAL_W = 21, BH_COL_FIELDS = 22 };
+enum { BH_Y0 = 0, BH_WY = 1, BH_IDIM_Y = 2, BH_BRIGHT_Y = 3, BH_HAL_Y0 = 4, BH_HAL_WY = 5, BH_ROW_FIELDS = 8 };
+
+struct BhTables {
+  uint32_t* cols = nullptr;   // [BH_COL_FIELDS][2 sides][W] (ints and float bits)
+  uint32_t* rows = nullptr;   // [H][2 sides][BH_ROW_FIELDS]
+  bool usable = false;
+};
+
+__global__ void __launch_bounds__(256) k_bloomh_geometry(const PassLaunch L, uint32_t* cols, uint32_t* rows, uint32_t* bad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int W = L.out_w, H = L.out_h;
+  const float* P = L.params;
+  const float k[4] = {P[RPG_K78], P[RPG_K56], P[RPG_K34], P[RPG_K12]};
+  const float dx = P[RPG_DXY];
+  uint32_t why = 0u;
+  if (i < W) {
+    for (int side = 0; side < 2; ++side) {
+      const bool lo = side == 0;
+      const float u = vary(L.plane[0], i, 0, lo);
+      // evaluation order of blur17 (below): -k78, -k56, -k34, -k12, centre, +k12, +k34, +k56, +k78
+      float us[9];
+      for (int q = 0; q < 4; ++q) {
+        us[q] = u - k[q] * dx;
+        us[8 - q] = u + k[q] * dx;
+      }
+      us[4] = u;
+      for (int q = 0; q < 9; ++q) {
+        const LinTap t = lin_tap(us[q], L.in.w);
+        const int d = t.i0 - i;
+        if (d < -kBhSegLeft || d + 1 > kBhSeg - kBhSegLeft - 64) why |= 1u;
+        cols[((BH_DX + q) * 2 + side) * W + i] = (uint32_t)d;
+        cols[((BH_WX + q) * 2 + side) * W + i] = f2bits(t.w);
+      }
+      cols[(BH_IDIM_X * 2 + side) * W + i] = (uint32_t)near_tap(vary(L.plane[2], i, 0, lo), L.extra[0].w);
+      cols[(BH_BRIGHT_X * 2 + side) * W + i] = (uint32_t)near_tap(vary(L.plane[4], i, 0, lo), L.extra[1].w);
+      const LinTap h = lin_tap(vary(L.plane[6], i, 0, lo), L.extra[2].w);
+      cols[(BH_HAL_X0 * 2 + side) * W + i] = (uint32_t)h.i0;
+      cols[(BH_HAL_W * 2 + side) * W + i] = f2bits(h.w);
+    }
+  }
+  if (i < H) {
+    for (int side = 0; side < 2; ++side) {
+      const bool lo = side == 0;
+      uint32_t* r = rows + ((size_t)i * 2 + side) * BH_ROW_FIELDS;
+      const float v = vary(L.plane[1], 0, i, lo);
+      const LinTap t = lin_tap(v - k[0] * 0.0f, L.in.h);   // every tap: v -+ k * 0 = v
+      // the strip keeps three consecutive source rows staged: the pair must lie within one row of the target row
+      if (t.i0 < i - 1 || t.i0 > i) why |= 2u;
+      r[BH_Y0] = (uint32_t)t.i0;
+      r[BH_WY] = f2bits(t.w);
+      r[BH_IDIM_Y] = (uint32_t)near_tap(vary(L.plane[3], 0, i, lo), L.extra[0].h);
+      r[BH_BRIGHT_Y] = (uint32_t)near_tap(vary(L.plane[5], 0, i, lo), L.extra[1].h);
+      const LinTap h = lin_tap(vary(L.plane[7], 0, i, lo), L.extra[2].h);
+      r[BH_HAL_Y0] = (uint32_t)h.i0;
+      r[BH_HAL_WY] = f2bits(h.w);
+      r[6] = r[7] = 0u;
+    }
+  }
+  if (why) atomicOr(bad, why);
+}
+
+struct BhCol {   // one triangle's column quantities of a thread
+  uint32_t off[9];   // byte offset of tap q's first texel inside a staged row
+  float wx[9];
+  int idim_x, bright_x, hal_x0;
+  float hal_w;
+};
+struct BhRow {
+  int y0;
+  float wy;
+  int idim_y, bright_y, hal_y0;
+  float hal_wy;
+};
+
+__device__ __forceinline__ float3 f3(float4 v) { return make_float3(v.x, v.y, v.z); }
+__device__ __forceinline__ float3 lerp3(float w, float3 a, float3 b) {
+  return make_float3(fma_(w, b.x - a.x, a.x), fma_(w, b.y - a.y, a.y), fma_(w, b.z - a.z, a.z));
+}
+__device__ __forceinline__ float3 dec3(uint32_t t, const SrgbLds& l) {
+  return make_float3(l.dec[t & 255u], l.dec[(t >> 8) & 255u], l.dec[(t >> 16) & 255u]);
+}
+
+// one target pixel; ring = this wave's three staged rows (row r in slot r % 3), `TWO`: the vertical weight is not 0
+template <class SO, bool TWO>
+__device__ __forceinline__ void bloomh_pixel(const PassLaunch& L, const SrgbLds& lds, const uint8_t* ring, const BhCol& c, const BhRow& r,
+                                             int x, int y, int z) {
+  const float* P = L.params;
+  const int Hin = L.in.h;
+  const uint8_t* rowA = ring + (uint32_t)(clampi(r.y0, 0, Hin - 1) % 3) * (kBhSeg * 16u);
+  const uint8_t* rowB = ring + (uint32_t)(clampi(r.y0 + 1, 0, Hin - 1) % 3) * (kBhSeg * 16u);
+  auto tap = [&](int q) -> float3 {
+    const float4 a0 = *reinterpret_cast<const float4*>(rowA + c.off[q]), a1 = *reinterpret_cast<const float4*>(rowA + c.off[q] + 16u);
+    float3 top = lerp3(c.wx[q], f3(a0), f3(a1));
+    if (TWO) {
+      const float4 b0 = *reinterpret_cast<const float4*>(rowB + c.off[q]), b1 = *reinterpret_cast<const float4*>(rowB + c.off[q] + 16u);
+      top = lerp3(r.wy, top, lerp3(c.wx[q], f3(b0), f3(b1)));
+    }
+    return top;
+  };
+  // tex2Dblur17fast in the GL's evaluation order (see blur17 above)
+  const float w[4] = {P[RPG_W78], P[RPG_W56], P[RPG_W34], P[RPG_W12]};
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const float3 s = tap(q);
+    sx += w[q] * s.x; sy += w[q] * s.y; sz += w[q] * s.z;
+  }
+  {
+    const float3 d = tap(3), s = tap(4);
+    sx += 1.0f * s.x; sy += 1.0f * s.y; sz += 1.0f * s.z;
+    sx += w[3] * d.x; sy += w[3] * d.y; sz += w[3] * d.z;
+  }
+#pragma unroll
+  for (int q = 3; q >= 0; --q) {
+    const float3 s = tap(8 - q);
+    sx += w[q] * s.x; sy += w[q] * s.y; sz += w[q] * s.z;
+  }
+  const float si = P[RPG_SUM_INV];
+  const float bl[3] = {sx * si, sy * si, sz * si};
+  // the three single taps: MASKED_SCANLINES and BRIGHTPASS (NEAREST), HALATION_BLUR (LINEAR, 320x240)
+  const uint32_t* i0 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[0], z));
+  const uint32_t* i1 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[1], z));
+  const uint32_t* i2 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[2], z));
+  const float3 idim = dec3(i0[r.idim_y * L.extra[0].w + c.idim_x], lds), bright = dec3(i1[r.bright_y * L.extra[1].w + c.bright_x], lds);
+  const int hw = L.extra[2].w, hh = L.extra[2].h;
+  const int hx0 = clampi(c.hal_x0, 0, hw - 1), hx1 = clampi(c.hal_x0 + 1, 0, hw - 1);
+  const int hy0 = clampi(r.hal_y0, 0, hh - 1), hy1 = clampi(r.hal_y0 + 1, 0, hh - 1);
+  const float3 h00 = dec3(i2[hy0 * hw + hx0], lds), h10 = dec3(i2[hy0 * hw + hx1], lds);
+  const float3 h01 = dec3(i2[hy1 * hw + hx0], lds), h11 = dec3(i2[hy1 * hw + hx1], lds);
+  const float3 hal = lerp3(r.hal_wy, lerp3(c.hal_w, h00, h10), lerp3(c.hal_w, h01, h11));
+  const float mask_amplify = P[RPG_MASK_AMPLIFY];
+  const float i3[3] = {idim.x, idim.y, idim.z}, b3[3] = {bright.x, bright.y, bright.z}, h3[3] = {hal.x, hal.y, hal.z};
+  float out[3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const float dimpass = i3[ch] - b3[ch];
+    out[ch] = (dimpass + bl[ch]) * ((mask_amplify * 2.0f) * (1.0f - 0.075f)) + h3[ch] * 0.075f;   // as k_royale_bloom_h
+  }
+  SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+}
+
+__device__ __forceinline__ BhRow load_bh_row(const uint32_t* rows, int y, int side) {
+  const uint32_t* r = rows + ((size_t)y * 2 + side) * BH_ROW_FIELDS;
+  return BhRow{(int)r[BH_Y0], bits2f(r[BH_WY]), (int)r[BH_IDIM_Y], (int)r[BH_BRIGHT_Y], (int)r[BH_HAL_Y0], bits2f(r[BH_HAL_WY])};
+}
+
+__device__ __forceinline__ BhCol load_bh_col(const uint32_t* cols, int W, int xc, int xw, int side) {
+  BhCol c;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    c.off[q] = (uint32_t)((int)cols[((BH_DX + q) * 2 + side) * W + xc] + (xc - xw) + kBhSegLeft) * 16u;
+    c.wx[q] = bits2f(cols[((BH_WX + q) * 2 + side) * W + xc]);
+  }
+  c.idim_x = (int)cols[(BH_IDIM_X * 2 + side) * W + xc];
+  c.bright_x = (int)cols[(BH_BRIGHT_X * 2 + side) * W + xc];
+  c.hal_x0 = (int)cols[(BH_HAL_X0 * 2 + side) * W + xc];
+  c.hal_w = bits2f(cols[(BH_HAL_W * 2 + side) * W + xc]);
+  return c;
+}
+
+// One strip.  MODE 0 / 1: every pixel of it lies in the lower / upper triangle (all but the few strips the quad's
+// diagonal crosses): one set of column quantities in registers, row quantities wave-uniform.  MODE 2: per-lane selection.
+template <class SO, int MODE>
+__device__ __forceinline__ void bloomh_strip(const PassLaunch& L, const SrgbLds& lds, uint8_t* ring, const uint32_t* __restrict__ cols,
+                                             const uint32_t* __restrict__ rows, int z, int xw, int ys, int lane) {
+  const int W = L.out_w, H = L.out_h, Win = L.in.w, Hin = L.in.h;
+  const int x = xw + lane;
+  const bool live = x < W;
+  const int xc = live ? x : W - 1;
+  BhCol c0;
+  if (MODE != 2) c0 = load_bh_col(cols, W, xc, xw, MODE == 1 ? 1 : 0);
+  const uint32_t* img = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
+  // source rows are staged in increasing order; row r lives in ring slot r % 3
+  auto stage = [&](int r) {
+    float4* slot = reinterpret_cast<float4*>(ring) + (r % 3) * kBhSeg;
+    for (int j = lane; j < kBhSeg; j += 64) {
+      const uint32_t t = img[r * Win + clampi(xw - kBhSegLeft + j, 0, Win - 1)];
+      slot[j] = make_float4(lds.dec[t & 255u], lds.dec[(t >> 8) & 255u], lds.dec[(t >> 16) & 255u], 0.0f);
+    }
+  };
+  int staged = -1;   // highest source row staged so far
+#pragma unroll 1
+  for (int k = 0; k < kBhRows; ++k) {
+    const int y = ys + k;
+    if (y >= H) break;
+    const BhRow r0 = load_bh_row(rows, y, MODE == 1 ? 1 : 0);
+    BhRow r1 = r0;
+    if (MODE == 2) r1 = load_bh_row(rows, y, 1);
+    // rows this target row needs: y0 and y0 + 1, clamped; k_bloomh_geometry checked y - 1 <= y0 <= y
+    const int need_lo = clampi(min(r0.y0, r1.y0), 0, Hin - 1);
+    const int need_hi = clampi(max(r0.y0, r1.y0) + 1, 0, Hin - 1);
+    if (staged < need_lo - 1) staged = need_lo - 1;
+    // (other lanes' reads of the slot being replaced, and their reads of what is written now, must not be moved
+    // across the staging by the compiler: LDS operations of a wave execute in order, a wavefront fence pins them)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    while (staged < need_hi) stage(++staged);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!live) continue;
+    if (MODE != 2) {
+      if (r0.wy != 0.0f) bloomh_pixel<SO, true>(L, lds, ring, c0, r0, x, y, z);
+      else bloomh_pixel<SO, false>(L, lds, ring, c0, r0, x, y, z);
+    } else {
+      // (rare: the column quantities of this pixel's triangle come from memory instead of registers)
+      const bool lo = rcd::lower_tri(x, y, W, H);
+      const BhCol c = load_bh_col(cols, W, xc, xw, lo ? 0 : 1);
+      const BhRow r{lo ? r0.y0 : r1.y0, lo ? r0.wy : r1.wy, lo ? r0.idim_y : r1.idim_y, lo ? r0.bright_y : r1.bright_y,
+                    lo ? r0.hal_y0 : r1.hal_y0, lo ? r0.hal_wy : r1.hal_wy};
+      bloomh_pixel<SO, true>(L, lds, ring, c, r, x, y, z);
+    }
+  }
+}
+
+template <class SO>
+__global__ void __launch_bounds__(kBhWaves * 64, 3) k_royale_bloom_h_strip(const PassLaunch L, const uint32_t* __restrict__ cols,
+                                                                          const uint32_t* __restrict__ rows) {
+  RC_SRGB_LDS(lds, L);
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint8_t* ring = reinterpret_cast<uint8_t*>(rc_dyn_lds_ + ((256 + (int)kSrgbRuns + 3) & ~3) + wave * kBhRingDwords);
+  const StripGrid<kBhRows> G(L.out_w, L.out_h, L.n_frames);
+  const int W = G.W, H = G.H;
+  for (int strip = (int)blockIdx.x * kBhWaves + wave; strip < G.total; strip += (int)gridDim.x * kBhWaves) {
+    int z, xw, ys;
+    G.locate(strip, &z, &xw, &ys);
+    // the lower triangle holds the pixels with (2y+1) W <= (2x+1) H: the strip is all lower if its (min x, max y)
+    // pixel is, all upper if its (max x, min y) pixel is not
+    const int xmax = min(xw + 63, W - 1), ymax = min(ys + kBhRows - 1, H - 1);
+    if (rcd::lower_tri(xw, ymax, W, H)) bloomh_strip<SO, 0>(L, lds, ring, cols, rows, z, xw, ys, lane);
+    else if (!rcd::lower_tri(xmax, ys, W, H)) bloomh_strip<SO, 1>(L, lds, ring, cols, rows, z, xw, ys, lane);
+    else bloomh_strip<SO, 2>(L, lds, ring, cols, rows, z, xw, ys, lane);
+  }
+}
+
+void buildBhTables(const PassLaunch& L, hipStream_t s, BhTables* T) {
+  uint32_t* bad = nullptr;
+  const size_t colWords = (size_t)BH_COL_FIELDS * 2 * L.out_w, rowWords = (size_t)L.out_h * 2 * BH_ROW_FIELDS;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&T->cols), colWords * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&T->rows), rowWords * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&bad), 4) == hipSuccess;
+  uint32_t hbad = 1;
+  if (ok) ok = hipMemsetAsync(bad, 0, 4, s) == hipSuccess;
+  if (ok) {
+    const int n = L.out_w > L.out_h ? L.out_w : L.out_h;
+    hipLaunchKernelGGL(k_bloomh_geometry, dim3((n + 255) / 256), dim3(256), 0, s, L, T->cols, T->rows, bad);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  }
+  if (bad) (void)hipFree(bad);
+  T->usable = ok && hbad == 0;
+  if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc bloom-h] tables for %dx%d: hip ok %d, geometry flags %u\n", L.out_w, L.out_h, (int)ok, hbad);
+  if (!T->usable) {
+    if (T->cols) (void)hipFree(T->cols);
+    if (T->rows) (void)hipFree(T->rows);
+    *T = BhTables();
+  }
+}
+
+}  // namespace
+
+namespace rck {
+#define GO(...)                                                                              \
+  do {                                                                                       \
+    hipLaunchKernelGGL((__VA_ARGS__), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L); \
+    return hipGetLastError();                                                                \
+  } while (0)
+using OutS = St<FMT_SRGB8>;
+
+hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s) {
+  if (SrgbNearEdge::matches(L.in) && OutS::matches(L)) GO(k_royale_bloom_v<SrgbNearEdge, OutS>);
+  GO(k_royale_bloom_v<SRT, StRT>);
+}
+hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
+  if (SrgbLinEdge::matches(L.in) && SrgbNearEdge::matches(L.extra[0]) && SrgbNearEdge::matches(L.extra[1]) &&
+      SrgbLinEdge::matches(L.extra[2]) && OutS::matches(L)) {
+    if (!(L.flags & RC_FLAG_GENERAL_ONLY) && separable(L, 0, 4) && L.in.frame_stride && L.extra[0].frame_stride && L.extra[1].frame_stride) {
+      static std::mutex mu;
+      static std::map<GeoKey, BhTables> cache;
+      if (const BhTables* T = geo_tables<BhTables>(L, s, mu, cache, buildBhTables)) {
+        const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kBhRows - 1) / kBhRows) * L.n_frames;
+        const long blocks = (strips + kBhWaves - 1) / kBhWaves;
+        const unsigned lds = (unsigned)(((256 + (int)kSrgbRuns + 3) & ~3) + kBhWaves * kBhRingDwords) * 4u;
+        auto kernel = k_royale_bloom_h_strip<OutS>;
+        static bool attr = false;
+        if (!attr) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return hipGetLastError();
+          attr = true;
+        }
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks < 768 ? blocks : 768)), dim3(kBhWaves * 64), lds, s, L, T->cols, T->rows);
+        return hipGetLastError();
+      }
+    }
+    GO(k_royale_bloom_h<SrgbLinEdge, SrgbNearEdge, SrgbNearEdge, SrgbLinEdge, OutS>);
+  }
+  GO(k_royale_bloom_h<SRT, SRT, SRT, SRT, StRT>);
+}
+}  // namespace rck
