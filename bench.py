@@ -6,13 +6,22 @@ frames that are already resident in HBM.  One process per GPU; frames are indepe
 GPUs shard the batch with no data-path collective (weak scaling: --batch frames per GPU per
 step).  torch is used for device memory, the stream and the barrier / MAX-over-ranks reduce.
 
+Launch: `python bench.py --gpus N ...` starts N rank processes itself (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set per child, before anything touches the GPU in the parent, which only relays rank 0's line);
+under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the ranks already exist and
+--gpus must equal WORLD_SIZE.  Either way a rank fails loudly if it has no device of its own.
+
 Prints ONE JSON line on rank 0 with the BASELINE metric plus `roofline` (dominant kernel,
-HIP-event timed on the launch stream) and `cpu_baseline` (the oracle, timed on the host cores
-on a bounded sample of the same workload; reported baseline only).
+HIP-event timed on the launch stream), `cpu_baseline` (the oracle, timed on the host cores
+on a bounded sample of the same workload; reported baseline only) and, for crt-royale, `mask_rendered`:
+the same measurement with pass 6's unwritten varying read as 0, i.e. what GPU GL drivers render (the
+default is what Mesa llvmpipe renders: that pass discards every fragment and the phosphor mask stays black).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import threading
@@ -263,19 +272,109 @@ def io_measurements(e, w, h, batch, reps):
     return res
 
 
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: one fresh child process per rank (this parent has not imported torch
+    and never touches a GPU).  Rank 0's stdout (the JSON line) is relayed; any rank's failure fails the run."""
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(free_port()))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # a rank that dies must not leave the others waiting in a rendezvous or a barrier: stop everybody
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()             # the exact children this process started
+            break
+        time.sleep(0.1)
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write((out0[0] if out0 else b"").decode())
+    sys.stdout.flush()
+    if failed or any(codes):
+        raise SystemExit("bench.py: a rank failed (exit codes %s): no result" % codes)
+    return 0
+
+
+def dry_run(args):
+    """The multi-rank control flow on the CPU (gloo): shard the global batch, barrier, time, MAX over ranks, rank 0
+    prints the line.  No engine, no GPU - what tests/test_sharding_gloo.py drives."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_frames(args.batch * world, rank, world)      # weak scaling: --batch frames per rank
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    done = 0
+    for _ in range(args.steps):
+        done += len(mine)                                      # stands in for applyShaderBatch over this rank's shard
+        time.sleep(0.001 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    counts = [len(mine)]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.zeros(world, dtype=torch.int64)
+        c[rank] = len(mine)
+        dist.all_reduce(c)
+        counts = [int(v) for v in c]
+        assert dist.get_world_size() == args.gpus
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "value": aggregate(counts, args.steps, dt), "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "frames_per_rank": counts, "scaling": "weak",
+                          "data": "none (dry run: launch / shard / reduce path only)"}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (256 x 1080p = 2.1 GB in, 2.1 GB out)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per kernel launch (0 = engine default)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--io", action="store_true",
                     help="also time the ingest / egress kernels and the whole host-to-host frame path (side "
                          "measurements under \"io\"; never part of `value`)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise the launch / sharding / reduction path without a GPU (gloo, no engine): for tests")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)          # the parent never imports torch or touches a GPU
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d: launch one rank per GPU (python bench.py --gpus N, or "
+                         "torch.distributed.run --nproc-per-node N bench.py --gpus N)" % (args.gpus, world_env))
+    if args.dry_run:
+        return dry_run(args)
 
     import numpy as np
     import torch
@@ -290,6 +389,10 @@ def main():
     rehearsal = os.environ.get("RC_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
+    if not rehearsal and torch.cuda.device_count() < max(world, local + 1):
+        # one rank per GPU of ONE node: every rank sees the same count, so every rank stops here (no half-started job)
+        raise SystemExit("bench.py: rank %d of %d has no GPU of its own (%d device(s) visible): %d ranks requested, %d device(s)"
+                         % (rank, world, torch.cuda.device_count(), world, torch.cuda.device_count()))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -320,11 +423,14 @@ def main():
     # synthetic frames, resident in HBM before the timed region: uniform noise, alpha 255
     g = torch.Generator(device="cuda")
     g.manual_seed(1234 + rank)
-    frames = torch.randint(0, 256, (args.batch, h, w, 4), dtype=torch.uint8, device="cuda", generator=g)
+    # this rank's contiguous block of the global batch (weak scaling: --batch frames per rank); no frame is exchanged
+    mine = shard_frames(args.batch * world, rank, world)
+    n_local = len(mine)
+    frames = torch.randint(0, 256, (n_local, h, w, 4), dtype=torch.uint8, device="cuda", generator=g)
     frames[..., 3] = 255
 
     def step():
-        e.applyShaderBatch(frames, args.batch, w, h)
+        e.applyShaderBatch(frames, n_local, w, h)
 
     def barrier():
         if world > 1:
@@ -339,10 +445,16 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    dt = max_over_ranks(dt)
+    if world > 1:
+        assert dist.get_world_size() == args.gpus
 
     # per-kernel timing with HIP events on the launch stream, over the same steps again
     e.setProfiling(True)
@@ -360,6 +472,32 @@ def main():
     chain_bytes = sum(q["read_bytes_per_frame"] + q["write_bytes_per_frame"] for q in prof)
 
     value = aggregate([args.batch] * world, args.steps, dt)
+    # the same with pass 6's unwritten varying read as 0 (GPU GL drivers): the phosphor mask is rendered and passes 7-10
+    # carry signal everywhere.  Same steps, same barriers; its own per-pass timing.
+    mask_rendered = None
+    if key.startswith("crt-royale"):
+        e.setUndefinedVaryingZero(True)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dtm = max_over_ranks(time.perf_counter() - t0)
+        e.setProfiling(True)
+        for _ in range(args.steps):
+            step()
+        profm = [e.passProfile(i) for i in range(e.passCount())]
+        e.setProfiling(False)
+        e.setUndefinedVaryingZero(False)
+        bytes_m = sum(q["read_bytes_per_frame"] + q["write_bytes_per_frame"] for q in profm)
+        vm = aggregate([args.batch] * world, args.steps, dtm)
+        mask_rendered = {"value": vm, "unit": "frames/s", "ms_per_step": dtm / args.steps * 1e3,
+                         "algorithmic_bytes_per_frame": bytes_m,
+                         "hbm_roofline_frac_whole_chain": vm / world * bytes_m / (HBM_PEAK_GBS * 1e9),
+                         "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in profm],
+                         "note": "rc_engine_set_undefined_varying_zero(1): what GL drivers that read 0 from an unwritten varying render"}
     ceiling = copy_ceiling(torch)
     out = {
         # BASELINE.json's metric for the default workload; other --workload values are side measurements
@@ -383,6 +521,8 @@ def main():
                      "valu": pmc_valu(infos[dom]["kernel"], frames_per_launch, avg_ms)},
         "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in prof],
     }
+    if mask_rendered is not None:
+        out["mask_rendered"] = mask_rendered
     if args.io and rank == 0:
         out["io"] = io_measurements(e, w, h, args.batch, max(3, args.steps))
     if rank == 0:
@@ -395,4 +535,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

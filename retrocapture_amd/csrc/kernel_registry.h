@@ -39,7 +39,8 @@ struct KernelEntry {
   std::vector<const char*> samplers;    // extra sampler uniform names, in PassLaunch::extra order
   rck::LaunchFn launch;
   void (*setup)(const PassGeometry& g, rcd::PassLaunch& L);  // planes + derived constants
-  bool frame_invariant;                 // output does not depend on the frame
+  bool frame_invariant;                 // the shader reads nothing that changes from frame to frame (FrameCount, ...): with
+                                        // frame-invariant inputs its output is rendered once and kept (shader_engine.cpp runChunk)
   bool reads_input = true;              // false: the shader never samples its `Texture` input
   // Optional: returns an error text if the kernel cannot honour these parameter values
   const char* (*validate)(const float* params) = nullptr;

@@ -8,7 +8,7 @@
 // uv scales) is computed once per launch on the host (royale_setup.cpp) with the same float
 // operations and handed over in PassLaunch::params / planes; the kernels do the per-pixel part.
 // One thread per target pixel, 64x4 workgroups, blockIdx.z = frame.
-#include "royale_common.h"
+#include "royale_strip.h"
 
 using namespace rcd;
 using namespace rcroyale;
@@ -85,6 +85,61 @@ __global__ void __launch_bounds__(256) k_royale_first_bytemap(const PassLaunch L
   const uint32_t o = map[p & 255u] | (map[(p >> 8) & 255u] << 8) | (map[(p >> 16) & 255u] << 16) | 0xff000000u;
   *(reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z) + ((size_t)y * L.out_w + x)) = o;
   RC_TILE_LOOP_END
+}
+
+// The same at 1:1 (every target pixel's NEAREST texel is the texel under it - verified per geometry by
+// k_first_identity with the sampler's operations): the byte map itself is computed once per geometry by
+// k_first_bytemap_table, and the pass is a streaming copy through it, four pixels per thread.
+struct FirstTables {
+  uint32_t* map = nullptr;   // 256 entries
+  bool usable = false;
+};
+template <int OUT_FMT>
+__global__ void __launch_bounds__(256) k_first_bytemap_table(const PassLaunch L, uint32_t* map) {
+  RC_SRGB_LDS(lds, L);
+  const int t = (int)threadIdx.x;
+  const float lin = pow_((float)t * (1.0f / 255.0f), 2.5f);
+  map[t] = OUT_FMT == FMT_SRGB8 ? srgb8(lin, &lds) : unorm8(lin);
+}
+__global__ void __launch_bounds__(256) k_first_identity(const PassLaunch L, uint32_t* bad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool ok = true;
+  for (int side = 0; side < 2; ++side) {
+    if (i < L.out_w) ok = ok && rcstrip::near_tap(vary(L.plane[0], i, 0, side == 0), L.in.w) == i;
+    if (i < L.out_h) ok = ok && rcstrip::near_tap(vary(L.plane[1], 0, i, side == 0), L.in.h) == i;
+  }
+  if (!ok) atomicOr(bad, 1u);
+}
+__global__ void __launch_bounds__(256) k_royale_first_copy(const PassLaunch L, const uint32_t* __restrict__ gmap) {
+  __shared__ uint32_t map[256];
+  map[threadIdx.x] = gmap[threadIdx.x];
+  __syncthreads();
+  const uint32_t quads_per_frame = (uint32_t)(L.out_w * L.out_h) >> 2, total = quads_per_frame * (uint32_t)L.n_frames;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t z = i / quads_per_frame, q = i - z * quads_per_frame;
+    const uint4 p = reinterpret_cast<const uint4*>(frame_ptr(L.in, (int)z))[q];
+    auto m = [&](uint32_t t) { return map[t & 255u] | (map[(t >> 8) & 255u] << 8) | (map[(t >> 16) & 255u] << 16) | 0xff000000u; };
+    reinterpret_cast<uint4*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z)[q] = make_uint4(m(p.x), m(p.y), m(p.z), m(p.w));
+  }
+}
+void buildFirstTables(const PassLaunch& L, hipStream_t s, FirstTables* T) {
+  uint32_t* bad = nullptr;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&T->map), 1024) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&bad), 4) == hipSuccess;
+  uint32_t hbad = 1;
+  if (ok) ok = hipMemsetAsync(bad, 0, 4, s) == hipSuccess;
+  if (ok) {
+    if (L.out_fmt == FMT_SRGB8) hipLaunchKernelGGL(k_first_bytemap_table<FMT_SRGB8>, dim3(1), dim3(256), rcd::srgb_lds_bytes(L), s, L, T->map);
+    else hipLaunchKernelGGL(k_first_bytemap_table<FMT_RGBA8>, dim3(1), dim3(256), rcd::srgb_lds_bytes(L), s, L, T->map);
+    const int n = L.out_w > L.out_h ? L.out_w : L.out_h;
+    hipLaunchKernelGGL(k_first_identity, dim3((n + 255) / 256), dim3(256), 0, s, L, bad);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  }
+  if (bad) (void)hipFree(bad);
+  T->usable = ok && hbad == 0;
+  if (!T->usable && T->map) {
+    (void)hipFree(T->map);
+    T->map = nullptr;
+  }
 }
 
 // ------------------------------------------------------------------------------- P2 ------
@@ -366,6 +421,18 @@ namespace rck {
 hipError_t launch_royale_first(const PassLaunch& L, hipStream_t s) {
   const bool bytes_in = (L.in.fmt == FMT_RGBX8 || L.in.fmt == FMT_RGBA8) && !L.in.linear && L.in.wrap == WRAP_EDGE;
   if (bytes_in && L.params[RP0_INTERLACED] == 0.0f && !(L.flags & RC_FLAG_GENERAL_ONLY)) {
+    // 1:1, rows of whole 16-byte groups, 16-byte aligned frames: the streaming form
+    if ((L.out_fmt == FMT_SRGB8 || L.out_fmt == FMT_RGBA8) && L.in.w == L.out_w && L.in.h == L.out_h && ((L.out_w * L.out_h) & 3) == 0 &&
+        (L.in.frame_stride & 15u) == 0 && (reinterpret_cast<uintptr_t>(L.in.base) & 15u) == 0 && rcstrip::separable(L, 0, 1)) {
+      static std::mutex mu;
+      static std::map<rcstrip::GeoKey, FirstTables> cache;
+      if (const FirstTables* T = rcstrip::geo_tables<FirstTables>(L, s, mu, cache, buildFirstTables)) {
+        const long quads = (long)(L.out_w * L.out_h / 4) * L.n_frames;
+        const long blocks = (quads + 255) / 256;
+        hipLaunchKernelGGL(k_royale_first_copy, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, L, T->map);
+        return hipGetLastError();
+      }
+    }
     if (L.out_fmt == FMT_SRGB8) {
       hipLaunchKernelGGL(k_royale_first_bytemap<FMT_SRGB8>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
       return hipGetLastError();

@@ -413,9 +413,10 @@ size_t rc_preset_dump_json(const char* path, char* buf, size_t cap) {
   std::string out;
   try {
     rc::ShaderPreset p;
+    rc::MissingSourceScope missing(true);   // a dump is about the preset text: absent shader files are counted, not logged
     const bool ok = p.load(path);
     std::ostringstream o;
-    o << "{\"preset\":" << jstr(path) << ",\"ok\":" << (ok ? "true" : "false") << ",\"passes\":[";
+    o << "{\"preset\":" << jstr(path) << ",\"ok\":" << (ok ? "true" : "false") << ",\"missing_files\":" << missing.count() << ",\"passes\":[";
     bool first = true;
     for (const auto& s : p.getPasses()) {
       o << (first ? "" : ",") << "{\"shader\":" << jstr(s.shaderPath) << ",\"filter_linear\":" << (s.filterLinear ? "true" : "false")

@@ -20,6 +20,7 @@ LogLevel threshold() {
   return lvl;
 }
 thread_local std::string t_last_error;
+thread_local int t_missing_depth = 0, t_missing_count = 0;
 std::mutex g_io;
 }  // namespace
 
@@ -33,4 +34,21 @@ void log(LogLevel level, const std::string& msg) {
 
 const std::string& last_error() { return t_last_error; }
 void clear_last_error() { t_last_error.clear(); }
+MissingSourceScope::MissingSourceScope(bool quiet) {
+  if (quiet) {
+    if (t_missing_depth++ == 0) t_missing_count = 0;
+  } else {
+    t_missing_depth += 0x10000;  // not quiet: note_missing_source() lets the warning through
+  }
+}
+MissingSourceScope::~MissingSourceScope() {
+  if (t_missing_depth >= 0x10000) t_missing_depth -= 0x10000;
+  else --t_missing_depth;
+}
+int MissingSourceScope::count() const { return t_missing_count; }
+bool note_missing_source() {
+  if (t_missing_depth <= 0 || t_missing_depth >= 0x10000) return false;
+  ++t_missing_count;
+  return true;
+}
 }  // namespace rc

@@ -9,7 +9,16 @@ namespace rc {
 enum class LogLevel { Debug = 0, Info = 1, Warn = 2, Error = 3 };
 void log(LogLevel level, const std::string& msg);
 const std::string& last_error();
-void clear_last_error();  // the C ABI clears it on entry of calls whose status depends on it
+void clear_last_error();
+// While an engine that was told shader sources may be absent (setAllowMissingSources) loads a preset, the
+// per-file "not found" warnings are counted instead of printed; the engine prints one summary line.
+struct MissingSourceScope {
+  explicit MissingSourceScope(bool quiet);
+  ~MissingSourceScope();
+  int count() const;
+};
+// returns true if the warning was absorbed by an active scope
+bool note_missing_source();  // the C ABI clears it on entry of calls whose status depends on it
 }  // namespace rc
 
 #define RC_LOG_DEBUG(m) ::rc::log(::rc::LogLevel::Debug, (m))

@@ -287,7 +287,12 @@ void registerRoyaleKernels(std::vector<KernelEntry>& r) {
   r.push_back({id("bloom-approx.glsl"), "royale-bloom-approx", {}, {"PassPrev2Texture"}, rck::launch_royale_bloom_approx, setupBloomApprox, false});
   r.push_back({"blurs/blur9fast-vertical.glsl", "blur9fast-v", {}, {}, rck::launch_blur9, setupBlur9V, false});
   r.push_back({"blurs/blur9fast-horizontal.glsl", "blur9fast-h", {}, {}, rck::launch_blur9, setupBlur9H, false});
-  r.push_back({id("mask-resize-vertical.glsl"), "royale-mask-v", {}, {"mask_slot_texture_small"}, rck::launch_royale_mask_v, setupMaskV, true});
+  {
+    // the vertical mask resize samples the mask LUT only (its `Texture` input, pass 4's output, is never read)
+    KernelEntry e{id("mask-resize-vertical.glsl"), "royale-mask-v", {}, {"mask_slot_texture_small"}, rck::launch_royale_mask_v, setupMaskV, true};
+    e.reads_input = false;
+    r.push_back(e);
+  }
   r.push_back({id("mask-resize-horizontal.glsl"), "royale-mask-h", {}, {}, rck::launch_royale_mask_h, setupMaskH, true});
   r.push_back({id("scanlines-horizontal-apply-mask.glsl"), "royale-scanlines-h", {}, {"PassPrev6Texture", "PassPrev3Texture"},
                rck::launch_royale_scan_h, setupScanH, false});

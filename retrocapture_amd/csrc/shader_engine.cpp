@@ -174,6 +174,7 @@ bool ShaderEngine::loadPreset(const std::string& presetPath) {  // :228-319
     std::lock_guard<std::mutex> lock(m_paramMutex);
     m_customParameters.clear();
   }
+  MissingSourceScope missing(m_allowMissingSources);
   if (!m_preset.load(presetPath)) return false;
   {
     std::lock_guard<std::mutex> lock(m_paramMutex);
@@ -194,6 +195,9 @@ bool ShaderEngine::loadPreset(const std::string& presetPath) {  // :228-319
   } else {
     RC_LOG_WARN("Preset loaded but no pass is usable");
   }
+  if (missing.count() > 0)
+    RC_LOG_WARN("Preset " + presetPath + ": " + std::to_string(missing.count()) +
+                " shader file lookup(s) found no file on this machine; those passes run from the kernel registry's parameter tables");
   // As in the reference, a preset that parsed is "active" even if passes failed (:316-318).
   m_shaderActive = true;
   return true;
@@ -231,7 +235,7 @@ bool ShaderEngine::compilePass(size_t i) {
       return false;
     }
     // No shader text on this machine: take the parameter table the registry carries.
-    RC_LOG_WARN("Shader file not readable, using the built-in parameter table: " + pi.shaderPath);
+    if (!note_missing_source()) RC_LOG_WARN("Shader file not readable, using the built-in parameter table: " + pi.shaderPath);
     for (const KernelParam& kp : entry->params) {
       ShaderParameterInfo info;
       info.defaultValue = kp.def;
@@ -447,7 +451,7 @@ rcd::Tex ShaderEngine::passTexture(size_t p) const {
   const ShaderPassData& pd = m_passes[p];
   rcd::Tex t;
   t.base = pd.target.ptr;
-  t.frame_stride = pd.frameBytes;
+  t.frame_stride = pd.invariant ? 0 : pd.frameBytes;
   t.w = (int)pd.width;
   t.h = (int)pd.height;
   t.fmt = pd.format;
@@ -971,6 +975,23 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
           return false;
         }
       }
+      // Frame-invariant pass (see ShaderPassData::invariant): every texture it samples is shared by all frames
+      bool servedFromCache = false;
+      pd.invariant = false;
+      if (k.frame_invariant && !last && !pd.feedbackEnabled && !m_generalOnly) {
+        bool inv = !k.reads_input || L.in.frame_stride == 0;
+        for (size_t s2 = 0; s2 < k.samplers.size() && s2 < (size_t)rcd::kMaxExtra; ++s2) inv = inv && L.extra[s2].frame_stride == 0;
+        if (inv) {
+          pd.invariant = true;
+          L.n_frames = 1;
+          L.frame_count0 = 0;
+          std::vector<uint8_t> key(sizeof(L));
+          std::memcpy(key.data(), &L, sizeof(L));
+          servedFromCache = key == pd.invariantKey;
+          pd.invariantKey.swap(key);
+        }
+      }
+      if (!pd.invariant) pd.invariantKey.clear();
       // algorithmic read bytes per frame: distinct sampled textures, once each
       {
         const void* seen[1 + rcd::kMaxExtra];
@@ -985,7 +1006,13 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
         if (k.reads_input) add(L.in);
         for (size_t s2 = 0; s2 < k.samplers.size() && s2 < (size_t)rcd::kMaxExtra; ++s2) add(L.extra[s2]);
         if (m_passReadBytes.size() != m_passes.size()) m_passReadBytes.assign(m_passes.size(), 0);
-        m_passReadBytes[i] = rb;
+        m_passReadBytes[i] = pd.invariant ? 0 : rb;   // a pass rendered once per configuration moves no bytes per frame
+      }
+      if (servedFromCache) {
+        rcd::Tex nextCached = passTexture(i);
+        nextCached.base = target;
+        current = nextCached;
+        continue;
       }
       TimedLaunch tl{i, nFrames, nullptr, nullptr};
       if (m_profiling) {
@@ -1052,7 +1079,7 @@ bool ShaderEngine::collectProfile(std::vector<PassProfile>* out) {
 
 void ShaderEngine::passBytes(size_t i, uint64_t* readBytes, uint64_t* writeBytes) const {
   if (readBytes) *readBytes = i < m_passReadBytes.size() ? m_passReadBytes[i] : 0;
-  if (writeBytes) *writeBytes = i < m_passes.size() && m_passes[i].kernel ? m_passes[i].frameBytes : 0;
+  if (writeBytes) *writeBytes = i < m_passes.size() && m_passes[i].kernel && !m_passes[i].invariant ? m_passes[i].frameBytes : 0;
 }
 
 bool ShaderEngine::readPass(size_t i, uint32_t frame, void* host, size_t bytes) {
@@ -1062,7 +1089,9 @@ bool ShaderEngine::readPass(size_t i, uint32_t frame, void* host, size_t bytes) 
   const bool last = (i + 1 == m_passes.size());
   // intermediates hold the last chunk only; the last pass holds the whole batch
   uint64_t index = frame;
-  if (!last) {
+  if (pd.invariant) {
+    index = 0;
+  } else if (!last) {
     if (frame < m_lastChunkFirst || frame >= m_lastChunkFirst + m_lastChunkFrames) return false;
     index = frame - m_lastChunkFirst;
   }

@@ -51,6 +51,11 @@ struct ShaderPassData {  // reference ShaderEngine.h:19-40
   int feedbackLinear = 1, feedbackWrap = rcd::WRAP_EDGE;  // sampler state of the partner texture object
   DeviceBuffer lastTarget;  // last pass only, when it takes part in feedback: its own render target
   const void* lastWritten = nullptr;  // where the most recent chunk of this pass was rendered
+  // A pass whose shader and inputs do not depend on the frame (crt-royale's two mask-resize passes: LUT -> 64x68 ->
+  // 120x68) is rendered once into frame 0 of its target and sampled with frame stride 0 until anything its result
+  // depends on changes (sizes, parameters, flags, the textures bound): `invariantKey` is the launch it was rendered with.
+  bool invariant = false;
+  std::vector<uint8_t> invariantKey;
   size_t frameBytes = 0;
   std::map<std::string, float> extractedParameters;
   std::map<std::string, ShaderParameterInfo> parameterInfo;

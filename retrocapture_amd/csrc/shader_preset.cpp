@@ -267,7 +267,7 @@ std::string ShaderPreset::resolvePath(const std::string& path) const {
   candidate = (cwd / path).lexically_normal();
   if (pathExists(candidate)) return candidate.string();
   if (pathExists(root / clean)) return (root / clean).string();
-  RC_LOG_WARN("Shader not found: " + path + " (tried: " + candidate.string() + ")");
+  if (!note_missing_source()) RC_LOG_WARN("Shader not found: " + path + " (tried: " + candidate.string() + ")");
   return candidate.string();
 }
 
