@@ -363,9 +363,9 @@ __global__ void __launch_bounds__(256) k_royale_brightpass(const PassLaunch L) {
 // ------------------------------------------------------------------------------ P11 ------
 // geometry-aa-last-pass.glsl FS 5451-5531 (flat geometry path), get_border_dim_factor 5250.
 template <class SI, class SO, bool MIP>
-__global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
-  RC_SRGB_LDS(lds, L);
-  RC_TILE_LOOP_BEGIN
+__device__ __forceinline__ void last_pixel(const PassLaunch& L, const SrgbLds& lds_, int x, int y, int z, bool lo) {
+  const SrgbLds* ldsp = &lds_;
+#define lds (*ldsp)
   const float tsx = (float)L.in.w, tsy = (float)L.in.h;
   const float* P = L.params;
   const float lcd_gamma = P[1], osx = P[37], osy = P[38], border_size = P[39], border_darkness = P[40], border_compress = P[41];
@@ -407,7 +407,166 @@ __global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
   // the three output-gamma pows: red and green as a packed pair (rc_vecmath.h), blue alone
   const v2f rg = exp2_v<v2f>(log2_v(v2f{c.x * f, c.y * f}) * inv_gamma);
   SO::put(L, z, x, y, make_float4(rg.x, rg.y, pow_(c.z * f, inv_gamma), 1.0f), &lds);
+#undef lds
+}
+
+template <class SI, class SO, bool MIP>
+__global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  last_pixel<SI, SO, MIP>(L, lds, x, y, z, lo);
   RC_TILE_LOOP_END
+}
+
+// ------------------------------------------------------------------ P11, strip form ------
+// Separable geometry (royale_strip.h), flat mode: the one LINEAR tap of a pixel decomposes into a per-column pair
+// (first texel, weight) and a per-row pair; a thread walks kLastRows rows of one column, filters each source row
+// horizontally once, and evaluates two target rows per step so that their six output-gamma pows run as three
+// packed pairs (rc_vecmath.h).  The border factor is 1 away from the border (k_royale_last explains why), which
+// k_last_geometry records per column / row as "border distance is zero".
+constexpr int kLastRows = 8;
+enum { LS_X0 = 0, LS_WX = 1, LS_BX = 2, LS_COL_FIELDS = 3 };
+enum { LS_Y0 = 0, LS_WY = 1, LS_BY = 2, LS_ROW_FIELDS = 4 };
+struct LastTables {
+  uint32_t* cols = nullptr;   // [LS_COL_FIELDS][2][W]
+  uint32_t* rows = nullptr;   // [H][2][LS_ROW_FIELDS]
+  bool usable = false;
+};
+__global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint32_t* cols, uint32_t* rows, uint32_t* bad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float tsx = (float)L.in.w, tsy = (float)L.in.h;
+  const float* P = L.params;
+  const float osx = P[37], osy = P[38], border_size = P[39];
+  const float vsix = 1.0f / tsx, vsiy = 1.0f / tsy;
+  uint32_t why = 0u;
+  if (i < L.out_w)
+    for (int side = 0; side < 2; ++side) {
+      const float u = vary(L.plane[0], i, 0, side == 0);
+      const float fu = u * (tsx * vsix);
+      const float vu = (fu - 0.5f) / osx + 0.5f;
+      const rcstrip::LinTap t = rcstrip::lin_tap(vu * (tsx * vsix), L.in.w);
+      const float ex = minps(vu, 1.0f - vu) * P[RP11_ASPECT_X];
+      cols[(LS_X0 * 2 + side) * L.out_w + i] = (uint32_t)t.i0;
+      cols[(LS_WX * 2 + side) * L.out_w + i] = f2bits(t.w);
+      cols[(LS_BX * 2 + side) * L.out_w + i] = f2bits(maxps(border_size - ex, 0.0f));
+    }
+  if (i < L.out_h)
+    for (int side = 0; side < 2; ++side) {
+      const float v = vary(L.plane[1], 0, i, side == 0);
+      const float fv = v * (tsy * vsiy);
+      const float vv = (fv - 0.5f) / osy + 0.5f;
+      const rcstrip::LinTap t = rcstrip::lin_tap(vv * (tsy * vsiy), L.in.h);
+      const float ey = minps(vv, 1.0f - vv) * P[RP11_ASPECT_Y];
+      uint32_t* r = rows + ((size_t)i * 2 + side) * LS_ROW_FIELDS;
+      if (t.i0 < i - 1 || t.i0 > i) why |= 1u;   // the strip keeps rows y-1 .. y+2 of a row pair
+      r[LS_Y0] = (uint32_t)t.i0;
+      r[LS_WY] = f2bits(t.w);
+      r[LS_BY] = f2bits(maxps(border_size - ey, 0.0f));
+      r[3] = 0u;
+    }
+  if (!(border_size > 0.0f)) why |= 2u;   // border_size = 0 makes the penetration 0/0 everywhere: general form
+  if (why) atomicOr(bad, why);
+}
+
+template <class SO>
+__global__ void __launch_bounds__(256) k_royale_last_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
+  RC_SRGB_LDS(lds, L);
+  const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const rcstrip::StripGrid<kLastRows> G(L.out_w, L.out_h, L.n_frames);
+  const int W = G.W, H = G.H, Win = L.in.w, Hin = L.in.h;
+  const float* P = L.params;
+  const float inv_gamma = 1.0f / P[1], border_size = P[39], border_darkness = P[40], border_compress = P[41];
+  for (int strip = (int)blockIdx.x * 4 + wave; strip < G.total; strip += (int)gridDim.x * 4) {
+    int z, xw, ys;
+    G.locate(strip, &z, &xw, &ys);
+    const int x = xw + lane;
+    if (x >= W) continue;
+    const int xmax = min(xw + 63, W - 1), ymax = min(ys + kLastRows - 1, H - 1);
+    const bool all_lo = rcd::lower_tri(xw, ymax, W, H), all_up = !rcd::lower_tri(xmax, ys, W, H);
+    if (!all_lo && !all_up) {   // the quad's diagonal crosses this strip: per-pixel form
+      for (int y = ys; y <= ymax; ++y) last_pixel<SrgbLinEdge, SO, false>(L, lds, x, y, z, rcd::lower_tri(x, y, W, H));
+      continue;
+    }
+    const int side = all_lo ? 0 : 1;
+    const int x0 = (int)cols[(LS_X0 * 2 + side) * W + x];
+    const float wx = bits2f(cols[(LS_WX * 2 + side) * W + x]), bx = bits2f(cols[(LS_BX * 2 + side) * W + x]);
+    const int xa = clampi(x0, 0, Win - 1), xb = clampi(x0 + 1, 0, Win - 1);
+    const uint32_t* img = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
+    auto hrow = [&](int r, float* h) {   // the sampler's horizontal lerp of source row r (clamped), three channels
+      const uint32_t* p = img + clampi(r, 0, Hin - 1) * Win;
+      const uint32_t ta = p[xa], tb = p[xb];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float a = lds.dec[(ta >> (8 * ch)) & 255u], b = lds.dec[(tb >> (8 * ch)) & 255u];
+        h[ch] = fma_(wx, b - a, a);
+      }
+    };
+    float w0[3], w1[3], w2[3], w3[3];   // rows y-1, y, y+1, y+2 of the current row pair
+    hrow(ys - 1, w0);
+    hrow(ys, w1);
+#pragma unroll
+    for (int k = 0; k < kLastRows; k += 2) {
+      const int y = ys + k;
+      if (y >= H) break;
+      hrow(y + 1, w2);
+      hrow(y + 2, w3);
+      const uint32_t* ra = rows + ((size_t)y * 2 + side) * LS_ROW_FIELDS;
+      const uint32_t* rb = rows + ((size_t)min(y + 1, H - 1) * 2 + side) * LS_ROW_FIELDS;
+      const bool a_up = (int)ra[LS_Y0] == y - 1, b_up = (int)rb[LS_Y0] == y;   // the pair starts one row above the target row
+      const float wya = bits2f(ra[LS_WY]), wyb = bits2f(rb[LS_WY]), bya = bits2f(ra[LS_BY]), byb = bits2f(rb[LS_BY]);
+      float ca[3], cb[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float la = a_up ? w0[ch] : w1[ch], ha = a_up ? w1[ch] : w2[ch];
+        const float lb = b_up ? w1[ch] : w2[ch], hb = b_up ? w2[ch] : w3[ch];
+        ca[ch] = fma_(wya, ha - la, la);
+        cb[ch] = fma_(wyb, hb - lb, lb);
+      }
+      // border dimming (get_border_dim_factor, as k_royale_last): 1 unless the pixel is within border_size of an edge
+      auto dim = [&](float by) -> float {
+        float f = 1.0f;
+        if (bx != 0.0f || by != 0.0f) {
+          const float pen = __builtin_sqrtf(bx * bx + by * by) / border_size;
+          const float esc = maxps(1.0f - pen, 0.0f);
+          f = minps(pow_(esc, border_darkness) * maxps(1.0f, border_compress), 1.0f);
+        }
+        return f;
+      };
+      const float fa = dim(bya), fb = dim(byb);
+      // six output-gamma pows as three packed pairs
+      const v2f rg_a = exp2_v<v2f>(log2_v(v2f{ca[0] * fa, ca[1] * fa}) * inv_gamma);
+      const v2f rg_b = exp2_v<v2f>(log2_v(v2f{cb[0] * fb, cb[1] * fb}) * inv_gamma);
+      const v2f bb = exp2_v<v2f>(log2_v(v2f{ca[2] * fa, cb[2] * fb}) * inv_gamma);
+      SO::put(L, z, x, y, make_float4(rg_a.x, rg_a.y, bb.x, 1.0f), &lds);
+      if (y + 1 < H) SO::put(L, z, x, y + 1, make_float4(rg_b.x, rg_b.y, bb.y, 1.0f), &lds);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        w0[ch] = w2[ch];
+        w1[ch] = w3[ch];
+      }
+    }
+  }
+}
+
+void buildLastTables(const PassLaunch& L, hipStream_t s, LastTables* T) {
+  uint32_t* bad = nullptr;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&T->cols), (size_t)LS_COL_FIELDS * 2 * L.out_w * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&T->rows), (size_t)L.out_h * 2 * LS_ROW_FIELDS * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&bad), 4) == hipSuccess;
+  uint32_t hbad = 1;
+  if (ok) ok = hipMemsetAsync(bad, 0, 4, s) == hipSuccess;
+  if (ok) {
+    const int n = L.out_w > L.out_h ? L.out_w : L.out_h;
+    hipLaunchKernelGGL(k_last_geometry, dim3((n + 255) / 256), dim3(256), 0, s, L, T->cols, T->rows, bad);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  }
+  if (bad) (void)hipFree(bad);
+  T->usable = ok && hbad == 0;
+  if (!T->usable) {
+    if (T->cols) (void)hipFree(T->cols);
+    if (T->rows) (void)hipFree(T->rows);
+    *T = LastTables();
+  }
 }
 
 }  // namespace
@@ -484,7 +643,20 @@ hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
     if (SrgbLinEdge::matches(L.in) && St<FMT_RGBA8>::matches(L)) GO((k_royale_last<SrgbLinEdge, St<FMT_RGBA8>, true>));
     GO((k_royale_last<SRT, StRT, true>));
   }
-  if (SrgbLinEdge::matches(L.in) && St<FMT_RGBA8>::matches(L)) GO((k_royale_last<SrgbLinEdge, St<FMT_RGBA8>, false>));
+  if (SrgbLinEdge::matches(L.in) && St<FMT_RGBA8>::matches(L)) {
+    if (!(L.flags & RC_FLAG_GENERAL_ONLY) && rcstrip::separable(L, 0, 1)) {
+      static std::mutex mu;
+      static std::map<rcstrip::GeoKey, LastTables> cache;
+      if (const LastTables* T = rcstrip::geo_tables<LastTables>(L, s, mu, cache, buildLastTables)) {
+        const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kLastRows - 1) / kLastRows) * L.n_frames;
+        const long blocks = (strips + 3) / 4;
+        hipLaunchKernelGGL((k_royale_last_strip<St<FMT_RGBA8>>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), rcd::srgb_lds_bytes(L), s, L,
+                           T->cols, T->rows);
+        return hipGetLastError();
+      }
+    }
+    GO((k_royale_last<SrgbLinEdge, St<FMT_RGBA8>, false>));
+  }
   GO((k_royale_last<SRT, StRT, false>));
 }
 }  // namespace rck

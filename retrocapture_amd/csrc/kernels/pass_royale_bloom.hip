@@ -78,6 +78,129 @@ __global__ void __launch_bounds__(256, 4) k_royale_bloom_h(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// ------------------------------------------------------------------ P9, strip form ------
+// bloom-vertical samples its input (pass 8's target) through a NEAREST sampler: the nine taps of tex2Dblur17fast
+// are nine texels of the pixel's own column, at row offsets that are the same for every row of a geometry (the
+// taps sit 0.03 - 0.47 texel away from a texel boundary, float rounding of the coordinate is 1e-4): 0, -+(1 or 2),
+// -+(3 or 4), -+(5 or 6), -+(7 or 8), fixed by the blur's sigma.  k_bloomv_geometry verifies that with the sampler's
+// operations for every row and column of both triangles and returns the offsets; the strip kernel is instantiated
+// per offset pattern, a thread walks kBvRows rows of one column with the 16 + kBvRows decoded texels in registers.
+constexpr int kBvRows = 8;
+struct BvTables {
+  int pattern = -1;   // bit q: the q-th tap pair (k12, k34, k56, k78) sits at distance 2q + 2 instead of 2q + 1
+  bool usable = false;
+};
+__global__ void __launch_bounds__(256) k_bloomv_geometry(const PassLaunch L, int* offs, uint32_t* bad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float* P = L.params;
+  const float k[4] = {P[RPG_K78], P[RPG_K56], P[RPG_K34], P[RPG_K12]};
+  const float dy = P[RPG_DXY];
+  uint32_t why = 0u;
+  auto row_offsets = [&](int y, bool lo, int* o) {
+    const float v = vary(L.plane[1], 0, y, lo);
+    for (int q = 0; q < 4; ++q) {
+      o[q] = (int)__builtin_floorf((v - k[q] * dy) * (float)L.in.h) - y;
+      o[8 - q] = (int)__builtin_floorf((v + k[q] * dy) * (float)L.in.h) - y;
+    }
+    o[4] = (int)__builtin_floorf(v * (float)L.in.h) - y;
+  };
+  int ref[9];
+  row_offsets(L.out_h / 2, true, ref);
+  if (i == 0)
+    for (int q = 0; q < 9; ++q) offs[q] = ref[q];
+  if (i < L.out_h)
+    for (int side = 0; side < 2; ++side) {
+      int o[9];
+      row_offsets(i, side == 0, o);
+      for (int q = 0; q < 9; ++q)
+        if (o[q] != ref[q]) why |= 1u;
+    }
+  if (i < L.out_w)
+    for (int side = 0; side < 2; ++side) {
+      const float u = vary(L.plane[0], i, 0, side == 0);
+      // every tap: u -+ k * 0 = u
+      if ((int)__builtin_floorf((u - k[0] * 0.0f) * (float)L.in.w) != i) why |= 2u;
+    }
+  if (why) atomicOr(bad, why);
+}
+
+template <class SO, int PATTERN>
+__global__ void __launch_bounds__(256) k_royale_bloom_v_strip(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  constexpr int o12 = 1 + ((PATTERN >> 0) & 1), o34 = 3 + ((PATTERN >> 1) & 1), o56 = 5 + ((PATTERN >> 2) & 1), o78 = 7 + ((PATTERN >> 3) & 1);
+  const float* P = L.params;
+  const float w78 = P[RPG_W78], w56 = P[RPG_W56], w34 = P[RPG_W34], w12 = P[RPG_W12], si = P[RPG_SUM_INV];
+  const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const StripGrid<kBvRows> G(L.out_w, L.out_h, L.n_frames);
+  const int W = G.W, H = G.H, Hin = L.in.h;
+  for (int strip = (int)blockIdx.x * 4 + wave; strip < G.total; strip += (int)gridDim.x * 4) {
+    int z, xw, ys;
+    G.locate(strip, &z, &xw, &ys);
+    const int x = xw + lane;
+    if (x >= W) continue;
+    const uint32_t* img = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
+    float win[kBvRows + 16][3];
+#pragma unroll
+    for (int j = 0; j < kBvRows + 16; ++j) {
+      const uint32_t t = img[clampi(ys - 8 + j, 0, Hin - 1) * L.in.w + x];
+      win[j][0] = lds.dec[t & 255u];
+      win[j][1] = lds.dec[(t >> 8) & 255u];
+      win[j][2] = lds.dec[(t >> 16) & 255u];
+    }
+#pragma unroll
+    for (int k = 0; k < kBvRows; ++k) {
+      const int y = ys + k;
+      if (y >= H) break;
+      float out[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        // tex2Dblur17fast in the GL's evaluation order (blur17 above)
+        float s = w78 * win[k + 8 - o78][ch];
+        s += w56 * win[k + 8 - o56][ch];
+        s += w34 * win[k + 8 - o34][ch];
+        s += 1.0f * win[k + 8][ch];
+        s += w12 * win[k + 8 - o12][ch];
+        s += w12 * win[k + 8 + o12][ch];
+        s += w34 * win[k + 8 + o34][ch];
+        s += w56 * win[k + 8 + o56][ch];
+        s += w78 * win[k + 8 + o78][ch];
+        out[ch] = s * si;
+      }
+      SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
+    }
+  }
+}
+
+void buildBvTables(const PassLaunch& L, hipStream_t s, BvTables* T) {
+  int* offs = nullptr;
+  uint32_t* bad = nullptr;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&offs), 9 * sizeof(int)) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&bad), 4) == hipSuccess;
+  uint32_t hbad = 1;
+  int ho[9] = {0};
+  if (ok) ok = hipMemsetAsync(bad, 0, 4, s) == hipSuccess;
+  if (ok) {
+    const int n = L.out_w > L.out_h ? L.out_w : L.out_h;
+    hipLaunchKernelGGL(k_bloomv_geometry, dim3((n + 255) / 256), dim3(256), 0, s, L, offs, bad);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+         hipMemcpyAsync(ho, offs, sizeof(ho), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  }
+  if (offs) (void)hipFree(offs);
+  if (bad) (void)hipFree(bad);
+  int pattern = 0;
+  if (ok && hbad == 0 && ho[4] == 0) {
+    for (int q = 0; q < 4; ++q) {   // ho[3 - q] / ho[5 + q]: the pair at nominal distance 2q + 1
+      const int d = ho[5 + q];
+      if (ho[3 - q] != -d || (d != 2 * q + 1 && d != 2 * q + 2)) ok = false;
+      if (d == 2 * q + 2) pattern |= 1 << q;
+    }
+  } else {
+    ok = false;
+  }
+  T->usable = ok;
+  T->pattern = ok ? pattern : -1;
+  if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc bloom-v] %dx%d: ok %d flags %u pattern %d\n", L.out_w, L.out_h, (int)ok, hbad, T->pattern);
+}
+
 // ----------------------------------------------------------------- P10, strip form ------
 // One wave renders 64 columns x kBhRows rows.  The nine blur taps of a pixel read a row of the input texture
 // (pass 9's sRGB8 target) through a LINEAR sampler at horizontal offsets of up to 7.x texels: the wave decodes each
@@ -357,8 +480,30 @@ namespace rck {
   } while (0)
 using OutS = St<FMT_SRGB8>;
 
+template <int PATTERN>
+hipError_t launch_bloom_v_strip(const PassLaunch& L, hipStream_t s) {
+  const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kBvRows - 1) / kBvRows) * L.n_frames;
+  const long blocks = (strips + 3) / 4;
+  hipLaunchKernelGGL((k_royale_bloom_v_strip<OutS, PATTERN>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), rcd::srgb_lds_bytes(L), s, L);
+  return hipGetLastError();
+}
 hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s) {
-  if (SrgbNearEdge::matches(L.in) && OutS::matches(L)) GO(k_royale_bloom_v<SrgbNearEdge, OutS>);
+  if (SrgbNearEdge::matches(L.in) && OutS::matches(L)) {
+    if (!(L.flags & RC_FLAG_GENERAL_ONLY) && separable(L, 0, 1) && L.in.w == L.out_w) {
+      static std::mutex mu;
+      static std::map<GeoKey, BvTables> cache;
+      if (const BvTables* T = geo_tables<BvTables>(L, s, mu, cache, buildBvTables)) {
+        switch (T->pattern) {
+#define RC_BV(p) case p: return launch_bloom_v_strip<p>(L, s);
+          RC_BV(0) RC_BV(1) RC_BV(2) RC_BV(3) RC_BV(4) RC_BV(5) RC_BV(6) RC_BV(7)
+          RC_BV(8) RC_BV(9) RC_BV(10) RC_BV(11) RC_BV(12) RC_BV(13) RC_BV(14) RC_BV(15)
+#undef RC_BV
+          default: break;
+        }
+      }
+    }
+    GO(k_royale_bloom_v<SrgbNearEdge, OutS>);
+  }
   GO(k_royale_bloom_v<SRT, StRT>);
 }
 hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
