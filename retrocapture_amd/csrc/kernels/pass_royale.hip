@@ -8,6 +8,9 @@
 // uv scales) is computed once per launch on the host (royale_setup.cpp) with the same float
 // operations and handed over in PassLaunch::params / planes; the kernels do the per-pixel part.
 // One thread per target pixel, 64x4 workgroups, blockIdx.z = frame.
+#include <cstdio>
+#include <cstdlib>
+
 #include "royale_strip.h"
 
 using namespace rcd;
@@ -297,9 +300,9 @@ __device__ __forceinline__ float fake_bloom_tail(float scan, float mask, float s
 
 // FAKE: extra = PassPrev6 (VERTICAL_SCANLINES), PassPrev5 (BLOOM_APPROX), PassPrev3 (HALATION_BLUR)
 template <class SI, class S0, class SO, bool FAKE>
-__global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
-  RC_SRGB_LDS(lds, L);
-  RC_TILE_LOOP_BEGIN
+__device__ __forceinline__ void scan_h_pixel(const PassLaunch& L, const SrgbLds& lds_, int x, int y, int z, bool lo) {
+  const SrgbLds* ldsp = &lds_;
+#define lds (*ldsp)
   const float vu = vary(L.plane[0], x, y, lo), vv = vary(L.plane[1], x, y, lo);
   const float twx = vu * L.params[RP7_TPS_X], twy = vv * L.params[RP7_TPS_Y];
   const float tux = fractf(twx * 0.5f) * 2.0f, tuy = fractf(twy * 0.5f) * 2.0f;
@@ -325,15 +328,202 @@ __global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
     }
   }
   SO::put(L, z, x, y, o, &lds);
+#undef lds
+}
+
+template <class SI, class S0, class SO, bool FAKE>
+__global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  scan_h_pixel<SI, S0, SO, FAKE>(L, lds, x, y, z, lo);
   RC_TILE_LOOP_END
+}
+
+// ------------------------------------------------------------------- P7, strip form ------
+// Separable geometry (royale_strip.h).  The six scanline taps of a pixel (two per channel, at the channel's
+// convergence offset) are LINEAR taps of pass 1's target at texel centres: the first reads texels (x-1, x), the
+// second (x, x+1) - verified per geometry - with per-column weights and per-column Quilez factors; vertically they
+// share one row pair.  A thread walks kShRows rows of one column and filters each source row horizontally once
+// (six values); rows whose mask texels are all zero in a wave (every row on a GL that discards pass 6's fragments)
+// skip the scanline work like the general kernel does per pixel.
+constexpr int kShRows = 8;
+enum { SH_WXA = 0, SH_WXB = 3, SH_FY = 6, SH_FZ = 9, SH_MX = 12, SH_COL_FIELDS = 13 };
+enum { SH_Y0 = 0, SH_WY = 1, SH_MY = 2, SH_ROW_FIELDS = 4 };
+struct ScanHTables {
+  uint32_t* cols = nullptr;   // [SH_COL_FIELDS][2][W]
+  uint32_t* rows = nullptr;   // [H][2][SH_ROW_FIELDS]
+  bool usable = false;
+};
+__global__ void __launch_bounds__(256) k_scanh_geometry(const PassLaunch L, uint32_t* cols, uint32_t* rows, uint32_t* bad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float* P = L.params;
+  const float tsx = P[RP7_SCAN_TW], tsy = P[RP7_SCAN_TH], tix = P[RP7_SCAN_TIX], tiy = P[RP7_SCAN_TIY];
+  const Tex& scan = L.extra[0];
+  uint32_t why = 0u;
+  if (i < L.out_w)
+    for (int side = 0; side < 2; ++side) {
+      const bool lo = side == 0;
+      const float su = vary(L.plane[2], i, 0, lo);
+      const float conv_x[3] = {0.1f, 0.3f, 0.5f};
+      for (int ch = 0; ch < 3; ++ch) {   // scanline_h_1ch's horizontal part
+        const float u = su - conv_x[ch] * tix;
+        const float ctx = u * tsx;
+        const float phx = __builtin_floorf(ctx - kUnderHalf) + 0.5f;
+        const float puv_x = phx * tix;
+        const float xd = ctx - phx;
+        const float w2 = xd * xd * xd * (xd * (xd * 6.0f - 15.0f) + 10.0f);
+        const float wy = 1.0f - w2, wz = w2;
+        const float dot = ((0.0f * 1.0f + wy * 1.0f) + wz * 1.0f) + 0.0f * 1.0f;
+        const float fx = 0.0f / dot, fy = wy / dot, fz = wz / dot, fw = 0.0f / dot;
+        const rcstrip::LinTap ta = rcstrip::lin_tap(puv_x, scan.w), tb = rcstrip::lin_tap(puv_x + tix, scan.w);
+        if (ta.i0 != i - 1 || tb.i0 != i) why |= 1u;
+        if (!(fx == 0.0f && fw == 0.0f)) why |= 2u;
+        cols[((SH_WXA + ch) * 2 + side) * L.out_w + i] = f2bits(ta.w);
+        cols[((SH_WXB + ch) * 2 + side) * L.out_w + i] = f2bits(tb.w);
+        cols[((SH_FY + ch) * 2 + side) * L.out_w + i] = f2bits(fy);
+        cols[((SH_FZ + ch) * 2 + side) * L.out_w + i] = f2bits(fz);
+      }
+      const float vu = vary(L.plane[0], i, 0, lo);
+      const float tux = fractf(vu * P[RP7_TPS_X] * 0.5f) * 2.0f;
+      cols[(SH_MX * 2 + side) * L.out_w + i] = (uint32_t)rcstrip::near_tap(P[RP7_START_X] + tux * P[RP7_UVS_X], L.in.w);
+    }
+  if (i < L.out_h)
+    for (int side = 0; side < 2; ++side) {
+      const bool lo = side == 0;
+      uint32_t* r = rows + ((size_t)i * 2 + side) * SH_ROW_FIELDS;
+      const float sv = vary(L.plane[3], 0, i, lo) - 0.0f;
+      const float puv_y = (sv * tsy) * tiy;
+      const rcstrip::LinTap t = rcstrip::lin_tap(puv_y + 0.0f, scan.h);
+      if (t.i0 < i - 1 || t.i0 > i || rcstrip::lin_tap(puv_y, scan.h).i0 != t.i0) why |= 4u;
+      r[SH_Y0] = (uint32_t)t.i0;
+      r[SH_WY] = f2bits(t.w);
+      const float vv = vary(L.plane[1], 0, i, lo);
+      const float tuy = fractf(vv * P[RP7_TPS_Y] * 0.5f) * 2.0f;
+      r[SH_MY] = (uint32_t)rcstrip::near_tap(P[RP7_START_Y] + tuy * P[RP7_UVS_Y], L.in.h);
+      r[3] = 0u;
+    }
+  if (scan.w != L.out_w || scan.h != L.out_h) why |= 8u;
+  if (why) atomicOr(bad, why);
+}
+
+template <class SO>
+__global__ void __launch_bounds__(256) k_royale_scan_h_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
+  RC_SRGB_LDS(lds, L);
+  using MaskS = S<FMT_RGBA8, 0, WRAP_EDGE>;
+  const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const rcstrip::StripGrid<kShRows> G(L.out_w, L.out_h, L.n_frames);
+  const int W = G.W, H = G.H;
+  const Tex& scan = L.extra[0];
+  for (int strip = (int)blockIdx.x * 4 + wave; strip < G.total; strip += (int)gridDim.x * 4) {
+    int z, xw, ys;
+    G.locate(strip, &z, &xw, &ys);
+    const int x = xw + lane;
+    const bool live = x < W;
+    const int xc = live ? x : W - 1;
+    const int xmax = min(xw + 63, W - 1), ymax = min(ys + kShRows - 1, H - 1);
+    const bool all_lo = rcd::lower_tri(xw, ymax, W, H), all_up = !rcd::lower_tri(xmax, ys, W, H);
+    if (!all_lo && !all_up) {   // the quad's diagonal crosses this strip: per-pixel form
+      if (live)
+        for (int y = ys; y <= ymax; ++y) scan_h_pixel<MaskS, SrgbLinEdge, SO, false>(L, lds, x, y, z, rcd::lower_tri(x, y, W, H));
+      continue;
+    }
+    const int side = all_lo ? 0 : 1;
+    float wxa[3], wxb[3], fy[3], fz[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      wxa[ch] = bits2f(cols[((SH_WXA + ch) * 2 + side) * W + xc]);
+      wxb[ch] = bits2f(cols[((SH_WXB + ch) * 2 + side) * W + xc]);
+      fy[ch] = bits2f(cols[((SH_FY + ch) * 2 + side) * W + xc]);
+      fz[ch] = bits2f(cols[((SH_FZ + ch) * 2 + side) * W + xc]);
+    }
+    const int mx = (int)cols[(SH_MX * 2 + side) * W + xc];
+    const uint32_t* mimg = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
+    const uint32_t* simg = reinterpret_cast<const uint32_t*>(frame_ptr(scan, z));
+    const int xl = clampi(xc - 1, 0, scan.w - 1), xm = clampi(xc, 0, scan.w - 1), xr = clampi(xc + 1, 0, scan.w - 1);
+    // horizontally filtered source rows: ha = tap 1 (texels x-1, x), hb = tap 2 (texels x, x+1), per channel
+    auto hrow = [&](int r, float* ha, float* hb) {
+      const uint32_t* p = simg + clampi(r, 0, scan.h - 1) * scan.w;
+      const uint32_t tl = p[xl], tm = p[xm], tr = p[xr];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float dl = lds.dec[(tl >> (8 * ch)) & 255u], dm = lds.dec[(tm >> (8 * ch)) & 255u], dr = lds.dec[(tr >> (8 * ch)) & 255u];
+        ha[ch] = fma_(wxa[ch], dm - dl, dl);
+        hb[ch] = fma_(wxb[ch], dr - dm, dm);
+      }
+    };
+    float a0[3], b0[3], a1[3], b1[3];   // the row pair in use: source rows `have` and `have + 1`
+    int have = -1000;
+#pragma unroll 1
+    for (int k = 0; k < kShRows; ++k) {
+      const int y = ys + k;
+      if (y >= H) break;
+      const uint32_t* rr = rows + ((size_t)y * 2 + side) * SH_ROW_FIELDS;
+      const int y0 = (int)rr[SH_Y0], my = (int)rr[SH_MY];
+      const float wy = bits2f(rr[SH_WY]);
+      const uint32_t mt = mimg[my * L.in.w + mx];
+      const bool any = (mt & 0x00ffffffu) != 0u;
+      uint32_t px = 0xff000000u;   // scan * 0 (or NaN): stored as 0, alpha 1
+      if (__builtin_amdgcn_ballot_w64(any) != 0ull) {   // wave-uniform
+        if (y0 != have) {
+          if (y0 == have + 1) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+              a0[ch] = a1[ch];
+              b0[ch] = b1[ch];
+            }
+          } else {
+            hrow(y0, a0, b0);
+          }
+          hrow(y0 + 1, a1, b1);
+          have = y0;
+        }
+        if (live && any) {
+          const float k255 = 1.0f / 255.0f;
+          const float mask[3] = {(float)(mt & 255u) * k255, (float)((mt >> 8) & 255u) * k255, (float)((mt >> 16) & 255u) * k255};
+          float o[3];
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const float c1 = fma_(wy, a1[ch] - a0[ch], a0[ch]), c2 = fma_(wy, b1[ch] - b0[ch], b0[ch]);
+            const float m = c1 * fy[ch] + c2 * fz[ch];   // ((0*fx + a1*fy) + a2*fz) + 0*fw with fx = fw = 0
+            o[ch] = maxps(m, 0.0f) * mask[ch];
+          }
+          SO::put(L, z, x, y, make_float4(o[0], o[1], o[2], 1.0f), &lds);
+          continue;
+        }
+      }
+      if (live) reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z)[(size_t)y * W + x] = px;
+    }
+  }
+}
+
+void buildScanHTables(const PassLaunch& L, hipStream_t s, ScanHTables* T) {
+  uint32_t* bad = nullptr;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&T->cols), (size_t)SH_COL_FIELDS * 2 * L.out_w * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&T->rows), (size_t)L.out_h * 2 * SH_ROW_FIELDS * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&bad), 4) == hipSuccess;
+  uint32_t hbad = 1;
+  if (ok) ok = hipMemsetAsync(bad, 0, 4, s) == hipSuccess;
+  if (ok) {
+    const int n = L.out_w > L.out_h ? L.out_w : L.out_h;
+    hipLaunchKernelGGL(k_scanh_geometry, dim3((n + 255) / 256), dim3(256), 0, s, L, T->cols, T->rows, bad);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  }
+  if (bad) (void)hipFree(bad);
+  T->usable = ok && hbad == 0;
+  if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc scan-h] %dx%d: ok %d flags %u\n", L.out_w, L.out_h, (int)ok, hbad);
+  if (!T->usable) {
+    if (T->cols) (void)hipFree(T->cols);
+    if (T->rows) (void)hipFree(T->rows);
+    *T = ScanHTables();
+  }
 }
 
 // ------------------------------------------------------------------------------- P8 ------
 // brightpass.glsl FS 14610-14663; extra[0] = PassPrev4Texture.
 template <class SI, class S0, class SO>
-__global__ void __launch_bounds__(256) k_royale_brightpass(const PassLaunch L) {
-  RC_SRGB_LDS(lds, L);
-  RC_TILE_LOOP_BEGIN
+__device__ __forceinline__ void brightpass_pixel(const PassLaunch& L, const SrgbLds& lds_, int x, int y, int z, bool lo) {
+  const SrgbLds* ldsp = &lds_;
+#define lds (*ldsp)
   const float4 idim = SI::get(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
   float4 o = make_float4(0.f, 0.f, 0.f, 1.0f);
   // brightpass = intensity_dim * ratio: a zero (or NaN-producing) input stores 0 whatever the ratio
@@ -357,7 +547,149 @@ __global__ void __launch_bounds__(256) k_royale_brightpass(const PassLaunch L) {
     o = make_float4(out[0], out[1], out[2], 1.0f);
   }
   SO::put(L, z, x, y, o, &lds);
+#undef lds
+}
+
+template <class SI, class S0, class SO>
+__global__ void __launch_bounds__(256) k_royale_brightpass(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  brightpass_pixel<SI, S0, SO>(L, lds, x, y, z, lo);
   RC_TILE_LOOP_END
+}
+
+// the per-channel arithmetic of brightpass.glsl, as in brightpass_pixel
+__device__ __forceinline__ float brightpass_channel(float in, float bl, float cw, float mask_amplify) {
+  const float intensity = in * 2.0f * mask_amplify * 1.0f;
+  const float pba = 1.0f * bl;
+  const float max_area = maxps(pba - cw * intensity, 0.0f);
+  const float area_under = 0.8f * max_area;
+  const float int_under = in * ((2.0f * mask_amplify) * 0.8f);
+  const float ratio_temp = ((1.0f - area_under) / int_under - 1.0f) / (cw - 1.0f);
+  return in * clampf(ratio_temp, 0.0f, 1.0f);
+}
+
+// ------------------------------------------------------------------- P8, strip form ------
+// Separable geometry (royale_strip.h): the NEAREST tap of pass 7's target is the texel (ix(x), iy(y)); the LINEAR tap
+// of the 320x240 halation blur is magnified, so a thread walking a column keeps the two horizontally filtered blur
+// rows of the current row pair and refilters only when the pair moves on (every fourth target row or so).
+constexpr int kBpRows = 8;
+enum { BP_IX = 0, BP_BX0 = 1, BP_BWX = 2, BP_COL_FIELDS = 3 };
+enum { BP_IY = 0, BP_BY0 = 1, BP_BWY = 2, BP_ROW_FIELDS = 4 };
+struct BpTables {
+  uint32_t* cols = nullptr;
+  uint32_t* rows = nullptr;
+  bool usable = false;
+};
+__global__ void __launch_bounds__(256) k_brightpass_geometry(const PassLaunch L, uint32_t* cols, uint32_t* rows) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < L.out_w)
+    for (int side = 0; side < 2; ++side) {
+      const rcstrip::LinTap t = rcstrip::lin_tap(vary(L.plane[2], i, 0, side == 0), L.extra[0].w);
+      cols[(BP_IX * 2 + side) * L.out_w + i] = (uint32_t)rcstrip::near_tap(vary(L.plane[0], i, 0, side == 0), L.in.w);
+      cols[(BP_BX0 * 2 + side) * L.out_w + i] = (uint32_t)t.i0;
+      cols[(BP_BWX * 2 + side) * L.out_w + i] = f2bits(t.w);
+    }
+  if (i < L.out_h)
+    for (int side = 0; side < 2; ++side) {
+      uint32_t* r = rows + ((size_t)i * 2 + side) * BP_ROW_FIELDS;
+      const rcstrip::LinTap t = rcstrip::lin_tap(vary(L.plane[3], 0, i, side == 0), L.extra[0].h);
+      r[BP_IY] = (uint32_t)rcstrip::near_tap(vary(L.plane[1], 0, i, side == 0), L.in.h);
+      r[BP_BY0] = (uint32_t)t.i0;
+      r[BP_BWY] = f2bits(t.w);
+      r[3] = 0u;
+    }
+}
+
+template <class SO>
+__global__ void __launch_bounds__(256) k_royale_brightpass_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
+  RC_SRGB_LDS(lds, L);
+  const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const rcstrip::StripGrid<kBpRows> G(L.out_w, L.out_h, L.n_frames);
+  const int W = G.W, H = G.H;
+  const Tex& blur = L.extra[0];
+  const float cw = L.params[RP8_CENTER_WEIGHT], mask_amplify = L.params[RP8_MASK_AMPLIFY];
+  for (int strip = (int)blockIdx.x * 4 + wave; strip < G.total; strip += (int)gridDim.x * 4) {
+    int z, xw, ys;
+    G.locate(strip, &z, &xw, &ys);
+    const int x = xw + lane;
+    const bool live = x < W;
+    const int xc = live ? x : W - 1;
+    const int xmax = min(xw + 63, W - 1), ymax = min(ys + kBpRows - 1, H - 1);
+    const bool all_lo = rcd::lower_tri(xw, ymax, W, H), all_up = !rcd::lower_tri(xmax, ys, W, H);
+    if (!all_lo && !all_up) {   // the quad's diagonal crosses this strip: per-pixel form
+      if (live)
+        for (int y = ys; y <= ymax; ++y) brightpass_pixel<SrgbNearEdge, SrgbLinEdge, SO>(L, lds, x, y, z, rcd::lower_tri(x, y, W, H));
+      continue;
+    }
+    const int side = all_lo ? 0 : 1;
+    const int ix = (int)cols[(BP_IX * 2 + side) * W + xc], bx0 = (int)cols[(BP_BX0 * 2 + side) * W + xc];
+    const float bwx = bits2f(cols[(BP_BWX * 2 + side) * W + xc]);
+    const int bxa = clampi(bx0, 0, blur.w - 1), bxb = clampi(bx0 + 1, 0, blur.w - 1);
+    const uint32_t* iimg = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
+    const uint32_t* bimg = reinterpret_cast<const uint32_t*>(frame_ptr(blur, z));
+    auto hrow = [&](int r, float* h) {
+      const uint32_t* p = bimg + clampi(r, 0, blur.h - 1) * blur.w;
+      const uint32_t ta = p[bxa], tb = p[bxb];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float a = lds.dec[(ta >> (8 * ch)) & 255u], b = lds.dec[(tb >> (8 * ch)) & 255u];
+        h[ch] = fma_(bwx, b - a, a);
+      }
+    };
+    float h0[3], h1[3];
+    int have = -1000;
+#pragma unroll 1
+    for (int k = 0; k < kBpRows; ++k) {
+      const int y = ys + k;
+      if (y >= H) break;
+      const uint32_t* rr = rows + ((size_t)y * 2 + side) * BP_ROW_FIELDS;
+      const int iy = (int)rr[BP_IY], by0 = (int)rr[BP_BY0];
+      const float bwy = bits2f(rr[BP_BWY]);
+      const uint32_t it = iimg[iy * L.in.w + ix];
+      const bool any = (it & 0x00ffffffu) != 0u;   // decode(0) = 0: a zero input stores 0 whatever the ratio
+      if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+        if (by0 != have) {
+          if (by0 == have + 1) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) h0[ch] = h1[ch];
+          } else {
+            hrow(by0, h0);
+          }
+          hrow(by0 + 1, h1);
+          have = by0;
+        }
+        if (live && any) {
+          float o[3];
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const float in = lds.dec[(it >> (8 * ch)) & 255u];
+            const float bl = fma_(bwy, h1[ch] - h0[ch], h0[ch]);
+            o[ch] = brightpass_channel(in, bl, cw, mask_amplify);
+          }
+          SO::put(L, z, x, y, make_float4(o[0], o[1], o[2], 1.0f), &lds);
+          continue;
+        }
+      }
+      if (live) reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z)[(size_t)y * W + x] = 0xff000000u;
+    }
+  }
+}
+
+void buildBpTables(const PassLaunch& L, hipStream_t s, BpTables* T) {
+  bool ok = hipMalloc(reinterpret_cast<void**>(&T->cols), (size_t)BP_COL_FIELDS * 2 * L.out_w * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&T->rows), (size_t)L.out_h * 2 * BP_ROW_FIELDS * 4) == hipSuccess;
+  if (ok) {
+    const int n = L.out_w > L.out_h ? L.out_w : L.out_h;
+    hipLaunchKernelGGL(k_brightpass_geometry, dim3((n + 255) / 256), dim3(256), 0, s, L, T->cols, T->rows);
+    ok = hipGetLastError() == hipSuccess;
+  }
+  T->usable = ok;
+  if (!ok) {
+    if (T->cols) (void)hipFree(T->cols);
+    if (T->rows) (void)hipFree(T->rows);
+    *T = BpTables();
+  }
 }
 
 // ------------------------------------------------------------------------------ P11 ------
@@ -624,7 +956,20 @@ hipError_t launch_blur9(const PassLaunch& L, hipStream_t s) {
 }
 hipError_t launch_royale_scan_h(const PassLaunch& L, hipStream_t s) {
   using MaskS = S<FMT_RGBA8, 0, WRAP_EDGE>;
-  if (MaskS::matches(L.in) && SrgbLinEdge::matches(L.extra[0]) && OutS::matches(L)) GO((k_royale_scan_h<MaskS, SrgbLinEdge, OutS, false>));
+  if (MaskS::matches(L.in) && SrgbLinEdge::matches(L.extra[0]) && OutS::matches(L)) {
+    if (!(L.flags & RC_FLAG_GENERAL_ONLY) && rcstrip::separable(L, 0, 2)) {
+      static std::mutex mu;
+      static std::map<rcstrip::GeoKey, ScanHTables> cache;
+      if (const ScanHTables* T = rcstrip::geo_tables<ScanHTables>(L, s, mu, cache, buildScanHTables)) {
+        const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kShRows - 1) / kShRows) * L.n_frames;
+        const long blocks = (strips + 3) / 4;
+        hipLaunchKernelGGL((k_royale_scan_h_strip<OutS>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), rcd::srgb_lds_bytes(L), s, L, T->cols,
+                           T->rows);
+        return hipGetLastError();
+      }
+    }
+    GO((k_royale_scan_h<MaskS, SrgbLinEdge, OutS, false>));
+  }
   GO((k_royale_scan_h<SRT, SRT, StRT, false>));
 }
 hipError_t launch_royale_scan_h_fake(const PassLaunch& L, hipStream_t s) {
@@ -635,7 +980,20 @@ hipError_t launch_royale_scan_h_fake(const PassLaunch& L, hipStream_t s) {
   GO((k_royale_scan_h<SRT, SRT, StRT, true>));
 }
 hipError_t launch_royale_brightpass(const PassLaunch& L, hipStream_t s) {
-  if (SrgbNearEdge::matches(L.in) && SrgbLinEdge::matches(L.extra[0]) && OutS::matches(L)) GO(k_royale_brightpass<SrgbNearEdge, SrgbLinEdge, OutS>);
+  if (SrgbNearEdge::matches(L.in) && SrgbLinEdge::matches(L.extra[0]) && OutS::matches(L)) {
+    if (!(L.flags & RC_FLAG_GENERAL_ONLY) && rcstrip::separable(L, 0, 2)) {
+      static std::mutex mu;
+      static std::map<rcstrip::GeoKey, BpTables> cache;
+      if (const BpTables* T = rcstrip::geo_tables<BpTables>(L, s, mu, cache, buildBpTables)) {
+        const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kBpRows - 1) / kBpRows) * L.n_frames;
+        const long blocks = (strips + 3) / 4;
+        hipLaunchKernelGGL((k_royale_brightpass_strip<OutS>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), rcd::srgb_lds_bytes(L), s, L,
+                           T->cols, T->rows);
+        return hipGetLastError();
+      }
+    }
+    GO(k_royale_brightpass<SrgbNearEdge, SrgbLinEdge, OutS>);
+  }
   GO(k_royale_brightpass<SRT, SRT, StRT>);
 }
 hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
