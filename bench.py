@@ -235,6 +235,8 @@ def io_measurements(e, w, h, batch, reps):
     def piped():
         for fr in h_frames:
             while not pipe.submit(fr, "rgb24", w, h):
+                if pipe.inFlight() == 0:      # not a full ring: a real failure (rc_last_error has the text)
+                    raise SystemExit("rc_pipeline_submit failed with nothing in flight")
                 pipe.receive(wait=True)
         while pipe.inFlight():
             pipe.receive(wait=True)
@@ -249,6 +251,8 @@ def io_measurements(e, w, h, batch, reps):
         for _k in range(n):
             buf = pipe.inputBuffer("rgb24", w, h)
             while buf is None:
+                if pipe.inFlight() == 0:
+                    raise SystemExit("rc_pipeline_input_buffer failed with nothing in flight")
                 pipe.receive(wait=True)
                 buf = pipe.inputBuffer("rgb24", w, h)
             pipe.submit(buf, "rgb24", w, h)

@@ -212,11 +212,15 @@ void rc_overscan_viewport(uint32_t fbo_w, uint32_t fbo_h, float pct_x, float pct
  * The reference's per-frame path between a capture buffer and the encoder's RGB24 buffer:
  * FrameProcessor upload (FrameProcessor.cpp:43-222) -> applyShader -> readback through double-
  * buffered PBOs (PBOManager.cpp:86-170, FrameCapturePipeline.cpp:974-1084).  Here: a ring of `slots`
- * (1..8) on three HIP streams (copy in / engine stream / copy out) linked by events, so the PCIe
+ * (2..8) on three HIP streams (copy in / engine stream / copy out) linked by events, so the PCIe
  * copies of neighbouring frames overlap the kernels.  submit() copies the caller's (unpinned) frame
  * into pinned staging and queues H2D + rc_ingest + chain + rc_egress_rgb24 + D2H; receive() hands out
- * the oldest finished frame (RGB24, row 0 first) in pipeline-owned pinned memory, valid until that
- * slot is reused.  Frames return in submission order. */
+ * the oldest finished frame (RGB24, row 0 first) in pipeline-owned pinned memory.  Ownership rule: a
+ * received frame is the caller's until the NEXT rc_pipeline_receive (or rc_pipeline_destroy); its slot
+ * is not reused before that, so N slots carry at most N - 1 frames in flight besides the one the caller
+ * holds.  Frames return in submission order.  Lifetime: a pipeline may outlive its engine - when the
+ * engine is destroyed (or shut down) the pipeline drains its streams and every later submit / receive /
+ * input_buffer call fails; destroy the pipeline afterwards as usual. */
 typedef struct rc_pipeline rc_pipeline;
 rc_pipeline* rc_pipeline_create(rc_engine* e, int slots);
 void rc_pipeline_destroy(rc_pipeline* p);

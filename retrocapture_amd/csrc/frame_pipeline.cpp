@@ -26,7 +26,8 @@ size_t frameBytes(int pixfmt, uint32_t w, uint32_t h) {
 }  // namespace
 
 FramePipeline::FramePipeline(ShaderEngine* engine, int slots) : m_engine(engine) {
-  if (!engine || slots < 1) return;
+  if (!engine) return;
+  if (slots < 2) slots = 2;   // one slot can be held by the caller (see receive)
   if (slots > 8) slots = 8;
   m_slots.resize((size_t)slots);
   if (!hipOk(hipStreamCreateWithFlags(&m_in, hipStreamNonBlocking), "stream") ||
@@ -38,9 +39,19 @@ FramePipeline::FramePipeline(ShaderEngine* engine, int slots) : m_engine(engine)
         !hipOk(hipEventCreateWithFlags(&s.d2hDone, hipEventDisableTiming), "event"))
       return;
   m_ok = true;
+  m_engine->attachClient(this);
+}
+
+void FramePipeline::engineGone() {
+  if (m_in) (void)hipStreamSynchronize(m_in);
+  if (m_engine) (void)hipStreamSynchronize(m_engine->stream());
+  if (m_out) (void)hipStreamSynchronize(m_out);
+  m_engine = nullptr;
+  m_ok = false;   // submit / receive / inputBuffer now fail; frames already received stay valid
 }
 
 FramePipeline::~FramePipeline() {
+  if (m_engine) m_engine->detachClient(this);
   if (m_in) (void)hipStreamSynchronize(m_in);
   if (m_out) (void)hipStreamSynchronize(m_out);
   if (m_engine) (void)hipStreamSynchronize(m_engine->stream());
@@ -70,7 +81,7 @@ bool FramePipeline::grow(void** p, size_t* have, size_t need, bool host) {
 }
 
 bool FramePipeline::submit(const void* hostFrame, int pixfmt, uint32_t width, uint32_t height) {
-  if (!m_ok || !hostFrame || m_inFlight == (int)m_slots.size()) return false;
+  if (!m_ok || !hostFrame || full()) return false;
   const size_t inBytes = frameBytes(pixfmt, width, height);
   if (inBytes == 0 || (pixfmt == 3 && (width & 1u))) return false;
   Slot& s = m_slots[(size_t)m_head];
@@ -163,7 +174,7 @@ bool FramePipeline::submit(const void* hostFrame, int pixfmt, uint32_t width, ui
 }
 
 void* FramePipeline::inputBuffer(int pixfmt, uint32_t width, uint32_t height) {
-  if (!m_ok || m_inFlight == (int)m_slots.size()) return nullptr;
+  if (!m_ok || full()) return nullptr;
   const size_t inBytes = frameBytes(pixfmt, width, height);
   Slot& s = m_slots[(size_t)m_head];
   if (inBytes == 0 || !grow(&s.hostIn, &s.hostInBytes, inBytes, true)) return nullptr;
@@ -181,6 +192,7 @@ bool FramePipeline::receive(const void** hostRgb24, uint32_t* width, uint32_t* h
   if (hostRgb24) *hostRgb24 = s.hostOut;
   if (width) *width = s.outW;
   if (height) *height = s.outH;
+  m_held = m_tail;   // the caller's until the next receive(): submit() keeps off it (the previous one is released)
   m_tail = (m_tail + 1) % (int)m_slots.size();
   --m_inFlight;
   return true;

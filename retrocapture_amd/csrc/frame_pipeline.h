@@ -20,7 +20,7 @@
 
 namespace rc {
 
-class FramePipeline {
+class FramePipeline : public EngineClient {
  public:
   FramePipeline(ShaderEngine* engine, int slots);
   ~FramePipeline();
@@ -31,9 +31,13 @@ class FramePipeline {
   // Pinned staging memory of the slot the next submit() will use, sized for such a frame: a caller that
   // captures straight into it and passes the same pointer to submit() saves the host-side copy.
   void* inputBuffer(int pixfmt, uint32_t width, uint32_t height);
-  // Oldest submitted frame: RGB24, row 0 first, in pinned memory owned by the pipeline and valid
-  // until that slot is submitted to again.  wait = false returns false when it is not finished yet.
+  // Oldest submitted frame: RGB24, row 0 first, in pinned memory owned by the pipeline.  The frame stays the
+  // caller's until the NEXT receive() (or the pipeline's destruction): its slot is not reused by submit() /
+  // inputBuffer() before that, so a ring of N slots carries at most N - 1 frames in flight besides the one the
+  // caller holds.  wait = false returns false when the frame is not finished yet.
   bool receive(const void** hostRgb24, uint32_t* width, uint32_t* height, bool wait);
+  // The engine is shutting down (ShaderEngine::shutdown / destructor): drain, then refuse further work.
+  void engineGone() override;
   int inFlight() const { return m_inFlight; }
   void setFlipY(bool flip) { m_flipY = flip; }
   // Optional stages of the reference's frame path (src/core/FrameCapturePipeline.cpp): NEAREST
@@ -71,6 +75,8 @@ class FramePipeline {
   std::vector<Slot> m_slots;
   hipStream_t m_in = nullptr, m_out = nullptr;
   int m_head = 0, m_tail = 0, m_inFlight = 0;
+  int m_held = -1;   // slot whose output the caller received last and may still be reading
+  bool full() const { return m_inFlight + (m_held >= 0 ? 1 : 0) >= (int)m_slots.size(); }
   bool m_ok = false, m_flipY = false;
   uint32_t m_logicalW = 0, m_logicalH = 0, m_outW = 0, m_outH = 0;
   float m_overscanX = 0.0f, m_overscanY = 0.0f, m_brightness = 1.0f, m_contrast = 1.0f;

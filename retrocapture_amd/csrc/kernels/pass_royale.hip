@@ -407,14 +407,14 @@ __global__ void __launch_bounds__(256) k_scanh_geometry(const PassLaunch L, uint
 }
 
 template <class SO>
-__global__ void __launch_bounds__(256) k_royale_scan_h_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
+__global__ void __launch_bounds__(512) k_royale_scan_h_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
   RC_SRGB_LDS(lds, L);
   using MaskS = S<FMT_RGBA8, 0, WRAP_EDGE>;
   const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const rcstrip::StripGrid<kShRows> G(L.out_w, L.out_h, L.n_frames);
   const int W = G.W, H = G.H;
   const Tex& scan = L.extra[0];
-  for (int strip = (int)blockIdx.x * 4 + wave; strip < G.total; strip += (int)gridDim.x * 4) {
+  for (int strip = (int)blockIdx.x * 8 + wave; strip < G.total; strip += (int)gridDim.x * 8) {
     int z, xw, ys;
     G.locate(strip, &z, &xw, &ys);
     const int x = xw + lane;
@@ -602,14 +602,14 @@ __global__ void __launch_bounds__(256) k_brightpass_geometry(const PassLaunch L,
 }
 
 template <class SO>
-__global__ void __launch_bounds__(256) k_royale_brightpass_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
+__global__ void __launch_bounds__(512) k_royale_brightpass_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
   RC_SRGB_LDS(lds, L);
   const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const rcstrip::StripGrid<kBpRows> G(L.out_w, L.out_h, L.n_frames);
   const int W = G.W, H = G.H;
   const Tex& blur = L.extra[0];
   const float cw = L.params[RP8_CENTER_WEIGHT], mask_amplify = L.params[RP8_MASK_AMPLIFY];
-  for (int strip = (int)blockIdx.x * 4 + wave; strip < G.total; strip += (int)gridDim.x * 4) {
+  for (int strip = (int)blockIdx.x * 8 + wave; strip < G.total; strip += (int)gridDim.x * 8) {
     int z, xw, ys;
     G.locate(strip, &z, &xw, &ys);
     const int x = xw + lane;
@@ -801,14 +801,14 @@ __global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint3
 }
 
 template <class SO>
-__global__ void __launch_bounds__(256) k_royale_last_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
+__global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
   RC_SRGB_LDS(lds, L);
   const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const rcstrip::StripGrid<kLastRows> G(L.out_w, L.out_h, L.n_frames);
   const int W = G.W, H = G.H, Win = L.in.w, Hin = L.in.h;
   const float* P = L.params;
   const float inv_gamma = 1.0f / P[1], border_size = P[39], border_darkness = P[40], border_compress = P[41];
-  for (int strip = (int)blockIdx.x * 4 + wave; strip < G.total; strip += (int)gridDim.x * 4) {
+  for (int strip = (int)blockIdx.x * 8 + wave; strip < G.total; strip += (int)gridDim.x * 8) {
     int z, xw, ys;
     G.locate(strip, &z, &xw, &ys);
     const int x = xw + lane;
@@ -962,8 +962,8 @@ hipError_t launch_royale_scan_h(const PassLaunch& L, hipStream_t s) {
       static std::map<rcstrip::GeoKey, ScanHTables> cache;
       if (const ScanHTables* T = rcstrip::geo_tables<ScanHTables>(L, s, mu, cache, buildScanHTables)) {
         const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kShRows - 1) / kShRows) * L.n_frames;
-        const long blocks = (strips + 3) / 4;
-        hipLaunchKernelGGL((k_royale_scan_h_strip<OutS>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), rcd::srgb_lds_bytes(L), s, L, T->cols,
+        const long blocks = (strips + 7) / 8;
+        hipLaunchKernelGGL((k_royale_scan_h_strip<OutS>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512), rcd::srgb_lds_bytes(L), s, L, T->cols,
                            T->rows);
         return hipGetLastError();
       }
@@ -986,8 +986,8 @@ hipError_t launch_royale_brightpass(const PassLaunch& L, hipStream_t s) {
       static std::map<rcstrip::GeoKey, BpTables> cache;
       if (const BpTables* T = rcstrip::geo_tables<BpTables>(L, s, mu, cache, buildBpTables)) {
         const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kBpRows - 1) / kBpRows) * L.n_frames;
-        const long blocks = (strips + 3) / 4;
-        hipLaunchKernelGGL((k_royale_brightpass_strip<OutS>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), rcd::srgb_lds_bytes(L), s, L,
+        const long blocks = (strips + 7) / 8;
+        hipLaunchKernelGGL((k_royale_brightpass_strip<OutS>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512), rcd::srgb_lds_bytes(L), s, L,
                            T->cols, T->rows);
         return hipGetLastError();
       }
@@ -1007,8 +1007,8 @@ hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
       static std::map<rcstrip::GeoKey, LastTables> cache;
       if (const LastTables* T = rcstrip::geo_tables<LastTables>(L, s, mu, cache, buildLastTables)) {
         const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kLastRows - 1) / kLastRows) * L.n_frames;
-        const long blocks = (strips + 3) / 4;
-        hipLaunchKernelGGL((k_royale_last_strip<St<FMT_RGBA8>>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), rcd::srgb_lds_bytes(L), s, L,
+        const long blocks = (strips + 7) / 8;
+        hipLaunchKernelGGL((k_royale_last_strip<St<FMT_RGBA8>>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512), rcd::srgb_lds_bytes(L), s, L,
                            T->cols, T->rows);
         return hipGetLastError();
       }

@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) k_bloomv_geometry(const PassLaunch L, int
 }
 
 template <class SO, int PATTERN>
-__global__ void __launch_bounds__(256) k_royale_bloom_v_strip(const PassLaunch L) {
+__global__ void __launch_bounds__(512) k_royale_bloom_v_strip(const PassLaunch L) {
   RC_SRGB_LDS(lds, L);
   constexpr int o12 = 1 + ((PATTERN >> 0) & 1), o34 = 3 + ((PATTERN >> 1) & 1), o56 = 5 + ((PATTERN >> 2) & 1), o78 = 7 + ((PATTERN >> 3) & 1);
   const float* P = L.params;
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) k_royale_bloom_v_strip(const PassLaunch L
   const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const StripGrid<kBvRows> G(L.out_w, L.out_h, L.n_frames);
   const int W = G.W, H = G.H, Hin = L.in.h;
-  for (int strip = (int)blockIdx.x * 4 + wave; strip < G.total; strip += (int)gridDim.x * 4) {
+  for (int strip = (int)blockIdx.x * 8 + wave; strip < G.total; strip += (int)gridDim.x * 8) {
     int z, xw, ys;
     G.locate(strip, &z, &xw, &ys);
     const int x = xw + lane;
@@ -297,9 +297,10 @@ __device__ __forceinline__ float3 dec3(uint32_t t, const SrgbLds& l) {
 }
 
 // one target pixel; ring = this wave's three staged rows (row r in slot r % 3), `TWO`: the vertical weight is not 0
-template <class SO, bool TWO>
+// HALC: the two horizontally filtered halation rows of the pixel's row pair are handed over (hal_rows[0..2], [3..5])
+template <class SO, bool TWO, bool HALC>
 __device__ __forceinline__ void bloomh_pixel(const PassLaunch& L, const SrgbLds& lds, const uint8_t* ring, const BhCol& c, const BhRow& r,
-                                             int x, int y, int z) {
+                                             int x, int y, int z, const float* hal_rows) {
   const float* P = L.params;
   const int Hin = L.in.h;
   const uint8_t* rowA = ring + (uint32_t)(clampi(r.y0, 0, Hin - 1) % 3) * (kBhSeg * 16u);
@@ -338,12 +339,17 @@ __device__ __forceinline__ void bloomh_pixel(const PassLaunch& L, const SrgbLds&
   const uint32_t* i1 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[1], z));
   const uint32_t* i2 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[2], z));
   const float3 idim = dec3(i0[r.idim_y * L.extra[0].w + c.idim_x], lds), bright = dec3(i1[r.bright_y * L.extra[1].w + c.bright_x], lds);
-  const int hw = L.extra[2].w, hh = L.extra[2].h;
-  const int hx0 = clampi(c.hal_x0, 0, hw - 1), hx1 = clampi(c.hal_x0 + 1, 0, hw - 1);
-  const int hy0 = clampi(r.hal_y0, 0, hh - 1), hy1 = clampi(r.hal_y0 + 1, 0, hh - 1);
-  const float3 h00 = dec3(i2[hy0 * hw + hx0], lds), h10 = dec3(i2[hy0 * hw + hx1], lds);
-  const float3 h01 = dec3(i2[hy1 * hw + hx0], lds), h11 = dec3(i2[hy1 * hw + hx1], lds);
-  const float3 hal = lerp3(r.hal_wy, lerp3(c.hal_w, h00, h10), lerp3(c.hal_w, h01, h11));
+  float3 hal;
+  if (HALC) {
+    hal = lerp3(r.hal_wy, make_float3(hal_rows[0], hal_rows[1], hal_rows[2]), make_float3(hal_rows[3], hal_rows[4], hal_rows[5]));
+  } else {
+    const int hw = L.extra[2].w, hh = L.extra[2].h;
+    const int hx0 = clampi(c.hal_x0, 0, hw - 1), hx1 = clampi(c.hal_x0 + 1, 0, hw - 1);
+    const int hy0 = clampi(r.hal_y0, 0, hh - 1), hy1 = clampi(r.hal_y0 + 1, 0, hh - 1);
+    const float3 h00 = dec3(i2[hy0 * hw + hx0], lds), h10 = dec3(i2[hy0 * hw + hx1], lds);
+    const float3 h01 = dec3(i2[hy1 * hw + hx0], lds), h11 = dec3(i2[hy1 * hw + hx1], lds);
+    hal = lerp3(r.hal_wy, lerp3(c.hal_w, h00, h10), lerp3(c.hal_w, h01, h11));
+  }
   const float mask_amplify = P[RPG_MASK_AMPLIFY];
   const float i3[3] = {idim.x, idim.y, idim.z}, b3[3] = {bright.x, bright.y, bright.z}, h3[3] = {hal.x, hal.y, hal.z};
   float out[3];
@@ -395,11 +401,36 @@ __device__ __forceinline__ void bloomh_strip(const PassLaunch& L, const SrgbLds&
     }
   };
   int staged = -1;   // highest source row staged so far
+  // the halation blur (320x240) is magnified: its row pair changes every few target rows; keep the pair's two
+  // horizontally filtered rows (MODE 0 / 1)
+  float hal_rows[6];
+  int hal_have = -1000;
+  const uint32_t* himg = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[2], z));
+  auto hal_hrow = [&](int r, float* h) {
+    const int hw = L.extra[2].w;
+    const uint32_t* p = himg + clampi(r, 0, L.extra[2].h - 1) * hw;
+    const uint32_t ta = p[clampi(c0.hal_x0, 0, hw - 1)], tb = p[clampi(c0.hal_x0 + 1, 0, hw - 1)];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float a = lds.dec[(ta >> (8 * ch)) & 255u], b = lds.dec[(tb >> (8 * ch)) & 255u];
+      h[ch] = fma_(c0.hal_w, b - a, a);
+    }
+  };
 #pragma unroll 1
   for (int k = 0; k < kBhRows; ++k) {
     const int y = ys + k;
     if (y >= H) break;
     const BhRow r0 = load_bh_row(rows, y, MODE == 1 ? 1 : 0);
+    if (MODE != 2 && r0.hal_y0 != hal_have) {
+      if (r0.hal_y0 == hal_have + 1) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) hal_rows[ch] = hal_rows[3 + ch];
+      } else {
+        hal_hrow(r0.hal_y0, hal_rows);
+      }
+      hal_hrow(r0.hal_y0 + 1, hal_rows + 3);
+      hal_have = r0.hal_y0;
+    }
     BhRow r1 = r0;
     if (MODE == 2) r1 = load_bh_row(rows, y, 1);
     // rows this target row needs: y0 and y0 + 1, clamped; k_bloomh_geometry checked y - 1 <= y0 <= y
@@ -414,15 +445,15 @@ __device__ __forceinline__ void bloomh_strip(const PassLaunch& L, const SrgbLds&
     __builtin_amdgcn_wave_barrier();
     if (!live) continue;
     if (MODE != 2) {
-      if (r0.wy != 0.0f) bloomh_pixel<SO, true>(L, lds, ring, c0, r0, x, y, z);
-      else bloomh_pixel<SO, false>(L, lds, ring, c0, r0, x, y, z);
+      if (r0.wy != 0.0f) bloomh_pixel<SO, true, true>(L, lds, ring, c0, r0, x, y, z, hal_rows);
+      else bloomh_pixel<SO, false, true>(L, lds, ring, c0, r0, x, y, z, hal_rows);
     } else {
       // (rare: the column quantities of this pixel's triangle come from memory instead of registers)
       const bool lo = rcd::lower_tri(x, y, W, H);
       const BhCol c = load_bh_col(cols, W, xc, xw, lo ? 0 : 1);
       const BhRow r{lo ? r0.y0 : r1.y0, lo ? r0.wy : r1.wy, lo ? r0.idim_y : r1.idim_y, lo ? r0.bright_y : r1.bright_y,
                     lo ? r0.hal_y0 : r1.hal_y0, lo ? r0.hal_wy : r1.hal_wy};
-      bloomh_pixel<SO, true>(L, lds, ring, c, r, x, y, z);
+      bloomh_pixel<SO, true, false>(L, lds, ring, c, r, x, y, z, nullptr);
     }
   }
 }
@@ -483,8 +514,8 @@ using OutS = St<FMT_SRGB8>;
 template <int PATTERN>
 hipError_t launch_bloom_v_strip(const PassLaunch& L, hipStream_t s) {
   const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kBvRows - 1) / kBvRows) * L.n_frames;
-  const long blocks = (strips + 3) / 4;
-  hipLaunchKernelGGL((k_royale_bloom_v_strip<OutS, PATTERN>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), rcd::srgb_lds_bytes(L), s, L);
+  const long blocks = (strips + 7) / 8;
+  hipLaunchKernelGGL((k_royale_bloom_v_strip<OutS, PATTERN>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s) {

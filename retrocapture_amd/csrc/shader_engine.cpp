@@ -82,7 +82,18 @@ bool ShaderEngine::init(int device, hipStream_t stream) {  // :22-60
   return true;
 }
 
+void ShaderEngine::attachClient(EngineClient* c) {
+  if (c) m_clients.push_back(c);
+}
+void ShaderEngine::detachClient(EngineClient* c) {
+  m_clients.erase(std::remove(m_clients.begin(), m_clients.end(), c), m_clients.end());
+}
+
 void ShaderEngine::shutdown() {  // :62-86
+  // pipelines built on this engine drain their streams and let go of it first
+  std::vector<EngineClient*> clients;
+  clients.swap(m_clients);
+  for (EngineClient* c : clients) c->engineGone();
   if (!m_initialized) return;
   disableShader();
   cleanupPresetPasses();
@@ -643,6 +654,9 @@ bool ShaderEngine::bindSamplers(size_t i, const KernelEntry& k, const rcd::Tex& 
       if (!hipOk(hipMemsetAsync(t.feedback.ptr, 0, t.frameBytes, m_stream), "feedback clear")) return false;
       t.feedbackLinear = 1;
       t.feedbackWrap = rcd::WRAP_EDGE;
+      t.feedbackWidth = t.width;
+      t.feedbackHeight = t.height;
+      t.feedbackFormat = t.format;
       *lostDraw = true;
     }
     rcd::Tex ft = passTexture(fp);
@@ -887,6 +901,15 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
   for (size_t i = 0; i < m_passes.size(); ++i) {
     ShaderPassData& pd = m_passes[i];
     const bool last = (i + 1 == m_passes.size());
+    // A pass whose size changed (viewport, input size, resolution clamp) gets a new render target in the reference,
+    // which also deletes its feedback partner and clears feedbackEnabled (:918-933); the partner is created again,
+    // empty, when a program next asks for it - including the lost draw of that frame (bindSamplers).
+    if (pd.feedback.ptr && (pd.feedbackWidth != pd.width || pd.feedbackHeight != pd.height || pd.feedbackFormat != pd.format)) {
+      if (!hipOk(hipStreamSynchronize(m_stream), "sync")) return false;   // the old partner may still be read by queued kernels
+      (void)hipFree(pd.feedback.ptr);
+      pd.feedback = DeviceBuffer();
+      pd.feedbackEnabled = false;
+    }
     void* target = last ? finalOut : pd.target.ptr;
     if (last && pd.feedbackEnabled) {
       // the last pass ping-pongs too: it renders into its own buffer, copied to the output below

@@ -49,6 +49,8 @@ struct ShaderPassData {  // reference ShaderEngine.h:19-40
   DeviceBuffer feedback;
   bool feedbackEnabled = false;
   int feedbackLinear = 1, feedbackWrap = rcd::WRAP_EDGE;  // sampler state of the partner texture object
+  uint32_t feedbackWidth = 0, feedbackHeight = 0;          // the size it was created with (it is dropped when the pass's size changes)
+  int feedbackFormat = -1;
   DeviceBuffer lastTarget;  // last pass only, when it takes part in feedback: its own render target
   const void* lastWritten = nullptr;  // where the most recent chunk of this pass was rendered
   // A pass whose shader and inputs do not depend on the frame (crt-royale's two mask-resize passes: LUT -> 64x68 ->
@@ -66,10 +68,20 @@ struct LutTexture {
   int width = 0, height = 0;
 };
 
+// Something that holds a pointer to an engine (a FramePipeline): told when the engine shuts down, so that it
+// stops using it instead of dereferencing a dead object.
+struct EngineClient {
+  virtual void engineGone() = 0;
+ protected:
+  ~EngineClient() = default;
+};
+
 class ShaderEngine {
  public:
   ShaderEngine();
   ~ShaderEngine();
+  void attachClient(EngineClient* c);
+  void detachClient(EngineClient* c);
 
   // device < 0: keep the current HIP device.  stream may be null (default stream).
   bool init(int device = -1, hipStream_t stream = nullptr);
@@ -179,6 +191,7 @@ class ShaderEngine {
   std::vector<PassProfile> m_profile;
   std::vector<uint64_t> m_passReadBytes;
 
+  std::vector<EngineClient*> m_clients;
   mutable std::mutex m_paramMutex;  // the reference shares these maps across threads unguarded
   std::map<std::string, float> m_customParameters;
 

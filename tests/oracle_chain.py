@@ -104,6 +104,12 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
     for i, p in enumerate(passes):
         spec = chain_specs.SHADERS[chain_specs.identity(p["shader"])]
         declared = spec["samplers"]
+        if state is not None and i in state.feedback and state.feedback[i].shape[:2] != (sizes[i][1], sizes[i][0]):
+            # the pass's size changed: the reference recreates its framebuffer, deletes the feedback partner and clears
+            # feedbackEnabled (cpp:918-933); the partner comes back, empty, when a program next asks for it
+            del state.feedback[i]
+            state.feedback_state.pop(i, None)
+            state.feedback_enabled.discard(i)
         bound = {}                      # sampler name -> unit set in this draw
         unit = 1
 

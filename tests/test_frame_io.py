@@ -139,3 +139,29 @@ def test_frame_pipeline_equals_direct_path(fmt, preset_tree, rc_lib):
     pipe.close()
     e.shutdown()
     e2.shutdown()
+
+
+@pytest.mark.gpu
+def test_frame_pipeline_ownership_and_engine_lifetime(preset_tree, rc_lib):
+    """A received frame stays intact while further frames are submitted (its slot is not reused before the next
+    receive), and shutting the engine down before the pipeline is closed is safe: the pipeline lets go of it."""
+    from gpu_util import make_engine
+    from retrocapture_amd import engine
+    w, h = 64, 48
+    rng = np.random.default_rng(3)
+    frames = [rng.integers(0, 256, h * w * 3, dtype=np.uint8) for _ in range(6)]
+    e = make_engine(preset_tree["stock"], w, h)
+    pipe = engine.FramePipeline(e, slots=2)
+    assert pipe.submit(frames[0], "rgb24", w, h)
+    first = pipe.receive(wait=True)           # a view of the pipeline's pinned memory: ours until the next receive
+    keep = first.copy()
+    assert pipe.submit(frames[1], "rgb24", w, h)
+    assert not pipe.submit(frames[2], "rgb24", w, h)      # 2 slots: one held by us, one in flight
+    assert np.array_equal(first, keep)                    # ... and the held frame was not overwritten
+    second = pipe.receive(wait=True).copy()
+    assert not np.array_equal(second, keep)
+    assert pipe.submit(frames[2], "rgb24", w, h)
+    e.shutdown()                                          # engine first: the pipeline drains and detaches
+    assert not pipe.submit(frames[3], "rgb24", w, h)
+    assert pipe.receive(wait=True) is None
+    pipe.close()

@@ -382,6 +382,30 @@ def test_pass_feedback_matches_golden(case, as_batch, preset_tree, rc_lib):
     e.shutdown()
 
 
+def test_pass_feedback_survives_a_viewport_change(preset_tree, rc_lib):
+    """The viewport changes between frames: the passes that scale with it get new render targets, and the
+    reference then deletes their feedback partners, which come back empty (and with the lost draw) when a program
+    next asks (ShaderEngine.cpp:918-933, :1285-1347).  Engine against the oracle's restatement of that rule,
+    frame by frame; a growing viewport would read out of bounds if the partner kept its old allocation."""
+    from gpu_util import make_engine, run_engine
+    from oracle_chain import ChainState
+    from retrocapture_amd import engine as eng
+    rng = np.random.default_rng(31)
+    frames = rng.integers(0, 256, (7, 40, 64, 3), dtype=np.uint8)
+    viewports = [(64, 40), (64, 40), (150, 90), (150, 90), (150, 90), (97, 61), (97, 61)]
+    passes = eng.preset_dump(preset_tree["feedback-persist"])["passes"]
+    e = make_engine(preset_tree["feedback-persist"], *viewports[0])
+    st = ChainState()
+    for f, (vw, vh) in enumerate(viewports):
+        e.setViewport(vw, vh)
+        final = run_engine(e, frames[f])[0]
+        want = run_chain(passes, frames[f], vw, vh, frame_count=f + 1, state=st)
+        assert final.shape == want[-1].shape, (f, final.shape, want[-1].shape)
+        assert np.array_equal(e.readPass(0, 0), want[0]), "frame %d pass 0" % f
+        assert np.array_equal(final, want[-1]), "frame %d" % f
+    e.shutdown()
+
+
 def test_ntsc_full_size_batch(preset_tree, rc_lib):
     """BASELINE config 3 at full size: 1920x1080 source, 1024x1080 RGBA32F intermediate, 512x1080 output;
     a batch of 3 frames (FrameCount 1..3 drives the chroma phase), every byte against the oracle."""
