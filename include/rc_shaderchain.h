@@ -268,6 +268,12 @@ const char* rc_version(void);
 /* Names of the registered kernels ("identity\n" list) for diagnostics. */
 size_t rc_kernel_list(char* buf, size_t cap);
 
+/* ShaderPreset::saveAs without an engine (reference ShaderPreset.cpp:557-661): loads `preset_path` and writes it
+ * to `out_path` line by line, replacing the value of every line whose key is one of the preset's own global
+ * parameters or one of the n custom (name, value) pairs - a parameter without a line in the file gets none, as
+ * in the reference.  RC_OK, RC_ERR_LOAD or RC_ERR_INVALID. */
+int rc_preset_save_as(const char* preset_path, const char* out_path, const char* const* names, const float* values, int n);
+
 /* Standalone preset parser check (ShaderPreset::load, ShaderPreset.cpp:18-333): writes a JSON
  * description of the parsed preset; returns the length needed.  No GPU needed. */
 size_t rc_preset_dump_json(const char* glslp_path, char* buf, size_t cap);

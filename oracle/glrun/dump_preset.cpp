@@ -4,6 +4,7 @@
 // restated parser with this across the whole shader corpus.
 #include <cstdio>
 #include <string>
+#include <unordered_map>
 
 #include "shader/ShaderPreset.h"
 
@@ -18,6 +19,20 @@ static std::string esc(const std::string& s) {
 }
 
 int main(int argc, char** argv) {
+  // dump_preset --saveas <in.glslp> <out.glslp> [name=value ...]: the reference's ShaderPreset::saveAs
+  // (ShaderPreset.cpp:557-661) with the given custom parameters, for the save / reload round-trip test
+  if (argc >= 4 && std::string(argv[1]) == "--saveas") {
+    ShaderPreset p;
+    if (!p.load(argv[2])) return 2;
+    std::unordered_map<std::string, float> custom;
+    for (int a = 4; a < argc; ++a) {
+      std::string kv = argv[a];
+      size_t eq = kv.find('=');
+      if (eq == std::string::npos) return 3;
+      custom[kv.substr(0, eq)] = std::stof(kv.substr(eq + 1));
+    }
+    return p.saveAs(argv[3], custom) ? 0 : 4;
+  }
   for (int a = 1; a < argc; ++a) {
     ShaderPreset p;
     bool ok = p.load(argv[a]);

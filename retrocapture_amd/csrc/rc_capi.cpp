@@ -447,6 +447,19 @@ size_t rc_preset_dump_json(const char* path, char* buf, size_t cap) {
   return copy_out(out, buf, cap);
 }
 
+int rc_preset_save_as(const char* preset_path, const char* out_path, const char* const* names, const float* values, int n) {
+  if (!preset_path || !out_path || n < 0 || (n > 0 && (!names || !values))) return RC_ERR_INVALID;
+  return guarded([&] {
+    rc::ShaderPreset p;
+    rc::MissingSourceScope missing(true);
+    if (!p.load(preset_path)) return (int)RC_ERR_LOAD;
+    std::unordered_map<std::string, float> custom;
+    for (int i = 0; i < n; ++i)
+      if (names[i]) custom[names[i]] = values[i];
+    return p.saveAs(out_path, custom) ? (int)RC_OK : (int)RC_ERR_LOAD;
+  });
+}
+
 int rc_png_decode_rgba8(const char* path, void* rgba, size_t cap, int* width, int* height) {
   if (!path || !rgba) return RC_ERR_INVALID;
   return guarded([&] {

@@ -102,6 +102,7 @@ SYMBOLS = [
     ("rc_version", C.c_char_p, []),
     ("rc_kernel_list", C.c_size_t, [C.c_char_p, C.c_size_t]),
     ("rc_preset_dump_json", C.c_size_t, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("rc_preset_save_as", C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     ("rc_shader_params_json", C.c_size_t, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("rc_png_decode_rgba8", C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 ]
@@ -311,6 +312,14 @@ def royale_scan_tables(off):
     if lib.rc_selftest_royale_scan_tables(C.c_float(off), A.ctypes.data, B.ctypes.data, A.size, B.size) != n:
         raise RcError("rc_selftest_royale_scan_tables failed")
     return A, B[..., 0].copy().view(np.float32), B[..., 1].copy().view(np.float32)
+
+
+def preset_save_as(preset_path, out_path, custom=None):
+    """ShaderPreset::saveAs without an engine; custom: {name: value}.  True on success."""
+    custom = custom or {}
+    names = (C.c_char_p * max(1, len(custom)))(*[k.encode() for k in custom])
+    values = (C.c_float * max(1, len(custom)))(*[float(v) for v in custom.values()])
+    return load_library().rc_preset_save_as(str(preset_path).encode(), str(out_path).encode(), names, values, len(custom)) == 0
 
 
 def kernel_list():

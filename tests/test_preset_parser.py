@@ -129,3 +129,84 @@ def test_pragma_parameters_of_config_shaders(rc_lib):
         for (name, default), p in zip(spec["params"], info["params"]):
             assert abs(p["default"] - default) < 1e-6, (ident, name)
         assert info["parameter_uniform"] == bool(want)
+
+
+SAVE_PRESET = '''# a preset with global parameter lines in several styles
+shaders = 1
+shader0 = "x.glsl"
+filter_linear0 = true
+CURVATURE_X = "0.10"
+CURVATURE_Y = 0.15   # kept comment
+MASK_BRIGHTNESS= 0.70
+  SCANLINE_WEIGHT   =   "6.0"
+untouched = 2.5
+'''
+# what ShaderPreset::saveAs makes of it with CURVATURE_X = 0.25, SCANLINE_WEIGHT = 7, NOT_IN_FILE = 1 (produced by
+# the reference's own saveAs - test_save_as_matches_the_reference below regenerates and compares it): every
+# `key = float` line is a global parameter and is rewritten ("key = " + the value's leading blanks / quote + "%f"
+# without trailing zeros + closing quote); a trailing comment is part of the value and goes; no line is added
+SAVED_PRESET = ('# a preset with global parameter lines in several styles\nshaders = 1\nshader0 = "x.glsl"\nfilter_linear0 = true\n'
+                'CURVATURE_X =  "0.25"\nCURVATURE_Y =  0.15\nMASK_BRIGHTNESS =  0.7\nSCANLINE_WEIGHT =    "7"\nuntouched =  2.5\n')
+SAVE_CUSTOM = {"CURVATURE_X": 0.25, "SCANLINE_WEIGHT": 7.0, "NOT_IN_FILE": 1.0}
+
+
+def test_save_as_round_trip(tmp_path, rc_lib):
+    """saveAs (reference ShaderPreset.cpp:557-661): load -> custom values -> save -> reload.  Lines of known
+    parameters are rewritten in place (prefix / quotes / trailing text of the value kept, "%f" with trailing zeros
+    stripped), every other line is copied, a parameter without a line gets none; the reloaded preset has the same
+    passes and the new values."""
+    from retrocapture_amd import engine
+    src, dst = tmp_path / "in.glslp", tmp_path / "out.glslp"
+    src.write_text(SAVE_PRESET)
+    before = engine.preset_dump(str(src))
+    assert engine.preset_save_as(str(src), str(dst), SAVE_CUSTOM)
+    assert dst.read_text() == SAVED_PRESET
+    after = engine.preset_dump(str(dst))
+    assert [dict(p, shader=os.path.basename(p["shader"])) for p in after["passes"]] == \
+           [dict(p, shader=os.path.basename(p["shader"])) for p in before["passes"]]
+    assert after["textures"] == before["textures"]
+    want = dict(before["params"], CURVATURE_X=0.25, SCANLINE_WEIGHT=7.0)
+    assert after["params"].keys() == want.keys()
+    for k, v in want.items():
+        assert abs(after["params"][k] - v) < 1e-6, k
+    # saving again without changes keeps every value (each save adds a blank after "=": the reference's rule)
+    again = tmp_path / "again.glslp"
+    assert engine.preset_save_as(str(dst), str(again), {})
+    assert engine.preset_dump(str(again))["params"] == after["params"]
+
+
+@pytest.mark.reference
+def test_save_as_matches_the_reference(tmp_path, rc_lib):
+    """The same save through the reference's own ShaderPreset::saveAs (oracle/_ref/dump_preset --saveas): identical
+    bytes; and identical bytes on presets of the reference's corpus that carry global parameters."""
+    from retrocapture_amd import engine
+    if not os.path.exists(DUMP):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    env = dict(os.environ, RETROCAPTURE_LOG_LEVEL="error")
+    src = tmp_path / "in.glslp"
+    src.write_text(SAVE_PRESET)
+    ref_out = tmp_path / "ref.glslp"
+    args = ["%s=%r" % kv for kv in SAVE_CUSTOM.items()]
+    subprocess.run([DUMP, "--saveas", str(src), str(ref_out)] + args, cwd=REFERENCE, env=env, check=True, capture_output=True)
+    assert ref_out.read_text() == SAVED_PRESET
+    n = 0
+    for path in all_presets():
+        d = engine.preset_dump(path)
+        if not d["ok"] or not d["params"] or len(d["passes"]) > 64:
+            continue
+        custom = {k: v * 1.5 + 0.125 for k, v in list(d["params"].items())[:3]}
+        mine, ref = tmp_path / "m.glslp", tmp_path / "r.glslp"
+        r = subprocess.run([DUMP, "--saveas", path, str(ref)] + ["%s=%r" % kv for kv in custom.items()], cwd=REFERENCE, env=env,
+                           capture_output=True)
+        assert r.returncode == 0, path
+        cwd = os.getcwd()
+        os.chdir(REFERENCE)
+        try:
+            assert engine.preset_save_as(path, str(mine), custom), path
+        finally:
+            os.chdir(cwd)
+        assert mine.read_bytes() == ref.read_bytes(), path
+        n += 1
+        if n >= 60:
+            break
+    assert n >= 40
