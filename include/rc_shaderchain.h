@@ -108,7 +108,7 @@ int rc_engine_save_preset(rc_engine* e, const char* path);
 /* ---- inspection (no reference counterpart; used by tests and tools) -------------------- */
 typedef struct {
   uint32_t width, height;   /* render-target size at the last apply                       */
-  int format;               /* 0 RGBA8, 1 sRGB8_ALPHA8, 3 RGBA32F                          */
+  int format;               /* 0 RGBA8, 1 sRGB8_ALPHA8, 3 RGBA32F, 4 four binary16 (fp16 option) */
   int has_kernel;           /* 0: pass is skipped                                          */
   int filter_linear;        /* the pass's filter_linear / wrap (state set on its INPUT)    */
   int wrap;                 /* 0 edge, 1 border, 2 repeat, 3 mirrored_repeat               */
@@ -156,6 +156,14 @@ int rc_engine_read_history(rc_engine* e, int k, uint32_t* width, uint32_t* heigh
  * rules once per source pixel when the sampling pattern allows it).  Both forms give identical
  * results; 1 forces the general form (diagnostics / tests).  Default 0. */
 void rc_engine_set_general_kernels_only(rc_engine* e, int general_only);
+/* float_framebuffer render targets (the reference creates GL_RGBA32F, ShaderEngine.cpp:2872-2923) stored as
+ * four binary16 values per texel instead: 8 bytes instead of 16 (ntsc-256px-svideo at 1080p: 45.9 -> 28.2 MB of
+ * algorithmic bytes per frame).  Every pass still computes in float; a store to such a target rounds to nearest
+ * even, a fetch widens exactly - the chain equals the fp32 chain with those targets rounded to binary16, which
+ * the tests check bit for bit, and differs from the fp32 (bit-exact, default) path by at most 1 step of the final
+ * 8-bit output on the ntsc presets (asserted in tests/test_fp16_targets.py).  rc_pass_info.format reports 4
+ * (RC_FMT_F16) for such a target and rc_engine_read_pass returns its 8-byte texels.  Default 0. */
+void rc_engine_set_float_target_fp16(rc_engine* e, int on);
 
 /* ---- frame ingest / egress (device buffers; stream may be NULL) ------------------------------
  * rc_ingest replaces the pixel-format handling of FrameProcessor::processFrame (reference

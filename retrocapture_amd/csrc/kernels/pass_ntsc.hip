@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) k_ntsc_pass2(const PassLaunch L) {
 constexpr int kNtscSegMax = 192;              // 2 * 63 + (2 * 32 + 1) columns, rounded up to even
 struct NtscRow { float y[2][kNtscSegMax / 2], i[2][kNtscSegMax / 2], q[2][kNtscSegMax / 2]; };
 
-template <int IN_WRAP, int TAPS, int EPI>
+template <int IN_FMT, int IN_WRAP, int TAPS, int EPI>
 __global__ void __launch_bounds__(256, 8) k_ntsc_pass2_rows(const PassLaunch L) {
   constexpr int kNtscSeg = (2 * 63 + 2 * TAPS + 1 + 1) & ~1;
   __shared__ NtscRow rows[4];
@@ -189,10 +189,9 @@ __global__ void __launch_bounds__(256, 8) k_ntsc_pass2_rows(const PassLaunch L) 
         const int sx_raw = c_first + j;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (IN_WRAP == WRAP_BORDER) {
-          if (sx_raw >= 0 && sx_raw < L.in.w && sy_raw >= 0 && sy_raw < L.in.h)
-            t = *reinterpret_cast<const float4*>(img + texel_off(L.in.w, sx_raw, sy_raw, 16u));
+          if (sx_raw >= 0 && sx_raw < L.in.w && sy_raw >= 0 && sy_raw < L.in.h) t = texel<IN_FMT>(L.in, img, sx_raw, sy_raw, nullptr);
         } else {
-          t = *reinterpret_cast<const float4*>(img + texel_off(L.in.w, clampi(sx_raw, 0, L.in.w - 1), clampi(sy_raw, 0, L.in.h - 1), 16u));
+          t = texel<IN_FMT>(L.in, img, clampi(sx_raw, 0, L.in.w - 1), clampi(sy_raw, 0, L.in.h - 1), nullptr);
         }
         row.y[j & 1][j >> 1] = t.x;
         row.i[j & 1][j >> 1] = t.y;
@@ -231,6 +230,8 @@ hipError_t launch_pass1(const PassLaunch& L, hipStream_t s) {
   // shipped presets: nearest on the RGB source frame, RGBA32F target
   if (L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_F32)
     hipLaunchKernelGGL((k_ntsc_pass1<FMT_RGBX8, 0, WRAP_EDGE, FMT_F32, false, COMPOSITE, TWO_PHASE>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  else if (L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_F16)   // fp16 storage option
+    hipLaunchKernelGGL((k_ntsc_pass1<FMT_RGBX8, 0, WRAP_EDGE, FMT_F16, false, COMPOSITE, TWO_PHASE>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   else if (L.in.fmt == FMT_RGBX8 && !L.in.linear && L.in.wrap == WRAP_BORDER && L.out_fmt == FMT_F32)
     hipLaunchKernelGGL((k_ntsc_pass1<FMT_RGBX8, 0, WRAP_BORDER, FMT_F32, false, COMPOSITE, TWO_PHASE>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   else
@@ -239,10 +240,15 @@ hipError_t launch_pass1(const PassLaunch& L, hipStream_t s) {
 }
 template <int TAPS, int EPI>
 hipError_t launch_pass2(const PassLaunch& L, hipStream_t s) {
-  if (L.in.fmt == FMT_F32 && !L.in.linear && L.out_fmt == FMT_RGBA8 && (L.flags & RC_FLAG_NTSC_REGULAR) &&
+  if ((L.in.fmt == FMT_F32 || L.in.fmt == FMT_F16) && !L.in.linear && L.out_fmt == FMT_RGBA8 && (L.flags & RC_FLAG_NTSC_REGULAR) &&
       !(L.flags & RC_FLAG_GENERAL_ONLY) && (L.in.wrap == WRAP_EDGE || L.in.wrap == WRAP_BORDER)) {
-    if (L.in.wrap == WRAP_EDGE) hipLaunchKernelGGL((k_ntsc_pass2_rows<WRAP_EDGE, TAPS, EPI>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
-    else hipLaunchKernelGGL((k_ntsc_pass2_rows<WRAP_BORDER, TAPS, EPI>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+    if (L.in.fmt == FMT_F32) {
+      if (L.in.wrap == WRAP_EDGE) hipLaunchKernelGGL((k_ntsc_pass2_rows<FMT_F32, WRAP_EDGE, TAPS, EPI>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+      else hipLaunchKernelGGL((k_ntsc_pass2_rows<FMT_F32, WRAP_BORDER, TAPS, EPI>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+    } else {
+      if (L.in.wrap == WRAP_EDGE) hipLaunchKernelGGL((k_ntsc_pass2_rows<FMT_F16, WRAP_EDGE, TAPS, EPI>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+      else hipLaunchKernelGGL((k_ntsc_pass2_rows<FMT_F16, WRAP_BORDER, TAPS, EPI>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+    }
     return hipGetLastError();
   }
   if (L.in.fmt == FMT_F32 && !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8)

@@ -18,7 +18,10 @@
 namespace rcd {
 
 // ---------------------------------------------------------------- launch descriptors ----
-enum Fmt : int { FMT_RGBA8 = 0, FMT_SRGB8 = 1, FMT_RGBX8 = 2, FMT_F32 = 3 };
+// FMT_F16: opt-in storage of float_framebuffer targets as four binary16 values (engine setFloatTargetFp16): the pass
+// still computes in float, a store rounds to nearest even, a fetch widens exactly.  Not the reference's format (RGBA32F).
+enum Fmt : int { FMT_RGBA8 = 0, FMT_SRGB8 = 1, FMT_RGBX8 = 2, FMT_F32 = 3, FMT_F16 = 4 };
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 enum Wrap : int { WRAP_EDGE = 0, WRAP_BORDER = 1, WRAP_REPEAT = 2, WRAP_MIRROR = 3 };
 
 struct Tex {
@@ -270,6 +273,10 @@ __device__ __forceinline__ float4 texel(const Tex& t, const uint8_t* img, int x,
   if (FMT == FMT_F32) {
     return *reinterpret_cast<const float4*>(img + texel_off(t.w, x, y, 16u));
   }
+  if (FMT == FMT_F16) {
+    const half4_t h = *reinterpret_cast<const half4_t*>(img + texel_off(t.w, x, y, 8u));
+    return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+  }
   uint32_t p = *reinterpret_cast<const uint32_t*>(img + texel_off(t.w, x, y, 4u));
   const float k = 1.0f / 255.0f;
   uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u, a = p >> 24;
@@ -366,7 +373,7 @@ __device__ __forceinline__ float4 sample(const Tex& t, const uint8_t* img, float
   return sample_linear_f<FMT, WRAP>(t, img, s, v, lds);
 }
 
-__device__ __forceinline__ int texel_bytes(int fmt) { return fmt == FMT_F32 ? 16 : 4; }
+__device__ __forceinline__ int texel_bytes(int fmt) { return fmt == FMT_F32 ? 16 : (fmt == FMT_F16 ? 8 : 4); }
 __device__ __forceinline__ const uint8_t* frame_ptr(const Tex& t, int z) {
   return static_cast<const uint8_t*>(t.base) + t.frame_stride * (uint64_t)z;
 }
@@ -392,6 +399,9 @@ __device__ __forceinline__ void store(const PassLaunch& L, int z, int x, int y, 
   uint8_t* o = static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z;
   if (OUT_FMT == FMT_F32) {
     *reinterpret_cast<float4*>(o + texel_off(L.out_w, x, y, 16u)) = c;
+  } else if (OUT_FMT == FMT_F16) {
+    const half4_t h = {(_Float16)c.x, (_Float16)c.y, (_Float16)c.z, (_Float16)c.w};   // round to nearest even
+    *reinterpret_cast<half4_t*>(o + texel_off(L.out_w, x, y, 8u)) = h;
   } else if (OUT_FMT == FMT_SRGB8) {
     uint32_t p = srgb8(c.x, t) | (srgb8(c.y, t) << 8) | (srgb8(c.z, t) << 16) | (unorm8(c.w) << 24);
     *reinterpret_cast<uint32_t*>(o + texel_off(L.out_w, x, y, 4u)) = p;
@@ -439,11 +449,13 @@ __device__ __forceinline__ float4 sample_rt(const Tex& t, const uint8_t* img, fl
     case FMT_SRGB8: return sample_rt_filter<FMT_SRGB8>(t, img, s, v, lds);
     case FMT_RGBX8: return sample_rt_filter<FMT_RGBX8>(t, img, s, v, lds);
     case FMT_F32: return sample_rt_filter<FMT_F32>(t, img, s, v, lds);
+    case FMT_F16: return sample_rt_filter<FMT_F16>(t, img, s, v, lds);
     default: return sample_rt_filter<FMT_RGBA8>(t, img, s, v, lds);
   }
 }
 __device__ __forceinline__ void store_rt(const PassLaunch& L, int z, int x, int y, float4 c, const SrgbLds* t) {
   if (L.out_fmt == FMT_F32) store<FMT_F32>(L, z, x, y, c, t);
+  else if (L.out_fmt == FMT_F16) store<FMT_F16>(L, z, x, y, c, t);
   else if (L.out_fmt == FMT_SRGB8) store<FMT_SRGB8>(L, z, x, y, c, t);
   else store<FMT_RGBA8>(L, z, x, y, c, t);
 }

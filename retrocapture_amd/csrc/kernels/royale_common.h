@@ -24,7 +24,7 @@ struct S {
   }
   static bool matches(const Tex& t) { return t.fmt == FMT && (t.linear != 0) == (LIN != 0) && t.wrap == WRAP; }
   // 8-bit texels: every sampled value is 0 or in [2^-40, 1], which is what div_safe_ needs
-  static constexpr bool kUnitRange = FMT != FMT_F32;
+  static constexpr bool kUnitRange = FMT != FMT_F32 && FMT != FMT_F16;
 };
 struct SRT {
   static __device__ __forceinline__ float4 get(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* l) {

@@ -395,6 +395,9 @@ int rc_engine_read_history(rc_engine* e, int k, uint32_t* width, uint32_t* heigh
 void rc_engine_set_general_kernels_only(rc_engine* e, int general_only) {
   if (e) e->impl.setGeneralKernelsOnly(general_only != 0);
 }
+void rc_engine_set_float_target_fp16(rc_engine* e, int on) {
+  if (e) e->impl.setFloatTargetFp16(on != 0);
+}
 void rc_engine_set_allow_missing_sources(rc_engine* e, int allow) {
   if (e) e->impl.setAllowMissingSources(allow != 0);
 }

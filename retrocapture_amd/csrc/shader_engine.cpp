@@ -24,7 +24,7 @@ int wrapFromString(const std::string& w) {  // ShaderEngine.cpp:3208-3228
   return rcd::WRAP_EDGE;
 }
 
-size_t texelBytes(int fmt) { return fmt == rcd::FMT_F32 ? 16 : 4; }
+size_t texelBytes(int fmt) { return fmt == rcd::FMT_F32 ? 16 : (fmt == rcd::FMT_F16 ? 8 : 4); }
 
 bool hipOk(hipError_t e, const char* what) {
   if (e == hipSuccess) return true;
@@ -214,6 +214,14 @@ bool ShaderEngine::loadPreset(const std::string& presetPath) {  // :228-319
   return true;
 }
 
+// Render-target format of a pass (:2882-2890): RGBA32F for float_framebuffer, else SRGB8_ALPHA8 for srgb_framebuffer,
+// else RGBA8.  setFloatTargetFp16(true) stores the float targets as four binary16 values instead (not the reference's
+// format: an opt-in that halves their traffic, within the tolerance stated in DESIGN.md).
+int ShaderEngine::targetFormat(const ShaderPass& pi) const {
+  if (pi.floatFramebuffer) return m_floatTargetFp16 ? rcd::FMT_F16 : rcd::FMT_F32;
+  return pi.srgbFramebuffer ? rcd::FMT_SRGB8 : rcd::FMT_RGBA8;
+}
+
 bool ShaderEngine::loadPresetPasses() {  // :750-848
   const auto& passes = m_preset.getPasses();
   cleanupPresetPasses();
@@ -232,7 +240,7 @@ bool ShaderEngine::compilePass(size_t i) {
   ShaderPassData& pd = m_passes[i];
   const ShaderPass& pi = pd.passInfo;
   pd.kernel = nullptr;
-  pd.format = pi.floatFramebuffer ? rcd::FMT_F32 : (pi.srgbFramebuffer ? rcd::FMT_SRGB8 : rcd::FMT_RGBA8);  // :2882-2890
+  pd.format = targetFormat(pi);
 
   if (lowerExt(pi.shaderPath) == ".slang") {
     RC_LOG_ERROR("Slang shaders (.slang) are not supported in pass " + std::to_string(i));
@@ -438,6 +446,7 @@ void ShaderEngine::resolvePassSizes(uint32_t width, uint32_t height) {
     }
     pd.width = ow;
     pd.height = oh;
+    pd.format = targetFormat(pi);   // (the float storage choice can change between frames)
     pd.frameBytes = (size_t)ow * oh * texelBytes(pd.format);
     cw = ow;
     ch = oh;
@@ -1054,7 +1063,7 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
     // mipmap_input of the next pass: the reference generates the chain when that pass binds this texture
     pd.mipLevels = 0;
     if (!last && m_passes[i + 1].kernel && m_passes[i + 1].kernel->mip_aware && m_passes[i + 1].passInfo.mipmapInput &&
-        m_passes[i + 1].passInfo.filterLinear && (pd.format == rcd::FMT_SRGB8 || pd.format == rcd::FMT_F32)) {
+        m_passes[i + 1].passInfo.filterLinear && (pd.format == rcd::FMT_SRGB8 || pd.format == rcd::FMT_F32 || pd.format == rcd::FMT_F16)) {
       if (!buildMipChain(i, target, nFrames)) return false;
     }
     // this pass's output becomes the next pass's input

@@ -133,6 +133,9 @@ class ShaderEngine {
   // GL drivers that zero undefined varyings, and the resized phosphor mask is rendered.
   void setUndefinedVaryingZero(bool zero) { m_undefVaryingZero = zero; }
   void setGeneralKernelsOnly(bool on) { m_generalOnly = on; }
+  // float_framebuffer targets stored as four binary16 values (8 bytes per texel) instead of RGBA32F: arithmetic stays
+  // float, only the storage of those targets rounds.  Off by default (bit-exact); see DESIGN.md for the tolerance.
+  void setFloatTargetFp16(bool on) { m_floatTargetFp16 = on; }
   uint32_t getChunkFrames() const { return m_chunk; }
   hipStream_t stream() const { return m_stream; }
   size_t passCount() const { return m_passes.size(); }
@@ -182,6 +185,7 @@ class ShaderEngine {
   bool m_allowMissingSources = false;
   bool m_undefVaryingZero = false;
   bool m_generalOnly = false;
+  bool m_floatTargetFp16 = false;
   struct Vec4 { float x, y, z, w; };
   std::unordered_map<std::string, Vec4> m_uniforms;
   DeviceBuffer m_batchOutput;
@@ -195,6 +199,7 @@ class ShaderEngine {
   mutable std::mutex m_paramMutex;  // the reference shares these maps across threads unguarded
   std::map<std::string, float> m_customParameters;
 
+  int targetFormat(const ShaderPass& pi) const;
   bool loadPresetPasses();
   bool compilePass(size_t i);
   void cleanupPresetPasses();

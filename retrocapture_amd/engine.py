@@ -75,6 +75,7 @@ SYMBOLS = [
     ("rc_engine_set_allow_missing_sources", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_undefined_varying_zero", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_general_kernels_only", None, [C.c_void_p, C.c_int]),
+    ("rc_engine_set_float_target_fp16", None, [C.c_void_p, C.c_int]),
     ("rc_engine_history_count", C.c_int, [C.c_void_p]),
     ("rc_engine_read_history", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p,
                                          C.c_size_t]),
@@ -486,6 +487,10 @@ class ShaderEngine:
             raise RcError("readHistory(%d) failed" % k)
         return arr
 
+    def setFloatTargetFp16(self, on):
+        """float_framebuffer targets stored as binary16 (opt-in; default off = RGBA32F, bit-exact)."""
+        self._lib.rc_engine_set_float_target_fp16(self._need(), int(bool(on)))
+
     def setGeneralKernelsOnly(self, on):
         self._lib.rc_engine_set_general_kernels_only(self._need(), int(bool(on)))
 
@@ -496,7 +501,7 @@ class ShaderEngine:
         info = _RcPassInfo()
         if self._lib.rc_engine_pass_info(self._need(), int(i), C.byref(info)) != 0:
             raise IndexError(i)
-        return {"width": info.width, "height": info.height, "format": {0: "rgba8", 1: "srgb8", 3: "f32"}[info.format],
+        return {"width": info.width, "height": info.height, "format": {0: "rgba8", 1: "srgb8", 3: "f32", 4: "f16"}[info.format],
                 "has_kernel": bool(info.has_kernel), "filter_linear": bool(info.filter_linear),
                 "wrap": ["clamp_to_edge", "clamp_to_border", "repeat", "mirrored_repeat"][info.wrap],
                 "kernel": info.kernel.decode(), "alias": info.alias.decode()}
@@ -505,7 +510,7 @@ class ShaderEngine:
         """Host copy (numpy) of pass i's render target for `frame` of the last batch."""
         import numpy as np
         info = self.passInfo(i)
-        dt = np.float32 if info["format"] == "f32" else np.uint8
+        dt = {"f32": np.float32, "f16": np.float16}.get(info["format"], np.uint8)
         arr = np.empty((info["height"], info["width"], 4), dt)
         rc = self._lib.rc_engine_read_pass(self._h, int(i), int(frame), arr.ctypes.data, arr.nbytes)
         if rc != 0:

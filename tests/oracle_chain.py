@@ -72,14 +72,16 @@ def _history_tex(arr):
 
 
 def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global_params=None, flags=0,
-              given=None, state=None, force_f32=False):
+              given=None, state=None, force_f32=False, f16_targets=False):
     """passes: list of dicts as produced by the preset dump (shader, filter_linear, wrap,
     alias, float_fb, srgb_fb, stx, sx, sty, sy).  rgb: (h, w, 3) uint8 source frame.
     luts: name -> (rgba array, linear, wrap).  given: optional list of per-pass arrays to feed forward
     instead of the oracle's own outputs (isolates each pass when checking against golden data).
     state: a ChainState carried from frame to frame (frame history); None = stateless.
     force_f32: every pass target is RGBA32F (the float-precision goldens, not the reference's formats).
-    Returns the list of per-pass outputs."""
+    f16_targets: float targets are stored as binary16 (the engine's opt-in setFloatTargetFp16): each float pass
+    output is rounded to nearest-even binary16 and the passes after it read the widened values.
+    Returns the list of per-pass outputs (float targets as float32 holding the rounded values when f16_targets)."""
     h, w, _ = rgb.shape
     src = np.concatenate([rgb, np.full((h, w, 1), 255, np.uint8)], -1)
     sizes = pass_sizes(passes, w, h, vw, vh)
@@ -188,6 +190,8 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
             o = np.zeros((oh, ow, 4), np.float32 if fmts[i] == "f32" else np.uint8)
         else:
             o = run_pass(spec["oracle"], cur, ow, oh, out_fmt=fmts[i], extra=extra, **call)
+        if f16_targets and fmts[i] == "f32":
+            o = o.astype(np.float16).astype(np.float32)
         outs.append(o)
         cur = tex_of_pass(i)
     if state is not None and state.feedback_enabled:
