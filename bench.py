@@ -110,7 +110,7 @@ def pmc_traffic(kernel_name, frames_per_launch):
              "k_royale_bloom_horizontal": "k_royale_bloom_h", "k_royale_bloom_vertical": "k_royale_bloom_v"}
     want = alias.get(want, want)
     rows = {r["kernel"]: r for r in csv.DictReader(open(files[-1]))}
-    for name in (want + "2", want):      # k_royale_scan_v2: the two-rows-per-thread form the fast path launches
+    for name in (want + "_strip", want + "_tab", want + "2", want):      # the form the fast path launches
         r = rows.get(name)
         if r and r.get("FETCH_SIZE_avg") and r.get("WRITE_SIZE_avg"):
             return (2.0 * float(r["FETCH_SIZE_avg"]) + float(r["WRITE_SIZE_avg"])) * 1024.0
@@ -128,7 +128,7 @@ def pmc_valu(kernel_name, frames_per_launch, avg_launch_ms):
         return None
     want = {"royale-scanlines-v": "k_royale_scan_v", "royale-bloom-h": "k_royale_bloom_h"}.get(kernel_name, "k_" + kernel_name.replace("-", "_"))
     rows = {r["kernel"]: r for r in csv.DictReader(open(files[-1]))}
-    for name in (want + "2", want):
+    for name in (want + "_strip", want + "_tab", want + "2", want):
         r = rows.get(name)
         if r and r.get("SQ_INSTS_VALU_avg"):
             insts = float(r["SQ_INSTS_VALU_avg"])
