@@ -208,7 +208,7 @@ void buildBvTables(const PassLaunch& L, hipStream_t s, BvTables* T) {
 // sampler clamps them) and the taps read decoded neighbours from there.  Per tap a thread holds (first texel, weight)
 // of its column - for both triangles - in registers (k_bloomh_geometry).  A row whose vertical weight is exactly 0
 // (the usual case at 1:1) filters one source row, any other row the pair the sampler would fetch.
-constexpr int kBhRows = 8;
+constexpr int kBhRows = 16;
 constexpr int kBhWaves = 4;
 constexpr int kBhSeg = 84;      // staged columns: 10 + 64 + 10
 constexpr int kBhSegLeft = 10;
@@ -298,9 +298,10 @@ __device__ __forceinline__ float3 dec3(uint32_t t, const SrgbLds& l) {
 
 // one target pixel; ring = this wave's three staged rows (row r in slot r % 3), `TWO`: the vertical weight is not 0
 // HALC: the two horizontally filtered halation rows of the pixel's row pair are handed over (hal_rows[0..2], [3..5])
-template <class SO, bool TWO, bool HALC>
+// PRE: the texels of the two NEAREST taps were fetched ahead (pre_idim, pre_bright)
+template <class SO, bool TWO, bool HALC, bool PRE = false>
 __device__ __forceinline__ void bloomh_pixel(const PassLaunch& L, const SrgbLds& lds, const uint8_t* ring, const BhCol& c, const BhRow& r,
-                                             int x, int y, int z, const float* hal_rows) {
+                                             int x, int y, int z, const float* hal_rows, uint32_t pre_idim = 0u, uint32_t pre_bright = 0u) {
   const float* P = L.params;
   const int Hin = L.in.h;
   const uint8_t* rowA = ring + (uint32_t)(clampi(r.y0, 0, Hin - 1) % 3) * (kBhSeg * 16u);
@@ -338,7 +339,8 @@ __device__ __forceinline__ void bloomh_pixel(const PassLaunch& L, const SrgbLds&
   const uint32_t* i0 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[0], z));
   const uint32_t* i1 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[1], z));
   const uint32_t* i2 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[2], z));
-  const float3 idim = dec3(i0[r.idim_y * L.extra[0].w + c.idim_x], lds), bright = dec3(i1[r.bright_y * L.extra[1].w + c.bright_x], lds);
+  const float3 idim = dec3(PRE ? pre_idim : i0[r.idim_y * L.extra[0].w + c.idim_x], lds);
+  const float3 bright = dec3(PRE ? pre_bright : i1[r.bright_y * L.extra[1].w + c.bright_x], lds);
   float3 hal;
   if (HALC) {
     hal = lerp3(r.hal_wy, make_float3(hal_rows[0], hal_rows[1], hal_rows[2]), make_float3(hal_rows[3], hal_rows[4], hal_rows[5]));
@@ -380,32 +382,35 @@ __device__ __forceinline__ BhCol load_bh_col(const uint32_t* cols, int W, int xc
   return c;
 }
 
-// One strip.  MODE 0 / 1: every pixel of it lies in the lower / upper triangle (all but the few strips the quad's
-// diagonal crosses): one set of column quantities in registers, row quantities wave-uniform.  MODE 2: per-lane selection.
-template <class SO, int MODE>
-__device__ __forceinline__ void bloomh_strip(const PassLaunch& L, const SrgbLds& lds, uint8_t* ring, const uint32_t* __restrict__ cols,
-                                             const uint32_t* __restrict__ rows, int z, int xw, int ys, int lane) {
+// One strip whose pixels all lie in one triangle (SIDE 0 lower, 1 upper: all but the few strips the quad's diagonal
+// crosses): one set of column quantities in registers, row quantities wave-uniform.  The loop is software-pipelined:
+// the row quantities, the texels of the next source row to stage and the texels of the two NEAREST taps of the
+// next target row are fetched one iteration ahead, so that their latency hides behind the current row's arithmetic.
+template <class SO, int SIDE>
+__device__ __forceinline__ void bloomh_strip_side(const PassLaunch& L, const SrgbLds& lds, uint8_t* ring, const uint32_t* __restrict__ cols,
+                                                  const uint32_t* __restrict__ rows, int z, int xw, int ys, int lane) {
   const int W = L.out_w, H = L.out_h, Win = L.in.w, Hin = L.in.h;
   const int x = xw + lane;
   const bool live = x < W;
   const int xc = live ? x : W - 1;
-  BhCol c0;
-  if (MODE != 2) c0 = load_bh_col(cols, W, xc, xw, MODE == 1 ? 1 : 0);
+  const BhCol c0 = load_bh_col(cols, W, xc, xw, SIDE);
   const uint32_t* img = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
-  // source rows are staged in increasing order; row r lives in ring slot r % 3
-  auto stage = [&](int r) {
-    float4* slot = reinterpret_cast<float4*>(ring) + (r % 3) * kBhSeg;
-    for (int j = lane; j < kBhSeg; j += 64) {
-      const uint32_t t = img[r * Win + clampi(xw - kBhSegLeft + j, 0, Win - 1)];
-      slot[j] = make_float4(lds.dec[t & 255u], lds.dec[(t >> 8) & 255u], lds.dec[(t >> 16) & 255u], 0.0f);
-    }
-  };
-  int staged = -1;   // highest source row staged so far
-  // the halation blur (320x240) is magnified: its row pair changes every few target rows; keep the pair's two
-  // horizontally filtered rows (MODE 0 / 1)
-  float hal_rows[6];
-  int hal_have = -1000;
+  const uint32_t* i0 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[0], z));
+  const uint32_t* i1 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[1], z));
   const uint32_t* himg = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[2], z));
+  // the staged segment: columns xw - 10 .. xw + 73 (clamped like the sampler clamps them); lane l fetches column
+  // l and, for l < 20, column 64 + l
+  const int sx0 = clampi(xw - kBhSegLeft + lane, 0, Win - 1), sx1 = clampi(xw - kBhSegLeft + 64 + lane, 0, Win - 1);
+  const bool second = lane < kBhSeg - 64;
+  auto fetch_row = [&](int r, uint32_t* t0, uint32_t* t1) {
+    *t0 = img[r * Win + sx0];
+    *t1 = second ? img[r * Win + sx1] : 0u;
+  };
+  auto store_row = [&](int r, uint32_t t0, uint32_t t1) {   // row r lives in ring slot r % 3
+    float4* slot = reinterpret_cast<float4*>(ring) + (r % 3) * kBhSeg;
+    slot[lane] = make_float4(lds.dec[t0 & 255u], lds.dec[(t0 >> 8) & 255u], lds.dec[(t0 >> 16) & 255u], 0.0f);
+    if (second) slot[64 + lane] = make_float4(lds.dec[t1 & 255u], lds.dec[(t1 >> 8) & 255u], lds.dec[(t1 >> 16) & 255u], 0.0f);
+  };
   auto hal_hrow = [&](int r, float* h) {
     const int hw = L.extra[2].w;
     const uint32_t* p = himg + clampi(r, 0, L.extra[2].h - 1) * hw;
@@ -416,45 +421,102 @@ __device__ __forceinline__ void bloomh_strip(const PassLaunch& L, const SrgbLds&
       h[ch] = fma_(c0.hal_w, b - a, a);
     }
   };
+  int staged = -1;        // highest source row in the ring
+  int pre_row = -1;       // source row whose texels are in pre_t0 / pre_t1 (fetched ahead), or -1
+  uint32_t pre_t0 = 0u, pre_t1 = 0u;
+  float hal_rows[6];      // the two horizontally filtered halation rows of the current pair (changes every few rows)
+  int hal_have = -1000;
+  BhRow cur = load_bh_row(rows, ys, SIDE);
+  uint32_t cur_idim = i0[cur.idim_y * L.extra[0].w + c0.idim_x], cur_bright = i1[cur.bright_y * L.extra[1].w + c0.bright_x];
 #pragma unroll 1
   for (int k = 0; k < kBhRows; ++k) {
     const int y = ys + k;
     if (y >= H) break;
-    const BhRow r0 = load_bh_row(rows, y, MODE == 1 ? 1 : 0);
-    if (MODE != 2 && r0.hal_y0 != hal_have) {
-      if (r0.hal_y0 == hal_have + 1) {
+    const int need_lo = clampi(cur.y0, 0, Hin - 1), need_hi = clampi(cur.y0 + 1, 0, Hin - 1);   // k_bloomh_geometry: y - 1 <= y0 <= y
+    // ---- stage what this row needs (normally: nothing, or the one row fetched during the previous iteration).
+    // Other lanes read what a lane writes here: the compiler must not move LDS accesses across the staging (the LDS
+    // itself executes a wave's operations in order); a compiler-level memory barrier does that without draining the
+    // loads that were issued ahead.
+    if (staged < need_lo - 1) staged = need_lo - 1;
+    asm volatile("" ::: "memory");
+    while (staged < need_hi) {
+      ++staged;
+      if (staged == pre_row) {
+        store_row(staged, pre_t0, pre_t1);
+      } else {
+        uint32_t t0, t1;
+        fetch_row(staged, &t0, &t1);
+        store_row(staged, t0, t1);
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- fetch ahead for the next target row: its row quantities, the texels of its two NEAREST taps, and the source
+    // row it will add to the ring (at most one: y0 grows by at most 1 per row)
+    const int yn = y + 1 < H ? y + 1 : y;
+    const BhRow nxt = load_bh_row(rows, yn, SIDE);
+    const uint32_t nxt_idim = i0[nxt.idim_y * L.extra[0].w + c0.idim_x], nxt_bright = i1[nxt.bright_y * L.extra[1].w + c0.bright_x];
+    const int next_hi = clampi(nxt.y0 + 1, 0, Hin - 1);
+    pre_row = -1;
+    if (next_hi > staged) {
+      pre_row = staged + 1;
+      fetch_row(pre_row, &pre_t0, &pre_t1);
+    }
+    if (cur.hal_y0 != hal_have) {
+      if (cur.hal_y0 == hal_have + 1) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) hal_rows[ch] = hal_rows[3 + ch];
       } else {
-        hal_hrow(r0.hal_y0, hal_rows);
+        hal_hrow(cur.hal_y0, hal_rows);
       }
-      hal_hrow(r0.hal_y0 + 1, hal_rows + 3);
-      hal_have = r0.hal_y0;
+      hal_hrow(cur.hal_y0 + 1, hal_rows + 3);
+      hal_have = cur.hal_y0;
     }
-    BhRow r1 = r0;
-    if (MODE == 2) r1 = load_bh_row(rows, y, 1);
-    // rows this target row needs: y0 and y0 + 1, clamped; k_bloomh_geometry checked y - 1 <= y0 <= y
+    if (live) {
+      if (cur.wy != 0.0f) bloomh_pixel<SO, true, true, true>(L, lds, ring, c0, cur, x, y, z, hal_rows, cur_idim, cur_bright);
+      else bloomh_pixel<SO, false, true, true>(L, lds, ring, c0, cur, x, y, z, hal_rows, cur_idim, cur_bright);
+    }
+    cur = nxt;
+    cur_idim = nxt_idim;
+    cur_bright = nxt_bright;
+  }
+}
+
+// A strip the quad's diagonal crosses (rare): per-lane triangle, the column quantities come from memory per pixel.
+template <class SO>
+__device__ __forceinline__ void bloomh_strip_mixed(const PassLaunch& L, const SrgbLds& lds, uint8_t* ring, const uint32_t* __restrict__ cols,
+                                                   const uint32_t* __restrict__ rows, int z, int xw, int ys, int lane) {
+  const int W = L.out_w, H = L.out_h, Win = L.in.w, Hin = L.in.h;
+  const int x = xw + lane;
+  const bool live = x < W;
+  const int xc = live ? x : W - 1;
+  const uint32_t* img = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
+  auto stage = [&](int r) {
+    float4* slot = reinterpret_cast<float4*>(ring) + (r % 3) * kBhSeg;
+    for (int j = lane; j < kBhSeg; j += 64) {
+      const uint32_t t = img[r * Win + clampi(xw - kBhSegLeft + j, 0, Win - 1)];
+      slot[j] = make_float4(lds.dec[t & 255u], lds.dec[(t >> 8) & 255u], lds.dec[(t >> 16) & 255u], 0.0f);
+    }
+  };
+  int staged = -1;
+#pragma unroll 1
+  for (int k = 0; k < kBhRows; ++k) {
+    const int y = ys + k;
+    if (y >= H) break;
+    const BhRow r0 = load_bh_row(rows, y, 0), r1 = load_bh_row(rows, y, 1);
     const int need_lo = clampi(min(r0.y0, r1.y0), 0, Hin - 1);
     const int need_hi = clampi(max(r0.y0, r1.y0) + 1, 0, Hin - 1);
     if (staged < need_lo - 1) staged = need_lo - 1;
-    // (other lanes' reads of the slot being replaced, and their reads of what is written now, must not be moved
-    // across the staging by the compiler: LDS operations of a wave execute in order, a wavefront fence pins them)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     while (staged < need_hi) stage(++staged);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (!live) continue;
-    if (MODE != 2) {
-      if (r0.wy != 0.0f) bloomh_pixel<SO, true, true>(L, lds, ring, c0, r0, x, y, z, hal_rows);
-      else bloomh_pixel<SO, false, true>(L, lds, ring, c0, r0, x, y, z, hal_rows);
-    } else {
-      // (rare: the column quantities of this pixel's triangle come from memory instead of registers)
-      const bool lo = rcd::lower_tri(x, y, W, H);
-      const BhCol c = load_bh_col(cols, W, xc, xw, lo ? 0 : 1);
-      const BhRow r{lo ? r0.y0 : r1.y0, lo ? r0.wy : r1.wy, lo ? r0.idim_y : r1.idim_y, lo ? r0.bright_y : r1.bright_y,
-                    lo ? r0.hal_y0 : r1.hal_y0, lo ? r0.hal_wy : r1.hal_wy};
-      bloomh_pixel<SO, true, false>(L, lds, ring, c, r, x, y, z, nullptr);
-    }
+    const bool lo = rcd::lower_tri(x, y, W, H);
+    const BhCol c = load_bh_col(cols, W, xc, xw, lo ? 0 : 1);
+    const BhRow r{lo ? r0.y0 : r1.y0, lo ? r0.wy : r1.wy, lo ? r0.idim_y : r1.idim_y, lo ? r0.bright_y : r1.bright_y,
+                  lo ? r0.hal_y0 : r1.hal_y0, lo ? r0.hal_wy : r1.hal_wy};
+    bloomh_pixel<SO, true, false>(L, lds, ring, c, r, x, y, z, nullptr);
   }
 }
 
@@ -473,9 +535,9 @@ __global__ void __launch_bounds__(kBhWaves * 64, 3) k_royale_bloom_h_strip(const
     // the lower triangle holds the pixels with (2y+1) W <= (2x+1) H: the strip is all lower if its (min x, max y)
     // pixel is, all upper if its (max x, min y) pixel is not
     const int xmax = min(xw + 63, W - 1), ymax = min(ys + kBhRows - 1, H - 1);
-    if (rcd::lower_tri(xw, ymax, W, H)) bloomh_strip<SO, 0>(L, lds, ring, cols, rows, z, xw, ys, lane);
-    else if (!rcd::lower_tri(xmax, ys, W, H)) bloomh_strip<SO, 1>(L, lds, ring, cols, rows, z, xw, ys, lane);
-    else bloomh_strip<SO, 2>(L, lds, ring, cols, rows, z, xw, ys, lane);
+    if (rcd::lower_tri(xw, ymax, W, H)) bloomh_strip_side<SO, 0>(L, lds, ring, cols, rows, z, xw, ys, lane);
+    else if (!rcd::lower_tri(xmax, ys, W, H)) bloomh_strip_side<SO, 1>(L, lds, ring, cols, rows, z, xw, ys, lane);
+    else bloomh_strip_mixed<SO>(L, lds, ring, cols, rows, z, xw, ys, lane);
   }
 }
 
