@@ -116,6 +116,13 @@ typedef struct {
  * drivers that hand back 0 for such a varying render the resized mask instead. */
 #define O_FLAG_ROYALE_UNDEF_VARYING_ZERO 1
 
+/* scalefx/scalefx.glslp (rc_passes_scalefx.c): pass 1 params SFX_CLR, SFX_SAA; pass 2 extra[0] = PassPrev2Texture;
+ * pass 3 param SFX_SCN; pass 4 extra[0] = PassPrev5Texture (the original frame) */
+void o_pass_scalefx0(const o_pass_args* a);
+void o_pass_scalefx1(const o_pass_args* a);
+void o_pass_scalefx2(const o_pass_args* a);
+void o_pass_scalefx3(const o_pass_args* a);
+void o_pass_scalefx4(const o_pass_args* a);
 void o_pass_stock(const o_pass_args* a);
 void o_pass_scanline(const o_pass_args* a);
 void o_pass_crt_pi(const o_pass_args* a);

@@ -226,6 +226,15 @@ std::vector<KernelEntry> build() {
                {{"brighten_scanlines", 16.0f, 1.0f, 32.0f, 0.5f, "Brighten Scanlines"}, {"brighten_lcd", 4.0f, 1.0f, 12.0f, 0.1f, "Brighten LCD"}},
                {}, rck::launch_lcd3x, setupTexCoord, true});
   r.push_back({"scalenx/shaders/epx.glsl", "epx", {}, {}, rck::launch_epx, setupTexCoord, true});
+  // scalefx/scalefx.glslp (kernels/pass_scalefx.hip): TEX0 = TexCoord in every pass
+  r.push_back({"scalefx/shaders/scalefx-pass0.glsl", "scalefx-pass0", {}, {}, rck::launch_scalefx0, setupTexCoord, true});
+  r.push_back({"scalefx/shaders/scalefx-pass1.glsl", "scalefx-pass1",
+               {{"SFX_CLR", 0.50f, 0.01f, 1.00f, 0.01f, "ScaleFX Threshold"}, {"SFX_SAA", 1.00f, 0.00f, 1.00f, 1.00f, "ScaleFX Filter AA"}},
+               {}, rck::launch_scalefx1, setupTexCoord, true});
+  r.push_back({"scalefx/shaders/scalefx-pass2.glsl", "scalefx-pass2", {}, {"PassPrev2Texture"}, rck::launch_scalefx2, setupTexCoord, true});
+  r.push_back({"scalefx/shaders/scalefx-pass3.glsl", "scalefx-pass3", {{"SFX_SCN", 1.0f, 0.0f, 1.0f, 1.0f, "ScaleFX Filter Corners"}},
+               {}, rck::launch_scalefx3, setupTexCoord, true});
+  r.push_back({"scalefx/shaders/scalefx-pass4.glsl", "scalefx-pass4", {}, {"PassPrev5Texture"}, rck::launch_scalefx4, setupTexCoord, true});
   r.push_back({"interpolation/shaders/quilez.glsl", "quilez", {}, {}, rck::launch_quilez, setupTexCoord, true});
   r.push_back({"interpolation/shaders/smootheststep.glsl", "smootheststep", {}, {}, rck::launch_smootheststep, setupTexCoord, true});
   r.push_back({"interpolation/shaders/sharp-bilinear.glsl", "sharp-bilinear",

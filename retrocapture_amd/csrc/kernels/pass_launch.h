@@ -36,6 +36,11 @@ hipError_t launch_ntsc_pass2_2phase_linear(const PassLaunch& L, hipStream_t s);
 hipError_t launch_ntsc_pass2_2phase_plain(const PassLaunch& L, hipStream_t s);
 hipError_t launch_xbr_lv3(const PassLaunch& L, hipStream_t s);
 hipError_t launch_xbr_lv2(const PassLaunch& L, hipStream_t s);
+hipError_t launch_scalefx0(const PassLaunch& L, hipStream_t s);
+hipError_t launch_scalefx1(const PassLaunch& L, hipStream_t s);
+hipError_t launch_scalefx2(const PassLaunch& L, hipStream_t s);
+hipError_t launch_scalefx3(const PassLaunch& L, hipStream_t s);
+hipError_t launch_scalefx4(const PassLaunch& L, hipStream_t s);
 hipError_t launch_glow_linearize(const PassLaunch& L, hipStream_t s);
 hipError_t launch_glow_threshold(const PassLaunch& L, hipStream_t s);
 hipError_t launch_glow_blur_h(const PassLaunch& L, hipStream_t s);

@@ -91,6 +91,36 @@ filter_linear5 = true
     "bilinear": ("bilinear.glslp", 'shaders = 1\n\nshader0 = stock.glsl\nfilter_linear0 = true\n'),
     "crt-easymode": ("crt/crt-easymode.glslp", 'shaders = 1\n\nshader0 = shaders/crt-easymode.glsl\nfilter_linear0 = false\n'),
     "crt-nes-mini": ("crt/crt-nes-mini.glslp", 'shaders = 1\n\nshader0 = shaders/crt-nes-mini.glsl\n'),
+    # same keys / values as the reference's scalefx/scalefx.glslp
+    "scalefx": ("scalefx/scalefx.glslp", """shaders = 5
+
+shader0 = shaders/scalefx-pass0.glsl
+filter_linear0 = false
+scale_type0 = source
+scale0 = 1.0
+float_framebuffer0 = true
+
+shader1 = shaders/scalefx-pass1.glsl
+filter_linear1 = false
+scale_type1 = source
+scale1 = 1.0
+float_framebuffer1 = true
+
+shader2 = shaders/scalefx-pass2.glsl
+filter_linear2 = false
+scale_type2 = source
+scale2 = 1.0
+
+shader3 = shaders/scalefx-pass3.glsl
+filter_linear3 = false
+scale_type3 = source
+scale3 = 1.0
+
+shader4 = shaders/scalefx-pass4.glsl
+filter_linear4 = false
+scale_type4 = source
+scale4 = 3.0
+"""),
     "epx": ("scalenx/epx.glslp", 'shaders = 1\n\nshader0 = shaders/epx.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 2.0\n'),
     "lcd1x": ("handheld/lcd1x.glslp", 'shaders = "1"\n\nshader0 = "shaders/lcd1x.glsl"\n\nfilter_linear0 = "false"\nwrap_mode0 = "clamp_to_border"\n'
                                       'mipmap_input0 = "false"\nalias0 = ""\nfloat_framebuffer0 = "false"\nsrgb_framebuffer0 = "false"\n'),
@@ -327,6 +357,11 @@ SHADERS = {
     "crt/shaders/crt-nes-mini.glsl": {"oracle": "crt_nes_mini",
                                       "params": [("SCANTHICK", 2.0), ("INTENSITY", 0.15), ("BRIGHTBOOST", 0.15)], "samplers": []},
     "scalenx/shaders/epx.glsl": {"oracle": "epx", "params": [], "samplers": []},
+    "scalefx/shaders/scalefx-pass0.glsl": {"oracle": "scalefx0", "params": [], "samplers": []},
+    "scalefx/shaders/scalefx-pass1.glsl": {"oracle": "scalefx1", "params": [("SFX_CLR", 0.5), ("SFX_SAA", 1.0)], "samplers": []},
+    "scalefx/shaders/scalefx-pass2.glsl": {"oracle": "scalefx2", "params": [], "samplers": ["PassPrev2Texture"]},
+    "scalefx/shaders/scalefx-pass3.glsl": {"oracle": "scalefx3", "params": [("SFX_SCN", 1.0)], "samplers": []},
+    "scalefx/shaders/scalefx-pass4.glsl": {"oracle": "scalefx4", "params": [], "samplers": ["PassPrev5Texture"]},
     "handheld/shaders/lcd1x.glsl": {"oracle": "lcd1x", "params": [("BRIGHTEN_SCANLINES", 16.0), ("BRIGHTEN_LCD", 4.0)], "samplers": []},
     "handheld/shaders/lcd3x.glsl": {"oracle": "lcd3x", "params": [("brighten_scanlines", 16.0), ("brighten_lcd", 4.0)], "samplers": []},
     "dithering/shaders/bayer-matrix-dithering.glsl": {"oracle": "bayer", "params": [("animate", 0.0), ("dither_size", 0.0)], "samplers": []},

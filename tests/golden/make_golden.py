@@ -479,6 +479,28 @@ def case_epx():
     run_case("epx_mixed_64x48_to_64x48", GLSL + "/scalenx/epx.glslp", mixed(64, 48, 141), 64, 48)
 
 
+def pixelart(w, h, seed):
+    """Flat blocks of a six-colour palette, one-pixel diagonals and a noise patch: what ScaleFX's edge levels act on."""
+    rng = np.random.default_rng(seed)
+    pal = rng.integers(0, 256, (6, 3), dtype=np.uint8)
+    low = rng.integers(0, 6, (h // 4 + 1, w // 4 + 1))
+    img = pal[np.kron(low, np.ones((4, 4), int))[:h, :w]]
+    for i in range(min(w, h)):
+        img[i, (i * 2) % w] = pal[(i // 3) % 6]
+    img[h // 2:h // 2 + 8, w // 2:w // 2 + 12] = rng.integers(0, 256, (8, 12, 3), dtype=np.uint8)
+    return img
+
+
+def case_scalefx():
+    """scalefx/scalefx.glslp (5 passes, two RGBA32F metric targets, PassPrev2Texture / PassPrev5Texture = original frame);
+    the last pass scales source x 3, so the viewport does not matter."""
+    Q = GLSL + "/scalefx/scalefx.glslp"
+    run_case("scalefx_48x40", Q, pixelart(48, 40, 1), 144, 120)
+    run_case("scalefx_noise_37x29", Q, noise(37, 29, 171), 64, 64)
+    run_case("scalefx_params_56x44", Q, pixelart(56, 44, 172), 100, 100, params=[("SFX_CLR", 0.35), ("SFX_SAA", 0.0), ("SFX_SCN", 0.0)])
+    run_case("f32_scalefx_40x32", Q, pixelart(40, 32, 173), 120, 96, f32=True)
+
+
 def case_lcd3x():
     Q = GLSL + "/handheld/lcd1x.glslp"
     run_case("lcd1x_64x48_to_192x144", Q, mixed(64, 48, 153), 192, 144)
@@ -507,7 +529,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -30,6 +30,9 @@ GOLDEN_CASES = {
     "xbr_lv3_noise_40x36_to_240x216": "xbr-lv3",
     "xbr_lv3_corner1_40x36_to_200x180": "xbr-lv3",
     "xbr_lv3_corner2_40x36_to_240x216": "xbr-lv3",
+    "scalefx_48x40": "scalefx",                                 # 5 passes, two RGBA32F metric targets, PassPrev5 = original frame
+    "scalefx_noise_37x29": "scalefx",
+    "scalefx_params_56x44": "scalefx",
 }
 
 
@@ -298,6 +301,7 @@ def test_royale_interlaced_source_and_batch(preset_tree, rc_lib):
     ("ntsc-2phase-plain", 31, 20, 60, 41),
     ("ntsc-256px-svideo", 1, 1, 3, 2),
     ("xbr-lv3", 37, 29, 259, 203),      # 7x, ragged
+    ("scalefx", 70, 41, 64, 64),         # output 3x the source whatever the viewport
     ("xbr-lv3", 2, 2, 9, 7),
     ("xbr-lv3", 64, 56, 64, 56),        # 1:1
 ])

@@ -13,6 +13,9 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 # golden file prefix -> preset text key
 CASES = {
+    "scalefx_48x40": "scalefx",
+    "scalefx_noise_37x29": "scalefx",
+    "scalefx_params_56x44": "scalefx",            # SFX_CLR 0.35, SFX_SAA 0, SFX_SCN 0
     "scanline_320x240": "scanline",
     "scanline_64x48_to_160x100": "scanline",
     "crt_pi_96x64_to_192x128": "crt-pi",
@@ -182,6 +185,7 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
 # before it.  Floor = fraction of float components that must be bit-identical; below 1.0 only where a
 # last-bit residual is known and documented.
 FLOAT_CASES = {
+    "f32_scalefx_40x32": ("scalefx", {}),
     "f32_scanline_64x48_to_160x100": ("scanline", {}),
     "f32_crt_pi_80x60_to_250x190": ("crt-pi", {}),
     "f32_ntsc_svideo_96x64_to_256x192": ("ntsc-256px-svideo", {}),
