@@ -271,6 +271,11 @@ int rc_selftest_srgb8_device(int device, const float* d_src, uint8_t* d_dst, siz
  * 9 = scanline * 3 + channel.  Returns the node count (also with null pointers), negative on error. */
 int rc_selftest_royale_scan_tables(float off, float* A, uint32_t* B, size_t a_floats, size_t b_words);
 
+/* crt/crt-geom.glslp: what the shader's VERTEX stage hands every pixel (it depends on uniforms only), evaluated on the
+ * host exactly as the engine does per launch (csrc/kernels/geom_math.h): params = the 17 #pragma parameters in
+ * declaration order, out = sinangle.xy, cosangle.xy, stretch.xyz.  For tests against the oracle; no GPU needed. */
+int rc_selftest_crt_geom_vertex(const float* params, float* out);
+
 const char* rc_last_error(void);
 const char* rc_version(void);
 /* Names of the registered kernels ("identity\n" list) for diagnostics. */

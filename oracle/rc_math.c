@@ -53,7 +53,12 @@ float o_log2(float x) {
   return fmaf(y, p, logexp);
 }
 
-float o_pow(float x, float y) { return o_exp2(o_log2(x) * y); }
+/* lp_build_pow selects 0 where "x == 0" under an unordered compare, so a NaN base gives 0 too (measured:
+ * pow(NaN, y) = 0 for quiet / signalling / negative NaNs, while log2(NaN) and exp2(NaN) are NaN) */
+float o_pow(float x, float y) {
+  if (x != x) return 0.0f;
+  return o_exp2(o_log2(x) * y);
+}
 float o_exp(float x) { return o_exp2(x * 1.4426950408889634f); }
 float o_log(float x) { return o_log2(x) * 0.69314718055994529f; }
 

@@ -127,6 +127,9 @@ void o_pass_stock(const o_pass_args* a);
 void o_pass_scanline(const o_pass_args* a);
 void o_pass_crt_pi(const o_pass_args* a);
 void o_pass_crt_easymode(const o_pass_args* a);        /* 17 params */
+void o_pass_crt_geom(const o_pass_args* a);            /* 17 params; reads FrameCount (rc_passes_geom.c) */
+float o_acos(float x);
+void o_crt_geom_vertex(const float* params, float* out); /* sinangle.xy, cosangle.xy, stretch.xyz */
 void o_pass_crt_nes_mini(const o_pass_args* a);        /* 3 params */
 void o_pass_bayer(const o_pass_args* a);               /* 2 params; reads FrameCount */
 void o_pass_epx(const o_pass_args* a);

@@ -41,6 +41,7 @@ o_vec4 o_texel(const o_tex* t, int x, int y) {
   return v4((float)p[0] * k, (float)p[1] * k, (float)p[2] * k, (float)p[3] * k);
 }
 
+static inline int nan_to_min(float f) { return f != f ? (-2147483647 - 1) : (int)f; }
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 static inline int modi(int v, int n) { int r = v % n; return r < 0 ? r + n : r; }
 static inline int mirrori(int v, int n) { int p = modi(v, 2 * n); return p < n ? p : 2 * n - 1 - p; }
@@ -74,7 +75,8 @@ o_vec4 o_sample(const o_tex* t, float s, float v) {
   if (!t->linear) {
     float fs = s, fv = v;
     if (t->wrap == O_WRAP_REPEAT) { fs = s - floorf(s); fv = v - floorf(v); }
-    int x = (int)floorf(fs * (float)t->w), y = (int)floorf(fv * (float)t->h);
+    /* a NaN coordinate converts to INT_MIN (cvttps2dq): texel 0 after clamp-to-edge, the border otherwise */
+    int x = nan_to_min(floorf(fs * (float)t->w)), y = nan_to_min(floorf(fv * (float)t->h));
     if (t->wrap == O_WRAP_REPEAT) { x = clampi(x, 0, t->w - 1); y = clampi(y, 0, t->h - 1); }
     return fetch_wrapped(t, x, y);
   }

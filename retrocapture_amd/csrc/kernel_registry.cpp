@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "kernels/geom_math.h"
 #include "royale_setup.h"
 #include "varying.h"
 
@@ -26,6 +27,17 @@ void setupCrtPi(const PassGeometry& g, rcd::PassLaunch& L) {
   L.plane[1] = planeV(1.0001f, g.out_w, g.out_h, g.out_fmt);
 }
 
+// crt-geom.glsl VS 176-206: TEX0 = TexCoord * 1.0001, mod_factor = TexCoord.x * TextureSize.x * OutputSize.x / InputSize.x,
+// and sinangle / cosangle / stretch, which depend on uniforms only (the same value at all four vertices, so the plane
+// equations hand every pixel that value unchanged): evaluated here with the device's own float primitives.
+void setupCrtGeom(const PassGeometry& g, rcd::PassLaunch& L) {
+  L.plane[0] = planeU(1.0001f, g.out_w, g.out_h, g.out_fmt);
+  L.plane[1] = planeV(1.0001f, g.out_w, g.out_h, g.out_fmt);
+  const float tsx = (float)g.in_w;
+  const float mf1 = ((1.0f * tsx) * (float)g.out_w) / tsx;
+  L.plane[2] = makePlane(0.f, mf1, mf1, 0.f, g.out_w, g.out_h, g.out_fmt);
+  rcgeom::vertex_constants(L.params);
+}
 // glow/blur_{horiz,vert}.glsl: the nine weights exp(-0.35 i^2) and their sum.  The loop is unrolled by the GL's
 // compiler and exp() of a constant folded with a correctly rounded exp, not the run-time polynomial.
 void setupGlowBlur(const PassGeometry& g, rcd::PassLaunch& L) {
@@ -246,6 +258,26 @@ std::vector<KernelEntry> build() {
                 {"INTENSITY", 0.15f, 0.0f, 1.0f, 0.01f, "Scanline Intensity"},
                 {"BRIGHTBOOST", 0.15f, 0.0f, 1.0f, 0.01f, "Luminance Boost"}},
                {}, rck::launch_crt_nes_mini, setupNesMini, false});
+  // crt/crt-geom.glslp (kernels/pass_geom.hip); reads FrameCount (interlacing simulation for >= 400 source lines)
+  r.push_back({"crt/shaders/crt-geom.glsl", "crt-geom",
+               {{"CRTgamma", 2.4f, 0.1f, 5.0f, 0.1f, "CRTGeom Target Gamma"},
+                {"monitorgamma", 2.2f, 0.1f, 5.0f, 0.1f, "CRTGeom Monitor Gamma"},
+                {"d", 1.6f, 0.1f, 3.0f, 0.1f, "CRTGeom Distance"},
+                {"CURVATURE", 1.0f, 0.0f, 1.0f, 1.0f, "CRTGeom Curvature Toggle"},
+                {"R", 2.0f, 0.1f, 10.0f, 0.1f, "CRTGeom Curvature Radius"},
+                {"cornersize", 0.03f, 0.001f, 1.0f, 0.005f, "CRTGeom Corner Size"},
+                {"cornersmooth", 1000.0f, 80.0f, 2000.0f, 100.0f, "CRTGeom Corner Smoothness"},
+                {"x_tilt", 0.0f, -0.5f, 0.5f, 0.05f, "CRTGeom Horizontal Tilt"},
+                {"y_tilt", 0.0f, -0.5f, 0.5f, 0.05f, "CRTGeom Vertical Tilt"},
+                {"overscan_x", 100.0f, -125.0f, 125.0f, 1.0f, "CRTGeom Horiz. Overscan %"},
+                {"overscan_y", 100.0f, -125.0f, 125.0f, 1.0f, "CRTGeom Vert. Overscan %"},
+                {"DOTMASK", 0.3f, 0.0f, 1.0f, 0.1f, "CRTGeom Dot Mask Strength"},
+                {"SHARPER", 1.0f, 1.0f, 3.0f, 1.0f, "CRTGeom Sharpness"},
+                {"scanline_weight", 0.3f, 0.1f, 0.5f, 0.05f, "CRTGeom Scanline Weight"},
+                {"lum", 0.0f, 0.0f, 1.0f, 0.01f, "CRTGeom Luminance"},
+                {"interlace_detect", 1.0f, 0.0f, 1.0f, 1.0f, "CRTGeom Interlacing Simulation"},
+                {"SATURATION", 1.0f, 0.0f, 2.0f, 0.05f, "CRTGeom Saturation"}},
+               {}, rck::launch_crt_geom, setupCrtGeom, false});
   r.push_back({"crt/shaders/crt-easymode.glsl", "crt-easymode",
                {{"SHARPNESS_H", 0.5f, 0.0f, 1.0f, 0.05f, "Sharpness Horizontal"},
                 {"SHARPNESS_V", 1.0f, 0.0f, 1.0f, 0.05f, "Sharpness Vertical"},

@@ -14,6 +14,7 @@ hipError_t launch_scanline(const PassLaunch& L, hipStream_t s);
 hipError_t launch_crt_pi(const PassLaunch& L, hipStream_t s);
 hipError_t launch_zfast_crt(const PassLaunch& L, hipStream_t s);
 hipError_t launch_crt_easymode(const PassLaunch& L, hipStream_t s);
+hipError_t launch_crt_geom(const PassLaunch& L, hipStream_t s);   // pass_geom.hip
 hipError_t launch_crt_nes_mini(const PassLaunch& L, hipStream_t s);
 hipError_t launch_quilez(const PassLaunch& L, hipStream_t s);
 hipError_t launch_epx(const PassLaunch& L, hipStream_t s);

@@ -309,6 +309,8 @@ __device__ __forceinline__ float4 sample_nearest(const Tex& t, const uint8_t* im
     s = s - __builtin_floorf(s);
     v = v - __builtin_floorf(v);
   }
+  // a NaN coordinate converts to INT_MIN on the GL's CPU: the border (clamp-to-edge, like the (int)NaN = 0 here, lands on texel 0)
+  if (WRAP == WRAP_BORDER && (s != s || v != v)) return make_float4(0.f, 0.f, 0.f, 0.f);
   int x = (int)__builtin_floorf(s * (float)t.w), y = (int)__builtin_floorf(v * (float)t.h);
   if (WRAP == WRAP_REPEAT) {
     x = clampi(x, 0, t.w - 1);

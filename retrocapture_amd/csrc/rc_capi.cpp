@@ -8,6 +8,7 @@
 #include "png_lut.h"
 #include "rc_log.h"
 #include "frame_pipeline.h"
+#include "kernels/geom_math.h"
 #include "present_setup.h"
 #include "shader_engine.h"
 #include "srgb_encode.h"
@@ -386,6 +387,14 @@ int rc_selftest_royale_scan_tables(float off, float* A, uint32_t* B, size_t a_fl
     rck::royale_scan_tables_host(off, A, B);
     return (int)n;
   });
+}
+int rc_selftest_crt_geom_vertex(const float* params, float* out) {
+  if (!params || !out) return RC_ERR_INVALID;
+  float P[rcd::kMaxParams] = {};
+  for (int k = 0; k < 17; ++k) P[k] = params[k];
+  rcgeom::vertex_constants(P);
+  for (int k = 0; k < 7; ++k) out[k] = P[rcgeom::GP_SIN_X + k];
+  return RC_OK;
 }
 int rc_engine_history_count(rc_engine* e) { return e ? (int)e->impl.historyCount() : 0; }
 int rc_engine_read_history(rc_engine* e, int k, uint32_t* width, uint32_t* height, void* host, size_t bytes) {

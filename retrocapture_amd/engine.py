@@ -99,6 +99,7 @@ SYMBOLS = [
     ("rc_selftest_srgb8_host", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("rc_selftest_royale_scan_tables", C.c_int, [C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     ("rc_selftest_srgb8_device", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("rc_selftest_crt_geom_vertex", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rc_last_error", C.c_char_p, []),
     ("rc_version", C.c_char_p, []),
     ("rc_kernel_list", C.c_size_t, [C.c_char_p, C.c_size_t]),
@@ -313,6 +314,18 @@ def royale_scan_tables(off):
     if lib.rc_selftest_royale_scan_tables(C.c_float(off), A.ctypes.data, B.ctypes.data, A.size, B.size) != n:
         raise RcError("rc_selftest_royale_scan_tables failed")
     return A, B[..., 0].copy().view(np.float32), B[..., 1].copy().view(np.float32)
+
+
+def crt_geom_vertex(params):
+    """crt-geom's vertex-stage constants for 17 parameter values: (sinangle.xy, cosangle.xy, stretch.xyz) float32."""
+    import numpy as np
+    p = np.ascontiguousarray(params, np.float32)
+    if p.shape != (17,):
+        raise ValueError("17 parameters expected")
+    out = np.zeros(7, np.float32)
+    if load_library().rc_selftest_crt_geom_vertex(p.ctypes.data, out.ctypes.data) != 0:
+        raise RcError("rc_selftest_crt_geom_vertex failed")
+    return out
 
 
 def preset_save_as(preset_path, out_path, custom=None):

@@ -89,6 +89,7 @@ filter_linear5 = true
                           'shaders = 2\nshader0 = ../stock.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 2.0\n'
                           'shader1 = ../stock.glsl\nfilter_linear1 = true'),
     "bilinear": ("bilinear.glslp", 'shaders = 1\n\nshader0 = stock.glsl\nfilter_linear0 = true\n'),
+    "crt-geom": ("crt/crt-geom.glslp", 'shaders = 1\n\nshader0 = shaders/crt-geom.glsl\nfilter_linear0 = false\n'),
     "crt-easymode": ("crt/crt-easymode.glslp", 'shaders = 1\n\nshader0 = shaders/crt-easymode.glsl\nfilter_linear0 = false\n'),
     "crt-nes-mini": ("crt/crt-nes-mini.glslp", 'shaders = 1\n\nshader0 = shaders/crt-nes-mini.glsl\n'),
     # same keys / values as the reference's scalefx/scalefx.glslp
@@ -353,6 +354,13 @@ SHADERS = {
                    ("MASK_STAGGER", 0.0), ("MASK_SIZE", 1.0), ("SCANLINE_STRENGTH", 1.0), ("SCANLINE_BEAM_WIDTH_MIN", 1.5),
                    ("SCANLINE_BEAM_WIDTH_MAX", 1.5), ("SCANLINE_BRIGHT_MIN", 0.35), ("SCANLINE_BRIGHT_MAX", 0.65),
                    ("SCANLINE_CUTOFF", 400.0), ("GAMMA_INPUT", 2.0), ("GAMMA_OUTPUT", 1.8), ("BRIGHT_BOOST", 1.2), ("DILATION", 1.0)],
+        "samplers": []},
+    "crt/shaders/crt-geom.glsl": {
+        "oracle": "crt_geom",
+        "params": [("CRTgamma", 2.4), ("monitorgamma", 2.2), ("d", 1.6), ("CURVATURE", 1.0), ("R", 2.0), ("cornersize", 0.03),
+                   ("cornersmooth", 1000.0), ("x_tilt", 0.0), ("y_tilt", 0.0), ("overscan_x", 100.0), ("overscan_y", 100.0),
+                   ("DOTMASK", 0.3), ("SHARPER", 1.0), ("scanline_weight", 0.3), ("lum", 0.0), ("interlace_detect", 1.0),
+                   ("SATURATION", 1.0)],
         "samplers": []},
     "crt/shaders/crt-nes-mini.glsl": {"oracle": "crt_nes_mini",
                                       "params": [("SCANTHICK", 2.0), ("INTENSITY", 0.15), ("BRIGHTBOOST", 0.15)], "samplers": []},

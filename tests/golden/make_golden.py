@@ -501,6 +501,22 @@ def case_scalefx():
     run_case("f32_scalefx_40x32", Q, pixelart(40, 32, 173), 120, 96, f32=True)
 
 
+def case_crt_geom():
+    """crt/crt-geom.glslp: curvature + Lanczos2 + beam profile; the vertex shader computes the stretch
+    varyings (sin/cos/acos); a source of >= 400 lines turns the interlacing simulation on (FrameCount parity)."""
+    P = GLSL + "/crt/crt-geom.glslp"
+    run_case("crt_geom_96x64_to_301x217", P, mixed(96, 64, 130), 301, 217)
+    run_case("crt_geom_params_80x60_to_320x240", P, noise(80, 60, 131), 320, 240,
+             params=[("CRTgamma", 2.0), ("monitorgamma", 2.4), ("d", 2.0), ("R", 3.5), ("cornersize", 0.1), ("cornersmooth", 400.0),
+                     ("x_tilt", 0.2), ("y_tilt", -0.15), ("overscan_x", 104.0), ("overscan_y", 97.0), ("DOTMASK", 0.5),
+                     ("SHARPER", 2.0), ("scanline_weight", 0.25), ("lum", 0.1), ("SATURATION", 1.3)])
+    run_case("crt_geom_flat_72x56_to_288x224", P, mixed(72, 56, 132), 288, 224, params=[("CURVATURE", 0.0), ("interlace_detect", 0.0)])
+    run_case("crt_geom_interlace_40x400_to_160x300_f2", P, mixed(40, 400, 133), 160, 300, frames=2)
+    run_case("f32_crt_geom_64x48_to_200x150", P, mixed(64, 48, 134), 200, 150, f32=True)
+    run_case("f32_crt_geom_params_64x48_to_200x150", P, noise(64, 48, 135), 200, 150, f32=True,
+             params=[("x_tilt", -0.3), ("y_tilt", 0.25), ("R", 1.5), ("d", 1.2), ("SATURATION", 0.7), ("lum", 0.2)])
+
+
 def case_lcd3x():
     Q = GLSL + "/handheld/lcd1x.glslp"
     run_case("lcd1x_64x48_to_192x144", Q, mixed(64, 48, 153), 192, 144)
@@ -529,7 +545,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

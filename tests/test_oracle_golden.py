@@ -16,6 +16,10 @@ CASES = {
     "scalefx_48x40": "scalefx",
     "scalefx_noise_37x29": "scalefx",
     "scalefx_params_56x44": "scalefx",            # SFX_CLR 0.35, SFX_SAA 0, SFX_SCN 0
+    "crt_geom_96x64_to_301x217": "crt-geom",
+    "crt_geom_params_80x60_to_320x240": "crt-geom",            # tilt, overscan, corner, SHARPER 2, saturation ...
+    "crt_geom_flat_72x56_to_288x224": "crt-geom",              # CURVATURE 0
+    "crt_geom_interlace_40x400_to_160x300_f2": "crt-geom",     # >= 400 source lines: FrameCount parity shifts the field
     "scanline_320x240": "scanline",
     "scanline_64x48_to_160x100": "scanline",
     "crt_pi_96x64_to_192x128": "crt-pi",
@@ -186,6 +190,8 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
 # last-bit residual is known and documented.
 FLOAT_CASES = {
     "f32_scalefx_40x32": ("scalefx", {}),
+    "f32_crt_geom_64x48_to_200x150": ("crt-geom", {}),
+    "f32_crt_geom_params_64x48_to_200x150": ("crt-geom", {}),   # strong tilt: 42 pixels whose ray misses the tube (NaN geometry)
     "f32_scanline_64x48_to_160x100": ("scanline", {}),
     "f32_crt_pi_80x60_to_250x190": ("crt-pi", {}),
     "f32_ntsc_svideo_96x64_to_256x192": ("ntsc-256px-svideo", {}),
