@@ -1,5 +1,9 @@
+"""Per-pass device time of crt-royale at 1920x1080 (batch 8): MASK=1 renders the mask passes, PROF=1 prints microseconds
+per frame for passes 0..11 (engine pass profile), REPS = untimed repetitions.  Run from the repo root on the GPU box:
+    PROF=1 python3 profiles/time_royale_passes.py
+"""
 import sys, os, tempfile
-R=os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'tests'))
+R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'tests'))
 import numpy as np, torch, chain_specs
 from gpu_util import make_engine, run_engine, to_device_rgba
 tmp=tempfile.mkdtemp(); tree=chain_specs.write_tree(tmp)

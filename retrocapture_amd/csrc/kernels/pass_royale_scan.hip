@@ -28,8 +28,10 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
+#include "../rc_log.h"
 #include "royale_common.h"
 
 using namespace rcd;
@@ -609,7 +611,8 @@ const ScanTables* scanTablesFor(const PassLaunch& L, hipStream_t s) {
   }
   if (bad) (void)hipFree(bad);
   T.usable = ok && hbad == 0;
-  if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc scan] tables for %dx%d: hip ok %d, geometry flags %u\n", L.out_w, L.out_h, (int)ok, hbad);
+  RC_LOG_DEBUG("crt-royale scanline pass " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h) + ": expansion tables " +
+               (ok && hbad == 0 ? "in use" : "not usable (geometry flags " + std::to_string(hbad) + "), exact per-pixel form"));
   if (!T.usable) {
     if (T.A) (void)hipFree(T.A);
     if (T.B) (void)hipFree(T.B);
