@@ -48,6 +48,7 @@ WORKLOADS = {
     "xbr-lv3": ("xbr-lv3", 256, 224, 3840, 2160, "xbr/xbr-lv3.glslp 1-pass upscale 256x224 -> 3840x2160"),
     "xbr-lv2": ("xbr-lv2", 256, 224, 3840, 2160, "xbr/xbr-lv2.glslp 1-pass upscale 256x224 -> 3840x2160"),
     "scanline": ("scanline", 320, 240, 320, 240, "scanlines/shaders/scanline.glsl 1-pass, 320x240"),
+    "crt-geom": ("crt-geom", 640, 480, 1920, 1440, "crt/crt-geom.glslp 1-pass (curvature, interlacing simulation on), 640x480 -> 1920x1440"),
     "scalefx": ("scalefx", 256, 224, 768, 672, "scalefx/scalefx.glslp 5-pass pixel-art upscale 256x224 -> 768x672"),
 }
 
