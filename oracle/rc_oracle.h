@@ -115,6 +115,9 @@ typedef struct {
  * undefined value makes the fragment shader discard every pixel (default, flags = 0); GL
  * drivers that hand back 0 for such a varying render the resized mask instead. */
 #define O_FLAG_ROYALE_UNDEF_VARYING_ZERO 1
+/* o_pass_stock: take the ordinary sampler even where llvmpipe's blit fast path would apply to a plain draw
+ * (glGenerateMipmap's per-level blits of an RGBA8 texture do, measured: rc_sampler.c o_gen_mipmaps) */
+#define O_FLAG_STOCK_NO_BLIT 2
 
 /* scalefx/scalefx.glslp (rc_passes_scalefx.c): pass 1 params SFX_CLR, SFX_SAA; pass 2 extra[0] = PassPrev2Texture;
  * pass 3 param SFX_SCN; pass 4 extra[0] = PassPrev5Texture (the original frame) */

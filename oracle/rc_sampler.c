@@ -164,6 +164,19 @@ o_vec4 o_sample_quad(const o_tex* t, float s, float v, float s_dx0, float s_dx1,
   a.data = t->mip[l0]; a.w = t->w >> l0 ? t->w >> l0 : 1; a.h = t->h >> l0 ? t->h >> l0 : 1; a.n_levels = 0;
   b.data = t->mip[l1]; b.w = t->w >> l1 ? t->w >> l1 : 1; b.h = t->h >> l1 ? t->h >> l1 : 1; b.n_levels = 0;
   const o_vec4 c0 = o_sample(&a, s, v), c1 = o_sample(&b, s, v);
+  /* RGBA8 / GL_RGB textures on the 8-bit filter path (edge / repeat wrap): the two level samples are bytes and so is
+   * the blend between them - weight floor(frac(lod) * 256), a + ((w (b - a) + 128) >> 8) (measured with a float
+   * target at four LODs: every value k/255, 0 mismatches) */
+  if (t->linear && (t->fmt == O_FMT_RGBA8 || t->fmt == O_FMT_RGBX8) && t->wrap != O_WRAP_BORDER && t->wrap != O_WRAP_MIRROR) {
+    const int w8 = (int)floorf(w * 256.0f);
+    const float* p0 = &c0.x; const float* p1 = &c1.x;
+    float out[4];
+    for (int c = 0; c < 4; ++c) {
+      const int a8 = (int)rintf(p0[c] * 255.0f), b8 = (int)rintf(p1[c] * 255.0f);
+      out[c] = (float)((a8 + ((w8 * (b8 - a8) + 128) >> 8)) & 255) * (1.0f / 255.0f);
+    }
+    return v4(out[0], out[1], out[2], out[3]);
+  }
   return v4(fmaf(w, c1.x - c0.x, c0.x), fmaf(w, c1.y - c0.y, c0.y), fmaf(w, c1.z - c0.z, c0.z), fmaf(w, c1.w - c0.w, c0.w));
 }
 
@@ -175,8 +188,10 @@ void o_gen_mipmaps(const void* level0, int w, int h, int fmt, void* const* dst, 
     o_tex t = {0};
     t.data = src; t.w = sw; t.h = sh; t.fmt = fmt; t.linear = 1; t.wrap = O_WRAP_EDGE;
     o_pass_args a = {0};
-    a.in = &t; a.src_w = sw; a.src_h = sh; a.out_w = dw; a.out_h = dh; a.out_fmt = fmt; a.dst = dst[k];
+    a.in = &t; a.src_w = sw; a.src_h = sh; a.out_w = dw; a.out_h = dh; a.dst = dst[k];
+    a.out_fmt = fmt == O_FMT_RGBX8 ? O_FMT_RGBA8 : fmt;   /* GL_RGB: alpha reads 1 at every level */
     a.y0 = 0; a.y1 = dh; a.n_passes = 1; a.vp_w = dw; a.vp_h = dh;
+    a.flags = O_FLAG_STOCK_NO_BLIT;
     o_pass_stock(&a);
     src = dst[k];
   }

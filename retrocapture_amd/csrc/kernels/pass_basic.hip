@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(256) k_crt_pi(const PassLaunch L) {
 namespace rck {
 
 hipError_t launch_stock(const PassLaunch& L, hipStream_t s) {
-  if (L.in.fmt == FMT_RGBA8 && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8) {
+  if (L.in.fmt == FMT_RGBA8 && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8 && !(L.flags & RC_FLAG_STOCK_NO_BLIT)) {
     if (L.in.linear) hipLaunchKernelGGL(k_stock_blit<true>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
     else hipLaunchKernelGGL(k_stock_blit<false>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
     return hipGetLastError();

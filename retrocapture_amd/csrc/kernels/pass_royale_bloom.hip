@@ -556,6 +556,43 @@ void buildBhTables(const PassLaunch& L, hipStream_t s, BhTables* T) {
   if (bad) (void)hipFree(bad);
   T->usable = ok && hbad == 0;
   if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc bloom-h] tables for %dx%d: hip ok %d, geometry flags %u\n", L.out_w, L.out_h, (int)ok, hbad);
+  if (std::getenv("RC_DEBUG_BH") && ok) {
+    std::vector<uint32_t> hc(colWords), hr(rowWords);
+    (void)hipMemcpy(hc.data(), T->cols, colWords * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hr.data(), T->rows, rowWords * 4, hipMemcpyDeviceToHost);
+    const int W = L.out_w, H = L.out_h;
+    int cdiff = 0, rdiff = 0, wy0 = 0, wyhi = 0, y0eq = 0;
+    std::map<std::vector<int>, int> pat;
+    for (int i = 0; i < W; ++i) {
+      bool d = false;
+      std::vector<int> pv;
+      for (int f = 0; f < BH_COL_FIELDS; ++f) {
+        if (hc[(f * 2 + 0) * W + i] != hc[(f * 2 + 1) * W + i]) d = true;
+        if (f < 9) pv.push_back((int)hc[(f * 2 + 0) * W + i]);
+      }
+      pv.push_back((int)hc[(BH_IDIM_X * 2) * W + i] - i);
+      pv.push_back((int)hc[(BH_BRIGHT_X * 2) * W + i] - i);
+      pat[pv]++;
+      cdiff += d;
+    }
+    for (int i = 0; i < H; ++i) {
+      bool d = false;
+      for (int f = 0; f < 6; ++f) if (hr[((size_t)i * 2 + 0) * BH_ROW_FIELDS + f] != hr[((size_t)i * 2 + 1) * BH_ROW_FIELDS + f]) d = true;
+      rdiff += d;
+      const float wy = bits2f(hr[((size_t)i * 2) * BH_ROW_FIELDS + BH_WY]);
+      wy0 += wy == 0.0f;
+      wyhi += wy > 0.5f;
+      y0eq += (int)hr[((size_t)i * 2) * BH_ROW_FIELDS + BH_Y0] == i;
+    }
+    std::fprintf(stderr, "[rc bloom-h dbg] cols differing between sides %d/%d, rows %d/%d; rows wy==0 %d, wy>0.5 %d, y0==y %d; patterns %zu\n", cdiff, W, rdiff, H, wy0, wyhi, y0eq, pat.size());
+    for (auto& kv : pat) {
+      std::fprintf(stderr, "   pattern x%d:", kv.second);
+      for (int v : kv.first) std::fprintf(stderr, " %d", v);
+      std::fprintf(stderr, "\n");
+    }
+    int hx = 0; for (int i = 1; i < W; ++i) hx += hc[(BH_HAL_X0 * 2) * W + i] != hc[(BH_HAL_X0 * 2) * W + i - 1];
+    std::fprintf(stderr, "   hal x0 changes %d, hal texture %dx%d, params k %g %g %g %g dx %g\n", hx, L.extra[2].w, L.extra[2].h, L.params[RPG_K78], L.params[RPG_K56], L.params[RPG_K34], L.params[RPG_K12], L.params[RPG_DXY]);
+  }
   if (!T->usable) {
     if (T->cols) (void)hipFree(T->cols);
     if (T->rows) (void)hipFree(T->rows);

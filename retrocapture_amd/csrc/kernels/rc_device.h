@@ -43,6 +43,7 @@ struct Plane {
 
 // PassLaunch::flags bits (bit 0 is crt-royale's RC_FLAG_UNDEF_VARYING_ZERO, kernels/royale_params.h)
 constexpr int RC_FLAG_GENERAL_ONLY = 1 << 16; // launchers must pick the general kernel form
+constexpr int RC_FLAG_STOCK_NO_BLIT = 1 << 17; // stock.glsl: the ordinary sampler even where llvmpipe's blit fast path would apply (mip generation)
 constexpr int RC_FLAG_XBR_REGULAR = 1 << 8;
 constexpr int RC_FLAG_NTSC_REGULAR = 1 << 9; // ntsc pass 2: tap k of target column x reads source column c(x)+k-24, c(x+1) = c(x)+2  // xbr: sampled columns/rows are centre-2..centre+2 for every target pixel
 
@@ -499,6 +500,19 @@ __device__ __forceinline__ float4 sample_mip(const Tex& t, int z, float s, float
   const uint8_t *i0, *i1;
   const Tex t0 = mip_level(t, z, l0, &i0), t1 = mip_level(t, z, l1, &i1);
   const float4 c0 = sample_rt(t0, i0, s, v, lds), c1 = sample_rt(t1, i1, s, v, lds);
+  // RGBA8 / GL_RGB textures on the 8-bit filter path: the blend between the two level samples (bytes) is 8-bit too,
+  // weight floor(frac(lod) * 256), a + ((w (b - a) + 128) >> 8)  (oracle/rc_sampler.c o_sample_quad, measured)
+  if (t.linear && (t.fmt == FMT_RGBA8 || t.fmt == FMT_RGBX8) && t.wrap != WRAP_BORDER && t.wrap != WRAP_MIRROR) {
+    const int w8 = (int)__builtin_floorf(w * 256.0f);
+    const float a[4] = {c0.x, c0.y, c0.z, c0.w}, b[4] = {c1.x, c1.y, c1.z, c1.w};
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int a8 = (int)__builtin_rintf(a[c] * 255.0f), b8 = (int)__builtin_rintf(b[c] * 255.0f);
+      o[c] = (float)((a8 + ((w8 * (b8 - a8) + 128) >> 8)) & 255) * (1.0f / 255.0f);
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+  }
   return make_float4(fma_(w, c1.x - c0.x, c0.x), fma_(w, c1.y - c0.y, c0.y), fma_(w, c1.z - c0.z, c0.z), fma_(w, c1.w - c0.w, c0.w));
 }
 

@@ -109,8 +109,11 @@ void ShaderEngine::cleanupPresetPasses() {
     if (p.scratch.ptr) (void)hipFree(p.scratch.ptr);
     if (p.feedback.ptr) (void)hipFree(p.feedback.ptr);
     if (p.lastTarget.ptr) (void)hipFree(p.lastTarget.ptr);
+    if (p.mips.ptr) (void)hipFree(p.mips.ptr);
   }
   m_passes.clear();
+  if (m_sourceMips.ptr) (void)hipFree(m_sourceMips.ptr);
+  m_sourceMips = DeviceBuffer();
   for (auto& h : m_frameHistory)
     if (h.buf.ptr) (void)hipFree(h.buf.ptr);
   m_frameHistory.clear();
@@ -491,57 +494,68 @@ rcd::Tex ShaderEngine::passTexture(size_t p) const {
 }
 
 // glGenerateMipmap as llvmpipe does it (measured, oracle/rc_sampler.c): every level is a LINEAR,
-// clamp-to-edge blit of the level above in the texture's own format - the stock kernel.
-bool ShaderEngine::buildMipChain(size_t p, const void* level0, uint32_t nFrames) {
-  ShaderPassData& pd = m_passes[p];
-  const uint32_t bpp = texelBytes(pd.format);
+// clamp-to-edge draw of the level above in the texture's own format - the stock kernel with the ordinary sampler
+// (sRGB8: decoded, filtered in float, re-encoded; RGBA8 / GL_RGB: the 8-bit fixed-point filter - NOT the blit
+// fast path a plain RGBA8 -> RGBA8 copy takes).
+bool ShaderEngine::buildMipLevels(const rcd::Tex& level0, uint32_t nFrames, DeviceBuffer* mips, int* outLevels, size_t* outFrameBytes) {
+  const int storeFmt = level0.fmt == rcd::FMT_RGBX8 ? rcd::FMT_RGBA8 : level0.fmt;   // GL_RGB: alpha reads 1 at every level
+  const uint32_t bpp = texelBytes(storeFmt);
   int levels = 1;
   size_t bytes = 0;
-  for (uint32_t w = pd.width, h = pd.height; w > 1 || h > 1;) {
+  for (uint32_t w = (uint32_t)level0.w, h = (uint32_t)level0.h; w > 1 || h > 1;) {
     w = std::max(1u, w >> 1);
     h = std::max(1u, h >> 1);
     bytes += (size_t)w * h * bpp;
     if (++levels == 15) break;
   }
-  pd.mipLevels = levels;
-  pd.mipFrameBytes = bytes;
+  *outLevels = levels;
+  *outFrameBytes = bytes;
   if (levels <= 1) return true;
-  if (!ensureBuffer(pd.mips, bytes * nFrames)) return false;
-  rcd::Tex src;
-  src.base = level0;
-  src.frame_stride = pd.frameBytes;
-  src.w = (int)pd.width;
-  src.h = (int)pd.height;
-  src.fmt = pd.format;
+  if (!ensureBuffer(*mips, bytes * nFrames)) return false;
+  rcd::Tex src = level0;
   src.linear = 1;
   src.wrap = rcd::WRAP_EDGE;
+  src.n_levels = 0;
+  src.mip_base = nullptr;
   size_t off = 0;
   for (int k = 1; k < levels; ++k) {
-    const int dw = std::max(1, (int)pd.width >> k), dh = std::max(1, (int)pd.height >> k);
+    const int dw = std::max(1, level0.w >> k), dh = std::max(1, level0.h >> k);
     rcd::PassLaunch L;
     std::memset(static_cast<void*>(&L), 0, sizeof(L));
     L.srgb_enc = m_srgbEnc;
     L.in = src;
-    L.out = static_cast<uint8_t*>(pd.mips.ptr) + off;
+    L.out = static_cast<uint8_t*>(mips->ptr) + off;
     L.out_frame_stride = bytes;
     L.out_w = dw;
     L.out_h = dh;
-    L.out_fmt = pd.format;
+    L.out_fmt = storeFmt;
     L.src_w = src.w;
     L.src_h = src.h;
     L.vp_w = dw;
     L.vp_h = dh;
     L.n_frames = (int)nFrames;
-    L.plane[0] = makePlane(0.f, 1.f, 1.f, 0.f, dw, dh, pd.format);
-    L.plane[1] = makePlane(0.f, 0.f, 1.f, 1.f, dw, dh, pd.format);
+    L.flags = rcd::RC_FLAG_STOCK_NO_BLIT;
+    L.plane[0] = makePlane(0.f, 1.f, 1.f, 0.f, dw, dh, storeFmt);
+    L.plane[1] = makePlane(0.f, 0.f, 1.f, 1.f, dw, dh, storeFmt);
     if (!hipOk(rck::launch_stock(L, m_stream), "mip level")) return false;
     src.base = L.out;
     src.frame_stride = bytes;
     src.w = dw;
     src.h = dh;
+    src.fmt = storeFmt;
     off += (size_t)dw * dh * bpp;
   }
   return true;
+}
+bool ShaderEngine::buildMipChain(size_t p, const void* level0, uint32_t nFrames) {
+  ShaderPassData& pd = m_passes[p];
+  rcd::Tex t;
+  t.base = level0;
+  t.frame_stride = pd.frameBytes;
+  t.w = (int)pd.width;
+  t.h = (int)pd.height;
+  t.fmt = pd.format;
+  return buildMipLevels(t, nFrames, &pd.mips, &pd.mipLevels, &pd.mipFrameBytes);
 }
 
 rcd::Tex ShaderEngine::lutTexture(const std::string& name) const {  // :1361-1415
@@ -901,6 +915,17 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
   sourceTex.linear = m_passes[0].passInfo.filterLinear ? 1 : 0;
   sourceTex.wrap = wrapFromString(m_passes[0].passInfo.wrapMode);
 
+  // mipmap_input0: the reference generates the chain on the source texture as well (ShaderEngine.cpp:1019-1031)
+  if (m_passes[0].kernel && m_passes[0].kernel->mip_aware && m_passes[0].passInfo.mipmapInput && m_passes[0].passInfo.filterLinear) {
+    int levels = 0;
+    size_t frameBytes = 0;
+    if (!buildMipLevels(sourceTex, nFrames, &m_sourceMips, &levels, &frameBytes)) return false;
+    if (levels > 1) {
+      sourceTex.n_levels = levels;
+      sourceTex.mip_base = m_sourceMips.ptr;
+      sourceTex.mip_frame_stride = frameBytes;
+    }
+  }
   rcd::Tex current = sourceTex;
   std::map<std::string, float> custom;
   {
@@ -971,8 +996,7 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
       }
       if (pd.passInfo.mipmapInput && k.mip_aware) {
         if (current.n_levels <= 1 && (current.w > 1 || current.h > 1)) {
-          RC_LOG_ERROR("pass " + std::to_string(i) + ": mipmap_input needs an sRGB8 or float render target as input "
-                       "(llvmpipe's mip generation is restated for those formats only)");
+          RC_LOG_ERROR("pass " + std::to_string(i) + ": mipmap_input without filter_linear (GL_NEAREST_MIPMAP_NEAREST) is not restated");
           return false;
         }
       } else if (pd.passInfo.mipmapInput && (current.w != L.out_w || current.h != L.out_h)) {
@@ -1063,7 +1087,7 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
     // mipmap_input of the next pass: the reference generates the chain when that pass binds this texture
     pd.mipLevels = 0;
     if (!last && m_passes[i + 1].kernel && m_passes[i + 1].kernel->mip_aware && m_passes[i + 1].passInfo.mipmapInput &&
-        m_passes[i + 1].passInfo.filterLinear && (pd.format == rcd::FMT_SRGB8 || pd.format == rcd::FMT_F32 || pd.format == rcd::FMT_F16)) {
+        m_passes[i + 1].passInfo.filterLinear) {
       if (!buildMipChain(i, target, nFrames)) return false;
     }
     // this pass's output becomes the next pass's input

@@ -232,6 +232,9 @@ class ShaderEngine {
   bool presetSamplesFeedback() const;
   rcd::Tex passTexture(size_t passIndex) const;
   bool buildMipChain(size_t passIndex, const void* level0, uint32_t nFrames);
+  // levels 1.. of the chain of `level0` (fmt RGBX8 = the GL_RGB source frame) into `mips`, packed per frame
+  bool buildMipLevels(const rcd::Tex& level0, uint32_t nFrames, DeviceBuffer* mips, int* levels, size_t* frameBytes);
+  DeviceBuffer m_sourceMips;   // mipmap_input0: the chain of the source frames of the current chunk
   bool runChunk(const void* inputs, uint64_t inStride, uint32_t width, uint32_t height, uint32_t nFrames,
                 int firstFrameCount, void* finalOut);
 };

@@ -89,6 +89,14 @@ filter_linear5 = true
                           'shaders = 2\nshader0 = ../stock.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 2.0\n'
                           'shader1 = ../stock.glsl\nfilter_linear1 = true'),
     "bilinear": ("bilinear.glslp", 'shaders = 1\n\nshader0 = stock.glsl\nfilter_linear0 = true\n'),
+    # synthesized: mipmap_input on the GL_RGB source frame / on a plain RGBA8 render target (8-bit mip generation and blend)
+    **{"mip-source-%s" % sc: ("crt/t-mip-source-%s.glslp" % sc,
+                              "shaders = 1\nshader0 = shaders/glow/blur_horiz.glsl\nfilter_linear0 = true\nmipmap_input0 = true\n"
+                              "scale_type0 = source\nscale0 = %s\n" % sc) for sc in ("0.4", "0.23")},
+    **{"mip-rgba8-%s" % sc: ("crt/t-mip-rgba8-%s.glslp" % sc,
+                             "shaders = 2\nshader0 = ../stock.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n"
+                             "shader1 = shaders/glow/blur_horiz.glsl\nfilter_linear1 = true\nmipmap_input1 = true\n"
+                             "scale_type1 = source\nscale1 = %s\n" % sc) for sc in ("0.37", "0.6")},
     "crt-geom": ("crt/crt-geom.glslp", 'shaders = 1\n\nshader0 = shaders/crt-geom.glsl\nfilter_linear0 = false\n'),
     "crt-easymode": ("crt/crt-easymode.glslp", 'shaders = 1\n\nshader0 = shaders/crt-easymode.glsl\nfilter_linear0 = false\n'),
     "crt-nes-mini": ("crt/crt-nes-mini.glslp", 'shaders = 1\n\nshader0 = shaders/crt-nes-mini.glsl\n'),

@@ -517,6 +517,19 @@ def case_crt_geom():
              params=[("x_tilt", -0.3), ("y_tilt", 0.25), ("R", 1.5), ("d", 1.2), ("SATURATION", 0.7), ("lum", 0.2)])
 
 
+def case_mip_rgba8():
+    """mipmap_input on 8-bit textures: the GL_RGB source frame (mipmap_input0) and a plain RGBA8 render target, sampled
+    by glow/blur_horiz (nine trilinear taps) at fractional LODs; llvmpipe generates and blends these levels in 8 bits."""
+    with tempfile.TemporaryDirectory() as d:
+        src = 'shaders = 1\nshader0 = %s/crt/shaders/glow/blur_horiz.glsl\nfilter_linear0 = true\nmipmap_input0 = true\nscale_type0 = source\nscale0 = %s\n'
+        run_case("mip_source_96x64_s0.4", write_preset(d, src % (GLSL, "0.4")), noise(96, 64, 170), 200, 150)
+        run_case("mip_source_125x95_s0.23", write_preset(d, src % (GLSL, "0.23")), mixed(125, 95, 171), 200, 150)
+        fbo = ('shaders = 2\nshader0 = %s/stock.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n'
+               'shader1 = %s/crt/shaders/glow/blur_horiz.glsl\nfilter_linear1 = true\nmipmap_input1 = true\nscale_type1 = source\nscale1 = %s\n')
+        run_case("mip_rgba8_96x64_s0.37", write_preset(d, fbo % (GLSL, GLSL, "0.37")), noise(96, 64, 172), 200, 150)
+        run_case("mip_rgba8_101x67_s0.6", write_preset(d, fbo % (GLSL, GLSL, "0.6")), mixed(101, 67, 173), 200, 150)
+
+
 def case_lcd3x():
     Q = GLSL + "/handheld/lcd1x.glslp"
     run_case("lcd1x_64x48_to_192x144", Q, mixed(64, 48, 153), 192, 144)
@@ -545,7 +558,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -100,7 +100,8 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
             mip_cache[k] = Tex(given[k] if given is not None else outs[k], fmts[k], nxt["filter_linear"], nxt["wrap"], mipmap=mip)
         return mip_cache[k]
 
-    source_tex = Tex(src, "rgbx8", passes[0]["filter_linear"], passes[0]["wrap"])
+    # mipmap_input0: the reference generates the chain on the SOURCE texture too (ShaderEngine.cpp:1019-1031)
+    source_tex = Tex(src, "rgbx8", passes[0]["filter_linear"], passes[0]["wrap"], mipmap=bool(passes[0].get("mipmap")) and passes[0]["filter_linear"])
     cur = source_tex
     pass0_call = None
     for i, p in enumerate(passes):

@@ -701,3 +701,24 @@ def test_crt_geom_matches_oracle_at_size(params, preset_tree, rc_lib):
     got = run_engine(e, rgb)[0]
     assert np.array_equal(got, want[0]), "%d differing bytes" % int((got != want[0]).sum())
     e.shutdown()
+
+
+@pytest.mark.parametrize("case,key", [("mip_source_96x64_s0.4", "mip-source-0.4"), ("mip_source_125x95_s0.23", "mip-source-0.23"),
+                                      ("mip_rgba8_96x64_s0.37", "mip-rgba8-0.37"), ("mip_rgba8_101x67_s0.6", "mip-rgba8-0.6")])
+def test_mipmap_input_on_8bit_textures_matches_llvmpipe(case, key, preset_tree, rc_lib):
+    """mipmap_input on the GL_RGB source frame and on a plain RGBA8 render target: llvmpipe builds those levels with the
+    ordinary 8-bit LINEAR filter (not its blit fast path) and blends the two level samples in 8 bits
+    (weight floor(frac(lod) * 256)); nine trilinear taps per pixel at fractional LODs, every pass byte-exact."""
+    from gpu_util import make_engine, run_engine
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    vw, vh = [int(v) for v in g["viewport"]]
+    e = make_engine(preset_tree[key], vw, vh)
+    final = run_engine(e, g["input_rgb"])
+    n = int(g["n_passes"])
+    for i in range(n):
+        assert np.array_equal(e.readPass(i, 0), g["pass%d" % i]), "pass %d" % i
+    assert np.array_equal(final[0], g["pass%d" % (n - 1)])
+    batch = np.stack([g["input_rgb"]] * 3)          # the chain is built per frame of a batch
+    out = run_engine(e, batch)
+    assert all(np.array_equal(out[k], final[0]) for k in range(3))
+    e.shutdown()

@@ -16,6 +16,10 @@ CASES = {
     "scalefx_48x40": "scalefx",
     "scalefx_noise_37x29": "scalefx",
     "scalefx_params_56x44": "scalefx",            # SFX_CLR 0.35, SFX_SAA 0, SFX_SCN 0
+    "mip_source_96x64_s0.4": "mip-source-0.4",                  # mipmap_input0: the GL_RGB source frame, 8-bit levels and blend
+    "mip_source_125x95_s0.23": "mip-source-0.23",
+    "mip_rgba8_96x64_s0.37": "mip-rgba8-0.37",                  # mipmap_input on a plain RGBA8 render target
+    "mip_rgba8_101x67_s0.6": "mip-rgba8-0.6",
     "crt_geom_96x64_to_301x217": "crt-geom",
     "crt_geom_params_80x60_to_320x240": "crt-geom",            # tilt, overscan, corner, SHARPER 2, saturation ...
     "crt_geom_flat_72x56_to_288x224": "crt-geom",              # CURVATURE 0
