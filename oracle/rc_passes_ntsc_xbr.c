@@ -326,7 +326,7 @@ void o_pass_xbr_lv3(const o_pass_args* a) {
 
 /* ----------------------------------------------------------------------------- xbr-lv2 -- */
 /* shaders/shaders_glsl/xbr/shaders/xbr-lv2.glsl (VS 100-117 = the same 5x5 coordinate set as xbr-lv3, FS 260-361),
- * CORNER_C + SMOOTH_TIPS as the file defines them; the small_details < 0.5 branch (the default).
+ * CORNER_C + SMOOTH_TIPS as the file defines them; both branches of small_details.
  * params: XBR_SCALE (a commented-out `//#pragma parameter` line that the reference's scan still picks up; unused),
  * XBR_Y_WEIGHT, XBR_EQ_THRESHOLD, XBR_LV1_COEFFICIENT, XBR_LV2_COEFFICIENT, small_details
  *
@@ -357,9 +357,26 @@ static inline f4 line_clamp(const float* A, const float* B, const float* dl, con
   }
   return r;
 }
+/* weighted_distance (FS 222-225), seven terms: balanced like wd's five, (((ab + ac) + (de + df)) + (ij + kl)) + 2*gh
+ * (of eight candidate trees the best fit on the float golden; the differences between them are below the
+ * residual this shader's parity carries anyway) */
+static inline f4 wd7(f4 a, f4 b, f4 c, f4 d, f4 e, f4 f, f4 g, f4 h, f4 i, f4 j, f4 k, f4 l) {
+  f4 t1 = f4_df(a, b), t2 = f4_df(a, c), t3 = f4_df(d, e), t4 = f4_df(d, f), t5 = f4_df(i, j), t6 = f4_df(k, l), t7 = f4_df(g, h), r;
+  for (int q = 0; q < 4; ++q) r.v[q] = (((t1.v[q] + t2.v[q]) + (t3.v[q] + t4.v[q])) + (t5.v[q] + t6.v[q])) + 2.0f * t7.v[q];
+  return r;
+}
+/* mul(mat4x3(p0..p3), y_weight * Y) = (y_weight * Y) * mat: one dot per column, x*c0 + (y*c1 + z*c2) */
+static inline f4 lumy(o_vec4 p0, o_vec4 p1, o_vec4 p2, o_vec4 p3, const float* yw) {
+  const o_vec4* p[4] = {&p0, &p1, &p2, &p3};
+  f4 r;
+  for (int k = 0; k < 4; ++k) r.v[k] = yw[0] * p[k]->x + (yw[1] * p[k]->y + yw[2] * p[k]->z);
+  return r;
+}
 static void xbr_lv2_body(const o_pass_args* a) {
   const int W = a->out_w, H = a->out_h;
   const float thr = a->params[2], lv2 = a->params[4];
+  const int details = !(a->params[5] < 0.5f);
+  const float yw[3] = {a->params[1] * 0.2126f, a->params[1] * 0.7152f, a->params[1] * 0.0722f};   /* y_weight * Y */
   const float tsx = (float)a->in->w, tsy = (float)a->in->h;
   const float dx = 1.0f / tsx, dy = 1.0f / tsy;
   const float xoff[5] = {-2.0f * dx, -dx, 0.0f, dx, 2.0f * dx};
@@ -397,6 +414,7 @@ static void xbr_lv2_body(const o_pass_args* a) {
       f4 b = lumc(B, D, Hh, F), c = lumc(C, A, G, I), e = lumc(E, E, E, E);
       f4 d = YZWX(b), f = WXYZ(b), g = ZWXY(c), h = ZWXY(b), i = WXYZ(c);
       f4 i4 = lumc(I4, C1, A0, G5), i5 = lumc(I5, C4, A1, G0), h5 = lumc(H5, F4, B1, D0);
+      if (details) { i4 = lumy(I4, C1, A0, G5, yw); i5 = lumy(I5, C4, A1, G0, yw); h5 = lumy(H5, F4, B1, D0, yw); }
       /* `f4` is declared (FS 295) but never assigned in this file - xbr-lv3 has f4 = h5.yzwx - so wd1 and the
        * CORNER_C rule read an undefined value, which llvmpipe materialises as 0 */
       const f4 f4_ = i;   /* the unassigned `f4` as wd1 sees it (see above) */
@@ -416,6 +434,12 @@ static void xbr_lv2_body(const o_pass_args* a) {
       f4 fx45i = line_clamp(Ao, Bo, delta, Co, 0.25f, fpy, fpx), fx45 = line_clamp(Ao, Bo, delta, Co, 0.0f, fpy, fpx);
       f4 fx30 = line_clamp(Ao, Bx, delta_l, Cx, 0.0f, fpy, fpx), fx60 = line_clamp(Ao, By, delta_u, Cy, 0.0f, fpy, fpx);
       f4 wd1 = wd(e, c, g, i, h5, f4_, h, f), wd2 = wd(h, d, i5, f, i4, b, e, i);
+      if (details) {   /* FS 322-323 */
+        /* the unassigned f4 again: |x - f4| comes out 0 in both calls (fitted: of 144 combinations of what the two
+         * uses could read, only "f4 = its partner" reproduces llvmpipe) */
+        wd1 = wd7(e, c, g, i, i, h5, h, f, b, d, i4, i5);
+        wd2 = wd7(h, d, i5, f, b, i4, e, i, g, h5, c, c);
+      }
       f4 dfg = f4_df(f, g), dhc = f4_df(h, c), def = f4_df(e, f), deh = f4_df(e, h);
       float maximos[4];
       int px[4];

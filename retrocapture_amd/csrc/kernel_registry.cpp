@@ -390,9 +390,6 @@ std::vector<KernelEntry> build() {
                    {"XBR_LV2_COEFFICIENT", 2.0f, 1.0f, 3.0f, 0.1f, "Lv2 Coefficient"},
                    {"small_details", 0.0f, 0.0f, 1.0f, 1.0f, "Preserve Small Details"}},
                   {}, rck::launch_xbr_lv2, setupXbrLv2, true};
-    e.validate = [](const float* p) -> const char* {
-      return p[5] < 0.5f ? nullptr : "xbr-lv2.glsl: only the small_details = 0 branch is restated";
-    };
     r.push_back(e);
   }
   registerRoyaleKernels(r);

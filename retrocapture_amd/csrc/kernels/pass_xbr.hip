@@ -30,6 +30,16 @@ __device__ __forceinline__ F4 yzwx(const F4& a) { return F4{{a.v[1], a.v[2], a.v
 __device__ __forceinline__ F4 wxyz(const F4& a) { return F4{{a.v[3], a.v[0], a.v[1], a.v[2]}}; }
 __device__ __forceinline__ F4 zwxy(const F4& a) { return F4{{a.v[2], a.v[3], a.v[0], a.v[1]}}; }
 __device__ __forceinline__ float df1(float a, float b) { return __builtin_fabsf(a - b); }
+// xbr-lv2's seven-term weighted_distance: (((ab + ac) + (de + df)) + (ij + kl)) + 2*gh (oracle/rc_passes_ntsc_xbr.c wd7)
+__device__ __forceinline__ F4 wd7(const F4& a, const F4& b, const F4& c, const F4& d, const F4& e, const F4& f, const F4& g,
+                                  const F4& h, const F4& i, const F4& j, const F4& k, const F4& l) {
+  F4 r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    r.v[q] = (((df1(a.v[q], b.v[q]) + df1(a.v[q], c.v[q])) + (df1(d.v[q], e.v[q]) + df1(d.v[q], f.v[q]))) +
+              (df1(i.v[q], j.v[q]) + df1(k.v[q], l.v[q]))) + 2.0f * df1(g.v[q], h.v[q]);
+  return r;
+}
 __device__ __forceinline__ F4 wd(const F4& a, const F4& b, const F4& c, const F4& d, const F4& e, const F4& f,
                                  const F4& g, const F4& h) {
   F4 r;
@@ -187,7 +197,7 @@ __global__ void __launch_bounds__(256) k_xbr_lv3(const PassLaunch L) {
 }
 
 // ----------------------------------------------------------------------------- xbr-lv2 ------
-// xbr/shaders/xbr-lv2.glsl FS 260-361 (CORNER_C, SMOOTH_TIPS, small_details < 0.5), same 5x5 coordinate set.
+// xbr/shaders/xbr-lv2.glsl FS 260-361 (CORNER_C, SMOOTH_TIPS, both branches of small_details), same 5x5 coordinate set.
 // Restated as in oracle/rc_passes_ntsc_xbr.c, including what llvmpipe makes of the shader's unassigned `f4`
 // (reads as `i` in wd1; eq(f, f4) true) - parity "partial", see there.
 // params: XBR_SCALE (unused: a commented-out pragma the reference's scan still lists), XBR_Y_WEIGHT, XBR_EQ_THRESHOLD,
@@ -232,9 +242,18 @@ __global__ void __launch_bounds__(256) k_xbr_lv2(const PassLaunch L) {
   const float le = dot_rgbw(E);
   const F4 e = F4{{le, le, le, le}};
   const F4 d = yzwx(b), f = wxyz(b), g = zwxy(c), h = zwxy(b), i = wxyz(c);
-  const F4 i4 = F4{{dot_rgbw(I4), dot_rgbw(C1), dot_rgbw(A0), dot_rgbw(G5)}}, i5 = F4{{dot_rgbw(I5), dot_rgbw(C4), dot_rgbw(A1), dot_rgbw(G0)}};
-  const F4 h5 = F4{{dot_rgbw(H5), dot_rgbw(F4_), dot_rgbw(B1), dot_rgbw(D0)}};
-  const F4 wd1 = wd(e, c, g, i, h5, i, h, f), wd2 = wd(h, d, i5, f, i4, b, e, i);
+  F4 i4 = F4{{dot_rgbw(I4), dot_rgbw(C1), dot_rgbw(A0), dot_rgbw(G5)}}, i5 = F4{{dot_rgbw(I5), dot_rgbw(C4), dot_rgbw(A1), dot_rgbw(G0)}};
+  F4 h5 = F4{{dot_rgbw(H5), dot_rgbw(F4_), dot_rgbw(B1), dot_rgbw(D0)}};
+  F4 wd1 = wd(e, c, g, i, h5, i, h, f), wd2 = wd(h, d, i5, f, i4, b, e, i);
+  if (!(L.params[5] < 0.5f)) {   // small_details (FS 285-290, 320-323): outer lumas with XBR_Y_WEIGHT * Y, seven-term distance
+    const float y0 = L.params[1] * 0.2126f, y1 = L.params[1] * 0.7152f, y2 = L.params[1] * 0.0722f;
+    auto ly = [&](const float4 p) { return y0 * p.x + (y1 * p.y + y2 * p.z); };
+    i4 = F4{{ly(I4), ly(C1), ly(A0), ly(G5)}};
+    i5 = F4{{ly(I5), ly(C4), ly(A1), ly(G0)}};
+    h5 = F4{{ly(H5), ly(F4_), ly(B1), ly(D0)}};
+    wd1 = wd7(e, c, g, i, i, h5, h, f, b, d, i4, i5);   // the unassigned f4: |x - f4| = 0 in both calls (oracle)
+    wd2 = wd7(h, d, i5, f, b, i4, e, i, g, h5, c, c);
+  }
   const float Ao[4] = {1.0f, -1.0f, -1.0f, 1.0f}, Bo[4] = {1.0f, 1.0f, -1.0f, -1.0f}, Co[4] = {1.5f, 0.5f, -0.5f, 0.5f};
   const float Bx[4] = {0.5f, 2.0f, -0.5f, -2.0f}, Cx[4] = {1.0f, 1.0f, -0.5f, 0.0f};
   const float By[4] = {2.0f, 0.5f, -2.0f, -0.5f}, Cy[4] = {2.0f, 0.0f, -1.0f, 0.5f};

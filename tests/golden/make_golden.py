@@ -425,6 +425,10 @@ def case_xbr_lv2():
     run_case("xbr_lv2_noise_40x36_to_240x216", P, noise(40, 36, 81), 240, 216)
     run_case("xbr_lv2_params_48x40_to_331x217", P, mixed(48, 40, 82), 331, 217, params=[("XBR_EQ_THRESHOLD", 25.0), ("XBR_LV2_COEFFICIENT", 1.4)])
     run_case("f32_xbr_lv2_48x40_to_331x217", P, mixed(48, 40, 83), 331, 217, f32=True)
+    # "Preserve Small Details": the outer luma samples weighted with XBR_Y_WEIGHT * Y and the 7-term weighted distance
+    run_case("xbr_lv2_details_64x56_to_256x224", P, mixed(64, 56, 84), 256, 224, params=[("small_details", 1.0)])
+    run_case("xbr_lv2_details_noise_40x36_to_240x216", P, noise(40, 36, 85), 240, 216, params=[("small_details", 1.0), ("XBR_Y_WEIGHT", 60.0)])
+    run_case("f32_xbr_lv2_details_48x40_to_331x217", P, pixel_art(48, 40, 86), 331, 217, f32=True, params=[("small_details", 1.0)])
 
 
 def case_royale_ntsc():

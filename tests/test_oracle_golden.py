@@ -77,6 +77,8 @@ CASES = {
     "xbr_lv2_64x56_to_256x224": "xbr-lv2",
     "xbr_lv2_noise_40x36_to_240x216": "xbr-lv2",
     "xbr_lv2_params_48x40_to_331x217": "xbr-lv2",
+    "xbr_lv2_details_64x56_to_256x224": "xbr-lv2",              # small_details = 1
+    "xbr_lv2_details_noise_40x36_to_240x216": "xbr-lv2",        # small_details = 1, XBR_Y_WEIGHT 60
     "crt_hyllian_glow_96x64_to_256x192": "crt-hyllian-glow",
     "crt_hyllian_glow_80x60_to_250x190": "crt-hyllian-glow",         # pass 3 is 63x48: not viewport / 4, fractional mip LOD
     "crt_hyllian_glow_params_64x48_to_200x150": "crt-hyllian-glow",
@@ -218,6 +220,7 @@ FLOAT_CASES = {
     "f32_sharp_bilinear_64x48_to_200x150": ("sharp-bilinear", {}),
     "f32_crt_easymode_64x48_to_200x150": ("crt-easymode", {0: 0.95}),   # 8-bit goldens exact; <= 3e-7 in float
     "f32_xbr_lv2_48x40_to_331x217": ("xbr-lv2", {0: 0.99}),   # parity "partial", see above
+    "f32_xbr_lv2_details_48x40_to_331x217": ("xbr-lv2", {0: 0.99}),
     "f32_crt_hyllian_glow_64x48_to_160x120": ("crt-hyllian-glow", {1: 0.93, 3: 0.5, 4: 0.93}),
     "f32_crt_hyllian_glow_64x48_to_150x110": ("crt-hyllian-glow", {1: 0.80, 3: 0.4, 4: 0.93}),
 }
