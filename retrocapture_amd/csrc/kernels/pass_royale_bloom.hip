@@ -209,10 +209,17 @@ void buildBvTables(const PassLaunch& L, hipStream_t s, BvTables* T) {
 // of its column - for both triangles - in registers (k_bloomh_geometry).  A row whose vertical weight is exactly 0
 // (the usual case at 1:1) filters one source row, any other row the pair the sampler would fetch.
 constexpr int kBhRows = 16;
-constexpr int kBhWaves = 4;
+constexpr int kBhWaves = 12;
 constexpr int kBhSeg = 84;      // staged columns: 10 + 64 + 10
 constexpr int kBhSegLeft = 10;
-constexpr int kBhRingDwords = 3 * kBhSeg * 4;   // per wave: three rows of float4
+// A staged row holds, per column j, the PAIR of texels (j, j + 1) every horizontal lerp needs: red and green
+// interleaved {R[j], R[j+1], G[j], G[j+1]} (one ds_read_b128, 4 LDS cycles) and blue {B[j], B[j+1]} (one ds_read_b64,
+// 2 cycles) - a float4 per texel would be read as two ds_read_b96 at 8 cycles each.  The staging lane of column j gets
+// column j + 1's decoded texel from the next lane (ds_bpermute) and writes the whole pair entry with 16- and 8-byte stores.
+// Twelve waves share one workgroup (one copy of the 35 KB sRGB tables + 12 rings = 108 KB of LDS, one workgroup per CU).
+constexpr int kBhRowRG = kBhSeg * 16;             // bytes: the {R, R', G, G'} plane of a staged row
+constexpr int kBhRowBytes = kBhSeg * 24;          // ... followed by the {B, B'} plane
+constexpr int kBhRingDwords = 3 * kBhRowBytes / 4;   // per wave: three staged rows
 enum { BH_DX = 0, BH_WX = 9, BH_IDIM_X = 18, BH_BRIGHT_X = 19, BH_HAL_X0 = 20, BH_HAL_W = 21, BH_COL_FIELDS = 22 };
 enum { BH_Y0 = 0, BH_WY = 1, BH_IDIM_Y = 2, BH_BRIGHT_Y = 3, BH_HAL_Y0 = 4, BH_HAL_WY = 5, BH_ROW_FIELDS = 8 };
 
@@ -296,6 +303,15 @@ __device__ __forceinline__ float3 dec3(uint32_t t, const SrgbLds& l) {
   return make_float3(l.dec[t & 255u], l.dec[(t >> 8) & 255u], l.dec[(t >> 16) & 255u]);
 }
 
+// the pair (texel j, texel j + 1) of staged column j of a ring row
+__device__ __forceinline__ void ring_store(uint8_t* row, int j, float r, float g, float b, float r1, float g1, float b1) {
+  *reinterpret_cast<float4*>(row + j * 16) = make_float4(r, r1, g, g1);
+  *reinterpret_cast<float2*>(row + kBhRowRG + j * 8) = make_float2(b, b1);
+}
+// value of the next lane (lane 63 gets lane 0's): a cross-lane read through the LDS crossbar, no memory access
+__device__ __forceinline__ float next_lane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, __builtin_bit_cast(int, v)));
+}
 // one target pixel; ring = this wave's three staged rows (row r in slot r % 3), `TWO`: the vertical weight is not 0
 // HALC: the two horizontally filtered halation rows of the pixel's row pair are handed over (hal_rows[0..2], [3..5])
 // PRE: the texels of the two NEAREST taps were fetched ahead (pre_idim, pre_bright)
@@ -304,15 +320,16 @@ __device__ __forceinline__ void bloomh_pixel(const PassLaunch& L, const SrgbLds&
                                              int x, int y, int z, const float* hal_rows, uint32_t pre_idim = 0u, uint32_t pre_bright = 0u) {
   const float* P = L.params;
   const int Hin = L.in.h;
-  const uint8_t* rowA = ring + (uint32_t)(clampi(r.y0, 0, Hin - 1) % 3) * (kBhSeg * 16u);
-  const uint8_t* rowB = ring + (uint32_t)(clampi(r.y0 + 1, 0, Hin - 1) % 3) * (kBhSeg * 16u);
+  const uint8_t* rowA = ring + (uint32_t)(clampi(r.y0, 0, Hin - 1) % 3) * (uint32_t)kBhRowBytes;
+  const uint8_t* rowB = ring + (uint32_t)(clampi(r.y0 + 1, 0, Hin - 1) % 3) * (uint32_t)kBhRowBytes;
+  auto pair_lerp = [&](const uint8_t* row, int q) -> float3 {   // c.off[q]: byte offset of the pair in the blue plane (8 B per column)
+    const float4 rg = *reinterpret_cast<const float4*>(row + 2u * c.off[q]);
+    const float2 bb = *reinterpret_cast<const float2*>(row + kBhRowRG + c.off[q]);
+    return lerp3(c.wx[q], make_float3(rg.x, rg.z, bb.x), make_float3(rg.y, rg.w, bb.y));
+  };
   auto tap = [&](int q) -> float3 {
-    const float4 a0 = *reinterpret_cast<const float4*>(rowA + c.off[q]), a1 = *reinterpret_cast<const float4*>(rowA + c.off[q] + 16u);
-    float3 top = lerp3(c.wx[q], f3(a0), f3(a1));
-    if (TWO) {
-      const float4 b0 = *reinterpret_cast<const float4*>(rowB + c.off[q]), b1 = *reinterpret_cast<const float4*>(rowB + c.off[q] + 16u);
-      top = lerp3(r.wy, top, lerp3(c.wx[q], f3(b0), f3(b1)));
-    }
+    float3 top = pair_lerp(rowA, q);
+    if (TWO) top = lerp3(r.wy, top, pair_lerp(rowB, q));
     return top;
   };
   // tex2Dblur17fast in the GL's evaluation order (see blur17 above)
@@ -372,7 +389,7 @@ __device__ __forceinline__ BhCol load_bh_col(const uint32_t* cols, int W, int xc
   BhCol c;
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
-    c.off[q] = (uint32_t)((int)cols[((BH_DX + q) * 2 + side) * W + xc] + (xc - xw) + kBhSegLeft) * 16u;
+    c.off[q] = (uint32_t)((int)cols[((BH_DX + q) * 2 + side) * W + xc] + (xc - xw) + kBhSegLeft) * 8u;
     c.wx[q] = bits2f(cols[((BH_WX + q) * 2 + side) * W + xc]);
   }
   c.idim_x = (int)cols[(BH_IDIM_X * 2 + side) * W + xc];
@@ -407,9 +424,19 @@ __device__ __forceinline__ void bloomh_strip_side(const PassLaunch& L, const Srg
     *t1 = second ? img[r * Win + sx1] : 0u;
   };
   auto store_row = [&](int r, uint32_t t0, uint32_t t1) {   // row r lives in ring slot r % 3
-    float4* slot = reinterpret_cast<float4*>(ring) + (r % 3) * kBhSeg;
-    slot[lane] = make_float4(lds.dec[t0 & 255u], lds.dec[(t0 >> 8) & 255u], lds.dec[(t0 >> 16) & 255u], 0.0f);
-    if (second) slot[64 + lane] = make_float4(lds.dec[t1 & 255u], lds.dec[(t1 >> 8) & 255u], lds.dec[(t1 >> 16) & 255u], 0.0f);
+    uint8_t* slot = ring + (r % 3) * kBhRowBytes;
+    const float a0 = lds.dec[t0 & 255u], a1 = lds.dec[(t0 >> 8) & 255u], a2 = lds.dec[(t0 >> 16) & 255u];
+    const float b0 = lds.dec[t1 & 255u], b1 = lds.dec[(t1 >> 8) & 255u], b2 = lds.dec[(t1 >> 16) & 255u];   // lanes >= 20: unused
+    // the right-hand partner of column `lane` is the next lane's texel, of column 63 it is column 64 (lane 0's second texel)
+    float n0 = next_lane(a0, lane), n1 = next_lane(a1, lane), n2 = next_lane(a2, lane);
+    const float m0 = next_lane(b0, lane), m1 = next_lane(b1, lane), m2 = next_lane(b2, lane);
+    if (lane == 63) {
+      n0 = m0;   // lane 63's next_lane(b.) is lane 0's b.: the texel of column 64
+      n1 = m1;
+      n2 = m2;
+    }
+    ring_store(slot, lane, a0, a1, a2, n0, n1, n2);
+    if (second) ring_store(slot, 64 + lane, b0, b1, b2, m0, m1, m2);   // (column 83's partner is never read)
   };
   auto hal_hrow = [&](int r, float* h) {
     const int hw = L.extra[2].w;
@@ -492,10 +519,11 @@ __device__ __forceinline__ void bloomh_strip_mixed(const PassLaunch& L, const Sr
   const int xc = live ? x : W - 1;
   const uint32_t* img = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
   auto stage = [&](int r) {
-    float4* slot = reinterpret_cast<float4*>(ring) + (r % 3) * kBhSeg;
-    for (int j = lane; j < kBhSeg; j += 64) {
-      const uint32_t t = img[r * Win + clampi(xw - kBhSegLeft + j, 0, Win - 1)];
-      slot[j] = make_float4(lds.dec[t & 255u], lds.dec[(t >> 8) & 255u], lds.dec[(t >> 16) & 255u], 0.0f);
+    uint8_t* slot = ring + (r % 3) * kBhRowBytes;
+    for (int j = lane; j < kBhSeg; j += 64) {   // (rare path: both texels of the pair fetched and decoded by the lane)
+      const uint32_t t = img[r * Win + clampi(xw - kBhSegLeft + j, 0, Win - 1)], u = img[r * Win + clampi(xw - kBhSegLeft + j + 1, 0, Win - 1)];
+      ring_store(slot, j, lds.dec[t & 255u], lds.dec[(t >> 8) & 255u], lds.dec[(t >> 16) & 255u], lds.dec[u & 255u], lds.dec[(u >> 8) & 255u],
+                 lds.dec[(u >> 16) & 255u]);
     }
   };
   int staged = -1;
@@ -521,7 +549,7 @@ __device__ __forceinline__ void bloomh_strip_mixed(const PassLaunch& L, const Sr
 }
 
 template <class SO>
-__global__ void __launch_bounds__(kBhWaves * 64, 3) k_royale_bloom_h_strip(const PassLaunch L, const uint32_t* __restrict__ cols,
+__global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const PassLaunch L, const uint32_t* __restrict__ cols,
                                                                           const uint32_t* __restrict__ rows) {
   RC_SRGB_LDS(lds, L);
   const int tid = (int)threadIdx.x, lane = tid & 63;
@@ -555,7 +583,6 @@ void buildBhTables(const PassLaunch& L, hipStream_t s, BhTables* T) {
   }
   if (bad) (void)hipFree(bad);
   T->usable = ok && hbad == 0;
-  if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc bloom-h] tables for %dx%d: hip ok %d, geometry flags %u\n", L.out_w, L.out_h, (int)ok, hbad);
   if (std::getenv("RC_DEBUG_BH") && ok) {
     std::vector<uint32_t> hc(colWords), hr(rowWords);
     (void)hipMemcpy(hc.data(), T->cols, colWords * 4, hipMemcpyDeviceToHost);
@@ -652,7 +679,7 @@ hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
           if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return hipGetLastError();
           attr = true;
         }
-        hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks < 768 ? blocks : 768)), dim3(kBhWaves * 64), lds, s, L, T->cols, T->rows);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(kBhWaves * 64), lds, s, L, T->cols, T->rows);
         return hipGetLastError();
       }
     }
