@@ -213,7 +213,7 @@ __device__ __forceinline__ float lv2_line(float A, float B, float dl, float C, f
 __device__ __forceinline__ float dot_rgbw(const float4 p) { return p.x * 14.352f + (p.y * 28.176f + p.z * 5.472f); }
 
 // GENERIC false: RGBX8 / RGBA8 NEAREST clamp-to-edge source and a plain RGBA8 target (the shipped preset)
-template <int IN_FMT, bool GENERIC>
+template <int IN_FMT, bool GENERIC, bool DETAILS>
 __global__ void __launch_bounds__(256) k_xbr_lv2(const PassLaunch L) {
   RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) k_xbr_lv2(const PassLaunch L) {
   F4 i4 = F4{{dot_rgbw(I4), dot_rgbw(C1), dot_rgbw(A0), dot_rgbw(G5)}}, i5 = F4{{dot_rgbw(I5), dot_rgbw(C4), dot_rgbw(A1), dot_rgbw(G0)}};
   F4 h5 = F4{{dot_rgbw(H5), dot_rgbw(F4_), dot_rgbw(B1), dot_rgbw(D0)}};
   F4 wd1 = wd(e, c, g, i, h5, i, h, f), wd2 = wd(h, d, i5, f, i4, b, e, i);
-  if (!(L.params[5] < 0.5f)) {   // small_details (FS 285-290, 320-323): outer lumas with XBR_Y_WEIGHT * Y, seven-term distance
+  if (DETAILS) {   // small_details >= 0.5 (FS 285-290, 320-323): outer lumas with XBR_Y_WEIGHT * Y, seven-term distance
     const float y0 = L.params[1] * 0.2126f, y1 = L.params[1] * 0.7152f, y2 = L.params[1] * 0.0722f;
     auto ly = [&](const float4 p) { return y0 * p.x + (y1 * p.y + y2 * p.z); };
     i4 = F4{{ly(I4), ly(C1), ly(A0), ly(G5)}};
@@ -484,9 +484,16 @@ namespace rck {
 
 hipError_t launch_xbr_lv2(const PassLaunch& L, hipStream_t s) {
   const bool fast = !L.in.linear && L.in.wrap == WRAP_EDGE && L.out_fmt == FMT_RGBA8 && !(L.flags & RC_FLAG_GENERAL_ONLY);
-  if (fast && L.in.fmt == FMT_RGBX8) hipLaunchKernelGGL((k_xbr_lv2<FMT_RGBX8, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
-  else if (fast && L.in.fmt == FMT_RGBA8) hipLaunchKernelGGL((k_xbr_lv2<FMT_RGBA8, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
-  else hipLaunchKernelGGL((k_xbr_lv2<FMT_RGBA8, true>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  const bool details = !(L.params[5] < 0.5f);   // "Preserve Small Details"
+#define RC_XBR2(FMT, GEN)                                                                                                          \
+  do {                                                                                                                             \
+    if (details) hipLaunchKernelGGL((k_xbr_lv2<FMT, GEN, true>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);              \
+    else hipLaunchKernelGGL((k_xbr_lv2<FMT, GEN, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);                     \
+  } while (0)
+  if (fast && L.in.fmt == FMT_RGBX8) RC_XBR2(FMT_RGBX8, false);
+  else if (fast && L.in.fmt == FMT_RGBA8) RC_XBR2(FMT_RGBA8, false);
+  else RC_XBR2(FMT_RGBA8, true);
+#undef RC_XBR2
   return hipGetLastError();
 }
 hipError_t launch_xbr_lv3(const PassLaunch& L, hipStream_t s) {
