@@ -225,6 +225,9 @@ int main(int argc, char** argv) {
     BindAttribLocation(p.program, 0, "Position");
     BindAttribLocation(p.program, 0, "VertexCoord");
     BindAttribLocation(p.program, 1, "TexCoord");
+    // :712-718: the motion-blur shaders' per-history-frame coordinates all alias location 1
+    for (const char* n : {"PrevTexCoord", "Prev1TexCoord", "Prev2TexCoord", "Prev3TexCoord", "Prev4TexCoord", "Prev5TexCoord", "Prev6TexCoord"})
+      BindAttribLocation(p.program, 1, n);
     BindAttribLocation(p.program, 2, "COLOR");
     LinkProgram(p.program);
     GLint ok = 0;

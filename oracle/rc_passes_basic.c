@@ -207,6 +207,106 @@ void o_pass_mix_frames(const o_pass_args* a) {
   o_fp_leave(csr);
 }
 
+/* The other frame-history shaders of motionblur/ (each a one-pass preset, NEAREST input).  extra[] = the history
+ * textures in the order given per function; every one of them samples all textures at the same coordinate
+ * (motionblur-simple's PrevNTexCoord attributes alias TexCoord's location in the reference, ShaderEngine.cpp:712-718).
+ *
+ * motionblur-simple.glsl (VS 81-97, FS 178-199): extra[0..6] = Prev6, Prev5, ..., Prev1, PrevTexture;
+ *   c = P6; c = (c + P5)/2; ... c = (c + Prev)/2; c = (c + Texture)/2, all four components. */
+static void o_pass_motionblur_simple_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      o_vec4 c = o_sample(a->extra[0], u, v);
+      for (int k = 1; k <= 7; ++k) {
+        const o_vec4 t = k < 7 ? o_sample(a->extra[k], u, v) : o_sample(a->in, u, v);
+        c.x = (c.x + t.x) / 2.0f; c.y = (c.y + t.y) / 2.0f; c.z = (c.z + t.z) / 2.0f; c.w = (c.w + t.w) / 2.0f;
+      }
+      store_px(a, x, y, c);
+    }
+}
+void o_pass_motionblur_simple(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_motionblur_simple_body(a); o_fp_leave(csr); }
+
+/* braid-rewind.glsl (VS 50-66, FS 135-160): the blend with the seven history frames applies only while rewinding
+ * (FrameDirection < 0); the reference always sets FrameDirection = 1 (ShaderEngine.cpp:2164-2170), so the pass outputs
+ * the current frame's sample, all four components.  (The history samplers are still declared, hence bound.) */
+static void o_pass_braid_rewind_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      store_px(a, x, y, o_sample(a->in, o_varying_at(&tu, x, y, lo), o_varying_at(&tv, x, y, lo)));
+    }
+}
+void o_pass_braid_rewind(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_braid_rewind_body(a); o_fp_leave(csr); }
+
+/* response-time.glsl (VS 52-56, FS 122-136): param response_time; extra[0..6] = PrevTexture, Prev1, ..., Prev6;
+ *   rgb += (prev_k - rgb) * response_time^(k+1), alpha 0.  pow(x, 2.0) is lowered to x*x (and 4.0 to two squarings),
+ *   the other powers run the exp2/log2 polynomials. */
+static void o_pass_response_time_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float rt = a->params[0];
+  float k[7];
+  k[0] = rt;
+  k[1] = rt * rt;
+  k[2] = o_pow(rt, 3.0f);
+  k[3] = (rt * rt) * (rt * rt);
+  k[4] = o_pow(rt, 5.0f);
+  k[5] = o_pow(rt, 6.0f);
+  k[6] = o_pow(rt, 7.0f);
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      o_vec4 c = o_sample(a->in, u, v);
+      for (int q = 0; q < 7; ++q) {
+        const o_vec4 p = o_sample(a->extra[q], u, v);
+        c.x = c.x + (p.x - c.x) * k[q]; c.y = c.y + (p.y - c.y) * k[q]; c.z = c.z + (p.z - c.z) * k[q];
+      }
+      c.w = 0.0f;
+      store_px(a, x, y, c);
+    }
+}
+void o_pass_response_time(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_response_time_body(a); o_fp_leave(csr); }
+
+/* mix_frames_smart.glsl (VS 41-45: TEX0 = TexCoord * 1.0001; FS 64-105): param DEFLICKER_EMPHASIS;
+ * extra[0..4] = PrevTexture, Prev1, ..., Prev4.  Mixes the current and the previous frame 50:50 where alternate frames
+ * repeat and adjacent ones differ (a flicker pattern); all the tests are exact comparisons or a step(). */
+static void o_pass_mix_frames_smart_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float edge = 0.000001f + a->params[0];
+  const float k1 = 1.0001f;
+  o_varying tu = o_varying_setup(0.f * k1, 1.f * k1, 1.f * k1, 0.f * k1, W, H, a->out_fmt);
+  o_varying tv = o_varying_setup(0.f * k1, 0.f * k1, 1.f * k1, 1.f * k1, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      o_vec4 c[6];
+      c[0] = o_sample(a->in, u, v);
+      for (int q = 0; q < 5; ++q) c[q + 1] = o_sample(a->extra[q], u, v);
+#define IS_EQ(i, j) ((c[i].x == c[j].x && c[i].y == c[j].y && c[i].z == c[j].z) ? 1.0f : 0.0f)
+#define IS_AEQ(i, j) ((!(fabsf(c[i].x - c[j].x) >= edge) && !(fabsf(c[i].y - c[j].y) >= edge) && !(fabsf(c[i].z - c[j].z) >= edge)) ? 1.0f : 0.0f)
+      const float alt = IS_AEQ(0, 2) * IS_AEQ(2, 4) + IS_AEQ(1, 3) * IS_AEQ(3, 5);
+      float m = (1.0f - IS_EQ(0, 3)) * (1.0f - IS_EQ(0, 5)) * (1.0f - IS_EQ(1, 2)) * (1.0f - IS_EQ(1, 4)) * (1.0f - IS_EQ(2, 3)) * (1.0f - IS_EQ(2, 5));
+      m = m * (alt < 1.0f ? alt : 1.0f);
+#undef IS_EQ
+#undef IS_AEQ
+      const float t = m * 0.5f;
+      o_vec4 o;
+      /* mix() with a per-pixel weight: a + t (b - a) */
+      o.x = c[0].x + t * (c[1].x - c[0].x); o.y = c[0].y + t * (c[1].y - c[0].y); o.z = c[0].z + t * (c[1].z - c[0].z);
+      o.w = 1.0f;
+      store_px(a, x, y, o);
+    }
+}
+void o_pass_mix_frames_smart(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_mix_frames_smart_body(a); o_fp_leave(csr); }
+
 /* Conformance fixture tests/fixtures/conformance/feedback-persist.glsl (this repository's own shader,
  * FS main): max(cur*0.75 + old0*0.25, old1*PERSIST); extra[0] = PassFeedback0, extra[1] = PassFeedback1.
  * params: PERSIST */

@@ -38,6 +38,19 @@ void setupCrtGeom(const PassGeometry& g, rcd::PassLaunch& L) {
   L.plane[2] = makePlane(0.f, mf1, mf1, 0.f, g.out_w, g.out_h, g.out_fmt);
   rcgeom::vertex_constants(L.params);
 }
+// response-time.glsl FS 126-133: response_time and pow(response_time, 2.0 .. 7.0) as the GL evaluates them - the
+// exponents 2 and 4 are lowered to multiplications, the others run the exp2/log2 polynomials
+void setupResponseTime(const PassGeometry& g, rcd::PassLaunch& L) {
+  setupTexCoord(g, L);
+  const float rt = L.params[0];
+  L.params[1] = rt;
+  L.params[2] = rt * rt;
+  L.params[3] = rcd::pow_(rt, 3.0f);
+  L.params[4] = (rt * rt) * (rt * rt);
+  L.params[5] = rcd::pow_(rt, 5.0f);
+  L.params[6] = rcd::pow_(rt, 6.0f);
+  L.params[7] = rcd::pow_(rt, 7.0f);
+}
 // glow/blur_{horiz,vert}.glsl: the nine weights exp(-0.35 i^2) and their sum.  The loop is unrolled by the GL's
 // compiler and exp() of a constant folded with a correctly rounded exp, not the run-time polynomial.
 void setupGlowBlur(const PassGeometry& g, rcd::PassLaunch& L) {
@@ -352,6 +365,19 @@ std::vector<KernelEntry> build() {
                {"PassFeedback0", "PassFeedback1"}, rck::launch_feedback_persist, setupTexCoord, false});
   r.push_back({"motionblur/shaders/mix_frames.glsl", "mix-frames", {}, {"PrevTexture"}, rck::launch_mix_frames, setupCrtPi,
                false, true, nullptr, nullptr, true});  // VS: TEX0 = TexCoord * 1.0001 (mix_frames.glsl:53)
+  // the other four motionblur/ presets: frame history down to Prev6Texture (kernels/pass_basic.hip)
+  r.push_back({"motionblur/shaders/motionblur-simple.glsl", "motionblur-simple", {},
+               {"Prev6Texture", "Prev5Texture", "Prev4Texture", "Prev3Texture", "Prev2Texture", "Prev1Texture", "PrevTexture"},
+               rck::launch_motionblur_simple, setupTexCoord, false, true, nullptr, nullptr, true});
+  r.push_back({"motionblur/shaders/braid-rewind.glsl", "braid-rewind", {},
+               {"Prev6Texture", "Prev5Texture", "Prev4Texture", "Prev3Texture", "Prev2Texture", "Prev1Texture", "PrevTexture"},
+               rck::launch_braid_rewind, setupTexCoord, false, true, nullptr, nullptr, true});
+  r.push_back({"motionblur/shaders/response-time.glsl", "response-time", {{"response_time", 0.333f, 0.0f, 0.777f, 0.111f, "LCD Response Time"}},
+               {"PrevTexture", "Prev1Texture", "Prev2Texture", "Prev3Texture", "Prev4Texture", "Prev5Texture", "Prev6Texture"},
+               rck::launch_response_time, setupResponseTime, false, true, nullptr, nullptr, true});
+  r.push_back({"motionblur/shaders/mix_frames_smart.glsl", "mix-frames-smart", {{"DEFLICKER_EMPHASIS", 0.0f, 0.0f, 1.0f, 0.01f, "Deflicker Emphasis"}},
+               {"PrevTexture", "Prev1Texture", "Prev2Texture", "Prev3Texture", "Prev4Texture"},
+               rck::launch_mix_frames_smart, setupCrtPi, false, true, nullptr, nullptr, true});   // VS: TEX0 = TexCoord * 1.0001
   r.push_back({"ntsc/shaders/ntsc-pass1-svideo-3phase.glsl", "ntsc-pass1-svideo-3phase", {}, {},
                rck::launch_ntsc_pass1, setupNtscPass1, false});
   r.push_back({"ntsc/shaders/ntsc-pass2-3phase-gamma.glsl", "ntsc-pass2-3phase-gamma", {}, {},

@@ -98,6 +98,70 @@ __global__ void __launch_bounds__(256) k_mix_frames(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// The other frame-history shaders of motionblur/ (oracle/rc_passes_basic.c); every texture is sampled at the pass's one
+// coordinate (motionblur-simple's PrevNTexCoord attributes alias TexCoord's location in the reference).
+// motionblur-simple.glsl FS 178-199: extra[0..6] = Prev6 .. Prev1, PrevTexture; c = (c + next) / 2 down to the current frame
+__global__ void __launch_bounds__(256) k_motionblur_simple(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  float4 c = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), u, v, &lds);
+#pragma unroll
+  for (int k = 1; k <= 7; ++k) {
+    const float4 t = k < 7 ? sample_rt(L.extra[k], frame_ptr(L.extra[k], z), u, v, &lds) : sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+    c = make_float4((c.x + t.x) / 2.0f, (c.y + t.y) / 2.0f, (c.z + t.z) / 2.0f, (c.w + t.w) / 2.0f);
+  }
+  store_rt(L, z, x, y, c, &lds);
+  RC_TILE_LOOP_END
+}
+// braid-rewind.glsl FS 135-160: FrameDirection is always 1 in the reference, so the history blend never applies
+__global__ void __launch_bounds__(256) k_braid_rewind(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  store_rt(L, z, x, y, sample_rt(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds), &lds);
+  RC_TILE_LOOP_END
+}
+// response-time.glsl FS 122-136: extra[0..6] = PrevTexture, Prev1 .. Prev6; params[0] = response_time, params[1..7] = its
+// powers 1..7 as the GL evaluates them (host, kernel_registry.cpp); alpha 0
+__global__ void __launch_bounds__(256) k_response_time(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  float4 c = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const float4 p = sample_rt(L.extra[q], frame_ptr(L.extra[q], z), u, v, &lds);
+    const float k = L.params[1 + q];
+    c.x = c.x + (p.x - c.x) * k;
+    c.y = c.y + (p.y - c.y) * k;
+    c.z = c.z + (p.z - c.z) * k;
+  }
+  c.w = 0.0f;
+  store_rt(L, z, x, y, c, &lds);
+  RC_TILE_LOOP_END
+}
+// mix_frames_smart.glsl FS 64-105: extra[0..4] = PrevTexture, Prev1 .. Prev4; params[0] = DEFLICKER_EMPHASIS
+__global__ void __launch_bounds__(256) k_mix_frames_smart(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  const float edge = 0.000001f + L.params[0];
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  float4 c[6];
+  c[0] = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+#pragma unroll
+  for (int q = 0; q < 5; ++q) c[q + 1] = sample_rt(L.extra[q], frame_ptr(L.extra[q], z), u, v, &lds);
+  auto is_eq = [&](int i, int j) { return (c[i].x == c[j].x && c[i].y == c[j].y && c[i].z == c[j].z) ? 1.0f : 0.0f; };
+  auto is_aeq = [&](int i, int j) {
+    return (!(__builtin_fabsf(c[i].x - c[j].x) >= edge) && !(__builtin_fabsf(c[i].y - c[j].y) >= edge) && !(__builtin_fabsf(c[i].z - c[j].z) >= edge)) ? 1.0f : 0.0f;
+  };
+  const float alt = is_aeq(0, 2) * is_aeq(2, 4) + is_aeq(1, 3) * is_aeq(3, 5);
+  float m = (1.0f - is_eq(0, 3)) * (1.0f - is_eq(0, 5)) * (1.0f - is_eq(1, 2)) * (1.0f - is_eq(1, 4)) * (1.0f - is_eq(2, 3)) * (1.0f - is_eq(2, 5));
+  m = m * (alt < 1.0f ? alt : 1.0f);
+  const float t = m * 0.5f;
+  store_rt(L, z, x, y, make_float4(c[0].x + t * (c[1].x - c[0].x), c[0].y + t * (c[1].y - c[0].y), c[0].z + t * (c[1].z - c[0].z), 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
 // Conformance fixture tests/fixtures/conformance/feedback-persist.glsl (this repository's own shader):
 // max(cur*0.75 + old0*0.25, old1*PERSIST); extra[0] = PassFeedback0, extra[1] = PassFeedback1
 __global__ void __launch_bounds__(256) k_feedback_persist(const PassLaunch L) {
@@ -455,6 +519,16 @@ hipError_t launch_mix_frames(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_mix_frames, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
+#define RC_SIMPLE_LAUNCH(fn, kernel)                                                        \
+  hipError_t fn(const PassLaunch& L, hipStream_t s) {                                       \
+    hipLaunchKernelGGL(kernel, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);       \
+    return hipGetLastError();                                                               \
+  }
+RC_SIMPLE_LAUNCH(launch_motionblur_simple, k_motionblur_simple)
+RC_SIMPLE_LAUNCH(launch_braid_rewind, k_braid_rewind)
+RC_SIMPLE_LAUNCH(launch_response_time, k_response_time)
+RC_SIMPLE_LAUNCH(launch_mix_frames_smart, k_mix_frames_smart)
+#undef RC_SIMPLE_LAUNCH
 hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_feedback_persist, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();

@@ -47,7 +47,7 @@ constexpr int RC_FLAG_STOCK_NO_BLIT = 1 << 17; // stock.glsl: the ordinary sampl
 constexpr int RC_FLAG_XBR_REGULAR = 1 << 8;
 constexpr int RC_FLAG_NTSC_REGULAR = 1 << 9; // ntsc pass 2: tap k of target column x reads source column c(x)+k-24, c(x+1) = c(x)+2  // xbr: sampled columns/rows are centre-2..centre+2 for every target pixel
 
-constexpr int kMaxExtra = 6;
+constexpr int kMaxExtra = 8;
 constexpr int kMaxPlanes = 12;
 constexpr int kMaxParams = 48;
 

@@ -114,6 +114,9 @@ void ShaderEngine::cleanupPresetPasses() {
   m_passes.clear();
   if (m_sourceMips.ptr) (void)hipFree(m_sourceMips.ptr);
   m_sourceMips = DeviceBuffer();
+  if (m_historyCleared.ptr) (void)hipFree(m_historyCleared.ptr);
+  m_historyCleared = DeviceBuffer();
+  m_historyClearedBytes = 0;
   for (auto& h : m_frameHistory)
     if (h.buf.ptr) (void)hipFree(h.buf.ptr);
   m_frameHistory.clear();
@@ -856,12 +859,25 @@ bool ShaderEngine::pushHistory(const void* finalFrame, int frameCount, const rcd
     return false;
   }
   HistoryFrame hf;
+  const void* recycled = nullptr;
   if (m_frameHistory.size() >= kMaxFrameHistory) {  // reuse the oldest (:1764-1778)
     hf = m_frameHistory.back();
     m_frameHistory.pop_back();
+    recycled = hf.buf.ptr;
   }
   const size_t bytes = (size_t)lastPass.width * lastPass.height * 4;
   if (!ensureBuffer(hf.buf, bytes)) return false;
+  if (recycled) {
+    // The reference clears the recycled texture to (0, 0, 0, 1) (:1797-1798) and draws into it while this frame's
+    // binding still has it on a sampler unit (the oldest entry: Prev6Texture) - every fragment of the re-draw reads
+    // its own, just cleared, texel (pinned on llvmpipe, tests/golden/motionblur_simple_*_f9).  Here: a constant
+    // cleared image of the same size stands in for it on those units.
+    if (m_historyCleared.bytes < bytes || m_historyClearedBytes != bytes) {
+      if (!ensureBuffer(m_historyCleared, bytes)) return false;
+      if (!hipOk(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m_historyCleared.ptr), (int)0xff000000u, bytes / 4, m_stream), "history clear")) return false;
+      m_historyClearedBytes = bytes;
+    }
+  }
   hf.width = lastPass.width;
   hf.height = lastPass.height;
 
@@ -887,6 +903,7 @@ bool ShaderEngine::pushHistory(const void* finalFrame, int frameCount, const rcd
     auto it = m_pass0Units.find(k.samplers[s]);
     const int u = it == m_pass0Units.end() ? 0 : it->second;
     L.extra[s] = (u > 0 && u < (int)m_units.size()) ? m_units[(size_t)u] : L.in;
+    if (recycled && L.extra[s].base == recycled) L.extra[s].base = m_historyCleared.ptr;
   }
   for (size_t q = 0; q < k.params.size() && q < (size_t)rcd::kMaxParams; ++q) L.params[q] = effectiveParameter(p0, k.params[q], custom);
   PassGeometry geo;

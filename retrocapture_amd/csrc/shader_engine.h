@@ -235,6 +235,8 @@ class ShaderEngine {
   // levels 1.. of the chain of `level0` (fmt RGBX8 = the GL_RGB source frame) into `mips`, packed per frame
   bool buildMipLevels(const rcd::Tex& level0, uint32_t nFrames, DeviceBuffer* mips, int* levels, size_t* frameBytes);
   DeviceBuffer m_sourceMips;   // mipmap_input0: the chain of the source frames of the current chunk
+  DeviceBuffer m_historyCleared;   // (0, 0, 0, 1) image: what a recycled history texture reads as during its own re-draw
+  size_t m_historyClearedBytes = 0;
   bool runChunk(const void* inputs, uint64_t inStride, uint32_t width, uint32_t height, uint32_t nFrames,
                 int firstFrameCount, void* finalOut);
 };

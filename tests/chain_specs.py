@@ -47,6 +47,11 @@ scale_y1 = 1.0
     "xbr-lv3": ("xbr/xbr-lv3.glslp", 'shaders = 1\n\nshader0 = shaders/xbr-lv3.glsl\nfilter_linear0 = false\n'),
     "xbr-lv2": ("xbr/xbr-lv2.glslp", 'shaders = 1\n\nshader0 = shaders/xbr-lv2.glsl\nfilter_linear0 = false\n'),
     # same keys / values as the reference's motionblur/mix_frames.glslp
+    # same keys / values as the reference's other motionblur/ presets
+    "motionblur-simple": ("motionblur/motionblur-simple.glslp", 'shaders = 1\n\nshader0 = shaders/motionblur-simple.glsl\nfilter_linear0 = false\n'),
+    "braid-rewind": ("motionblur/braid-rewind.glslp", 'shaders = 1\n\nshader0 = shaders/braid-rewind.glsl\nfilter_linear0 = false\n'),
+    "response-time": ("motionblur/response-time.glslp", 'shaders = 1\n\nshader0 = shaders/response-time.glsl\nfilter_linear0 = false\n'),
+    "mix-frames-smart": ("motionblur/mix_frames_smart.glslp", 'shaders = "1"\n\nshader0 = "shaders/mix_frames_smart.glsl"\nfilter_linear0 = "false"\n'),
     "mix-frames": ("motionblur/mix_frames.glslp", 'shaders = "1"\n\nshader0 = "shaders/mix_frames.glsl"\nfilter_linear0 = "false"\n'),
     # PassFeedback conformance preset: the stock shader, then this repository's fixture shader
     "feedback-persist": ("feedback-persist.glslp",
@@ -347,6 +352,17 @@ SHADERS = {
                                           "samplers": ["PassFeedback0", "PassFeedback1"]},
     "motionblur/shaders/mix_frames.glsl": {"oracle": "mix_frames", "params": [], "samplers": ["PrevTexture"],
                                            "size_independent": True},
+    "motionblur/shaders/motionblur-simple.glsl": {"oracle": "motionblur_simple", "params": [], "size_independent": True,
+                                                  "samplers": ["Prev6Texture", "Prev5Texture", "Prev4Texture", "Prev3Texture", "Prev2Texture",
+                                                               "Prev1Texture", "PrevTexture"]},
+    "motionblur/shaders/braid-rewind.glsl": {"oracle": "braid_rewind", "params": [], "size_independent": True,
+                                             "samplers": ["Prev6Texture", "Prev5Texture", "Prev4Texture", "Prev3Texture", "Prev2Texture",
+                                                          "Prev1Texture", "PrevTexture"]},
+    "motionblur/shaders/response-time.glsl": {"oracle": "response_time", "params": [("response_time", 0.333)], "size_independent": True,
+                                              "samplers": ["PrevTexture", "Prev1Texture", "Prev2Texture", "Prev3Texture", "Prev4Texture",
+                                                           "Prev5Texture", "Prev6Texture"]},
+    "motionblur/shaders/mix_frames_smart.glsl": {"oracle": "mix_frames_smart", "params": [("DEFLICKER_EMPHASIS", 0.0)], "size_independent": True,
+                                                 "samplers": ["PrevTexture", "Prev1Texture", "Prev2Texture", "Prev3Texture", "Prev4Texture"]},
     **{"ntsc/shaders/ntsc-pass1-%s.glsl" % n: {"oracle": "ntsc_pass1_" + n.replace("-", "_"), "params": [], "samplers": []}
        for n in ("svideo-3phase", "composite-3phase", "svideo-2phase", "composite-2phase")},
     **{"ntsc/shaders/ntsc-pass2-%s.glsl" % n: {"oracle": "ntsc_pass2_" + n.replace("-", "_"), "params": [], "samplers": []}

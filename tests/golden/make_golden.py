@@ -258,6 +258,36 @@ def case_mix_frames():
     run_case("mix_frames_48x36_to_120x90_f9", GLSL + "/motionblur/mix_frames.glslp", moving(48, 36, 9, 21), 120, 90)
 
 
+def flicker(w, h, n, seed):
+    """n frames whose pixels partly alternate between two colours frame by frame (what mix_frames_smart looks for),
+    partly move, partly stay."""
+    rng = np.random.default_rng(seed)
+    a, b = rng.integers(0, 256, (h, w, 3), dtype=np.uint8), rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    kind = rng.integers(0, 4, (h, w, 1))
+    out = np.zeros((n, h, w, 3), np.uint8)
+    for f in range(n):
+        alt = a if f % 2 == 0 else b
+        near = np.clip(alt.astype(np.int16) + rng.integers(-1, 2, (h, w, 3)), 0, 255).astype(np.uint8)
+        rnd = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        out[f] = np.where(kind == 0, alt, np.where(kind == 1, near, np.where(kind == 2, a, rnd)))
+    return out
+
+
+def case_motionblur():
+    """The other four motionblur/ presets: frame history down to Prev6Texture, first-frames rule included (2 and 9 frames)."""
+    M = GLSL + "/motionblur/"
+    run_case("motionblur_simple_48x36_to_120x90_f9", M + "motionblur-simple.glslp", moving(48, 36, 9, 31), 120, 90)
+    run_case("motionblur_simple_40x30_to_40x30_f3", M + "motionblur-simple.glslp", moving(40, 30, 3, 32), 40, 30)
+    run_case("braid_rewind_48x36_to_120x90_f8", M + "braid-rewind.glslp", moving(48, 36, 8, 33), 120, 90)
+    run_case("response_time_48x36_to_120x90_f9", M + "response-time.glslp", moving(48, 36, 9, 34), 120, 90)
+    run_case("response_time_params_40x30_to_100x75_f4", M + "response-time.glslp", moving(40, 30, 4, 35), 100, 75, params=[("response_time", 0.666)])
+    run_case("mix_frames_smart_48x36_to_120x90_f8", M + "mix_frames_smart.glslp", flicker(48, 36, 8, 36), 120, 90)
+    run_case("mix_frames_smart_params_40x30_to_40x30_f7", M + "mix_frames_smart.glslp", flicker(40, 30, 7, 37), 40, 30, params=[("DEFLICKER_EMPHASIS", 0.01)])
+    run_case("f32_response_time_48x36_to_120x90_f9", M + "response-time.glslp", moving(48, 36, 9, 38), 120, 90, f32=True)
+    run_case("f32_mix_frames_smart_48x36_to_120x90_f8", M + "mix_frames_smart.glslp", flicker(48, 36, 8, 39), 120, 90, f32=True)
+    run_case("f32_motionblur_simple_48x36_to_120x90_f9", M + "motionblur-simple.glslp", moving(48, 36, 9, 40), 120, 90, f32=True)
+
+
 def case_feedback():
     # PassFeedback (reference ShaderEngine.cpp:1285-1347, swap :1710-1718): no shader in the reference's
     # tree declares it, so the engine semantics are pinned with a fixture shader of this repository
@@ -562,7 +592,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

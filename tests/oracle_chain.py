@@ -10,6 +10,7 @@ import math
 import numpy as np
 
 import chain_specs
+import oracle_lib
 from oracle_lib import Tex, run_pass
 
 
@@ -216,6 +217,17 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
         final = cur
         extra = [units[state.pass0_units[n]] if state.pass0_units.get(n, 0) else final for n in spec["samplers"]]
         ow, oh = sizes[-1]
+        if len(state.history) == 7:
+            # a full ring recycles its OLDEST texture as the target of this very draw (cpp:1762-1768) and clears it to
+            # (0, 0, 0, 1) first (:1797-1798) - while the frame's binding still has it on a sampler unit (Prev6Texture):
+            # every fragment reads its own, just cleared, texel (llvmpipe renders straight into the texture's memory)
+            oldest = state.history[6]
+            if oldest.shape[:2] != (oh, ow):
+                raise NotImplementedError("history ring recycling a texture of another size (re-allocated: undefined content)")
+            cleared = np.zeros_like(oldest)
+            cleared[..., 3] = 255
+            extra = [Tex(cleared, t.fmt, t.c.linear, {v: k for k, v in oracle_lib.WRAP.items()}.get(t.c.wrap, "clamp_to_edge"))
+                     if getattr(t, "arr", None) is oldest else t for t in extra]
         hist = run_pass(spec["oracle"], final, ow, oh, out_fmt="rgba8", extra=extra, **call)
         state.history.insert(0, hist)
         del state.history[7:]

@@ -319,17 +319,27 @@ def test_engine_matches_oracle(key, w, h, vw, vh, preset_tree, rc_lib):
     e.shutdown()
 
 
-@pytest.mark.parametrize("case", ["mix_frames_72x40_to_72x40_f3", "mix_frames_48x36_to_120x90_f9"])
+HISTORY_CASES = {"mix_frames_72x40_to_72x40_f3": "mix-frames", "mix_frames_48x36_to_120x90_f9": "mix-frames",
+                 "motionblur_simple_48x36_to_120x90_f9": "motionblur-simple", "motionblur_simple_40x30_to_40x30_f3": "motionblur-simple",
+                 "braid_rewind_48x36_to_120x90_f8": "braid-rewind", "response_time_48x36_to_120x90_f9": "response-time",
+                 "response_time_params_40x30_to_100x75_f4": "response-time", "mix_frames_smart_48x36_to_120x90_f8": "mix-frames-smart",
+                 "mix_frames_smart_params_40x30_to_40x30_f7": "mix-frames-smart"}
+
+
+@pytest.mark.parametrize("case", sorted(HISTORY_CASES))
 @pytest.mark.parametrize("as_batch", [False, True])
 def test_frame_history_matches_golden(case, as_batch, preset_tree, rc_lib):
-    """A preset whose pass samples PrevTexture: output of the last frame and the whole history ring
-    (first-frame rule, recursion through pass 0's program, wrap of the 7-deep ring) against llvmpipe,
-    with the frames applied one call at a time and as one batch."""
+    """The five motionblur/ presets (PrevTexture .. Prev6Texture): output of the last frame and the whole history ring
+    (first-frame rule, recursion through pass 0's program, wrap of the 7-deep ring with its recycled-and-cleared oldest
+    texture) against llvmpipe, with the frames applied one call at a time and as one batch."""
     from gpu_util import make_engine, run_engine
     g = np.load(os.path.join(GOLD, case + ".npz"))
     vw, vh = [int(v) for v in g["viewport"]]
     frames = g["input_rgb"]
-    e = make_engine(preset_tree["mix-frames"], vw, vh)
+    e = make_engine(preset_tree[HISTORY_CASES[case]], vw, vh)
+    if "param_names" in g:
+        for k, v in zip(g["param_names"], g["param_values"]):
+            assert e.setShaderParameter(str(k), float(v))
     if as_batch:
         final = run_engine(e, frames)[-1]
     else:

@@ -33,6 +33,13 @@ CASES = {
     "feedback_persist_64x40_to_64x40_f1": "feedback-persist",
     "feedback_persist_64x40_to_64x40_f2": "feedback-persist",
     "feedback_persist_64x40_to_150x90_f5": "feedback-persist",
+    "motionblur_simple_48x36_to_120x90_f9": "motionblur-simple",   # Prev .. Prev6; 9 frames: the full ring recycles (and clears) its oldest texture
+    "motionblur_simple_40x30_to_40x30_f3": "motionblur-simple",
+    "braid_rewind_48x36_to_120x90_f8": "braid-rewind",
+    "response_time_48x36_to_120x90_f9": "response-time",
+    "response_time_params_40x30_to_100x75_f4": "response-time",
+    "mix_frames_smart_48x36_to_120x90_f8": "mix-frames-smart",
+    "mix_frames_smart_params_40x30_to_40x30_f7": "mix-frames-smart",
     "mix_frames_72x40_to_72x40_f3": "mix-frames",
     "mix_frames_48x36_to_120x90_f9": "mix-frames",
     "ntsc_256px_composite_80x48_to_200x144": "ntsc-256px",
@@ -124,14 +131,19 @@ def run_sequence(passes, frames_rgb, vw, vh, **kw):
     return outs, st
 
 
-@pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] == "mix-frames"))
+HISTORY_PRESETS = ("mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart")
+
+
+@pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] in HISTORY_PRESETS))
 def test_oracle_frame_history_matches_llvmpipe(case, tmp_path, rc_lib):
     """Presets that sample frame history: the last frame's output AND the ring's content after
-    3 / 9 frames (first-frame rule, recursion through pass 0's program, wrap of the 7-deep ring)."""
+    3 ... 9 frames (first-frame rule, recursion through pass 0's program, wrap of the 7-deep ring - whose oldest
+    texture is recycled as the target of the history draw, cleared, while still bound as Prev6Texture)."""
     g = np.load(os.path.join(GOLD, case + ".npz"))
     passes = preset_passes(tmp_path, CASES[case])
     vw, vh = [int(v) for v in g["viewport"]]
-    outs, st = run_sequence(passes, g["input_rgb"], vw, vh)
+    custom = dict(zip([str(n) for n in g["param_names"]], [float(v) for v in g["param_values"]])) if "param_names" in g else None
+    outs, st = run_sequence(passes, g["input_rgb"], vw, vh, custom=custom)
     assert np.array_equal(outs[-1], g["pass0"])
     assert len(st.history) == int(g["n_history"]) == min(7, g["input_rgb"].shape[0])
     for k, hk in enumerate(st.history):
@@ -151,7 +163,7 @@ def test_oracle_pass_feedback_matches_llvmpipe(case, tmp_path, rc_lib):
         assert np.array_equal(outs[i], g["pass%d" % i]), "pass %d" % i
 
 
-@pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] not in ("mix-frames", "feedback-persist")))
+@pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] not in HISTORY_PRESETS + ("feedback-persist",)))
 def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
     g = np.load(os.path.join(GOLD, case + ".npz"))
     key = CASES[case]
@@ -249,9 +261,14 @@ def test_oracle_arithmetic_at_float_precision(case, tmp_path, rc_lib):
         assert ulp.size == 0 or ulp.max() <= 9000, "pass %d: max %d ulp" % (i, int(ulp.max()))
 
 
-def test_frame_history_at_float_precision(tmp_path, rc_lib):
-    g = np.load(os.path.join(GOLD, "f32_mix_frames_48x36_to_120x90_f3.npz"))
-    passes = preset_passes(tmp_path, "mix-frames")
+FLOAT_HISTORY = {"f32_mix_frames_48x36_to_120x90_f3": "mix-frames", "f32_response_time_48x36_to_120x90_f9": "response-time",
+                 "f32_mix_frames_smart_48x36_to_120x90_f8": "mix-frames-smart", "f32_motionblur_simple_48x36_to_120x90_f9": "motionblur-simple"}
+
+
+@pytest.mark.parametrize("case", sorted(FLOAT_HISTORY))
+def test_frame_history_at_float_precision(case, tmp_path, rc_lib):
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    passes = preset_passes(tmp_path, FLOAT_HISTORY[case])
     vw, vh = [int(v) for v in g["viewport"]]
     outs, st = run_sequence(passes, g["input_rgb"], vw, vh, force_f32=True)
     assert np.array_equal(outs[-1].view(np.uint32), g["pass0"].view(np.uint32))
@@ -323,4 +340,4 @@ def test_every_golden_file_has_a_case():
     assert names <= set(CASES) | set(FLOAT_CASES) | set(WRAP_CASES) | EXTRA_GOLDEN
 
 
-EXTRA_GOLDEN = {"f32_mix_frames_48x36_to_120x90_f3"} | set(BLIT_CASES)
+EXTRA_GOLDEN = set(FLOAT_HISTORY) | set(BLIT_CASES)
