@@ -331,26 +331,26 @@ void o_pass_xbr_lv3(const o_pass_args* a) {
  * XBR_Y_WEIGHT, XBR_EQ_THRESHOLD, XBR_LV1_COEFFICIENT, XBR_LV2_COEFFICIENT, small_details
  *
  * The shader reads a variable it never assigns: `f4` (declared FS 295; xbr-lv3 has f4 = h5.yzwx).  What llvmpipe makes
- * of the two uses was fitted on the goldens: in the weighted distance wd1 it reads as `i`, and eq(f, f4) in the
- * CORNER_C rule comes out true.  PARITY: "partial" for this shader - with those two choices the 8-bit output matches
- * llvmpipe in 99.99 % of the bytes with a maximum difference of 1 (float target: 99.3 % bit-identical, <= 3e-7): the
- * association of the line-equation sums is fitted, not fully pinned. */
+ * of its uses was fitted on the goldens: in the five-term weighted distance wd1 it reads as `i`, eq(f, f4) in the
+ * CORNER_C rule comes out true, and in the seven-term distances of the small_details branch |x - f4| is 0.  With the
+ * line equations pinned by float-target probes taken inside the complete shader (line_clamp below) the oracle is
+ * byte-exact on all five 8-bit goldens and bit-identical on both float goldens (both branches of small_details). */
 static inline float dot_rgbw(o_vec4 p) { return p.x * 14.352f + (p.y * 28.176f + p.z * 5.472f); }
 static inline f4 lumc(o_vec4 p0, o_vec4 p1, o_vec4 p2, o_vec4 p3) {
   f4 r = {{dot_rgbw(p0), dot_rgbw(p1), dot_rgbw(p2), dot_rgbw(p3)}};
   return r;
 }
-/* clamp((A*fp.y + B*fp.x + delta - C [- Ci]) / (2*delta), 0, 1).  `delta` is a mutable global, so nothing is
- * folded; the order of the additions follows the compiler's multiply-add fusing (as in rc_passes_royale.c): where
- * B*fp.x is a real product (|B| != 1: the 30 and 60 degree lines) the plain addends gather first,
- * B*fx + ((A*fy + delta) - C); where A and B are +-1 (the 45 degree lines) ((A*fy + delta) + B*fx) - C fits best */
-static inline f4 line_clamp(const float* A, const float* B, const float* dl, const float* C, float ci, float fy, float fx) {
+/* clamp((A*fp.y + B*fp.x + delta - C [- Ci]) / (2*delta), 0, 1).  `delta` is a mutable global, so nothing is folded at
+ * compile time; pinned with float-target probes taken inside the complete shader (all 16 components bit-identical):
+ *  - the 30 and 60 degree lines: the plain addends combine first and the products join from the inside out,
+ *    B*fx + (A*fy + (delta - C));
+ *  - the two 45 degree lines (fx45, fx45i) share s = B*fx + (A*fy + delta): (s - Co) and (s - (Co + Ci));
+ * then a true division by 2*delta and the clamp. */
+static inline f4 line_clamp(const float* A, const float* B, const float* dl, const float* C, float ci, int shared, float fy, float fx) {
   f4 r;
   for (int k = 0; k < 4; ++k) {
-    float num;
-    const float cc = ci != 0.0f ? C[k] + ci : C[k];   /* the two constants fold: (x - Co) - Ci -> x - (Co + Ci) */
-    if (fabsf(B[k]) != 1.0f) num = B[k] * fx + ((A[k] * fy + dl[k]) - cc);
-    else num = ((A[k] * fy + dl[k]) + B[k] * fx) - cc;
+    const float cc = ci != 0.0f ? C[k] + ci : C[k];
+    const float num = shared ? (B[k] * fx + (A[k] * fy + dl[k])) - cc : B[k] * fx + (A[k] * fy + (dl[k] - cc));
     float t = num / (2.0f * dl[k]);
     t = t > 0.0f ? t : 0.0f;
     r.v[k] = t < 1.0f ? t : 1.0f;
@@ -431,8 +431,8 @@ static void xbr_lv2_body(const o_pass_args* a) {
 #undef EQ
       b4 r2_left = b4_and(b4_ne(e, g), b4_ne(d, g));
       b4 r2_up = b4_and(b4_ne(e, c), b4_ne(b, c));
-      f4 fx45i = line_clamp(Ao, Bo, delta, Co, 0.25f, fpy, fpx), fx45 = line_clamp(Ao, Bo, delta, Co, 0.0f, fpy, fpx);
-      f4 fx30 = line_clamp(Ao, Bx, delta_l, Cx, 0.0f, fpy, fpx), fx60 = line_clamp(Ao, By, delta_u, Cy, 0.0f, fpy, fpx);
+      f4 fx45i = line_clamp(Ao, Bo, delta, Co, 0.25f, 1, fpy, fpx), fx45 = line_clamp(Ao, Bo, delta, Co, 0.0f, 1, fpy, fpx);
+      f4 fx30 = line_clamp(Ao, Bx, delta_l, Cx, 0.0f, 0, fpy, fpx), fx60 = line_clamp(Ao, By, delta_u, Cy, 0.0f, 0, fpy, fpx);
       f4 wd1 = wd(e, c, g, i, h5, f4_, h, f), wd2 = wd(h, d, i5, f, i4, b, e, i);
       if (details) {   /* FS 322-323 */
         /* the unassigned f4 again: |x - f4| comes out 0 in both calls (fitted: of 144 combinations of what the two

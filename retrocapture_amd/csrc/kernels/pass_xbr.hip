@@ -199,13 +199,14 @@ __global__ void __launch_bounds__(256) k_xbr_lv3(const PassLaunch L) {
 // ----------------------------------------------------------------------------- xbr-lv2 ------
 // xbr/shaders/xbr-lv2.glsl FS 260-361 (CORNER_C, SMOOTH_TIPS, both branches of small_details), same 5x5 coordinate set.
 // Restated as in oracle/rc_passes_ntsc_xbr.c, including what llvmpipe makes of the shader's unassigned `f4`
-// (reads as `i` in wd1; eq(f, f4) true) - parity "partial", see there.
+// (reads as `i` in wd1; eq(f, f4) true; |x - f4| = 0 in the small_details distances); byte-exact against llvmpipe.
 // params: XBR_SCALE (unused: a commented-out pragma the reference's scan still lists), XBR_Y_WEIGHT, XBR_EQ_THRESHOLD,
 // XBR_LV1_COEFFICIENT, XBR_LV2_COEFFICIENT, small_details
+// SHARED: the two 45-degree lines share s = B*fx + (A*fy + delta); the others fold (delta - C) first (oracle line_clamp)
+template <bool SHARED>
 __device__ __forceinline__ float lv2_line(float A, float B, float dl, float C, float ci, float fy, float fx) {
-  // addition order as in oracle/rc_passes_ntsc_xbr.c (line_clamp)
   const float cc = ci != 0.0f ? C + ci : C;
-  const float num = __builtin_fabsf(B) != 1.0f ? B * fx + ((A * fy + dl) - cc) : ((A * fy + dl) + B * fx) - cc;
+  const float num = SHARED ? (B * fx + (A * fy + dl)) - cc : B * fx + (A * fy + (dl - cc));
   float t = num / (2.0f * dl);
   t = t > 0.0f ? t : 0.0f;
   return t < 1.0f ? t : 1.0f;
@@ -275,10 +276,10 @@ __global__ void __launch_bounds__(256) k_xbr_lv2(const PassLaunch L) {
     const bool edri = wd1.v[k] <= wd2.v[k] && ne;
     const bool edr = wd1.v[k] + 0.1f <= wd2.v[k] && r1;
     const bool edr_l = lv2 * dfg <= dhc && r2l && edr, edr_u = lv2 * dhc <= dfg && r2u && edr;
-    const float f45 = edr ? lv2_line(Ao[k], Bo[k], third, Co[k], 0.0f, fpy, fpx) : 0.0f;
-    const float f45i = edri ? lv2_line(Ao[k], Bo[k], third, Co[k], 0.25f, fpy, fpx) : 0.0f;
-    const float f30 = edr_l ? lv2_line(Ao[k], Bx[k], dl[k], Cx[k], 0.0f, fpy, fpx) : 0.0f;
-    const float f60 = edr_u ? lv2_line(Ao[k], By[k], du[k], Cy[k], 0.0f, fpy, fpx) : 0.0f;
+    const float f45 = edr ? lv2_line<true>(Ao[k], Bo[k], third, Co[k], 0.0f, fpy, fpx) : 0.0f;
+    const float f45i = edri ? lv2_line<true>(Ao[k], Bo[k], third, Co[k], 0.25f, fpy, fpx) : 0.0f;
+    const float f30 = edr_l ? lv2_line<false>(Ao[k], Bx[k], dl[k], Cx[k], 0.0f, fpy, fpx) : 0.0f;
+    const float f60 = edr_u ? lv2_line<false>(Ao[k], By[k], du[k], Cy[k], 0.0f, fpy, fpx) : 0.0f;
     px[k] = df1(e.v[k], f.v[k]) <= df1(e.v[k], h.v[k]);
     const float m1 = f30 > f60 ? f30 : f60, m2 = f45 > f45i ? f45 : f45i;
     maximos[k] = m1 > m2 ? m1 : m2;

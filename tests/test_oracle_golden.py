@@ -96,16 +96,12 @@ CASES = {
     "crt_royale_maskon_96x128_to_512x384": "crt-royale",
 }
 
-# exact-match floor per preset (fraction of bytes identical to llvmpipe) and max |diff|
-# crt-royale: every pass that stores to an sRGB8 target can differ from llvmpipe by 1 LSB in
-# ~0.3 % of the bytes, because llvmpipe's sRGB encode runs through the x86 RSQRTPS
-# approximation and is not monotone ("sRGB8 store"); RGBA8 passes must be exact.
+# exact-match floor per preset (fraction of bytes identical to llvmpipe) and max |diff|.
 # Every preset is bit-exact against llvmpipe, its sRGB8 passes included (the sRGB8 encode is llvmpipe's own
-# RSQRTPS-based conversion, verified for every float in [0,1]: oracle/probes/srgb_encode_sweep.py), except:
-#  - xbr-lv2 (parity "partial": the shader reads an unassigned variable),
-#  - pass 3 of the crt-hyllian-glow case whose mip-mapped input is sampled at a fractional LOD (63x48 target):
-#    2 of 12 096 bytes differ by 1 (float residual of the two-level blend).
-BAR = {"xbr-lv2": (0.9998, 1)}
+# RSQRTPS-based conversion, verified for every float in [0,1]: oracle/probes/srgb_encode_sweep.py), except
+# pass 3 of the crt-hyllian-glow case whose mip-mapped input is sampled at a fractional LOD (63x48 target):
+# 2 of 12 096 bytes differ by 1 (float residual of the two-level blend).
+BAR = {}
 CASE_PASS_BAR = {("crt_hyllian_glow_80x60_to_250x190", 3): (0.9998, 1)}
 
 
@@ -186,11 +182,7 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
             d = np.abs(o.astype(np.int32) - ref.astype(np.int32))
             exact = float((d == 0).mean())
             fmt = str(g["pass%d_fmt" % i])
-            if key == "xbr-lv2":
-                # parity "partial" (oracle/rc_passes_ntsc_xbr.c): the shader reads an unassigned variable and the
-                # association of its line-equation sums is not pinned; alpha (never written by the shader) is exact
-                assert d.max() <= 1 and exact >= 0.9998, "pass %d: exact %.5f max %d" % (i, exact, d.max())
-            elif fmt == "rgba8":
+            if fmt == "rgba8":
                 assert d.max() == 0, "RGBA8 pass %d must be bit-exact: exact %.5f max %d" % (i, exact, d.max())
             assert d.max() <= maxdiff and exact >= floor, "pass %d: exact %.5f max %d" % (i, exact, d.max())
         else:
@@ -231,8 +223,8 @@ FLOAT_CASES = {
     "f32_smootheststep_64x48_to_200x150": ("smootheststep", {}),
     "f32_sharp_bilinear_64x48_to_200x150": ("sharp-bilinear", {}),
     "f32_crt_easymode_64x48_to_200x150": ("crt-easymode", {0: 0.95}),   # 8-bit goldens exact; <= 3e-7 in float
-    "f32_xbr_lv2_48x40_to_331x217": ("xbr-lv2", {0: 0.99}),   # parity "partial", see above
-    "f32_xbr_lv2_details_48x40_to_331x217": ("xbr-lv2", {0: 0.99}),
+    "f32_xbr_lv2_48x40_to_331x217": ("xbr-lv2", {}),
+    "f32_xbr_lv2_details_48x40_to_331x217": ("xbr-lv2", {}),
     "f32_crt_hyllian_glow_64x48_to_160x120": ("crt-hyllian-glow", {1: 0.93, 3: 0.5, 4: 0.93}),
     "f32_crt_hyllian_glow_64x48_to_150x110": ("crt-hyllian-glow", {1: 0.80, 3: 0.4, 4: 0.93}),
 }
