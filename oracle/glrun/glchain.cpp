@@ -340,7 +340,8 @@ int main(int argc, char** argv) {
         BindTexture(GL_TEXTURE_2D, p.tex);
         // GLCHAIN_F32=1: every pass renders to RGBA32F, so that the shaders' arithmetic can be compared
         // at float precision (8-bit targets hide last-bit differences); not the reference's formats
-        const bool f32 = pi.floatFramebuffer || force_f32;
+        // GLCHAIN_F32_LAST=1: only the last pass (to look at one pass's floats behind the reference's own formats)
+        const bool f32 = pi.floatFramebuffer || force_f32 || (getenv("GLCHAIN_F32_LAST") != nullptr && i + 1 == passes.size());
         GLenum ifmt = f32 ? GL_RGBA32F : pi.srgbFramebuffer ? GL_SRGB8_ALPHA8 : (getenv("GLCHAIN_RGBA8") ? GL_RGBA8 : GL_RGBA);
         if (getenv("GLCHAIN_NODITHER")) Disable(GL_DITHER);
         TexImage2D(GL_TEXTURE_2D, 0, ifmt, ow, oh, 0, GL_RGBA, f32 ? GL_FLOAT : GL_UNSIGNED_BYTE, nullptr);
@@ -657,7 +658,8 @@ int main(int argc, char** argv) {
     BindTexture(GL_TEXTURE_2D, p.written_tex ? p.written_tex : p.tex);
     std::string fn = out_dir + "/pass" + std::to_string(i) + ".bin";
     FILE* fo = fopen(fn.c_str(), "wb");
-    if (p.info.floatFramebuffer || force_f32) {
+    const bool last_f32 = getenv("GLCHAIN_F32_LAST") != nullptr && i + 1 == passes.size();
+    if (p.info.floatFramebuffer || force_f32 || last_f32) {
       std::vector<float> d((size_t)p.w * p.h * 4);
       GetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, GL_FLOAT, d.data());
       fwrite(d.data(), 4, d.size(), fo);
@@ -669,7 +671,7 @@ int main(int argc, char** argv) {
     }
     fclose(fo);
     meta << "pass " << i << " " << p.w << " " << p.h << " "
-         << ((p.info.floatFramebuffer || force_f32) ? "f32" : p.info.srgbFramebuffer ? "srgb8" : "rgba8") << " lin="
+         << ((p.info.floatFramebuffer || force_f32 || last_f32) ? "f32" : p.info.srgbFramebuffer ? "srgb8" : "rgba8") << " lin="
          << p.info.filterLinear << " wrap=" << p.info.wrapMode << " alias=" << p.info.alias
          << " shader=" << p.info.shaderPath << "\n";
     for (auto& kv : p.params) meta << "  param " << kv.first << " " << kv.second << "\n";
