@@ -81,6 +81,7 @@ void o_royale_beam_array(const float* dist, const float* color, float ph, float*
  * W x H target: plane-equation setup per triangle of the quad (BL,BR,TR)+(TR,TL,BL). */
 typedef struct { float a0_lo, dx_lo, dy_lo, a0_up, dx_up, dy_up; } o_varying;
 o_varying o_varying_setup(float a_bl, float a_br, float a_tr, float a_tl, int W, int H, int out_fmt);
+o_varying o_varying_setup_fan(float a_bl, float a_br, float a_tr, float a_tl, int W, int H, int out_fmt);   /* the GL's own blit quad */
 static inline int o_lower_tri(int x, int y, int W, int H) {
   return ((double)y + 0.5) * (double)W <= ((double)x + 0.5) * (double)H;
 }

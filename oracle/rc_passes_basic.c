@@ -69,6 +69,10 @@ static int blit_tile_inside(float a0, float d, int texsize, int x, int extent) {
 static void o_pass_stock_body(const o_pass_args* a) {
   const int W = a->out_w, H = a->out_h;
   o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  if (a->flags & O_FLAG_STOCK_NO_BLIT) {   /* a mip level: drawn by the GL's blitter, whose quad is a triangle fan */
+    tu = o_varying_setup_fan(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt);
+    tv = o_varying_setup_fan(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  }
   if (a->in->fmt == O_FMT_RGBA8 && a->in->wrap == O_WRAP_EDGE && a->out_fmt == O_FMT_RGBA8 && !(a->flags & O_FLAG_STOCK_NO_BLIT)) {
     const uint8_t* tex = (const uint8_t*)a->in->data;
     const int TW = a->in->w, TH = a->in->h;

@@ -64,9 +64,11 @@ static void glow_blur(const o_pass_args* a, int horizontal) {
   float k[9], k_total = 0.0f;
   for (int i = -4; i <= 4; ++i) {
     const float fi = (float)i;
-    /* the loop is unrolled and exp() of a constant is folded at compile time with the C library's exp2f/expf
-     * (correctly rounded), not the run-time polynomial */
-    k[i + 4] = (float)exp((double)(-0.35f * fi * fi));
+    /* the loop is unrolled and exp(-0.35 * i * i) of a constant i is folded at compile time - after the lowering
+     * exp(x) -> exp2(x * log2e) and the re-association that moves the constant factor onto one operand:
+     * exp2f(i * (i * (-0.35f * log2e))) in float (pinned with a float probe of blur_vert on exact texels: bit-identical;
+     * a correctly rounded exp() differs in the last bit of two of the nine weights) */
+    k[i + 4] = exp2f(fi * (fi * (-0.35f * 1.4426950408889634f)));
     k_total += k[i + 4];
   }
   for (int y = a->y0; y < a->y1; ++y)
@@ -145,6 +147,9 @@ void o_pass_crt_hyllian_glow(const o_pass_args* a) {
       const float lobes[4] = {fpx * fpx * fpx, fpx * fpx, fpx, 1.0f};
       float ip[4]; /* invX * lobes: columns accumulated left to right */
       for (int r = 0; r < 4; ++r) ip[r] = ((m[0][r] * lobes[0] + m[1][r] * lobes[1]) + m[2][r] * lobes[2]) + m[3][r] * lobes[3];
+      /* row 1 has a literal 0 in column 2 and lobes[3] is the literal 1: what is left is two products and a plain
+       * addend, and the addend joins the inner product (in-situ float probe, bit-identical) */
+      ip[1] = m[1][1] * lobes[1] + (m[0][1] * lobes[0] + m[3][1]);
       float col[2][4];
       for (int r = 0; r < 2; ++r) {
         const float* q0 = &c[r][0].x; const float* q1 = &c[r][1].x; const float* q2 = &c[r][2].x; const float* q3 = &c[r][3].x;
@@ -161,8 +166,10 @@ void o_pass_crt_hyllian_glow(const o_pass_args* a) {
         const float lum0 = MIXRT(bmin, bmax, col[0][ch]);
         const float lum1 = MIXRT(bmin, bmax, col[1][ch]);
         float d0 = (scan * pos0) / (lum0 + 0.0000001f), d1 = (scan * pos1) / (lum1 + 0.0000001f);
-        d0 = o_exp(-d0 * d0);
-        d1 = o_exp(-d1 * d1);
+        /* exp(-d*d) = exp2(((-d) * d) * log2e) with the constant moved onto one factor: exp2(d * (d * -log2e))
+         * (in-situ float probe, bit-identical) */
+        d0 = o_exp2(d0 * (d0 * -1.4426950408889634f));
+        d1 = o_exp2(d1 * (d1 * -1.4426950408889634f));
         const float cc = boost * (col[0][ch] * d0 + col[1][ch] * d1);
         out[ch] = o_pow(cc, 1.0f / gout);
       }

@@ -43,6 +43,20 @@ o_varying o_varying_setup(float a_bl, float a_br, float a_tr, float a_tl, int W,
   return v;
 }
 
+/* The quad of the GL's own blits (glGenerateMipmap: Mesa's u_blitter draws a TRIANGLE_FAN BL, BR, TR, TL): the first
+ * triangle is the pass quad's, the second reaches the rasteriser as (TR, TL, BL) - anchored at TR, with the diagonal
+ * edge in its y slope (lp_state_setup.c emit_linear_coef restated for these vertices). */
+o_varying o_varying_setup_fan(float a_bl, float a_br, float a_tr, float a_tl, int W, int H, int out_fmt) {
+  o_varying v = o_varying_setup(a_bl, a_br, a_tr, a_tl, W, H, out_fmt);
+  if (out_fmt == O_FMT_RGBA8) return v;
+  const float fw = (float)W, fh = (float)H;
+  const float ooa = 1.0f / (fw * fh), hy = fh * ooa, wx = fw * ooa;
+  v.dx_up = hy * (a_tr - a_tl);
+  v.dy_up = wx * (a_tr - a_bl) - wx * (a_tr - a_tl);
+  v.a0_up = a_tr - (v.dx_up * (fw - 0.5f) + v.dy_up * (fh - 0.5f));
+  return v;
+}
+
 float o_varying_at(const o_varying* v, int x, int y, int lower) {
   if (lower) return fmaf(v->dy_lo, (float)y, fmaf(v->dx_lo, (float)x, v->a0_lo));
   return fmaf(v->dy_up, (float)y, fmaf(v->dx_up, (float)x, v->a0_up));

@@ -51,14 +51,15 @@ void setupResponseTime(const PassGeometry& g, rcd::PassLaunch& L) {
   L.params[6] = rcd::pow_(rt, 6.0f);
   L.params[7] = rcd::pow_(rt, 7.0f);
 }
-// glow/blur_{horiz,vert}.glsl: the nine weights exp(-0.35 i^2) and their sum.  The loop is unrolled by the GL's
-// compiler and exp() of a constant folded with a correctly rounded exp, not the run-time polynomial.
+// glow/blur_{horiz,vert}.glsl: the nine weights exp(-0.35 i^2) and their sum.  The loop is unrolled by the GL's compiler
+// and the constant folded after exp(x) -> exp2(x * log2e) with the constant factor moved onto one operand:
+// exp2f(i * (i * (-0.35f * log2e))) in float (oracle/rc_passes_glow.c glow_blur).
 void setupGlowBlur(const PassGeometry& g, rcd::PassLaunch& L) {
   setupTexCoord(g, L);
   float total = 0.0f;
   for (int i = -4; i <= 4; ++i) {
     const float fi = (float)i;
-    const float k = (float)std::exp((double)(-0.35f * fi * fi));
+    const float k = exp2f(fi * (fi * (-0.35f * 1.4426950408889634f)));
     L.params[i + 4] = k;
     total += k;
   }

@@ -162,6 +162,9 @@ __global__ void __launch_bounds__(256) k_crt_hyllian_glow(const PassLaunch L) {
   float ip[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) ip[r] = ((m[r] * l0 + m[4 + r] * l1) + m[8 + r] * l2) + m[12 + r] * 1.0f;
+  // row 1 has a literal 0 in column 2 and the last lobe is the literal 1: two products and a plain addend, which joins
+  // the inner product (oracle/rc_passes_glow.c: in-situ float probe, bit-identical)
+  ip[1] = m[4 + 1] * l1 + (m[1] * l0 + m[12 + 1]);
   const float pos0 = fpy, pos1 = 1.0f - fpy;
   float out[4];
 #pragma unroll
@@ -175,8 +178,9 @@ __global__ void __launch_bounds__(256) k_crt_hyllian_glow(const PassLaunch L) {
     }
     const float lum0 = mix_rt_(bmin, bmax, col[0]), lum1 = mix_rt_(bmin, bmax, col[1]);
     float d0 = (scan * pos0) / (lum0 + 0.0000001f), d1 = (scan * pos1) / (lum1 + 0.0000001f);
-    d0 = exp_(-d0 * d0);
-    d1 = exp_(-d1 * d1);
+    // exp(-d*d): the constant of exp(x) = exp2(x * log2e) moves onto one factor (oracle)
+    d0 = exp2_(d0 * (d0 * -1.4426950408889634f));
+    d1 = exp2_(d1 * (d1 * -1.4426950408889634f));
     out[ch] = pow_(boost * (col[0] * d0 + col[1] * d1), 1.0f / gout);
   }
   store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], out[3]), &lds);

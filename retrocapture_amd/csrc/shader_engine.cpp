@@ -538,8 +538,8 @@ bool ShaderEngine::buildMipLevels(const rcd::Tex& level0, uint32_t nFrames, Devi
     L.vp_h = dh;
     L.n_frames = (int)nFrames;
     L.flags = rcd::RC_FLAG_STOCK_NO_BLIT;
-    L.plane[0] = makePlane(0.f, 1.f, 1.f, 0.f, dw, dh, storeFmt);
-    L.plane[1] = makePlane(0.f, 0.f, 1.f, 1.f, dw, dh, storeFmt);
+    L.plane[0] = makePlaneFan(0.f, 1.f, 1.f, 0.f, dw, dh, storeFmt);   // drawn by the GL's blitter: a triangle fan
+    L.plane[1] = makePlaneFan(0.f, 0.f, 1.f, 1.f, dw, dh, storeFmt);
     if (!hipOk(rck::launch_stock(L, m_stream), "mip level")) return false;
     src.base = L.out;
     src.frame_stride = bytes;

@@ -27,4 +27,18 @@ rcd::Plane makePlane(float a_bl, float a_br, float a_tr, float a_tl, int W, int 
   return p;
 }
 
+// The quad of the GL's own blits (glGenerateMipmap: Mesa's u_blitter draws the TRIANGLE_FAN BL, BR, TR, TL): the first
+// triangle is the pass quad's, the second reaches the rasteriser as (TR, TL, BL) - set up from vertex TR with the
+// diagonal edge in its y slope (oracle/rc_varying.c o_varying_setup_fan; float mip levels bit-identical with it).
+rcd::Plane makePlaneFan(float a_bl, float a_br, float a_tr, float a_tl, int W, int H, int out_fmt) {
+  rcd::Plane p = makePlane(a_bl, a_br, a_tr, a_tl, W, H, out_fmt);
+  if (out_fmt == rcd::FMT_RGBA8) return p;
+  const float fw = (float)W, fh = (float)H;
+  const float ooa = 1.0f / (fw * fh), hy = fh * ooa, wx = fw * ooa;
+  p.dx_up = hy * (a_tr - a_tl);
+  p.dy_up = wx * (a_tr - a_bl) - wx * (a_tr - a_tl);
+  p.a0_up = a_tr - (p.dx_up * (fw - 0.5f) + p.dy_up * (fh - 0.5f));
+  return p;
+}
+
 }  // namespace rc

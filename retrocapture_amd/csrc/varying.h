@@ -13,6 +13,8 @@
 namespace rc {
 // Vertex values at bottom-left, bottom-right, top-right, top-left.
 rcd::Plane makePlane(float a_bl, float a_br, float a_tr, float a_tl, int W, int H, int out_fmt);
+// the same for the quad the GL's own blits draw (mip level generation)
+rcd::Plane makePlaneFan(float a_bl, float a_br, float a_tr, float a_tl, int W, int H, int out_fmt);
 // TexCoord-proportional varyings: value = k * TexCoord.x (or .y)
 inline rcd::Plane planeU(float k, int W, int H, int fmt) { return makePlane(0.f * k, 1.f * k, 1.f * k, 0.f * k, W, H, fmt); }
 inline rcd::Plane planeV(float k, int W, int H, int fmt) { return makePlane(0.f * k, 0.f * k, 1.f * k, 1.f * k, W, H, fmt); }

@@ -96,13 +96,10 @@ CASES = {
     "crt_royale_maskon_96x128_to_512x384": "crt-royale",
 }
 
-# exact-match floor per preset (fraction of bytes identical to llvmpipe) and max |diff|.
-# Every preset is bit-exact against llvmpipe, its sRGB8 passes included (the sRGB8 encode is llvmpipe's own
-# RSQRTPS-based conversion, verified for every float in [0,1]: oracle/probes/srgb_encode_sweep.py), except
-# pass 3 of the crt-hyllian-glow case whose mip-mapped input is sampled at a fractional LOD (63x48 target):
-# 2 of 12 096 bytes differ by 1 (float residual of the two-level blend).
+# Every golden of every preset is byte-exact against llvmpipe, the sRGB8 passes included (the sRGB8 encode is
+# llvmpipe's own RSQRTPS-based conversion, verified for every float in [0,1]: oracle/probes/srgb_encode_sweep.py).
 BAR = {}
-CASE_PASS_BAR = {("crt_hyllian_glow_80x60_to_250x190", 3): (0.9998, 1)}
+CASE_PASS_BAR = {}
 
 
 def royale_luts():
@@ -212,9 +209,6 @@ FLOAT_CASES = {
     # pass 8 (the last pass, mipmap_input = true at 1:1): llvmpipe's trilinear LOD is a hair above 0 on some pixel
     # quads and blends a 1e-7 share of mip level 1 into the sample; restated (rc_sampler.c), bit-identical
     "f32_crt_royale_fake_bloom_maskon_64x48_to_128x96": ("crt-royale-fake-bloom", {1: 0.99}),
-    # crt-hyllian-glow: passes 0, 2 and 5 bit-identical; the residuals of pass 1 (<= 3e-6 absolute), of the two
-    # blurs (1 ulp: the association of the nine-term sum is not pinned) and of the mip-mapped pass 3 are far below
-    # an 8-bit step - the 8-bit goldens of every pass match at the sRGB-encode residual and the final pass exactly
     "f32_zfast_crt_64x48_to_200x150": ("zfast-crt", {}),
     "f32_crt_nes_mini_64x48_to_200x150": ("crt-nes-mini", {}),
     "f32_quilez_64x48_to_200x150": ("quilez", {}),
@@ -225,8 +219,8 @@ FLOAT_CASES = {
     "f32_crt_easymode_64x48_to_200x150": ("crt-easymode", {0: 0.95}),   # 8-bit goldens exact; <= 3e-7 in float
     "f32_xbr_lv2_48x40_to_331x217": ("xbr-lv2", {}),
     "f32_xbr_lv2_details_48x40_to_331x217": ("xbr-lv2", {}),
-    "f32_crt_hyllian_glow_64x48_to_160x120": ("crt-hyllian-glow", {1: 0.93, 3: 0.5, 4: 0.93}),
-    "f32_crt_hyllian_glow_64x48_to_150x110": ("crt-hyllian-glow", {1: 0.80, 3: 0.4, 4: 0.93}),
+    "f32_crt_hyllian_glow_64x48_to_160x120": ("crt-hyllian-glow", {}),   # all six passes bit-identical (mip-mapped pass 3 included)
+    "f32_crt_hyllian_glow_64x48_to_150x110": ("crt-hyllian-glow", {}),
 }
 
 
@@ -246,9 +240,6 @@ def test_oracle_arithmetic_at_float_precision(case, tmp_path, rc_lib):
         same = (o.view(np.uint32) == r.view(np.uint32)) | (np.isnan(o) & np.isnan(r))
         frac = float(same[..., :3].mean())
         assert frac >= floors.get(i, 1.0), "pass %d: %.5f of the float components bit-identical" % (i, frac)
-        if key == "crt-hyllian-glow":   # cancellation in the cubic filter: bound the absolute error instead of ulps
-            assert float(np.nanmax(np.abs(o - r)[..., :3])) <= 5e-6, "pass %d" % i   # (NaN where both are NaN)
-            continue
         ulp = np.abs(o.view(np.int32).astype(np.int64) - r.view(np.int32).astype(np.int64))[..., :3][~same[..., :3]]
         assert ulp.size == 0 or ulp.max() <= 9000, "pass %d: max %d ulp" % (i, int(ulp.max()))
 
