@@ -86,7 +86,7 @@ static const float k_chroma3[25] = {
 static const float k_luma2[33] = {
     -0.000174844f, -0.000205844f, -0.000149453f, -0.000051693f, 0.000000000f,  -0.000066171f, -0.000245058f,
     -0.000432928f, -0.000472644f, -0.000252236f, 0.000198929f,  0.000687058f,  0.000944112f,  0.000803467f,
-    0.000363199f,  0.000013422f,  0.000253402f,  0.001339461f,  0.002932972f,  0.003983485f,  0.00302668f,
+    0.000363199f,  0.000013422f,  0.000253402f,  0.001339461f,  0.002932972f,  0.003983485f,  0.003026683f,
     -0.001102056f, -0.008373026f, -0.016897700f, -0.022914480f, -0.021642347f, -0.008863273f, 0.017271957f,
     0.054921920f,  0.098342579f,  0.139044281f,  0.168055832f,  0.178571429f};
 static const float k_chroma2[33] = {
@@ -184,14 +184,14 @@ static inline f4 wd(f4 a, f4 b, f4 c, f4 d, f4 e, f4 f, f4 g, f4 h) {
 }
 /* smoothstep(C - delta, C + delta, A*fp.y + B*fp.x) (FS :267-271, :302-306).  The edges fold to
  * constants and the compiler moves the additive constant inward: the numerator is evaluated as
- * (A*fy - e0) + B*fx (measured on every component of the five calls), except where A = B = -1
- * (fx45.z), whose sum is first rewritten as -(fy + fx) and keeps the outer subtraction. */
+ * (A*fy - e0) + B*fx (float probes taken inside the complete shader, every component of the five calls), except where
+ * A = B = +-1 (fx45.x and fx45.z): there the sum is plain, (fy + fx) or -(fy + fx), and keeps the outer subtraction. */
 static inline f4 line_sstep(const float* A, const float* B, const float* C, float fy, float fx) {
   f4 r;
   for (int k = 0; k < 4; ++k) {
     const float e0 = C[k] - 0.4f, e1 = C[k] + 0.4f;
     float num;
-    if (A[k] == -1.0f && B[k] == -1.0f) num = (A[k] * fy + B[k] * fx) - e0;
+    if ((A[k] == -1.0f && B[k] == -1.0f) || (A[k] == 1.0f && B[k] == 1.0f)) num = (A[k] * fy + B[k] * fx) - e0;
     else num = (A[k] * fy - e0) + B[k] * fx;
     float t = num / (e1 - e0);
     t = t > 0.0f ? t : 0.0f;

@@ -94,7 +94,7 @@ __constant__ float k_chroma3[25] = {
 __constant__ float k_luma2[33] = {
     -0.000174844f, -0.000205844f, -0.000149453f, -0.000051693f, 0.000000000f,  -0.000066171f, -0.000245058f,
     -0.000432928f, -0.000472644f, -0.000252236f, 0.000198929f,  0.000687058f,  0.000944112f,  0.000803467f,
-    0.000363199f,  0.000013422f,  0.000253402f,  0.001339461f,  0.002932972f,  0.003983485f,  0.00302668f,
+    0.000363199f,  0.000013422f,  0.000253402f,  0.001339461f,  0.002932972f,  0.003983485f,  0.003026683f,
     -0.001102056f, -0.008373026f, -0.016897700f, -0.022914480f, -0.021642347f, -0.008863273f, 0.017271957f,
     0.054921920f,  0.098342579f,  0.139044281f,  0.168055832f,  0.178571429f};
 __constant__ float k_chroma2[33] = {

@@ -52,7 +52,7 @@ __device__ __forceinline__ F4 wd(const F4& a, const F4& b, const F4& c, const F4
 // smoothstep(C - 0.4, C + 0.4, A*fy + B*fx) for one component
 __device__ __forceinline__ float line_sstep(float A, float B, float C, float fy, float fx) {
   const float e0 = C - 0.4f, e1 = C + 0.4f;
-  const float num = (A == -1.0f && B == -1.0f) ? (A * fy + B * fx) - e0 : (A * fy - e0) + B * fx;
+  const float num = ((A == -1.0f && B == -1.0f) || (A == 1.0f && B == 1.0f)) ? (A * fy + B * fx) - e0 : (A * fy - e0) + B * fx;
   float t = num / (e1 - e0);
   t = t > 0.0f ? t : 0.0f;
   t = t < 1.0f ? t : 1.0f;
@@ -408,7 +408,7 @@ __device__ __forceinline__ float line_sstep_c(float fy, float fx) {
                               {5.0f, 3.0f, -3.0f, -1.0f}, {5.0f, -1.0f, -3.0f, 3.0f}};
   constexpr float A = A_[LINE][K], B = B_[LINE][K], C = C_[LINE][K];
   constexpr float e0 = C - 0.4f, e1 = C + 0.4f, d = e1 - e0, rd = 1.0f / d;
-  const float num = (A == -1.0f && B == -1.0f) ? (A * fy + B * fx) - e0 : (A * fy - e0) + B * fx;
+  const float num = ((A == -1.0f && B == -1.0f) || (A == 1.0f && B == 1.0f)) ? (A * fy + B * fx) - e0 : (A * fy - e0) + B * fx;
   float t = div_const_(num, d, rd);
   t = t > 0.0f ? t : 0.0f;
   t = t < 1.0f ? t : 1.0f;
