@@ -390,8 +390,9 @@ static float em_curve(float x, float sharp) {
 }
 static o_vec4 em_tex(const o_tex* t, float u, float v, float dil) {
   const o_vec4 c = o_sample(t, u, v);
-  const o_vec4 r = {c.x * (1.0f + dil * (c.x - 1.0f)), c.y * (1.0f + dil * (c.y - 1.0f)), c.z * (1.0f + dil * (c.z - 1.0f)),
-                    c.w * (1.0f + dil * (c.w - 1.0f))};
+  /* dilate(): col * mix(1.0, col, DILATION) with a uniform weight: a*(1 - t) + b*t (in-situ float probe) */
+  const float om = 1.0f - dil;
+  const o_vec4 r = {c.x * (om + c.x * dil), c.y * (om + c.y * dil), c.z * (om + c.z * dil), c.w * (om + c.w * dil)};
   return r;
 }
 static void em_lanczos(const o_tex* t, float u, float v, float dx, const float* k, float dil, float* out3) {

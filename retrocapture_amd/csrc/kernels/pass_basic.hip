@@ -369,9 +369,11 @@ __device__ __forceinline__ void em_lanczos(const Tex& t, const uint8_t* img, flo
     const float su = q == 0 ? u - dx : (q == 1 ? u : (q == 2 ? u + dx : u + 2.0f * dx));
     const float sv = q == 0 ? v - 0.0f : (q == 1 ? v : (q == 2 ? v + 0.0f : v + 2.0f * 0.0f));
     const float4 c = GENERIC ? sample_rt(t, img, su, sv, lds) : sample<FMT_RGBX8, 0, WRAP_EDGE>(t, img, su, sv, lds);
-    m[q][0] = c.x * (1.0f + dil * (c.x - 1.0f));
-    m[q][1] = c.y * (1.0f + dil * (c.y - 1.0f));
-    m[q][2] = c.z * (1.0f + dil * (c.z - 1.0f));
+    // dilate(): col * mix(1.0, col, DILATION) with a uniform weight: a*(1 - t) + b*t (oracle: in-situ float probe)
+    const float om = 1.0f - dil;
+    m[q][0] = c.x * (om + c.x * dil);
+    m[q][1] = c.y * (om + c.y * dil);
+    m[q][2] = c.z * (om + c.z * dil);
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {

@@ -53,7 +53,8 @@ __device__ __forceinline__ F gamma_impl1(F s, F s_inv) {
   const F sph = s + 0.5f;
   const F lanczos_sum = c0 + div_sel_<F, SAFE>(F(c1), s + 1.0f);  // s + 1 in [1.25, 1.5]
   // base is in [0.69, 0.78] for s = 1/beta in [1/4, 1/2]: a positive normal, no log2 edge cases
-  const F base = div_const_v<F>(sph + g, e, 1.0f / e);
+  // (s + 0.5 + g) / e: the GL folds the two additive constants, (s + (0.5 + g)) / e (oracle gamma_impl1)
+  const F base = div_const_v<F>(s + (0.5f + g), e, 1.0f / e);
   return (exp2_v<F, true>(log2_core_v<F>(base) * sph) * lanczos_sum) * s_inv;  // finite argument
 }
 
