@@ -162,6 +162,8 @@ void o_pass_royale_scan_h_fake(const o_pass_args* a); /* P7 of crt-royale-fake-b
 void o_pass_royale_brightpass(const o_pass_args* a);  /* P8  brightpass; extra[0] = PassPrev4 */
 void o_pass_royale_bloom_v(const o_pass_args* a);     /* P9  bloom-vertical */
 void o_pass_royale_bloom_h(const o_pass_args* a);     /* P10 bloom-horizontal-reconstitute; extra = PassPrev3, PassPrev2, PassPrev6 */
+int o_royale_last_is_general(const float* params);       /* tex2Daa / curved geometry selected (rc_passes_royale_last.c) */
+void o_pass_royale_last_general(const o_pass_args* a);
 void o_pass_royale_last(const o_pass_args* a);        /* P11 geometry-aa-last-pass; 44 params */
 /* ntsc/ntsc-256px-svideo.glslp (2 passes) and xbr/xbr-lv3.glslp (1 pass) */
 /* the ntsc family: ntsc-pass1-{svideo,composite}-{2,3}phase.glsl, ntsc-pass2-{2,3}phase{,-gamma,-linear}.glsl */

@@ -695,11 +695,16 @@ void o_pass_royale_bloom_h(const o_pass_args* a) {
 /* geometry-aa-last-pass.glsl: VS 5337-5400, FS 5451-5531, get_border_dim_factor 5250-5261,
  * get_aspect_vector 2512-2520.  LAST_PASS + SIMULATE_CRT_ON_LCD: output gamma = lcd_gamma.
  * params: the file's 44 #pragma parameters in declaration order (lines 21-64).
- * Only the flat path (geom_mode_runtime <= 0.5 and overscan == 1) is restated. */
+ * The flat path (geom_mode_runtime <= 0.5 and overscan == 1) is restated here; the tex2Daa / curved-geometry path is
+ * rc_passes_royale_last.c. */
 enum { RP_LCD_GAMMA = 1, RP_GEOM_MODE = 30, RP_OVERSCAN_X = 37, RP_OVERSCAN_Y = 38, RP_BORDER_SIZE = 39,
        RP_BORDER_DARKNESS = 40, RP_BORDER_COMPRESS = 41 };
 
 void o_pass_royale_last(const o_pass_args* a) {
+  if (o_royale_last_is_general(a->params) && a->in->n_levels <= 1) {
+    o_pass_royale_last_general(a);
+    return;
+  }
   ENTER;
   const int W = a->out_w, H = a->out_h;
   const float tsx = (float)a->in->w, tsy = (float)a->in->h; /* texture_size == video_size */

@@ -67,7 +67,13 @@ static inline float lerpf(float w, float a, float b) { return fmaf(w, b - a, a);
 static inline float linear_coord(float s, int n, int wrap) {
   if (wrap == O_WRAP_REPEAT) s = s - floorf(s);
   float u = s * (float)n;
-  if (wrap == O_WRAP_EDGE) u = fminf(fmaxf(u, 0.0f), (float)n);
+  if (wrap == O_WRAP_EDGE) {
+    /* lp_bld_sample_soa.c, linear + CLAMP_TO_EDGE: min(u, n) first (MINPS: n when u is NaN - a NaN coordinate filters at
+     * the LAST texel), then - 0.5, then max(.., 0) */
+    u = u < (float)n ? u : (float)n;
+    u = u - 0.5f;
+    return u > 0.0f ? u : 0.0f;
+  }
   return u - 0.5f;
 }
 

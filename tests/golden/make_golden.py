@@ -149,6 +149,27 @@ def case_crt_royale():
         run_case("crt_royale_128x96_to_400x300", GLSL + "/crt/crt-royale.glslp", noise(128, 96, 6), 400, 300, luts=luts)
 
 
+ROYALE_GEOM = {
+    # name suffix -> the last pass's geometry parameters (crt-royale-geometry-aa-last-pass.glsl 50-58)
+    "sphere": [("geom_mode_runtime", 1.0)],
+    "sphere_alt_tilt": [("geom_mode_runtime", 2.0), ("geom_tilt_angle_x", 0.2), ("geom_tilt_angle_y", -0.15), ("geom_radius", 1.5)],
+    "cylinder": [("geom_mode_runtime", 3.0), ("geom_view_dist", 1.25), ("geom_overscan_x", 1.0625), ("aa_cubic_c", 0.25)],
+    "flat_overscan": [("geom_overscan_x", 1.125), ("geom_overscan_y", 0.9375), ("border_size", 0.03)],
+}
+
+
+def case_crt_royale_geom():
+    """crt-royale with curved geometry / overscan: the last pass's tex2Daa12x + ray-cast branch."""
+    with tempfile.TemporaryDirectory() as d:
+        luts = royale_luts(d)
+        for k, params in ROYALE_GEOM.items():
+            run_case("crt_royale_geom_%s_96x72_to_240x180" % k, GLSL + "/crt/crt-royale.glslp", mixed(96, 72, 31), 240, 180, luts=luts, params=params)
+            run_case("f32_crt_royale_geom_%s_64x48_to_128x96" % k, GLSL + "/crt/crt-royale.glslp", mixed(64, 48, 5), 128, 96, luts=luts,
+                     params=params, f32=True)
+        run_case("crt_royale_geom_sphere_128x96_to_401x299", GLSL + "/crt/crt-royale.glslp", noise(128, 96, 33), 401, 299, luts=luts,
+                 params=ROYALE_GEOM["sphere"])
+
+
 def case_crt_royale_mask_active(f32=False):
     """crt-royale as a GL driver that returns 0 for an unwritten varying would render it.
     Pass 6's fragment shader tests `max(tile_uv_wrap.x, tile_uv_wrap.y) <= mask_resize_num_tiles`
@@ -592,7 +613,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -30,6 +30,12 @@ CASES = {
     "crt_pi_80x60_to_250x190": "crt-pi",
     "crt_royale_160x120_to_320x240": "crt-royale",
     "crt_royale_128x96_to_400x300": "crt-royale",
+    # the last pass's tex2Daa12x / ray-cast branch (geom_mode_runtime 1..3, overscan != 1; rc_passes_royale_last.c)
+    "crt_royale_geom_sphere_96x72_to_240x180": "crt-royale",
+    "crt_royale_geom_sphere_alt_tilt_96x72_to_240x180": "crt-royale",
+    "crt_royale_geom_cylinder_96x72_to_240x180": "crt-royale",
+    "crt_royale_geom_flat_overscan_96x72_to_240x180": "crt-royale",
+    "crt_royale_geom_sphere_128x96_to_401x299": "crt-royale",
     "feedback_persist_64x40_to_64x40_f1": "feedback-persist",
     "feedback_persist_64x40_to_64x40_f2": "feedback-persist",
     "feedback_persist_64x40_to_150x90_f5": "feedback-persist",
@@ -186,7 +192,7 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
             assert np.array_equal(o.view(np.uint32), ref.view(np.uint32)) or np.allclose(o, ref, rtol=1e-6, atol=1e-7)
     # ... and the whole chain end to end on the oracle's own intermediates
     if key.startswith("crt-royale"):
-        own = run_chain(passes, g["input_rgb"], vw, vh, frame_count=int(g["frames"]), luts=luts, flags=flags)
+        own = run_chain(passes, g["input_rgb"], vw, vh, frame_count=int(g["frames"]), luts=luts, flags=flags, custom=custom)
         for i in range(len(golden)):
             assert np.array_equal(own[i], golden[i]), "end to end, pass %d" % i
 
@@ -206,6 +212,10 @@ FLOAT_CASES = {
     "f32_xbr_lv3_48x40_to_331x217": ("xbr-lv3", {}),
     "f32_crt_royale_64x48_to_128x96": ("crt-royale", {}),
     "f32_crt_royale_maskon_64x48_to_128x96": ("crt-royale", {}),
+    "f32_crt_royale_geom_sphere_64x48_to_128x96": ("crt-royale", {}),
+    "f32_crt_royale_geom_sphere_alt_tilt_64x48_to_128x96": ("crt-royale", {}),
+    "f32_crt_royale_geom_cylinder_64x48_to_128x96": ("crt-royale", {}),
+    "f32_crt_royale_geom_flat_overscan_64x48_to_128x96": ("crt-royale", {}),
     # pass 8 (the last pass, mipmap_input = true at 1:1): llvmpipe's trilinear LOD is a hair above 0 on some pixel
     # quads and blends a 1e-7 share of mip level 1 into the sample; restated (rc_sampler.c), bit-identical
     "f32_crt_royale_fake_bloom_maskon_64x48_to_128x96": ("crt-royale-fake-bloom", {}),
