@@ -17,7 +17,7 @@ PY
 # a one-pass preset of just that shader: the compiled code does not depend on the rest of the chain
 printf 'shaders = 1\nshader0 = %s/crt/shaders/crt-royale/src/crt-royale-geometry-aa-last-pass.glsl\nfilter_linear0 = true\n' "$GLSL" > "$T/last.glslp"
 run() {  # $1 = env assignment, $2 = output listing
-  ( cd "$REF" && env "$1" RETROCAPTURE_LOG_LEVEL=error "$ROOT/oracle/_ref/glchain" --preset "$T/last.glslp" --input "$T/in.rgb" \
+  ( cd "$REF" && env "$1" MESA_SHADER_CACHE_DISABLE=true RETROCAPTURE_LOG_LEVEL=error "$ROOT/oracle/_ref/glchain" --preset "$T/last.glslp" --input "$T/in.rgb" \
       --w 32 --h 24 --vw 64 --vh 48 --frames 1 --out "$T" ) > /dev/null 2> "$2"
 }
 run LP_DEBUG=fs "$T/fs.txt"

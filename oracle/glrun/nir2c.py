@@ -13,7 +13,7 @@ Generated signature:
     static void fn(const float* U, const float* IN, float* OUT, void* TEXCTX)
 U = the default uniform block in dwords (offsets listed in fn_uniforms[]), IN = the shader inputs in declaration order
 (fn_inputs[]; vec4 attributes take four consecutive floats), OUT = the outputs in declaration order (fn_outputs[]),
-RCN_TEX(TEXCTX, unit, u, v, dst4) fetches a texel.  Only what the restated shaders use is handled; anything else raises.
+RCN_TEX(TEXCTX, unit, u, v, dst4) fetches a texel.  RCN_NO_TABLES / RCN_TABLES_ONLY leave out the tables / the function.  Only what the restated shaders use is handled; anything else raises.
 """
 import argparse
 import re
@@ -260,6 +260,7 @@ def translate(text, stage, name):
             raise ValueError("unhandled op %s in: %s" % (op, s))
     out = []
     out.append("/* generated by oracle/glrun/nir2c.py from Mesa's NIR listing of the %s stage - do not edit */" % stage)
+    out.append("#ifndef RCN_NO_TABLES")
     for kind, lst in (("uniforms", [(u[0], u[1], u[2], 0) for u in g.uniforms]),
                       ("inputs", [(i[0], g.in_off[i[0]], i[1], int(i[2])) for i in g.inputs]),
                       ("outputs", [(o[0], g.out_off[o[0]], o[1], int(o[2])) for o in g.outputs])):
@@ -267,6 +268,8 @@ def translate(text, stage, name):
         for nm, off, cnt, flat in lst:
             out.append('  {"%s", %d, %d, %d},' % (nm, off, cnt, flat))
         out.append("  {0, 0, 0, 0}};")
+    out.append("#endif")
+    out.append("#ifndef RCN_TABLES_ONLY")
     out.append("RCN_FN void %s(const float* U, const float* IN, float* OUT, void* TEXCTX) {" % name)
     fl = sorted(g.decl_f, key=int)
     for k in range(0, len(fl), 24):
@@ -279,6 +282,7 @@ def translate(text, stage, name):
     out.append("  (void)U; (void)IN; (void)OUT; (void)TEXCTX;")
     out.extend(g.lines)
     out.append("}")
+    out.append("#endif")
     return "\n".join(out) + "\n"
 
 

@@ -58,6 +58,8 @@ struct KernelEntry {
   bool ignores_texture_height = false;
   // ... or the kernel restates its shader under that override (its setup reads PassGeometry::pass_index).
   bool texture_height_override = false;
+  // validate with the whole launch in view (input texture state, target format): a reason, or nullptr to go ahead
+  const char* (*validate_launch)(const rcd::PassLaunch& L) = nullptr;
 };
 
 const KernelEntry* findKernel(const std::string& shaderPath);

@@ -64,6 +64,7 @@ hipError_t launch_royale_brightpass(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s);
+hipError_t launch_royale_last_general(const PassLaunch& L, hipStream_t s);   // pass_royale_last_general.hip
 
 // frame_io.hip: pixel-format conversion either side of the chain (fmt: 0 RGB24, 1 BGRA, 2 RGBA, 3 YUYV422)
 hipError_t launch_ingest(const void* src, int fmt, uint32_t w, uint32_t h, uint32_t n, void* dst_rgba8, hipStream_t s);

@@ -997,6 +997,10 @@ hipError_t launch_royale_brightpass(const PassLaunch& L, hipStream_t s) {
   GO(k_royale_brightpass<SRT, SRT, StRT>);
 }
 hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
+  if (lastIsGeneral(L.params)) {
+    if (L.in.n_levels > 1) return hipErrorNotSupported;   // refused with its reason before the launch (royale_setup.cpp, validateLastLaunch)
+    return launch_royale_last_general(L, s);
+  }
   if (L.in.n_levels > 1) {
     if (SrgbLinEdge::matches(L.in) && St<FMT_RGBA8>::matches(L)) GO((k_royale_last<SrgbLinEdge, St<FMT_RGBA8>, true>));
     GO((k_royale_last<SRT, StRT, true>));

@@ -1,0 +1,104 @@
+// crt-royale pass 11, general form: geometry-aa-last-pass.glsl with curved geometry (geom_mode_runtime 1..3: sphere,
+// alt. sphere, cylinder) or overscan != 1 - FS 5451-5531 takes the tex2Daa12x branch (3985-4063: twelve LINEAR taps on
+// a quincunx-like grid, cubic weights of the run-time aa_cubic_c, red and blue offset by a third of a pixel) and, when
+// curved, casts a ray per pixel and builds the pixel-to-uv tangent matrix (2527-3010).
+//
+// The default parameters take the flat form (pass_royale.hip: k_royale_last / k_royale_last_strip); this one exists so
+// that every value of the 44 parameters runs, and runs with the GL's results.  The GL's compiler rearranges these
+// ~1200 scalar operations freely (the sample grid is folded to constants, weight sums are factored, sub-expressions are
+// shared across the geometry branches), so the per-pixel body is the GL's own final instruction order:
+// gen/royale_last_fs.inc is produced by oracle/glrun/nir2c.py from the NIR listing of Mesa llvmpipe (recipe:
+// oracle/glrun/gen_royale_last.sh) - one statement per instruction - and the float built-ins map to rc_device.h's
+// llvmpipe-exact primitives.  Around it, as for every pass: the vertex stage is evaluated once per launch on the host
+// (royale_setup.cpp, setupLast), the two varyings that change across the quad are plane equations, one thread per pixel.
+//
+// Roofline: the pass reads a 13-tap neighbourhood that stays in L2 and writes 4 B per pixel; it is VALU-bound by the
+// ray cast and the twelve-tap filter.
+#include "royale_common.h"
+
+using namespace rcd;
+using namespace rcroyale;
+
+namespace {
+
+struct TexCtx {
+  const Tex* t;
+  const uint8_t* img;
+  const SrgbLds* lds;
+};
+
+#define RCN_FN __device__ __forceinline__ static
+#define RCN_BITS(u) bits2f(u)
+#define RCN_ABS(x) __builtin_fabsf(x)
+#define RCN_RSQ(x) (1.0f / __builtin_sqrtf(x))
+#define RCN_RCP(x) (1.0f / (x))
+#define RCN_SQRT(x) __builtin_sqrtf(x)
+#define RCN_SIGN(x) rcn_sign(x)
+#define RCN_SIN(x) sin_(x)
+#define RCN_COS(x) cos_(x)
+#define RCN_DIV(a, b) ((a) / (b))
+#define RCN_MIN(a, b) rcn_min(a, b)
+#define RCN_MAX(a, b) rcn_max(a, b)
+#define RCN_POW(a, b) rcn_pow(a, b)
+
+__device__ __forceinline__ float rcn_sign(float x) { return x == 0.0f ? 0.0f : __builtin_copysignf(1.0f, x); }
+// fmin / fmax as gallivm builds them (MINPS / MAXPS, then the first operand where the second is NaN)
+__device__ __forceinline__ float rcn_min(float a, float b) { return b != b ? a : (a < b ? a : b); }
+__device__ __forceinline__ float rcn_max(float a, float b) { return b != b ? a : (a > b ? a : b); }
+// llvmpipe's pow selects 0 where "x == 0" under an unordered compare: a NaN base gives 0
+__device__ __forceinline__ float rcn_pow(float x, float y) { return x != x ? 0.0f : pow_(x, y); }
+
+template <class SI>
+__device__ __forceinline__ void rcn_tex(void* ctx, float u, float v, float* dst) {
+  const TexCtx* c = static_cast<const TexCtx*>(ctx);
+  const float4 t = SI::get(*c->t, c->img, u, v, c->lds);
+  dst[0] = t.x;
+  dst[1] = t.y;
+  dst[2] = t.z;
+  dst[3] = t.w;
+}
+
+// the generated body samples through RCN_TEX; the sampler policy is the enclosing template's
+template <class SI>
+struct LastFs {
+#define RCN_TEX(ctx, unit, u, v, dst) rcn_tex<SI>(ctx, u, v, dst)
+#define RCN_NO_TABLES
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wunused-but-set-variable"
+#pragma clang diagnostic ignored "-Wunused-variable"
+#include "gen/royale_last_fs.inc"
+#pragma clang diagnostic pop
+#undef RCN_NO_TABLES
+#undef RCN_TEX
+};
+
+template <class SI, class SO>
+__global__ void __launch_bounds__(256) k_royale_last_general(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const float* P = L.params;
+  // the fragment stage's uniform block, in the layout the listing addresses (gen/royale_last_fs.inc, royale_last_fs_uniforms)
+  const float U[12] = {P[1], P[28], P[30], P[31], P[32], P[39], P[40], P[41], (float)L.in.w, (float)L.in.h, (float)L.in.w, (float)L.in.h};
+  RC_TILE_LOOP_BEGIN
+  float in[kLastVaryings], out[4];
+#pragma unroll
+  for (int k = 2; k < kLastVaryings; ++k) in[k] = P[RP11_VARYING0 + k];   // the same at all four vertices: constant planes
+  in[0] = vary(L.plane[0], x, y, lo);
+  in[1] = vary(L.plane[1], x, y, lo);
+  TexCtx ctx{&L.in, frame_ptr(L.in, z), &lds};
+  LastFs<SI>::royale_last_fs(U, in, out, &ctx);
+  SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], out[3]), &lds);
+  RC_TILE_LOOP_END
+}
+
+}  // namespace
+
+namespace rck {
+hipError_t launch_royale_last_general(const PassLaunch& L, hipStream_t s) {
+  if (SrgbLinEdge::matches(L.in) && St<FMT_RGBA8>::matches(L)) {
+    hipLaunchKernelGGL((k_royale_last_general<SrgbLinEdge, St<FMT_RGBA8>>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL((k_royale_last_general<SRT, StRT>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  return hipGetLastError();
+}
+}  // namespace rck

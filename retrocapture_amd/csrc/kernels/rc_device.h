@@ -49,7 +49,7 @@ constexpr int RC_FLAG_NTSC_REGULAR = 1 << 9; // ntsc pass 2: tap k of target col
 
 constexpr int kMaxExtra = 8;
 constexpr int kMaxPlanes = 12;
-constexpr int kMaxParams = 48;
+constexpr int kMaxParams = 80;
 
 struct PassLaunch {
   Tex in;                 // the pass's "Texture" sampler
@@ -299,7 +299,9 @@ template <int WRAP>
 __device__ __forceinline__ float linear_coord(float s, int n) {
   if (WRAP == WRAP_REPEAT) s = s - __builtin_floorf(s);
   float u = s * (float)n;
-  if (WRAP == WRAP_EDGE) u = fminf(fmaxf(u, 0.0f), (float)n);
+  // CLAMP_TO_EDGE as llvmpipe orders it: min(u, n) first - which is n for a NaN coordinate (MINPS there, minnum here), so
+  // a NaN coordinate filters at the last texel - then - 0.5, then max(.., 0)
+  if (WRAP == WRAP_EDGE) return fmaxf(fminf(u, (float)n) - 0.5f, 0.0f);
   return u - 0.5f;
 }
 

@@ -22,7 +22,13 @@ enum {  // blur17 (passes 9, 10)
 };
 enum {  // pass 11: params[0..43] are the shader's 44 #pragma parameters; derived values follow
   RP11_ASPECT_X = 44, RP11_ASPECT_Y = 45,
+  // general form (tex2Daa / curved geometry, pass_royale_last_general.hip): the vertex stage's outputs by varying slot
+  // (4 * VARn + component, gen/royale_last_fs.inc royale_last_fs_inputs); slots 0 and 1 (tex_uv) are planes instead
+  RP11_VARYING0 = 48,
 };
+constexpr int kLastVaryings = 26;
+// geometry-aa-last-pass.glsl FS 5480: geom_mode_runtime > 0.5 or geom_overscan != 1 select the tex2Daa / ray-cast form
+inline bool lastIsGeneral(const float* P) { return P[30] > 0.5f || P[37] != 1.0f || P[38] != 1.0f; }
 
 // PassLaunch::flags
 enum { RC_FLAG_UNDEF_VARYING_ZERO = 1 };

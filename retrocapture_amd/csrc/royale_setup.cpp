@@ -2,7 +2,11 @@
 
 #include <cmath>
 
+#include <cstring>
+#include <string>
+
 #include "kernels/royale_params.h"
+#include "rc_log.h"
 #include "varying.h"
 
 namespace rc {
@@ -242,8 +246,88 @@ void setupBloomH(const PassGeometry& g, PassLaunch& L) {
   L.plane[7] = planeV01(vv0 * h.in_h / h.tex_h, vv1 * h.in_h / h.tex_h, g, g.out_fmt);
 }
 
+// ---- pass 11, general form: the vertex stage (geometry-aa-last-pass.glsl VS 5337-5400 with get_ideal_global_eye_pos
+// 4843-5020: eye position and global-to-local matrix from sin / cos of the tilt angles) in the GL's own instruction
+// order - kernels/gen/royale_last_vs.inc, generated from Mesa's NIR listing (oracle/glrun/nir2c.py)
+namespace lastvs {
+#define RCN_FN static
+#define RCN_BITS(u) rcd::bits2f(u)
+#define RCN_ABS(x) std::fabs(x)
+#define RCN_RSQ(x) (1.0f / std::sqrt(x))
+#define RCN_RCP(x) (1.0f / (x))
+#define RCN_SQRT(x) std::sqrt(x)
+#define RCN_SIGN(x) ((x) == 0.0f ? 0.0f : std::copysign(1.0f, (x)))
+#define RCN_SIN(x) rcd::sin_(x)
+#define RCN_COS(x) rcd::cos_(x)
+#define RCN_DIV(a, b) ((a) / (b))
+#define RCN_MIN(a, b) vmin(a, b)
+#define RCN_MAX(a, b) vmax(a, b)
+#define RCN_POW(a, b) ((a) != (a) ? 0.0f : rcd::pow_(a, b))
+#define RCN_TEX(ctx, unit, u, v, dst) ((void)0)
+inline float vmin(float a, float b) { return b != b ? a : (a < b ? a : b); }   // gallivm's fmin / fmax: the operand that is not NaN
+inline float vmax(float a, float b) { return b != b ? a : (a > b ? a : b); }
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wunused-but-set-variable"
+#pragma clang diagnostic ignored "-Wunused-variable"
+#include "kernels/gen/royale_last_vs.inc"
+#define RCN_TABLES_ONLY
+#include "kernels/gen/royale_last_fs.inc"
+#undef RCN_TABLES_ONLY
+#pragma clang diagnostic pop
+template <class T>
+void setUniform(float* U, const T* table, const char* name, const float* v, int n) {
+  for (; table->name; ++table)
+    if (!std::strcmp(table->name, name)) {
+      for (int k = 0; k < n && k < table->n; ++k) U[table->off + k] = v[k];
+      return;
+    }
+}
+}  // namespace lastvs
+
+void setupLastGeneral(const PassGeometry& g, PassLaunch& L) {
+  using namespace lastvs;
+  // the kernel addresses the fragment stage's uniform block by position (pass_royale_last_general.hip): keep the two in step
+  static const char* const kFsUniforms[] = {"lcd_gamma", "aa_cubic_c", "geom_mode_runtime", "geom_radius", "geom_view_dist", "border_size",
+                                            "border_darkness", "border_compress", "TextureSize", "InputSize"};
+  static const int kFsOffsets[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10};
+  for (int k = 0; k < 10; ++k)
+    if (!royale_last_fs_uniforms[k].name || std::strcmp(royale_last_fs_uniforms[k].name, kFsUniforms[k]) || royale_last_fs_uniforms[k].off != kFsOffsets[k])
+      RC_LOG_ERROR("crt-royale last pass: generated uniform layout changed (entry " + std::to_string(k) + ")");
+  const float* P = L.params;
+  static const struct { const char* name; int idx; } pn[] = {{"geom_mode_runtime", 30}, {"geom_radius", 31}, {"geom_view_dist", 32},
+                                                             {"geom_tilt_angle_x", 33}, {"geom_tilt_angle_y", 34}, {"geom_aspect_ratio_x", 35},
+                                                             {"geom_aspect_ratio_y", 36}, {"geom_overscan_x", 37}, {"geom_overscan_y", 38}};
+  float U[64] = {};
+  for (const auto& e : pn) setUniform(U, royale_last_vs_uniforms, e.name, &P[e.idx], 1);
+  static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const float tex_size[2] = {(float)g.in_w, (float)g.in_h}, out_size[2] = {(float)g.out_w, (float)g.out_h};
+  setUniform(U, royale_last_vs_uniforms, "MVPMatrix", ident, 16);
+  setUniform(U, royale_last_vs_uniforms, "OutputSize", out_size, 2);
+  setUniform(U, royale_last_vs_uniforms, "TextureSize", tex_size, 2);
+  setUniform(U, royale_last_vs_uniforms, "InputSize", tex_size, 2);
+  // the quad's vertices: BL, BR, TR, TL (reference ShaderEngine.cpp:2945-2960)
+  static const float pos[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}}, uv[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+  float out[4][48] = {};
+  for (int v = 0; v < 4; ++v) {
+    const float in[8] = {pos[v][0], pos[v][1], 0.0f, 1.0f, uv[v][0], uv[v][1], 0.0f, 1.0f};
+    royale_last_vs(U, in, out[v], nullptr);
+  }
+  L.plane[0] = makePlane(out[0][0], out[1][0], out[2][0], out[3][0], g.out_w, g.out_h, rcd::FMT_SRGB8);   // tex_uv: two-triangle planes (setupLast)
+  L.plane[1] = makePlane(out[0][1], out[1][1], out[2][1], out[3][1], g.out_w, g.out_h, rcd::FMT_SRGB8);
+  for (int k = 2; k < kLastVaryings; ++k) {
+    // everything else is built from uniforms alone: the same bits at the four vertices, a constant plane
+    for (int v = 1; v < 4; ++v)
+      if (std::memcmp(&out[v][k], &out[0][k], 4)) RC_LOG_ERROR("crt-royale last pass: varying slot " + std::to_string(k) + " differs across the quad");
+    L.params[RP11_VARYING0 + k] = out[0][k];
+  }
+}
+
 // ---- pass 11: geometry-aa-last-pass VS 5337-5400 (flat path); get_aspect_vector 2512-2520
 void setupLast(const PassGeometry& g, PassLaunch& L) {
+  if (lastIsGeneral(L.params)) {
+    setupLastGeneral(g, L);
+    return;
+  }
   // This vertex shader also emits eye_pos_local, which is NaN in the flat geometry mode; the GL
   // then rasterises the quad as two triangles even on an RGBA8 target (measured), so the planes
   // are the two-triangle ones regardless of the target format.
@@ -256,10 +340,11 @@ void setupLast(const PassGeometry& g, PassLaunch& L) {
   L.params[RP11_ASPECT_Y] = gy * rs;
 }
 
-const char* validateLast(const float* P) {
-  // only the flat path of geometry-aa-last-pass.glsl is restated (FS 5480-5515)
-  if (P[30] > 0.5f) return "crt-royale: geom_mode_runtime > 0.5 (curved geometry) is not supported by the HIP kernel";
-  if (P[37] != 1.0f || P[38] != 1.0f) return "crt-royale: geom_overscan != 1 (tex2Daa path) is not supported by the HIP kernel";
+// crt-royale-fake-bloom's last pass samples with implicit LOD (mipmap_input); thirteen such taps per pixel in the
+// tex2Daa / curved form are not restated
+const char* validateLastLaunch(const PassLaunch& L) {
+  if (lastIsGeneral(L.params) && L.in.n_levels > 1)
+    return "crt-royale: mipmap_input on the last pass together with geom_mode_runtime > 0.5 or geom_overscan != 1 is not supported by the HIP kernel";
   return nullptr;
 }
 
@@ -350,7 +435,7 @@ void registerRoyaleKernels(std::vector<KernelEntry>& r) {
                 {"interlace_bff", 0.0f, 0.0f, 1.0f, 1.0f, "Interlacing - Bottom Field First"},
                 {"interlace_1080i", 0.0f, 0.0f, 1.0f, 1.0f, "Interlace - Detect 1080i"}},
                {}, rck::launch_royale_last, setupLast, false});
-  r.back().validate = validateLast;
+  r.back().validate_launch = validateLastLaunch;
   r.back().mip_aware = true;   // mipmap_input (crt-royale-fake-bloom): LOD from the pixel quad, chain built by the engine
   for (auto& e : r) {
     const std::string n = e.name;

@@ -1048,6 +1048,12 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
           return false;
         }
       }
+      if (k.validate_launch) {
+        if (const char* why = k.validate_launch(L)) {
+          RC_LOG_ERROR(why);
+          return false;
+        }
+      }
       // Frame-invariant pass (see ShaderPassData::invariant): every texture it samples is shared by all frames
       bool servedFromCache = false;
       pd.invariant = false;

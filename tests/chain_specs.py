@@ -308,6 +308,8 @@ def _royale_ntsc(pass1, pass2, width):
 
 
 import re
+# crt-royale with an RGBA32F last target: the last pass's floats as computed, for the curved-geometry / tex2Daa form
+PRESETS["crt-royale-f32-last"] = ("crt/crt-royale-f32-last.glslp", PRESETS["crt-royale"][1] + 'float_framebuffer11 = "true"\n')
 PRESETS["crt-royale-ntsc-256px-svideo"] = ("crt/crt-royale-ntsc-256px-svideo.glslp", _royale_ntsc("svideo-3phase", "3phase", 1536))
 PRESETS["crt-royale-ntsc-320px-composite"] = ("crt/crt-royale-ntsc-320px-composite.glslp", _royale_ntsc("composite-2phase", "2phase", 1280))
 

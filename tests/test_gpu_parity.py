@@ -100,6 +100,52 @@ def test_royale_matches_oracle_and_golden(case, preset_tree, rc_lib):
     e.shutdown()
 
 
+ROYALE_GEOM_GOLDEN = ["crt_royale_geom_sphere_96x72_to_240x180", "crt_royale_geom_sphere_alt_tilt_96x72_to_240x180",
+                      "crt_royale_geom_cylinder_96x72_to_240x180", "crt_royale_geom_flat_overscan_96x72_to_240x180",
+                      "crt_royale_geom_sphere_128x96_to_401x299"]
+
+
+@pytest.mark.parametrize("case", ROYALE_GEOM_GOLDEN)
+def test_royale_curved_geometry_and_overscan_match_llvmpipe(case, preset_tree, rc_lib):
+    """geom_mode_runtime 1..3 (sphere, alt. sphere, cylinder), tilt, overscan and aa_cubic_c: the last pass's tex2Daa12x /
+    ray-cast form (kernels/pass_royale_last_general.hip), every pass byte for byte what llvmpipe rendered."""
+    from gpu_util import make_engine, run_engine
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    vw, vh = [int(v) for v in g["viewport"]]
+    e = make_engine(preset_tree["crt-royale"], vw, vh)
+    for name, v in zip(g["param_names"], g["param_values"]):
+        assert e.setShaderParameter(str(name), float(v))
+    final = run_engine(e, g["input_rgb"])
+    for i in range(12):
+        assert np.array_equal(e.readPass(i, 0), g["pass%d" % i]), "pass %d vs llvmpipe golden" % i
+    assert np.array_equal(final[0], g["pass11"])
+    e.shutdown()
+
+
+@pytest.mark.parametrize("params", [{"geom_mode_runtime": 1.0}, {"geom_mode_runtime": 2.0, "geom_tilt_angle_x": -0.35, "geom_tilt_angle_y": 0.3, "geom_radius": 1.1},
+                                    {"geom_mode_runtime": 3.0, "geom_view_dist": 0.75, "geom_overscan_y": 1.25, "border_size": 0.1, "border_compress": 1.0},
+                                    {"geom_overscan_x": 0.75, "geom_overscan_y": 1.5, "aa_cubic_c": 1.0, "lcd_gamma": 1.8}])
+def test_royale_general_last_pass_floats_match_oracle(params, preset_tree, rc_lib):
+    """The same form into an RGBA32F target at a larger size: the kernel's floats are the oracle's bit for bit (the oracle's
+    are llvmpipe's: tests/test_oracle_golden.py, f32_crt_royale_geom_*), NaN pixels included."""
+    from gpu_util import make_engine, run_engine
+    from retrocapture_amd import engine as eng
+    rgb = np.random.default_rng(77).integers(0, 256, (150, 200, 3), dtype=np.uint8)
+    vw, vh = 517, 389
+    passes = eng.preset_dump(preset_tree["crt-royale-f32-last"])["passes"]
+    want = run_chain(passes, rgb, vw, vh, luts=royale_luts(), custom=params)
+    e = make_engine(preset_tree["crt-royale-f32-last"], vw, vh)
+    for k, v in params.items():
+        assert e.setShaderParameter(k, v)
+    run_engine(e, rgb)
+    assert np.array_equal(e.readPass(10, 0), want[10])
+    got = e.readPass(11, 0)
+    assert got.dtype == np.float32 and got.shape == want[11].shape
+    same = (got.view(np.uint32) == want[11].view(np.uint32)) | (np.isnan(got) & np.isnan(want[11]))
+    assert same.all(), "%d of %d float components differ" % (int((~same).sum()), same.size)
+    e.shutdown()
+
+
 @pytest.mark.parametrize("w,h,vw,vh", [(160, 120, 320, 240), (96, 128, 517, 389), (300, 40, 300, 40)])
 def test_royale_specialised_and_general_forms_agree(w, h, vw, vh, preset_tree, rc_lib):
     """Passes with a specialised form (P0: byte map of the nearest texel) must equal their general
@@ -265,6 +311,12 @@ def test_fake_bloom_forms_agree_and_mipmap_input_rule(preset_tree, rc_lib):
     e.setGeneralKernelsOnly(False)
     s = run_engine(e, big)
     assert np.array_equal(g, s) and s.shape == (1, 1080, 1920, 4)
+    # curved geometry on this preset would need thirteen implicit-LOD taps per pixel: refused loudly, not mis-rendered
+    from gpu_util import to_device_rgba
+    from retrocapture_amd.engine import RcError
+    assert e.setShaderParameter("geom_mode_runtime", 1.0)
+    with pytest.raises(RcError, match="mipmap_input"):
+        e.applyShader(to_device_rgba(frames[:1]), 128, 96)
     e.shutdown()
 
 
