@@ -179,8 +179,38 @@ void o_pass_crt_hyllian_glow(const o_pass_args* a) {
   LEAVE;
 }
 
-/* P5: params BLOOM_STRENGTH, OUTPUT_GAMMA, PHOSPHOR_LAYOUT, MASK_INTENSITY; extra[0] = PassPrev4Texture.
- * Phosphor layouts 0, 1, 2, 4 and 5 (the two-colour column / checker masks) are restated. */
+/* resolve2.glsl mask_weights (129-400), layouts 3 and 6..19: the colour of cell [w][z], w = floor(mod(coord.y, ny)),
+ * z = floor(mod(coord.x, nx)) with coord = gl_FragCoord (pixel + 0.5: the float mod is the integer one, the quotient
+ * never comes within 0.03 of an integer).  The shader's ternary chains test w == 1, w == 2, ... and leave the LAST row
+ * to w == 0; rows below are indexed by w.  R G B M(agenta) Y(ellow) C(yan) K(black): a channel is 1 where the colour
+ * has it and 1 - MASK_INTENSITY elsewhere.  Layout 12 reads w without ever writing it (`int w, z = 0;`): the GL's
+ * compiler resolves the undefined comparison to false - its second table - on every row (golden). */
+typedef struct { int nx, ny; const char* rows[6]; } mask_layout;
+static const mask_layout k_mask_layouts[20] = {
+    [3] = {4, 3, {"KKMG", "MGKK", "MGMG"}},
+    [6] = {4, 1, {"RGBK"}},
+    [7] = {5, 1, {"RMBGG"}},
+    [8] = {7, 1, {"RRYGCBB"}},
+    [9] = {4, 1, {"RYCB"}},
+    [10] = {4, 1, {"RMCG"}},
+    [11] = {4, 2, {"BKRG", "RGBK"}},
+    [12] = {4, 1, {"CBRY"}},
+    [13] = {4, 4, {"CBRY", "RYCB", "RYCB", "CBRY"}},
+    [14] = {6, 3, {"KKKMGK", "MGKKKK", "MGKMGK"}},
+    [15] = {8, 4, {"KKKKRYCB", "RYCBRYCB", "RYCBKKKK", "RYCBRYCB"}},
+    [16] = {4, 3, {"KKYB", "YBKK", "YBYB"}},
+    [17] = {10, 4, {"RRKKKKBBGG", "RMBGGRMBGG", "KBBGGRRKKK", "RMBGGRMBGG"}},
+    [18] = {10, 4, {"RRKKKKGGBB", "RYGBBRYGBB", "KGGBBRRKKK", "RYGBBRYGBB"}},
+    [19] = {14, 6, {"KKKKKKKKRRYGCB", "RRYGCBBRRYGCBB", "RRYGCBBRRYGCBB", "RRYGCBBKKKKKKK", "RRYGCBBRRYGCBB", "RRYGCBBRRYGCBB"}},
+};
+static int mask_bits(char c) {   /* bit 0 red, 1 green, 2 blue */
+  switch (c) {
+    case 'R': return 1; case 'G': return 2; case 'B': return 4; case 'M': return 5; case 'Y': return 3; case 'C': return 6;
+    default: return 0;
+  }
+}
+
+/* P5: params BLOOM_STRENGTH, OUTPUT_GAMMA, PHOSPHOR_LAYOUT, MASK_INTENSITY; extra[0] = PassPrev4Texture. */
 void o_pass_hyllian_resolve2(const o_pass_args* a) {
   ENTER;
   const int W = a->out_w, H = a->out_h;
@@ -208,6 +238,10 @@ void o_pass_hyllian_resolve2(const o_pass_args* a) {
             w3[k] = ap + my * (inv - ap);
           } else w3[k] = ap;
         }
+      } else if (layout >= 3 && layout <= 19 && k_mask_layouts[layout].nx) {
+        const mask_layout* m = &k_mask_layouts[layout];
+        const int bits = mask_bits(m->rows[y % m->ny][x % m->nx]);
+        for (int k = 0; k < 3; ++k) w3[k] = ((bits >> k) & 1) ? on : off;
       }
       const float s3[3] = {s.x, s.y, s.z}, b3[3] = {b.x, b.y, b.z};
       float out[3];

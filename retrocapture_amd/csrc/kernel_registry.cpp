@@ -352,12 +352,6 @@ std::vector<KernelEntry> build() {
                    {"PHOSPHOR_LAYOUT", 4.0f, 0.0f, 19.0f, 1.0f, "PHOSPHOR LAYOUT"},
                    {"MASK_INTENSITY", 0.5f, 0.0f, 1.0f, 0.1f, "MASK INTENSITY"}},
                   {"PassPrev4Texture"}, rck::launch_hyllian_resolve2, setupTexCoord, false};
-    e.validate = [](const float* p) -> const char* {
-      const int layout = (int)p[2];
-      return (layout == 0 || layout == 1 || layout == 2 || layout == 4 || layout == 5)
-                 ? nullptr
-                 : "resolve2.glsl: only PHOSPHOR_LAYOUT 0, 1, 2, 4 and 5 are restated";
-    };
     r.push_back(e);
   }
   // conformance fixture of this repository (tests/fixtures/conformance/): pins PassFeedback, which no

@@ -187,8 +187,47 @@ __global__ void __launch_bounds__(256) k_crt_hyllian_glow(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// resolve2.glsl mask_weights (129-400), layouts 3 and 6..19: cell [w][z] of the layout's table, w = floor(mod(coord.y, ny)),
+// z = floor(mod(coord.x, nx)) at coord = pixel + 0.5 (the float mod equals the integer one: the quotient stays 0.03 away
+// from every integer).  The shader's ternary chains test w == 1, w == 2, ... and leave the last row to w == 0; the rows
+// here are indexed by w.  A cell is three bits - red, green, blue: 1 where the colour has the channel, 1 - MASK_INTENSITY
+// elsewhere - and a row packs up to 14 cells.  Layout 12 compares a never-written `w`: the GL takes its second table on
+// every row (llvmpipe golden, tests/golden/crt_hyllian_glow_layouts_*).
+constexpr uint64_t mask_row(const char* r) {
+  uint64_t v = 0;
+  for (int i = 0; r[i]; ++i) {
+    const char c = r[i];
+    const uint64_t b = c == 'R' ? 1 : c == 'G' ? 2 : c == 'B' ? 4 : c == 'M' ? 5 : c == 'Y' ? 3 : c == 'C' ? 6 : 0;
+    v |= b << (3 * i);
+  }
+  return v;
+}
+struct MaskLayout {
+  int nx, ny;
+  uint64_t rows[6];
+};
+__constant__ MaskLayout k_mask_layouts[20] = {
+    {0, 0, {}}, {0, 0, {}}, {0, 0, {}},
+    {4, 3, {mask_row("KKMG"), mask_row("MGKK"), mask_row("MGMG")}},
+    {0, 0, {}}, {0, 0, {}},
+    {4, 1, {mask_row("RGBK")}},
+    {5, 1, {mask_row("RMBGG")}},
+    {7, 1, {mask_row("RRYGCBB")}},
+    {4, 1, {mask_row("RYCB")}},
+    {4, 1, {mask_row("RMCG")}},
+    {4, 2, {mask_row("BKRG"), mask_row("RGBK")}},
+    {4, 1, {mask_row("CBRY")}},
+    {4, 4, {mask_row("CBRY"), mask_row("RYCB"), mask_row("RYCB"), mask_row("CBRY")}},
+    {6, 3, {mask_row("KKKMGK"), mask_row("MGKKKK"), mask_row("MGKMGK")}},
+    {8, 4, {mask_row("KKKKRYCB"), mask_row("RYCBRYCB"), mask_row("RYCBKKKK"), mask_row("RYCBRYCB")}},
+    {4, 3, {mask_row("KKYB"), mask_row("YBKK"), mask_row("YBYB")}},
+    {10, 4, {mask_row("RRKKKKBBGG"), mask_row("RMBGGRMBGG"), mask_row("KBBGGRRKKK"), mask_row("RMBGGRMBGG")}},
+    {10, 4, {mask_row("RRKKKKGGBB"), mask_row("RYGBBRYGBB"), mask_row("KGGBBRRKKK"), mask_row("RYGBBRYGBB")}},
+    {14, 6, {mask_row("KKKKKKKKRRYGCB"), mask_row("RRYGCBBRRYGCBB"), mask_row("RRYGCBBRRYGCBB"), mask_row("RRYGCBBKKKKKKK"), mask_row("RRYGCBBRRYGCBB"),
+             mask_row("RRYGCBBRRYGCBB")}},
+};
+
 // params: BLOOM_STRENGTH, OUTPUT_GAMMA, PHOSPHOR_LAYOUT, MASK_INTENSITY; extra[0] = PassPrev4Texture.
-// Phosphor layouts 0, 1, 2, 4, 5 (host validates).
 __global__ void __launch_bounds__(256) k_hyllian_resolve2(const PassLaunch L) {
   RC_SRGB_LDS(lds, L);
   RC_TILE_LOOP_BEGIN
@@ -201,7 +240,12 @@ __global__ void __launch_bounds__(256) k_hyllian_resolve2(const PassLaunch L) {
   const float mx = __builtin_floorf(fx - 2.0f * __builtin_floorf(fx / 2.0f)), my = __builtin_floorf(fy - 2.0f * __builtin_floorf(fy / 2.0f));
   const float on = 1.0f, off = 1.0f - intensity;
   float w3[3] = {1.0f, 1.0f, 1.0f};
-  if (layout != 0) {
+  if (layout == 3 || (layout >= 6 && layout <= 19)) {
+    const MaskLayout& m = k_mask_layouts[layout];
+    const uint32_t bits = (uint32_t)(m.rows[y % m.ny] >> (3 * (x % m.nx)));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w3[k] = ((bits >> k) & 1u) ? on : off;
+  } else if (layout == 1 || layout == 2 || layout == 4 || layout == 5) {
     const bool rgb = layout == 1 || layout == 2;   // magenta / green columns; else yellow / blue
     const float a3[3] = {on, rgb ? off : on, rgb ? on : off}, b3[3] = {off, rgb ? on : off, rgb ? off : on};
 #pragma unroll

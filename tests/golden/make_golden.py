@@ -470,6 +470,28 @@ def case_hyllian_glow():
              params=[("HFILTER_SHARPNESS", 0.7), ("CRT_ANTI_RINGING", 0.6), ("MASK_INTENSITY", 0.7), ("PHOSPHOR_LAYOUT", 5.0)])
 
 
+def case_hyllian_layouts():
+    """resolve2.glsl's twenty PHOSPHOR_LAYOUT masks (mask_weights, 129-400): one chain run per layout; the first five
+    passes do not depend on it and are kept once, the last pass once per layout."""
+    P = GLSL + "/crt/crt-hyllian-glow.glslp"
+    rgb = mixed(48, 36, 75)
+    merged = None
+    for lay in range(20):
+        tmp = "_tmp_hyllian_layout"
+        run_case(tmp, P, rgb, 143, 101, params=[("PHOSPHOR_LAYOUT", float(lay)), ("MASK_INTENSITY", 0.7)])
+        g = dict(np.load(os.path.join(HERE, tmp + ".npz")))
+        os.remove(os.path.join(HERE, tmp + ".npz"))
+        if merged is None:
+            merged = {k: v for k, v in g.items() if k not in ("pass5", "sha256_last", "param_names", "param_values")}
+        else:
+            for i in range(5):
+                assert np.array_equal(merged["pass%d" % i], g["pass%d" % i])
+        merged["pass5_layout%d" % lay] = g["pass5"]
+    merged["mask_intensity"] = np.float32(0.7)
+    np.savez_compressed(os.path.join(HERE, "crt_hyllian_glow_layouts_48x36_to_143x101.npz"), **merged)
+    print("wrote crt_hyllian_glow_layouts_48x36_to_143x101")
+
+
 def case_xbr_lv2():
     P = GLSL + "/xbr/xbr-lv2.glslp"
     run_case("xbr_lv2_64x56_to_256x224", P, mixed(64, 56, 80), 256, 224)
@@ -613,7 +635,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

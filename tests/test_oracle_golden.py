@@ -197,6 +197,20 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
             assert np.array_equal(own[i], golden[i]), "end to end, pass %d" % i
 
 
+def test_hyllian_phosphor_layouts(tmp_path, rc_lib):
+    """resolve2.glsl mask_weights: all twenty PHOSPHOR_LAYOUT tables against llvmpipe (one golden: the five passes in front
+    are shared, the last pass is stored per layout)."""
+    g = np.load(os.path.join(GOLD, "crt_hyllian_glow_layouts_48x36_to_143x101.npz"))
+    passes = preset_passes(tmp_path, "crt-hyllian-glow")
+    given = [g["pass%d" % i] for i in range(5)] + [g["pass5_layout0"]]
+    for lay in range(20):
+        outs = run_chain(passes, g["input_rgb"], 143, 101, given=given,
+                         custom={"PHOSPHOR_LAYOUT": float(lay), "MASK_INTENSITY": float(g["mask_intensity"])})
+        assert np.array_equal(outs[5], g["pass5_layout%d" % lay]), "layout %d" % lay
+        if lay:
+            assert not np.array_equal(outs[5], g["pass5_layout0"])
+
+
 # Float-precision goldens: the same shaders with every render target forced to RGBA32F on llvmpipe
 # (tests/golden/make_golden.py case_float), each pass fed the GL's own float output of the passes
 # before it.  Floor = fraction of float components that must be bit-identical; below 1.0 only where a
