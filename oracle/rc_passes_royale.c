@@ -701,7 +701,7 @@ enum { RP_LCD_GAMMA = 1, RP_GEOM_MODE = 30, RP_OVERSCAN_X = 37, RP_OVERSCAN_Y = 
        RP_BORDER_DARKNESS = 40, RP_BORDER_COMPRESS = 41 };
 
 void o_pass_royale_last(const o_pass_args* a) {
-  if (o_royale_last_is_general(a->params) && a->in->n_levels <= 1) {
+  if (o_royale_last_is_general(a->params)) {
     o_pass_royale_last_general(a);
     return;
   }

@@ -35,11 +35,32 @@ static inline float rcn_max(float a, float b) { return b != b ? a : (a > b ? a :
 #define RCN_MIN(a, b) rcn_min(a, b)
 #define RCN_MAX(a, b) rcn_max(a, b)
 #define RCN_POW(a, b) o_pow(a, b)
-#define RCN_TEX(ctx, unit, u, v, dst)                 \
-  do {                                                \
-    o_vec4 t_ = o_sample((const o_tex*)(ctx), u, v);  \
-    dst[0] = t_.x; dst[1] = t_.y; dst[2] = t_.z; dst[3] = t_.w; \
-  } while (0)
+/* texture(): plain, or - mipmap_input, crt-royale-fake-bloom - with the LOD llvmpipe derives per tex instruction from the
+ * coordinate differences inside the 2x2 quad: the coordinates of every tap are first recorded at the quad's pixels
+ * (TEX_RECORD), then each tap of this pixel is filtered with its own differences (TEX_MIP; rc_sampler.c o_sample_quad) */
+enum { TEX_PLAIN = 0, TEX_RECORD = 1, TEX_MIP = 2, MAX_TAPS = 16 };
+typedef struct {
+  const o_tex* t;
+  int mode, n;
+  float (*rec)[2];            /* TEX_RECORD: where the coordinates go */
+  const float (*q[4])[2];     /* TEX_MIP: recorded coordinates at (x0, y0), (x0 + 1, y0), (x0, y0), (x0, y0 + 1) */
+} tex_ctx;
+static void rcn_tex(void* vctx, float u, float v, float* dst) {
+  tex_ctx* c = (tex_ctx*)vctx;
+  o_vec4 r = {0.f, 0.f, 0.f, 0.f};
+  if (c->mode == TEX_RECORD) {
+    if (c->n < MAX_TAPS) { c->rec[c->n][0] = u; c->rec[c->n][1] = v; }
+    c->n++;
+  } else if (c->mode == TEX_MIP) {
+    const int k = c->n++;
+    r = o_sample_quad(c->t, u, v, c->q[0][k][0], c->q[1][k][0], c->q[0][k][1], c->q[1][k][1], c->q[2][k][0], c->q[3][k][0], c->q[2][k][1],
+                      c->q[3][k][1]);
+  } else {
+    r = o_sample(c->t, u, v);
+  }
+  dst[0] = r.x; dst[1] = r.y; dst[2] = r.z; dst[3] = r.w;
+}
+#define RCN_TEX(ctx, unit, u, v, dst) rcn_tex(ctx, u, v, dst)
 
 #pragma GCC diagnostic push
 #pragma GCC diagnostic ignored "-Wunused-but-set-variable"
@@ -96,17 +117,33 @@ void o_pass_royale_last_general(const o_pass_args* a) {
     const int s = royale_last_fs_inputs[k].off;
     pl[k] = o_varying_setup(vout[0][s], vout[1][s], vout[2][s], vout[3][s], W, H, O_FMT_SRGB8);
   }
+  const int mip = a->in->n_levels > 1;
   for (int y = a->y0; y < a->y1; ++y)
     for (int x = 0; x < W; ++x) {
       const int lo = o_lower_tri(x, y, W, H);
-      float in[32] = {0}, out[4];
-      for (int k = 0; k < n_in; ++k) {
-        const int s = royale_last_fs_inputs[k].off;
-        /* flat: the provoking (last) vertex of the triangle - BL for both of this quad's triangles... every flat
-         * varying of this shader is uniform-only, the same at all four vertices */
-        in[s] = royale_last_fs_inputs[k].flat ? vout[0][s] : o_varying_at(&pl[k], x, y, lo);
+      float in[32] = {0}, out[4], rec[4][MAX_TAPS][2];
+      tex_ctx ctx = {a->in, TEX_PLAIN, 0, 0, {0, 0, 0, 0}};
+      /* one set of differences per quad, at its top-left pixel: (x0, y0), (x0 + 1, y0) and (x0, y0 + 1) as THIS pixel's
+       * triangle extrapolates them (rc_sampler.c; f32_crt_royale_fake_bloom_geom_cylinder_tilt tells this from differences
+       * along the pixel's own row and column) */
+      const int x0 = x & ~1, y0 = y & ~1;
+      const int qx[5] = {x0, x0 + 1, x0, x0, x}, qy[5] = {y0, y0, y0, y0 + 1, y};
+      for (int e = mip ? 0 : 4; e < 5; ++e) {
+        for (int k = 0; k < n_in; ++k) {
+          const int s = royale_last_fs_inputs[k].off;
+          /* flat varyings take the provoking vertex: every one of this shader is uniform-only, the same at all four */
+          in[s] = royale_last_fs_inputs[k].flat ? vout[0][s] : o_varying_at(&pl[k], qx[e], qy[e], lo);
+        }
+        ctx.n = 0;
+        if (e < 4) {
+          ctx.mode = TEX_RECORD;
+          ctx.rec = rec[e];
+        } else if (mip) {
+          ctx.mode = TEX_MIP;
+          for (int q = 0; q < 4; ++q) ctx.q[q] = (const float (*)[2])rec[q];
+        }
+        royale_last_fs(Uf, in, out, &ctx);
       }
-      royale_last_fs(Uf, in, out, (void*)a->in);
       o_vec4 o = {out[0], out[1], out[2], out[3]};
       o_store_pixel(a, x, y, o);
     }

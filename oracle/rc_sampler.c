@@ -14,8 +14,11 @@
  *     result k * (1/255f).
  *   - store: UNORM8 = rint(clamp(x,0,1) * 255) (ties to even); sRGB8: monotone table.
  *   - mip-mapped (GL_LINEAR_MIPMAP_LINEAR, measured with textureQueryLOD and level dumps):
- *     rho^2 = max((dsdx*W)^2 + (dtdx*H)^2, (dsdy*W)^2 + (dtdy*H)^2) from per-pixel coordinate differences
- *     inside the 2x2 quad; lod = max(0, 0.5 * (exponent(rho^2) + mantissa(rho^2) - 1)) (a linear "fast
+ *     rho^2 = max((dsdx*W)^2 + (dtdx*H)^2, (dsdy*W)^2 + (dtdy*H)^2), ONE set of differences per 2x2 quad taken at its
+ *     top-left pixel (right - left on the top row, bottom - top in the left column; lp_bld_sample.c
+ *     lp_build_packed_ddx_ddy_twocoord).  Where s depends on x alone and t on y alone - every pass but crt-royale's curved
+ *     last pass - the differences along the pixel's own row / column are the same floats, and the callers pass those
+ *     (pinned either way by tests/golden f32_crt_royale_fake_bloom_geom_*); lod = max(0, 0.5 * (exponent(rho^2) + mantissa(rho^2) - 1)) (a linear "fast
  *     log2"), clamped to the last level; result = fma(frac(lod), S(l+1) - S(l), S(l)) with S = the LINEAR
  *     sample of a level.  glGenerateMipmap = one LINEAR blit per level (sRGB8 decoded / re-encoded).
  */

@@ -998,7 +998,6 @@ hipError_t launch_royale_brightpass(const PassLaunch& L, hipStream_t s) {
 }
 hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
   if (lastIsGeneral(L.params)) {
-    if (L.in.n_levels > 1) return hipErrorNotSupported;   // refused with its reason before the launch (royale_setup.cpp, validateLastLaunch)
     return launch_royale_last_general(L, s);
   }
   if (L.in.n_levels > 1) {

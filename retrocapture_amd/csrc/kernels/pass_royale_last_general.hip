@@ -21,10 +21,19 @@ using namespace rcroyale;
 
 namespace {
 
+// texture(): plain, or - mipmap_input, crt-royale-fake-bloom - with the LOD the GL derives per tex instruction from ONE
+// set of coordinate differences per 2x2 pixel quad, taken at the quad's top-left pixel (rc_device.h, mip-mapped sampling).
+// The body is then evaluated at the quad's top-left, top-right and bottom-left pixels first - as this pixel's triangle
+// extrapolates them - recording the taps' coordinates (the arithmetic that only feeds colours drops out of those three
+// evaluations), and the fourth evaluation filters tap k at lod[k].
+enum { TEX_PLAIN = 0, TEX_REC_TL, TEX_REC_TR, TEX_REC_BL, TEX_MIP };
+constexpr int kMaxTaps = 13;
 struct TexCtx {
   const Tex* t;
   const uint8_t* img;
   const SrgbLds* lds;
+  int z, n;
+  float tl[kMaxTaps][2], tr[kMaxTaps][2], lod[kMaxTaps];
 };
 
 #define RCN_FN __device__ __forceinline__ static
@@ -48,20 +57,36 @@ __device__ __forceinline__ float rcn_max(float a, float b) { return b != b ? a :
 // llvmpipe's pow selects 0 where "x == 0" under an unordered compare: a NaN base gives 0
 __device__ __forceinline__ float rcn_pow(float x, float y) { return x != x ? 0.0f : pow_(x, y); }
 
-template <class SI>
+template <class SI, int MODE>
 __device__ __forceinline__ void rcn_tex(void* ctx, float u, float v, float* dst) {
-  const TexCtx* c = static_cast<const TexCtx*>(ctx);
-  const float4 t = SI::get(*c->t, c->img, u, v, c->lds);
+  TexCtx* c = static_cast<TexCtx*>(ctx);
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == TEX_PLAIN) {
+    t = SI::get(*c->t, c->img, u, v, c->lds);
+  } else {
+    const int k = c->n++;   // a compile-time constant once the body is inlined: the taps sit in straight-line code
+    if (MODE == TEX_REC_TL) {
+      c->tl[k][0] = u;
+      c->tl[k][1] = v;
+    } else if (MODE == TEX_REC_TR) {
+      c->tr[k][0] = u;
+      c->tr[k][1] = v;
+    } else if (MODE == TEX_REC_BL) {
+      c->lod[k] = lod_from_quad(*c->t, c->tl[k][0], c->tr[k][0], c->tl[k][1], c->tr[k][1], c->tl[k][0], u, c->tl[k][1], v);
+    } else {
+      t = c->lod[k] > 0.0f ? sample_mip(*c->t, c->z, u, v, c->lod[k], c->lds) : SI::get(*c->t, c->img, u, v, c->lds);
+    }
+  }
   dst[0] = t.x;
   dst[1] = t.y;
   dst[2] = t.z;
   dst[3] = t.w;
 }
 
-// the generated body samples through RCN_TEX; the sampler policy is the enclosing template's
-template <class SI>
+// the generated body samples through RCN_TEX; the sampler policy and the tap mode are the enclosing template's
+template <class SI, int MODE>
 struct LastFs {
-#define RCN_TEX(ctx, unit, u, v, dst) rcn_tex<SI>(ctx, u, v, dst)
+#define RCN_TEX(ctx, unit, u, v, dst) rcn_tex<SI, MODE>(ctx, u, v, dst)
 #define RCN_NO_TABLES
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wunused-but-set-variable"
@@ -72,7 +97,7 @@ struct LastFs {
 #undef RCN_TEX
 };
 
-template <class SI, class SO>
+template <class SI, class SO, bool MIP>
 __global__ void __launch_bounds__(256) k_royale_last_general(const PassLaunch L) {
   RC_SRGB_LDS(lds, L);
   const float* P = L.params;
@@ -82,10 +107,30 @@ __global__ void __launch_bounds__(256) k_royale_last_general(const PassLaunch L)
   float in[kLastVaryings], out[4];
 #pragma unroll
   for (int k = 2; k < kLastVaryings; ++k) in[k] = P[RP11_VARYING0 + k];   // the same at all four vertices: constant planes
+  TexCtx ctx;
+  ctx.t = &L.in;
+  ctx.img = frame_ptr(L.in, z);
+  ctx.lds = &lds;
+  ctx.z = z;
+  if (MIP) {
+    const int x0 = x & ~1, y0 = y & ~1;
+    in[0] = vary(L.plane[0], x0, y0, lo);
+    in[1] = vary(L.plane[1], x0, y0, lo);
+    ctx.n = 0;
+    LastFs<SI, TEX_REC_TL>::royale_last_fs(U, in, out, &ctx);
+    in[0] = vary(L.plane[0], x0 + 1, y0, lo);
+    in[1] = vary(L.plane[1], x0 + 1, y0, lo);
+    ctx.n = 0;
+    LastFs<SI, TEX_REC_TR>::royale_last_fs(U, in, out, &ctx);
+    in[0] = vary(L.plane[0], x0, y0 + 1, lo);
+    in[1] = vary(L.plane[1], x0, y0 + 1, lo);
+    ctx.n = 0;
+    LastFs<SI, TEX_REC_BL>::royale_last_fs(U, in, out, &ctx);
+  }
   in[0] = vary(L.plane[0], x, y, lo);
   in[1] = vary(L.plane[1], x, y, lo);
-  TexCtx ctx{&L.in, frame_ptr(L.in, z), &lds};
-  LastFs<SI>::royale_last_fs(U, in, out, &ctx);
+  ctx.n = 0;
+  LastFs<SI, MIP ? TEX_MIP : TEX_PLAIN>::royale_last_fs(U, in, out, &ctx);
   SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], out[3]), &lds);
   RC_TILE_LOOP_END
 }
@@ -94,11 +139,15 @@ __global__ void __launch_bounds__(256) k_royale_last_general(const PassLaunch L)
 
 namespace rck {
 hipError_t launch_royale_last_general(const PassLaunch& L, hipStream_t s) {
-  if (SrgbLinEdge::matches(L.in) && St<FMT_RGBA8>::matches(L)) {
-    hipLaunchKernelGGL((k_royale_last_general<SrgbLinEdge, St<FMT_RGBA8>>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  if (L.in.n_levels > 1) {   // mipmap_input: four evaluations per pixel, run-time sampler only
+    hipLaunchKernelGGL((k_royale_last_general<SRT, StRT, true>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((k_royale_last_general<SRT, StRT>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  if (SrgbLinEdge::matches(L.in) && St<FMT_RGBA8>::matches(L)) {
+    hipLaunchKernelGGL((k_royale_last_general<SrgbLinEdge, St<FMT_RGBA8>, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL((k_royale_last_general<SRT, StRT, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 }  // namespace rck

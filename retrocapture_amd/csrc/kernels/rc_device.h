@@ -466,7 +466,8 @@ __device__ __forceinline__ void store_rt(const PassLaunch& L, int z, int x, int 
 }
 // ------------------------------------------------------------------- mip-mapped sampling ----
 // texture() on a mip-mapped input (GL_LINEAR_MIPMAP_LINEAR, ShaderEngine.cpp:1022-1033) as llvmpipe evaluates
-// it: rho^2 from per-pixel coordinate differences inside the 2x2 quad, lod = 0.5 * (exponent + mantissa - 1)
+// it: rho^2 from ONE set of coordinate differences per 2x2 quad, taken at its top-left pixel (callers with separable
+// coordinates pass the differences along the pixel's own row / column: the same floats), lod = 0.5 * (exponent + mantissa - 1)
 // of rho^2, the two nearest levels filtered LINEAR and blended with fma (oracle/rc_sampler.c).
 __device__ __forceinline__ float fast_log2_(float x) {
   const uint32_t b = f2bits(x);

@@ -340,14 +340,6 @@ void setupLast(const PassGeometry& g, PassLaunch& L) {
   L.params[RP11_ASPECT_Y] = gy * rs;
 }
 
-// crt-royale-fake-bloom's last pass samples with implicit LOD (mipmap_input); thirteen such taps per pixel in the
-// tex2Daa / curved form are not restated
-const char* validateLastLaunch(const PassLaunch& L) {
-  if (lastIsGeneral(L.params) && L.in.n_levels > 1)
-    return "crt-royale: mipmap_input on the last pass together with geom_mode_runtime > 0.5 or geom_overscan != 1 is not supported by the HIP kernel";
-  return nullptr;
-}
-
 }  // namespace
 
 void registerRoyaleKernels(std::vector<KernelEntry>& r) {
@@ -435,7 +427,6 @@ void registerRoyaleKernels(std::vector<KernelEntry>& r) {
                 {"interlace_bff", 0.0f, 0.0f, 1.0f, 1.0f, "Interlacing - Bottom Field First"},
                 {"interlace_1080i", 0.0f, 0.0f, 1.0f, 1.0f, "Interlace - Detect 1080i"}},
                {}, rck::launch_royale_last, setupLast, false});
-  r.back().validate_launch = validateLastLaunch;
   r.back().mip_aware = true;   // mipmap_input (crt-royale-fake-bloom): LOD from the pixel quad, chain built by the engine
   for (auto& e : r) {
     const std::string n = e.name;

@@ -170,6 +170,31 @@ def case_crt_royale_geom():
                  params=ROYALE_GEOM["sphere"])
 
 
+def case_royale_fake_bloom_geom():
+    """crt-royale-fake-bloom (mask pass active) with curved geometry / overscan: its last pass declares mipmap_input, so each
+    of the twelve tex2Daa taps takes its LOD from the pixel quad; overscan 1.6 minifies enough to reach mip levels 1-2."""
+    import shutil
+    with tempfile.TemporaryDirectory() as d:
+        luts = royale_luts(d)
+        dst = os.path.join(d, "shaders_glsl")
+        os.makedirs(os.path.join(dst, "crt", "shaders"))
+        shutil.copytree(GLSL + "/crt/shaders/crt-royale", dst + "/crt/shaders/crt-royale")
+        shutil.copytree(GLSL + "/blurs", dst + "/blurs")
+        shutil.copy(GLSL + "/crt/crt-royale-fake-bloom.glslp", dst + "/crt/crt-royale-fake-bloom.glslp")
+        f = dst + "/crt/shaders/crt-royale/src/crt-royale-mask-resize-horizontal.glsl"
+        txt = open(f).read()
+        needle = "max(tile_uv_wrap.x, tile_uv_wrap.y) <= mask_resize_num_tiles"
+        assert txt.count(needle) == 1
+        open(f, "w").write(txt.replace(needle, "0.0 <= mask_resize_num_tiles"))
+        P = dst + "/crt/crt-royale-fake-bloom.glslp"
+        cases = {"sphere": [("geom_mode_runtime", 1.0), ("geom_overscan_x", 1.6), ("geom_overscan_y", 1.6)],
+                 "cylinder_tilt": [("geom_mode_runtime", 3.0), ("geom_tilt_angle_x", 0.25), ("geom_radius", 1.2)],
+                 "flat_overscan": [("geom_overscan_x", 2.5), ("geom_overscan_y", 1.75)]}
+        for k, params in cases.items():
+            run_case("crt_royale_fake_bloom_geom_%s_maskon_96x72_to_240x180" % k, P, mixed(96, 72, 41), 240, 180, luts=luts, params=params)
+            run_case("f32_crt_royale_fake_bloom_geom_%s_maskon_64x48_to_128x96" % k, P, mixed(64, 48, 5), 128, 96, luts=luts, params=params, f32=True)
+
+
 def case_crt_royale_mask_active(f32=False):
     """crt-royale as a GL driver that returns 0 for an unwritten varying would render it.
     Pass 6's fragment shader tests `max(tile_uv_wrap.x, tile_uv_wrap.y) <= mask_resize_num_tiles`
@@ -635,7 +660,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -102,7 +102,10 @@ def test_royale_matches_oracle_and_golden(case, preset_tree, rc_lib):
 
 ROYALE_GEOM_GOLDEN = ["crt_royale_geom_sphere_96x72_to_240x180", "crt_royale_geom_sphere_alt_tilt_96x72_to_240x180",
                       "crt_royale_geom_cylinder_96x72_to_240x180", "crt_royale_geom_flat_overscan_96x72_to_240x180",
-                      "crt_royale_geom_sphere_128x96_to_401x299"]
+                      "crt_royale_geom_sphere_128x96_to_401x299",
+                      # crt-royale-fake-bloom: the last pass is mip-mapped, every tex2Daa tap takes its LOD from the pixel quad
+                      "crt_royale_fake_bloom_geom_sphere_maskon_96x72_to_240x180", "crt_royale_fake_bloom_geom_cylinder_tilt_maskon_96x72_to_240x180",
+                      "crt_royale_fake_bloom_geom_flat_overscan_maskon_96x72_to_240x180"]
 
 
 @pytest.mark.parametrize("case", ROYALE_GEOM_GOLDEN)
@@ -112,13 +115,15 @@ def test_royale_curved_geometry_and_overscan_match_llvmpipe(case, preset_tree, r
     from gpu_util import make_engine, run_engine
     g = np.load(os.path.join(GOLD, case + ".npz"))
     vw, vh = [int(v) for v in g["viewport"]]
-    e = make_engine(preset_tree["crt-royale"], vw, vh)
+    e = make_engine(preset_tree["crt-royale-fake-bloom" if "fake_bloom" in case else "crt-royale"], vw, vh)
+    e.setUndefinedVaryingZero("maskon" in case)
     for name, v in zip(g["param_names"], g["param_values"]):
         assert e.setShaderParameter(str(name), float(v))
     final = run_engine(e, g["input_rgb"])
-    for i in range(12):
+    n = int(g["n_passes"])
+    for i in range(n):
         assert np.array_equal(e.readPass(i, 0), g["pass%d" % i]), "pass %d vs llvmpipe golden" % i
-    assert np.array_equal(final[0], g["pass11"])
+    assert np.array_equal(final[0], g["pass%d" % (n - 1)])
     e.shutdown()
 
 
@@ -323,12 +328,6 @@ def test_fake_bloom_forms_agree_and_mipmap_input_rule(preset_tree, rc_lib):
     e.setGeneralKernelsOnly(False)
     s = run_engine(e, big)
     assert np.array_equal(g, s) and s.shape == (1, 1080, 1920, 4)
-    # curved geometry on this preset would need thirteen implicit-LOD taps per pixel: refused loudly, not mis-rendered
-    from gpu_util import to_device_rgba
-    from retrocapture_amd.engine import RcError
-    assert e.setShaderParameter("geom_mode_runtime", 1.0)
-    with pytest.raises(RcError, match="mipmap_input"):
-        e.applyShader(to_device_rgba(frames[:1]), 128, 96)
     e.shutdown()
 
 

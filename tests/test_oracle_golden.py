@@ -36,6 +36,10 @@ CASES = {
     "crt_royale_geom_cylinder_96x72_to_240x180": "crt-royale",
     "crt_royale_geom_flat_overscan_96x72_to_240x180": "crt-royale",
     "crt_royale_geom_sphere_128x96_to_401x299": "crt-royale",
+    # ... on crt-royale-fake-bloom, whose last pass is mip-mapped: per-tap LOD from the quad's top-left differences
+    "crt_royale_fake_bloom_geom_sphere_maskon_96x72_to_240x180": "crt-royale-fake-bloom",
+    "crt_royale_fake_bloom_geom_cylinder_tilt_maskon_96x72_to_240x180": "crt-royale-fake-bloom",
+    "crt_royale_fake_bloom_geom_flat_overscan_maskon_96x72_to_240x180": "crt-royale-fake-bloom",
     "feedback_persist_64x40_to_64x40_f1": "feedback-persist",
     "feedback_persist_64x40_to_64x40_f2": "feedback-persist",
     "feedback_persist_64x40_to_150x90_f5": "feedback-persist",
@@ -230,6 +234,9 @@ FLOAT_CASES = {
     "f32_crt_royale_geom_sphere_alt_tilt_64x48_to_128x96": ("crt-royale", {}),
     "f32_crt_royale_geom_cylinder_64x48_to_128x96": ("crt-royale", {}),
     "f32_crt_royale_geom_flat_overscan_64x48_to_128x96": ("crt-royale", {}),
+    "f32_crt_royale_fake_bloom_geom_sphere_maskon_64x48_to_128x96": ("crt-royale-fake-bloom", {}),
+    "f32_crt_royale_fake_bloom_geom_cylinder_tilt_maskon_64x48_to_128x96": ("crt-royale-fake-bloom", {}),   # non-separable coordinates: pins the quad rule
+    "f32_crt_royale_fake_bloom_geom_flat_overscan_maskon_64x48_to_128x96": ("crt-royale-fake-bloom", {}),
     # pass 8 (the last pass, mipmap_input = true at 1:1): llvmpipe's trilinear LOD is a hair above 0 on some pixel
     # quads and blends a 1e-7 share of mip level 1 into the sample; restated (rc_sampler.c), bit-identical
     "f32_crt_royale_fake_bloom_maskon_64x48_to_128x96": ("crt-royale-fake-bloom", {}),
@@ -344,4 +351,4 @@ def test_every_golden_file_has_a_case():
     assert names <= set(CASES) | set(FLOAT_CASES) | set(WRAP_CASES) | EXTRA_GOLDEN
 
 
-EXTRA_GOLDEN = set(FLOAT_HISTORY) | set(BLIT_CASES)
+EXTRA_GOLDEN = set(FLOAT_HISTORY) | set(BLIT_CASES) | {"crt_hyllian_glow_layouts_48x36_to_143x101"}   # test_hyllian_phosphor_layouts
