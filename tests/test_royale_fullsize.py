@@ -83,6 +83,31 @@ def test_crt_royale_1080p_every_pass_against_the_oracle(mask_rendered, preset_tr
         assert final[0][..., :3].std() > 10      # the mask path carries signal
 
 
+@pytest.mark.parametrize("params", [{"geom_mode_runtime": 2.0, "geom_tilt_angle_x": 0.1, "geom_tilt_angle_y": -0.05},
+                                    {"geom_overscan_x": 1.05, "geom_overscan_y": 0.95}])
+def test_crt_royale_1080p_curved_last_pass_against_the_oracle(params, preset_tree, rc_lib):
+    """The headline size with the last pass in its tex2Daa / ray-cast form (curved geometry, overscan): every pass against the
+    oracle fed the engine's own previous passes; the parameters only reach pass 11."""
+    from gpu_util import make_engine, run_engine
+    from retrocapture_amd import engine as eng
+    oracle_lib.set_threads(min(16, os.cpu_count() or 1))
+    passes = eng.preset_dump(preset_tree["crt-royale"])["passes"]
+    frame = smooth(W, H, 21)
+    e = make_engine(preset_tree["crt-royale"], W, H)
+    e.setUndefinedVaryingZero(True)
+    flat = run_engine(e, frame)[0]
+    for k, v in params.items():
+        assert e.setShaderParameter(k, v)
+    final = run_engine(e, frame)[0]
+    mine = [e.readPass(i, 0) for i in range(12)]
+    e.shutdown()
+    want = run_chain(passes, frame, W, H, luts=royale_luts(), flags=1, given=mine, custom=params)
+    for i in range(12):
+        bad = int((want[i] != mine[i]).sum())
+        assert bad == 0, "pass %d: %d bytes differ from the oracle" % (i, bad)
+    assert np.array_equal(final, want[11]) and not np.array_equal(final, flat) and final[..., :3].std() > 10
+
+
 def test_scanline_table_form_fallback_share(preset_tree, rc_lib):
     """Geometry that is not the regular 1:1 one (here 1080 -> 1000 lines) must take the general form: same bytes
     as the oracle on a band."""
