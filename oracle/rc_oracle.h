@@ -148,6 +148,8 @@ void o_pass_mix_frames(const o_pass_args* a);         /* extra[0] = PrevTexture 
 void o_pass_motionblur_simple(const o_pass_args* a);  /* extra[0..6] = Prev6 .. Prev1, PrevTexture */
 void o_pass_braid_rewind(const o_pass_args* a);       /* history declared, not used (FrameDirection = 1) */
 void o_pass_response_time(const o_pass_args* a);      /* 1 param; extra[0..6] = PrevTexture, Prev1 .. Prev6 */
+void o_pass_shutter_3d(const o_pass_args* a);         /* 7 params; extra[0] = PrevTexture */
+void o_pass_anti_flicker(const o_pass_args* a);       /* 1 param; extra[0] = PrevTexture, extra[1] = Prev1Texture */
 void o_pass_mix_frames_smart(const o_pass_args* a);   /* 1 param; extra[0..4] = PrevTexture, Prev1 .. Prev4 */
 /* crt-royale (shaders/shaders_glsl/crt/shaders/crt-royale/src/ and blurs/blur9fast-{vertical,horizontal}.glsl) */
 void o_pass_royale_first(const o_pass_args* a);       /* P0  first-pass-linearize-crt-gamma-bob-fields */

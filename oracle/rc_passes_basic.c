@@ -652,3 +652,77 @@ static void o_pass_lcd1x_body(const o_pass_args* a) {
     }
 }
 void o_pass_lcd1x(const o_pass_args* a) { unsigned csr = o_fp_enter(); o_pass_lcd1x_body(a); o_fp_leave(csr); }
+
+/* stereoscopic-3d/shaders/shutter-3d.glsl (stereoscopic-3d/shutter-to-side-by-side.glslp): VS 61-73, FS 123-143; operation
+ * order from the GL's final instruction listing (LP_DEBUG=fs / GALLIVM_DEBUG=tgsi).  params: ZOOM, vert_pos, horz_pos,
+ * separation, flicker, height_mod, swap_eye; extra[0] = PrevTexture.  The left / right eye coordinates are varyings; timer
+ * = |swap_eye - mod(FrameCount, 2)| is the same at every vertex. */
+static void shutter_3d_vertex(const float* P, float isx, float isy, float tsx, float tsy, float tcx, float tcy, float* lr) {
+  const float hx = (0.5f * isx) / tsx, hy = (0.5f * isy) / tsy;
+  const float tx = tcx + -hx, ty = tcy + -hy;
+  float x = (tx * 2.0f) * P[0] + P[2], y = (ty * P[0]) * (1.0f / P[5]) + P[1];
+  x = x + hx;
+  y = y + hy;
+  const float sx = ((0.5f + P[3]) * isx) / tsx, sy = 0.0f / tsy;
+  lr[0] = x + -sx; lr[1] = y + -sy; lr[2] = x + sx; lr[3] = y + sy;
+}
+void o_pass_shutter_3d(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  const float* P = a->params;
+  const float isx = (float)a->in->w, isy = (float)a->in->h, tsx = isx, tsy = isy;
+  float v[4][4];   /* BL, BR, TR, TL */
+  static const float tc[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+  for (int k = 0; k < 4; ++k) shutter_3d_vertex(P, isx, isy, tsx, tsy, tc[k][0], tc[k][1], v[k]);
+  o_varying pl[4];
+  for (int c = 0; c < 4; ++c) pl[c] = o_varying_setup(v[0][c], v[1][c], v[2][c], v[3][c], W, H, a->out_fmt);
+  const float fc = (float)a->frame_count;
+  const float timer = fabsf(P[6] + -(fc + -(2.0f * floorf(fc / 2.0f))));
+  const float omt = 1.0f + -timer, flicker = P[4];
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float lx = o_varying_at(&pl[0], x, y, lo), ly = o_varying_at(&pl[1], x, y, lo);
+      const float rx = o_varying_at(&pl[2], x, y, lo), ry = o_varying_at(&pl[3], x, y, lo);
+      const o_vec4 L = o_sample(a->in, lx, ly), R = o_sample(a->in, rx, ry), Rh = o_sample(a->extra[0], rx, ry), Lh = o_sample(a->extra[0], lx, ly);
+      const float l4[4] = {L.x, L.y, L.z, L.w}, lh4[4] = {Lh.x, Lh.y, Lh.z, Lh.w}, r4[4] = {R.x, R.y, R.z, R.w}, rh4[4] = {Rh.x, Rh.y, Rh.z, Rh.w};
+      const float lcx = (lx * isx) / tsx, lcy = (ly * isy) / tsy, rcx = (rx * isx) / tsx, rcy = (ry * isy) / tsy;
+      const float lm = (lcy != lcy) ? lcx : (lcx < lcy ? lcx : lcy), rm = (rcy != rcy) ? rcx : (rcx < rcy ? rcx : rcy);
+      const float ml = (0.0001f < lm && lcx < 0.9999f && lcy < 0.9999f) ? 1.0f : 0.0f;
+      const float mr = (0.0001f < rm && rcx < 0.9999f && rcy < 0.9999f) ? 1.0f : 0.0f;
+      float o[4];
+      for (int c = 0; c < 4; ++c) {
+        const float lc = l4[c] * timer + (omt * lh4[c]) * flicker;
+        const float rc = r4[c] * omt + (rh4[c] * timer) * flicker;
+        o[c] = lc * ml + rc * mr;
+      }
+      const o_vec4 out = {o[0], o[1], o[2], o[3]};
+      store_px(a, x, y, out);
+    }
+  o_fp_leave(csr);
+}
+
+/* misc/anti-flicker.glsl FS 99-127 (no preset of the reference's tree names it; loaded as a one-pass chain).  params:
+ * lum_diff_thresh; extra[0] = PrevTexture, extra[1] = Prev1Texture.  YIQ dot products run blue, green, then red. */
+void o_pass_anti_flicker(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  const float th = a->params[0];
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      const o_vec4 c = o_sample(a->in, u, v), p0 = o_sample(a->extra[0], u, v), p1 = o_sample(a->extra[1], u, v);
+      const float cy = (c.z * 0.114f + c.y * 0.587f) + c.x * 0.2989f, ci = (c.z * -0.3216f + c.y * -0.2744f) + c.x * 0.5959f;
+      const float cq = (c.z * 0.3114f + c.y * -0.5229f) + c.x * 0.2115f;
+      const float py = (p0.z * 0.114f + p0.y * 0.587f) + p0.x * 0.2989f, pi = (p0.z * -0.3216f + p0.y * -0.2744f) + p0.x * 0.5959f;
+      const float pq = (p0.z * 0.3114f + p0.y * -0.5229f) + p0.x * 0.2115f;
+      const float p1y = (p1.z * 0.114f + p1.y * 0.587f) + p1.x * 0.2989f;
+      const int blend = (th < fabsf(cy + -py)) && (fabsf(cy + -p1y) < 1.0f + -th);
+      const float Y = blend ? (py + cy) / 2.0f : cy, I = blend ? (pi + ci) / 2.0f : ci, Q = blend ? (pq + cq) / 2.0f : cq;
+      const o_vec4 out = {(Q * 0.621f + Y) + I * 0.956f, (Q * -0.6474f + Y) + I * -0.272f, (Q * 1.7046f + Y) + I * -1.106f, 1.0f};
+      store_px(a, x, y, out);
+    }
+  o_fp_leave(csr);
+}

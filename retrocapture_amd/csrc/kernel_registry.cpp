@@ -51,6 +51,26 @@ void setupResponseTime(const PassGeometry& g, rcd::PassLaunch& L) {
   L.params[6] = rcd::pow_(rt, 6.0f);
   L.params[7] = rcd::pow_(rt, 7.0f);
 }
+// shutter-3d.glsl VS 61-73: left_coord / right_coord at the quad's vertices, in the GL's operation order (oracle/rc_passes_basic.c)
+void setupShutter3d(const PassGeometry& g, rcd::PassLaunch& L) {
+  const float* P = L.params;
+  const float isx = (float)g.in_w, isy = (float)g.in_h, tsx = isx, tsy = isy;
+  static const float tc[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};   // BL, BR, TR, TL
+  float v[4][4];
+  for (int k = 0; k < 4; ++k) {
+    const float hx = (0.5f * isx) / tsx, hy = (0.5f * isy) / tsy;
+    const float tx = tc[k][0] + -hx, ty = tc[k][1] + -hy;
+    float x = (tx * 2.0f) * P[0] + P[2], y = (ty * P[0]) * (1.0f / P[5]) + P[1];
+    x = x + hx;
+    y = y + hy;
+    const float sx = ((0.5f + P[3]) * isx) / tsx, sy = 0.0f / tsy;
+    v[k][0] = x + -sx;
+    v[k][1] = y + -sy;
+    v[k][2] = x + sx;
+    v[k][3] = y + sy;
+  }
+  for (int c = 0; c < 4; ++c) L.plane[c] = makePlane(v[0][c], v[1][c], v[2][c], v[3][c], g.out_w, g.out_h, g.out_fmt);
+}
 // glow/blur_{horiz,vert}.glsl: the nine weights exp(-0.35 i^2) and their sum.  The loop is unrolled by the GL's compiler
 // and the constant folded after exp(x) -> exp2(x * log2e) with the constant factor moved onto one operand:
 // exp2f(i * (i * (-0.35f * log2e))) in float (oracle/rc_passes_glow.c glow_blur).
@@ -373,6 +393,15 @@ std::vector<KernelEntry> build() {
   r.push_back({"motionblur/shaders/mix_frames_smart.glsl", "mix-frames-smart", {{"DEFLICKER_EMPHASIS", 0.0f, 0.0f, 1.0f, 0.01f, "Deflicker Emphasis"}},
                {"PrevTexture", "Prev1Texture", "Prev2Texture", "Prev3Texture", "Prev4Texture"},
                rck::launch_mix_frames_smart, setupCrtPi, false, true, nullptr, nullptr, true});   // VS: TEX0 = TexCoord * 1.0001
+  // two more frame-history shaders (kernels/pass_basic.hip): stereoscopic-3d/shutter-to-side-by-side.glslp and misc/anti-flicker.glsl
+  r.push_back({"stereoscopic-3d/shaders/shutter-3d.glsl", "shutter-3d",
+               {{"ZOOM", 1.0f, 0.0f, 2.0f, 0.01f, "Zoom"}, {"vert_pos", 0.0f, -2.0f, 2.0f, 0.01f, "Vertical Modifier"},
+                {"horz_pos", 0.0f, -2.0f, 2.0f, 0.01f, "Horizontal Modifier"}, {"separation", 0.0f, -2.0f, 2.0f, 0.01f, "Eye Separation"},
+                {"flicker", 0.0f, 0.0f, 1.0f, 0.25f, "Hold Last Frame (reduce flicker)"}, {"height_mod", 1.0f, 0.0f, 2.0f, 0.01f, "Image Height"},
+                {"swap_eye", 0.0f, 0.0f, 1.0f, 1.0f, "Swap Eye Sequence"}},
+               {"PrevTexture"}, rck::launch_shutter_3d, setupShutter3d, false, true, nullptr, nullptr, true});   // InputSize / TextureSize only as a ratio
+  r.push_back({"misc/anti-flicker.glsl", "anti-flicker", {{"lum_diff_thresh", 0.5f, 0.0f, 1.0f, 0.05f, "Flicker Luma Diff. Threshold"}},
+               {"PrevTexture", "Prev1Texture"}, rck::launch_anti_flicker, setupTexCoord, false, true, nullptr, nullptr, true});
   r.push_back({"ntsc/shaders/ntsc-pass1-svideo-3phase.glsl", "ntsc-pass1-svideo-3phase", {}, {},
                rck::launch_ntsc_pass1, setupNtscPass1, false});
   r.push_back({"ntsc/shaders/ntsc-pass2-3phase-gamma.glsl", "ntsc-pass2-3phase-gamma", {}, {},

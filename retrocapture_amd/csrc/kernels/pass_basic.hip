@@ -98,6 +98,54 @@ __global__ void __launch_bounds__(256) k_mix_frames(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// stereoscopic-3d/shaders/shutter-3d.glsl FS 123-143 (stereoscopic-3d/shutter-to-side-by-side.glslp): the left eye's frame
+// and the right eye's side by side, alternating with FrameCount parity, the other eye held from PrevTexture x flicker.
+// params: ZOOM, vert_pos, horz_pos, separation, flicker, height_mod, swap_eye; extra[0] = PrevTexture;
+// plane[0..3] = left_coord.xy, right_coord.xy (registry: setupShutter3d).  Operation order: the GL's instruction listing.
+__global__ void __launch_bounds__(256) k_shutter_3d(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const float isx = (float)L.in.w, isy = (float)L.in.h, flicker = L.params[4];
+  RC_TILE_LOOP_BEGIN
+  const float fc = (float)(L.frame_count0 + z);
+  const float timer = __builtin_fabsf(L.params[6] + -(fc + -(2.0f * __builtin_floorf(fc / 2.0f))));   // |swap_eye - mod(FrameCount, 2)|
+  const float omt = 1.0f + -timer;
+  const float lx = vary(L.plane[0], x, y, lo), ly = vary(L.plane[1], x, y, lo), rx = vary(L.plane[2], x, y, lo), ry = vary(L.plane[3], x, y, lo);
+  const uint8_t* img = frame_ptr(L.in, z);
+  const uint8_t* prev = frame_ptr(L.extra[0], z);
+  const float4 l = sample_rt(L.in, img, lx, ly, &lds), r = sample_rt(L.in, img, rx, ry, &lds);
+  const float4 lh = sample_rt(L.extra[0], prev, lx, ly, &lds), rh = sample_rt(L.extra[0], prev, rx, ry, &lds);
+  const float lcx = (lx * isx) / isx, lcy = (ly * isy) / isy, rcx = (rx * isx) / isx, rcy = (ry * isy) / isy;   // coord * InputSize / TextureSize
+  const float lm = lcy != lcy ? lcx : (lcx < lcy ? lcx : lcy), rm = rcy != rcy ? rcx : (rcx < rcy ? rcx : rcy);
+  const float ml = (0.0001f < lm && lcx < 0.9999f && lcy < 0.9999f) ? 1.0f : 0.0f;
+  const float mr = (0.0001f < rm && rcx < 0.9999f && rcy < 0.9999f) ? 1.0f : 0.0f;
+  const float l4[4] = {l.x, l.y, l.z, l.w}, lh4[4] = {lh.x, lh.y, lh.z, lh.w}, r4[4] = {r.x, r.y, r.z, r.w}, rh4[4] = {rh.x, rh.y, rh.z, rh.w};
+  float o[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o[c] = (l4[c] * timer + (omt * lh4[c]) * flicker) * ml + (r4[c] * omt + (rh4[c] * timer) * flicker) * mr;
+  store_rt(L, z, x, y, make_float4(o[0], o[1], o[2], o[3]), &lds);
+  RC_TILE_LOOP_END
+}
+
+// misc/anti-flicker.glsl FS 99-127: blends the previous frame in where the luma jumps against it but not against the frame
+// before.  params: lum_diff_thresh; extra[0] = PrevTexture, extra[1] = Prev1Texture.  The YIQ products run blue, green, red.
+__global__ void __launch_bounds__(256) k_anti_flicker(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const float th = L.params[0];
+  RC_TILE_LOOP_BEGIN
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+  const float4 p0 = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), u, v, &lds), p1 = sample_rt(L.extra[1], frame_ptr(L.extra[1], z), u, v, &lds);
+  const float cy = (c.z * 0.114f + c.y * 0.587f) + c.x * 0.2989f, ci = (c.z * -0.3216f + c.y * -0.2744f) + c.x * 0.5959f;
+  const float cq = (c.z * 0.3114f + c.y * -0.5229f) + c.x * 0.2115f;
+  const float py = (p0.z * 0.114f + p0.y * 0.587f) + p0.x * 0.2989f, pi = (p0.z * -0.3216f + p0.y * -0.2744f) + p0.x * 0.5959f;
+  const float pq = (p0.z * 0.3114f + p0.y * -0.5229f) + p0.x * 0.2115f;
+  const float p1y = (p1.z * 0.114f + p1.y * 0.587f) + p1.x * 0.2989f;
+  const bool blend = (th < __builtin_fabsf(cy + -py)) && (__builtin_fabsf(cy + -p1y) < 1.0f + -th);
+  const float Y = blend ? (py + cy) / 2.0f : cy, I = blend ? (pi + ci) / 2.0f : ci, Q = blend ? (pq + cq) / 2.0f : cq;
+  store_rt(L, z, x, y, make_float4((Q * 0.621f + Y) + I * 0.956f, (Q * -0.6474f + Y) + I * -0.272f, (Q * 1.7046f + Y) + I * -1.106f, 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
 // The other frame-history shaders of motionblur/ (oracle/rc_passes_basic.c); every texture is sampled at the pass's one
 // coordinate (motionblur-simple's PrevNTexCoord attributes alias TexCoord's location in the reference).
 // motionblur-simple.glsl FS 178-199: extra[0..6] = Prev6 .. Prev1, PrevTexture; c = (c + next) / 2 down to the current frame
@@ -530,6 +578,8 @@ RC_SIMPLE_LAUNCH(launch_motionblur_simple, k_motionblur_simple)
 RC_SIMPLE_LAUNCH(launch_braid_rewind, k_braid_rewind)
 RC_SIMPLE_LAUNCH(launch_response_time, k_response_time)
 RC_SIMPLE_LAUNCH(launch_mix_frames_smart, k_mix_frames_smart)
+RC_SIMPLE_LAUNCH(launch_shutter_3d, k_shutter_3d)
+RC_SIMPLE_LAUNCH(launch_anti_flicker, k_anti_flicker)
 #undef RC_SIMPLE_LAUNCH
 hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_feedback_persist, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);

@@ -50,6 +50,10 @@ scale_y1 = 1.0
     # same keys / values as the reference's other motionblur/ presets
     "motionblur-simple": ("motionblur/motionblur-simple.glslp", 'shaders = 1\n\nshader0 = shaders/motionblur-simple.glsl\nfilter_linear0 = false\n'),
     "braid-rewind": ("motionblur/braid-rewind.glslp", 'shaders = 1\n\nshader0 = shaders/braid-rewind.glsl\nfilter_linear0 = false\n'),
+    # Same keys / values as the reference's stereoscopic-3d/shutter-to-side-by-side.glslp
+    "shutter-3d": ("stereoscopic-3d/shutter-to-side-by-side.glslp", 'shaders = 1\n\nshader0 = shaders/shutter-3d.glsl\nwrap_mode0 = edge\n'),
+    # misc/anti-flicker.glsl has no preset in the reference's tree: a one-pass chain of this repository
+    "anti-flicker": ("misc/anti-flicker.glslp", 'shaders = 1\n\nshader0 = misc/anti-flicker.glsl\nfilter_linear0 = false\n'),
     "response-time": ("motionblur/response-time.glslp", 'shaders = 1\n\nshader0 = shaders/response-time.glsl\nfilter_linear0 = false\n'),
     "mix-frames-smart": ("motionblur/mix_frames_smart.glslp", 'shaders = "1"\n\nshader0 = "shaders/mix_frames_smart.glsl"\nfilter_linear0 = "false"\n'),
     "mix-frames": ("motionblur/mix_frames.glslp", 'shaders = "1"\n\nshader0 = "shaders/mix_frames.glsl"\nfilter_linear0 = "false"\n'),
@@ -363,6 +367,11 @@ SHADERS = {
     "motionblur/shaders/response-time.glsl": {"oracle": "response_time", "params": [("response_time", 0.333)], "size_independent": True,
                                               "samplers": ["PrevTexture", "Prev1Texture", "Prev2Texture", "Prev3Texture", "Prev4Texture",
                                                            "Prev5Texture", "Prev6Texture"]},
+    "stereoscopic-3d/shaders/shutter-3d.glsl": {"oracle": "shutter_3d", "size_independent": True, "samplers": ["PrevTexture"],
+                                                "params": [("ZOOM", 1.0), ("vert_pos", 0.0), ("horz_pos", 0.0), ("separation", 0.0), ("flicker", 0.0),
+                                                           ("height_mod", 1.0), ("swap_eye", 0.0)]},
+    "misc/anti-flicker.glsl": {"oracle": "anti_flicker", "size_independent": True, "samplers": ["PrevTexture", "Prev1Texture"],
+                               "params": [("lum_diff_thresh", 0.5)]},
     "motionblur/shaders/mix_frames_smart.glsl": {"oracle": "mix_frames_smart", "params": [("DEFLICKER_EMPHASIS", 0.0)], "size_independent": True,
                                                  "samplers": ["PrevTexture", "Prev1Texture", "Prev2Texture", "Prev3Texture", "Prev4Texture"]},
     **{"ntsc/shaders/ntsc-pass1-%s.glsl" % n: {"oracle": "ntsc_pass1_" + n.replace("-", "_"), "params": [], "samplers": []}

@@ -495,6 +495,21 @@ def case_hyllian_glow():
              params=[("HFILTER_SHARPNESS", 0.7), ("CRT_ANTI_RINGING", 0.6), ("MASK_INTENSITY", 0.7), ("PHOSPHOR_LAYOUT", 5.0)])
 
 
+def case_history_more():
+    """Two more frame-history shaders: stereoscopic-3d/shutter-to-side-by-side.glslp (PrevTexture; FrameCount parity selects
+    the eye) and misc/anti-flicker.glsl (PrevTexture, Prev1Texture; no preset in the reference's tree: one-pass chain)."""
+    S = GLSL + "/stereoscopic-3d/shutter-to-side-by-side.glslp"
+    prm = [("ZOOM", 0.9), ("vert_pos", -0.03), ("horz_pos", 0.05), ("separation", 0.1), ("flicker", 0.5), ("height_mod", 1.3), ("swap_eye", 1.0)]
+    run_case("shutter_3d_48x36_to_120x90_f4", S, moving(48, 36, 4, 51), 120, 90)
+    run_case("shutter_3d_params_48x36_to_131x77_f5", S, moving(48, 36, 5, 52), 131, 77, params=prm)
+    run_case("f32_shutter_3d_params_48x36_to_131x77_f5", S, moving(48, 36, 5, 53), 131, 77, params=prm, f32=True)
+    with tempfile.TemporaryDirectory() as d:
+        p = write_preset(d, 'shaders = 1\nshader0 = %s/misc/anti-flicker.glsl\nfilter_linear0 = false\n' % GLSL)
+        run_case("anti_flicker_48x36_to_120x90_f6", p, flicker(48, 36, 6, 54), 120, 90)
+        run_case("anti_flicker_params_40x30_to_40x30_f5", p, flicker(40, 30, 5, 55), 40, 30, params=[("lum_diff_thresh", 0.2)])
+        run_case("f32_anti_flicker_48x36_to_120x90_f6", p, flicker(48, 36, 6, 56), 120, 90, f32=True)
+
+
 def case_hyllian_layouts():
     """resolve2.glsl's twenty PHOSPHOR_LAYOUT masks (mask_weights, 129-400): one chain run per layout; the first five
     passes do not depend on it and are kept once, the last pass once per layout."""
@@ -660,7 +675,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

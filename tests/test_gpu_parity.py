@@ -382,13 +382,15 @@ HISTORY_CASES = {"mix_frames_72x40_to_72x40_f3": "mix-frames", "mix_frames_48x36
                  "motionblur_simple_48x36_to_120x90_f9": "motionblur-simple", "motionblur_simple_40x30_to_40x30_f3": "motionblur-simple",
                  "braid_rewind_48x36_to_120x90_f8": "braid-rewind", "response_time_48x36_to_120x90_f9": "response-time",
                  "response_time_params_40x30_to_100x75_f4": "response-time", "mix_frames_smart_48x36_to_120x90_f8": "mix-frames-smart",
-                 "mix_frames_smart_params_40x30_to_40x30_f7": "mix-frames-smart"}
+                 "mix_frames_smart_params_40x30_to_40x30_f7": "mix-frames-smart",
+                 "shutter_3d_48x36_to_120x90_f4": "shutter-3d", "shutter_3d_params_48x36_to_131x77_f5": "shutter-3d",
+                 "anti_flicker_48x36_to_120x90_f6": "anti-flicker", "anti_flicker_params_40x30_to_40x30_f5": "anti-flicker"}
 
 
 @pytest.mark.parametrize("case", sorted(HISTORY_CASES))
 @pytest.mark.parametrize("as_batch", [False, True])
 def test_frame_history_matches_golden(case, as_batch, preset_tree, rc_lib):
-    """The five motionblur/ presets (PrevTexture .. Prev6Texture): output of the last frame and the whole history ring
+    """The five motionblur/ presets (PrevTexture .. Prev6Texture), shutter-to-side-by-side and anti-flicker: output of the last frame and the whole history ring
     (first-frame rule, recursion through pass 0's program, wrap of the 7-deep ring with its recycled-and-cleared oldest
     texture) against llvmpipe, with the frames applied one call at a time and as one batch."""
     from gpu_util import make_engine, run_engine

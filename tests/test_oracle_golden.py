@@ -46,6 +46,10 @@ CASES = {
     "motionblur_simple_48x36_to_120x90_f9": "motionblur-simple",   # Prev .. Prev6; 9 frames: the full ring recycles (and clears) its oldest texture
     "motionblur_simple_40x30_to_40x30_f3": "motionblur-simple",
     "braid_rewind_48x36_to_120x90_f8": "braid-rewind",
+    "shutter_3d_48x36_to_120x90_f4": "shutter-3d",               # FrameCount parity selects the eye; PrevTexture held x flicker
+    "shutter_3d_params_48x36_to_131x77_f5": "shutter-3d",        # all seven parameters changed
+    "anti_flicker_48x36_to_120x90_f6": "anti-flicker",
+    "anti_flicker_params_40x30_to_40x30_f5": "anti-flicker",
     "response_time_48x36_to_120x90_f9": "response-time",
     "response_time_params_40x30_to_100x75_f4": "response-time",
     "mix_frames_smart_48x36_to_120x90_f8": "mix-frames-smart",
@@ -134,7 +138,7 @@ def run_sequence(passes, frames_rgb, vw, vh, **kw):
     return outs, st
 
 
-HISTORY_PRESETS = ("mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart")
+HISTORY_PRESETS = ("mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
 
 
 @pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] in HISTORY_PRESETS))
@@ -275,7 +279,8 @@ def test_oracle_arithmetic_at_float_precision(case, tmp_path, rc_lib):
         assert ulp.size == 0 or ulp.max() <= 9000, "pass %d: max %d ulp" % (i, int(ulp.max()))
 
 
-FLOAT_HISTORY = {"f32_mix_frames_48x36_to_120x90_f3": "mix-frames", "f32_response_time_48x36_to_120x90_f9": "response-time",
+FLOAT_HISTORY = {"f32_shutter_3d_params_48x36_to_131x77_f5": "shutter-3d", "f32_anti_flicker_48x36_to_120x90_f6": "anti-flicker",
+                 "f32_mix_frames_48x36_to_120x90_f3": "mix-frames", "f32_response_time_48x36_to_120x90_f9": "response-time",
                  "f32_mix_frames_smart_48x36_to_120x90_f8": "mix-frames-smart", "f32_motionblur_simple_48x36_to_120x90_f9": "motionblur-simple"}
 
 
@@ -284,7 +289,8 @@ def test_frame_history_at_float_precision(case, tmp_path, rc_lib):
     g = np.load(os.path.join(GOLD, case + ".npz"))
     passes = preset_passes(tmp_path, FLOAT_HISTORY[case])
     vw, vh = [int(v) for v in g["viewport"]]
-    outs, st = run_sequence(passes, g["input_rgb"], vw, vh, force_f32=True)
+    custom = dict(zip([str(n) for n in g["param_names"]], [float(v) for v in g["param_values"]])) if "param_names" in g else None
+    outs, st = run_sequence(passes, g["input_rgb"], vw, vh, force_f32=True, custom=custom)
     assert np.array_equal(outs[-1].view(np.uint32), g["pass0"].view(np.uint32))
 
 
