@@ -148,6 +148,13 @@ void o_pass_mix_frames(const o_pass_args* a);         /* extra[0] = PrevTexture 
 void o_pass_motionblur_simple(const o_pass_args* a);  /* extra[0..6] = Prev6 .. Prev1, PrevTexture */
 void o_pass_braid_rewind(const o_pass_args* a);       /* history declared, not used (FrameDirection = 1) */
 void o_pass_response_time(const o_pass_args* a);      /* 1 param; extra[0..6] = PrevTexture, Prev1 .. Prev6 */
+void o_pass_gba_color(const o_pass_args* a);          /* handheld/shaders/color/: 1 param (gba, gbc, vba) or none */
+void o_pass_gbc_color(const o_pass_args* a);
+void o_pass_vba_color(const o_pass_args* a);
+void o_pass_nds_color(const o_pass_args* a);
+void o_pass_palm_color(const o_pass_args* a);
+void o_pass_psp_color(const o_pass_args* a);
+void o_pass_gbc_gambatte_color(const o_pass_args* a);
 void o_pass_shutter_3d(const o_pass_args* a);         /* 7 params; extra[0] = PrevTexture */
 void o_pass_anti_flicker(const o_pass_args* a);       /* 1 param; extra[0] = PrevTexture, extra[1] = Prev1Texture */
 void o_pass_mix_frames_smart(const o_pass_args* a);   /* 1 param; extra[0..4] = PrevTexture, Prev1 .. Prev4 */

@@ -726,3 +726,66 @@ void o_pass_anti_flicker(const o_pass_args* a) {
     }
   o_fp_leave(csr);
 }
+
+/* handheld/shaders/color/{gba,gbc,nds,palm,psp,vba}-color.glsl (handheld/<name>-color.glslp and the lcd-grid-v2-* chains): one
+ * structure, FS main: pow(texel, gamma_in) * lum, clamp, a constant 3x3 matrix (the shader's `color * adjust` with sat = 1 and
+ * contrast = 1 folds to the plain coefficients), pow(.., 1 / display_gamma), alpha 0.  What differs, from the GL's final
+ * instruction listings: gamma_in = target_gamma + darken_screen (gba), - lighten_screen (gbc), + darken_screen * 1.7 (vba),
+ * a constant elsewhere; a zero coefficient drops its term (vba red); psp's blue row has two equal coefficients and runs
+ * as 0.01 * (R + G) + 0.98 * B. */
+typedef struct { float ga, gs, lum, m[3][3], inv; int factored_blue; } color_spec;
+static void color_body(const o_pass_args* a, const color_spec* s, float user) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  const float gin = s->ga + user * s->gs;
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const o_vec4 t = o_sample(a->in, o_varying_at(&tu, x, y, lo), o_varying_at(&tv, x, y, lo));
+      float c[3] = {o_pow(t.x, gin) * s->lum, o_pow(t.y, gin) * s->lum, o_pow(t.z, gin) * s->lum}, o[3];
+      for (int k = 0; k < 3; ++k) {
+        c[k] = c[k] > 0.0f ? c[k] : 0.0f;      /* fmax(x, 0) then fmin(., 1): MAXPS / MINPS */
+        c[k] = c[k] < 1.0f ? c[k] : 1.0f;
+      }
+      for (int k = 0; k < 3; ++k) {
+        float v;
+        if (k == 2 && s->factored_blue) v = s->m[2][0] * (c[0] + c[1]);
+        else v = s->m[k][0] * c[0] + s->m[k][1] * c[1];
+        if (s->m[k][2] != 0.0f) v = v + s->m[k][2] * c[2];
+        o[k] = o_pow(v, s->inv);
+      }
+      const o_vec4 out = {o[0], o[1], o[2], 0.0f};
+      store_px(a, x, y, out);
+    }
+  o_fp_leave(csr);
+}
+static const color_spec k_gba_color = {2.2f, 1.0f, 0.94f, {{0.82f, 0.24f, -0.06f}, {0.125f, 0.665f, 0.21f}, {0.195f, 0.075f, 0.73f}}, 1.0f / 2.2f, 0};
+static const color_spec k_gbc_color = {2.2f, -1.0f, 0.94f, {{0.82f, 0.24f, -0.06f}, {0.125f, 0.665f, 0.21f}, {0.195f, 0.075f, 0.73f}}, 1.0f / 2.2f, 0};
+static const color_spec k_nds_color = {1.91f, 0.0f, 0.89f, {{0.87f, 0.255f, -0.125f}, {0.10f, 0.645f, 0.255f}, {0.10f, 0.17f, 0.73f}}, 1.0f / 1.91f, 0};
+static const color_spec k_palm_color = {2.2f, 0.0f, 1.0f, {{0.83f, 0.26f, -0.09f}, {0.073f, 0.677f, 0.25f}, {0.085f, 0.12f, 0.795f}}, 1.0f / 2.2f, 0};
+static const color_spec k_psp_color = {2.21f, 0.0f, 1.0f, {{0.98f, 0.20f, -0.18f}, {0.04f, 0.795f, 0.165f}, {0.01f, 0.01f, 0.98f}}, 1.0f / 2.2f, 1};
+static const color_spec k_vba_color = {1.45f, 1.7f, 1.0f, {{0.73f, 0.27f, 0.0f}, {0.085f, 0.675f, 0.24f}, {0.085f, 0.24f, 0.675f}}, 1.0f / 1.45f, 0};
+void o_pass_gba_color(const o_pass_args* a) { color_body(a, &k_gba_color, a->params[0]); }   /* 1 param: darken_screen */
+void o_pass_gbc_color(const o_pass_args* a) { color_body(a, &k_gbc_color, a->params[0]); }   /* 1 param: lighten_screen */
+void o_pass_vba_color(const o_pass_args* a) { color_body(a, &k_vba_color, a->params[0]); }   /* 1 param: darken_screen */
+void o_pass_nds_color(const o_pass_args* a) { color_body(a, &k_nds_color, 0.0f); }
+void o_pass_palm_color(const o_pass_args* a) { color_body(a, &k_palm_color, 0.0f); }
+void o_pass_psp_color(const o_pass_args* a) { color_body(a, &k_psp_color, 0.0f); }
+
+/* handheld/shaders/color/gbc-gambatte-color.glsl FS main: a fixed matrix on the texel as sampled, products taken blue, green, red;
+ * alpha passes through. */
+void o_pass_gbc_gambatte_color(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const o_vec4 t = o_sample(a->in, o_varying_at(&tu, x, y, lo), o_varying_at(&tv, x, y, lo));
+      const float g8 = t.y * 0.125f;
+      const o_vec4 out = {(t.z * 0.0625f + g8) + t.x * 0.8125f, t.z * 0.25f + t.y * 0.75f, (t.z * 0.6875f + g8) + t.x * 0.1875f, t.w};
+      store_px(a, x, y, out);
+    }
+  o_fp_leave(csr);
+}

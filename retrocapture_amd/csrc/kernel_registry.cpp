@@ -51,6 +51,32 @@ void setupResponseTime(const PassGeometry& g, rcd::PassLaunch& L) {
   L.params[6] = rcd::pow_(rt, 6.0f);
   L.params[7] = rcd::pow_(rt, 7.0f);
 }
+// handheld/shaders/color/*-color.glsl: the constants of kernels/pass_basic.hip k_color_matrix (the GL's folded forms, oracle/rc_passes_basic.c)
+struct ColorSpec {
+  float ga, gs, lum, m[9], inv;
+  bool factored_blue;
+};
+void setupColor(const PassGeometry& g, rcd::PassLaunch& L, const ColorSpec& c) {
+  setupTexCoord(g, L);
+  L.params[8] = c.ga + (c.gs != 0.0f ? L.params[0] : 0.0f) * c.gs;   // target_gamma +/- the shader's one parameter (gs = 0: none)
+  L.params[9] = c.lum;
+  for (int k = 0; k < 9; ++k) L.params[10 + k] = c.m[k];
+  L.params[19] = c.inv;
+  L.params[20] = c.factored_blue ? 1.0f : 0.0f;
+}
+#define RC_COLOR_SETUP(fn, ...)                                        \
+  void fn(const PassGeometry& g, rcd::PassLaunch& L) {                  \
+    static const ColorSpec spec = __VA_ARGS__;                          \
+    setupColor(g, L, spec);                                             \
+  }
+RC_COLOR_SETUP(setupGbaColor, {2.2f, 1.0f, 0.94f, {0.82f, 0.24f, -0.06f, 0.125f, 0.665f, 0.21f, 0.195f, 0.075f, 0.73f}, 1.0f / 2.2f, false})
+RC_COLOR_SETUP(setupGbcColor, {2.2f, -1.0f, 0.94f, {0.82f, 0.24f, -0.06f, 0.125f, 0.665f, 0.21f, 0.195f, 0.075f, 0.73f}, 1.0f / 2.2f, false})
+RC_COLOR_SETUP(setupNdsColor, {1.91f, 0.0f, 0.89f, {0.87f, 0.255f, -0.125f, 0.10f, 0.645f, 0.255f, 0.10f, 0.17f, 0.73f}, 1.0f / 1.91f, false})
+RC_COLOR_SETUP(setupPalmColor, {2.2f, 0.0f, 1.0f, {0.83f, 0.26f, -0.09f, 0.073f, 0.677f, 0.25f, 0.085f, 0.12f, 0.795f}, 1.0f / 2.2f, false})
+RC_COLOR_SETUP(setupPspColor, {2.21f, 0.0f, 1.0f, {0.98f, 0.20f, -0.18f, 0.04f, 0.795f, 0.165f, 0.01f, 0.01f, 0.98f}, 1.0f / 2.2f, true})
+RC_COLOR_SETUP(setupVbaColor, {1.45f, 1.7f, 1.0f, {0.73f, 0.27f, 0.0f, 0.085f, 0.675f, 0.24f, 0.085f, 0.24f, 0.675f}, 1.0f / 1.45f, false})
+#undef RC_COLOR_SETUP
+
 // shutter-3d.glsl VS 61-73: left_coord / right_coord at the quad's vertices, in the GL's operation order (oracle/rc_passes_basic.c)
 void setupShutter3d(const PassGeometry& g, rcd::PassLaunch& L) {
   const float* P = L.params;
@@ -393,6 +419,18 @@ std::vector<KernelEntry> build() {
   r.push_back({"motionblur/shaders/mix_frames_smart.glsl", "mix-frames-smart", {{"DEFLICKER_EMPHASIS", 0.0f, 0.0f, 1.0f, 0.01f, "Deflicker Emphasis"}},
                {"PrevTexture", "Prev1Texture", "Prev2Texture", "Prev3Texture", "Prev4Texture"},
                rck::launch_mix_frames_smart, setupCrtPi, false, true, nullptr, nullptr, true});   // VS: TEX0 = TexCoord * 1.0001
+  // handheld/<name>-color.glslp (kernels/pass_basic.hip k_color_matrix); none of them reads a size uniform
+  r.push_back({"handheld/shaders/color/gba-color.glsl", "gba-color", {{"darken_screen", 1.0f, -0.25f, 1.0f, 0.05f, "Darken Screen"}}, {},
+               rck::launch_color_matrix, setupGbaColor, false, true, nullptr, nullptr, true});
+  r.push_back({"handheld/shaders/color/gbc-color.glsl", "gbc-color", {{"lighten_screen", 1.0f, 0.0f, 1.0f, 0.05f, "Lighten Screen"}}, {},
+               rck::launch_color_matrix, setupGbcColor, false, true, nullptr, nullptr, true});
+  r.push_back({"handheld/shaders/color/vba-color.glsl", "vba-color", {{"darken_screen", 1.0f, -1.0f, 1.0f, 0.05f, "Darken Intensity"}}, {},
+               rck::launch_color_matrix, setupVbaColor, false, true, nullptr, nullptr, true});
+  r.push_back({"handheld/shaders/color/nds-color.glsl", "nds-color", {}, {}, rck::launch_color_matrix, setupNdsColor, false, true, nullptr, nullptr, true});
+  r.push_back({"handheld/shaders/color/palm-color.glsl", "palm-color", {}, {}, rck::launch_color_matrix, setupPalmColor, false, true, nullptr, nullptr, true});
+  r.push_back({"handheld/shaders/color/psp-color.glsl", "psp-color", {}, {}, rck::launch_color_matrix, setupPspColor, false, true, nullptr, nullptr, true});
+  r.push_back({"handheld/shaders/color/gbc-gambatte-color.glsl", "gbc-gambatte-color", {}, {}, rck::launch_gbc_gambatte_color, setupTexCoord, false, true,
+               nullptr, nullptr, true});
   // two more frame-history shaders (kernels/pass_basic.hip): stereoscopic-3d/shutter-to-side-by-side.glslp and misc/anti-flicker.glsl
   r.push_back({"stereoscopic-3d/shaders/shutter-3d.glsl", "shutter-3d",
                {{"ZOOM", 1.0f, 0.0f, 2.0f, 0.01f, "Zoom"}, {"vert_pos", 0.0f, -2.0f, 2.0f, 0.01f, "Vertical Modifier"},

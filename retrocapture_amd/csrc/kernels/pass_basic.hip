@@ -98,6 +98,44 @@ __global__ void __launch_bounds__(256) k_mix_frames(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// handheld/shaders/color/{gba,gbc,nds,palm,psp,vba}-color.glsl FS main (handheld/<name>-color.glslp and the lcd-grid-v2-* chains):
+// pow(texel, gamma_in) * lum, clamp, a constant 3x3 matrix, pow(.., 1 / display_gamma), alpha 0.  The constants and the three
+// places where the GL's compiled form differs between the six files come from the registry (kernel_registry.cpp, setupColor*):
+// params[8] gamma_in, [9] lum, [10..18] the matrix by output channel, [19] 1 / display_gamma, [20] != 0: psp's blue row,
+// 0.01 * (R + G) + 0.98 * B.  A zero coefficient of the third column drops its term (vba red), as in the GL.
+__global__ void __launch_bounds__(256) k_color_matrix(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const float* P = L.params;
+  const float gin = P[8], lum = P[9], inv = P[19];
+  const bool factored_blue = P[20] != 0.0f;
+  RC_TILE_LOOP_BEGIN
+  const float4 t = sample_rt(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
+  float c[3] = {pow_(t.x, gin) * lum, pow_(t.y, gin) * lum, pow_(t.z, gin) * lum}, o[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    c[k] = c[k] > 0.0f ? c[k] : 0.0f;   // fmax(x, 0) then fmin(., 1) as MAXPS / MINPS
+    c[k] = c[k] < 1.0f ? c[k] : 1.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v = (k == 2 && factored_blue) ? P[16] * (c[0] + c[1]) : P[10 + 3 * k] * c[0] + P[11 + 3 * k] * c[1];
+    if (P[12 + 3 * k] != 0.0f) v = v + P[12 + 3 * k] * c[2];
+    o[k] = v != v ? 0.0f : pow_(v, inv);   // llvmpipe's pow of a NaN base is 0
+  }
+  store_rt(L, z, x, y, make_float4(o[0], o[1], o[2], 0.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
+// handheld/shaders/color/gbc-gambatte-color.glsl FS main: a fixed matrix on the texel as sampled (products blue, green, red), alpha kept
+__global__ void __launch_bounds__(256) k_gbc_gambatte_color(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  const float4 t = sample_rt(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
+  const float g8 = t.y * 0.125f;
+  store_rt(L, z, x, y, make_float4((t.z * 0.0625f + g8) + t.x * 0.8125f, t.z * 0.25f + t.y * 0.75f, (t.z * 0.6875f + g8) + t.x * 0.1875f, t.w), &lds);
+  RC_TILE_LOOP_END
+}
+
 // stereoscopic-3d/shaders/shutter-3d.glsl FS 123-143 (stereoscopic-3d/shutter-to-side-by-side.glslp): the left eye's frame
 // and the right eye's side by side, alternating with FrameCount parity, the other eye held from PrevTexture x flicker.
 // params: ZOOM, vert_pos, horz_pos, separation, flicker, height_mod, swap_eye; extra[0] = PrevTexture;
@@ -578,6 +616,8 @@ RC_SIMPLE_LAUNCH(launch_motionblur_simple, k_motionblur_simple)
 RC_SIMPLE_LAUNCH(launch_braid_rewind, k_braid_rewind)
 RC_SIMPLE_LAUNCH(launch_response_time, k_response_time)
 RC_SIMPLE_LAUNCH(launch_mix_frames_smart, k_mix_frames_smart)
+RC_SIMPLE_LAUNCH(launch_color_matrix, k_color_matrix)
+RC_SIMPLE_LAUNCH(launch_gbc_gambatte_color, k_gbc_gambatte_color)
 RC_SIMPLE_LAUNCH(launch_shutter_3d, k_shutter_3d)
 RC_SIMPLE_LAUNCH(launch_anti_flicker, k_anti_flicker)
 #undef RC_SIMPLE_LAUNCH

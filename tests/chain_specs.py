@@ -50,6 +50,14 @@ scale_y1 = 1.0
     # same keys / values as the reference's other motionblur/ presets
     "motionblur-simple": ("motionblur/motionblur-simple.glslp", 'shaders = 1\n\nshader0 = shaders/motionblur-simple.glsl\nfilter_linear0 = false\n'),
     "braid-rewind": ("motionblur/braid-rewind.glslp", 'shaders = 1\n\nshader0 = shaders/braid-rewind.glsl\nfilter_linear0 = false\n'),
+    # handheld/<name>-color.glslp: same keys / values as the reference's files
+    "gba-color": ("handheld/gba-color.glslp", 'shaders = 1\n\nshader0 = shaders/color/gba-color.glsl\n\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n'),
+    "gbc-color": ("handheld/gbc-color.glslp", 'shaders = 1\n\nshader0 = shaders/color/gbc-color.glsl\n\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n'),
+    "gbc-gambatte-color": ("handheld/gbc-gambatte-color.glslp", 'shaders = 1\n\nshader0 = shaders/color/gbc-gambatte-color.glsl\n\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n'),
+    "nds-color": ("handheld/nds-color.glslp", 'shaders = 1\n\nshader0 = shaders/color/nds-color.glsl\n\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n'),
+    "palm-color": ("handheld/palm-color.glslp", 'shaders = 1\n\nshader0 = shaders/color/palm-color.glsl\n\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n'),
+    "psp-color": ("handheld/psp-color.glslp", 'shaders = 1\n\nshader0 = shaders/color/psp-color.glsl\n\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n'),
+    "vba-color": ("handheld/vba-color.glslp", 'shaders = 1\n\nshader0 = shaders/color/vba-color.glsl\n\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n'),
     # Same keys / values as the reference's stereoscopic-3d/shutter-to-side-by-side.glslp
     "shutter-3d": ("stereoscopic-3d/shutter-to-side-by-side.glslp", 'shaders = 1\n\nshader0 = shaders/shutter-3d.glsl\nwrap_mode0 = edge\n'),
     # misc/anti-flicker.glsl has no preset in the reference's tree: a one-pass chain of this repository
@@ -367,6 +375,13 @@ SHADERS = {
     "motionblur/shaders/response-time.glsl": {"oracle": "response_time", "params": [("response_time", 0.333)], "size_independent": True,
                                               "samplers": ["PrevTexture", "Prev1Texture", "Prev2Texture", "Prev3Texture", "Prev4Texture",
                                                            "Prev5Texture", "Prev6Texture"]},
+    "handheld/shaders/color/gba-color.glsl": {"oracle": "gba_color", "params": [('darken_screen', 1.0)], "samplers": [], "size_independent": True},
+    "handheld/shaders/color/gbc-color.glsl": {"oracle": "gbc_color", "params": [('lighten_screen', 1.0)], "samplers": [], "size_independent": True},
+    "handheld/shaders/color/gbc-gambatte-color.glsl": {"oracle": "gbc_gambatte_color", "params": [], "samplers": [], "size_independent": True},
+    "handheld/shaders/color/nds-color.glsl": {"oracle": "nds_color", "params": [], "samplers": [], "size_independent": True},
+    "handheld/shaders/color/palm-color.glsl": {"oracle": "palm_color", "params": [], "samplers": [], "size_independent": True},
+    "handheld/shaders/color/psp-color.glsl": {"oracle": "psp_color", "params": [], "samplers": [], "size_independent": True},
+    "handheld/shaders/color/vba-color.glsl": {"oracle": "vba_color", "params": [('darken_screen', 1.0)], "samplers": [], "size_independent": True},
     "stereoscopic-3d/shaders/shutter-3d.glsl": {"oracle": "shutter_3d", "size_independent": True, "samplers": ["PrevTexture"],
                                                 "params": [("ZOOM", 1.0), ("vert_pos", 0.0), ("horz_pos", 0.0), ("separation", 0.0), ("flicker", 0.0),
                                                            ("height_mod", 1.0), ("swap_eye", 0.0)]},

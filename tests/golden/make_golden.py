@@ -495,6 +495,18 @@ def case_hyllian_glow():
              params=[("HFILTER_SHARPNESS", 0.7), ("CRT_ANTI_RINGING", 0.6), ("MASK_INTENSITY", 0.7), ("PHOSPHOR_LAYOUT", 5.0)])
 
 
+def case_handheld_color():
+    """handheld/{gba,gbc,gbc-gambatte,nds,palm,psp,vba}-color.glslp: 8-bit at two sizes and one float run each."""
+    for k, n in enumerate(("gba", "gbc", "gbc-gambatte", "nds", "palm", "psp", "vba")):
+        P = GLSL + "/handheld/%s-color.glslp" % n
+        t = n.replace("-", "_")
+        run_case("%s_color_64x48_to_160x120" % t, P, mixed(64, 48, 60 + k), 160, 120)
+        run_case("f32_%s_color_48x36_to_131x77" % t, P, mixed(48, 36, 70 + k), 131, 77, f32=True)
+    run_case("gba_color_params_40x30_to_97x61", GLSL + "/handheld/gba-color.glslp", noise(40, 30, 80), 97, 61, params=[("darken_screen", 0.35)])
+    run_case("gbc_color_params_40x30_to_97x61", GLSL + "/handheld/gbc-color.glslp", noise(40, 30, 81), 97, 61, params=[("lighten_screen", 0.25)])
+    run_case("vba_color_params_40x30_to_97x61", GLSL + "/handheld/vba-color.glslp", noise(40, 30, 82), 97, 61, params=[("darken_screen", -0.4)])
+
+
 def case_history_more():
     """Two more frame-history shaders: stereoscopic-3d/shutter-to-side-by-side.glslp (PrevTexture; FrameCount parity selects
     the eye) and misc/anti-flicker.glsl (PrevTexture, Prev1Texture; no preset in the reference's tree: one-pass chain)."""
@@ -675,7 +687,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -12,6 +12,17 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    # handheld/<name>-color.glslp
+    "gba_color_64x48_to_160x120": "gba-color",
+    "gbc_color_64x48_to_160x120": "gbc-color",
+    "gbc_gambatte_color_64x48_to_160x120": "gbc-gambatte-color",
+    "nds_color_64x48_to_160x120": "nds-color",
+    "palm_color_64x48_to_160x120": "palm-color",
+    "psp_color_64x48_to_160x120": "psp-color",
+    "vba_color_64x48_to_160x120": "vba-color",
+    "gba_color_params_40x30_to_97x61": "gba-color",
+    "gbc_color_params_40x30_to_97x61": "gbc-color",
+    "vba_color_params_40x30_to_97x61": "vba-color",
     "scanline_320x240": "scanline",
     "scanline_64x48_to_160x100": "scanline",
     "crt_pi_96x64_to_192x128": "crt-pi",

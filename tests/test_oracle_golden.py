@@ -46,6 +46,17 @@ CASES = {
     "motionblur_simple_48x36_to_120x90_f9": "motionblur-simple",   # Prev .. Prev6; 9 frames: the full ring recycles (and clears) its oldest texture
     "motionblur_simple_40x30_to_40x30_f3": "motionblur-simple",
     "braid_rewind_48x36_to_120x90_f8": "braid-rewind",
+    # handheld/<name>-color.glslp
+    "gba_color_64x48_to_160x120": "gba-color",
+    "gbc_color_64x48_to_160x120": "gbc-color",
+    "gbc_gambatte_color_64x48_to_160x120": "gbc-gambatte-color",
+    "nds_color_64x48_to_160x120": "nds-color",
+    "palm_color_64x48_to_160x120": "palm-color",
+    "psp_color_64x48_to_160x120": "psp-color",
+    "vba_color_64x48_to_160x120": "vba-color",
+    "gba_color_params_40x30_to_97x61": "gba-color",
+    "gbc_color_params_40x30_to_97x61": "gbc-color",
+    "vba_color_params_40x30_to_97x61": "vba-color",
     "shutter_3d_48x36_to_120x90_f4": "shutter-3d",               # FrameCount parity selects the eye; PrevTexture held x flicker
     "shutter_3d_params_48x36_to_131x77_f5": "shutter-3d",        # all seven parameters changed
     "anti_flicker_48x36_to_120x90_f6": "anti-flicker",
@@ -232,6 +243,13 @@ FLOAT_CASES = {
     "f32_ntsc_svideo_96x64_to_256x192": ("ntsc-256px-svideo", {}),
     "f32_ntsc_320px_72x40_to_320x120": ("ntsc-320px", {}),
     "f32_xbr_lv3_48x40_to_331x217": ("xbr-lv3", {}),
+    "f32_gba_color_48x36_to_131x77": ("gba-color", {}),
+    "f32_gbc_color_48x36_to_131x77": ("gbc-color", {}),
+    "f32_gbc_gambatte_color_48x36_to_131x77": ("gbc-gambatte-color", {}),
+    "f32_nds_color_48x36_to_131x77": ("nds-color", {}),
+    "f32_palm_color_48x36_to_131x77": ("palm-color", {}),
+    "f32_psp_color_48x36_to_131x77": ("psp-color", {}),
+    "f32_vba_color_48x36_to_131x77": ("vba-color", {}),
     "f32_crt_royale_64x48_to_128x96": ("crt-royale", {}),
     "f32_crt_royale_maskon_64x48_to_128x96": ("crt-royale", {}),
     "f32_crt_royale_geom_sphere_64x48_to_128x96": ("crt-royale", {}),
