@@ -1,0 +1,34 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE / build-time tool (this container only: needs /root/reference and oracle/_ref/glchain).
+# Regenerates the instruction lists (oracle/glrun/nir2c.py) from the NIR Mesa llvmpipe compiles for a shader of the reference:
+#   crt-royale's last pass (geometry-aa-last-pass.glsl, both stages)  -> royale_last_{vs,fs}.inc
+#   handheld/shaders/lcd-cgwg/lcd-grid-v2.glsl (fragment stage)        -> lcd_grid_v2_fs.inc
+# written to oracle/gen/ for the oracle and, the same text, to retrocapture_amd/csrc/kernels/gen/ for the HIP kernels.
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+REF="${REF:-/root/reference}"
+GLSL="$REF/shaders/shaders_glsl"
+T="$(mktemp -d)"
+trap 'rm -rf "$T"' EXIT
+python3 - "$T" <<'PY'
+import sys, numpy as np
+np.random.default_rng(1).integers(0, 256, (24, 32, 3), dtype=np.uint8).tofile(sys.argv[1] + "/in.rgb")
+PY
+listing() {  # $1 = shader below shaders_glsl, $2 = env assignment, $3 = output listing
+  # a one-pass preset of just that shader: the compiled code does not depend on the rest of the chain
+  printf 'shaders = 1\nshader0 = %s/%s\nfilter_linear0 = true\n' "$GLSL" "$1" > "$T/one.glslp"
+  ( cd "$REF" && env "$2" MESA_SHADER_CACHE_DISABLE=true RETROCAPTURE_LOG_LEVEL=error "$ROOT/oracle/_ref/glchain" --preset "$T/one.glslp" --input "$T/in.rgb" \
+      --w 32 --h 24 --vw 64 --vh 48 --frames 1 --out "$T" ) > /dev/null 2> "$3"
+}
+emit() {  # $1 = listing, $2 = stage, $3 = name
+  for d in "$ROOT/oracle/gen" "$ROOT/retrocapture_amd/csrc/kernels/gen"; do
+    mkdir -p "$d"
+    python3 "$HERE/nir2c.py" "$1" --stage "$2" --name "$3" > "$d/$3.inc"
+  done
+}
+R=crt/shaders/crt-royale/src/crt-royale-geometry-aa-last-pass.glsl
+listing "$R" LP_DEBUG=fs "$T/fs.txt" && emit "$T/fs.txt" fragment royale_last_fs
+listing "$R" GALLIVM_DEBUG=tgsi "$T/vs.txt" && emit "$T/vs.txt" vertex royale_last_vs
+listing handheld/shaders/lcd-cgwg/lcd-grid-v2.glsl LP_DEBUG=fs "$T/lcd.txt" && emit "$T/lcd.txt" fragment lcd_grid_v2_fs
+wc -l "$ROOT"/oracle/gen/*.inc

@@ -13,7 +13,7 @@ Generated signature:
     static void fn(const float* U, const float* IN, float* OUT, void* TEXCTX)
 U = the default uniform block in dwords (offsets listed in fn_uniforms[]), IN = the shader inputs in declaration order
 (fn_inputs[]; vec4 attributes take four consecutive floats), OUT = the outputs in declaration order (fn_outputs[]),
-RCN_TEX(TEXCTX, unit, u, v, dst4) fetches a texel.  RCN_NO_TABLES / RCN_TABLES_ONLY leave out the tables / the function.  Only what the restated shaders use is handled; anything else raises.
+RCN_TEX(TEXCTX, unit, u, v, dst4) samples, RCN_TXF(TEXCTX, unit, x, y, dst4) fetches texel (x, y) of level 0.  RCN_NO_TABLES / RCN_TABLES_ONLY leave out the tables / the function.  Only what the restated shaders use is handled; anything else raises.
 """
 import argparse
 import re
@@ -225,6 +225,16 @@ def translate(text, stage, name):
             g.decl_v["PHI" + n] = 0
             g.set(n, "PHI" + n)
             continue
+        if op.startswith("(float32)txf"):
+            # texelFetchOffset: integer coordinates (a vec2 built from f2i32 values, kept as floats: exact below 2^24) + constant offset
+            m2 = re.match(r"\(float32\)txf (%\d+) \(coord\), %\d+ \((0x[0-9a-f]+), (0x[0-9a-f]+)\) \(offset\), %\d+ \(0x0\) \(lod\), (\d+) \(texture\)", rhs)
+            if not m2:
+                raise ValueError("txf form: " + s)
+            c = m2.group(1)[1:]
+            g.types[n] = ("v", 4)
+            g.decl_v["v" + n] = 4
+            g.emit("RCN_TXF(TEXCTX, %s, (int)v%s[0] + %d, (int)v%s[1] + %d, v%s);" % (m2.group(4), c, int(m2.group(2), 16), c, int(m2.group(3), 16), n))
+            continue
         if op.startswith("(float32)tex"):
             coord = re.match(r"\(float32\)tex (%\d+) \(coord\), (\d+) \(texture\)", rhs)
             c = coord.group(1)[1:]
@@ -237,7 +247,7 @@ def translate(text, stage, name):
             g.types[n] = ("v", len(args))
             g.decl_v["v" + n] = len(args)
             for k, a in enumerate(args):
-                g.emit("v%s[%d] = %s;" % (n, k, g.val(a)))
+                g.emit("v%s[%d] = %s%s;" % (n, k, "(float)" if g.types.get(a.split(".")[0][1:]) == "i" else "", g.val(a)))
             continue
         if op in ALU1:
             g.set(n, ALU1[op].format(g.val(args[0])))
@@ -251,6 +261,8 @@ def translate(text, stage, name):
             g.set(n, BOOL2[op].format(g.val(args[0]), g.val(args[1])), "i")
         elif op == "inot":
             g.set(n, "(!%s)" % g.val(args[0]), "i")
+        elif op == "f2i32":
+            g.set(n, "RCN_F2I(%s)" % g.val(args[0]), "i")
         elif op == "b2f32":
             g.set(n, "(%s ? 1.0f : 0.0f)" % g.val(args[0]))
         elif op == "b32csel":

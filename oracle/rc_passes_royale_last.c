@@ -7,7 +7,7 @@
  * That is ~2400 scalar operations whose association the GL's compiler rearranges freely (constant folding of the
  * sample grid, factored weight sums, CSE across the branches), so instead of a hand restatement the body is the GL's own
  * final instruction list: oracle/glrun/nir2c.py turns the NIR llvmpipe compiles for this shader (LP_DEBUG=fs,
- * GALLIVM_DEBUG=tgsi; recipe oracle/glrun/gen_royale_last.sh) into straight C, one statement per instruction, and the
+ * GALLIVM_DEBUG=tgsi; recipe oracle/glrun/gen_lists.sh) into straight C, one statement per instruction, and the
  * float built-ins map to the llvmpipe-exact primitives of rc_math.c.  The vertex stage runs at the quad's four vertices
  * and every varying goes through the rasteriser's plane setup (rc_varying.c), as everywhere else.
  * Pinned by tests/golden/crt_royale_geom_*.npz and f32_crt_royale_geom_*.npz (llvmpipe outputs, 8-bit and float).

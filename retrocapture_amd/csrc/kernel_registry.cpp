@@ -419,6 +419,17 @@ std::vector<KernelEntry> build() {
   r.push_back({"motionblur/shaders/mix_frames_smart.glsl", "mix-frames-smart", {{"DEFLICKER_EMPHASIS", 0.0f, 0.0f, 1.0f, 0.01f, "Deflicker Emphasis"}},
                {"PrevTexture", "Prev1Texture", "Prev2Texture", "Prev3Texture", "Prev4Texture"},
                rck::launch_mix_frames_smart, setupCrtPi, false, true, nullptr, nullptr, true});   // VS: TEX0 = TexCoord * 1.0001
+  // handheld/lcd-grid-v2.glslp and the lcd-grid-v2-<colour>[-motionblur] chains (kernels/pass_lcd_grid.hip)
+  r.push_back({"handheld/shaders/lcd-cgwg/lcd-grid-v2.glsl", "lcd-grid-v2",
+               {{"RSUBPIX_R", 1.0f, 0.0f, 1.0f, 0.01f, "Colour of R subpixel: R"}, {"RSUBPIX_G", 0.0f, 0.0f, 1.0f, 0.01f, "Colour of R subpixel: G"},
+                {"RSUBPIX_B", 0.0f, 0.0f, 1.0f, 0.01f, "Colour of R subpixel: B"}, {"GSUBPIX_R", 0.0f, 0.0f, 1.0f, 0.01f, "Colour of G subpixel: R"},
+                {"GSUBPIX_G", 1.0f, 0.0f, 1.0f, 0.01f, "Colour of G subpixel: G"}, {"GSUBPIX_B", 0.0f, 0.0f, 1.0f, 0.01f, "Colour of G subpixel: B"},
+                {"BSUBPIX_R", 0.0f, 0.0f, 1.0f, 0.01f, "Colour of B subpixel: R"}, {"BSUBPIX_G", 0.0f, 0.0f, 1.0f, 0.01f, "Colour of B subpixel: G"},
+                {"BSUBPIX_B", 1.0f, 0.0f, 1.0f, 0.01f, "Colour of B subpixel: B"}, {"gain", 1.0f, 0.5f, 2.0f, 0.05f, "Gain"},
+                {"gamma", 3.0f, 0.5f, 5.0f, 0.1f, "LCD Input Gamma"}, {"outgamma", 2.2f, 0.5f, 5.0f, 0.1f, "LCD Output Gamma"},
+                {"blacklevel", 0.05f, 0.0f, 0.5f, 0.01f, "Black level"}, {"ambient", 0.0f, 0.0f, 0.5f, 0.01f, "Ambient"},
+                {"BGR", 0.0f, 0.0f, 1.0f, 1.0f, "BGR"}},
+               {}, rck::launch_lcd_grid_v2, setupTexCoord, false});
   // handheld/<name>-color.glslp (kernels/pass_basic.hip k_color_matrix); none of them reads a size uniform
   r.push_back({"handheld/shaders/color/gba-color.glsl", "gba-color", {{"darken_screen", 1.0f, -0.25f, 1.0f, 0.05f, "Darken Screen"}}, {},
                rck::launch_color_matrix, setupGbaColor, false, true, nullptr, nullptr, true});

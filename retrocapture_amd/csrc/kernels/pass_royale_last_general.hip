@@ -8,7 +8,7 @@
 // ~1200 scalar operations freely (the sample grid is folded to constants, weight sums are factored, sub-expressions are
 // shared across the geometry branches), so the per-pixel body is the GL's own final instruction order:
 // gen/royale_last_fs.inc is produced by oracle/glrun/nir2c.py from the NIR listing of Mesa llvmpipe (recipe:
-// oracle/glrun/gen_royale_last.sh) - one statement per instruction - and the float built-ins map to rc_device.h's
+// oracle/glrun/gen_lists.sh) - one statement per instruction - and the float built-ins map to rc_device.h's
 // llvmpipe-exact primitives.  Around it, as for every pass: the vertex stage is evaluated once per launch on the host
 // (royale_setup.cpp, setupLast), the two varyings that change across the quad are plane equations, one thread per pixel.
 //

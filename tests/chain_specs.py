@@ -320,6 +320,35 @@ def _royale_ntsc(pass1, pass2, width):
 
 
 import re
+# handheld/lcd-grid-v2.glslp and the lcd-grid-v2-<colour>[-motionblur] chains: same passes, keys and parameter values as the
+# reference's files (BGR is 1 in all but the plain, the -motionblur and the gbc ones)
+def _lcd_grid_v2(colour, motionblur):
+    passes = []
+    if motionblur:
+        passes.append(("../motionblur/shaders/response-time.glsl", "source"))
+    passes.append(("shaders/lcd-cgwg/lcd-grid-v2.glsl", "viewport"))
+    if colour:
+        passes.append(("shaders/color/%s-color.glsl" % colour, "source"))
+    t = 'shaders = "%d"\n\n' % len(passes)
+    for i, (sh, st) in enumerate(passes):
+        t += 'shader%d = "%s"\nfilter_linear%d = "false"\nscale_type%d = "%s"\nscale%d = "1.0"\n\n' % (i, sh, i, i, st, i)
+    names = ["RSUBPIX_R", "RSUBPIX_G", "RSUBPIX_B", "GSUBPIX_R", "GSUBPIX_G", "GSUBPIX_B", "BSUBPIX_R", "BSUBPIX_G", "BSUBPIX_B", "gain", "gamma",
+             "blacklevel", "ambient", "BGR"]
+    vals = [0.75, 0, 0, 0, 0.75, 0, 0, 0, 0.75, 1.5, 2.2, 0, 0, 1.0 if colour not in (None, "gbc") else 0.0]
+    t += 'parameters = "%s"\n' % ";".join(names)
+    for n, v in zip(names, vals):
+        t += '%s = "%f"\n' % (n, v)
+    return t
+
+
+PRESETS["lcd-grid-v2"] = ("handheld/lcd-grid-v2.glslp", _lcd_grid_v2(None, False))
+# the shader alone, without the preset files' parameter block (a one-pass chain of this repository): the #pragma defaults apply
+PRESETS["lcd-grid-v2-bare"] = ("handheld/lcd-grid-v2-bare.glslp", 'shaders = 1\nshader0 = shaders/lcd-cgwg/lcd-grid-v2.glsl\nfilter_linear0 = false\nscale_type0 = viewport\n')
+PRESETS["lcd-grid-v2-motionblur"] = ("handheld/lcd-grid-v2-motionblur.glslp", _lcd_grid_v2(None, True))
+for _c in ("gba", "gbc", "nds", "palm", "psp", "vba"):
+    PRESETS["lcd-grid-v2-%s-color" % _c] = ("handheld/lcd-grid-v2-%s-color.glslp" % _c, _lcd_grid_v2(_c, False))
+    PRESETS["lcd-grid-v2-%s-color-motionblur" % _c] = ("handheld/lcd-grid-v2-%s-color-motionblur.glslp" % _c, _lcd_grid_v2(_c, True))
+
 # crt-royale with an RGBA32F last target: the last pass's floats as computed, for the curved-geometry / tex2Daa form
 PRESETS["crt-royale-f32-last"] = ("crt/crt-royale-f32-last.glslp", PRESETS["crt-royale"][1] + 'float_framebuffer11 = "true"\n')
 PRESETS["crt-royale-ntsc-256px-svideo"] = ("crt/crt-royale-ntsc-256px-svideo.glslp", _royale_ntsc("svideo-3phase", "3phase", 1536))
@@ -382,6 +411,10 @@ SHADERS = {
     "handheld/shaders/color/palm-color.glsl": {"oracle": "palm_color", "params": [], "samplers": [], "size_independent": True},
     "handheld/shaders/color/psp-color.glsl": {"oracle": "psp_color", "params": [], "samplers": [], "size_independent": True},
     "handheld/shaders/color/vba-color.glsl": {"oracle": "vba_color", "params": [('darken_screen', 1.0)], "samplers": [], "size_independent": True},
+    "handheld/shaders/lcd-cgwg/lcd-grid-v2.glsl": {"oracle": "lcd_grid_v2", "samplers": [],
+                                                   "params": [("RSUBPIX_R", 1.0), ("RSUBPIX_G", 0.0), ("RSUBPIX_B", 0.0), ("GSUBPIX_R", 0.0), ("GSUBPIX_G", 1.0),
+                                                              ("GSUBPIX_B", 0.0), ("BSUBPIX_R", 0.0), ("BSUBPIX_G", 0.0), ("BSUBPIX_B", 1.0), ("gain", 1.0),
+                                                              ("gamma", 3.0), ("outgamma", 2.2), ("blacklevel", 0.05), ("ambient", 0.0), ("BGR", 0.0)]},
     "stereoscopic-3d/shaders/shutter-3d.glsl": {"oracle": "shutter_3d", "size_independent": True, "samplers": ["PrevTexture"],
                                                 "params": [("ZOOM", 1.0), ("vert_pos", 0.0), ("horz_pos", 0.0), ("separation", 0.0), ("flicker", 0.0),
                                                            ("height_mod", 1.0), ("swap_eye", 0.0)]},

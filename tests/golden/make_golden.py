@@ -495,6 +495,32 @@ def case_hyllian_glow():
              params=[("HFILTER_SHARPNESS", 0.7), ("CRT_ANTI_RINGING", 0.6), ("MASK_INTENSITY", 0.7), ("PHOSPHOR_LAYOUT", 5.0)])
 
 
+def case_lcd_grid_v2():
+    """handheld/lcd-grid-v2.glslp and its chains: with a colour pass behind it, and with motionblur/response-time in front (frame
+    history through a pass 0 that is not the last pass)."""
+    H = GLSL + "/handheld/"
+    run_case("lcd_grid_v2_64x48_to_320x240", H + "lcd-grid-v2.glslp", mixed(64, 48, 90), 320, 240)
+    run_case("lcd_grid_v2_40x30_to_233x171", H + "lcd-grid-v2.glslp", noise(40, 30, 91), 233, 171)
+    run_case("lcd_grid_v2_params_48x36_to_240x180", H + "lcd-grid-v2.glslp", mixed(48, 36, 92), 240, 180,
+             params=[("BGR", 1.0), ("gain", 1.2), ("gamma", 2.6), ("outgamma", 1.9), ("blacklevel", 0.07), ("ambient", 0.03), ("RSUBPIX_G", 0.15),
+                     ("GSUBPIX_B", 0.1), ("BSUBPIX_R", 0.05)])
+    run_case("f32_lcd_grid_v2_48x36_to_240x180", H + "lcd-grid-v2.glslp", mixed(48, 36, 93), 240, 180, f32=True)
+    run_case("f32_lcd_grid_v2_params_40x30_to_233x171", H + "lcd-grid-v2.glslp", noise(40, 30, 94), 233, 171, f32=True,
+             params=[("BGR", 1.0), ("gain", 0.8), ("gamma", 3.4), ("outgamma", 2.4), ("blacklevel", 0.02), ("ambient", 0.1)])
+    with tempfile.TemporaryDirectory() as d:
+        # without the preset files' own parameter block (which overrides custom values at draw time): every parameter moves
+        p = write_preset(d, 'shaders = 1\nshader0 = %s/handheld/shaders/lcd-cgwg/lcd-grid-v2.glsl\nfilter_linear0 = false\nscale_type0 = viewport\n' % GLSL)
+        prm = [("BGR", 1.0), ("gain", 1.2), ("gamma", 2.6), ("outgamma", 1.9), ("blacklevel", 0.07), ("ambient", 0.03), ("RSUBPIX_R", 0.9),
+               ("RSUBPIX_G", 0.15), ("GSUBPIX_G", 0.8), ("GSUBPIX_B", 0.1), ("BSUBPIX_R", 0.05), ("BSUBPIX_B", 0.85)]
+        run_case("lcd_grid_v2_bare_params_48x36_to_240x180", p, mixed(48, 36, 99), 240, 180, params=prm)
+        run_case("lcd_grid_v2_bare_defaults_40x30_to_97x61", p, noise(40, 30, 100), 97, 61)
+        run_case("f32_lcd_grid_v2_bare_params_40x30_to_233x171", p, noise(40, 30, 101), 233, 171, f32=True, params=prm)
+    run_case("lcd_grid_v2_gba_color_48x36_to_240x180", H + "lcd-grid-v2-gba-color.glslp", mixed(48, 36, 95), 240, 180)
+    run_case("lcd_grid_v2_gbc_color_48x36_to_200x150", H + "lcd-grid-v2-gbc-color.glslp", mixed(48, 36, 96), 200, 150)
+    run_case("lcd_grid_v2_psp_color_motionblur_48x36_to_200x150_f5", H + "lcd-grid-v2-psp-color-motionblur.glslp", moving(48, 36, 5, 97), 200, 150)
+    run_case("lcd_grid_v2_motionblur_48x36_to_200x150_f9", H + "lcd-grid-v2-motionblur.glslp", moving(48, 36, 9, 98), 200, 150)
+
+
 def case_handheld_color():
     """handheld/{gba,gbc,gbc-gambatte,nds,palm,psp,vba}-color.glslp: 8-bit at two sizes and one float run each."""
     for k, n in enumerate(("gba", "gbc", "gbc-gambatte", "nds", "palm", "psp", "vba")):
@@ -687,7 +713,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

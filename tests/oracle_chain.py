@@ -83,6 +83,8 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
     f16_targets: float targets are stored as binary16 (the engine's opt-in setFloatTargetFp16): each float pass
     output is rounded to nearest-even binary16 and the passes after it read the widened values.
     Returns the list of per-pass outputs (float targets as float32 holding the rounded values when f16_targets)."""
+    if global_params is None:
+        global_params = getattr(passes, "globals", None)
     h, w, _ = rgb.shape
     src = np.concatenate([rgb, np.full((h, w, 1), 255, np.uint8)], -1)
     sizes = pass_sizes(passes, w, h, vw, vh)

@@ -12,6 +12,14 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    # handheld/lcd-grid-v2.glslp and its chains (kernels/pass_lcd_grid.hip); "bare" = without the preset files' parameter block
+    "lcd_grid_v2_64x48_to_320x240": "lcd-grid-v2",
+    "lcd_grid_v2_40x30_to_233x171": "lcd-grid-v2",
+    "lcd_grid_v2_params_48x36_to_240x180": "lcd-grid-v2",
+    "lcd_grid_v2_bare_params_48x36_to_240x180": "lcd-grid-v2-bare",
+    "lcd_grid_v2_bare_defaults_40x30_to_97x61": "lcd-grid-v2-bare",
+    "lcd_grid_v2_gba_color_48x36_to_240x180": "lcd-grid-v2-gba-color",
+    "lcd_grid_v2_gbc_color_48x36_to_200x150": "lcd-grid-v2-gbc-color",
     # handheld/<name>-color.glslp
     "gba_color_64x48_to_160x120": "gba-color",
     "gbc_color_64x48_to_160x120": "gbc-color",
@@ -395,7 +403,10 @@ HISTORY_CASES = {"mix_frames_72x40_to_72x40_f3": "mix-frames", "mix_frames_48x36
                  "response_time_params_40x30_to_100x75_f4": "response-time", "mix_frames_smart_48x36_to_120x90_f8": "mix-frames-smart",
                  "mix_frames_smart_params_40x30_to_40x30_f7": "mix-frames-smart",
                  "shutter_3d_48x36_to_120x90_f4": "shutter-3d", "shutter_3d_params_48x36_to_131x77_f5": "shutter-3d",
-                 "anti_flicker_48x36_to_120x90_f6": "anti-flicker", "anti_flicker_params_40x30_to_40x30_f5": "anti-flicker"}
+                 "anti_flicker_48x36_to_120x90_f6": "anti-flicker", "anti_flicker_params_40x30_to_40x30_f5": "anti-flicker",
+                 # frame history through a pass 0 (response-time) that is not the last pass: the ring holds final outputs
+                 "lcd_grid_v2_psp_color_motionblur_48x36_to_200x150_f5": "lcd-grid-v2-psp-color-motionblur",
+                 "lcd_grid_v2_motionblur_48x36_to_200x150_f9": "lcd-grid-v2-motionblur"}
 
 
 @pytest.mark.parametrize("case", sorted(HISTORY_CASES))
@@ -417,7 +428,10 @@ def test_frame_history_matches_golden(case, as_batch, preset_tree, rc_lib):
     else:
         for f in range(frames.shape[0]):
             final = run_engine(e, frames[f])[0]
-    assert np.array_equal(final, g["pass0"])
+    n = int(g["n_passes"])
+    for i in range(n):
+        assert np.array_equal(e.readPass(i, frames.shape[0] - 1 if as_batch else 0), g["pass%d" % i]), "pass %d" % i
+    assert np.array_equal(final, g["pass%d" % (n - 1)])
     assert e.historyCount() == int(g["n_history"])
     for k in range(e.historyCount()):
         assert np.array_equal(e.readHistory(k), g["history%d" % k]), "history %d" % k

@@ -46,6 +46,16 @@ CASES = {
     "motionblur_simple_48x36_to_120x90_f9": "motionblur-simple",   # Prev .. Prev6; 9 frames: the full ring recycles (and clears) its oldest texture
     "motionblur_simple_40x30_to_40x30_f3": "motionblur-simple",
     "braid_rewind_48x36_to_120x90_f8": "braid-rewind",
+    # handheld/lcd-grid-v2.glslp and its chains (rc_passes_lcd.c); "bare" = the shader without the preset files' parameter block
+    "lcd_grid_v2_64x48_to_320x240": "lcd-grid-v2",
+    "lcd_grid_v2_40x30_to_233x171": "lcd-grid-v2",
+    "lcd_grid_v2_params_48x36_to_240x180": "lcd-grid-v2",        # custom values of the 14 names the preset file sets are overridden by it; outgamma moves
+    "lcd_grid_v2_bare_params_48x36_to_240x180": "lcd-grid-v2-bare",
+    "lcd_grid_v2_bare_defaults_40x30_to_97x61": "lcd-grid-v2-bare",
+    "lcd_grid_v2_gba_color_48x36_to_240x180": "lcd-grid-v2-gba-color",
+    "lcd_grid_v2_gbc_color_48x36_to_200x150": "lcd-grid-v2-gbc-color",
+    "lcd_grid_v2_psp_color_motionblur_48x36_to_200x150_f5": "lcd-grid-v2-psp-color-motionblur",   # frame history through a pass 0 that is not the last pass
+    "lcd_grid_v2_motionblur_48x36_to_200x150_f9": "lcd-grid-v2-motionblur",
     # handheld/<name>-color.glslp
     "gba_color_64x48_to_160x120": "gba-color",
     "gbc_color_64x48_to_160x120": "gbc-color",
@@ -136,7 +146,15 @@ def preset_passes(tmp_path, key):
     """Parse our hand-written preset with the product's parser (host only, no GPU)."""
     from retrocapture_amd import engine
     tree = chain_specs.write_tree(str(tmp_path))
-    return engine.preset_dump(tree[key])["passes"]
+    dump = engine.preset_dump(tree[key])
+    passes = PassList(dump["passes"])
+    # the preset file's own `parameters` block: applied at draw time, over custom values (oracle_chain.run_chain)
+    passes.globals = {k: v for k, v in dump.get("params", {}).items() if k != "parameters"}
+    return passes
+
+
+class PassList(list):
+    globals = None
 
 
 def run_sequence(passes, frames_rgb, vw, vh, **kw):
@@ -149,7 +167,7 @@ def run_sequence(passes, frames_rgb, vw, vh, **kw):
     return outs, st
 
 
-HISTORY_PRESETS = ("mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
+HISTORY_PRESETS = ("lcd-grid-v2-psp-color-motionblur", "lcd-grid-v2-motionblur", "mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
 
 
 @pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] in HISTORY_PRESETS))
@@ -162,7 +180,8 @@ def test_oracle_frame_history_matches_llvmpipe(case, tmp_path, rc_lib):
     vw, vh = [int(v) for v in g["viewport"]]
     custom = dict(zip([str(n) for n in g["param_names"]], [float(v) for v in g["param_values"]])) if "param_names" in g else None
     outs, st = run_sequence(passes, g["input_rgb"], vw, vh, custom=custom)
-    assert np.array_equal(outs[-1], g["pass0"])
+    for i in range(int(g["n_passes"])):
+        assert np.array_equal(outs[i], g["pass%d" % i]), "pass %d" % i
     assert len(st.history) == int(g["n_history"]) == min(7, g["input_rgb"].shape[0])
     for k, hk in enumerate(st.history):
         assert np.array_equal(hk, g["history%d" % k]), "history %d" % k
@@ -250,6 +269,9 @@ FLOAT_CASES = {
     "f32_palm_color_48x36_to_131x77": ("palm-color", {}),
     "f32_psp_color_48x36_to_131x77": ("psp-color", {}),
     "f32_vba_color_48x36_to_131x77": ("vba-color", {}),
+    "f32_lcd_grid_v2_48x36_to_240x180": ("lcd-grid-v2", {}),
+    "f32_lcd_grid_v2_params_40x30_to_233x171": ("lcd-grid-v2", {}),
+    "f32_lcd_grid_v2_bare_params_40x30_to_233x171": ("lcd-grid-v2-bare", {}),
     "f32_crt_royale_64x48_to_128x96": ("crt-royale", {}),
     "f32_crt_royale_maskon_64x48_to_128x96": ("crt-royale", {}),
     "f32_crt_royale_geom_sphere_64x48_to_128x96": ("crt-royale", {}),
