@@ -50,6 +50,8 @@ WORKLOADS = {
     "scanline": ("scanline", 320, 240, 320, 240, "scanlines/shaders/scanline.glsl 1-pass, 320x240"),
     "crt-geom": ("crt-geom", 640, 480, 1920, 1440, "crt/crt-geom.glslp 1-pass (curvature, interlacing simulation on), 640x480 -> 1920x1440"),
     "scalefx": ("scalefx", 256, 224, 768, 672, "scalefx/scalefx.glslp 5-pass pixel-art upscale 256x224 -> 768x672"),
+    "lcd-grid-v2": ("lcd-grid-v2-gba-color-motionblur", 240, 160, 1920, 1280,
+                    "handheld/lcd-grid-v2-gba-color-motionblur.glslp 3-pass (frame history: sequential frames), 240x160 -> 1920x1280"),
 }
 
 
@@ -364,6 +366,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="frames per kernel launch (0 = engine default)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
+                    help="set a shader parameter before the run (side measurement, e.g. geom_mode_runtime=1: crt-royale's curved last pass)")
     ap.add_argument("--fp16-targets", action="store_true",
                     help="store float_framebuffer targets as binary16 (rc_engine_set_float_target_fp16; side measurement "
                          "for the ntsc workload: 28.2 MB instead of 45.9 MB of algorithmic bytes per frame, output within "
@@ -429,6 +433,10 @@ def main():
     e.setViewport(vw, vh)
     if args.fp16_targets:
         e.setFloatTargetFp16(True)
+    for kv in args.param:
+        name, value = kv.split("=")
+        if not e.setShaderParameter(name, float(value)):
+            raise SystemExit("unknown shader parameter " + name)
     if args.chunk:
         e.setChunkFrames(args.chunk)
 
@@ -519,7 +527,7 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "float_target_storage": "f16" if args.fp16_targets else "f32",
-        "config": {"workload": desc, "frames_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
+        "config": {"workload": desc + (" [" + ", ".join(args.param) + "]" if args.param else ""), "frames_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
                    "chunk_frames": args.chunk or "default", "parallelism": "frames sharded, no collective",
                    "algorithmic_bytes_per_frame": chain_bytes,
                    "hbm_roofline_frac_whole_chain": value / world * chain_bytes / (HBM_PEAK_GBS * 1e9),

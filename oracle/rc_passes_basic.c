@@ -789,3 +789,59 @@ void o_pass_gbc_gambatte_color(const o_pass_args* a) {
     }
   o_fp_leave(csr);
 }
+
+/* handheld/shaders/retro-v2.glsl FS main (handheld/retro-v2.glslp, presets/retro-v2+<console>-color.glslp): pow(texel, 2.4), a
+ * border of width depending on RETRO_PIXEL_SIZE darkens each source pixel's edge, pow(.., 1/2.2), clamp.  Operation order from
+ * the GL's final instruction listing.  params: RETRO_PIXEL_SIZE. */
+static inline float nmin(float a, float b) { return b != b ? a : (a < b ? a : b); }   /* gallivm's fmin / fmax: the operand that is not NaN */
+static inline float nmax(float a, float b) { return b != b ? a : (a > b ? a : b); }
+void o_pass_retro_v2(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  const float rps = a->params[0], tsx = (float)a->in->w, tsy = (float)a->in->h;
+  const float px = tsx * (1.0f / (float)W), py = tsy * (1.0f / (float)H);   /* InputSize * (1 / OutputSize) */
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      const o_vec4 t = o_sample(a->in, u, v);
+      const float su = u * tsx, sv = v * tsy, fx = su - floorf(su), fy = sv - floorf(sv);
+      const float ax = nmin(nmax(fx + 0.5f * px, 0.0f), 1.0f), ay = nmin(nmax(fy + 0.5f * py, 0.0f), 1.0f);
+      const float cx = nmin(nmax(ax + -rps, 0.0f), px) / px, cy = nmin(nmax(ay + -rps, 0.0f), py) / py;
+      const float m = nmax(cx, cy);
+      const float k = (1.04f + fx * fy) * (1.0f + -m) + 0.36f * m;
+      const o_vec4 out = {nmin(nmax(o_pow(k * o_pow(t.x, 2.4f), 1.0f / 2.2f), 0.0f), 1.0f), nmin(nmax(o_pow(k * o_pow(t.y, 2.4f), 1.0f / 2.2f), 0.0f), 1.0f),
+                          nmin(nmax(o_pow(k * o_pow(t.z, 2.4f), 1.0f / 2.2f), 0.0f), 1.0f), 1.0f};
+      store_px(a, x, y, out);
+    }
+  o_fp_leave(csr);
+}
+
+/* handheld/shaders/mgba/agb001.glsl FS main (handheld/agb001.glslp, agb001-gba-color-motionblur.glslp): pow(texel * 0.8, 1.8) + 0.16,
+ * a 4x4 subpixel pattern per source texel - column 0 / 1 / 2 keeps red / green / blue and takes the others to 0.2, column 3 takes
+ * all to 0.4, row 3 another 0.8 - alpha 0.5.  The pattern index is int(mod(coord * size * 4, 4)) with mod as a - 4 floor(a / 4). */
+void o_pass_agb001(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  const float tsx = (float)a->in->w, tsy = (float)a->in->h;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      const o_vec4 t = o_sample(a->in, u, v);
+      float c[3] = {o_pow(t.x * 0.8f, 1.8f) + 0.16f, o_pow(t.y * 0.8f, 1.8f) + 0.16f, o_pow(t.z * 0.8f, 1.8f) + 0.16f};
+      const float ax = (u * tsx) * 4.0f, ay = (v * tsy) * 4.0f;
+      const float mx = ax + -(4.0f * floorf(ax / 4.0f)), my = ay + -(4.0f * floorf(ay / 4.0f));
+      const int ix = mx != mx ? (-2147483647 - 1) : (int)mx, iy = my != my ? (-2147483647 - 1) : (int)my;
+      for (int k = 0; k < 3; ++k) {
+        if (ix >= 0 && ix <= 2) { if (k != ix) c[k] = c[k] * 0.2f; }
+        else c[k] = c[k] * 0.4f;
+        if (!((unsigned)iy <= 2u)) c[k] = c[k] * 0.8f;
+      }
+      const o_vec4 out = {c[0], c[1], c[2], 0.5f};
+      store_px(a, x, y, out);
+    }
+  o_fp_leave(csr);
+}

@@ -430,6 +430,9 @@ std::vector<KernelEntry> build() {
                 {"blacklevel", 0.05f, 0.0f, 0.5f, 0.01f, "Black level"}, {"ambient", 0.0f, 0.0f, 0.5f, 0.01f, "Ambient"},
                 {"BGR", 0.0f, 0.0f, 1.0f, 1.0f, "BGR"}},
                {}, rck::launch_lcd_grid_v2, setupTexCoord, false});
+  r.push_back({"handheld/shaders/mgba/agb001.glsl", "agb001", {}, {}, rck::launch_agb001, setupTexCoord, false});
+  r.push_back({"handheld/shaders/retro-v2.glsl", "retro-v2", {{"RETRO_PIXEL_SIZE", 0.84f, 0.0f, 1.0f, 0.01f, "Retro Pixel Size"}}, {},
+               rck::launch_retro_v2, setupTexCoord, false});
   // handheld/<name>-color.glslp (kernels/pass_basic.hip k_color_matrix); none of them reads a size uniform
   r.push_back({"handheld/shaders/color/gba-color.glsl", "gba-color", {{"darken_screen", 1.0f, -0.25f, 1.0f, 0.05f, "Darken Screen"}}, {},
                rck::launch_color_matrix, setupGbaColor, false, true, nullptr, nullptr, true});

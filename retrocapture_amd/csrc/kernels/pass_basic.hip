@@ -126,6 +126,60 @@ __global__ void __launch_bounds__(256) k_color_matrix(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// handheld/shaders/retro-v2.glsl FS main (handheld/retro-v2.glslp, presets/retro-v2+<console>-color.glslp): pow(texel, 2.4); the edge
+// of every source pixel is darkened over a width set by RETRO_PIXEL_SIZE; pow(.., 1 / 2.2), clamp.  params[0] = RETRO_PIXEL_SIZE.
+// Operation order: the GL's instruction listing (oracle/rc_passes_basic.c).  fmin / fmax keep the operand that is not NaN.
+__global__ void __launch_bounds__(256) k_retro_v2(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const float rps = L.params[0], tsx = (float)L.in.w, tsy = (float)L.in.h;
+  const float px = tsx * (1.0f / (float)L.out_w), py = tsy * (1.0f / (float)L.out_h);   // InputSize * (1 / OutputSize)
+  auto nmin = [](float a, float b) { return b != b ? a : (a < b ? a : b); };
+  auto nmax = [](float a, float b) { return b != b ? a : (a > b ? a : b); };
+  RC_TILE_LOOP_BEGIN
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float4 t = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+  const float su = u * tsx, sv = v * tsy, fx = su - __builtin_floorf(su), fy = sv - __builtin_floorf(sv);
+  const float ax = nmin(nmax(fx + 0.5f * px, 0.0f), 1.0f), ay = nmin(nmax(fy + 0.5f * py, 0.0f), 1.0f);
+  const float cx = nmin(nmax(ax + -rps, 0.0f), px) / px, cy = nmin(nmax(ay + -rps, 0.0f), py) / py;
+  const float m = nmax(cx, cy);
+  const float k = (1.04f + fx * fy) * (1.0f + -m) + 0.36f * m;
+  const float c3[3] = {t.x, t.y, t.z};
+  float o[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float q = k * pow_(c3[c], 2.4f);
+    o[c] = nmin(nmax(q != q ? 0.0f : pow_(q, 1.0f / 2.2f), 0.0f), 1.0f);
+  }
+  store_rt(L, z, x, y, make_float4(o[0], o[1], o[2], 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
+// handheld/shaders/mgba/agb001.glsl FS main (handheld/agb001.glslp, agb001-gba-color-motionblur.glslp): pow(texel * 0.8, 1.8) + 0.16 under
+// a 4x4 subpixel pattern per source texel - column 0 / 1 / 2 keeps red / green / blue and takes the other two to 0.2, column 3
+// takes all to 0.4, row 3 another 0.8 - alpha 0.5.  Index: int(mod(coord * size * 4, 4)), mod as a - 4 floor(a / 4).
+__global__ void __launch_bounds__(256) k_agb001(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const float tsx = (float)L.in.w, tsy = (float)L.in.h;
+  RC_TILE_LOOP_BEGIN
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float4 t = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+  float c[3] = {pow_(t.x * 0.8f, 1.8f) + 0.16f, pow_(t.y * 0.8f, 1.8f) + 0.16f, pow_(t.z * 0.8f, 1.8f) + 0.16f};
+  const float ax = (u * tsx) * 4.0f, ay = (v * tsy) * 4.0f;
+  const float mx = ax + -(4.0f * __builtin_floorf(ax / 4.0f)), my = ay + -(4.0f * __builtin_floorf(ay / 4.0f));
+  const int ix = mx != mx ? (-2147483647 - 1) : (int)mx, iy = my != my ? (-2147483647 - 1) : (int)my;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (ix >= 0 && ix <= 2) {
+      if (k != ix) c[k] = c[k] * 0.2f;
+    } else {
+      c[k] = c[k] * 0.4f;
+    }
+    if (!((unsigned)iy <= 2u)) c[k] = c[k] * 0.8f;
+  }
+  store_rt(L, z, x, y, make_float4(c[0], c[1], c[2], 0.5f), &lds);
+  RC_TILE_LOOP_END
+}
+
 // handheld/shaders/color/gbc-gambatte-color.glsl FS main: a fixed matrix on the texel as sampled (products blue, green, red), alpha kept
 __global__ void __launch_bounds__(256) k_gbc_gambatte_color(const PassLaunch L) {
   RC_SRGB_LDS(lds, L);
@@ -617,6 +671,8 @@ RC_SIMPLE_LAUNCH(launch_braid_rewind, k_braid_rewind)
 RC_SIMPLE_LAUNCH(launch_response_time, k_response_time)
 RC_SIMPLE_LAUNCH(launch_mix_frames_smart, k_mix_frames_smart)
 RC_SIMPLE_LAUNCH(launch_color_matrix, k_color_matrix)
+RC_SIMPLE_LAUNCH(launch_retro_v2, k_retro_v2)
+RC_SIMPLE_LAUNCH(launch_agb001, k_agb001)
 RC_SIMPLE_LAUNCH(launch_gbc_gambatte_color, k_gbc_gambatte_color)
 RC_SIMPLE_LAUNCH(launch_shutter_3d, k_shutter_3d)
 RC_SIMPLE_LAUNCH(launch_anti_flicker, k_anti_flicker)

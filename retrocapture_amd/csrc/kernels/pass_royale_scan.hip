@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) k_scan_geometry(const PassLaunch L, ScanR
       const float svr[3] = {sv, sv + uv_step_y, sv + mix_rt(-uv_step_y, 2.0f * uv_step_y, 0.0f)};
       const int roff[3] = {0, 1, -1};
       for (int j = 0; j < 3; ++j) {
-        const float w = linear_coord<WRAP_EDGE>(svr[j], L.in.h);
+        const float w = linear_coord_edge_pair(svr[j], L.in.h);
         const float y0 = __builtin_floorf(w);
         r.wy[j] = w - y0;
         const float want = (float)(i + roff[j]);
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256) k_scan_geometry(const PassLaunch L, ScanR
       const float u = vary(L.plane[0], i, 0, side == 0);
       const float ctx = u * tsx, ptx = __builtin_floorf(ctx - kUnderHalf);
       const float su = ((ptx - 0.0f) + 0.5f) * tix;
-      const float w = linear_coord<WRAP_EDGE>(su, L.in.w);
+      const float w = linear_coord_edge_pair(su, L.in.w);
       const float x0 = __builtin_floorf(w);
       wx = w - x0;
       if (!(ptx == (float)i && x0 == (float)i)) why |= 64u;

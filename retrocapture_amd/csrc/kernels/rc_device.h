@@ -305,6 +305,11 @@ __device__ __forceinline__ float linear_coord(float s, int n) {
   return u - 0.5f;
 }
 
+// The same coordinate for the finite inputs of the host-verified table / strip forms: clamp(s n, 0, n) - 0.5 keeps the texel pair
+// (-1, 0) with weight 0.5 at the left / top edge where linear_coord's max(.., 0) gives (0, 1) with weight 0 - the same
+// filtered value, both texels of the pair being texel 0 after the index clamp - and the pair those tables are written for.
+__device__ __forceinline__ float linear_coord_edge_pair(float s, int n) { return fminf(fmaxf(s * (float)n, 0.0f), (float)n) - 0.5f; }
+
 // GL_NEAREST
 template <int FMT, int WRAP>
 __device__ __forceinline__ float4 sample_nearest(const Tex& t, const uint8_t* img, float s, float v, const SrgbLds* lds) {

@@ -21,9 +21,9 @@ struct LinTap {
   int i0;    // first texel of the pair (may be -1: both indices are clamped to the texture when fetched)
   float w;   // weight of the second texel
 };
-// sample_linear_f<., WRAP_EDGE> on one axis
+// sample_linear_f<., WRAP_EDGE> on one axis (rc_device.h linear_coord_edge_pair: the pair (-1, 0) at the left / top edge)
 __device__ __forceinline__ LinTap lin_tap(float s, int n) {
-  const float u = linear_coord<WRAP_EDGE>(s, n);
+  const float u = linear_coord_edge_pair(s, n);
   const float f = __builtin_floorf(u);
   return LinTap{(int)f, u - f};
 }

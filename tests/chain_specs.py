@@ -349,6 +349,26 @@ for _c in ("gba", "gbc", "nds", "palm", "psp", "vba"):
     PRESETS["lcd-grid-v2-%s-color" % _c] = ("handheld/lcd-grid-v2-%s-color.glslp" % _c, _lcd_grid_v2(_c, False))
     PRESETS["lcd-grid-v2-%s-color-motionblur" % _c] = ("handheld/lcd-grid-v2-%s-color-motionblur.glslp" % _c, _lcd_grid_v2(_c, True))
 
+# handheld/retro-v2.glslp and presets/retro-v2+<console>-color.glslp (same keys / values as the reference's files; the parameter
+# blocks of the nds / psp / vba ones name parameters their shaders do not declare - kept, they are inert)
+PRESETS["retro-v2"] = ("handheld/retro-v2.glslp", 'shaders = 1\n\nshader0 = shaders/retro-v2.glsl\nfilter_linear0 = false')
+for _c, _blk in (("gba", 'parameters = "darken_screen;RETRO_PIXEL_SIZE"\ndarken_screen = "1.000000"\nRETRO_PIXEL_SIZE = "0.840000"\n'),
+                 ("gbc", 'parameters = "RETRO_PIXEL_SIZE"\nRETRO_PIXEL_SIZE = "0.840000"\n'),
+                 ("nds", 'parameters = "target_gamma;RETRO_PIXEL_SIZE"\ntarget_gamma = "2.000000"\nRETRO_PIXEL_SIZE = "0.840000"\n'),
+                 ("psp", 'parameters = "target_gamma;RETRO_PIXEL_SIZE"\ntarget_gamma = "2.200000"\nRETRO_PIXEL_SIZE = "0.840000"\n'),
+                 ("vba", 'parameters = "dark_gamma;RETRO_PIXEL_SIZE"\ndark_gamma = "2.900000"\nRETRO_PIXEL_SIZE = "0.840000"\n')):
+    PRESETS["retro-v2+%s-color" % _c] = ("presets/retro-v2+%s-color.glslp" % _c,
+                                         'shaders = "2"\n\nshader0 = "../handheld/shaders/color/%s-color.glsl"\nshader1 = "../handheld/shaders/retro-v2.glsl"\n\n'
+                                         'filter_linear0 = "false"\nscale_type0 = "source"\nscale0 = "1.000000"\n\nfilter_linear1 = "false"\n\n' % _c + _blk)
+
+# handheld/agb001.glslp and agb001-gba-color-motionblur.glslp: same keys / values as the reference's files
+PRESETS["agb001"] = ("handheld/agb001.glslp", 'shaders = 2\n\nshader0 = shaders/mgba/agb001.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 4.0\n\n'
+                     'shader1 = ../stock.glsl\nfilter_linear1 = true\nscale_type1 = viewport\n')
+PRESETS["agb001-gba-color-motionblur"] = ("handheld/agb001-gba-color-motionblur.glslp",
+                                          'shaders = 3\n\nshader0 = ../motionblur/shaders/response-time.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n\n'
+                                          'shader1 = shaders/mgba/agb001.glsl\nfilter_linear1 = false\nscale_type1 = source\nscale1 = 4.0\n\n'
+                                          'shader2 = shaders/color/gba-color.glsl\nfilter_linear2 = true\nscale_type2 = viewport\n')
+
 # crt-royale with an RGBA32F last target: the last pass's floats as computed, for the curved-geometry / tex2Daa form
 PRESETS["crt-royale-f32-last"] = ("crt/crt-royale-f32-last.glslp", PRESETS["crt-royale"][1] + 'float_framebuffer11 = "true"\n')
 PRESETS["crt-royale-ntsc-256px-svideo"] = ("crt/crt-royale-ntsc-256px-svideo.glslp", _royale_ntsc("svideo-3phase", "3phase", 1536))
@@ -411,6 +431,8 @@ SHADERS = {
     "handheld/shaders/color/palm-color.glsl": {"oracle": "palm_color", "params": [], "samplers": [], "size_independent": True},
     "handheld/shaders/color/psp-color.glsl": {"oracle": "psp_color", "params": [], "samplers": [], "size_independent": True},
     "handheld/shaders/color/vba-color.glsl": {"oracle": "vba_color", "params": [('darken_screen', 1.0)], "samplers": [], "size_independent": True},
+    "handheld/shaders/mgba/agb001.glsl": {"oracle": "agb001", "samplers": [], "params": []},
+    "handheld/shaders/retro-v2.glsl": {"oracle": "retro_v2", "samplers": [], "params": [("RETRO_PIXEL_SIZE", 0.84)]},
     "handheld/shaders/lcd-cgwg/lcd-grid-v2.glsl": {"oracle": "lcd_grid_v2", "samplers": [],
                                                    "params": [("RSUBPIX_R", 1.0), ("RSUBPIX_G", 0.0), ("RSUBPIX_B", 0.0), ("GSUBPIX_R", 0.0), ("GSUBPIX_G", 1.0),
                                                               ("GSUBPIX_B", 0.0), ("BSUBPIX_R", 0.0), ("BSUBPIX_G", 0.0), ("BSUBPIX_B", 1.0), ("gain", 1.0),

@@ -495,6 +495,21 @@ def case_hyllian_glow():
              params=[("HFILTER_SHARPNESS", 0.7), ("CRT_ANTI_RINGING", 0.6), ("MASK_INTENSITY", 0.7), ("PHOSPHOR_LAYOUT", 5.0)])
 
 
+def case_agb001():
+    run_case("agb001_48x36_to_250x190", GLSL + "/handheld/agb001.glslp", mixed(48, 36, 120), 250, 190)
+    run_case("f32_agb001_40x30_to_233x171", GLSL + "/handheld/agb001.glslp", noise(40, 30, 121), 233, 171, f32=True)
+    run_case("agb001_gba_color_motionblur_48x36_to_250x190_f4", GLSL + "/handheld/agb001-gba-color-motionblur.glslp", moving(48, 36, 4, 122), 250, 190)
+
+
+def case_retro_v2():
+    R = GLSL + "/handheld/retro-v2.glslp"
+    run_case("retro_v2_64x48_to_320x240", R, mixed(64, 48, 110), 320, 240)
+    run_case("retro_v2_params_40x30_to_233x171", R, noise(40, 30, 111), 233, 171, params=[("RETRO_PIXEL_SIZE", 0.55)])
+    run_case("f32_retro_v2_48x36_to_240x180", R, mixed(48, 36, 112), 240, 180, f32=True)
+    run_case("retro_v2_gba_color_48x36_to_240x180", GLSL + "/presets/retro-v2+gba-color.glslp", mixed(48, 36, 113), 240, 180)
+    run_case("retro_v2_vba_color_40x30_to_233x171", GLSL + "/presets/retro-v2+vba-color.glslp", noise(40, 30, 114), 233, 171)
+
+
 def case_lcd_grid_v2():
     """handheld/lcd-grid-v2.glslp and its chains: with a colour pass behind it, and with motionblur/response-time in front (frame
     history through a pass 0 that is not the last pass)."""
@@ -713,7 +728,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

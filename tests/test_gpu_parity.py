@@ -12,6 +12,11 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "agb001_48x36_to_250x190": "agb001",
+    "retro_v2_64x48_to_320x240": "retro-v2",
+    "retro_v2_params_40x30_to_233x171": "retro-v2",
+    "retro_v2_gba_color_48x36_to_240x180": "retro-v2+gba-color",
+    "retro_v2_vba_color_40x30_to_233x171": "retro-v2+vba-color",
     # handheld/lcd-grid-v2.glslp and its chains (kernels/pass_lcd_grid.hip); "bare" = without the preset files' parameter block
     "lcd_grid_v2_64x48_to_320x240": "lcd-grid-v2",
     "lcd_grid_v2_40x30_to_233x171": "lcd-grid-v2",
@@ -406,7 +411,8 @@ HISTORY_CASES = {"mix_frames_72x40_to_72x40_f3": "mix-frames", "mix_frames_48x36
                  "anti_flicker_48x36_to_120x90_f6": "anti-flicker", "anti_flicker_params_40x30_to_40x30_f5": "anti-flicker",
                  # frame history through a pass 0 (response-time) that is not the last pass: the ring holds final outputs
                  "lcd_grid_v2_psp_color_motionblur_48x36_to_200x150_f5": "lcd-grid-v2-psp-color-motionblur",
-                 "lcd_grid_v2_motionblur_48x36_to_200x150_f9": "lcd-grid-v2-motionblur"}
+                 "lcd_grid_v2_motionblur_48x36_to_200x150_f9": "lcd-grid-v2-motionblur",
+                 "agb001_gba_color_motionblur_48x36_to_250x190_f4": "agb001-gba-color-motionblur"}
 
 
 @pytest.mark.parametrize("case", sorted(HISTORY_CASES))

@@ -56,6 +56,12 @@ CASES = {
     "lcd_grid_v2_gbc_color_48x36_to_200x150": "lcd-grid-v2-gbc-color",
     "lcd_grid_v2_psp_color_motionblur_48x36_to_200x150_f5": "lcd-grid-v2-psp-color-motionblur",   # frame history through a pass 0 that is not the last pass
     "lcd_grid_v2_motionblur_48x36_to_200x150_f9": "lcd-grid-v2-motionblur",
+    "agb001_48x36_to_250x190": "agb001",
+    "agb001_gba_color_motionblur_48x36_to_250x190_f4": "agb001-gba-color-motionblur",
+    "retro_v2_64x48_to_320x240": "retro-v2",
+    "retro_v2_params_40x30_to_233x171": "retro-v2",
+    "retro_v2_gba_color_48x36_to_240x180": "retro-v2+gba-color",
+    "retro_v2_vba_color_40x30_to_233x171": "retro-v2+vba-color",
     # handheld/<name>-color.glslp
     "gba_color_64x48_to_160x120": "gba-color",
     "gbc_color_64x48_to_160x120": "gbc-color",
@@ -167,7 +173,7 @@ def run_sequence(passes, frames_rgb, vw, vh, **kw):
     return outs, st
 
 
-HISTORY_PRESETS = ("lcd-grid-v2-psp-color-motionblur", "lcd-grid-v2-motionblur", "mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
+HISTORY_PRESETS = ("agb001-gba-color-motionblur", "lcd-grid-v2-psp-color-motionblur", "lcd-grid-v2-motionblur", "mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
 
 
 @pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] in HISTORY_PRESETS))
@@ -269,6 +275,8 @@ FLOAT_CASES = {
     "f32_palm_color_48x36_to_131x77": ("palm-color", {}),
     "f32_psp_color_48x36_to_131x77": ("psp-color", {}),
     "f32_vba_color_48x36_to_131x77": ("vba-color", {}),
+    "f32_agb001_40x30_to_233x171": ("agb001", {}),
+    "f32_retro_v2_48x36_to_240x180": ("retro-v2", {}),
     "f32_lcd_grid_v2_48x36_to_240x180": ("lcd-grid-v2", {}),
     "f32_lcd_grid_v2_params_40x30_to_233x171": ("lcd-grid-v2", {}),
     "f32_lcd_grid_v2_bare_params_40x30_to_233x171": ("lcd-grid-v2-bare", {}),
