@@ -845,3 +845,37 @@ void o_pass_agb001(const o_pass_args* a) {
     }
   o_fp_leave(csr);
 }
+
+/* handheld/console-border/shader-files/gb-pass-5.glsl (the last pass of the 75 console-border presets): the frame, scaled about its
+ * centre, under a border image that is blended in by its own alpha.  VS 46-58 in the GL's operation order; FS: frame + a (border - frame).
+ * params: SCALE, OUT_X, OUT_Y; extra[0] = BORDER. */
+void o_pass_gb_pass_5(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  const float* P = a->params;
+  const float osx = (float)W, osy = (float)H, isx = (float)a->in->w, isy = (float)a->in->h, tsx = isx;
+  /* the pass sits at index 3 in the 4-pass presets, where the reference hands TextureSize.y the TARGET's height (ShaderEngine.cpp:2418-2421) */
+  const float tsy = (a->pass_index == 3 && H != a->in->h) ? (float)H : isy;
+  const float scx = (osx / isx) / P[0], scy = (osy / isy) / P[0];
+  const float mx = (0.5f * isx) / tsx, my = (0.5f * isy) / tsy;
+  float v[4][4];
+  static const float tc[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+  for (int k = 0; k < 4; ++k) {
+    const float tx = mx + (tc[k][0] + -mx) * scx, ty = my + (tc[k][1] + -my) * scy;
+    const float bx = tx * (tsx / isx) + -0.5f, by = ty * (tsy / isy) + -0.5f;
+    v[k][0] = tx; v[k][1] = ty;
+    v[k][2] = 0.5f + ((bx * osx) / P[1]) / scx;
+    v[k][3] = 0.5f + ((by * osy) / P[2]) / scy;
+  }
+  o_varying pl[4];
+  for (int c = 0; c < 4; ++c) pl[c] = o_varying_setup(v[0][c], v[1][c], v[2][c], v[3][c], W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const o_vec4 b = o_sample(a->extra[0], o_varying_at(&pl[2], x, y, lo), o_varying_at(&pl[3], x, y, lo));
+      const o_vec4 f = o_sample(a->in, o_varying_at(&pl[0], x, y, lo), o_varying_at(&pl[1], x, y, lo));
+      const o_vec4 out = {f.x + b.w * (b.x + -f.x), f.y + b.w * (b.y + -f.y), f.z + b.w * (b.z + -f.z), f.w + b.w * (b.w + -f.w)};
+      store_px(a, x, y, out);
+    }
+  o_fp_leave(csr);
+}

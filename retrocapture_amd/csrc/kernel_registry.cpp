@@ -77,6 +77,26 @@ RC_COLOR_SETUP(setupPspColor, {2.21f, 0.0f, 1.0f, {0.98f, 0.20f, -0.18f, 0.04f, 
 RC_COLOR_SETUP(setupVbaColor, {1.45f, 1.7f, 1.0f, {0.73f, 0.27f, 0.0f, 0.085f, 0.675f, 0.24f, 0.085f, 0.24f, 0.675f}, 1.0f / 1.45f, false})
 #undef RC_COLOR_SETUP
 
+// gb-pass-5.glsl VS 46-58: TEX0 (the frame scaled about its centre) and tex_border at the quad's vertices, in the GL's operation order
+void setupGbPass5(const PassGeometry& g, rcd::PassLaunch& L) {
+  const float* P = L.params;
+  const float osx = (float)g.out_w, osy = (float)g.out_h, isx = (float)g.in_w, isy = (float)g.in_h, tsx = isx;
+  // at pass index 3 - where this pass sits in the 4-pass presets - the reference hands TextureSize.y the TARGET's height (ShaderEngine.cpp:2418-2421)
+  const float tsy = (g.pass_index == 3 && g.out_h != g.in_h) ? (float)g.out_h : isy;
+  const float scx = (osx / isx) / P[0], scy = (osy / isy) / P[0];
+  const float mx = (0.5f * isx) / tsx, my = (0.5f * isy) / tsy;
+  static const float tc[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};   // BL, BR, TR, TL
+  float v[4][4];
+  for (int k = 0; k < 4; ++k) {
+    const float tx = mx + (tc[k][0] + -mx) * scx, ty = my + (tc[k][1] + -my) * scy;
+    const float bx = tx * (tsx / isx) + -0.5f, by = ty * (tsy / isy) + -0.5f;
+    v[k][0] = tx;
+    v[k][1] = ty;
+    v[k][2] = 0.5f + ((bx * osx) / P[1]) / scx;
+    v[k][3] = 0.5f + ((by * osy) / P[2]) / scy;
+  }
+  for (int c = 0; c < 4; ++c) L.plane[c] = makePlane(v[0][c], v[1][c], v[2][c], v[3][c], g.out_w, g.out_h, g.out_fmt);
+}
 // shutter-3d.glsl VS 61-73: left_coord / right_coord at the quad's vertices, in the GL's operation order (oracle/rc_passes_basic.c)
 void setupShutter3d(const PassGeometry& g, rcd::PassLaunch& L) {
   const float* P = L.params;
@@ -430,6 +450,11 @@ std::vector<KernelEntry> build() {
                 {"blacklevel", 0.05f, 0.0f, 0.5f, 0.01f, "Black level"}, {"ambient", 0.0f, 0.0f, 0.5f, 0.01f, "Ambient"},
                 {"BGR", 0.0f, 0.0f, 1.0f, 1.0f, "BGR"}},
                {}, rck::launch_lcd_grid_v2, setupTexCoord, false});
+  r.push_back({"handheld/console-border/shader-files/gb-pass-5.glsl", "gb-pass-5",
+               {{"SCALE", 0.6667f, 0.6667f, 1.5f, 0.33333f, "Box Scale"}, {"OUT_X", 1600.0f, 1600.0f, 4800.0f, 8000.0f, "Out X"},
+                {"OUT_Y", 800.0f, 800.0f, 2400.0f, 400.0f, "Out Y"}},
+               {"BORDER"}, rck::launch_gb_pass_5, setupGbPass5, false});
+  r.back().texture_height_override = true;   // setupGbPass5 reads PassGeometry::pass_index
   r.push_back({"handheld/shaders/mgba/agb001.glsl", "agb001", {}, {}, rck::launch_agb001, setupTexCoord, false});
   r.push_back({"handheld/shaders/retro-v2.glsl", "retro-v2", {{"RETRO_PIXEL_SIZE", 0.84f, 0.0f, 1.0f, 0.01f, "Retro Pixel Size"}}, {},
                rck::launch_retro_v2, setupTexCoord, false});

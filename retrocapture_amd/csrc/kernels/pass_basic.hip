@@ -154,6 +154,18 @@ __global__ void __launch_bounds__(256) k_retro_v2(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// handheld/console-border/shader-files/gb-pass-5.glsl FS main (last pass of the console-border presets): the frame under a border image
+// blended in by its own alpha, frame + a (border - frame) on all four channels.  plane[0..1] = TEX0 (the frame scaled about its
+// centre), plane[2..3] = tex_border (registry: setupGbPass5); extra[0] = BORDER.
+__global__ void __launch_bounds__(256) k_gb_pass_5(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  const float4 b = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), vary(L.plane[2], x, y, lo), vary(L.plane[3], x, y, lo), &lds);
+  const float4 f = sample_rt(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
+  store_rt(L, z, x, y, make_float4(f.x + b.w * (b.x + -f.x), f.y + b.w * (b.y + -f.y), f.z + b.w * (b.z + -f.z), f.w + b.w * (b.w + -f.w)), &lds);
+  RC_TILE_LOOP_END
+}
+
 // handheld/shaders/mgba/agb001.glsl FS main (handheld/agb001.glslp, agb001-gba-color-motionblur.glslp): pow(texel * 0.8, 1.8) + 0.16 under
 // a 4x4 subpixel pattern per source texel - column 0 / 1 / 2 keeps red / green / blue and takes the other two to 0.2, column 3
 // takes all to 0.4, row 3 another 0.8 - alpha 0.5.  Index: int(mod(coord * size * 4, 4)), mod as a - 4 floor(a / 4).
@@ -673,6 +685,7 @@ RC_SIMPLE_LAUNCH(launch_mix_frames_smart, k_mix_frames_smart)
 RC_SIMPLE_LAUNCH(launch_color_matrix, k_color_matrix)
 RC_SIMPLE_LAUNCH(launch_retro_v2, k_retro_v2)
 RC_SIMPLE_LAUNCH(launch_agb001, k_agb001)
+RC_SIMPLE_LAUNCH(launch_gb_pass_5, k_gb_pass_5)
 RC_SIMPLE_LAUNCH(launch_gbc_gambatte_color, k_gbc_gambatte_color)
 RC_SIMPLE_LAUNCH(launch_shutter_3d, k_shutter_3d)
 RC_SIMPLE_LAUNCH(launch_anti_flicker, k_anti_flicker)

@@ -369,6 +369,85 @@ PRESETS["agb001-gba-color-motionblur"] = ("handheld/agb001-gba-color-motionblur.
                                           'shader1 = shaders/mgba/agb001.glsl\nfilter_linear1 = false\nscale_type1 = source\nscale1 = 4.0\n\n'
                                           'shader2 = shaders/color/gba-color.glsl\nfilter_linear2 = true\nscale_type2 = viewport\n')
 
+# handheld/console-border/: two of the 75 presets whose last pass lays a border image over the frame (gb-pass-5.glsl) - same passes,
+# keys and values as the reference's gba-lcd-grid-v2-3x.glslp and gbc-retro-v2-2x.glslp; the border PNG here is a small synthetic
+# image (tests/golden/lut_border_synthetic.png), the reference's are 1-2 MB artwork
+PRESETS["gba-lcd-grid-v2-3x"] = ("handheld/console-border/gba-lcd-grid-v2-3x.glslp", """shaders = 4
+shader0 = ../../motionblur/shaders/response-time.glsl
+shader1 = ../shaders/lcd-cgwg/lcd-grid-v2.glsl
+shader2 = ../shaders/color/gba-color.glsl
+shader3 = shader-files/gb-pass-5.glsl
+
+scale_type0 = source
+scale0 = 1
+
+scale_type1 = source
+scale1 = 3
+
+scale_type2 = source
+scale2 = 1
+
+filter_linear0 = false
+filter_linear1 = false
+filter_linear2 = false
+filter_linear3 = true
+
+textures = BORDER
+
+BORDER = resources/gba-border-square-4x.png
+BORDER_linear = true
+
+parameters = "SCALE;OUT_X;OUT_Y;RSUBPIX_R;RSUBPIX_G;RSUBPIX_B;GSUBPIX_R;GSUBPIX_G;GSUBPIX_B;BSUBPIX_R;BSUBPIX_G;BSUBPIX_B;gain;gamma;blacklevel;ambient;BGR"
+SCALE = "1.0"
+OUT_X = "2400.0"
+OUT_Y = "1200.0"
+RSUBPIX_R = "0.750000"
+RSUBPIX_G = "0.000000"
+RSUBPIX_B = "0.000000"
+GSUBPIX_R = "0.000000"
+GSUBPIX_G = "0.750000"
+GSUBPIX_B = "0.000000"
+BSUBPIX_R = "0.000000"
+BSUBPIX_G = "0.000000"
+BSUBPIX_B = "0.750000"
+gain = "1.500000"
+gamma = "2.200000"
+blacklevel = "0.000000"
+ambient = "0.000000"
+BGR = "1.000000"
+""")
+PRESETS["gbc-retro-v2-2x"] = ("handheld/console-border/gbc-retro-v2-2x.glslp", """shaders = 4
+shader0 = ../../motionblur/shaders/response-time.glsl
+shader1 = ../shaders/color/gbc-color.glsl
+shader2 = ../shaders/retro-v2.glsl
+shader3 = shader-files/gb-pass-5.glsl
+
+scale_type0 = source
+scale0 = 1
+
+scale_type1 = source
+scale1 = 1
+
+scale_type2 = source
+scale2 = 2
+
+filter_linear0 = false
+filter_linear1 = false
+filter_linear2 = false
+filter_linear3 = true
+
+textures = BORDER
+
+BORDER = resources/color-border-square-4x.png
+BORDER_linear = true
+
+parameters = "SCALE;OUT_X;OUT_Y;RETRO_PIXEL_SIZE"
+SCALE = "1.0"
+OUT_X = "1600.0"
+OUT_Y = "800.0"
+RETRO_PIXEL_SIZE = "0.55"
+""")
+
 # crt-royale with an RGBA32F last target: the last pass's floats as computed, for the curved-geometry / tex2Daa form
 PRESETS["crt-royale-f32-last"] = ("crt/crt-royale-f32-last.glslp", PRESETS["crt-royale"][1] + 'float_framebuffer11 = "true"\n')
 PRESETS["crt-royale-ntsc-256px-svideo"] = ("crt/crt-royale-ntsc-256px-svideo.glslp", _royale_ntsc("svideo-3phase", "3phase", 1536))
@@ -378,6 +457,8 @@ PRESETS["crt-royale-ntsc-320px-composite"] = ("crt/crt-royale-ntsc-320px-composi
 ASSETS = {"mask_slot_small_64.png": ("crt-royale", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png"),
           "mask_slot_small_64.png#fake-bloom": ("crt-royale-fake-bloom", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png"),
           "mask_slot_small_64.png#ntsc-256": ("crt-royale-ntsc-256px-svideo", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png"),
+          "gba-border": ("gba-lcd-grid-v2-3x", "resources/gba-border-square-4x.png", "lut_border_synthetic.png"),
+          "color-border": ("gbc-retro-v2-2x", "resources/color-border-square-4x.png", "lut_border_synthetic.png"),
           "mask_slot_small_64.png#ntsc-320": ("crt-royale-ntsc-320px-composite", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png")}
 
 ROYALE_LAST_PARAMS = [
@@ -431,6 +512,8 @@ SHADERS = {
     "handheld/shaders/color/palm-color.glsl": {"oracle": "palm_color", "params": [], "samplers": [], "size_independent": True},
     "handheld/shaders/color/psp-color.glsl": {"oracle": "psp_color", "params": [], "samplers": [], "size_independent": True},
     "handheld/shaders/color/vba-color.glsl": {"oracle": "vba_color", "params": [('darken_screen', 1.0)], "samplers": [], "size_independent": True},
+    "handheld/console-border/shader-files/gb-pass-5.glsl": {"oracle": "gb_pass_5", "samplers": ["BORDER"],
+                                                            "params": [("SCALE", 0.6667), ("OUT_X", 1600.0), ("OUT_Y", 800.0)]},
     "handheld/shaders/mgba/agb001.glsl": {"oracle": "agb001", "samplers": [], "params": []},
     "handheld/shaders/retro-v2.glsl": {"oracle": "retro_v2", "samplers": [], "params": [("RETRO_PIXEL_SIZE", 0.84)]},
     "handheld/shaders/lcd-cgwg/lcd-grid-v2.glsl": {"oracle": "lcd_grid_v2", "samplers": [],

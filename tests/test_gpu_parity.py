@@ -412,7 +412,10 @@ HISTORY_CASES = {"mix_frames_72x40_to_72x40_f3": "mix-frames", "mix_frames_48x36
                  # frame history through a pass 0 (response-time) that is not the last pass: the ring holds final outputs
                  "lcd_grid_v2_psp_color_motionblur_48x36_to_200x150_f5": "lcd-grid-v2-psp-color-motionblur",
                  "lcd_grid_v2_motionblur_48x36_to_200x150_f9": "lcd-grid-v2-motionblur",
-                 "agb001_gba_color_motionblur_48x36_to_250x190_f4": "agb001-gba-color-motionblur"}
+                 "agb001_gba_color_motionblur_48x36_to_250x190_f4": "agb001-gba-color-motionblur",
+                 # handheld/console-border/: a border image (LUT) laid over the frame by the last pass, which sits at pass index 3
+                 "console_border_gba_lcd_grid_v2_3x_48x32_to_300x200_f4": "gba-lcd-grid-v2-3x",
+                 "console_border_gbc_retro_v2_2x_40x36_to_233x171_f3": "gbc-retro-v2-2x"}
 
 
 @pytest.mark.parametrize("case", sorted(HISTORY_CASES))

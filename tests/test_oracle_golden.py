@@ -56,6 +56,8 @@ CASES = {
     "lcd_grid_v2_gbc_color_48x36_to_200x150": "lcd-grid-v2-gbc-color",
     "lcd_grid_v2_psp_color_motionblur_48x36_to_200x150_f5": "lcd-grid-v2-psp-color-motionblur",   # frame history through a pass 0 that is not the last pass
     "lcd_grid_v2_motionblur_48x36_to_200x150_f9": "lcd-grid-v2-motionblur",
+    "console_border_gba_lcd_grid_v2_3x_48x32_to_300x200_f4": "gba-lcd-grid-v2-3x",   # handheld/console-border/: border overlay (gb-pass-5) behind a history chain
+    "console_border_gbc_retro_v2_2x_40x36_to_233x171_f3": "gbc-retro-v2-2x",
     "agb001_48x36_to_250x190": "agb001",
     "agb001_gba_color_motionblur_48x36_to_250x190_f4": "agb001-gba-color-motionblur",
     "retro_v2_64x48_to_320x240": "retro-v2",
@@ -143,6 +145,18 @@ BAR = {}
 CASE_PASS_BAR = {}
 
 
+def border_luts():
+    return {"BORDER": (np.load(os.path.join(GOLD, "lut_border_synthetic.npy")), True, "clamp_to_border")}
+
+
+def luts_for(key):
+    if key.startswith("crt-royale"):
+        return royale_luts()
+    if key in ("gba-lcd-grid-v2-3x", "gbc-retro-v2-2x"):
+        return border_luts()
+    return None
+
+
 def royale_luts():
     lut = np.load(os.path.join(GOLD, "lut_mask_slot_small_64.npy"))
     return {"mask_slot_texture_small": (lut, True, "repeat")}
@@ -173,7 +187,7 @@ def run_sequence(passes, frames_rgb, vw, vh, **kw):
     return outs, st
 
 
-HISTORY_PRESETS = ("agb001-gba-color-motionblur", "lcd-grid-v2-psp-color-motionblur", "lcd-grid-v2-motionblur", "mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
+HISTORY_PRESETS = ("gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "agb001-gba-color-motionblur", "lcd-grid-v2-psp-color-motionblur", "lcd-grid-v2-motionblur", "mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
 
 
 @pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] in HISTORY_PRESETS))
@@ -185,7 +199,7 @@ def test_oracle_frame_history_matches_llvmpipe(case, tmp_path, rc_lib):
     passes = preset_passes(tmp_path, CASES[case])
     vw, vh = [int(v) for v in g["viewport"]]
     custom = dict(zip([str(n) for n in g["param_names"]], [float(v) for v in g["param_values"]])) if "param_names" in g else None
-    outs, st = run_sequence(passes, g["input_rgb"], vw, vh, custom=custom)
+    outs, st = run_sequence(passes, g["input_rgb"], vw, vh, custom=custom, luts=luts_for(CASES[case]))
     for i in range(int(g["n_passes"])):
         assert np.array_equal(outs[i], g["pass%d" % i]), "pass %d" % i
     assert len(st.history) == int(g["n_history"]) == min(7, g["input_rgb"].shape[0])
@@ -327,7 +341,7 @@ def test_oracle_arithmetic_at_float_precision(case, tmp_path, rc_lib):
         assert ulp.size == 0 or ulp.max() <= 9000, "pass %d: max %d ulp" % (i, int(ulp.max()))
 
 
-FLOAT_HISTORY = {"f32_shutter_3d_params_48x36_to_131x77_f5": "shutter-3d", "f32_anti_flicker_48x36_to_120x90_f6": "anti-flicker",
+FLOAT_HISTORY = {"f32_console_border_gbc_retro_v2_2x_40x36_to_233x171_f3": "gbc-retro-v2-2x", "f32_shutter_3d_params_48x36_to_131x77_f5": "shutter-3d", "f32_anti_flicker_48x36_to_120x90_f6": "anti-flicker",
                  "f32_mix_frames_48x36_to_120x90_f3": "mix-frames", "f32_response_time_48x36_to_120x90_f9": "response-time",
                  "f32_mix_frames_smart_48x36_to_120x90_f8": "mix-frames-smart", "f32_motionblur_simple_48x36_to_120x90_f9": "motionblur-simple"}
 
@@ -338,8 +352,9 @@ def test_frame_history_at_float_precision(case, tmp_path, rc_lib):
     passes = preset_passes(tmp_path, FLOAT_HISTORY[case])
     vw, vh = [int(v) for v in g["viewport"]]
     custom = dict(zip([str(n) for n in g["param_names"]], [float(v) for v in g["param_values"]])) if "param_names" in g else None
-    outs, st = run_sequence(passes, g["input_rgb"], vw, vh, force_f32=True, custom=custom)
-    assert np.array_equal(outs[-1].view(np.uint32), g["pass0"].view(np.uint32))
+    outs, st = run_sequence(passes, g["input_rgb"], vw, vh, force_f32=True, custom=custom, luts=luts_for(FLOAT_HISTORY[case]))
+    last = g["pass%d" % (int(g["n_passes"]) - 1)]
+    assert np.array_equal(outs[-1].view(np.uint32), last.view(np.uint32))
 
 
 WRAP_CASES = ["wrap_%s_%s_40x30_to_97x71" % (w, t) for w in ("clamp_to_edge", "clamp_to_border", "repeat", "mirrored_repeat")
