@@ -3,6 +3,7 @@
 # Regenerates the instruction lists (oracle/glrun/nir2c.py) from the NIR Mesa llvmpipe compiles for a shader of the reference:
 #   crt-royale's last pass (geometry-aa-last-pass.glsl, both stages)  -> royale_last_{vs,fs}.inc
 #   handheld/shaders/lcd-cgwg/lcd-grid-v2.glsl (fragment stage)        -> lcd_grid_v2_fs.inc
+#   handheld/shaders/lcd-cgwg/lcd-grid.glsl (fragment stage)           -> lcd_grid_fs.inc
 # written to oracle/gen/ for the oracle and, the same text, to retrocapture_amd/csrc/kernels/gen/ for the HIP kernels.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -31,4 +32,5 @@ R=crt/shaders/crt-royale/src/crt-royale-geometry-aa-last-pass.glsl
 listing "$R" LP_DEBUG=fs "$T/fs.txt" && emit "$T/fs.txt" fragment royale_last_fs
 listing "$R" GALLIVM_DEBUG=tgsi "$T/vs.txt" && emit "$T/vs.txt" vertex royale_last_vs
 listing handheld/shaders/lcd-cgwg/lcd-grid-v2.glsl LP_DEBUG=fs "$T/lcd.txt" && emit "$T/lcd.txt" fragment lcd_grid_v2_fs
+listing handheld/shaders/lcd-cgwg/lcd-grid.glsl LP_DEBUG=fs "$T/lcd1.txt" && emit "$T/lcd1.txt" fragment lcd_grid_fs
 wc -l "$ROOT"/oracle/gen/*.inc

@@ -151,6 +151,7 @@ void o_pass_response_time(const o_pass_args* a);      /* 1 param; extra[0..6] = 
 void o_pass_gb_pass_5(const o_pass_args* a);          /* 3 params; extra[0] = BORDER */
 void o_pass_agb001(const o_pass_args* a);             /* no params */
 void o_pass_retro_v2(const o_pass_args* a);           /* 1 param */
+void o_pass_lcd_grid(const o_pass_args* a);           /* 2 params (rc_passes_lcd.c) */
 void o_pass_lcd_grid_v2(const o_pass_args* a);        /* 15 params (rc_passes_lcd.c) */
 void o_pass_gba_color(const o_pass_args* a);          /* handheld/shaders/color/: 1 param (gba, gbc, vba) or none */
 void o_pass_gbc_color(const o_pass_args* a);

@@ -33,11 +33,16 @@ static void rcn_txf(void* ctx, int x, int y, float* dst) {
   dst[0] = r.x; dst[1] = r.y; dst[2] = r.z; dst[3] = r.w;
 }
 #define RCN_TXF(ctx, unit, x, y, dst) rcn_txf(ctx, x, y, dst)
-#define RCN_TEX(ctx, unit, u, v, dst) ((void)0)
+static void rcn_tex(void* ctx, float u, float v, float* dst) {
+  const o_vec4 r = o_sample((const o_tex*)ctx, u, v);
+  dst[0] = r.x; dst[1] = r.y; dst[2] = r.z; dst[3] = r.w;
+}
+#define RCN_TEX(ctx, unit, u, v, dst) rcn_tex(ctx, u, v, dst)
 
 #pragma GCC diagnostic push
 #pragma GCC diagnostic ignored "-Wunused-but-set-variable"
 #include "gen/lcd_grid_v2_fs.inc"
+#include "gen/lcd_grid_fs.inc"
 #pragma GCC diagnostic pop
 
 void o_pass_lcd_grid_v2(const o_pass_args* a) {
@@ -54,6 +59,27 @@ void o_pass_lcd_grid_v2(const o_pass_args* a) {
       const float in[2] = {o_varying_at(&tu, x, y, lo), o_varying_at(&tv, x, y, lo)};
       float out[4];
       lcd_grid_v2_fs(U, in, out, (void*)a->in);
+      const o_vec4 o = {out[0], out[1], out[2], out[3]};
+      o_store_pixel(a, x, y, o);
+    }
+  o_fp_leave(csr);
+}
+
+/* handheld/shaders/lcd-cgwg/lcd-grid.glsl (handheld/lcd-grid.glslp, nds.glslp and twenty console-border presets): the first version
+ * of the same idea - four sampled texels (texture(), not texelFetch) under the subpixel integrals, one GRID_STRENGTH and an input
+ * gamma; ~560 operations, the GL's own instruction list again (gen/lcd_grid_fs.inc), pinned by tests/golden/lcd_grid_*.
+ * params: GRID_STRENGTH, gamma. */
+void o_pass_lcd_grid(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  float U[8] = {(float)W, (float)H, (float)a->in->w, (float)a->in->h, (float)a->in->w, (float)a->in->h, a->params[0], a->params[1]};
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float in[2] = {o_varying_at(&tu, x, y, lo), o_varying_at(&tv, x, y, lo)};
+      float out[4];
+      lcd_grid_fs(U, in, out, (void*)a->in);
       const o_vec4 o = {out[0], out[1], out[2], out[3]};
       o_store_pixel(a, x, y, o);
     }

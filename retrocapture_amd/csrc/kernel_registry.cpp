@@ -439,6 +439,9 @@ std::vector<KernelEntry> build() {
   r.push_back({"motionblur/shaders/mix_frames_smart.glsl", "mix-frames-smart", {{"DEFLICKER_EMPHASIS", 0.0f, 0.0f, 1.0f, 0.01f, "Deflicker Emphasis"}},
                {"PrevTexture", "Prev1Texture", "Prev2Texture", "Prev3Texture", "Prev4Texture"},
                rck::launch_mix_frames_smart, setupCrtPi, false, true, nullptr, nullptr, true});   // VS: TEX0 = TexCoord * 1.0001
+  r.push_back({"handheld/shaders/lcd-cgwg/lcd-grid.glsl", "lcd-grid",
+               {{"GRID_STRENGTH", 0.05f, 0.0f, 1.0f, 0.01f, "LCD Grid Strength"}, {"gamma", 2.2f, 1.0f, 5.0f, 0.1f, "LCD Input Gamma"}}, {},
+               rck::launch_lcd_grid, setupTexCoord, false});
   // handheld/lcd-grid-v2.glslp and the lcd-grid-v2-<colour>[-motionblur] chains (kernels/pass_lcd_grid.hip)
   r.push_back({"handheld/shaders/lcd-cgwg/lcd-grid-v2.glsl", "lcd-grid-v2",
                {{"RSUBPIX_R", 1.0f, 0.0f, 1.0f, 0.01f, "Colour of R subpixel: R"}, {"RSUBPIX_G", 0.0f, 0.0f, 1.0f, 0.01f, "Colour of R subpixel: G"},

@@ -41,6 +41,14 @@ __device__ __forceinline__ void rcn_txf(void* vctx, int x, int y, float* dst) {
   dst[2] = r.z;
   dst[3] = r.w;
 }
+__device__ __forceinline__ void rcn_tex(void* vctx, float u, float v, float* dst) {
+  const TexCtx* c = static_cast<const TexCtx*>(vctx);
+  const float4 r = sample_rt(*c->t, c->img, u, v, c->lds);
+  dst[0] = r.x;
+  dst[1] = r.y;
+  dst[2] = r.z;
+  dst[3] = r.w;
+}
 // cvttps2dq: the "integer indefinite" value for NaN and out-of-range inputs
 __device__ __forceinline__ int rcn_f2i(float x) { return (x != x || x >= 2147483648.0f || x < -2147483648.0f) ? (-2147483647 - 1) : (int)x; }
 __device__ __forceinline__ float rcn_min(float a, float b) { return b != b ? a : (a < b ? a : b); }   // gallivm's fmin / fmax: the operand that is not NaN
@@ -58,11 +66,12 @@ __device__ __forceinline__ float rcn_pow(float x, float y) { return x != x ? 0.0
 #define RCN_MAX(a, b) rcn_max(a, b)
 #define RCN_POW(a, b) rcn_pow(a, b)
 #define RCN_TXF(ctx, unit, x, y, dst) rcn_txf(ctx, x, y, dst)
-#define RCN_TEX(ctx, unit, u, v, dst) ((void)0)
+#define RCN_TEX(ctx, unit, u, v, dst) rcn_tex(ctx, u, v, dst)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wunused-but-set-variable"
 #pragma clang diagnostic ignored "-Wunused-variable"
 #include "gen/lcd_grid_v2_fs.inc"
+#include "gen/lcd_grid_fs.inc"
 #pragma clang diagnostic pop
 
 // params[0..14]: the shader's 15 #pragma parameters in declaration order = dwords 6..20 of its uniform block
@@ -86,9 +95,28 @@ __global__ void __launch_bounds__(256) k_lcd_grid_v2(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// handheld/shaders/lcd-cgwg/lcd-grid.glsl (handheld/lcd-grid.glslp, nds.glslp, twenty console-border presets): the first version of the
+// same idea - four texture() samples under the subpixel integrals, one GRID_STRENGTH, an input gamma.  ~560 operations in the GL's
+// own order (gen/lcd_grid_fs.inc).  params[0..1]: GRID_STRENGTH, gamma = dwords 6, 7 of the uniform block.
+__global__ void __launch_bounds__(256) k_lcd_grid(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const float U[8] = {(float)L.out_w, (float)L.out_h, (float)L.in.w, (float)L.in.h, (float)L.in.w, (float)L.in.h, L.params[0], L.params[1]};
+  RC_TILE_LOOP_BEGIN
+  const float in[2] = {vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo)};
+  float out[4];
+  TexCtx ctx{&L.in, frame_ptr(L.in, z), &lds};
+  lcd_grid_fs(U, in, out, &ctx);
+  store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], out[3]), &lds);
+  RC_TILE_LOOP_END
+}
+
 }  // namespace
 
 namespace rck {
+hipError_t launch_lcd_grid(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_lcd_grid, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  return hipGetLastError();
+}
 hipError_t launch_lcd_grid_v2(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL(k_lcd_grid_v2, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();

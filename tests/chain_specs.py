@@ -361,6 +361,45 @@ for _c, _blk in (("gba", 'parameters = "darken_screen;RETRO_PIXEL_SIZE"\ndarken_
                                          'shaders = "2"\n\nshader0 = "../handheld/shaders/color/%s-color.glsl"\nshader1 = "../handheld/shaders/retro-v2.glsl"\n\n'
                                          'filter_linear0 = "false"\nscale_type0 = "source"\nscale0 = "1.000000"\n\nfilter_linear1 = "false"\n\n' % _c + _blk)
 
+# handheld/lcd-grid.glslp, and handheld/console-border/gba-3x.glslp (motionblur-simple, gba-color, lcd-grid, border overlay): same
+# keys / values as the reference's files
+PRESETS["lcd-grid"] = ("handheld/lcd-grid.glslp", 'shaders = 1\n\nshader0 = shaders/lcd-cgwg/lcd-grid.glsl\nfilter_linear0 = false')
+PRESETS["gba-3x"] = ("handheld/console-border/gba-3x.glslp", """shaders = "4"
+
+shader0 = "../../motionblur/shaders/motionblur-simple.glsl"
+scale_type0 = source
+scale0 = 1.0
+filter_linear0 = false
+
+shader1 = "../shaders/color/gba-color.glsl"
+filter_linear1 = false
+
+shader2 = "../shaders/lcd-cgwg/lcd-grid.glsl"
+filter_linear2 = "false"
+wrap_mode2 = "clamp_to_border"
+scale_type_x2 = "source"
+scale_x2 = "3.000000"
+scale_type_y2 = "source"
+scale_y2 = "3.000000"
+
+shader3 = "shader-files/gb-pass-5.glsl"
+filter_linear3 = "true"
+wrap_mode3 = "clamp_to_border"
+
+parameters = "SCALE;OUT_X;OUT_Y;GRID_STRENGTH;mixfactor"
+GRID_STRENGTH = "0.150000"
+SCALE = "1.0"
+OUT_X = "2400.0"
+OUT_Y = "1200.0"
+mixfactor = "0.50"
+
+textures = "BORDER"
+BORDER = "resources/gba-border-square-4x.png"
+BORDER_linear = "true"
+BORDER_wrap_mode = "clamp_to_border"
+BORDER_mipmap = "false"
+""")
+
 # handheld/agb001.glslp and agb001-gba-color-motionblur.glslp: same keys / values as the reference's files
 PRESETS["agb001"] = ("handheld/agb001.glslp", 'shaders = 2\n\nshader0 = shaders/mgba/agb001.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 4.0\n\n'
                      'shader1 = ../stock.glsl\nfilter_linear1 = true\nscale_type1 = viewport\n')
@@ -458,6 +497,7 @@ ASSETS = {"mask_slot_small_64.png": ("crt-royale", "shaders/crt-royale/mask_slot
           "mask_slot_small_64.png#fake-bloom": ("crt-royale-fake-bloom", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png"),
           "mask_slot_small_64.png#ntsc-256": ("crt-royale-ntsc-256px-svideo", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png"),
           "gba-border": ("gba-lcd-grid-v2-3x", "resources/gba-border-square-4x.png", "lut_border_synthetic.png"),
+          "gba-border#gba-3x": ("gba-3x", "resources/gba-border-square-4x.png", "lut_border_synthetic.png"),
           "color-border": ("gbc-retro-v2-2x", "resources/color-border-square-4x.png", "lut_border_synthetic.png"),
           "mask_slot_small_64.png#ntsc-320": ("crt-royale-ntsc-320px-composite", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png")}
 
@@ -516,6 +556,7 @@ SHADERS = {
                                                             "params": [("SCALE", 0.6667), ("OUT_X", 1600.0), ("OUT_Y", 800.0)]},
     "handheld/shaders/mgba/agb001.glsl": {"oracle": "agb001", "samplers": [], "params": []},
     "handheld/shaders/retro-v2.glsl": {"oracle": "retro_v2", "samplers": [], "params": [("RETRO_PIXEL_SIZE", 0.84)]},
+    "handheld/shaders/lcd-cgwg/lcd-grid.glsl": {"oracle": "lcd_grid", "samplers": [], "params": [("GRID_STRENGTH", 0.05), ("gamma", 2.2)]},
     "handheld/shaders/lcd-cgwg/lcd-grid-v2.glsl": {"oracle": "lcd_grid_v2", "samplers": [],
                                                    "params": [("RSUBPIX_R", 1.0), ("RSUBPIX_G", 0.0), ("RSUBPIX_B", 0.0), ("GSUBPIX_R", 0.0), ("GSUBPIX_G", 1.0),
                                                               ("GSUBPIX_B", 0.0), ("BSUBPIX_R", 0.0), ("BSUBPIX_G", 0.0), ("BSUBPIX_B", 1.0), ("gain", 1.0),

@@ -495,6 +495,19 @@ def case_hyllian_glow():
              params=[("HFILTER_SHARPNESS", 0.7), ("CRT_ANTI_RINGING", 0.6), ("MASK_INTENSITY", 0.7), ("PHOSPHOR_LAYOUT", 5.0)])
 
 
+def case_lcd_grid():
+    G = GLSL + "/handheld/lcd-grid.glslp"
+    run_case("lcd_grid_64x48_to_320x240", G, mixed(64, 48, 140), 320, 240)
+    run_case("lcd_grid_params_40x30_to_233x171", G, noise(40, 30, 141), 233, 171, params=[("GRID_STRENGTH", 0.3), ("gamma", 1.7)])
+    run_case("f32_lcd_grid_params_48x36_to_240x180", G, mixed(48, 36, 142), 240, 180, f32=True, params=[("GRID_STRENGTH", 0.2), ("gamma", 2.6)])
+    border = np.load(os.path.join(HERE, "lut_border_synthetic.npy"))
+    with tempfile.TemporaryDirectory() as d:
+        raw = os.path.join(d, "border.rgba")
+        border.tofile(raw)
+        run_case("console_border_gba_3x_48x32_to_300x200_f9", GLSL + "/handheld/console-border/gba-3x.glslp", moving(48, 32, 9, 143), 300, 200,
+                 luts=[("BORDER", (raw, border.shape[1], border.shape[0]))])
+
+
 def case_console_border():
     """handheld/console-border/: gb-pass-5.glsl lays a border image over the scaled frame.  The border here is the small synthetic
     image of tests/golden/lut_border_synthetic.npy handed to the runner as raw texels (the reference's PNGs are 1-2 MB artwork)."""
@@ -742,7 +755,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

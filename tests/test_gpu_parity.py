@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "lcd_grid_64x48_to_320x240": "lcd-grid",
+    "lcd_grid_params_40x30_to_233x171": "lcd-grid",
     "agb001_48x36_to_250x190": "agb001",
     "retro_v2_64x48_to_320x240": "retro-v2",
     "retro_v2_params_40x30_to_233x171": "retro-v2",
@@ -415,7 +417,8 @@ HISTORY_CASES = {"mix_frames_72x40_to_72x40_f3": "mix-frames", "mix_frames_48x36
                  "agb001_gba_color_motionblur_48x36_to_250x190_f4": "agb001-gba-color-motionblur",
                  # handheld/console-border/: a border image (LUT) laid over the frame by the last pass, which sits at pass index 3
                  "console_border_gba_lcd_grid_v2_3x_48x32_to_300x200_f4": "gba-lcd-grid-v2-3x",
-                 "console_border_gbc_retro_v2_2x_40x36_to_233x171_f3": "gbc-retro-v2-2x"}
+                 "console_border_gbc_retro_v2_2x_40x36_to_233x171_f3": "gbc-retro-v2-2x",
+                 "console_border_gba_3x_48x32_to_300x200_f9": "gba-3x"}
 
 
 @pytest.mark.parametrize("case", sorted(HISTORY_CASES))

@@ -58,6 +58,9 @@ CASES = {
     "lcd_grid_v2_motionblur_48x36_to_200x150_f9": "lcd-grid-v2-motionblur",
     "console_border_gba_lcd_grid_v2_3x_48x32_to_300x200_f4": "gba-lcd-grid-v2-3x",   # handheld/console-border/: border overlay (gb-pass-5) behind a history chain
     "console_border_gbc_retro_v2_2x_40x36_to_233x171_f3": "gbc-retro-v2-2x",
+    "lcd_grid_64x48_to_320x240": "lcd-grid",
+    "lcd_grid_params_40x30_to_233x171": "lcd-grid",
+    "console_border_gba_3x_48x32_to_300x200_f9": "gba-3x",      # motionblur-simple (Prev .. Prev6, full ring) in front of a 4-pass chain with a border LUT
     "agb001_48x36_to_250x190": "agb001",
     "agb001_gba_color_motionblur_48x36_to_250x190_f4": "agb001-gba-color-motionblur",
     "retro_v2_64x48_to_320x240": "retro-v2",
@@ -152,7 +155,7 @@ def border_luts():
 def luts_for(key):
     if key.startswith("crt-royale"):
         return royale_luts()
-    if key in ("gba-lcd-grid-v2-3x", "gbc-retro-v2-2x"):
+    if key in ("gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "gba-3x"):
         return border_luts()
     return None
 
@@ -187,7 +190,7 @@ def run_sequence(passes, frames_rgb, vw, vh, **kw):
     return outs, st
 
 
-HISTORY_PRESETS = ("gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "agb001-gba-color-motionblur", "lcd-grid-v2-psp-color-motionblur", "lcd-grid-v2-motionblur", "mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
+HISTORY_PRESETS = ("gba-3x", "gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "agb001-gba-color-motionblur", "lcd-grid-v2-psp-color-motionblur", "lcd-grid-v2-motionblur", "mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
 
 
 @pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] in HISTORY_PRESETS))
@@ -289,6 +292,7 @@ FLOAT_CASES = {
     "f32_palm_color_48x36_to_131x77": ("palm-color", {}),
     "f32_psp_color_48x36_to_131x77": ("psp-color", {}),
     "f32_vba_color_48x36_to_131x77": ("vba-color", {}),
+    "f32_lcd_grid_params_48x36_to_240x180": ("lcd-grid", {}),
     "f32_agb001_40x30_to_233x171": ("agb001", {}),
     "f32_retro_v2_48x36_to_240x180": ("retro-v2", {}),
     "f32_lcd_grid_v2_48x36_to_240x180": ("lcd-grid-v2", {}),
