@@ -879,3 +879,42 @@ void o_pass_gb_pass_5(const o_pass_args* a) {
     }
   o_fp_leave(csr);
 }
+
+/* borders/resources/imgborder-{sgb,gameboy-player,sgba}.glsl (one text, three sets of #pragma defaults; borders/sgb/, gameboy-player/,
+ * sgba/ presets): the frame placed inside a border image, which covers it by its own alpha - or not at all inside the viewport when
+ * border_on_top is set.  VS 93-103 / FS 165-173 in the GL's operation order.
+ * params: box_scale, location_x, location_y, in_res_x, in_res_y, border_on_top, border_zoom_x, border_zoom_y, OS_MASK_TOP, OS_MASK_BOTTOM,
+ * OS_MASK_LEFT, OS_MASK_RIGHT; extra[0] = BORDER. */
+void o_pass_imgborder(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  const float* P = a->params;
+  const float osx = (float)W, osy = (float)H, isx = (float)a->in->w, isy = (float)a->in->h, tsx = isx;
+  const float tsy = (a->pass_index == 3 && H != a->in->h) ? (float)H : isy;   /* the reference's TextureSize.y rule for pass index 3 */
+  const float mx = (P[1] * isx) / tsx, my = (P[2] * isy) / tsy;
+  const float scx = (osx / P[3]) / P[0], scy = (osy / P[4]) / P[0];
+  const float rx = tsx / isx, ry = tsy / isy;
+  float v[4][4];
+  static const float tc[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+  for (int k = 0; k < 4; ++k) {
+    v[k][0] = mx + (tc[k][0] + -mx) * scx;                       /* screen_coord */
+    v[k][1] = my + (tc[k][1] + -my) * scy;
+    v[k][2] = 0.4999f + (tc[k][0] * rx + -0.4999f) * P[6];       /* TEX0: the border image, zoomed about its centre */
+    v[k][3] = 0.4999f + (tc[k][1] * ry + -0.4999f) * P[7];
+  }
+  o_varying pl[4];
+  for (int c = 0; c < 4; ++c) pl[c] = o_varying_setup(v[0][c], v[1][c], v[2][c], v[3][c], W, H, a->out_fmt);
+  const float x_hi = 0.9999f + -P[11], x_lo = 0.0001f + P[10], y_hi = 0.9999f + -P[9], y_lo = 0.0001f + P[8];
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float sx = o_varying_at(&pl[0], x, y, lo), sy = o_varying_at(&pl[1], x, y, lo);
+      const o_vec4 f = o_sample(a->in, sx, sy);
+      const o_vec4 b = o_sample(a->extra[0], o_varying_at(&pl[2], x, y, lo), o_varying_at(&pl[3], x, y, lo));
+      const int inside = sx < x_hi && x_lo < sx && sy < y_hi && y_lo < sy && 0.5f < P[5];
+      const float al = inside ? 0.0f : b.w;
+      const o_vec4 out = {f.x + al * (b.x + -f.x), f.y + al * (b.y + -f.y), f.z + al * (b.z + -f.z), f.w + al * (al + -f.w)};
+      store_px(a, x, y, out);
+    }
+  o_fp_leave(csr);
+}

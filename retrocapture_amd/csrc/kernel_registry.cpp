@@ -97,6 +97,24 @@ void setupGbPass5(const PassGeometry& g, rcd::PassLaunch& L) {
   }
   for (int c = 0; c < 4; ++c) L.plane[c] = makePlane(v[0][c], v[1][c], v[2][c], v[3][c], g.out_w, g.out_h, g.out_fmt);
 }
+// imgborder-*.glsl VS 93-103: screen_coord (the frame placed and scaled) and TEX0 (the border zoomed about its centre) at the vertices
+void setupImgBorder(const PassGeometry& g, rcd::PassLaunch& L) {
+  const float* P = L.params;
+  const float osx = (float)g.out_w, osy = (float)g.out_h, isx = (float)g.in_w, isy = (float)g.in_h, tsx = isx;
+  const float tsy = (g.pass_index == 3 && g.out_h != g.in_h) ? (float)g.out_h : isy;   // the reference's TextureSize.y rule for pass index 3
+  const float mx = (P[1] * isx) / tsx, my = (P[2] * isy) / tsy;
+  const float scx = (osx / P[3]) / P[0], scy = (osy / P[4]) / P[0];
+  const float rx = tsx / isx, ry = tsy / isy;
+  static const float tc[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};   // BL, BR, TR, TL
+  float v[4][4];
+  for (int k = 0; k < 4; ++k) {
+    v[k][0] = mx + (tc[k][0] + -mx) * scx;
+    v[k][1] = my + (tc[k][1] + -my) * scy;
+    v[k][2] = 0.4999f + (tc[k][0] * rx + -0.4999f) * P[6];
+    v[k][3] = 0.4999f + (tc[k][1] * ry + -0.4999f) * P[7];
+  }
+  for (int c = 0; c < 4; ++c) L.plane[c] = makePlane(v[0][c], v[1][c], v[2][c], v[3][c], g.out_w, g.out_h, g.out_fmt);
+}
 // shutter-3d.glsl VS 61-73: left_coord / right_coord at the quad's vertices, in the GL's operation order (oracle/rc_passes_basic.c)
 void setupShutter3d(const PassGeometry& g, rcd::PassLaunch& L) {
   const float* P = L.params;
@@ -453,6 +471,25 @@ std::vector<KernelEntry> build() {
                 {"blacklevel", 0.05f, 0.0f, 0.5f, 0.01f, "Black level"}, {"ambient", 0.0f, 0.0f, 0.5f, 0.01f, "Ambient"},
                 {"BGR", 0.0f, 0.0f, 1.0f, 1.0f, "BGR"}},
                {}, rck::launch_lcd_grid_v2, setupTexCoord, false});
+  {
+    // borders/resources/imgborder-{sgb,gameboy-player,sgba}.glsl: one text, three sets of #pragma defaults
+    struct D { const char* id; const char* name; float box, rx, ry; };
+    static const D variants[] = {{"borders/resources/imgborder-sgb.glsl", "imgborder-sgb", 1.0f, 160.0f, 144.0f},
+                                 {"borders/resources/imgborder-gameboy-player.glsl", "imgborder-gameboy-player", 2.0f, 240.0f, 160.0f},
+                                 {"borders/resources/imgborder-sgba.glsl", "imgborder-sgba", 1.0f, 240.0f, 160.0f}};
+    for (const D& d : variants) {
+      KernelEntry e{d.id, d.name,
+                    {{"box_scale", d.box, 1.0f, 10.0f, 1.0f, "Image Scale"}, {"location_x", 0.5f, 0.0f, 1.0f, 0.05f, "Viewport X Pos."},
+                     {"location_y", 0.5f, 0.0f, 1.0f, 0.05f, "Viewport Y Pos."}, {"in_res_x", d.rx, 100.0f, 600.0f, 1.0f, "Viewport Size X"},
+                     {"in_res_y", d.ry, 64.0f, 512.0f, 1.0f, "Viewport Size Y"}, {"border_on_top", 0.0f, 0.0f, 1.0f, 1.0f, "Show Viewport"},
+                     {"border_zoom_x", 1.0f, 0.0f, 4.0f, 0.01f, "Border Zoom X"}, {"border_zoom_y", 1.0f, 0.0f, 4.0f, 0.01f, "Border Zoom Y"},
+                     {"OS_MASK_TOP", 0.0f, 0.0f, 1.0f, 0.01f, "OS Mask Top"}, {"OS_MASK_BOTTOM", 0.0f, 0.0f, 1.0f, 0.01f, "OS Mask Bottom"},
+                     {"OS_MASK_LEFT", 0.0f, 0.0f, 1.0f, 0.01f, "OS Mask Left"}, {"OS_MASK_RIGHT", 0.0f, 0.0f, 1.0f, 0.01f, "OS Mask Right"}},
+                    {"BORDER"}, rck::launch_imgborder, setupImgBorder, false};
+      e.texture_height_override = true;   // setupImgBorder reads PassGeometry::pass_index
+      r.push_back(e);
+    }
+  }
   r.push_back({"handheld/console-border/shader-files/gb-pass-5.glsl", "gb-pass-5",
                {{"SCALE", 0.6667f, 0.6667f, 1.5f, 0.33333f, "Box Scale"}, {"OUT_X", 1600.0f, 1600.0f, 4800.0f, 8000.0f, "Out X"},
                 {"OUT_Y", 800.0f, 800.0f, 2400.0f, 400.0f, "Out Y"}},

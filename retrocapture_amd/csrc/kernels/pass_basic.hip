@@ -166,6 +166,24 @@ __global__ void __launch_bounds__(256) k_gb_pass_5(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// borders/resources/imgborder-{sgb,gameboy-player,sgba}.glsl FS 165-173 (one text, three sets of defaults): the frame inside a border image
+// that covers it by its own alpha, or not at all inside the viewport when border_on_top is set.  plane[0..1] = screen_coord,
+// plane[2..3] = TEX0 (registry: setupImgBorder); params[5] border_on_top, [8..11] OS_MASK_TOP / BOTTOM / LEFT / RIGHT; extra[0] = BORDER.
+__global__ void __launch_bounds__(256) k_imgborder(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const float* P = L.params;
+  const float x_hi = 0.9999f + -P[11], x_lo = 0.0001f + P[10], y_hi = 0.9999f + -P[9], y_lo = 0.0001f + P[8];
+  const bool on_top = 0.5f < P[5];
+  RC_TILE_LOOP_BEGIN
+  const float sx = vary(L.plane[0], x, y, lo), sy = vary(L.plane[1], x, y, lo);
+  const float4 f = sample_rt(L.in, frame_ptr(L.in, z), sx, sy, &lds);
+  const float4 b = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), vary(L.plane[2], x, y, lo), vary(L.plane[3], x, y, lo), &lds);
+  const bool inside = sx < x_hi && x_lo < sx && sy < y_hi && y_lo < sy && on_top;
+  const float al = inside ? 0.0f : b.w;
+  store_rt(L, z, x, y, make_float4(f.x + al * (b.x + -f.x), f.y + al * (b.y + -f.y), f.z + al * (b.z + -f.z), f.w + al * (al + -f.w)), &lds);
+  RC_TILE_LOOP_END
+}
+
 // handheld/shaders/mgba/agb001.glsl FS main (handheld/agb001.glslp, agb001-gba-color-motionblur.glslp): pow(texel * 0.8, 1.8) + 0.16 under
 // a 4x4 subpixel pattern per source texel - column 0 / 1 / 2 keeps red / green / blue and takes the other two to 0.2, column 3
 // takes all to 0.4, row 3 another 0.8 - alpha 0.5.  Index: int(mod(coord * size * 4, 4)), mod as a - 4 floor(a / 4).
@@ -686,6 +704,7 @@ RC_SIMPLE_LAUNCH(launch_color_matrix, k_color_matrix)
 RC_SIMPLE_LAUNCH(launch_retro_v2, k_retro_v2)
 RC_SIMPLE_LAUNCH(launch_agb001, k_agb001)
 RC_SIMPLE_LAUNCH(launch_gb_pass_5, k_gb_pass_5)
+RC_SIMPLE_LAUNCH(launch_imgborder, k_imgborder)
 RC_SIMPLE_LAUNCH(launch_gbc_gambatte_color, k_gbc_gambatte_color)
 RC_SIMPLE_LAUNCH(launch_shutter_3d, k_shutter_3d)
 RC_SIMPLE_LAUNCH(launch_anti_flicker, k_anti_flicker)

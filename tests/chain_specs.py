@@ -361,6 +361,48 @@ for _c, _blk in (("gba", 'parameters = "darken_screen;RETRO_PIXEL_SIZE"\ndarken_
                                          'shaders = "2"\n\nshader0 = "../handheld/shaders/color/%s-color.glsl"\nshader1 = "../handheld/shaders/retro-v2.glsl"\n\n'
                                          'filter_linear0 = "false"\nscale_type0 = "source"\nscale0 = "1.000000"\n\nfilter_linear1 = "false"\n\n' % _c + _blk)
 
+# borders/sgb/sgb-crt-geom-1x.glslp and borders/gameboy-player/gameboy-player.glslp (same keys / values; synthetic border image, see above)
+PRESETS["sgb-crt-geom-1x"] = ("borders/sgb/sgb-crt-geom-1x.glslp", """shaders = 2
+
+textures = "BORDER"
+BORDER = "sgb.png"
+BORDER_linear = true
+
+# Pass0: Apply Game Boy Player border
+shader0 = "../resources/imgborder-sgb.glsl"
+scale_type_x0 = "absolute"
+scale_x0 = "256"
+scale_type_y0 = "absolute"
+scale_y0 = "224"
+
+shader1 = "../../crt/shaders/crt-geom.glsl"
+
+parameters = "box_scale;in_res_x;in_res_y;border_on_top"
+box_scale = 1.0
+in_res_x = 160.0
+in_res_y = 144.0
+border_on_top = 0.0
+""")
+PRESETS["gameboy-player"] = ("borders/gameboy-player/gameboy-player.glslp", """shaders = "1"
+shader0 = "../resources/imgborder-gameboy-player.glsl"
+
+scale_type_x0 = "absolute"
+scale_x0 = "608"
+scale_type_y0 = "absolute"
+scale_y0 = "448"
+
+parameters = "box_scale;location;in_res_x;in_res_y"
+box_scale = "2.000000"
+location = "0.500000"
+in_res_x = "240.000000"
+in_res_y = "160.000000"
+
+textures = "BORDER"
+BORDER = "gameboy-player.png"
+""")
+# the sgb shader alone, without a parameter block (a one-pass chain of this repository): every parameter can move
+PRESETS["imgborder-sgb-bare"] = ("borders/sgb/imgborder-sgb-bare.glslp", 'shaders = 1\nshader0 = "../resources/imgborder-sgb.glsl"\ntextures = "BORDER"\nBORDER = "sgb.png"\nBORDER_linear = true\n')
+
 # handheld/lcd-grid.glslp, and handheld/console-border/gba-3x.glslp (motionblur-simple, gba-color, lcd-grid, border overlay): same
 # keys / values as the reference's files
 PRESETS["lcd-grid"] = ("handheld/lcd-grid.glslp", 'shaders = 1\n\nshader0 = shaders/lcd-cgwg/lcd-grid.glsl\nfilter_linear0 = false')
@@ -498,6 +540,8 @@ ASSETS = {"mask_slot_small_64.png": ("crt-royale", "shaders/crt-royale/mask_slot
           "mask_slot_small_64.png#ntsc-256": ("crt-royale-ntsc-256px-svideo", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png"),
           "gba-border": ("gba-lcd-grid-v2-3x", "resources/gba-border-square-4x.png", "lut_border_synthetic.png"),
           "gba-border#gba-3x": ("gba-3x", "resources/gba-border-square-4x.png", "lut_border_synthetic.png"),
+          "sgb-border": ("sgb-crt-geom-1x", "sgb.png", "lut_border_synthetic.png"),
+          "gbp-border": ("gameboy-player", "gameboy-player.png", "lut_border_synthetic.png"),
           "color-border": ("gbc-retro-v2-2x", "resources/color-border-square-4x.png", "lut_border_synthetic.png"),
           "mask_slot_small_64.png#ntsc-320": ("crt-royale-ntsc-320px-composite", "shaders/crt-royale/mask_slot_small_64.png", "lut_mask_slot_small_64.png")}
 
@@ -552,6 +596,9 @@ SHADERS = {
     "handheld/shaders/color/palm-color.glsl": {"oracle": "palm_color", "params": [], "samplers": [], "size_independent": True},
     "handheld/shaders/color/psp-color.glsl": {"oracle": "psp_color", "params": [], "samplers": [], "size_independent": True},
     "handheld/shaders/color/vba-color.glsl": {"oracle": "vba_color", "params": [('darken_screen', 1.0)], "samplers": [], "size_independent": True},
+    "borders/resources/imgborder-sgb.glsl": {"oracle": "imgborder", "samplers": ["BORDER"], "params": [("box_scale", 1.0), ("location_x", 0.5), ("location_y", 0.5), ("in_res_x", 160.0), ("in_res_y", 144.0), ("border_on_top", 0.0), ("border_zoom_x", 1.0), ("border_zoom_y", 1.0), ("OS_MASK_TOP", 0.0), ("OS_MASK_BOTTOM", 0.0), ("OS_MASK_LEFT", 0.0), ("OS_MASK_RIGHT", 0.0)]},
+    "borders/resources/imgborder-gameboy-player.glsl": {"oracle": "imgborder", "samplers": ["BORDER"], "params": [("box_scale", 2.0), ("location_x", 0.5), ("location_y", 0.5), ("in_res_x", 240.0), ("in_res_y", 160.0), ("border_on_top", 0.0), ("border_zoom_x", 1.0), ("border_zoom_y", 1.0), ("OS_MASK_TOP", 0.0), ("OS_MASK_BOTTOM", 0.0), ("OS_MASK_LEFT", 0.0), ("OS_MASK_RIGHT", 0.0)]},
+    "borders/resources/imgborder-sgba.glsl": {"oracle": "imgborder", "samplers": ["BORDER"], "params": [("box_scale", 1.0), ("location_x", 0.5), ("location_y", 0.5), ("in_res_x", 240.0), ("in_res_y", 160.0), ("border_on_top", 0.0), ("border_zoom_x", 1.0), ("border_zoom_y", 1.0), ("OS_MASK_TOP", 0.0), ("OS_MASK_BOTTOM", 0.0), ("OS_MASK_LEFT", 0.0), ("OS_MASK_RIGHT", 0.0)]},
     "handheld/console-border/shader-files/gb-pass-5.glsl": {"oracle": "gb_pass_5", "samplers": ["BORDER"],
                                                             "params": [("SCALE", 0.6667), ("OUT_X", 1600.0), ("OUT_Y", 800.0)]},
     "handheld/shaders/mgba/agb001.glsl": {"oracle": "agb001", "samplers": [], "params": []},

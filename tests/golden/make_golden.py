@@ -495,6 +495,23 @@ def case_hyllian_glow():
              params=[("HFILTER_SHARPNESS", 0.7), ("CRT_ANTI_RINGING", 0.6), ("MASK_INTENSITY", 0.7), ("PHOSPHOR_LAYOUT", 5.0)])
 
 
+def case_imgborder():
+    """borders/: imgborder-{sgb,gameboy-player}.glsl (one shader text) - alone, in front of crt-geom, and with every parameter moved."""
+    B = GLSL + "/borders/"
+    border = np.load(os.path.join(HERE, "lut_border_synthetic.npy"))
+    with tempfile.TemporaryDirectory() as d:
+        raw = os.path.join(d, "border.rgba")
+        border.tofile(raw)
+        luts = [("BORDER", (raw, border.shape[1], border.shape[0]))]
+        run_case("imgborder_gameboy_player_60x40_to_304x224", B + "gameboy-player/gameboy-player.glslp", mixed(60, 40, 150), 304, 224, luts=luts)
+        run_case("imgborder_sgb_crt_geom_1x_40x36_to_256x224", B + "sgb/sgb-crt-geom-1x.glslp", mixed(40, 36, 151), 256, 224, luts=luts)
+        p = write_preset(d, 'shaders = 1\nshader0 = %s/borders/resources/imgborder-sgb.glsl\ntextures = "BORDER"\nBORDER = "sgb.png"\nBORDER_linear = true\n' % GLSL)
+        prm = [("box_scale", 2.0), ("location_x", 0.45), ("location_y", 0.6), ("in_res_x", 120.0), ("in_res_y", 90.0), ("border_on_top", 1.0),
+               ("border_zoom_x", 1.3), ("border_zoom_y", 0.8), ("OS_MASK_TOP", 0.05), ("OS_MASK_BOTTOM", 0.1), ("OS_MASK_LEFT", 0.02), ("OS_MASK_RIGHT", 0.07)]
+        run_case("imgborder_sgb_bare_params_40x30_to_233x171", p, noise(40, 30, 152), 233, 171, luts=luts, params=prm)
+        run_case("f32_imgborder_sgb_bare_params_40x30_to_233x171", p, noise(40, 30, 153), 233, 171, luts=luts, params=prm, f32=True)
+
+
 def case_lcd_grid():
     G = GLSL + "/handheld/lcd-grid.glslp"
     run_case("lcd_grid_64x48_to_320x240", G, mixed(64, 48, 140), 320, 240)
@@ -755,7 +772,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -12,6 +12,9 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "imgborder_gameboy_player_60x40_to_304x224": "gameboy-player",
+    "imgborder_sgb_crt_geom_1x_40x36_to_256x224": "sgb-crt-geom-1x",
+    "imgborder_sgb_bare_params_40x30_to_233x171": "imgborder-sgb-bare",
     "lcd_grid_64x48_to_320x240": "lcd-grid",
     "lcd_grid_params_40x30_to_233x171": "lcd-grid",
     "agb001_48x36_to_250x190": "agb001",

@@ -58,6 +58,9 @@ CASES = {
     "lcd_grid_v2_motionblur_48x36_to_200x150_f9": "lcd-grid-v2-motionblur",
     "console_border_gba_lcd_grid_v2_3x_48x32_to_300x200_f4": "gba-lcd-grid-v2-3x",   # handheld/console-border/: border overlay (gb-pass-5) behind a history chain
     "console_border_gbc_retro_v2_2x_40x36_to_233x171_f3": "gbc-retro-v2-2x",
+    "imgborder_gameboy_player_60x40_to_304x224": "gameboy-player",     # borders/: the frame inside a border image
+    "imgborder_sgb_crt_geom_1x_40x36_to_256x224": "sgb-crt-geom-1x",
+    "imgborder_sgb_bare_params_40x30_to_233x171": "imgborder-sgb-bare",
     "lcd_grid_64x48_to_320x240": "lcd-grid",
     "lcd_grid_params_40x30_to_233x171": "lcd-grid",
     "console_border_gba_3x_48x32_to_300x200_f9": "gba-3x",      # motionblur-simple (Prev .. Prev6, full ring) in front of a 4-pass chain with a border LUT
@@ -155,7 +158,7 @@ def border_luts():
 def luts_for(key):
     if key.startswith("crt-royale"):
         return royale_luts()
-    if key in ("gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "gba-3x"):
+    if key in ("gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "gba-3x", "sgb-crt-geom-1x", "gameboy-player", "imgborder-sgb-bare"):
         return border_luts()
     return None
 
@@ -230,7 +233,7 @@ def test_oracle_matches_llvmpipe(case, tmp_path, rc_lib):
     passes = preset_passes(tmp_path, key)
     vw, vh = [int(v) for v in g["viewport"]]
     flags = 1 if "maskon" in case else 0
-    luts = royale_luts() if key.startswith("crt-royale") else None
+    luts = luts_for(key)
     golden = [g["pass%d" % i] for i in range(int(g["n_passes"]))]
     custom = dict(zip([str(n) for n in g["param_names"]], [float(v) for v in g["param_values"]])) \
         if "param_names" in g else None
@@ -292,6 +295,7 @@ FLOAT_CASES = {
     "f32_palm_color_48x36_to_131x77": ("palm-color", {}),
     "f32_psp_color_48x36_to_131x77": ("psp-color", {}),
     "f32_vba_color_48x36_to_131x77": ("vba-color", {}),
+    "f32_imgborder_sgb_bare_params_40x30_to_233x171": ("imgborder-sgb-bare", {}),
     "f32_lcd_grid_params_48x36_to_240x180": ("lcd-grid", {}),
     "f32_agb001_40x30_to_233x171": ("agb001", {}),
     "f32_retro_v2_48x36_to_240x180": ("retro-v2", {}),
@@ -335,7 +339,7 @@ def test_oracle_arithmetic_at_float_precision(case, tmp_path, rc_lib):
     golden = [g["pass%d" % i] for i in range(n)]
     custom = dict(zip([str(x) for x in g["param_names"]], [float(v) for v in g["param_values"]])) if "param_names" in g else None
     outs = run_chain(passes, g["input_rgb"], vw, vh, frame_count=int(g["frames"]),
-                     luts=royale_luts() if key.startswith("crt-royale") else None, flags=1 if "maskon" in case else 0,
+                     luts=luts_for(key), flags=1 if "maskon" in case else 0,
                      given=golden, force_f32=True, custom=custom)
     for i, (o, r) in enumerate(zip(outs, golden)):
         same = (o.view(np.uint32) == r.view(np.uint32)) | (np.isnan(o) & np.isnan(r))
