@@ -918,3 +918,30 @@ void o_pass_imgborder(const o_pass_args* a) {
     }
   o_fp_leave(csr);
 }
+
+/* reshade/shaders/LUT/LUT.glsl FS main (reshade/{lut,gba,nds,vba,bsnes-gamma-ramp,spfft}.glslp): a colour LUT of LUT_Size slices laid side
+ * by side, sampled twice (LINEAR) and mixed along blue.  As written, `ceil(b + 0.000001 * (LUT_Size - 1.0))` rounds the colour itself up,
+ * so the second slice is slice 1 (or 0 for b = 0) - kept.  The mix runs only where the first sample's blue is below 1.
+ * params: LUT_Size; extra[0] = SamplerLUT. */
+void o_pass_lut(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  const float S = a->params[0], k = S + -1.0f;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const o_vec4 c = o_sample(a->in, o_varying_at(&tu, x, y, lo), o_varying_at(&tv, x, y, lo));
+      const float red = (c.x * k + 0.4999f) / (S * S), green = (c.y * k + 0.4999f) / S;
+      const float b1 = floorf(c.z * k) / S + red, b2 = ceilf(c.z + 0.000001f * k) / S + red;
+      const o_vec4 c1 = o_sample(a->extra[0], b1, green), c2 = o_sample(a->extra[0], b2, green);
+      float m = (c.z + -b1) / (b2 + -b1);
+      m = nmin(nmax(m, 0.0f), 32.0f);
+      o_vec4 out = c1;
+      if (c1.z < 1.0f) {
+        out.x = c1.x + m * (c2.x + -c1.x); out.y = c1.y + m * (c2.y + -c1.y); out.z = c1.z + m * (c2.z + -c1.z); out.w = c1.w + m * (c2.w + -c1.w);
+      }
+      store_px(a, x, y, out);
+    }
+  o_fp_leave(csr);
+}

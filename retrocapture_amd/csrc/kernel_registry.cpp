@@ -490,6 +490,8 @@ std::vector<KernelEntry> build() {
       r.push_back(e);
     }
   }
+  r.push_back({"reshade/shaders/LUT/LUT.glsl", "reshade-lut", {{"LUT_Size", 16.0f, 1.0f, 64.0f, 1.0f, "LUT Size"}}, {"SamplerLUT"},
+               rck::launch_lut, setupTexCoord, false, true, nullptr, nullptr, true});   // reads no size uniform
   r.push_back({"handheld/console-border/shader-files/gb-pass-5.glsl", "gb-pass-5",
                {{"SCALE", 0.6667f, 0.6667f, 1.5f, 0.33333f, "Box Scale"}, {"OUT_X", 1600.0f, 1600.0f, 4800.0f, 8000.0f, "Out X"},
                 {"OUT_Y", 800.0f, 800.0f, 2400.0f, 400.0f, "Out Y"}},

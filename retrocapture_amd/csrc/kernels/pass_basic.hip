@@ -184,6 +184,28 @@ __global__ void __launch_bounds__(256) k_imgborder(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// reshade/shaders/LUT/LUT.glsl FS main (reshade/{lut,gba,nds,vba,bsnes-gamma-ramp,spfft}.glslp): a colour LUT of LUT_Size slices side by
+// side, sampled twice and mixed along blue - where the first sample's blue is below 1.  As the shader is written,
+// ceil(b + 0.000001 * (LUT_Size - 1)) rounds the colour itself up: the second slice is slice 1 (kept).  params[0] = LUT_Size;
+// extra[0] = SamplerLUT.  fmin / fmax keep the operand that is not NaN (0 / 0 where both slices coincide).
+__global__ void __launch_bounds__(256) k_lut(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const float S = L.params[0], k = S + -1.0f;
+  auto nmin = [](float a, float b) { return b != b ? a : (a < b ? a : b); };
+  auto nmax = [](float a, float b) { return b != b ? a : (a > b ? a : b); };
+  RC_TILE_LOOP_BEGIN
+  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
+  const float red = (c.x * k + 0.4999f) / (S * S), green = (c.y * k + 0.4999f) / S;
+  const float b1 = __builtin_floorf(c.z * k) / S + red, b2 = __builtin_ceilf(c.z + 0.000001f * k) / S + red;
+  const uint8_t* lut = frame_ptr(L.extra[0], z);
+  const float4 c1 = sample_rt(L.extra[0], lut, b1, green, &lds), c2 = sample_rt(L.extra[0], lut, b2, green, &lds);
+  const float m = nmin(nmax((c.z + -b1) / (b2 + -b1), 0.0f), 32.0f);
+  float4 o = c1;
+  if (c1.z < 1.0f) o = make_float4(c1.x + m * (c2.x + -c1.x), c1.y + m * (c2.y + -c1.y), c1.z + m * (c2.z + -c1.z), c1.w + m * (c2.w + -c1.w));
+  store_rt(L, z, x, y, o, &lds);
+  RC_TILE_LOOP_END
+}
+
 // handheld/shaders/mgba/agb001.glsl FS main (handheld/agb001.glslp, agb001-gba-color-motionblur.glslp): pow(texel * 0.8, 1.8) + 0.16 under
 // a 4x4 subpixel pattern per source texel - column 0 / 1 / 2 keeps red / green / blue and takes the other two to 0.2, column 3
 // takes all to 0.4, row 3 another 0.8 - alpha 0.5.  Index: int(mod(coord * size * 4, 4)), mod as a - 4 floor(a / 4).
@@ -705,6 +727,7 @@ RC_SIMPLE_LAUNCH(launch_retro_v2, k_retro_v2)
 RC_SIMPLE_LAUNCH(launch_agb001, k_agb001)
 RC_SIMPLE_LAUNCH(launch_gb_pass_5, k_gb_pass_5)
 RC_SIMPLE_LAUNCH(launch_imgborder, k_imgborder)
+RC_SIMPLE_LAUNCH(launch_lut, k_lut)
 RC_SIMPLE_LAUNCH(launch_gbc_gambatte_color, k_gbc_gambatte_color)
 RC_SIMPLE_LAUNCH(launch_shutter_3d, k_shutter_3d)
 RC_SIMPLE_LAUNCH(launch_anti_flicker, k_anti_flicker)

@@ -495,6 +495,20 @@ def case_hyllian_glow():
              params=[("HFILTER_SHARPNESS", 0.7), ("CRT_ANTI_RINGING", 0.6), ("MASK_INTENSITY", 0.7), ("PHOSPHOR_LAYOUT", 5.0)])
 
 
+def case_reshade_lut():
+    """reshade/lut.glslp (16 slices) and reshade/gba.glslp (32 slices, LUT_Size from the preset file) on synthetic grades."""
+    with tempfile.TemporaryDirectory() as d:
+        luts = {}
+        for n in (16, 32):
+            img = np.load(os.path.join(HERE, "lut_color%d_synthetic.npy" % n))
+            raw = os.path.join(d, "lut%d.rgba" % n)
+            img.tofile(raw)
+            luts[n] = [("SamplerLUT", (raw, img.shape[1], img.shape[0]))]
+        run_case("reshade_lut_64x48_to_160x120", GLSL + "/reshade/lut.glslp", mixed(64, 48, 160), 160, 120, luts=luts[16])
+        run_case("reshade_gba_40x30_to_97x61", GLSL + "/reshade/gba.glslp", noise(40, 30, 161), 97, 61, luts=luts[32])
+        run_case("f32_reshade_lut_48x36_to_131x77", GLSL + "/reshade/lut.glslp", mixed(48, 36, 162), 131, 77, luts=luts[16], f32=True)
+
+
 def case_imgborder():
     """borders/: imgborder-{sgb,gameboy-player}.glsl (one shader text) - alone, in front of crt-geom, and with every parameter moved."""
     B = GLSL + "/borders/"
@@ -772,7 +786,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "reshade_lut_64x48_to_160x120": "reshade-lut",
+    "reshade_gba_40x30_to_97x61": "reshade-gba",
     "imgborder_gameboy_player_60x40_to_304x224": "gameboy-player",
     "imgborder_sgb_crt_geom_1x_40x36_to_256x224": "sgb-crt-geom-1x",
     "imgborder_sgb_bare_params_40x30_to_233x171": "imgborder-sgb-bare",

@@ -61,6 +61,8 @@ CASES = {
     "imgborder_gameboy_player_60x40_to_304x224": "gameboy-player",     # borders/: the frame inside a border image
     "imgborder_sgb_crt_geom_1x_40x36_to_256x224": "sgb-crt-geom-1x",
     "imgborder_sgb_bare_params_40x30_to_233x171": "imgborder-sgb-bare",
+    "reshade_lut_64x48_to_160x120": "reshade-lut",
+    "reshade_gba_40x30_to_97x61": "reshade-gba",
     "lcd_grid_64x48_to_320x240": "lcd-grid",
     "lcd_grid_params_40x30_to_233x171": "lcd-grid",
     "console_border_gba_3x_48x32_to_300x200_f9": "gba-3x",      # motionblur-simple (Prev .. Prev6, full ring) in front of a 4-pass chain with a border LUT
@@ -158,6 +160,9 @@ def border_luts():
 def luts_for(key):
     if key.startswith("crt-royale"):
         return royale_luts()
+    if key in ("reshade-lut", "reshade-gba"):
+        n = 16 if key == "reshade-lut" else 32
+        return {"SamplerLUT": (np.load(os.path.join(GOLD, "lut_color%d_synthetic.npy" % n)), True, "clamp_to_border")}
     if key in ("gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "gba-3x", "sgb-crt-geom-1x", "gameboy-player", "imgborder-sgb-bare"):
         return border_luts()
     return None
@@ -296,6 +301,7 @@ FLOAT_CASES = {
     "f32_psp_color_48x36_to_131x77": ("psp-color", {}),
     "f32_vba_color_48x36_to_131x77": ("vba-color", {}),
     "f32_imgborder_sgb_bare_params_40x30_to_233x171": ("imgborder-sgb-bare", {}),
+    "f32_reshade_lut_48x36_to_131x77": ("reshade-lut", {}),
     "f32_lcd_grid_params_48x36_to_240x180": ("lcd-grid", {}),
     "f32_agb001_40x30_to_233x171": ("agb001", {}),
     "f32_retro_v2_48x36_to_240x180": ("retro-v2", {}),
