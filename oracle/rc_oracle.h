@@ -149,6 +149,7 @@ void o_pass_motionblur_simple(const o_pass_args* a);  /* extra[0..6] = Prev6 .. 
 void o_pass_braid_rewind(const o_pass_args* a);       /* history declared, not used (FrameDirection = 1) */
 void o_pass_response_time(const o_pass_args* a);      /* 1 param; extra[0..6] = PrevTexture, Prev1 .. Prev6 */
 void o_pass_lut(const o_pass_args* a);                /* 1 param; extra[0] = SamplerLUT */
+void o_pass_console_border(const o_pass_args* a);     /* 8 params; extra[0] = BORDER */
 void o_pass_imgborder(const o_pass_args* a);          /* 12 params; extra[0] = BORDER */
 void o_pass_gb_pass_5(const o_pass_args* a);          /* 3 params; extra[0] = BORDER */
 void o_pass_agb001(const o_pass_args* a);             /* no params */

@@ -945,3 +945,14 @@ void o_pass_lut(const o_pass_args* a) {
     }
   o_fp_leave(csr);
 }
+
+/* handheld/console-border/shader-files/border.glsl: imgborder without the four OS_MASK parameters (its viewport test compares with the
+ * bare 0.9999 / 0.0001, which is what 0.9999 - 0 and 0.0001 + 0 are).  params: box_scale, location_x, location_y, in_res_x, in_res_y,
+ * border_on_top, border_zoom_x, border_zoom_y; extra[0] = BORDER. */
+void o_pass_console_border(const o_pass_args* a) {
+  float p12[12] = {0};
+  for (int k = 0; k < 8; ++k) p12[k] = a->params[k];
+  o_pass_args b = *a;
+  b.params = p12;
+  o_pass_imgborder(&b);
+}

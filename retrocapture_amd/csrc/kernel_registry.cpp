@@ -115,6 +115,11 @@ void setupImgBorder(const PassGeometry& g, rcd::PassLaunch& L) {
   }
   for (int c = 0; c < 4; ++c) L.plane[c] = makePlane(v[0][c], v[1][c], v[2][c], v[3][c], g.out_w, g.out_h, g.out_fmt);
 }
+// handheld/console-border/shader-files/border.glsl: the same shader without the four OS_MASK parameters (their value is 0)
+void setupConsoleBorder(const PassGeometry& g, rcd::PassLaunch& L) {
+  for (int k = 8; k < 12; ++k) L.params[k] = 0.0f;
+  setupImgBorder(g, L);
+}
 // shutter-3d.glsl VS 61-73: left_coord / right_coord at the quad's vertices, in the GL's operation order (oracle/rc_passes_basic.c)
 void setupShutter3d(const PassGeometry& g, rcd::PassLaunch& L) {
   const float* P = L.params;
@@ -489,6 +494,16 @@ std::vector<KernelEntry> build() {
       e.texture_height_override = true;   // setupImgBorder reads PassGeometry::pass_index
       r.push_back(e);
     }
+  }
+  {
+    KernelEntry e{"handheld/console-border/shader-files/border.glsl", "console-border",
+                  {{"box_scale", 4.0f, 1.0f, 10.0f, 1.0f, "Image Scale"}, {"location_x", 0.5f, 0.0f, 1.0f, 0.05f, "Viewport X Pos."},
+                   {"location_y", 0.5f, 0.0f, 1.0f, 0.05f, "Viewport Y Pos."}, {"in_res_x", 320.0f, 100.0f, 600.0f, 1.0f, "Viewport Size X"},
+                   {"in_res_y", 240.0f, 64.0f, 512.0f, 1.0f, "Viewport Size Y"}, {"border_on_top", 1.0f, 0.0f, 1.0f, 1.0f, "Show Viewport"},
+                   {"border_zoom_x", 1.0f, 0.0f, 4.0f, 0.01f, "Border Zoom X"}, {"border_zoom_y", 1.0f, 0.0f, 4.0f, 0.01f, "Border Zoom Y"}},
+                  {"BORDER"}, rck::launch_imgborder, setupConsoleBorder, false};
+    e.texture_height_override = true;
+    r.push_back(e);
   }
   r.push_back({"reshade/shaders/LUT/LUT.glsl", "reshade-lut", {{"LUT_Size", 16.0f, 1.0f, 64.0f, 1.0f, "LUT Size"}}, {"SamplerLUT"},
                rck::launch_lut, setupTexCoord, false, true, nullptr, nullptr, true});   // reads no size uniform

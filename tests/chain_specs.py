@@ -361,6 +361,37 @@ for _c, _blk in (("gba", 'parameters = "darken_screen;RETRO_PIXEL_SIZE"\ndarken_
                                          'shaders = "2"\n\nshader0 = "../handheld/shaders/color/%s-color.glsl"\nshader1 = "../handheld/shaders/retro-v2.glsl"\n\n'
                                          'filter_linear0 = "false"\nscale_type0 = "source"\nscale0 = "1.000000"\n\nfilter_linear1 = "false"\n\n' % _c + _blk)
 
+# handheld/console-border/ngpc-3x.glslp (same keys / values; synthetic border image)
+PRESETS["ngpc-3x"] = ("handheld/console-border/ngpc-3x.glslp", """shaders = "2"
+
+shader0 = "../shaders/lcd-cgwg/lcd-grid.glsl"
+filter_linear0 = "false"
+wrap_mode0 = "clamp_to_border"
+scale_type_x0 = "source"
+scale_x0 = "4.000000"
+scale_type_y0 = "source"
+scale_y0 = "4.000000"
+
+shader1 = "shader-files/border.glsl"
+filter_linear1 = "true"
+wrap_mode1 = "clamp_to_border"
+
+parameters = "box_scale;in_res_x;in_res_y;border_on_top;border_zoom_x;border_zoom_y"
+GRID_STRENGTH = "0.150000"
+box_scale = "3.0"
+in_res_x = "160.0"
+in_res_y = "152.0"
+border_on_top = "0.000000"
+border_zoom_x = "0.70"
+border_zoom_y = "0.79"
+
+textures = "BORDER"
+BORDER = "resources/ngpc-border-square-4x.png"
+BORDER_linear = "true"
+BORDER_wrap_mode = "clamp_to_border"
+BORDER_mipmap = "false"
+""")
+
 # reshade/lut.glslp and reshade/gba.glslp (same keys / values; the LUT images are small synthetic grades, tests/golden/lut_color*_synthetic.png)
 PRESETS["reshade-lut"] = ("reshade/lut.glslp", 'shaders = 1\n\nshader0 = shaders/LUT/LUT.glsl\n\ntextures = SamplerLUT\n\nSamplerLUT = shaders/LUT/16.png\nSamplerLUT_linear = true\n')
 PRESETS["reshade-gba"] = ("reshade/gba.glslp", 'shaders = 1\n\nshader0 = shaders/LUT/LUT.glsl\nfilter_linear0 = "false"\nscale_type_x0 = "source"\nscale_x0 = "1.000000"\n'
@@ -548,6 +579,7 @@ ASSETS = {"mask_slot_small_64.png": ("crt-royale", "shaders/crt-royale/mask_slot
           "gba-border#gba-3x": ("gba-3x", "resources/gba-border-square-4x.png", "lut_border_synthetic.png"),
           "lut16": ("reshade-lut", "shaders/LUT/16.png", "lut_color16_synthetic.png"),
           "lut32": ("reshade-gba", "shaders/LUT/GBA.png", "lut_color32_synthetic.png"),
+          "ngpc-border": ("ngpc-3x", "resources/ngpc-border-square-4x.png", "lut_border_synthetic.png"),
           "sgb-border": ("sgb-crt-geom-1x", "sgb.png", "lut_border_synthetic.png"),
           "gbp-border": ("gameboy-player", "gameboy-player.png", "lut_border_synthetic.png"),
           "color-border": ("gbc-retro-v2-2x", "resources/color-border-square-4x.png", "lut_border_synthetic.png"),
@@ -607,6 +639,9 @@ SHADERS = {
     "borders/resources/imgborder-sgb.glsl": {"oracle": "imgborder", "samplers": ["BORDER"], "params": [("box_scale", 1.0), ("location_x", 0.5), ("location_y", 0.5), ("in_res_x", 160.0), ("in_res_y", 144.0), ("border_on_top", 0.0), ("border_zoom_x", 1.0), ("border_zoom_y", 1.0), ("OS_MASK_TOP", 0.0), ("OS_MASK_BOTTOM", 0.0), ("OS_MASK_LEFT", 0.0), ("OS_MASK_RIGHT", 0.0)]},
     "borders/resources/imgborder-gameboy-player.glsl": {"oracle": "imgborder", "samplers": ["BORDER"], "params": [("box_scale", 2.0), ("location_x", 0.5), ("location_y", 0.5), ("in_res_x", 240.0), ("in_res_y", 160.0), ("border_on_top", 0.0), ("border_zoom_x", 1.0), ("border_zoom_y", 1.0), ("OS_MASK_TOP", 0.0), ("OS_MASK_BOTTOM", 0.0), ("OS_MASK_LEFT", 0.0), ("OS_MASK_RIGHT", 0.0)]},
     "borders/resources/imgborder-sgba.glsl": {"oracle": "imgborder", "samplers": ["BORDER"], "params": [("box_scale", 1.0), ("location_x", 0.5), ("location_y", 0.5), ("in_res_x", 240.0), ("in_res_y", 160.0), ("border_on_top", 0.0), ("border_zoom_x", 1.0), ("border_zoom_y", 1.0), ("OS_MASK_TOP", 0.0), ("OS_MASK_BOTTOM", 0.0), ("OS_MASK_LEFT", 0.0), ("OS_MASK_RIGHT", 0.0)]},
+    "handheld/console-border/shader-files/border.glsl": {"oracle": "console_border", "samplers": ["BORDER"],
+                                                         "params": [("box_scale", 4.0), ("location_x", 0.5), ("location_y", 0.5), ("in_res_x", 320.0),
+                                                                    ("in_res_y", 240.0), ("border_on_top", 1.0), ("border_zoom_x", 1.0), ("border_zoom_y", 1.0)]},
     "reshade/shaders/LUT/LUT.glsl": {"oracle": "lut", "samplers": ["SamplerLUT"], "params": [("LUT_Size", 16.0)], "size_independent": True},
     "handheld/console-border/shader-files/gb-pass-5.glsl": {"oracle": "gb_pass_5", "samplers": ["BORDER"],
                                                             "params": [("SCALE", 0.6667), ("OUT_X", 1600.0), ("OUT_Y", 800.0)]},

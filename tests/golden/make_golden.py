@@ -519,6 +519,7 @@ def case_imgborder():
         luts = [("BORDER", (raw, border.shape[1], border.shape[0]))]
         run_case("imgborder_gameboy_player_60x40_to_304x224", B + "gameboy-player/gameboy-player.glslp", mixed(60, 40, 150), 304, 224, luts=luts)
         run_case("imgborder_sgb_crt_geom_1x_40x36_to_256x224", B + "sgb/sgb-crt-geom-1x.glslp", mixed(40, 36, 151), 256, 224, luts=luts)
+        run_case("console_border_ngpc_3x_40x38_to_300x200", GLSL + "/handheld/console-border/ngpc-3x.glslp", mixed(40, 38, 154), 300, 200, luts=luts)
         p = write_preset(d, 'shaders = 1\nshader0 = %s/borders/resources/imgborder-sgb.glsl\ntextures = "BORDER"\nBORDER = "sgb.png"\nBORDER_linear = true\n' % GLSL)
         prm = [("box_scale", 2.0), ("location_x", 0.45), ("location_y", 0.6), ("in_res_x", 120.0), ("in_res_y", 90.0), ("border_on_top", 1.0),
                ("border_zoom_x", 1.3), ("border_zoom_y", 0.8), ("OS_MASK_TOP", 0.05), ("OS_MASK_BOTTOM", 0.1), ("OS_MASK_LEFT", 0.02), ("OS_MASK_RIGHT", 0.07)]

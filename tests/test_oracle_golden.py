@@ -61,6 +61,7 @@ CASES = {
     "imgborder_gameboy_player_60x40_to_304x224": "gameboy-player",     # borders/: the frame inside a border image
     "imgborder_sgb_crt_geom_1x_40x36_to_256x224": "sgb-crt-geom-1x",
     "imgborder_sgb_bare_params_40x30_to_233x171": "imgborder-sgb-bare",
+    "console_border_ngpc_3x_40x38_to_300x200": "ngpc-3x",
     "reshade_lut_64x48_to_160x120": "reshade-lut",
     "reshade_gba_40x30_to_97x61": "reshade-gba",
     "lcd_grid_64x48_to_320x240": "lcd-grid",
@@ -163,7 +164,7 @@ def luts_for(key):
     if key in ("reshade-lut", "reshade-gba"):
         n = 16 if key == "reshade-lut" else 32
         return {"SamplerLUT": (np.load(os.path.join(GOLD, "lut_color%d_synthetic.npy" % n)), True, "clamp_to_border")}
-    if key in ("gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "gba-3x", "sgb-crt-geom-1x", "gameboy-player", "imgborder-sgb-bare"):
+    if key in ("gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "gba-3x", "sgb-crt-geom-1x", "gameboy-player", "imgborder-sgb-bare", "ngpc-3x"):
         return border_luts()
     return None
 
