@@ -956,3 +956,21 @@ void o_pass_console_border(const o_pass_args* a) {
   b.params = p12;
   o_pass_imgborder(&b);
 }
+
+/* handheld/shaders/gb-palette/gb-palette.glsl FS main (handheld/gb-palette-{dmg,light,pocket}.glslp): the red channel as a grey level picks
+ * a row of a palette image; alpha = ceil(|1 - r|).  extra[0] = COLOR_PALETTE. */
+void o_pass_gb_palette(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const o_vec4 c = o_sample(a->in, o_varying_at(&tu, x, y, lo), o_varying_at(&tv, x, y, lo));
+      const float g = fabsf(1.0f + -c.x);
+      const o_vec4 p = o_sample(a->extra[0], 0.5f, g * 0.75f + 0.125f);
+      const o_vec4 out = {p.x, p.y, p.z, ceilf(g)};
+      store_px(a, x, y, out);
+    }
+  o_fp_leave(csr);
+}

@@ -505,6 +505,8 @@ std::vector<KernelEntry> build() {
     e.texture_height_override = true;
     r.push_back(e);
   }
+  r.push_back({"handheld/shaders/gb-palette/gb-palette.glsl", "gb-palette", {}, {"COLOR_PALETTE"}, rck::launch_gb_palette, setupTexCoord, false, true,
+               nullptr, nullptr, true});
   r.push_back({"reshade/shaders/LUT/LUT.glsl", "reshade-lut", {{"LUT_Size", 16.0f, 1.0f, 64.0f, 1.0f, "LUT Size"}}, {"SamplerLUT"},
                rck::launch_lut, setupTexCoord, false, true, nullptr, nullptr, true});   // reads no size uniform
   r.push_back({"handheld/console-border/shader-files/gb-pass-5.glsl", "gb-pass-5",

@@ -206,6 +206,18 @@ __global__ void __launch_bounds__(256) k_lut(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// handheld/shaders/gb-palette/gb-palette.glsl FS main (handheld/gb-palette-{dmg,light,pocket}.glslp): the red channel as a grey level picks a
+// row of the palette image (column 0.5); alpha = ceil(|1 - r|).  extra[0] = COLOR_PALETTE.
+__global__ void __launch_bounds__(256) k_gb_palette(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
+  const float g = __builtin_fabsf(1.0f + -c.x);
+  const float4 p = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), 0.5f, g * 0.75f + 0.125f, &lds);
+  store_rt(L, z, x, y, make_float4(p.x, p.y, p.z, __builtin_ceilf(g)), &lds);
+  RC_TILE_LOOP_END
+}
+
 // handheld/shaders/mgba/agb001.glsl FS main (handheld/agb001.glslp, agb001-gba-color-motionblur.glslp): pow(texel * 0.8, 1.8) + 0.16 under
 // a 4x4 subpixel pattern per source texel - column 0 / 1 / 2 keeps red / green / blue and takes the other two to 0.2, column 3
 // takes all to 0.4, row 3 another 0.8 - alpha 0.5.  Index: int(mod(coord * size * 4, 4)), mod as a - 4 floor(a / 4).
@@ -728,6 +740,7 @@ RC_SIMPLE_LAUNCH(launch_agb001, k_agb001)
 RC_SIMPLE_LAUNCH(launch_gb_pass_5, k_gb_pass_5)
 RC_SIMPLE_LAUNCH(launch_imgborder, k_imgborder)
 RC_SIMPLE_LAUNCH(launch_lut, k_lut)
+RC_SIMPLE_LAUNCH(launch_gb_palette, k_gb_palette)
 RC_SIMPLE_LAUNCH(launch_gbc_gambatte_color, k_gbc_gambatte_color)
 RC_SIMPLE_LAUNCH(launch_shutter_3d, k_shutter_3d)
 RC_SIMPLE_LAUNCH(launch_anti_flicker, k_anti_flicker)

@@ -495,6 +495,18 @@ def case_hyllian_glow():
              params=[("HFILTER_SHARPNESS", 0.7), ("CRT_ANTI_RINGING", 0.6), ("MASK_INTENSITY", 0.7), ("PHOSPHOR_LAYOUT", 5.0)])
 
 
+def case_gb_palette():
+    pal = np.load(os.path.join(HERE, "lut_palette_synthetic.npy"))
+    with tempfile.TemporaryDirectory() as d:
+        raw = os.path.join(d, "pal.rgba")
+        pal.tofile(raw)
+        grey = mixed(64, 48, 170)
+        grey[..., 0] = (grey[..., 0] // 85) * 85      # the four Game Boy grey levels in red, plus everything in between on the gradient band
+        grey[16:22] = mixed(64, 48, 171)[16:22]
+        run_case("gb_palette_dmg_64x48_to_64x48", GLSL + "/handheld/gb-palette-dmg.glslp", grey, 64, 48, luts=[("COLOR_PALETTE", (raw, pal.shape[1], pal.shape[0]))])
+        run_case("gb_palette_dmg_64x48_to_201x155", GLSL + "/handheld/gb-palette-dmg.glslp", grey, 201, 155, luts=[("COLOR_PALETTE", (raw, pal.shape[1], pal.shape[0]))])
+
+
 def case_reshade_lut():
     """reshade/lut.glslp (16 slices) and reshade/gba.glslp (32 slices, LUT_Size from the preset file) on synthetic grades."""
     with tempfile.TemporaryDirectory() as d:
@@ -787,7 +799,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"gb_palette": case_gb_palette, "reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

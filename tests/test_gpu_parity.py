@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "gb_palette_dmg_64x48_to_64x48": "gb-palette-dmg",
+    "gb_palette_dmg_64x48_to_201x155": "gb-palette-dmg",
     "console_border_ngpc_3x_40x38_to_300x200": "ngpc-3x",
     "reshade_lut_64x48_to_160x120": "reshade-lut",
     "reshade_gba_40x30_to_97x61": "reshade-gba",

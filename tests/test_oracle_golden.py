@@ -62,6 +62,8 @@ CASES = {
     "imgborder_sgb_crt_geom_1x_40x36_to_256x224": "sgb-crt-geom-1x",
     "imgborder_sgb_bare_params_40x30_to_233x171": "imgborder-sgb-bare",
     "console_border_ngpc_3x_40x38_to_300x200": "ngpc-3x",
+    "gb_palette_dmg_64x48_to_64x48": "gb-palette-dmg",
+    "gb_palette_dmg_64x48_to_201x155": "gb-palette-dmg",
     "reshade_lut_64x48_to_160x120": "reshade-lut",
     "reshade_gba_40x30_to_97x61": "reshade-gba",
     "lcd_grid_64x48_to_320x240": "lcd-grid",
@@ -161,6 +163,8 @@ def border_luts():
 def luts_for(key):
     if key.startswith("crt-royale"):
         return royale_luts()
+    if key == "gb-palette-dmg":
+        return {"COLOR_PALETTE": (np.load(os.path.join(GOLD, "lut_palette_synthetic.npy")), False, "clamp_to_border")}
     if key in ("reshade-lut", "reshade-gba"):
         n = 16 if key == "reshade-lut" else 32
         return {"SamplerLUT": (np.load(os.path.join(GOLD, "lut_color%d_synthetic.npy" % n)), True, "clamp_to_border")}
