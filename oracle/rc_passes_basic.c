@@ -974,3 +974,23 @@ void o_pass_gb_palette(const o_pass_args* a) {
     }
   o_fp_leave(csr);
 }
+
+/* crt/shaders/crt-potato/shader-files/crt-potato.glsl FS main (crt/crt-potato-{cool,warm}.glslp): the frame times a small mask image tiled
+ * every 2 target pixels across and every floor(OutputSize.y / InputSize.y + 0.000001) lines down (gl_FragCoord = pixel + 0.5).
+ * extra[0] = MASK. */
+void o_pass_crt_potato(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  const float scale = floorf((float)H / (float)a->in->h + 0.000001f);
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float fx = ((float)x + 0.5f) / 2.0f, fy = (((float)y + 0.5f) * 1.0f + 0.0f) / scale;
+      const o_vec4 m = o_sample(a->extra[0], fx - floorf(fx), fy - floorf(fy));
+      const o_vec4 c = o_sample(a->in, o_varying_at(&tu, x, y, lo), o_varying_at(&tv, x, y, lo));
+      const o_vec4 out = {m.x * c.x, m.y * c.y, m.z * c.z, m.w * c.w};
+      store_px(a, x, y, out);
+    }
+  o_fp_leave(csr);
+}

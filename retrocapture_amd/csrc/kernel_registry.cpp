@@ -505,6 +505,7 @@ std::vector<KernelEntry> build() {
     e.texture_height_override = true;
     r.push_back(e);
   }
+  r.push_back({"crt/shaders/crt-potato/shader-files/crt-potato.glsl", "crt-potato", {}, {"MASK"}, rck::launch_crt_potato, setupTexCoord, false});
   r.push_back({"handheld/shaders/gb-palette/gb-palette.glsl", "gb-palette", {}, {"COLOR_PALETTE"}, rck::launch_gb_palette, setupTexCoord, false, true,
                nullptr, nullptr, true});
   r.push_back({"reshade/shaders/LUT/LUT.glsl", "reshade-lut", {{"LUT_Size", 16.0f, 1.0f, 64.0f, 1.0f, "LUT Size"}}, {"SamplerLUT"},

@@ -218,6 +218,19 @@ __global__ void __launch_bounds__(256) k_gb_palette(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// crt/shaders/crt-potato/shader-files/crt-potato.glsl FS main (crt/crt-potato-{cool,warm}.glslp): the frame times a small mask image tiled
+// every 2 target pixels across and every floor(OutputSize.y / InputSize.y + 0.000001) lines down; gl_FragCoord = pixel + 0.5.  extra[0] = MASK.
+__global__ void __launch_bounds__(256) k_crt_potato(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const float scale = __builtin_floorf((float)L.out_h / (float)L.in.h + 0.000001f);
+  RC_TILE_LOOP_BEGIN
+  const float fx = ((float)x + 0.5f) / 2.0f, fy = ((float)y + 0.5f) / scale;
+  const float4 m = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), fx - __builtin_floorf(fx), fy - __builtin_floorf(fy), &lds);
+  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo), &lds);
+  store_rt(L, z, x, y, make_float4(m.x * c.x, m.y * c.y, m.z * c.z, m.w * c.w), &lds);
+  RC_TILE_LOOP_END
+}
+
 // handheld/shaders/mgba/agb001.glsl FS main (handheld/agb001.glslp, agb001-gba-color-motionblur.glslp): pow(texel * 0.8, 1.8) + 0.16 under
 // a 4x4 subpixel pattern per source texel - column 0 / 1 / 2 keeps red / green / blue and takes the other two to 0.2, column 3
 // takes all to 0.4, row 3 another 0.8 - alpha 0.5.  Index: int(mod(coord * size * 4, 4)), mod as a - 4 floor(a / 4).
@@ -741,6 +754,7 @@ RC_SIMPLE_LAUNCH(launch_gb_pass_5, k_gb_pass_5)
 RC_SIMPLE_LAUNCH(launch_imgborder, k_imgborder)
 RC_SIMPLE_LAUNCH(launch_lut, k_lut)
 RC_SIMPLE_LAUNCH(launch_gb_palette, k_gb_palette)
+RC_SIMPLE_LAUNCH(launch_crt_potato, k_crt_potato)
 RC_SIMPLE_LAUNCH(launch_gbc_gambatte_color, k_gbc_gambatte_color)
 RC_SIMPLE_LAUNCH(launch_shutter_3d, k_shutter_3d)
 RC_SIMPLE_LAUNCH(launch_anti_flicker, k_anti_flicker)

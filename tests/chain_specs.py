@@ -392,6 +392,10 @@ BORDER_wrap_mode = "clamp_to_border"
 BORDER_mipmap = "false"
 """)
 
+# crt/crt-potato-cool.glslp (same keys / values; synthetic mask image)
+PRESETS["crt-potato-cool"] = ("crt/crt-potato-cool.glslp", 'shaders = 1\n\nshader0 = shaders/crt-potato/shader-files/crt-potato.glsl\nfilter_linear0 = false\nscale_type0 = viewport\n'
+                              'scale0 = 1.0\nalias0 = "PASS0"\n\ntextures = MASK\nMASK = shaders/crt-potato/resources/crt-potato-thin.png\nMASK_linear = false\nMASK_wrap_mode = "repeat"\n')
+
 # handheld/gb-palette-dmg.glslp (same keys / values; synthetic 4-band palette image)
 PRESETS["gb-palette-dmg"] = ("handheld/gb-palette-dmg.glslp", 'shaders = 1\nshader0 = shaders/gb-palette/gb-palette.glsl\n\nscale_type0 = source\nfilter_linear0 = false\n\n'
                              'textures = COLOR_PALETTE\nCOLOR_PALETTE = shaders/gb-palette/resources/palette-dmg.png\nCOLOR_PALETTE_linear = false\n')
@@ -585,6 +589,7 @@ ASSETS = {"mask_slot_small_64.png": ("crt-royale", "shaders/crt-royale/mask_slot
           "lut32": ("reshade-gba", "shaders/LUT/GBA.png", "lut_color32_synthetic.png"),
           "ngpc-border": ("ngpc-3x", "resources/ngpc-border-square-4x.png", "lut_border_synthetic.png"),
           "gb-palette": ("gb-palette-dmg", "shaders/gb-palette/resources/palette-dmg.png", "lut_palette_synthetic.png"),
+          "potato-mask": ("crt-potato-cool", "shaders/crt-potato/resources/crt-potato-thin.png", "lut_potato_mask_synthetic.png"),
           "sgb-border": ("sgb-crt-geom-1x", "sgb.png", "lut_border_synthetic.png"),
           "gbp-border": ("gameboy-player", "gameboy-player.png", "lut_border_synthetic.png"),
           "color-border": ("gbc-retro-v2-2x", "resources/color-border-square-4x.png", "lut_border_synthetic.png"),
@@ -648,6 +653,7 @@ SHADERS = {
                                                          "params": [("box_scale", 4.0), ("location_x", 0.5), ("location_y", 0.5), ("in_res_x", 320.0),
                                                                     ("in_res_y", 240.0), ("border_on_top", 1.0), ("border_zoom_x", 1.0), ("border_zoom_y", 1.0)]},
     "handheld/shaders/gb-palette/gb-palette.glsl": {"oracle": "gb_palette", "samplers": ["COLOR_PALETTE"], "params": [], "size_independent": True},
+    "crt/shaders/crt-potato/shader-files/crt-potato.glsl": {"oracle": "crt_potato", "samplers": ["MASK"], "params": []},
     "reshade/shaders/LUT/LUT.glsl": {"oracle": "lut", "samplers": ["SamplerLUT"], "params": [("LUT_Size", 16.0)], "size_independent": True},
     "handheld/console-border/shader-files/gb-pass-5.glsl": {"oracle": "gb_pass_5", "samplers": ["BORDER"],
                                                             "params": [("SCALE", 0.6667), ("OUT_X", 1600.0), ("OUT_Y", 800.0)]},

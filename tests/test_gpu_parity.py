@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "crt_potato_64x48_to_320x240": "crt-potato-cool",
+    "crt_potato_40x30_to_233x171": "crt-potato-cool",
     "gb_palette_dmg_64x48_to_64x48": "gb-palette-dmg",
     "gb_palette_dmg_64x48_to_201x155": "gb-palette-dmg",
     "console_border_ngpc_3x_40x38_to_300x200": "ngpc-3x",

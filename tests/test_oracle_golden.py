@@ -62,6 +62,8 @@ CASES = {
     "imgborder_sgb_crt_geom_1x_40x36_to_256x224": "sgb-crt-geom-1x",
     "imgborder_sgb_bare_params_40x30_to_233x171": "imgborder-sgb-bare",
     "console_border_ngpc_3x_40x38_to_300x200": "ngpc-3x",
+    "crt_potato_64x48_to_320x240": "crt-potato-cool",
+    "crt_potato_40x30_to_233x171": "crt-potato-cool",
     "gb_palette_dmg_64x48_to_64x48": "gb-palette-dmg",
     "gb_palette_dmg_64x48_to_201x155": "gb-palette-dmg",
     "reshade_lut_64x48_to_160x120": "reshade-lut",
@@ -163,6 +165,8 @@ def border_luts():
 def luts_for(key):
     if key.startswith("crt-royale"):
         return royale_luts()
+    if key == "crt-potato-cool":
+        return {"MASK": (np.load(os.path.join(GOLD, "lut_potato_mask_synthetic.npy")), False, "repeat")}
     if key == "gb-palette-dmg":
         return {"COLOR_PALETTE": (np.load(os.path.join(GOLD, "lut_palette_synthetic.npy")), False, "clamp_to_border")}
     if key in ("reshade-lut", "reshade-gba"):
@@ -306,6 +310,7 @@ FLOAT_CASES = {
     "f32_psp_color_48x36_to_131x77": ("psp-color", {}),
     "f32_vba_color_48x36_to_131x77": ("vba-color", {}),
     "f32_imgborder_sgb_bare_params_40x30_to_233x171": ("imgborder-sgb-bare", {}),
+    "f32_crt_potato_48x36_to_240x200": ("crt-potato-cool", {}),
     "f32_reshade_lut_48x36_to_131x77": ("reshade-lut", {}),
     "f32_lcd_grid_params_48x36_to_240x180": ("lcd-grid", {}),
     "f32_agb001_40x30_to_233x171": ("agb001", {}),
