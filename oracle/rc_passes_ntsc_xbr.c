@@ -469,3 +469,33 @@ void o_pass_xbr_lv2(const o_pass_args* a) {
   xbr_lv2_body(a);
   o_fp_leave(csr);
 }
+
+/* ntsc/shaders/ntsc-gauss-pass.glsl (ntsc/ntsc-{256px,320px}[-svideo]-gauss-scanline.glslp, ntsc.glslp, ntsc-svideo.glslp): five source
+ * lines around the target pixel, pow(., NTSC_CRT_GAMMA), weighted with exp(-5 d^2) = exp2((-7.213475 d) d) of the line distance,
+ * x 1.15, pow(., 1 / NTSC_DISPLAY_GAMMA).  VS: one = 1 / TextureSize.y, pix_no = TexCoord.y * TextureSize.y.  params: the two gammas. */
+void o_pass_ntsc_gauss(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  const float tsy = (a->pass_index == 3 && H != a->in->h) ? (float)H : (float)a->in->h;   /* the reference's TextureSize.y rule for pass index 3 */
+  const float one = 1.0f / tsy, crt = a->params[0], inv = 1.0f / a->params[1];
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  o_varying pn = o_varying_setup(0.f * tsy, 0.f * tsy, 1.f * tsy, 1.f * tsy, W, H, a->out_fmt);
+  o_varying po = o_varying_setup(one, one, one, one, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo), o1 = o_varying_at(&po, x, y, lo);
+      const float pno = o_varying_at(&pn, x, y, lo), fr = pno - floorf(pno);
+      const float off[5] = {-2.0f * o1, -o1, 0.0f, o1, 2.0f * o1}, d[5] = {1.5f + fr, 0.5f + fr, fr + -0.5f, -1.5f + fr, -2.5f + fr};
+      float acc[3] = {0.f, 0.f, 0.f};
+      for (int k = 0; k < 5; ++k) {
+        const o_vec4 t = o_sample(a->in, u, k == 2 ? v : v + off[k]);
+        const float w = o_exp2((-7.213475f * d[k]) * d[k]);
+        const float c[3] = {o_pow(t.x, crt) * w, o_pow(t.y, crt) * w, o_pow(t.z, crt) * w};
+        for (int q = 0; q < 3; ++q) acc[q] = k == 0 ? c[q] : acc[q] + c[q];
+      }
+      const o_vec4 out = {o_pow(1.15f * acc[0], inv), o_pow(1.15f * acc[1], inv), o_pow(1.15f * acc[2], inv), 1.0f};
+      o_store_pixel(a, x, y, out);
+    }
+  o_fp_leave(csr);
+}

@@ -120,6 +120,14 @@ void setupConsoleBorder(const PassGeometry& g, rcd::PassLaunch& L) {
   for (int k = 8; k < 12; ++k) L.params[k] = 0.0f;
   setupImgBorder(g, L);
 }
+// ntsc-gauss-pass.glsl VS: pix_no = TexCoord.y * TextureSize.y and one = 1 / TextureSize.y
+void setupNtscGauss(const PassGeometry& g, rcd::PassLaunch& L) {
+  setupTexCoord(g, L);
+  const float tsy = (g.pass_index == 3 && g.out_h != g.in_h) ? (float)g.out_h : (float)g.in_h;   // the reference's TextureSize.y rule for pass index 3
+  const float one = 1.0f / tsy;
+  L.plane[2] = makePlane(0.f * tsy, 0.f * tsy, 1.f * tsy, 1.f * tsy, g.out_w, g.out_h, g.out_fmt);
+  L.plane[3] = makePlane(one, one, one, one, g.out_w, g.out_h, g.out_fmt);
+}
 // shutter-3d.glsl VS 61-73: left_coord / right_coord at the quad's vertices, in the GL's operation order (oracle/rc_passes_basic.c)
 void setupShutter3d(const PassGeometry& g, rcd::PassLaunch& L) {
   const float* P = L.params;
@@ -505,6 +513,15 @@ std::vector<KernelEntry> build() {
     e.texture_height_override = true;
     r.push_back(e);
   }
+  {
+    KernelEntry e{"ntsc/shaders/ntsc-gauss-pass.glsl", "ntsc-gauss",
+                  {{"NTSC_CRT_GAMMA", 2.5f, 0.0f, 10.0f, 0.1f, "NTSC CRT Gamma"}, {"NTSC_DISPLAY_GAMMA", 2.1f, 0.0f, 10.0f, 0.1f, "NTSC Display Gamma"}},
+                  {}, rck::launch_ntsc_gauss, setupNtscGauss, false};
+    e.texture_height_override = true;
+    r.push_back(e);
+  }
+  // ntsc/shaders/ntsc-stock.glsl: the text of stock.glsl (a plain copy, llvmpipe's blit rules included)
+  r.push_back({"ntsc/shaders/ntsc-stock.glsl", "ntsc-stock", {}, {}, rck::launch_stock, setupTexCoord, false, true, nullptr, nullptr, true});
   r.push_back({"crt/shaders/crt-potato/shader-files/crt-potato.glsl", "crt-potato", {}, {"MASK"}, rck::launch_crt_potato, setupTexCoord, false});
   r.push_back({"handheld/shaders/gb-palette/gb-palette.glsl", "gb-palette", {}, {"COLOR_PALETTE"}, rck::launch_gb_palette, setupTexCoord, false, true,
                nullptr, nullptr, true});

@@ -231,6 +231,30 @@ __global__ void __launch_bounds__(256) k_crt_potato(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// ntsc/shaders/ntsc-gauss-pass.glsl FS main (ntsc/ntsc-*-gauss-scanline.glslp, ntsc.glslp, ntsc-svideo.glslp): five source lines around the
+// target pixel, pow(., NTSC_CRT_GAMMA), weighted with exp(-5 d^2) = exp2((-7.213475 d) d) of the line distance, x 1.15,
+// pow(., 1 / NTSC_DISPLAY_GAMMA).  plane[2] = pix_no (TexCoord.y * TextureSize.y), plane[3] = one (1 / TextureSize.y): setupNtscGauss.
+__global__ void __launch_bounds__(256) k_ntsc_gauss(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const float crt = L.params[0], inv = 1.0f / L.params[1];
+  RC_TILE_LOOP_BEGIN
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo), o1 = vary(L.plane[3], x, y, lo);
+  const float pno = vary(L.plane[2], x, y, lo), fr = pno - __builtin_floorf(pno);
+  const float off[5] = {-2.0f * o1, -o1, 0.0f, o1, 2.0f * o1}, d[5] = {1.5f + fr, 0.5f + fr, fr + -0.5f, -1.5f + fr, -2.5f + fr};
+  const uint8_t* img = frame_ptr(L.in, z);
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const float4 t = sample_rt(L.in, img, u, k == 2 ? v : v + off[k], &lds);
+    const float w = exp2_((-7.213475f * d[k]) * d[k]);
+    const float c[3] = {pow_(t.x, crt) * w, pow_(t.y, crt) * w, pow_(t.z, crt) * w};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = k == 0 ? c[q] : acc[q] + c[q];
+  }
+  store_rt(L, z, x, y, make_float4(pow_(1.15f * acc[0], inv), pow_(1.15f * acc[1], inv), pow_(1.15f * acc[2], inv), 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
 // handheld/shaders/mgba/agb001.glsl FS main (handheld/agb001.glslp, agb001-gba-color-motionblur.glslp): pow(texel * 0.8, 1.8) + 0.16 under
 // a 4x4 subpixel pattern per source texel - column 0 / 1 / 2 keeps red / green / blue and takes the other two to 0.2, column 3
 // takes all to 0.4, row 3 another 0.8 - alpha 0.5.  Index: int(mod(coord * size * 4, 4)), mod as a - 4 floor(a / 4).
@@ -755,6 +779,7 @@ RC_SIMPLE_LAUNCH(launch_imgborder, k_imgborder)
 RC_SIMPLE_LAUNCH(launch_lut, k_lut)
 RC_SIMPLE_LAUNCH(launch_gb_palette, k_gb_palette)
 RC_SIMPLE_LAUNCH(launch_crt_potato, k_crt_potato)
+RC_SIMPLE_LAUNCH(launch_ntsc_gauss, k_ntsc_gauss)
 RC_SIMPLE_LAUNCH(launch_gbc_gambatte_color, k_gbc_gambatte_color)
 RC_SIMPLE_LAUNCH(launch_shutter_3d, k_shutter_3d)
 RC_SIMPLE_LAUNCH(launch_anti_flicker, k_anti_flicker)

@@ -38,6 +38,7 @@ hipError_t launch_imgborder(const PassLaunch& L, hipStream_t s);
 hipError_t launch_lut(const PassLaunch& L, hipStream_t s);
 hipError_t launch_gb_palette(const PassLaunch& L, hipStream_t s);
 hipError_t launch_crt_potato(const PassLaunch& L, hipStream_t s);
+hipError_t launch_ntsc_gauss(const PassLaunch& L, hipStream_t s);
 hipError_t launch_lcd_grid_v2(const PassLaunch& L, hipStream_t s);
 hipError_t launch_lcd_grid(const PassLaunch& L, hipStream_t s);     // pass_lcd_grid.hip
 hipError_t launch_gbc_gambatte_color(const PassLaunch& L, hipStream_t s);

@@ -392,6 +392,35 @@ BORDER_wrap_mode = "clamp_to_border"
 BORDER_mipmap = "false"
 """)
 
+# ntsc/ntsc-256px-svideo-gauss-scanline.glslp (same keys / values)
+PRESETS["ntsc-256px-svideo-gauss-scanline"] = ("ntsc/ntsc-256px-svideo-gauss-scanline.glslp", """shaders = 4
+shader0 = shaders/ntsc-pass1-svideo-3phase.glsl
+shader1 = shaders/ntsc-pass2-3phase.glsl
+shader2 = shaders/ntsc-gauss-pass.glsl
+shader3 = shaders/ntsc-stock.glsl
+
+filter_linear0 = false
+filter_linear1 = false
+filter_linear2 = false
+filter_linear3 = true 
+
+scale_type_x0 = absolute
+scale_type_y0 = source
+scale_x0 = 1024
+scale_y0 = 1.0
+frame_count_mod0 = 2
+float_framebuffer0 = true
+
+scale_type1 = source
+scale_x1 = 0.5
+scale_y1 = 1.0
+
+scale_type_x2 = source
+scale_type_y2 = viewport
+scale2 = 1.0
+
+""")
+
 # crt/crt-potato-cool.glslp (same keys / values; synthetic mask image)
 PRESETS["crt-potato-cool"] = ("crt/crt-potato-cool.glslp", 'shaders = 1\n\nshader0 = shaders/crt-potato/shader-files/crt-potato.glsl\nfilter_linear0 = false\nscale_type0 = viewport\n'
                               'scale0 = 1.0\nalias0 = "PASS0"\n\ntextures = MASK\nMASK = shaders/crt-potato/resources/crt-potato-thin.png\nMASK_linear = false\nMASK_wrap_mode = "repeat"\n')
@@ -654,6 +683,8 @@ SHADERS = {
                                                                     ("in_res_y", 240.0), ("border_on_top", 1.0), ("border_zoom_x", 1.0), ("border_zoom_y", 1.0)]},
     "handheld/shaders/gb-palette/gb-palette.glsl": {"oracle": "gb_palette", "samplers": ["COLOR_PALETTE"], "params": [], "size_independent": True},
     "crt/shaders/crt-potato/shader-files/crt-potato.glsl": {"oracle": "crt_potato", "samplers": ["MASK"], "params": []},
+    "ntsc/shaders/ntsc-gauss-pass.glsl": {"oracle": "ntsc_gauss", "samplers": [], "params": [("NTSC_CRT_GAMMA", 2.5), ("NTSC_DISPLAY_GAMMA", 2.1)]},
+    "ntsc/shaders/ntsc-stock.glsl": {"oracle": "stock", "params": [], "samplers": [], "size_independent": True},
     "reshade/shaders/LUT/LUT.glsl": {"oracle": "lut", "samplers": ["SamplerLUT"], "params": [("LUT_Size", 16.0)], "size_independent": True},
     "handheld/console-border/shader-files/gb-pass-5.glsl": {"oracle": "gb_pass_5", "samplers": ["BORDER"],
                                                             "params": [("SCALE", 0.6667), ("OUT_X", 1600.0), ("OUT_Y", 800.0)]},

@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "ntsc_gauss_scanline_96x64_to_320x240": "ntsc-256px-svideo-gauss-scanline",
+    "ntsc_gauss_scanline_params_72x40_to_300x171": "ntsc-256px-svideo-gauss-scanline",
     "crt_potato_64x48_to_320x240": "crt-potato-cool",
     "crt_potato_40x30_to_233x171": "crt-potato-cool",
     "gb_palette_dmg_64x48_to_64x48": "gb-palette-dmg",

@@ -62,6 +62,8 @@ CASES = {
     "imgborder_sgb_crt_geom_1x_40x36_to_256x224": "sgb-crt-geom-1x",
     "imgborder_sgb_bare_params_40x30_to_233x171": "imgborder-sgb-bare",
     "console_border_ngpc_3x_40x38_to_300x200": "ngpc-3x",
+    "ntsc_gauss_scanline_96x64_to_320x240": "ntsc-256px-svideo-gauss-scanline",
+    "ntsc_gauss_scanline_params_72x40_to_300x171": "ntsc-256px-svideo-gauss-scanline",
     "crt_potato_64x48_to_320x240": "crt-potato-cool",
     "crt_potato_40x30_to_233x171": "crt-potato-cool",
     "gb_palette_dmg_64x48_to_64x48": "gb-palette-dmg",
@@ -310,6 +312,7 @@ FLOAT_CASES = {
     "f32_psp_color_48x36_to_131x77": ("psp-color", {}),
     "f32_vba_color_48x36_to_131x77": ("vba-color", {}),
     "f32_imgborder_sgb_bare_params_40x30_to_233x171": ("imgborder-sgb-bare", {}),
+    "f32_ntsc_gauss_scanline_72x40_to_256x160": ("ntsc-256px-svideo-gauss-scanline", {}),
     "f32_crt_potato_48x36_to_240x200": ("crt-potato-cool", {}),
     "f32_reshade_lut_48x36_to_131x77": ("reshade-lut", {}),
     "f32_lcd_grid_params_48x36_to_240x180": ("lcd-grid", {}),
