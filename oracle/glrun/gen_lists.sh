@@ -4,6 +4,8 @@
 #   crt-royale's last pass (geometry-aa-last-pass.glsl, both stages)  -> royale_last_{vs,fs}.inc
 #   handheld/shaders/lcd-cgwg/lcd-grid-v2.glsl (fragment stage)        -> lcd_grid_v2_fs.inc
 #   handheld/shaders/lcd-cgwg/lcd-grid.glsl (fragment stage)           -> lcd_grid_fs.inc
+#   crt/shaders/tvout-tweaks.glsl (fragment stage)                     -> tvout_tweaks_fs.inc
+#   misc/image-adjustment.glsl (both stages)                           -> image_adjustment_{vs,fs}.inc
 # written to oracle/gen/ for the oracle and, the same text, to retrocapture_amd/csrc/kernels/gen/ for the HIP kernels.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -33,4 +35,7 @@ listing "$R" LP_DEBUG=fs "$T/fs.txt" && emit "$T/fs.txt" fragment royale_last_fs
 listing "$R" GALLIVM_DEBUG=tgsi "$T/vs.txt" && emit "$T/vs.txt" vertex royale_last_vs
 listing handheld/shaders/lcd-cgwg/lcd-grid-v2.glsl LP_DEBUG=fs "$T/lcd.txt" && emit "$T/lcd.txt" fragment lcd_grid_v2_fs
 listing handheld/shaders/lcd-cgwg/lcd-grid.glsl LP_DEBUG=fs "$T/lcd1.txt" && emit "$T/lcd1.txt" fragment lcd_grid_fs
+listing crt/shaders/tvout-tweaks.glsl LP_DEBUG=fs "$T/tv.txt" && emit "$T/tv.txt" fragment tvout_tweaks_fs
+listing misc/image-adjustment.glsl LP_DEBUG=fs "$T/ia.txt" && emit "$T/ia.txt" fragment image_adjustment_fs
+listing misc/image-adjustment.glsl GALLIVM_DEBUG=tgsi "$T/iav.txt" && emit "$T/iav.txt" vertex image_adjustment_vs
 wc -l "$ROOT"/oracle/gen/*.inc

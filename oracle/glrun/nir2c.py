@@ -261,6 +261,13 @@ def translate(text, stage, name):
             g.set(n, BOOL2[op].format(g.val(args[0]), g.val(args[1])), "i")
         elif op == "inot":
             g.set(n, "(!%s)" % g.val(args[0]), "i")
+        elif op == "i2f32":
+            # only met on integer uniforms (FrameCount), which the callers hand over as floats holding the integer's value
+            src = args[0].split(".")[0][1:]
+            if g.types.get(src) == "i":
+                g.set(n, "(float)%s" % g.val(args[0]))
+            else:
+                g.set(n, g.val(args[0]))
         elif op == "f2i32":
             g.set(n, "RCN_F2I(%s)" % g.val(args[0]), "i")
         elif op == "b2f32":

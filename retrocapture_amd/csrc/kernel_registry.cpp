@@ -1,4 +1,5 @@
 #include "kernel_registry.h"
+#include "list_setup.h"
 
 #include <cmath>
 #include <cstring>
@@ -519,6 +520,38 @@ std::vector<KernelEntry> build() {
                   {}, rck::launch_ntsc_gauss, setupNtscGauss, false};
     e.texture_height_override = true;
     r.push_back(e);
+  }
+  {
+    // the two instruction-list hubs (kernels/pass_lists.hip, list_setup.cpp); both restated under the pass-index-3 TextureSize.y rule
+    KernelEntry t{"crt/shaders/tvout-tweaks.glsl", "tvout-tweaks",
+                  {{"TVOUT_RESOLUTION", 256.0f, 0.0f, 1024.0f, 32.0f, "TVOut Signal Resolution"}, {"TVOUT_COMPOSITE_CONNECTION", 0.0f, 0.0f, 1.0f, 1.0f, "TVOut Composite Enable"},
+                   {"TVOUT_TV_COLOR_LEVELS", 0.0f, 0.0f, 1.0f, 1.0f, "TVOut TV Color Levels Enable"}, {"TVOUT_RESOLUTION_Y", 256.0f, 0.0f, 1024.0f, 32.0f, "TVOut Luma (Y) Resolution"},
+                   {"TVOUT_RESOLUTION_I", 83.2f, 0.0f, 256.0f, 8.0f, "TVOut Chroma (I) Resolution"}, {"TVOUT_RESOLUTION_Q", 25.6f, 0.0f, 256.0f, 8.0f, "TVOut Chroma (Q) Resolution"}},
+                  {}, rck::launch_tvout_tweaks, setupTvoutTweaks, false};
+    t.texture_height_override = true;
+    r.push_back(t);
+    KernelEntry a{"misc/image-adjustment.glsl", "image-adjustment",
+                  {{"ia_target_gamma", 2.2f, 0.1f, 5.0f, 0.1f, "Target Gamma"}, {"ia_monitor_gamma", 2.2f, 0.1f, 5.0f, 0.1f, "Monitor Gamma"},
+                   {"ia_overscan_percent_x", 0.0f, -25.0f, 25.0f, 1.0f, "Horizontal Overscan %"}, {"ia_overscan_percent_y", 0.0f, -25.0f, 25.0f, 1.0f, "Vertical Overscan %"},
+                   {"ia_saturation", 1.0f, 0.0f, 5.0f, 0.1f, "Saturation"}, {"ia_contrast", 1.0f, 0.0f, 10.0f, 0.05f, "Contrast"},
+                   {"ia_luminance", 1.0f, 0.0f, 2.0f, 0.1f, "Luminance"}, {"ia_black_level", 0.0f, -0.3f, 0.3f, 0.01f, "Black Level"},
+                   {"ia_bright_boost", 0.0f, -1.0f, 1.0f, 0.05f, "Brightness Boost"}, {"ia_R", 1.0f, 0.0f, 2.0f, 0.05f, "Red Channel"},
+                   {"ia_G", 1.0f, 0.0f, 2.0f, 0.05f, "Green Channel"}, {"ia_B", 1.0f, 0.0f, 2.0f, 0.05f, "Blue Channel"},
+                   {"ia_ZOOM", 1.0f, 0.0f, 4.0f, 0.01f, "Zoom Factor"}, {"ia_XPOS", 0.0f, -2.0f, 2.0f, 0.005f, "X Modifier"},
+                   {"ia_YPOS", 0.0f, -2.0f, 2.0f, 0.005f, "Y Modifier"}, {"ia_TOPMASK", 0.0f, 0.0f, 1.0f, 0.0025f, "Overscan Mask Top"},
+                   {"ia_BOTMASK", 0.0f, 0.0f, 1.0f, 0.0025f, "Overscan Mask Bottom"}, {"ia_LMASK", 0.0f, 0.0f, 1.0f, 0.0025f, "Overscan Mask Left"},
+                   {"ia_RMASK", 0.0f, 0.0f, 1.0f, 0.0025f, "Overscan Mask Right"}, {"ia_GRAIN_STR", 0.0f, 0.0f, 72.0f, 6.0f, "Film Grain"},
+                   {"ia_SHARPEN", 0.0f, 0.0f, 1.0f, 0.05f, "Sharpen"}, {"ia_FLIP_HORZ", 0.0f, 0.0f, 1.0f, 1.0f, "Flip Horiz Axis"},
+                   {"ia_FLIP_VERT", 0.0f, 0.0f, 1.0f, 1.0f, "Flip Vert Axis"}},
+                  {}, rck::launch_image_adjustment, setupImageAdjustment, false};
+    a.texture_height_override = true;
+    // the shader "flips" by moving the quad itself (flip_pos = 1 - VertexCoord on clip-space coordinates: x in [0, 2]), which leaves half the
+    // target to the clear colour and the rest to clipped triangles: not restated
+    a.validate = [](const float* p) -> const char* {
+      return (p[21] > 0.5f || p[22] > 0.5f) ? "image-adjustment.glsl: ia_FLIP_HORZ / ia_FLIP_VERT move the quad half off the target (clipped geometry), which is not restated"
+                                           : nullptr;
+    };
+    r.push_back(a);
   }
   // ntsc/shaders/ntsc-stock.glsl: the text of stock.glsl (a plain copy, llvmpipe's blit rules included)
   r.push_back({"ntsc/shaders/ntsc-stock.glsl", "ntsc-stock", {}, {}, rck::launch_stock, setupTexCoord, false, true, nullptr, nullptr, true});

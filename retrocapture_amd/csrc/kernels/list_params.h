@@ -1,0 +1,7 @@
+// PassLaunch::params layout of the instruction-list passes of pass_lists.hip: the shader's #pragma parameters first (as for every
+// pass), the list's uniform block - in the dword layout gen/<name>_fs.inc addresses - from kListU0 on (filled by list_setup.cpp).
+#pragma once
+constexpr int kListU0 = 32;
+constexpr int kTvoutU = 10;             // tvout_tweaks_fs_uniforms: 6 parameters, TextureSize, InputSize
+constexpr int kImageAdjU = 21;          // image_adjustment_fs_uniforms: 16 parameters, FrameCount, TextureSize, InputSize
+constexpr int kImageAdjFrameCount = 16;

@@ -1,0 +1,84 @@
+// Two hub shaders of the reference's preset tree whose per-pixel bodies are the GL's own instruction lists (gen/*.inc, produced by
+// oracle/glrun/nir2c.py from Mesa llvmpipe's NIR; recipe oracle/glrun/gen_lists.sh; pass_lcd_grid.hip and pass_royale_last_general.hip
+// explain why):
+//   crt/shaders/tvout-tweaks.glsl (39 presets), FS 99-214: sinc resampling of Y, I and Q at three signal bandwidths - 32 sin per pixel -
+//       composite cross-talk and TV colour levels behind run-time switches; ~840 operations, 17 (wave-uniform) branches.
+//   misc/image-adjustment.glsl (48 presets): gamma, saturation / contrast / luminance, channel gains, overscan masks, film grain seeded
+//       by FrameCount, sharpen; its vertex stage (zoom, shift, overscan) runs on the host per launch (list_setup.cpp); the two flip
+//       parameters move the quad itself half off the target and are refused (kernel_registry.cpp).
+// One thread per target pixel; uniform blocks are built per launch in the layouts the lists address.  Both are VALU-bound.
+#include "list_params.h"
+#include "pass_launch.h"
+#include "rc_vecmath.h"
+
+using namespace rcd;
+
+namespace {
+
+struct TexCtx {
+  const Tex* t;
+  const uint8_t* img;
+  const SrgbLds* lds;
+};
+__device__ __forceinline__ void rcn_tex(void* vctx, float u, float v, float* dst) {
+  const TexCtx* c = static_cast<const TexCtx*>(vctx);
+  const float4 r = sample_rt(*c->t, c->img, u, v, c->lds);
+  dst[0] = r.x;
+  dst[1] = r.y;
+  dst[2] = r.z;
+  dst[3] = r.w;
+}
+__device__ __forceinline__ float rcn_min(float a, float b) { return b != b ? a : (a < b ? a : b); }   // gallivm's fmin / fmax: the operand that is not NaN
+__device__ __forceinline__ float rcn_max(float a, float b) { return b != b ? a : (a > b ? a : b); }
+__device__ __forceinline__ float rcn_pow(float x, float y) { return x != x ? 0.0f : pow_(x, y); }     // llvmpipe: pow of a NaN base is 0
+
+#define RCN_FN __device__ __forceinline__ static
+#define RCN_NO_TABLES
+#define RCN_BITS(u) bits2f(u)
+#define RCN_ABS(x) __builtin_fabsf(x)
+#define RCN_RCP(x) (1.0f / (x))
+#define RCN_DIV(a, b) ((a) / (b))
+#define RCN_FLOOR(x) __builtin_floorf(x)
+#define RCN_FRACT(x) ((x) - __builtin_floorf(x))
+#define RCN_MIN(a, b) rcn_min(a, b)
+#define RCN_MAX(a, b) rcn_max(a, b)
+#define RCN_POW(a, b) rcn_pow(a, b)
+#define RCN_SIN(x) sin_(x)
+#define RCN_TEX(ctx, unit, u, v, dst) rcn_tex(ctx, u, v, dst)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wunused-but-set-variable"
+#pragma clang diagnostic ignored "-Wunused-variable"
+#include "gen/tvout_tweaks_fs.inc"
+#include "gen/image_adjustment_fs.inc"
+#pragma clang diagnostic pop
+
+// The uniform block of the list is handed over ready-made in params[kListU0 ..] (registry: setupTvoutTweaks / setupImageAdjustment).
+// FC: the block's FrameCount slot (an int uniform the lists take as a float holding its value), or -1
+template <int NU, int FC, void (*FS)(const float*, const float*, float*, void*)>
+__global__ void __launch_bounds__(256) k_list_pass(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  float U[NU];
+#pragma unroll
+  for (int k = 0; k < NU; ++k) U[k] = L.params[kListU0 + k];
+  RC_TILE_LOOP_BEGIN
+  if (FC >= 0) U[FC] = (float)(L.frame_count0 + z);
+  const float in[2] = {vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo)};
+  float out[4];
+  TexCtx ctx{&L.in, frame_ptr(L.in, z), &lds};
+  FS(U, in, out, &ctx);
+  store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], out[3]), &lds);
+  RC_TILE_LOOP_END
+}
+
+}  // namespace
+
+namespace rck {
+hipError_t launch_tvout_tweaks(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL((k_list_pass<kTvoutU, -1, tvout_tweaks_fs>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  return hipGetLastError();
+}
+hipError_t launch_image_adjustment(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL((k_list_pass<kImageAdjU, kImageAdjFrameCount, image_adjustment_fs>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  return hipGetLastError();
+}
+}  // namespace rck

@@ -1,0 +1,84 @@
+#include "list_setup.h"
+
+#include <cmath>
+#include <cstring>
+
+#include "kernels/list_params.h"
+#include "rc_log.h"
+#include "varying.h"
+
+namespace rc {
+namespace {
+
+// the generated tables (uniform name -> dword) and image-adjustment's vertex stage, with host primitives
+#define RCN_FN static
+#define RCN_BITS(u) rcd::bits2f(u)
+#define RCN_DIV(a, b) ((a) / (b))
+#define RCN_TEX(ctx, unit, u, v, dst) ((void)0)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wunused-but-set-variable"
+#pragma clang diagnostic ignored "-Wunused-variable"
+#include "kernels/gen/image_adjustment_vs.inc"
+#define RCN_TABLES_ONLY
+#include "kernels/gen/image_adjustment_fs.inc"
+#include "kernels/gen/tvout_tweaks_fs.inc"
+#undef RCN_TABLES_ONLY
+#pragma clang diagnostic pop
+
+template <class T>
+void put(float* U, const T* table, const char* name, const float* v, int n, int cap) {
+  for (; table->name; ++table)
+    if (!std::strcmp(table->name, name)) {
+      for (int k = 0; k < n && k < table->n && table->off + k < cap; ++k) U[table->off + k] = v[k];
+      return;
+    }
+}
+// TextureSize / InputSize / OutputSize as the reference hands them over: pass index 3 gets TextureSize.y = the TARGET's height when it
+// scales its height (ShaderEngine.cpp:2418-2421)
+template <class T>
+void putSizes(float* U, const T* table, const PassGeometry& g, int cap) {
+  const float os[2] = {(float)g.out_w, (float)g.out_h}, is[2] = {(float)g.in_w, (float)g.in_h};
+  const float ts[2] = {is[0], (g.pass_index == 3 && g.out_h != g.in_h) ? (float)g.out_h : is[1]};
+  put(U, table, "OutputSize", os, 2, cap);
+  put(U, table, "InputSize", is, 2, cap);
+  put(U, table, "TextureSize", ts, 2, cap);
+}
+
+const char* const kTvoutNames[6] = {"TVOUT_RESOLUTION", "TVOUT_COMPOSITE_CONNECTION", "TVOUT_TV_COLOR_LEVELS", "TVOUT_RESOLUTION_Y", "TVOUT_RESOLUTION_I",
+                                    "TVOUT_RESOLUTION_Q"};
+const char* const kImageAdjNames[23] = {"ia_target_gamma", "ia_monitor_gamma", "ia_overscan_percent_x", "ia_overscan_percent_y", "ia_saturation", "ia_contrast",
+                                        "ia_luminance", "ia_black_level", "ia_bright_boost", "ia_R", "ia_G", "ia_B", "ia_ZOOM", "ia_XPOS", "ia_YPOS", "ia_TOPMASK",
+                                        "ia_BOTMASK", "ia_LMASK", "ia_RMASK", "ia_GRAIN_STR", "ia_SHARPEN", "ia_FLIP_HORZ", "ia_FLIP_VERT"};
+
+}  // namespace
+
+void setupTvoutTweaks(const PassGeometry& g, rcd::PassLaunch& L) {
+  L.plane[0] = planeU(1.0f, g.out_w, g.out_h, g.out_fmt);
+  L.plane[1] = planeV(1.0f, g.out_w, g.out_h, g.out_fmt);
+  float* U = L.params + kListU0;
+  for (int k = 0; k < kTvoutU; ++k) U[k] = 0.0f;
+  putSizes(U, tvout_tweaks_fs_uniforms, g, kTvoutU);
+  for (int k = 0; k < 6; ++k) put(U, tvout_tweaks_fs_uniforms, kTvoutNames[k], &L.params[k], 1, kTvoutU);
+}
+
+void setupImageAdjustment(const PassGeometry& g, rcd::PassLaunch& L) {
+  float* U = L.params + kListU0;
+  for (int k = 0; k < kImageAdjU; ++k) U[k] = 0.0f;
+  putSizes(U, image_adjustment_fs_uniforms, g, kImageAdjU);
+  for (int k = 0; k < 23; ++k) put(U, image_adjustment_fs_uniforms, kImageAdjNames[k], &L.params[k], 1, kImageAdjU);
+  // vertex stage (image-adjustment.glsl VS: overscan, zoom, shift, flip of TexCoord) at the quad's vertices BL, BR, TR, TL
+  float Uv[64] = {};
+  static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  put(Uv, image_adjustment_vs_uniforms, "MVPMatrix", ident, 16, 64);
+  putSizes(Uv, image_adjustment_vs_uniforms, g, 64);
+  for (int k = 0; k < 23; ++k) put(Uv, image_adjustment_vs_uniforms, kImageAdjNames[k], &L.params[k], 1, 64);
+  static const float pos[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}}, uv[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+  float out[4][48] = {};
+  for (int v = 0; v < 4; ++v) {
+    const float in[8] = {pos[v][0], pos[v][1], 0.0f, 1.0f, uv[v][0], uv[v][1], 0.0f, 1.0f};
+    image_adjustment_vs(Uv, in, out[v], nullptr);
+  }
+  for (int c = 0; c < 2; ++c) L.plane[c] = makePlane(out[0][c], out[1][c], out[2][c], out[3][c], g.out_w, g.out_h, g.out_fmt);
+}
+
+}  // namespace rc

@@ -1,0 +1,8 @@
+// Per-launch host setup of the instruction-list passes (kernels/pass_lists.hip): uniform blocks by name, image-adjustment's vertex stage.
+#pragma once
+#include "kernel_registry.h"
+
+namespace rc {
+void setupTvoutTweaks(const PassGeometry& g, rcd::PassLaunch& L);
+void setupImageAdjustment(const PassGeometry& g, rcd::PassLaunch& L);
+}  // namespace rc

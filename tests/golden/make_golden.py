@@ -495,6 +495,28 @@ def case_hyllian_glow():
              params=[("HFILTER_SHARPNESS", 0.7), ("CRT_ANTI_RINGING", 0.6), ("MASK_INTENSITY", 0.7), ("PHOSPHOR_LAYOUT", 5.0)])
 
 
+def case_tvout():
+    """crt/shaders/tvout-tweaks.glsl and misc/image-adjustment.glsl: in the reference's presets (image-adjustment at pass index 3 in the 4-pass one) and
+    alone with their parameters moved (composite cross-talk and colour levels on; zoom, shift, overscan, masks, grain by FrameCount, sharpen)."""
+    P = GLSL + "/presets/"
+    run_case("tvout_64x48_to_320x240", P + "tvout/tvout.glslp", mixed(64, 48, 200), 320, 240)
+    run_case("tvout_ntsc_256px_svideo_72x40_to_300x171", P + "tvout/tvout+ntsc-256px-svideo.glslp", mixed(72, 40, 201), 300, 171)
+    run_case("retro_v2_image_adjustment_40x30_to_233x171", P + "retro-v2+image-adjustment.glslp", noise(40, 30, 202), 233, 171)
+    with tempfile.TemporaryDirectory() as d:
+        pt = write_preset(d, 'shaders = 1\nshader0 = %s/crt/shaders/tvout-tweaks.glsl\nfilter_linear0 = false\n' % GLSL)
+        tprm = [("TVOUT_RESOLUTION", 192.0), ("TVOUT_COMPOSITE_CONNECTION", 1.0), ("TVOUT_TV_COLOR_LEVELS", 1.0), ("TVOUT_RESOLUTION_Y", 224.0),
+                ("TVOUT_RESOLUTION_I", 64.0), ("TVOUT_RESOLUTION_Q", 32.0)]
+        run_case("tvout_tweaks_bare_params_64x48_to_256x192", pt, mixed(64, 48, 203), 256, 192, params=tprm)
+        run_case("f32_tvout_tweaks_bare_params_48x36_to_200x150", pt, noise(48, 36, 204), 200, 150, params=tprm, f32=True)
+        pi = write_preset(d, 'shaders = 1\nshader0 = %s/misc/image-adjustment.glsl\nfilter_linear0 = false\n' % GLSL)
+        iprm = [("ia_target_gamma", 2.4), ("ia_monitor_gamma", 2.0), ("ia_overscan_percent_x", 4.0), ("ia_overscan_percent_y", -3.0), ("ia_saturation", 1.3),
+                ("ia_contrast", 1.1), ("ia_luminance", 0.9), ("ia_black_level", 0.03), ("ia_bright_boost", 0.1), ("ia_R", 1.1), ("ia_G", 0.95), ("ia_B", 1.05),
+                ("ia_ZOOM", 1.2), ("ia_XPOS", 0.03), ("ia_YPOS", -0.02), ("ia_TOPMASK", 0.05), ("ia_BOTMASK", 0.04), ("ia_LMASK", 0.03), ("ia_RMASK", 0.02),
+                ("ia_GRAIN_STR", 12.0), ("ia_SHARPEN", 0.4)]   # ia_FLIP_*: the shader moves the quad half off the target (not restated, refused)
+        run_case("image_adjustment_bare_params_64x48_to_256x192_f3", pi, mixed(64, 48, 205), 256, 192, params=iprm, frames=3)
+        run_case("f32_image_adjustment_bare_params_48x36_to_200x150_f2", pi, noise(48, 36, 206), 200, 150, params=iprm, f32=True, frames=2)
+
+
 def case_ntsc_gauss():
     N = GLSL + "/ntsc/ntsc-256px-svideo-gauss-scanline.glslp"
     run_case("ntsc_gauss_scanline_96x64_to_320x240", N, mixed(96, 64, 190), 320, 240)
@@ -817,7 +839,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"ntsc_gauss": case_ntsc_gauss, "crt_potato": case_crt_potato, "gb_palette": case_gb_palette, "reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"tvout": case_tvout, "ntsc_gauss": case_ntsc_gauss, "crt_potato": case_crt_potato, "gb_palette": case_gb_palette, "reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -12,6 +12,11 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "tvout_64x48_to_320x240": "tvout",
+    "tvout_ntsc_256px_svideo_72x40_to_300x171": "tvout+ntsc-256px-svideo",
+    "retro_v2_image_adjustment_40x30_to_233x171": "retro-v2+image-adjustment",
+    "tvout_tweaks_bare_params_64x48_to_256x192": "tvout-tweaks-bare",
+    "image_adjustment_bare_params_64x48_to_256x192_f3": "image-adjustment-bare",
     "ntsc_gauss_scanline_96x64_to_320x240": "ntsc-256px-svideo-gauss-scanline",
     "ntsc_gauss_scanline_params_72x40_to_300x171": "ntsc-256px-svideo-gauss-scanline",
     "crt_potato_64x48_to_320x240": "crt-potato-cool",

@@ -62,6 +62,11 @@ CASES = {
     "imgborder_sgb_crt_geom_1x_40x36_to_256x224": "sgb-crt-geom-1x",
     "imgborder_sgb_bare_params_40x30_to_233x171": "imgborder-sgb-bare",
     "console_border_ngpc_3x_40x38_to_300x200": "ngpc-3x",
+    "tvout_64x48_to_320x240": "tvout",                                               # crt/shaders/tvout-tweaks + misc/image-adjustment (instruction lists)
+    "tvout_ntsc_256px_svideo_72x40_to_300x171": "tvout+ntsc-256px-svideo",         # image-adjustment at pass index 3 (TextureSize.y rule)
+    "retro_v2_image_adjustment_40x30_to_233x171": "retro-v2+image-adjustment",
+    "tvout_tweaks_bare_params_64x48_to_256x192": "tvout-tweaks-bare",
+    "image_adjustment_bare_params_64x48_to_256x192_f3": "image-adjustment-bare",   # film grain seeded by FrameCount (3rd frame), zoom, shift, masks, sharpen
     "ntsc_gauss_scanline_96x64_to_320x240": "ntsc-256px-svideo-gauss-scanline",
     "ntsc_gauss_scanline_params_72x40_to_300x171": "ntsc-256px-svideo-gauss-scanline",
     "crt_potato_64x48_to_320x240": "crt-potato-cool",
@@ -312,6 +317,8 @@ FLOAT_CASES = {
     "f32_psp_color_48x36_to_131x77": ("psp-color", {}),
     "f32_vba_color_48x36_to_131x77": ("vba-color", {}),
     "f32_imgborder_sgb_bare_params_40x30_to_233x171": ("imgborder-sgb-bare", {}),
+    "f32_tvout_tweaks_bare_params_48x36_to_200x150": ("tvout-tweaks-bare", {}),
+    "f32_image_adjustment_bare_params_48x36_to_200x150_f2": ("image-adjustment-bare", {}),
     "f32_ntsc_gauss_scanline_72x40_to_256x160": ("ntsc-256px-svideo-gauss-scanline", {}),
     "f32_crt_potato_48x36_to_240x200": ("crt-potato-cool", {}),
     "f32_reshade_lut_48x36_to_131x77": ("reshade-lut", {}),
