@@ -692,7 +692,7 @@ SHADERS = {
                                                                     ("in_res_y", 240.0), ("border_on_top", 1.0), ("border_zoom_x", 1.0), ("border_zoom_y", 1.0)]},
     "handheld/shaders/gb-palette/gb-palette.glsl": {"oracle": "gb_palette", "samplers": ["COLOR_PALETTE"], "params": [], "size_independent": True},
     "crt/shaders/crt-potato/shader-files/crt-potato.glsl": {"oracle": "crt_potato", "samplers": ["MASK"], "params": []},
-    "crt/shaders/tvout-tweaks.glsl": {"oracle": "tvout_tweaks", "samplers": [], "params": [('TVOUT_RESOLUTION', 256.0), ('TVOUT_COMPOSITE_CONNECTION', 0.0), ('TVOUT_TV_COLOR_LEVELS', 0.0), ('TVOUT_RESOLUTION_Y', 256.0), ('TVOUT_RESOLUTION_I', 83.2), ('TVOUT_RESOLUTION_Q', 25.6)]},
+    "crt/shaders/tvout-tweaks.glsl": {"oracle": "tvout_tweaks", "samplers": [], "params": [('TVOUT_RESOLUTION', 256.0), ('TVOUT_COMPOSITE_CONNECTION', 0.0), ('TVOUT_TV_COLOR_LEVELS', 0.0), ('TVOUT_RESOLUTION_Y', 256.0), ('TVOUT_RESOLUTION_I', 83.19999694824219), ('TVOUT_RESOLUTION_Q', 25.600000381469727)]},
     "misc/image-adjustment.glsl": {"oracle": "image_adjustment", "samplers": [], "params": [('ia_target_gamma', 2.2), ('ia_monitor_gamma', 2.2), ('ia_overscan_percent_x', 0.0), ('ia_overscan_percent_y', 0.0), ('ia_saturation', 1.0), ('ia_contrast', 1.0), ('ia_luminance', 1.0), ('ia_black_level', 0.0), ('ia_bright_boost', 0.0), ('ia_R', 1.0), ('ia_G', 1.0), ('ia_B', 1.0), ('ia_ZOOM', 1.0), ('ia_XPOS', 0.0), ('ia_YPOS', 0.0), ('ia_TOPMASK', 0.0), ('ia_BOTMASK', 0.0), ('ia_LMASK', 0.0), ('ia_RMASK', 0.0), ('ia_GRAIN_STR', 0.0), ('ia_SHARPEN', 0.0), ('ia_FLIP_HORZ', 0.0), ('ia_FLIP_VERT', 0.0)]},
     "ntsc/shaders/ntsc-gauss-pass.glsl": {"oracle": "ntsc_gauss", "samplers": [], "params": [("NTSC_CRT_GAMMA", 2.5), ("NTSC_DISPLAY_GAMMA", 2.1)]},
     "ntsc/shaders/ntsc-stock.glsl": {"oracle": "stock", "params": [], "samplers": [], "size_independent": True},
