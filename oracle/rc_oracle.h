@@ -151,6 +151,7 @@ void o_pass_response_time(const o_pass_args* a);      /* 1 param; extra[0..6] = 
 void o_pass_tvout_tweaks(const o_pass_args* a);       /* 6 params (rc_passes_lists.c) */
 void o_pass_image_adjustment(const o_pass_args* a);   /* 23 params (rc_passes_lists.c) */
 void o_pass_ntsc_gauss(const o_pass_args* a);         /* 2 params (rc_passes_ntsc_xbr.c) */
+void o_pass_interlacing(const o_pass_args* a);        /* 3 params */
 void o_pass_crt_potato(const o_pass_args* a);         /* no params; extra[0] = MASK */
 void o_pass_gb_palette(const o_pass_args* a);         /* no params; extra[0] = COLOR_PALETTE */
 void o_pass_lut(const o_pass_args* a);                /* 1 param; extra[0] = SamplerLUT */

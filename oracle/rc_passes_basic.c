@@ -994,3 +994,26 @@ void o_pass_crt_potato(const o_pass_args* a) {
     }
   o_fp_leave(csr);
 }
+
+/* misc/interlacing.glsl FS main (24 presets): every other line of the frame dimmed to `percent`; above 400 source lines the field alternates
+ * with FrameCount (enable_480i) and top_field_first shifts it.  The shader the reference's pass-index-3 TextureSize.y rule was written for
+ * (ShaderEngine.cpp:2418-2421).  Operation order from the GL's instruction listing.  params: percent, enable_480i, top_field_first. */
+void o_pass_interlacing(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  const float* P = a->params;
+  const float isy = (float)a->in->h, tsy = (a->pass_index == 3 && H != a->in->h) ? (float)H : isy, fc = (float)a->frame_count;
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      const o_vec4 c = o_sample(a->in, u, v);
+      const float line = 400.0f < isy ? (tsy * v + P[2]) + fc * P[1] : (2.000001f * tsy) * v + P[2];
+      const float m = line + -(1.99999f * floorf(line / 1.99999f));
+      const int keep = 0.99999f < m;
+      const o_vec4 out = {keep ? c.x : P[0] * c.x, keep ? c.y : P[0] * c.y, keep ? c.z : P[0] * c.z, keep ? c.w : P[0] * c.w};
+      store_px(a, x, y, out);
+    }
+  o_fp_leave(csr);
+}

@@ -129,6 +129,11 @@ void setupNtscGauss(const PassGeometry& g, rcd::PassLaunch& L) {
   L.plane[2] = makePlane(0.f * tsy, 0.f * tsy, 1.f * tsy, 1.f * tsy, g.out_w, g.out_h, g.out_fmt);
   L.plane[3] = makePlane(one, one, one, one, g.out_w, g.out_h, g.out_fmt);
 }
+// interlacing.glsl: TextureSize.y as the reference hands it to pass index 3 (the target's height when the pass scales its height)
+void setupInterlacing(const PassGeometry& g, rcd::PassLaunch& L) {
+  setupTexCoord(g, L);
+  L.params[8] = (g.pass_index == 3 && g.out_h != g.in_h) ? (float)g.out_h : (float)g.in_h;
+}
 // shutter-3d.glsl VS 61-73: left_coord / right_coord at the quad's vertices, in the GL's operation order (oracle/rc_passes_basic.c)
 void setupShutter3d(const PassGeometry& g, rcd::PassLaunch& L) {
   const float* P = L.params;
@@ -552,6 +557,14 @@ std::vector<KernelEntry> build() {
                                            : nullptr;
     };
     r.push_back(a);
+  }
+  {
+    KernelEntry e{"misc/interlacing.glsl", "interlacing",
+                  {{"percent", 0.0f, 0.0f, 1.0f, 0.05f, "Interlacing Scanline Bright %"}, {"enable_480i", 1.0f, 0.0f, 1.0f, 1.0f, "Enable 480i Mode"},
+                   {"top_field_first", 0.0f, 0.0f, 1.0f, 1.0f, "Top Field First Enable"}},
+                  {}, rck::launch_interlacing, setupInterlacing, false};
+    e.texture_height_override = true;
+    r.push_back(e);
   }
   // ntsc/shaders/ntsc-stock.glsl: the text of stock.glsl (a plain copy, llvmpipe's blit rules included)
   r.push_back({"ntsc/shaders/ntsc-stock.glsl", "ntsc-stock", {}, {}, rck::launch_stock, setupTexCoord, false, true, nullptr, nullptr, true});

@@ -255,6 +255,24 @@ __global__ void __launch_bounds__(256) k_ntsc_gauss(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// misc/interlacing.glsl FS main (24 presets): every other line dimmed to `percent`; above 400 source lines the field alternates with FrameCount
+// (enable_480i), top_field_first shifts it.  params: percent, enable_480i, top_field_first, [8] = TextureSize.y as the reference hands it over
+// (the pass-index-3 rule was written for this shader; registry: setupInterlacing).
+__global__ void __launch_bounds__(256) k_interlacing(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  const float* P = L.params;
+  const float isy = (float)L.in.h, tsy = P[8];
+  RC_TILE_LOOP_BEGIN
+  const float fc = (float)(L.frame_count0 + z);
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds);
+  const float line = 400.0f < isy ? (tsy * v + P[2]) + fc * P[1] : (2.000001f * tsy) * v + P[2];
+  const float m = line + -(1.99999f * __builtin_floorf(line / 1.99999f));
+  const bool keep = 0.99999f < m;
+  store_rt(L, z, x, y, keep ? c : make_float4(P[0] * c.x, P[0] * c.y, P[0] * c.z, P[0] * c.w), &lds);
+  RC_TILE_LOOP_END
+}
+
 // handheld/shaders/mgba/agb001.glsl FS main (handheld/agb001.glslp, agb001-gba-color-motionblur.glslp): pow(texel * 0.8, 1.8) + 0.16 under
 // a 4x4 subpixel pattern per source texel - column 0 / 1 / 2 keeps red / green / blue and takes the other two to 0.2, column 3
 // takes all to 0.4, row 3 another 0.8 - alpha 0.5.  Index: int(mod(coord * size * 4, 4)), mod as a - 4 floor(a / 4).
@@ -780,6 +798,7 @@ RC_SIMPLE_LAUNCH(launch_lut, k_lut)
 RC_SIMPLE_LAUNCH(launch_gb_palette, k_gb_palette)
 RC_SIMPLE_LAUNCH(launch_crt_potato, k_crt_potato)
 RC_SIMPLE_LAUNCH(launch_ntsc_gauss, k_ntsc_gauss)
+RC_SIMPLE_LAUNCH(launch_interlacing, k_interlacing)
 RC_SIMPLE_LAUNCH(launch_gbc_gambatte_color, k_gbc_gambatte_color)
 RC_SIMPLE_LAUNCH(launch_shutter_3d, k_shutter_3d)
 RC_SIMPLE_LAUNCH(launch_anti_flicker, k_anti_flicker)

@@ -39,6 +39,7 @@ hipError_t launch_lut(const PassLaunch& L, hipStream_t s);
 hipError_t launch_gb_palette(const PassLaunch& L, hipStream_t s);
 hipError_t launch_crt_potato(const PassLaunch& L, hipStream_t s);
 hipError_t launch_ntsc_gauss(const PassLaunch& L, hipStream_t s);
+hipError_t launch_interlacing(const PassLaunch& L, hipStream_t s);
 hipError_t launch_tvout_tweaks(const PassLaunch& L, hipStream_t s);       // pass_lists.hip
 hipError_t launch_image_adjustment(const PassLaunch& L, hipStream_t s);
 hipError_t launch_lcd_grid_v2(const PassLaunch& L, hipStream_t s);

@@ -12,6 +12,10 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "tvout_interlacing_64x48_to_320x240": "tvout+interlacing",
+    "interlacing_bare_40x420_to_160x420_f3": "interlacing-bare",
+    "interlacing_bare_40x420_to_120x300_f2": "interlacing-bare",
+    "interlacing_bare_48x36_to_200x150": "interlacing-bare",
     "tvout_64x48_to_320x240": "tvout",
     "tvout_ntsc_256px_svideo_72x40_to_300x171": "tvout+ntsc-256px-svideo",
     "retro_v2_image_adjustment_40x30_to_233x171": "retro-v2+image-adjustment",
