@@ -6,6 +6,7 @@
 #   handheld/shaders/lcd-cgwg/lcd-grid.glsl (fragment stage)           -> lcd_grid_fs.inc
 #   crt/shaders/tvout-tweaks.glsl (fragment stage)                     -> tvout_tweaks_fs.inc
 #   misc/image-adjustment.glsl (both stages)                           -> image_adjustment_{vs,fs}.inc
+#   windowed/shaders/jinc2-sharper.glsl (fragment stage)               -> jinc2_sharper_fs.inc
 # written to oracle/gen/ for the oracle and, the same text, to retrocapture_amd/csrc/kernels/gen/ for the HIP kernels.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -38,4 +39,5 @@ listing handheld/shaders/lcd-cgwg/lcd-grid.glsl LP_DEBUG=fs "$T/lcd1.txt" && emi
 listing crt/shaders/tvout-tweaks.glsl LP_DEBUG=fs "$T/tv.txt" && emit "$T/tv.txt" fragment tvout_tweaks_fs
 listing misc/image-adjustment.glsl LP_DEBUG=fs "$T/ia.txt" && emit "$T/ia.txt" fragment image_adjustment_fs
 listing misc/image-adjustment.glsl GALLIVM_DEBUG=tgsi "$T/iav.txt" && emit "$T/iav.txt" vertex image_adjustment_vs
+listing windowed/shaders/jinc2-sharper.glsl LP_DEBUG=fs "$T/j2.txt" && emit "$T/j2.txt" fragment jinc2_sharper_fs
 wc -l "$ROOT"/oracle/gen/*.inc

@@ -181,6 +181,16 @@ def translate(text, stage, name):
             g.types[n] = "reg"
             g.decl_v["r" + n] = 0
             continue
+        if op == "undefined":
+            # an output component the shader never writes (its store masks it out): zeros here, the caller's OUT keeps its own default
+            if ncomp == 1:
+                g.set(n, "0.0f")
+            else:
+                g.types[n] = ("v", ncomp)
+                g.decl_v["v" + n] = ncomp
+                for k in range(ncomp):
+                    g.emit("v%s[%d] = 0.0f;" % (n, k))
+            continue
         if op == "load_const":
             words = re.findall(r"0x([0-9a-f]{8})", rhs)
             g.const[n] = [int(w, 16) for w in words]

@@ -28,6 +28,7 @@ static inline float rcn_max(float a, float b) { return b != b ? a : (a > b ? a :
 #define RCN_MAX(a, b) rcn_max(a, b)
 #define RCN_POW(a, b) o_pow(a, b)
 #define RCN_SIN(x) o_sin(x)
+#define RCN_SQRT(x) sqrtf(x)
 static void rcn_tex(void* ctx, float u, float v, float* dst) {
   const o_vec4 r = o_sample((const o_tex*)ctx, u, v);
   dst[0] = r.x; dst[1] = r.y; dst[2] = r.z; dst[3] = r.w;
@@ -37,6 +38,7 @@ static void rcn_tex(void* ctx, float u, float v, float* dst) {
 #pragma GCC diagnostic push
 #pragma GCC diagnostic ignored "-Wunused-but-set-variable"
 #include "gen/tvout_tweaks_fs.inc"
+#include "gen/jinc2_sharper_fs.inc"
 #include "gen/image_adjustment_vs.inc"
 #include "gen/image_adjustment_fs.inc"
 #pragma GCC diagnostic pop
@@ -112,6 +114,28 @@ void o_pass_image_adjustment(const o_pass_args* a) {
       const float in[2] = {o_varying_at(&pl[0], x, y, lo), o_varying_at(&pl[1], x, y, lo)};
       float out[4];
       image_adjustment_fs(Uf, in, out, (void*)a->in);
+      const o_vec4 o = {out[0], out[1], out[2], out[3]};
+      o_store_pixel(a, x, y, o);
+    }
+  o_fp_leave(csr);
+}
+
+/* windowed/shaders/jinc2-sharper.glsl (windowed/jinc2-sharper.glslp, the tvout-jinc-sharpen presets, 10 in all): a 4x4 jinc-windowed-jinc
+ * resampler - 16 taps, each weight two sin of a sqrt distance - with anti-ringing clamp; ~430 operations, the GL's instruction list.
+ * VS: TEX0 = TexCoord * 1.0001.  No parameters. */
+void o_pass_jinc2_sharper(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  float U[8] = {0};
+  put_sizes(U, jinc2_sharper_fs_uniforms, a, 1);
+  o_varying tu = o_varying_setup(0.f * 1.0001f, 1.f * 1.0001f, 1.f * 1.0001f, 0.f * 1.0001f, W, H, a->out_fmt);
+  o_varying tv = o_varying_setup(0.f * 1.0001f, 0.f * 1.0001f, 1.f * 1.0001f, 1.f * 1.0001f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float in[2] = {o_varying_at(&tu, x, y, lo), o_varying_at(&tv, x, y, lo)};
+      float out[4] = {0.f, 0.f, 0.f, 0.f};   /* the shader never writes alpha: the GL stores 0 */
+      jinc2_sharper_fs(U, in, out, (void*)a->in);
       const o_vec4 o = {out[0], out[1], out[2], out[3]};
       o_store_pixel(a, x, y, o);
     }

@@ -535,6 +535,9 @@ std::vector<KernelEntry> build() {
                   {}, rck::launch_tvout_tweaks, setupTvoutTweaks, false};
     t.texture_height_override = true;
     r.push_back(t);
+    KernelEntry j{"windowed/shaders/jinc2-sharper.glsl", "jinc2-sharper", {}, {}, rck::launch_jinc2_sharper, setupJinc2Sharper, false};
+    j.texture_height_override = true;
+    r.push_back(j);
     KernelEntry a{"misc/image-adjustment.glsl", "image-adjustment",
                   {{"ia_target_gamma", 2.2f, 0.1f, 5.0f, 0.1f, "Target Gamma"}, {"ia_monitor_gamma", 2.2f, 0.1f, 5.0f, 0.1f, "Monitor Gamma"},
                    {"ia_overscan_percent_x", 0.0f, -25.0f, 25.0f, 1.0f, "Horizontal Overscan %"}, {"ia_overscan_percent_y", 0.0f, -25.0f, 25.0f, 1.0f, "Vertical Overscan %"},

@@ -5,3 +5,4 @@ constexpr int kListU0 = 32;
 constexpr int kTvoutU = 10;             // tvout_tweaks_fs_uniforms: 6 parameters, TextureSize, InputSize
 constexpr int kImageAdjU = 21;          // image_adjustment_fs_uniforms: 16 parameters, FrameCount, TextureSize, InputSize
 constexpr int kImageAdjFrameCount = 16;
+constexpr int kJinc2U = 2;              // jinc2_sharper_fs_uniforms: TextureSize

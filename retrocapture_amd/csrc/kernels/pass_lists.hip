@@ -44,11 +44,13 @@ __device__ __forceinline__ float rcn_pow(float x, float y) { return x != x ? 0.0
 #define RCN_MAX(a, b) rcn_max(a, b)
 #define RCN_POW(a, b) rcn_pow(a, b)
 #define RCN_SIN(x) sin_(x)
+#define RCN_SQRT(x) __builtin_sqrtf(x)
 #define RCN_TEX(ctx, unit, u, v, dst) rcn_tex(ctx, u, v, dst)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wunused-but-set-variable"
 #pragma clang diagnostic ignored "-Wunused-variable"
 #include "gen/tvout_tweaks_fs.inc"
+#include "gen/jinc2_sharper_fs.inc"
 #include "gen/image_adjustment_fs.inc"
 #pragma clang diagnostic pop
 
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(256) k_list_pass(const PassLaunch L) {
   RC_TILE_LOOP_BEGIN
   if (FC >= 0) U[FC] = (float)(L.frame_count0 + z);
   const float in[2] = {vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo)};
-  float out[4];
+  float out[4] = {0.f, 0.f, 0.f, 0.f};   // a component the shader never writes (jinc2-sharper's alpha) is stored as 0 by the GL
   TexCtx ctx{&L.in, frame_ptr(L.in, z), &lds};
   FS(U, in, out, &ctx);
   store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], out[3]), &lds);
@@ -75,6 +77,12 @@ __global__ void __launch_bounds__(256) k_list_pass(const PassLaunch L) {
 namespace rck {
 hipError_t launch_tvout_tweaks(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL((k_list_pass<kTvoutU, -1, tvout_tweaks_fs>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  return hipGetLastError();
+}
+// windowed/shaders/jinc2-sharper.glsl (10 presets): a 4x4 jinc-windowed-jinc resampler - 16 taps, two sin of a sqrt distance each - with an
+// anti-ringing clamp; ~430 operations.  Uniform block: TextureSize only.
+hipError_t launch_jinc2_sharper(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL((k_list_pass<kJinc2U, -1, jinc2_sharper_fs>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_image_adjustment(const PassLaunch& L, hipStream_t s) {

@@ -22,6 +22,7 @@ namespace {
 #define RCN_TABLES_ONLY
 #include "kernels/gen/image_adjustment_fs.inc"
 #include "kernels/gen/tvout_tweaks_fs.inc"
+#include "kernels/gen/jinc2_sharper_fs.inc"
 #undef RCN_TABLES_ONLY
 #pragma clang diagnostic pop
 
@@ -59,6 +60,14 @@ void setupTvoutTweaks(const PassGeometry& g, rcd::PassLaunch& L) {
   for (int k = 0; k < kTvoutU; ++k) U[k] = 0.0f;
   putSizes(U, tvout_tweaks_fs_uniforms, g, kTvoutU);
   for (int k = 0; k < 6; ++k) put(U, tvout_tweaks_fs_uniforms, kTvoutNames[k], &L.params[k], 1, kTvoutU);
+}
+
+void setupJinc2Sharper(const PassGeometry& g, rcd::PassLaunch& L) {
+  L.plane[0] = planeU(1.0001f, g.out_w, g.out_h, g.out_fmt);   // VS: TEX0 = TexCoord * 1.0001
+  L.plane[1] = planeV(1.0001f, g.out_w, g.out_h, g.out_fmt);
+  float* U = L.params + kListU0;
+  for (int k = 0; k < kJinc2U; ++k) U[k] = 0.0f;
+  putSizes(U, jinc2_sharper_fs_uniforms, g, kJinc2U);
 }
 
 void setupImageAdjustment(const PassGeometry& g, rcd::PassLaunch& L) {

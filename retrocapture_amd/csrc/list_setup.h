@@ -5,4 +5,5 @@
 namespace rc {
 void setupTvoutTweaks(const PassGeometry& g, rcd::PassLaunch& L);
 void setupImageAdjustment(const PassGeometry& g, rcd::PassLaunch& L);
+void setupJinc2Sharper(const PassGeometry& g, rcd::PassLaunch& L);
 }  // namespace rc

@@ -398,6 +398,8 @@ PRESETS["tvout"] = ("presets/tvout/tvout.glslp", '#tvout preset for 240p CRTs\n\
 PRESETS["tvout+ntsc-256px-svideo"] = ("presets/tvout/tvout+ntsc-256px-svideo.glslp", 'shaders = "4"\n\nshader0 = "../../ntsc/shaders/ntsc-pass1-svideo-3phase.glsl"\nfilter_linear0 = "false"\nframe_count_mod0 = "2"\nfloat_framebuffer0 = "true"\nscale_type_x0 = "absolute"\nscale_x0 = "1536"\nscale_type_y0 = "source"\nscale_y0 = "1.000000"\n\nshader1 = "../../ntsc/shaders/ntsc-pass2-3phase.glsl"\nfilter_linear1 = "false"\nfloat_framebuffer1 = "false"\nscale_type_x1 = "source"\nscale_x1 = "0.500000"\nscale_type_y1 = "source"\nscale_y1 = "1.000000"\n\nshader2 = "../../crt/shaders/tvout-tweaks.glsl"\nfilter_linear2 = "false"\nfloat_framebuffer2 = "false"\nscale_type_x2 = "viewport"\nscale_x2 = "1.000000"\nscale_type_y2 = "source"\nscale_y2 = "1.000000"\n\nshader3 = "../../misc/image-adjustment.glsl"\nfloat_framebuffer3 = "false"\n\nparameters = "TVOUT_RESOLUTION;TVOUT_COMPOSITE_CONNECTION;TVOUT_TV_COLOR_LEVELS;target_gamma;monitor_gamma;overscan_percent_x;overscan_percent_y;saturation;contrast;luminance;bright_boost;R;G;B"\nTVOUT_RESOLUTION = "512.000000"\nTVOUT_COMPOSITE_CONNECTION = "0.000000"\nTVOUT_TV_COLOR_LEVELS = "1.000000"\ntarget_gamma = "2.400000"\nmonitor_gamma = "2.200000"\noverscan_percent_x = "0.000000"\noverscan_percent_y = "0.000000"\nsaturation = "1.000000"\ncontrast = "1.000000"\nluminance = "1.000000"\nbright_boost = "0.000000"\nR = "1.000000"\nG = "1.000000"\nB = "1.000000"')
 PRESETS["retro-v2+image-adjustment"] = ("presets/retro-v2+image-adjustment.glslp", 'shaders = "2"\n\nshader0 = "../misc/image-adjustment.glsl"\nshader1 = "../handheld/shaders/retro-v2.glsl"\n\nfilter_linear0 = "false"\nscale_type0 = "source"\nscale0 = "1.000000"\n\nfilter_linear1 = "false"\n\nparameters = "target_gamma;monitor_gamma;overscan_percent_x;overscan_percent_y;saturation;contrast;luminance;bright_boost;R;G;B;RETRO_PIXEL_SIZE"\ntarget_gamma = "2.200000"\nmonitor_gamma = "2.20000"\noverscan_percent_x = "0.000000"\noverscan_percent_y = "0.000000"\nsaturation = "1.000000"\ncontrast = "1.000000"\nluminance = "1.000000"\nbright_boost = "0.000000"\nR = "1.000000"\nG = "1.000000"\nB = "1.000000"\nRETRO_PIXEL_SIZE = "0.840000"\n')
 PRESETS["tvout+interlacing"] = ("presets/tvout+interlacing/tvout+interlacing.glslp", '#tvout preset for 480p CRTs\n\nshaders = "3"\nshader0 = "../../crt/shaders/tvout-tweaks.glsl"\nshader1 = "../../misc/image-adjustment.glsl"\nshader2 = "../../misc/interlacing.glsl"\n\nscale_type_x0 = "viewport"\nscale_x0 = "1.000000"\nscale_type_y0 = "source"\nscale_y0 = "1.000000"\n\nparameters = "TVOUT_RESOLUTION;TVOUT_COMPOSITE_CONNECTION;TVOUT_TV_COLOR_LEVELS;target_gamma;monitor_gamma;overscan_percent_x;overscan_percent_y;saturation;contrast;luminance;bright_boost;R;G;B"\nTVOUT_RESOLUTION = "320.000000"\nTVOUT_COMPOSITE_CONNECTION = "0.000000"\nTVOUT_TV_COLOR_LEVELS = "1.000000"\ntarget_gamma = "2.400000"\nmonitor_gamma = "2.200000"\noverscan_percent_x = "0.000000"\noverscan_percent_y = "0.000000"\nsaturation = "1.000000"\ncontrast = "1.000000"\nluminance = "1.000000"\nbright_boost = "0.000000"\nR = "1.000000"\nG = "1.000000"\nB = "1.000000"')
+PRESETS["jinc2-sharper"] = ("windowed/jinc2-sharper.glslp", 'shaders = 1\n\nshader0 = shaders/jinc2-sharper.glsl\nfilter_linear0 = false\n')
+PRESETS["tvout-jinc-sharpen"] = ("presets/tvout/tvout-jinc-sharpen.glslp", '#try to sharpen blended output with Jinc2 set with very low Window Sinc parameter\n\nshaders = "3"\nshader0 = "../../crt/shaders/tvout-tweaks.glsl"\nshader1 = "../../misc/image-adjustment.glsl"\nshader2 = "../../windowed/shaders/jinc2-sharper.glsl"\nshader3 = "../../misc/interlacing.glsl"\n\nscale_type_x0 = "source"\nscale_x0 = "2.000000"\nscale_type_y0 = "source"\nscale_y0 = "1.000000"\n\n\nscale_type_x2 = "viewport"\nscale_x2 = "1.000000"\nscale_type_y2 = "source"\nscale_y2 = "1.000000"\n\n\n\nparameters = "TVOUT_RESOLUTION;TVOUT_COMPOSITE_CONNECTION;TVOUT_TV_COLOR_LEVELS;target_gamma;monitor_gamma;overscan_percent_x;overscan_percent_y;saturation;contrast;luminance;bright_boost;R;G;B;JINC2_WINDOW_SINC;JINC2_SINC;JINC2_AR_STRENGTH"\nTVOUT_RESOLUTION = "160.000000"\nTVOUT_COMPOSITE_CONNECTION = "0.000000"\nTVOUT_TV_COLOR_LEVELS = "0.000000"\ntarget_gamma = "2.400000"\nmonitor_gamma = "2.200000"\noverscan_percent_x = "0.000000"\noverscan_percent_y = "0.000000"\nsaturation = "1.000000"\ncontrast = "1.000000"\nluminance = "1.000000"\nbright_boost = "0.000000"\nR = "1.000000"\nG = "1.000000"\nB = "1.000000"\nJINC2_WINDOW_SINC = "0.010000"\nJINC2_SINC = "0.9"\nJINC2_AR_STRENGTH = "0.900000"\n')
 PRESETS["interlacing-bare"] = ("misc/interlacing-bare.glslp", 'shaders = 1\nshader0 = misc/interlacing.glsl\nfilter_linear0 = false\n')
 # image-adjustment alone, no parameter block (a one-pass chain of this repository): every parameter can move
 PRESETS["image-adjustment-bare"] = ("misc/image-adjustment-bare.glslp", 'shaders = 1\nshader0 = misc/image-adjustment.glsl\nfilter_linear0 = false\n')
@@ -694,6 +696,7 @@ SHADERS = {
                                                                     ("in_res_y", 240.0), ("border_on_top", 1.0), ("border_zoom_x", 1.0), ("border_zoom_y", 1.0)]},
     "handheld/shaders/gb-palette/gb-palette.glsl": {"oracle": "gb_palette", "samplers": ["COLOR_PALETTE"], "params": [], "size_independent": True},
     "crt/shaders/crt-potato/shader-files/crt-potato.glsl": {"oracle": "crt_potato", "samplers": ["MASK"], "params": []},
+    "windowed/shaders/jinc2-sharper.glsl": {"oracle": "jinc2_sharper", "samplers": [], "params": []},
     "misc/interlacing.glsl": {"oracle": "interlacing", "samplers": [], "params": [("percent", 0.0), ("enable_480i", 1.0), ("top_field_first", 0.0)]},
     "crt/shaders/tvout-tweaks.glsl": {"oracle": "tvout_tweaks", "samplers": [], "params": [('TVOUT_RESOLUTION', 256.0), ('TVOUT_COMPOSITE_CONNECTION', 0.0), ('TVOUT_TV_COLOR_LEVELS', 0.0), ('TVOUT_RESOLUTION_Y', 256.0), ('TVOUT_RESOLUTION_I', 83.19999694824219), ('TVOUT_RESOLUTION_Q', 25.600000381469727)]},
     "misc/image-adjustment.glsl": {"oracle": "image_adjustment", "samplers": [], "params": [('ia_target_gamma', 2.2), ('ia_monitor_gamma', 2.2), ('ia_overscan_percent_x', 0.0), ('ia_overscan_percent_y', 0.0), ('ia_saturation', 1.0), ('ia_contrast', 1.0), ('ia_luminance', 1.0), ('ia_black_level', 0.0), ('ia_bright_boost', 0.0), ('ia_R', 1.0), ('ia_G', 1.0), ('ia_B', 1.0), ('ia_ZOOM', 1.0), ('ia_XPOS', 0.0), ('ia_YPOS', 0.0), ('ia_TOPMASK', 0.0), ('ia_BOTMASK', 0.0), ('ia_LMASK', 0.0), ('ia_RMASK', 0.0), ('ia_GRAIN_STR', 0.0), ('ia_SHARPEN', 0.0), ('ia_FLIP_HORZ', 0.0), ('ia_FLIP_VERT', 0.0)]},

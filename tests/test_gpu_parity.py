@@ -12,6 +12,9 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "jinc2_sharper_64x48_to_320x240": "jinc2-sharper",
+    "jinc2_sharper_40x30_to_233x171": "jinc2-sharper",
+    "tvout_jinc_sharpen_64x48_to_320x240_f2": "tvout-jinc-sharpen",
     "tvout_interlacing_64x48_to_320x240": "tvout+interlacing",
     "interlacing_bare_40x420_to_160x420_f3": "interlacing-bare",
     "interlacing_bare_40x420_to_120x300_f2": "interlacing-bare",

@@ -62,6 +62,9 @@ CASES = {
     "imgborder_sgb_crt_geom_1x_40x36_to_256x224": "sgb-crt-geom-1x",
     "imgborder_sgb_bare_params_40x30_to_233x171": "imgborder-sgb-bare",
     "console_border_ngpc_3x_40x38_to_300x200": "ngpc-3x",
+    "jinc2_sharper_64x48_to_320x240": "jinc2-sharper",
+    "jinc2_sharper_40x30_to_233x171": "jinc2-sharper",
+    "tvout_jinc_sharpen_64x48_to_320x240_f2": "tvout-jinc-sharpen",          # 4 passes: tvout, image-adjustment, jinc2-sharper, interlacing (pass index 3)
     "tvout_interlacing_64x48_to_320x240": "tvout+interlacing",
     "interlacing_bare_40x420_to_160x420_f3": "interlacing-bare",    # > 400 source lines: the field alternates with FrameCount
     "interlacing_bare_40x420_to_120x300_f2": "interlacing-bare",
@@ -321,6 +324,7 @@ FLOAT_CASES = {
     "f32_psp_color_48x36_to_131x77": ("psp-color", {}),
     "f32_vba_color_48x36_to_131x77": ("vba-color", {}),
     "f32_imgborder_sgb_bare_params_40x30_to_233x171": ("imgborder-sgb-bare", {}),
+    "f32_jinc2_sharper_48x36_to_200x150": ("jinc2-sharper", {}),
     "f32_interlacing_bare_40x420_to_160x420_f2": ("interlacing-bare", {}),
     "f32_tvout_tweaks_bare_params_48x36_to_200x150": ("tvout-tweaks-bare", {}),
     "f32_image_adjustment_bare_params_48x36_to_200x150_f2": ("image-adjustment-bare", {}),
