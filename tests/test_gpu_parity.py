@@ -324,6 +324,19 @@ def test_hyllian_glow_specialised_and_general_forms_agree(w, h, vw, vh, preset_t
     e.shutdown()
 
 
+def test_image_adjustment_flip_is_refused(preset_tree, rc_lib):
+    """misc/image-adjustment.glsl's ia_FLIP_* move the quad itself half off the target (clipped geometry): refused with the reason, not mis-rendered."""
+    from gpu_util import make_engine, run_engine, to_device_rgba
+    from retrocapture_amd.engine import RcError
+    frame = np.random.default_rng(3).integers(0, 256, (1, 30, 40, 3), dtype=np.uint8)
+    e = make_engine(preset_tree["image-adjustment-bare"], 120, 90)
+    assert run_engine(e, frame).shape == (1, 90, 120, 4)
+    assert e.setShaderParameter("ia_FLIP_HORZ", 1.0)
+    with pytest.raises(RcError, match="ia_FLIP"):
+        e.applyShader(to_device_rgba(frame), 40, 30)
+    e.shutdown()
+
+
 def test_hyllian_all_phosphor_layouts_match_llvmpipe(preset_tree, rc_lib):
     """resolve2.glsl's twenty PHOSPHOR_LAYOUT masks (the shader's mask_weights tables, layout 12's undefined row index
     included): every pass byte for byte what llvmpipe rendered."""
