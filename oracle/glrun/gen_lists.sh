@@ -7,6 +7,7 @@
 #   crt/shaders/tvout-tweaks.glsl (fragment stage)                     -> tvout_tweaks_fs.inc
 #   misc/image-adjustment.glsl (both stages)                           -> image_adjustment_{vs,fs}.inc
 #   windowed/shaders/jinc2-sharper.glsl (fragment stage)               -> jinc2_sharper_fs.inc
+#   crt/shaders/crt-lottes.glsl, crt/shaders/fakelottes.glsl (fragment) -> crt_lottes_fs.inc, fakelottes_fs.inc
 # written to oracle/gen/ for the oracle and, the same text, to retrocapture_amd/csrc/kernels/gen/ for the HIP kernels.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -40,4 +41,6 @@ listing crt/shaders/tvout-tweaks.glsl LP_DEBUG=fs "$T/tv.txt" && emit "$T/tv.txt
 listing misc/image-adjustment.glsl LP_DEBUG=fs "$T/ia.txt" && emit "$T/ia.txt" fragment image_adjustment_fs
 listing misc/image-adjustment.glsl GALLIVM_DEBUG=tgsi "$T/iav.txt" && emit "$T/iav.txt" vertex image_adjustment_vs
 listing windowed/shaders/jinc2-sharper.glsl LP_DEBUG=fs "$T/j2.txt" && emit "$T/j2.txt" fragment jinc2_sharper_fs
+listing crt/shaders/crt-lottes.glsl LP_DEBUG=fs "$T/lo.txt" && emit "$T/lo.txt" fragment crt_lottes_fs
+listing crt/shaders/fakelottes.glsl LP_DEBUG=fs "$T/fl.txt" && emit "$T/fl.txt" fragment fakelottes_fs
 wc -l "$ROOT"/oracle/gen/*.inc

@@ -29,6 +29,7 @@ static inline float rcn_max(float a, float b) { return b != b ? a : (a > b ? a :
 #define RCN_POW(a, b) o_pow(a, b)
 #define RCN_SIN(x) o_sin(x)
 #define RCN_SQRT(x) sqrtf(x)
+#define RCN_EXP2(x) o_exp2(x)
 static void rcn_tex(void* ctx, float u, float v, float* dst) {
   const o_vec4 r = o_sample((const o_tex*)ctx, u, v);
   dst[0] = r.x; dst[1] = r.y; dst[2] = r.z; dst[3] = r.w;
@@ -39,6 +40,8 @@ static void rcn_tex(void* ctx, float u, float v, float* dst) {
 #pragma GCC diagnostic ignored "-Wunused-but-set-variable"
 #include "gen/tvout_tweaks_fs.inc"
 #include "gen/jinc2_sharper_fs.inc"
+#include "gen/crt_lottes_fs.inc"
+#include "gen/fakelottes_fs.inc"
 #include "gen/image_adjustment_vs.inc"
 #include "gen/image_adjustment_fs.inc"
 #pragma GCC diagnostic pop
@@ -140,4 +143,39 @@ void o_pass_jinc2_sharper(const o_pass_args* a) {
       o_store_pixel(a, x, y, o);
     }
   o_fp_leave(csr);
+}
+
+/* crt/shaders/crt-lottes.glsl (crt/crt-lottes.glslp; ~2 500 operations: 31 taps under gaussian pixel / scanline / bloom kernels, tube warp, four
+ * shadow masks on gl_FragCoord, 48 branches) and crt/shaders/fakelottes.glsl (crt/fakelottes.glslp: its one-tap cousin).  Both read
+ * gl_FragCoord (pixel + 0.5; handed over in the list's input slots 32..35) through gl_FbWposYTransform = (1, 0, -1, height).
+ * params in #pragma order. */
+static void run_fragcoord_list(const o_pass_args* a, void (*fs)(const float*, const float*, float*, void*), const void* table, const char* const* names, int n) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  float U[48] = {0};
+  const float ytr[4] = {1.0f, 0.0f, -1.0f, (float)H};
+  put_sizes(U, table, a, 1);
+  put(U, table, "gl_FbWposYTransform", ytr, 4);
+  for (int k = 0; k < n; ++k) put(U, table, names[k], &a->params[k], 1);
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      float in[36] = {0}, out[4] = {0.f, 0.f, 0.f, 0.f};
+      in[0] = o_varying_at(&tu, x, y, lo);
+      in[1] = o_varying_at(&tv, x, y, lo);
+      in[32] = (float)x + 0.5f; in[33] = (float)y + 0.5f; in[34] = 0.5f; in[35] = 1.0f;
+      fs(U, in, out, (void*)a->in);
+      const o_vec4 o = {out[0], out[1], out[2], out[3]};
+      o_store_pixel(a, x, y, o);
+    }
+  o_fp_leave(csr);
+}
+void o_pass_crt_lottes(const o_pass_args* a) {
+  static const char* const names[13] = {"hardScan", "hardPix", "warpX", "warpY", "maskDark", "maskLight", "scaleInLinearGamma", "shadowMask", "brightBoost", "hardBloomPix", "hardBloomScan", "bloomAmount", "shape"};
+  run_fragcoord_list(a, crt_lottes_fs, crt_lottes_fs_uniforms, names, 13);
+}
+void o_pass_fakelottes(const o_pass_args* a) {
+  static const char* const names[10] = {"shadowMask", "SCANLINE_SINE_COMP_B", "warpX", "warpY", "maskDark", "maskLight", "crt_gamma", "monitor_gamma", "SCANLINE_SINE_COMP_A", "SCANLINE_BASE_BRIGHTNESS"};
+  run_fragcoord_list(a, fakelottes_fs, fakelottes_fs_uniforms, names, 10);
 }

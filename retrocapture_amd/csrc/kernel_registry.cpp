@@ -535,6 +535,25 @@ std::vector<KernelEntry> build() {
                   {}, rck::launch_tvout_tweaks, setupTvoutTweaks, false};
     t.texture_height_override = true;
     r.push_back(t);
+    KernelEntry lo{"crt/shaders/crt-lottes.glsl", "crt-lottes",
+                   {{"hardScan", -8.0f, -20.0f, 0.0f, 1.0f, "hardScan"}, {"hardPix", -3.0f, -20.0f, 0.0f, 1.0f, "hardPix"}, {"warpX", 0.031f, 0.0f, 0.125f, 0.01f, "warpX"},
+                    {"warpY", 0.041f, 0.0f, 0.125f, 0.01f, "warpY"}, {"maskDark", 0.5f, 0.0f, 2.0f, 0.1f, "maskDark"}, {"maskLight", 1.5f, 0.0f, 2.0f, 0.1f, "maskLight"},
+                    {"scaleInLinearGamma", 1.0f, 0.0f, 1.0f, 1.0f, "scaleInLinearGamma"}, {"shadowMask", 3.0f, 0.0f, 4.0f, 1.0f, "shadowMask"},
+                    {"brightBoost", 1.0f, 0.0f, 2.0f, 0.05f, "brightness boost"}, {"hardBloomPix", -1.5f, -2.0f, -0.5f, 0.1f, "bloom-x soft"},
+                    {"hardBloomScan", -2.0f, -4.0f, -1.0f, 0.1f, "bloom-y soft"}, {"bloomAmount", 0.15f, 0.0f, 1.0f, 0.05f, "bloom ammount"},
+                    {"shape", 2.0f, 0.0f, 10.0f, 0.05f, "filter kernel shape"}},
+                   {}, rck::launch_crt_lottes, setupCrtLottes, false};
+    lo.texture_height_override = true;
+    r.push_back(lo);
+    KernelEntry fl{"crt/shaders/fakelottes.glsl", "fakelottes",
+                   {{"shadowMask", 1.0f, 0.0f, 4.0f, 1.0f, "shadowMask"}, {"SCANLINE_SINE_COMP_B", 0.40f, 0.0f, 1.0f, 0.05f, "Scanline Intensity"},
+                    {"warpX", 0.031f, 0.0f, 0.125f, 0.01f, "warpX"}, {"warpY", 0.041f, 0.0f, 0.125f, 0.01f, "warpY"}, {"maskDark", 0.5f, 0.0f, 2.0f, 0.1f, "maskDark"},
+                    {"maskLight", 1.5f, 0.0f, 2.0f, 0.1f, "maskLight"}, {"crt_gamma", 2.5f, 1.0f, 4.0f, 0.05f, "CRT Gamma"},
+                    {"monitor_gamma", 2.2f, 1.0f, 4.0f, 0.05f, "Monitor Gamma"}, {"SCANLINE_SINE_COMP_A", 0.0f, 0.0f, 0.10f, 0.01f, "Scanline Sine Comp A"},
+                    {"SCANLINE_BASE_BRIGHTNESS", 0.95f, 0.0f, 1.0f, 0.01f, "Scanline Base Brightness"}},
+                   {}, rck::launch_fakelottes, setupFakeLottes, false};
+    fl.texture_height_override = true;
+    r.push_back(fl);
     KernelEntry j{"windowed/shaders/jinc2-sharper.glsl", "jinc2-sharper", {}, {}, rck::launch_jinc2_sharper, setupJinc2Sharper, false};
     j.texture_height_override = true;
     r.push_back(j);

@@ -6,3 +6,5 @@ constexpr int kTvoutU = 10;             // tvout_tweaks_fs_uniforms: 6 parameter
 constexpr int kImageAdjU = 21;          // image_adjustment_fs_uniforms: 16 parameters, FrameCount, TextureSize, InputSize
 constexpr int kImageAdjFrameCount = 16;
 constexpr int kJinc2U = 2;              // jinc2_sharper_fs_uniforms: TextureSize
+constexpr int kLottesU = 24;            // crt_lottes_fs_uniforms: sizes, 13 parameters, gl_FbWposYTransform at 20
+constexpr int kFakeLottesU = 20;        // fakelottes_fs_uniforms: sizes, 10 parameters, gl_FbWposYTransform at 16

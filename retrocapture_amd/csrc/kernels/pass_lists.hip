@@ -45,12 +45,15 @@ __device__ __forceinline__ float rcn_pow(float x, float y) { return x != x ? 0.0
 #define RCN_POW(a, b) rcn_pow(a, b)
 #define RCN_SIN(x) sin_(x)
 #define RCN_SQRT(x) __builtin_sqrtf(x)
+#define RCN_EXP2(x) exp2_(x)
 #define RCN_TEX(ctx, unit, u, v, dst) rcn_tex(ctx, u, v, dst)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wunused-but-set-variable"
 #pragma clang diagnostic ignored "-Wunused-variable"
 #include "gen/tvout_tweaks_fs.inc"
 #include "gen/jinc2_sharper_fs.inc"
+#include "gen/crt_lottes_fs.inc"
+#include "gen/fakelottes_fs.inc"
 #include "gen/image_adjustment_fs.inc"
 #pragma clang diagnostic pop
 
@@ -64,7 +67,14 @@ __global__ void __launch_bounds__(256) k_list_pass(const PassLaunch L) {
   for (int k = 0; k < NU; ++k) U[k] = L.params[kListU0 + k];
   RC_TILE_LOOP_BEGIN
   if (FC >= 0) U[FC] = (float)(L.frame_count0 + z);
-  const float in[2] = {vary(L.plane[0], x, y, lo), vary(L.plane[1], x, y, lo)};
+  // varying slots 0, 1 = TEX0; 32..35 = gl_FragCoord (pixel + 0.5), read by the lists that build a mask on screen position
+  float in[36];
+  in[0] = vary(L.plane[0], x, y, lo);
+  in[1] = vary(L.plane[1], x, y, lo);
+  in[32] = (float)x + 0.5f;
+  in[33] = (float)y + 0.5f;
+  in[34] = 0.5f;
+  in[35] = 1.0f;
   float out[4] = {0.f, 0.f, 0.f, 0.f};   // a component the shader never writes (jinc2-sharper's alpha) is stored as 0 by the GL
   TexCtx ctx{&L.in, frame_ptr(L.in, z), &lds};
   FS(U, in, out, &ctx);
@@ -83,6 +93,16 @@ hipError_t launch_tvout_tweaks(const PassLaunch& L, hipStream_t s) {
 // anti-ringing clamp; ~430 operations.  Uniform block: TextureSize only.
 hipError_t launch_jinc2_sharper(const PassLaunch& L, hipStream_t s) {
   hipLaunchKernelGGL((k_list_pass<kJinc2U, -1, jinc2_sharper_fs>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  return hipGetLastError();
+}
+// crt/shaders/crt-lottes.glsl (~2 500 operations: 31 taps under gaussian pixel / scanline / bloom kernels, tube warp, four shadow masks on
+// gl_FragCoord, 48 branches) and its one-tap cousin crt/shaders/fakelottes.glsl
+hipError_t launch_crt_lottes(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL((k_list_pass<kLottesU, -1, crt_lottes_fs>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  return hipGetLastError();
+}
+hipError_t launch_fakelottes(const PassLaunch& L, hipStream_t s) {
+  hipLaunchKernelGGL((k_list_pass<kFakeLottesU, -1, fakelottes_fs>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
 hipError_t launch_image_adjustment(const PassLaunch& L, hipStream_t s) {

@@ -23,6 +23,8 @@ namespace {
 #include "kernels/gen/image_adjustment_fs.inc"
 #include "kernels/gen/tvout_tweaks_fs.inc"
 #include "kernels/gen/jinc2_sharper_fs.inc"
+#include "kernels/gen/crt_lottes_fs.inc"
+#include "kernels/gen/fakelottes_fs.inc"
 #undef RCN_TABLES_ONLY
 #pragma clang diagnostic pop
 
@@ -61,6 +63,25 @@ void setupTvoutTweaks(const PassGeometry& g, rcd::PassLaunch& L) {
   putSizes(U, tvout_tweaks_fs_uniforms, g, kTvoutU);
   for (int k = 0; k < 6; ++k) put(U, tvout_tweaks_fs_uniforms, kTvoutNames[k], &L.params[k], 1, kTvoutU);
 }
+
+namespace {
+const char* const kLottesNames[13] = {"hardScan", "hardPix", "warpX", "warpY", "maskDark", "maskLight", "scaleInLinearGamma", "shadowMask", "brightBoost", "hardBloomPix", "hardBloomScan", "bloomAmount", "shape"};
+const char* const kFakeLottesNames[10] = {"shadowMask", "SCANLINE_SINE_COMP_B", "warpX", "warpY", "maskDark", "maskLight", "crt_gamma", "monitor_gamma", "SCANLINE_SINE_COMP_A", "SCANLINE_BASE_BRIGHTNESS"};
+// a list that reads gl_FragCoord: TEX0 = TexCoord, gl_FbWposYTransform = (1, 0, -1, height)
+template <class T>
+void setupFragCoordList(const PassGeometry& g, rcd::PassLaunch& L, const T* table, const char* const* names, int n, int nu) {
+  L.plane[0] = planeU(1.0f, g.out_w, g.out_h, g.out_fmt);
+  L.plane[1] = planeV(1.0f, g.out_w, g.out_h, g.out_fmt);
+  float* U = L.params + kListU0;
+  for (int k = 0; k < nu; ++k) U[k] = 0.0f;
+  putSizes(U, table, g, nu);
+  const float ytr[4] = {1.0f, 0.0f, -1.0f, (float)g.out_h};
+  put(U, table, "gl_FbWposYTransform", ytr, 4, nu);
+  for (int k = 0; k < n; ++k) put(U, table, names[k], &L.params[k], 1, nu);
+}
+}  // namespace
+void setupCrtLottes(const PassGeometry& g, rcd::PassLaunch& L) { setupFragCoordList(g, L, crt_lottes_fs_uniforms, kLottesNames, 13, kLottesU); }
+void setupFakeLottes(const PassGeometry& g, rcd::PassLaunch& L) { setupFragCoordList(g, L, fakelottes_fs_uniforms, kFakeLottesNames, 10, kFakeLottesU); }
 
 void setupJinc2Sharper(const PassGeometry& g, rcd::PassLaunch& L) {
   L.plane[0] = planeU(1.0001f, g.out_w, g.out_h, g.out_fmt);   // VS: TEX0 = TexCoord * 1.0001

@@ -6,4 +6,6 @@ namespace rc {
 void setupTvoutTweaks(const PassGeometry& g, rcd::PassLaunch& L);
 void setupImageAdjustment(const PassGeometry& g, rcd::PassLaunch& L);
 void setupJinc2Sharper(const PassGeometry& g, rcd::PassLaunch& L);
+void setupCrtLottes(const PassGeometry& g, rcd::PassLaunch& L);
+void setupFakeLottes(const PassGeometry& g, rcd::PassLaunch& L);
 }  // namespace rc

@@ -495,6 +495,22 @@ def case_hyllian_glow():
              params=[("HFILTER_SHARPNESS", 0.7), ("CRT_ANTI_RINGING", 0.6), ("MASK_INTENSITY", 0.7), ("PHOSPHOR_LAYOUT", 5.0)])
 
 
+def case_lottes():
+    L, F = GLSL + "/crt/crt-lottes.glslp", GLSL + "/crt/fakelottes.glslp"
+    run_case("crt_lottes_64x48_to_320x240", L, mixed(64, 48, 230), 320, 240)
+    run_case("crt_lottes_params_40x30_to_233x171", L, noise(40, 30, 231), 233, 171,
+             params=[("hardScan", -6.0), ("hardPix", -4.0), ("warpX", 0.06), ("warpY", 0.02), ("maskDark", 0.7), ("maskLight", 1.3), ("scaleInLinearGamma", 0.0),
+                     ("shadowMask", 1.0), ("brightBoost", 1.2), ("bloomAmount", 0.3), ("shape", 3.0)])
+    for m in (0.0, 2.0, 4.0):
+        run_case("crt_lottes_mask%d_48x36_to_200x150" % int(m), L, mixed(48, 36, 232), 200, 150, params=[("shadowMask", m)])
+    run_case("f32_crt_lottes_48x36_to_200x150", L, mixed(48, 36, 233), 200, 150, f32=True)
+    run_case("fakelottes_64x48_to_320x240", F, mixed(64, 48, 234), 320, 240)
+    run_case("fakelottes_params_40x30_to_233x171", F, noise(40, 30, 235), 233, 171,
+             params=[("shadowMask", 3.0), ("SCANLINE_SINE_COMP_B", 0.6), ("warpX", 0.05), ("maskDark", 0.8), ("crt_gamma", 2.2), ("monitor_gamma", 2.0),
+                     ("SCANLINE_SINE_COMP_A", 0.05), ("SCANLINE_BASE_BRIGHTNESS", 0.9)])
+    run_case("f32_fakelottes_48x36_to_200x150", F, mixed(48, 36, 236), 200, 150, f32=True)
+
+
 def case_jinc2():
     run_case("jinc2_sharper_64x48_to_320x240", GLSL + "/windowed/jinc2-sharper.glslp", mixed(64, 48, 220), 320, 240)
     run_case("jinc2_sharper_40x30_to_233x171", GLSL + "/windowed/jinc2-sharper.glslp", noise(40, 30, 221), 233, 171)
@@ -858,7 +874,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"jinc2": case_jinc2, "interlacing": case_interlacing, "tvout": case_tvout, "ntsc_gauss": case_ntsc_gauss, "crt_potato": case_crt_potato, "gb_palette": case_gb_palette, "reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"lottes": case_lottes, "jinc2": case_jinc2, "interlacing": case_interlacing, "tvout": case_tvout, "ntsc_gauss": case_ntsc_gauss, "crt_potato": case_crt_potato, "gb_palette": case_gb_palette, "reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

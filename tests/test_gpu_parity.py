@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "crt_lottes_64x48_to_320x240": "crt-lottes",
+    "crt_lottes_params_40x30_to_233x171": "crt-lottes",
+    "crt_lottes_mask0_48x36_to_200x150": "crt-lottes",
+    "crt_lottes_mask2_48x36_to_200x150": "crt-lottes",
+    "crt_lottes_mask4_48x36_to_200x150": "crt-lottes",
+    "fakelottes_64x48_to_320x240": "fakelottes",
+    "fakelottes_params_40x30_to_233x171": "fakelottes",
     "jinc2_sharper_64x48_to_320x240": "jinc2-sharper",
     "jinc2_sharper_40x30_to_233x171": "jinc2-sharper",
     "tvout_jinc_sharpen_64x48_to_320x240_f2": "tvout-jinc-sharpen",

@@ -62,6 +62,13 @@ CASES = {
     "imgborder_sgb_crt_geom_1x_40x36_to_256x224": "sgb-crt-geom-1x",
     "imgborder_sgb_bare_params_40x30_to_233x171": "imgborder-sgb-bare",
     "console_border_ngpc_3x_40x38_to_300x200": "ngpc-3x",
+    "crt_lottes_64x48_to_320x240": "crt-lottes",
+    "crt_lottes_params_40x30_to_233x171": "crt-lottes",
+    "crt_lottes_mask0_48x36_to_200x150": "crt-lottes",
+    "crt_lottes_mask2_48x36_to_200x150": "crt-lottes",
+    "crt_lottes_mask4_48x36_to_200x150": "crt-lottes",
+    "fakelottes_64x48_to_320x240": "fakelottes",
+    "fakelottes_params_40x30_to_233x171": "fakelottes",
     "jinc2_sharper_64x48_to_320x240": "jinc2-sharper",
     "jinc2_sharper_40x30_to_233x171": "jinc2-sharper",
     "tvout_jinc_sharpen_64x48_to_320x240_f2": "tvout-jinc-sharpen",          # 4 passes: tvout, image-adjustment, jinc2-sharper, interlacing (pass index 3)
@@ -324,6 +331,8 @@ FLOAT_CASES = {
     "f32_psp_color_48x36_to_131x77": ("psp-color", {}),
     "f32_vba_color_48x36_to_131x77": ("vba-color", {}),
     "f32_imgborder_sgb_bare_params_40x30_to_233x171": ("imgborder-sgb-bare", {}),
+    "f32_crt_lottes_48x36_to_200x150": ("crt-lottes", {}),
+    "f32_fakelottes_48x36_to_200x150": ("fakelottes", {}),
     "f32_jinc2_sharper_48x36_to_200x150": ("jinc2-sharper", {}),
     "f32_interlacing_bare_40x420_to_160x420_f2": ("interlacing-bare", {}),
     "f32_tvout_tweaks_bare_params_48x36_to_200x150": ("tvout-tweaks-bare", {}),
