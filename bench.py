@@ -50,6 +50,9 @@ WORKLOADS = {
     "scanline": ("scanline", 320, 240, 320, 240, "scanlines/shaders/scanline.glsl 1-pass, 320x240"),
     "crt-geom": ("crt-geom", 640, 480, 1920, 1440, "crt/crt-geom.glslp 1-pass (curvature, interlacing simulation on), 640x480 -> 1920x1440"),
     "scalefx": ("scalefx", 256, 224, 768, 672, "scalefx/scalefx.glslp 5-pass pixel-art upscale 256x224 -> 768x672"),
+    "crt-lottes": ("crt-lottes", 640, 480, 1920, 1440, "crt/crt-lottes.glslp 1-pass (instruction-list kernel, ~2 500 operations / pixel), 640x480 -> 1920x1440"),
+    "tvout": ("tvout+ntsc-256px-svideo", 256, 224, 1280, 960,
+              "presets/tvout/tvout+ntsc-256px-svideo.glslp 4-pass (ntsc 3-phase, tvout-tweaks, image-adjustment), 256x224 -> 1280x960"),
     "lcd-grid-v2": ("lcd-grid-v2-gba-color-motionblur", 240, 160, 1920, 1280,
                     "handheld/lcd-grid-v2-gba-color-motionblur.glslp 3-pass (frame history: sequential frames), 240x160 -> 1920x1280"),
 }

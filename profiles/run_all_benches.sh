@@ -7,7 +7,7 @@ cd "$REPO"
 mkdir -p gpurun_out
 python3 bench.py > gpurun_out/bench_crt-royale.json 2> gpurun_out/bench_crt-royale.err
 echo "crt-royale done"
-for W in crt-royale-fake-bloom crt-hyllian-glow crt-easymode zfast-crt crt-pi crt-geom ntsc xbr-lv3 xbr-lv2 scalefx scanline lcd-grid-v2; do
+for W in crt-royale-fake-bloom crt-hyllian-glow crt-easymode zfast-crt crt-pi crt-geom ntsc xbr-lv3 xbr-lv2 scalefx scanline lcd-grid-v2 crt-lottes tvout; do
   python3 bench.py --workload $W --no-cpu-baseline > gpurun_out/bench_$W.json 2> gpurun_out/bench_$W.err
   echo "$W done"
 done

@@ -20,9 +20,21 @@ struct TexCtx {
   const uint8_t* img;
   const SrgbLds* lds;
 };
+// sampler policies: the run-time selected sampler, and compile-time ones for what the shipped presets bind (a NEAREST or LINEAR clamp-to-edge
+// RGBX8 source frame / RGBA8 target) - a list with 31 taps carries 31 copies of the sampler, so its size matters
+struct SampRT {
+  static __device__ __forceinline__ float4 get(const Tex& t, const uint8_t* img, float u, float v, const SrgbLds* l) { return sample_rt(t, img, u, v, l); }
+  static bool matches(const Tex&) { return true; }
+};
+template <int FMT, int LIN>
+struct SampEdge {
+  static __device__ __forceinline__ float4 get(const Tex& t, const uint8_t* img, float u, float v, const SrgbLds* l) { return sample<FMT, LIN, WRAP_EDGE>(t, img, u, v, l); }
+  static bool matches(const Tex& t) { return t.fmt == FMT && (t.linear != 0) == (LIN != 0) && t.wrap == WRAP_EDGE && t.n_levels <= 1; }
+};
+template <class SI>
 __device__ __forceinline__ void rcn_tex(void* vctx, float u, float v, float* dst) {
   const TexCtx* c = static_cast<const TexCtx*>(vctx);
-  const float4 r = sample_rt(*c->t, c->img, u, v, c->lds);
+  const float4 r = SI::get(*c->t, c->img, u, v, c->lds);
   dst[0] = r.x;
   dst[1] = r.y;
   dst[2] = r.z;
@@ -32,7 +44,7 @@ __device__ __forceinline__ float rcn_min(float a, float b) { return b != b ? a :
 __device__ __forceinline__ float rcn_max(float a, float b) { return b != b ? a : (a > b ? a : b); }
 __device__ __forceinline__ float rcn_pow(float x, float y) { return x != x ? 0.0f : pow_(x, y); }     // llvmpipe: pow of a NaN base is 0
 
-#define RCN_FN __device__ __forceinline__ static
+#define RCN_FN static __device__ __forceinline__
 #define RCN_NO_TABLES
 #define RCN_BITS(u) bits2f(u)
 #define RCN_ABS(x) __builtin_fabsf(x)
@@ -46,7 +58,10 @@ __device__ __forceinline__ float rcn_pow(float x, float y) { return x != x ? 0.0
 #define RCN_SIN(x) sin_(x)
 #define RCN_SQRT(x) __builtin_sqrtf(x)
 #define RCN_EXP2(x) exp2_(x)
-#define RCN_TEX(ctx, unit, u, v, dst) rcn_tex(ctx, u, v, dst)
+#define RCN_TEX(ctx, unit, u, v, dst) rcn_tex<SI>(ctx, u, v, dst)
+// the lists as static members of a template over the sampler policy
+template <class SI>
+struct Lists {
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wunused-but-set-variable"
 #pragma clang diagnostic ignored "-Wunused-variable"
@@ -56,10 +71,20 @@ __device__ __forceinline__ float rcn_pow(float x, float y) { return x != x ? 0.0
 #include "gen/fakelottes_fs.inc"
 #include "gen/image_adjustment_fs.inc"
 #pragma clang diagnostic pop
+};
+enum { LIST_TVOUT, LIST_JINC2, LIST_LOTTES, LIST_FAKELOTTES, LIST_IMAGE_ADJ };
+template <class SI, int WHICH>
+__device__ __forceinline__ void run_list(const float* U, const float* in, float* out, void* ctx) {
+  if (WHICH == LIST_TVOUT) Lists<SI>::tvout_tweaks_fs(U, in, out, ctx);
+  else if (WHICH == LIST_JINC2) Lists<SI>::jinc2_sharper_fs(U, in, out, ctx);
+  else if (WHICH == LIST_LOTTES) Lists<SI>::crt_lottes_fs(U, in, out, ctx);
+  else if (WHICH == LIST_FAKELOTTES) Lists<SI>::fakelottes_fs(U, in, out, ctx);
+  else Lists<SI>::image_adjustment_fs(U, in, out, ctx);
+}
 
 // The uniform block of the list is handed over ready-made in params[kListU0 ..] (registry: setupTvoutTweaks / setupImageAdjustment).
 // FC: the block's FrameCount slot (an int uniform the lists take as a float holding its value), or -1
-template <int NU, int FC, void (*FS)(const float*, const float*, float*, void*)>
+template <int NU, int FC, int WHICH, class SI>
 __global__ void __launch_bounds__(256) k_list_pass(const PassLaunch L) {
   RC_SRGB_LDS(lds, L);
   float U[NU];
@@ -77,7 +102,7 @@ __global__ void __launch_bounds__(256) k_list_pass(const PassLaunch L) {
   in[35] = 1.0f;
   float out[4] = {0.f, 0.f, 0.f, 0.f};   // a component the shader never writes (jinc2-sharper's alpha) is stored as 0 by the GL
   TexCtx ctx{&L.in, frame_ptr(L.in, z), &lds};
-  FS(U, in, out, &ctx);
+  run_list<SI, WHICH>(U, in, out, &ctx);
   store_rt(L, z, x, y, make_float4(out[0], out[1], out[2], out[3]), &lds);
   RC_TILE_LOOP_END
 }
@@ -85,28 +110,32 @@ __global__ void __launch_bounds__(256) k_list_pass(const PassLaunch L) {
 }  // namespace
 
 namespace rck {
-hipError_t launch_tvout_tweaks(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL((k_list_pass<kTvoutU, -1, tvout_tweaks_fs>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
-  return hipGetLastError();
+template <int NU, int FC, int WHICH>
+static hipError_t launch_list(const PassLaunch& L, hipStream_t s) {
+#define RC_LIST_GO(SI)                                                                                                   \
+  do {                                                                                                                   \
+    hipLaunchKernelGGL((k_list_pass<NU, FC, WHICH, SI>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);          \
+    return hipGetLastError();                                                                                            \
+  } while (0)
+  using XN = SampEdge<FMT_RGBX8, 0>;
+  using XL = SampEdge<FMT_RGBX8, 1>;
+  using AN = SampEdge<FMT_RGBA8, 0>;
+  using AL = SampEdge<FMT_RGBA8, 1>;
+  if (!(L.flags & RC_FLAG_GENERAL_ONLY)) {
+    if (XN::matches(L.in)) RC_LIST_GO(XN);
+    if (XL::matches(L.in)) RC_LIST_GO(XL);
+    if (AN::matches(L.in)) RC_LIST_GO(AN);
+    if (AL::matches(L.in)) RC_LIST_GO(AL);
+  }
+  RC_LIST_GO(SampRT);
+#undef RC_LIST_GO
 }
-// windowed/shaders/jinc2-sharper.glsl (10 presets): a 4x4 jinc-windowed-jinc resampler - 16 taps, two sin of a sqrt distance each - with an
-// anti-ringing clamp; ~430 operations.  Uniform block: TextureSize only.
-hipError_t launch_jinc2_sharper(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL((k_list_pass<kJinc2U, -1, jinc2_sharper_fs>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
-  return hipGetLastError();
-}
-// crt/shaders/crt-lottes.glsl (~2 500 operations: 31 taps under gaussian pixel / scanline / bloom kernels, tube warp, four shadow masks on
-// gl_FragCoord, 48 branches) and its one-tap cousin crt/shaders/fakelottes.glsl
-hipError_t launch_crt_lottes(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL((k_list_pass<kLottesU, -1, crt_lottes_fs>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
-  return hipGetLastError();
-}
-hipError_t launch_fakelottes(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL((k_list_pass<kFakeLottesU, -1, fakelottes_fs>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
-  return hipGetLastError();
-}
-hipError_t launch_image_adjustment(const PassLaunch& L, hipStream_t s) {
-  hipLaunchKernelGGL((k_list_pass<kImageAdjU, kImageAdjFrameCount, image_adjustment_fs>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
-  return hipGetLastError();
-}
+// crt/shaders/tvout-tweaks.glsl, windowed/shaders/jinc2-sharper.glsl (10 presets: a 4x4 jinc-windowed-jinc resampler, 16 taps, two sin of a sqrt
+// distance each, anti-ringing clamp), crt/shaders/crt-lottes.glsl (~2 500 operations: 31 taps under gaussian pixel / scanline / bloom kernels, tube
+// warp, four shadow masks on gl_FragCoord, 48 branches), its one-tap cousin crt/shaders/fakelottes.glsl, misc/image-adjustment.glsl
+hipError_t launch_tvout_tweaks(const PassLaunch& L, hipStream_t s) { return launch_list<kTvoutU, -1, LIST_TVOUT>(L, s); }
+hipError_t launch_jinc2_sharper(const PassLaunch& L, hipStream_t s) { return launch_list<kJinc2U, -1, LIST_JINC2>(L, s); }
+hipError_t launch_crt_lottes(const PassLaunch& L, hipStream_t s) { return launch_list<kLottesU, -1, LIST_LOTTES>(L, s); }
+hipError_t launch_fakelottes(const PassLaunch& L, hipStream_t s) { return launch_list<kFakeLottesU, -1, LIST_FAKELOTTES>(L, s); }
+hipError_t launch_image_adjustment(const PassLaunch& L, hipStream_t s) { return launch_list<kImageAdjU, kImageAdjFrameCount, LIST_IMAGE_ADJ>(L, s); }
 }  // namespace rck
