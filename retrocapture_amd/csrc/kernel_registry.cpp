@@ -591,6 +591,12 @@ std::vector<KernelEntry> build() {
   // ntsc/shaders/ntsc-stock.glsl: the text of stock.glsl (a plain copy, llvmpipe's blit rules included)
   r.push_back({"ntsc/shaders/ntsc-stock.glsl", "ntsc-stock", {}, {}, rck::launch_stock, setupTexCoord, false, true, nullptr, nullptr, true});
   r.push_back({"crt/shaders/crt-potato/shader-files/crt-potato.glsl", "crt-potato", {}, {"MASK"}, rck::launch_crt_potato, setupTexCoord, false});
+  // handheld/shaders/sameboy-palettes/: byte-identical copies of motionblur/shaders/response-time.glsl and gb-palette/gb-palette.glsl
+  r.push_back({"handheld/shaders/sameboy-palettes/response-time.glsl", "sameboy-response-time", {{"response_time", 0.333f, 0.0f, 0.777f, 0.111f, "LCD Response Time"}},
+               {"PrevTexture", "Prev1Texture", "Prev2Texture", "Prev3Texture", "Prev4Texture", "Prev5Texture", "Prev6Texture"},
+               rck::launch_response_time, setupResponseTime, false, true, nullptr, nullptr, true});
+  r.push_back({"handheld/shaders/sameboy-palettes/gb-palette.glsl", "sameboy-gb-palette", {}, {"COLOR_PALETTE"}, rck::launch_gb_palette, setupTexCoord, false, true,
+               nullptr, nullptr, true});
   r.push_back({"handheld/shaders/gb-palette/gb-palette.glsl", "gb-palette", {}, {"COLOR_PALETTE"}, rck::launch_gb_palette, setupTexCoord, false, true,
                nullptr, nullptr, true});
   r.push_back({"reshade/shaders/LUT/LUT.glsl", "reshade-lut", {{"LUT_Size", 16.0f, 1.0f, 64.0f, 1.0f, "LUT Size"}}, {"SamplerLUT"},

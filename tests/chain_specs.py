@@ -440,6 +440,8 @@ scale2 = 1.0
 PRESETS["crt-potato-cool"] = ("crt/crt-potato-cool.glslp", 'shaders = 1\n\nshader0 = shaders/crt-potato/shader-files/crt-potato.glsl\nfilter_linear0 = false\nscale_type0 = viewport\n'
                               'scale0 = 1.0\nalias0 = "PASS0"\n\ntextures = MASK\nMASK = shaders/crt-potato/resources/crt-potato-thin.png\nMASK_linear = false\nMASK_wrap_mode = "repeat"\n')
 
+# handheld/sameboy-dmg-response-time.glslp (same keys / values; its two shaders are byte-identical copies of motionblur/response-time and gb-palette)
+PRESETS["sameboy-dmg-response-time"] = ("handheld/sameboy-dmg-response-time.glslp", 'shaders = "2"\n\nshader0 = "shaders/sameboy-palettes/response-time.glsl"\nfilter_linear0 = "true"\nwrap_mode0 = "clamp_to_border"\nmipmap_input0 = "false"\nalias0 = ""\nfloat_framebuffer0 = "false"\nsrgb_framebuffer0 = "false"\nscale_type_x0 = "source"\nscale_x0 = "1.000000"\nscale_type_y0 = "source"\nscale_y0 = "1.000000"\nparameters = "response_time"\nresponse_time = "0.333000"\n\nshader1 = "shaders/sameboy-palettes/gb-palette.glsl"\nfilter_linear1 = "true"\nwrap_mode1 = "clamp_to_border"\nmipmap_input1 = "false"\nalias1 = ""\nfloat_framebuffer1 = "false"\nsrgb_framebuffer1 = "false"\nscale_type_x1 = "source"\nscale_x1 = "1.000000"\nscale_type_y1 = "source"\nscale_y1 = "1.000000"\ntextures = "COLOR_PALETTE"\nCOLOR_PALETTE = "shaders/sameboy-palettes/resources/DMG.png"\nCOLOR_PALETTE_linear = "false"\nCOLOR_PALETTE_wrap_mode = "clamp_to_border"\nCOLOR_PALETTE_mipmap = "false"\n')
 # handheld/gb-palette-dmg.glslp (same keys / values; synthetic 4-band palette image)
 PRESETS["gb-palette-dmg"] = ("handheld/gb-palette-dmg.glslp", 'shaders = 1\nshader0 = shaders/gb-palette/gb-palette.glsl\n\nscale_type0 = source\nfilter_linear0 = false\n\n'
                              'textures = COLOR_PALETTE\nCOLOR_PALETTE = shaders/gb-palette/resources/palette-dmg.png\nCOLOR_PALETTE_linear = false\n')
@@ -634,6 +636,7 @@ ASSETS = {"mask_slot_small_64.png": ("crt-royale", "shaders/crt-royale/mask_slot
           "ngpc-border": ("ngpc-3x", "resources/ngpc-border-square-4x.png", "lut_border_synthetic.png"),
           "gb-palette": ("gb-palette-dmg", "shaders/gb-palette/resources/palette-dmg.png", "lut_palette_synthetic.png"),
           "potato-mask": ("crt-potato-cool", "shaders/crt-potato/resources/crt-potato-thin.png", "lut_potato_mask_synthetic.png"),
+          "sameboy-palette": ("sameboy-dmg-response-time", "shaders/sameboy-palettes/resources/DMG.png", "lut_palette_synthetic.png"),
           "sgb-border": ("sgb-crt-geom-1x", "sgb.png", "lut_border_synthetic.png"),
           "gbp-border": ("gameboy-player", "gameboy-player.png", "lut_border_synthetic.png"),
           "color-border": ("gbc-retro-v2-2x", "resources/color-border-square-4x.png", "lut_border_synthetic.png"),
@@ -696,6 +699,10 @@ SHADERS = {
     "handheld/console-border/shader-files/border.glsl": {"oracle": "console_border", "samplers": ["BORDER"],
                                                          "params": [("box_scale", 4.0), ("location_x", 0.5), ("location_y", 0.5), ("in_res_x", 320.0),
                                                                     ("in_res_y", 240.0), ("border_on_top", 1.0), ("border_zoom_x", 1.0), ("border_zoom_y", 1.0)]},
+    "handheld/shaders/sameboy-palettes/gb-palette.glsl": {"oracle": "gb_palette", "samplers": ["COLOR_PALETTE"], "params": [], "size_independent": True},
+    "handheld/shaders/sameboy-palettes/response-time.glsl": {"oracle": "response_time", "params": [("response_time", 0.333)], "size_independent": True,
+                                                             "samplers": ["PrevTexture", "Prev1Texture", "Prev2Texture", "Prev3Texture", "Prev4Texture",
+                                                                          "Prev5Texture", "Prev6Texture"]},
     "handheld/shaders/gb-palette/gb-palette.glsl": {"oracle": "gb_palette", "samplers": ["COLOR_PALETTE"], "params": [], "size_independent": True},
     "crt/shaders/crt-potato/shader-files/crt-potato.glsl": {"oracle": "crt_potato", "samplers": ["MASK"], "params": []},
     "crt/shaders/crt-lottes.glsl": {"oracle": "crt_lottes", "samplers": [], "params": [('hardScan', -8.0), ('hardPix', -3.0), ('warpX', 0.03099999949336052), ('warpY', 0.04100000113248825), ('maskDark', 0.5), ('maskLight', 1.5), ('scaleInLinearGamma', 1.0), ('shadowMask', 3.0), ('brightBoost', 1.0), ('hardBloomPix', -1.5), ('hardBloomScan', -2.0), ('bloomAmount', 0.15000000596046448), ('shape', 2.0)]},

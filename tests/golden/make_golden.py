@@ -559,6 +559,19 @@ def case_ntsc_gauss():
     run_case("f32_ntsc_gauss_scanline_72x40_to_256x160", N, mixed(72, 40, 192), 256, 160, f32=True)
 
 
+def case_sameboy():
+    pal = np.load(os.path.join(HERE, "lut_palette_synthetic.npy"))
+    with tempfile.TemporaryDirectory() as d:
+        raw = os.path.join(d, "pal.rgba")
+        pal.tofile(raw)
+        fr = moving(48, 36, 9, 240)
+        fr[..., 0] = (fr[..., 0] // 85) * 85
+        run_case("sameboy_dmg_response_time_48x36_to_48x36_f9", GLSL + "/handheld/sameboy-dmg-response-time.glslp", fr, 48, 36,
+                 luts=[("COLOR_PALETTE", (raw, pal.shape[1], pal.shape[0]))])
+        run_case("sameboy_dmg_response_time_48x36_to_131x77_f4", GLSL + "/handheld/sameboy-dmg-response-time.glslp", fr[:4], 131, 77,
+                 luts=[("COLOR_PALETTE", (raw, pal.shape[1], pal.shape[0]))])
+
+
 def case_crt_potato():
     m = np.load(os.path.join(HERE, "lut_potato_mask_synthetic.npy"))
     with tempfile.TemporaryDirectory() as d:
@@ -874,7 +887,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"lottes": case_lottes, "jinc2": case_jinc2, "interlacing": case_interlacing, "tvout": case_tvout, "ntsc_gauss": case_ntsc_gauss, "crt_potato": case_crt_potato, "gb_palette": case_gb_palette, "reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"sameboy": case_sameboy, "lottes": case_lottes, "jinc2": case_jinc2, "interlacing": case_interlacing, "tvout": case_tvout, "ntsc_gauss": case_ntsc_gauss, "crt_potato": case_crt_potato, "gb_palette": case_gb_palette, "reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -462,7 +462,9 @@ HISTORY_CASES = {"mix_frames_72x40_to_72x40_f3": "mix-frames", "mix_frames_48x36
                  # handheld/console-border/: a border image (LUT) laid over the frame by the last pass, which sits at pass index 3
                  "console_border_gba_lcd_grid_v2_3x_48x32_to_300x200_f4": "gba-lcd-grid-v2-3x",
                  "console_border_gbc_retro_v2_2x_40x36_to_233x171_f3": "gbc-retro-v2-2x",
-                 "console_border_gba_3x_48x32_to_300x200_f9": "gba-3x"}
+                 "console_border_gba_3x_48x32_to_300x200_f9": "gba-3x",
+                 "sameboy_dmg_response_time_48x36_to_48x36_f9": "sameboy-dmg-response-time",
+                 "sameboy_dmg_response_time_48x36_to_131x77_f4": "sameboy-dmg-response-time"}
 
 
 @pytest.mark.parametrize("case", sorted(HISTORY_CASES))

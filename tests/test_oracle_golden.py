@@ -85,6 +85,8 @@ CASES = {
     "ntsc_gauss_scanline_params_72x40_to_300x171": "ntsc-256px-svideo-gauss-scanline",
     "crt_potato_64x48_to_320x240": "crt-potato-cool",
     "crt_potato_40x30_to_233x171": "crt-potato-cool",
+    "sameboy_dmg_response_time_48x36_to_48x36_f9": "sameboy-dmg-response-time",   # history (full ring) in front of a palette lookup
+    "sameboy_dmg_response_time_48x36_to_131x77_f4": "sameboy-dmg-response-time",
     "gb_palette_dmg_64x48_to_64x48": "gb-palette-dmg",
     "gb_palette_dmg_64x48_to_201x155": "gb-palette-dmg",
     "reshade_lut_64x48_to_160x120": "reshade-lut",
@@ -188,6 +190,8 @@ def luts_for(key):
         return royale_luts()
     if key == "crt-potato-cool":
         return {"MASK": (np.load(os.path.join(GOLD, "lut_potato_mask_synthetic.npy")), False, "repeat")}
+    if key == "sameboy-dmg-response-time":
+        return {"COLOR_PALETTE": (np.load(os.path.join(GOLD, "lut_palette_synthetic.npy")), False, "clamp_to_border")}
     if key == "gb-palette-dmg":
         return {"COLOR_PALETTE": (np.load(os.path.join(GOLD, "lut_palette_synthetic.npy")), False, "clamp_to_border")}
     if key in ("reshade-lut", "reshade-gba"):
@@ -228,7 +232,7 @@ def run_sequence(passes, frames_rgb, vw, vh, **kw):
     return outs, st
 
 
-HISTORY_PRESETS = ("gba-3x", "gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "agb001-gba-color-motionblur", "lcd-grid-v2-psp-color-motionblur", "lcd-grid-v2-motionblur", "mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
+HISTORY_PRESETS = ("sameboy-dmg-response-time", "gba-3x", "gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "agb001-gba-color-motionblur", "lcd-grid-v2-psp-color-motionblur", "lcd-grid-v2-motionblur", "mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
 
 
 @pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] in HISTORY_PRESETS))
