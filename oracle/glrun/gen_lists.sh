@@ -8,6 +8,7 @@
 #   misc/image-adjustment.glsl (both stages)                           -> image_adjustment_{vs,fs}.inc
 #   windowed/shaders/jinc2-sharper.glsl (fragment stage)               -> jinc2_sharper_fs.inc
 #   crt/shaders/crt-lottes.glsl, crt/shaders/fakelottes.glsl (fragment) -> crt_lottes_fs.inc, fakelottes_fs.inc
+#   stereoscopic-3d/shaders/side-by-side-simple.glsl (both stages)     -> side_by_side_{vs,fs}.inc
 # written to oracle/gen/ for the oracle and, the same text, to retrocapture_amd/csrc/kernels/gen/ for the HIP kernels.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -43,4 +44,7 @@ listing misc/image-adjustment.glsl GALLIVM_DEBUG=tgsi "$T/iav.txt" && emit "$T/i
 listing windowed/shaders/jinc2-sharper.glsl LP_DEBUG=fs "$T/j2.txt" && emit "$T/j2.txt" fragment jinc2_sharper_fs
 listing crt/shaders/crt-lottes.glsl LP_DEBUG=fs "$T/lo.txt" && emit "$T/lo.txt" fragment crt_lottes_fs
 listing crt/shaders/fakelottes.glsl LP_DEBUG=fs "$T/fl.txt" && emit "$T/fl.txt" fragment fakelottes_fs
+S=stereoscopic-3d/shaders/side-by-side-simple.glsl
+listing "$S" LP_DEBUG=fs "$T/sbs.txt" && emit "$T/sbs.txt" fragment side_by_side_fs
+listing "$S" GALLIVM_DEBUG=tgsi "$T/sbsv.txt" && emit "$T/sbsv.txt" vertex side_by_side_vs
 wc -l "$ROOT"/oracle/gen/*.inc

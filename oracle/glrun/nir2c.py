@@ -205,6 +205,8 @@ def translate(text, stage, name):
         if op == "deref_var":
             g.deref[n] = re.match(r"deref_var &([\w#]+)", rhs).group(1)
             continue
+        if op == "deref_array":   # MVPMatrix[i] in a vertex listing: only ever the address of the load_ubo that follows
+            continue
         if op == "@load_deref":
             var = g.deref[re.match(r"@load_deref \(%(\d+)\)", rhs).group(1)]
             off = g.in_off[var]

@@ -42,6 +42,8 @@ static void rcn_tex(void* ctx, float u, float v, float* dst) {
 #include "gen/jinc2_sharper_fs.inc"
 #include "gen/crt_lottes_fs.inc"
 #include "gen/fakelottes_fs.inc"
+#include "gen/side_by_side_vs.inc"
+#include "gen/side_by_side_fs.inc"
 #include "gen/image_adjustment_vs.inc"
 #include "gen/image_adjustment_fs.inc"
 #pragma GCC diagnostic pop
@@ -178,4 +180,41 @@ void o_pass_crt_lottes(const o_pass_args* a) {
 void o_pass_fakelottes(const o_pass_args* a) {
   static const char* const names[10] = {"shadowMask", "SCANLINE_SINE_COMP_B", "warpX", "warpY", "maskDark", "maskLight", "crt_gamma", "monitor_gamma", "SCANLINE_SINE_COMP_A", "SCANLINE_BASE_BRIGHTNESS"};
   run_fragcoord_list(a, fakelottes_fs, fakelottes_fs_uniforms, names, 10);
+}
+
+/* stereoscopic-3d/shaders/side-by-side-simple.glsl (stereoscopic-3d/side-by-side.glslp, sbs-{flat,warp}-mobile-16x9.glslp): the frame twice, one copy
+ * per eye, each placed and lens-warped; an eye's sample is taken only where its coordinate falls inside the frame (texture() inside branches),
+ * the two are added.  VS (zoom, width / height, horizontal placement) and FS are the GL's instruction lists.  params in #pragma order. */
+void o_pass_side_by_side(const o_pass_args* a) {
+  static const char* const names[9] = {"eye_sep", "y_loc", "BOTH", "ana_zoom", "WIDTH", "HEIGHT", "warpX", "warpY", "pulfrich"};
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  float Uv[64] = {0}, Uf[32] = {0};
+  static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  put(Uv, side_by_side_vs_uniforms, "MVPMatrix", ident, 16);
+  put_sizes(Uv, side_by_side_vs_uniforms, a, 1);
+  put_sizes(Uf, side_by_side_fs_uniforms, a, 1);
+  for (int k = 0; k < 9; ++k) {
+    put(Uv, side_by_side_vs_uniforms, names[k], &a->params[k], 1);
+    put(Uf, side_by_side_fs_uniforms, names[k], &a->params[k], 1);
+  }
+  static const float pos[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}}, uv[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+  float vout[4][48];
+  for (int v = 0; v < 4; ++v) {
+    const float in[8] = {pos[v][0], pos[v][1], 0.0f, 1.0f, uv[v][0], uv[v][1], 0.0f, 1.0f};
+    memset(vout[v], 0, sizeof vout[v]);
+    side_by_side_vs(Uv, in, vout[v], 0);
+  }
+  o_varying pl[2];
+  for (int c = 0; c < 2; ++c) pl[c] = o_varying_setup(vout[0][c], vout[1][c], vout[2][c], vout[3][c], W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float in[2] = {o_varying_at(&pl[0], x, y, lo), o_varying_at(&pl[1], x, y, lo)};
+      float out[4] = {0.f, 0.f, 0.f, 0.f};
+      side_by_side_fs(Uf, in, out, (void*)a->in);
+      const o_vec4 o = {out[0], out[1], out[2], out[3]};
+      o_store_pixel(a, x, y, o);
+    }
+  o_fp_leave(csr);
 }

@@ -554,6 +554,15 @@ std::vector<KernelEntry> build() {
                    {}, rck::launch_fakelottes, setupFakeLottes, false};
     fl.texture_height_override = true;
     r.push_back(fl);
+    KernelEntry sb{"stereoscopic-3d/shaders/side-by-side-simple.glsl", "side-by-side-simple",
+                   {{"eye_sep", 0.30f, -1.0f, 5.0f, 0.05f, "Eye Separation"}, {"y_loc", 0.25f, -1.0f, 1.0f, 0.01f, "Vertical Placement"},
+                    {"BOTH", 0.51f, -2.0f, 2.0f, 0.005f, "Horizontal Placement"}, {"ana_zoom", 0.75f, -2.0f, 2.0f, 0.05f, "Zoom"},
+                    {"WIDTH", 3.05f, 1.0f, 7.0f, 0.05f, "Side-by-Side Image Width"}, {"HEIGHT", 2.0f, 1.0f, 5.0f, 0.1f, "Side-by-Side Image Height"},
+                    {"warpX", 0.1f, 0.0f, 0.5f, 0.05f, "Lens Warp Correction X"}, {"warpY", 0.1f, 0.0f, 0.5f, 0.05f, "Lens Warp Correction Y"},
+                    {"pulfrich", 0.0f, 0.0f, 0.5f, 0.25f, "Pulfrich Effect"}},
+                   {}, rck::launch_side_by_side, setupSideBySide, false};
+    sb.texture_height_override = true;
+    r.push_back(sb);
     KernelEntry j{"windowed/shaders/jinc2-sharper.glsl", "jinc2-sharper", {}, {}, rck::launch_jinc2_sharper, setupJinc2Sharper, false};
     j.texture_height_override = true;
     r.push_back(j);

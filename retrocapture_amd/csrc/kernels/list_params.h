@@ -8,3 +8,4 @@ constexpr int kImageAdjFrameCount = 16;
 constexpr int kJinc2U = 2;              // jinc2_sharper_fs_uniforms: TextureSize
 constexpr int kLottesU = 24;            // crt_lottes_fs_uniforms: sizes, 13 parameters, gl_FbWposYTransform at 20
 constexpr int kFakeLottesU = 20;        // fakelottes_fs_uniforms: sizes, 10 parameters, gl_FbWposYTransform at 16
+constexpr int kSbsU = 9;                // side_by_side_fs_uniforms: TextureSize, InputSize, five parameters

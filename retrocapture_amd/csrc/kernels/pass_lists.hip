@@ -69,16 +69,18 @@ struct Lists {
 #include "gen/jinc2_sharper_fs.inc"
 #include "gen/crt_lottes_fs.inc"
 #include "gen/fakelottes_fs.inc"
+#include "gen/side_by_side_fs.inc"
 #include "gen/image_adjustment_fs.inc"
 #pragma clang diagnostic pop
 };
-enum { LIST_TVOUT, LIST_JINC2, LIST_LOTTES, LIST_FAKELOTTES, LIST_IMAGE_ADJ };
+enum { LIST_TVOUT, LIST_JINC2, LIST_LOTTES, LIST_FAKELOTTES, LIST_SBS, LIST_IMAGE_ADJ };
 template <class SI, int WHICH>
 __device__ __forceinline__ void run_list(const float* U, const float* in, float* out, void* ctx) {
   if (WHICH == LIST_TVOUT) Lists<SI>::tvout_tweaks_fs(U, in, out, ctx);
   else if (WHICH == LIST_JINC2) Lists<SI>::jinc2_sharper_fs(U, in, out, ctx);
   else if (WHICH == LIST_LOTTES) Lists<SI>::crt_lottes_fs(U, in, out, ctx);
   else if (WHICH == LIST_FAKELOTTES) Lists<SI>::fakelottes_fs(U, in, out, ctx);
+  else if (WHICH == LIST_SBS) Lists<SI>::side_by_side_fs(U, in, out, ctx);
   else Lists<SI>::image_adjustment_fs(U, in, out, ctx);
 }
 
@@ -137,5 +139,7 @@ hipError_t launch_tvout_tweaks(const PassLaunch& L, hipStream_t s) { return laun
 hipError_t launch_jinc2_sharper(const PassLaunch& L, hipStream_t s) { return launch_list<kJinc2U, -1, LIST_JINC2>(L, s); }
 hipError_t launch_crt_lottes(const PassLaunch& L, hipStream_t s) { return launch_list<kLottesU, -1, LIST_LOTTES>(L, s); }
 hipError_t launch_fakelottes(const PassLaunch& L, hipStream_t s) { return launch_list<kFakeLottesU, -1, LIST_FAKELOTTES>(L, s); }
+// stereoscopic-3d/shaders/side-by-side-simple.glsl: one copy of the frame per eye, sampled only inside the frame (taps inside branches), added
+hipError_t launch_side_by_side(const PassLaunch& L, hipStream_t s) { return launch_list<kSbsU, -1, LIST_SBS>(L, s); }
 hipError_t launch_image_adjustment(const PassLaunch& L, hipStream_t s) { return launch_list<kImageAdjU, kImageAdjFrameCount, LIST_IMAGE_ADJ>(L, s); }
 }  // namespace rck

@@ -19,12 +19,14 @@ namespace {
 #pragma clang diagnostic ignored "-Wunused-but-set-variable"
 #pragma clang diagnostic ignored "-Wunused-variable"
 #include "kernels/gen/image_adjustment_vs.inc"
+#include "kernels/gen/side_by_side_vs.inc"
 #define RCN_TABLES_ONLY
 #include "kernels/gen/image_adjustment_fs.inc"
 #include "kernels/gen/tvout_tweaks_fs.inc"
 #include "kernels/gen/jinc2_sharper_fs.inc"
 #include "kernels/gen/crt_lottes_fs.inc"
 #include "kernels/gen/fakelottes_fs.inc"
+#include "kernels/gen/side_by_side_fs.inc"
 #undef RCN_TABLES_ONLY
 #pragma clang diagnostic pop
 
@@ -82,6 +84,29 @@ void setupFragCoordList(const PassGeometry& g, rcd::PassLaunch& L, const T* tabl
 }  // namespace
 void setupCrtLottes(const PassGeometry& g, rcd::PassLaunch& L) { setupFragCoordList(g, L, crt_lottes_fs_uniforms, kLottesNames, 13, kLottesU); }
 void setupFakeLottes(const PassGeometry& g, rcd::PassLaunch& L) { setupFragCoordList(g, L, fakelottes_fs_uniforms, kFakeLottesNames, 10, kFakeLottesU); }
+
+// side-by-side-simple.glsl: uniform block by name, vertex stage (zoom, width / height, placement) at the quad's vertices
+void setupSideBySide(const PassGeometry& g, rcd::PassLaunch& L) {
+  static const char* const names[9] = {"eye_sep", "y_loc", "BOTH", "ana_zoom", "WIDTH", "HEIGHT", "warpX", "warpY", "pulfrich"};
+  float* U = L.params + kListU0;
+  for (int k = 0; k < kSbsU; ++k) U[k] = 0.0f;
+  putSizes(U, side_by_side_fs_uniforms, g, kSbsU);
+  float Uv[64] = {};
+  static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  put(Uv, side_by_side_vs_uniforms, "MVPMatrix", ident, 16, 64);
+  putSizes(Uv, side_by_side_vs_uniforms, g, 64);
+  for (int k = 0; k < 9; ++k) {
+    put(U, side_by_side_fs_uniforms, names[k], &L.params[k], 1, kSbsU);
+    put(Uv, side_by_side_vs_uniforms, names[k], &L.params[k], 1, 64);
+  }
+  static const float pos[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}}, uv[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+  float out[4][48] = {};
+  for (int v = 0; v < 4; ++v) {
+    const float in[8] = {pos[v][0], pos[v][1], 0.0f, 1.0f, uv[v][0], uv[v][1], 0.0f, 1.0f};
+    side_by_side_vs(Uv, in, out[v], nullptr);
+  }
+  for (int c = 0; c < 2; ++c) L.plane[c] = makePlane(out[0][c], out[1][c], out[2][c], out[3][c], g.out_w, g.out_h, g.out_fmt);
+}
 
 void setupJinc2Sharper(const PassGeometry& g, rcd::PassLaunch& L) {
   L.plane[0] = planeU(1.0001f, g.out_w, g.out_h, g.out_fmt);   // VS: TEX0 = TexCoord * 1.0001

@@ -8,4 +8,5 @@ void setupImageAdjustment(const PassGeometry& g, rcd::PassLaunch& L);
 void setupJinc2Sharper(const PassGeometry& g, rcd::PassLaunch& L);
 void setupCrtLottes(const PassGeometry& g, rcd::PassLaunch& L);
 void setupFakeLottes(const PassGeometry& g, rcd::PassLaunch& L);
+void setupSideBySide(const PassGeometry& g, rcd::PassLaunch& L);
 }  // namespace rc

@@ -398,6 +398,9 @@ PRESETS["tvout"] = ("presets/tvout/tvout.glslp", '#tvout preset for 240p CRTs\n\
 PRESETS["tvout+ntsc-256px-svideo"] = ("presets/tvout/tvout+ntsc-256px-svideo.glslp", 'shaders = "4"\n\nshader0 = "../../ntsc/shaders/ntsc-pass1-svideo-3phase.glsl"\nfilter_linear0 = "false"\nframe_count_mod0 = "2"\nfloat_framebuffer0 = "true"\nscale_type_x0 = "absolute"\nscale_x0 = "1536"\nscale_type_y0 = "source"\nscale_y0 = "1.000000"\n\nshader1 = "../../ntsc/shaders/ntsc-pass2-3phase.glsl"\nfilter_linear1 = "false"\nfloat_framebuffer1 = "false"\nscale_type_x1 = "source"\nscale_x1 = "0.500000"\nscale_type_y1 = "source"\nscale_y1 = "1.000000"\n\nshader2 = "../../crt/shaders/tvout-tweaks.glsl"\nfilter_linear2 = "false"\nfloat_framebuffer2 = "false"\nscale_type_x2 = "viewport"\nscale_x2 = "1.000000"\nscale_type_y2 = "source"\nscale_y2 = "1.000000"\n\nshader3 = "../../misc/image-adjustment.glsl"\nfloat_framebuffer3 = "false"\n\nparameters = "TVOUT_RESOLUTION;TVOUT_COMPOSITE_CONNECTION;TVOUT_TV_COLOR_LEVELS;target_gamma;monitor_gamma;overscan_percent_x;overscan_percent_y;saturation;contrast;luminance;bright_boost;R;G;B"\nTVOUT_RESOLUTION = "512.000000"\nTVOUT_COMPOSITE_CONNECTION = "0.000000"\nTVOUT_TV_COLOR_LEVELS = "1.000000"\ntarget_gamma = "2.400000"\nmonitor_gamma = "2.200000"\noverscan_percent_x = "0.000000"\noverscan_percent_y = "0.000000"\nsaturation = "1.000000"\ncontrast = "1.000000"\nluminance = "1.000000"\nbright_boost = "0.000000"\nR = "1.000000"\nG = "1.000000"\nB = "1.000000"')
 PRESETS["retro-v2+image-adjustment"] = ("presets/retro-v2+image-adjustment.glslp", 'shaders = "2"\n\nshader0 = "../misc/image-adjustment.glsl"\nshader1 = "../handheld/shaders/retro-v2.glsl"\n\nfilter_linear0 = "false"\nscale_type0 = "source"\nscale0 = "1.000000"\n\nfilter_linear1 = "false"\n\nparameters = "target_gamma;monitor_gamma;overscan_percent_x;overscan_percent_y;saturation;contrast;luminance;bright_boost;R;G;B;RETRO_PIXEL_SIZE"\ntarget_gamma = "2.200000"\nmonitor_gamma = "2.20000"\noverscan_percent_x = "0.000000"\noverscan_percent_y = "0.000000"\nsaturation = "1.000000"\ncontrast = "1.000000"\nluminance = "1.000000"\nbright_boost = "0.000000"\nR = "1.000000"\nG = "1.000000"\nB = "1.000000"\nRETRO_PIXEL_SIZE = "0.840000"\n')
 PRESETS["tvout+interlacing"] = ("presets/tvout+interlacing/tvout+interlacing.glslp", '#tvout preset for 480p CRTs\n\nshaders = "3"\nshader0 = "../../crt/shaders/tvout-tweaks.glsl"\nshader1 = "../../misc/image-adjustment.glsl"\nshader2 = "../../misc/interlacing.glsl"\n\nscale_type_x0 = "viewport"\nscale_x0 = "1.000000"\nscale_type_y0 = "source"\nscale_y0 = "1.000000"\n\nparameters = "TVOUT_RESOLUTION;TVOUT_COMPOSITE_CONNECTION;TVOUT_TV_COLOR_LEVELS;target_gamma;monitor_gamma;overscan_percent_x;overscan_percent_y;saturation;contrast;luminance;bright_boost;R;G;B"\nTVOUT_RESOLUTION = "320.000000"\nTVOUT_COMPOSITE_CONNECTION = "0.000000"\nTVOUT_TV_COLOR_LEVELS = "1.000000"\ntarget_gamma = "2.400000"\nmonitor_gamma = "2.200000"\noverscan_percent_x = "0.000000"\noverscan_percent_y = "0.000000"\nsaturation = "1.000000"\ncontrast = "1.000000"\nluminance = "1.000000"\nbright_boost = "0.000000"\nR = "1.000000"\nG = "1.000000"\nB = "1.000000"')
+PRESETS["side-by-side"] = ("stereoscopic-3d/side-by-side.glslp", 'shaders = 1\n\nshader0 = shaders/side-by-side-simple.glsl\n\nparameters = "eye_sep;y_loc;ana_zoom"\neye_sep = "0.30"\ny_loc = "0.25"\nana_zoom = "0.50"\n')
+PRESETS["sbs-warp-mobile-16x9"] = ("stereoscopic-3d/sbs-warp-mobile-16x9.glslp", 'shaders = 1\n\nshader0 = shaders/side-by-side-simple.glsl\n\nparameters = "eye_sep;y_loc;BOTH;ana_zoom;warpY;warpX"\neye_sep = "0.125"\ny_loc = "0.10"\nBOTH = "0.255"\nana_zoom = "0.66"\nwarpY = "0.1"\nwarpX = "0.1"\n')
+PRESETS["side-by-side-bare"] = ("stereoscopic-3d/side-by-side-bare.glslp", 'shaders = 1\nshader0 = shaders/side-by-side-simple.glsl\n')
 PRESETS["crt-lottes"] = ("crt/crt-lottes.glslp", 'shaders = 1\n\nshader0 = shaders/crt-lottes.glsl\nfilter_linear0 = false\n')
 PRESETS["fakelottes"] = ("crt/fakelottes.glslp", 'shaders = 1\n\nshader0 = shaders/fakelottes.glsl\nfilter_linear0 = true\n')
 PRESETS["jinc2-sharper"] = ("windowed/jinc2-sharper.glslp", 'shaders = 1\n\nshader0 = shaders/jinc2-sharper.glsl\nfilter_linear0 = false\n')
@@ -705,6 +708,7 @@ SHADERS = {
                                                                           "Prev5Texture", "Prev6Texture"]},
     "handheld/shaders/gb-palette/gb-palette.glsl": {"oracle": "gb_palette", "samplers": ["COLOR_PALETTE"], "params": [], "size_independent": True},
     "crt/shaders/crt-potato/shader-files/crt-potato.glsl": {"oracle": "crt_potato", "samplers": ["MASK"], "params": []},
+    "stereoscopic-3d/shaders/side-by-side-simple.glsl": {"oracle": "side_by_side", "samplers": [], "params": [('eye_sep', 0.30000001192092896), ('y_loc', 0.25), ('BOTH', 0.5099999904632568), ('ana_zoom', 0.75), ('WIDTH', 3.049999952316284), ('HEIGHT', 2.0), ('warpX', 0.10000000149011612), ('warpY', 0.10000000149011612), ('pulfrich', 0.0)]},
     "crt/shaders/crt-lottes.glsl": {"oracle": "crt_lottes", "samplers": [], "params": [('hardScan', -8.0), ('hardPix', -3.0), ('warpX', 0.03099999949336052), ('warpY', 0.04100000113248825), ('maskDark', 0.5), ('maskLight', 1.5), ('scaleInLinearGamma', 1.0), ('shadowMask', 3.0), ('brightBoost', 1.0), ('hardBloomPix', -1.5), ('hardBloomScan', -2.0), ('bloomAmount', 0.15000000596046448), ('shape', 2.0)]},
     "crt/shaders/fakelottes.glsl": {"oracle": "fakelottes", "samplers": [], "params": [('shadowMask', 1.0), ('SCANLINE_SINE_COMP_B', 0.4000000059604645), ('warpX', 0.03099999949336052), ('warpY', 0.04100000113248825), ('maskDark', 0.5), ('maskLight', 1.5), ('crt_gamma', 2.5), ('monitor_gamma', 2.200000047683716), ('SCANLINE_SINE_COMP_A', 0.0), ('SCANLINE_BASE_BRIGHTNESS', 0.949999988079071)]},
     "windowed/shaders/jinc2-sharper.glsl": {"oracle": "jinc2_sharper", "samplers": [], "params": []},

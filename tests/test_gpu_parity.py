@@ -12,6 +12,9 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "side_by_side_64x48_to_320x240": "side-by-side",
+    "sbs_warp_mobile_64x36_to_320x180": "sbs-warp-mobile-16x9",
+    "side_by_side_bare_params_40x30_to_233x171": "side-by-side-bare",
     "crt_lottes_64x48_to_320x240": "crt-lottes",
     "crt_lottes_params_40x30_to_233x171": "crt-lottes",
     "crt_lottes_mask0_48x36_to_200x150": "crt-lottes",

@@ -62,6 +62,9 @@ CASES = {
     "imgborder_sgb_crt_geom_1x_40x36_to_256x224": "sgb-crt-geom-1x",
     "imgborder_sgb_bare_params_40x30_to_233x171": "imgborder-sgb-bare",
     "console_border_ngpc_3x_40x38_to_300x200": "ngpc-3x",
+    "side_by_side_64x48_to_320x240": "side-by-side",
+    "sbs_warp_mobile_64x36_to_320x180": "sbs-warp-mobile-16x9",
+    "side_by_side_bare_params_40x30_to_233x171": "side-by-side-bare",
     "crt_lottes_64x48_to_320x240": "crt-lottes",
     "crt_lottes_params_40x30_to_233x171": "crt-lottes",
     "crt_lottes_mask0_48x36_to_200x150": "crt-lottes",
@@ -335,6 +338,7 @@ FLOAT_CASES = {
     "f32_psp_color_48x36_to_131x77": ("psp-color", {}),
     "f32_vba_color_48x36_to_131x77": ("vba-color", {}),
     "f32_imgborder_sgb_bare_params_40x30_to_233x171": ("imgborder-sgb-bare", {}),
+    "f32_side_by_side_bare_params_48x36_to_200x150": ("side-by-side-bare", {}),
     "f32_crt_lottes_48x36_to_200x150": ("crt-lottes", {}),
     "f32_fakelottes_48x36_to_200x150": ("fakelottes", {}),
     "f32_jinc2_sharper_48x36_to_200x150": ("jinc2-sharper", {}),
