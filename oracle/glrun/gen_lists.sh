@@ -9,6 +9,7 @@
 #   windowed/shaders/jinc2-sharper.glsl (fragment stage)               -> jinc2_sharper_fs.inc
 #   crt/shaders/crt-lottes.glsl, crt/shaders/fakelottes.glsl (fragment) -> crt_lottes_fs.inc, fakelottes_fs.inc
 #   stereoscopic-3d/shaders/side-by-side-simple.glsl (both stages)     -> side_by_side_{vs,fs}.inc
+#   handheld/shaders/sameboy-lcd.glsl (fragment stage)                 -> sameboy_lcd_fs.inc
 # written to oracle/gen/ for the oracle and, the same text, to retrocapture_amd/csrc/kernels/gen/ for the HIP kernels.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -47,4 +48,5 @@ listing crt/shaders/fakelottes.glsl LP_DEBUG=fs "$T/fl.txt" && emit "$T/fl.txt" 
 S=stereoscopic-3d/shaders/side-by-side-simple.glsl
 listing "$S" LP_DEBUG=fs "$T/sbs.txt" && emit "$T/sbs.txt" fragment side_by_side_fs
 listing "$S" GALLIVM_DEBUG=tgsi "$T/sbsv.txt" && emit "$T/sbsv.txt" vertex side_by_side_vs
+listing handheld/shaders/sameboy-lcd.glsl LP_DEBUG=fs "$T/sl.txt" && emit "$T/sl.txt" fragment sameboy_lcd_fs
 wc -l "$ROOT"/oracle/gen/*.inc

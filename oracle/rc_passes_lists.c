@@ -44,6 +44,7 @@ static void rcn_tex(void* ctx, float u, float v, float* dst) {
 #include "gen/fakelottes_fs.inc"
 #include "gen/side_by_side_vs.inc"
 #include "gen/side_by_side_fs.inc"
+#include "gen/sameboy_lcd_fs.inc"
 #include "gen/image_adjustment_vs.inc"
 #include "gen/image_adjustment_fs.inc"
 #pragma GCC diagnostic pop
@@ -213,6 +214,29 @@ void o_pass_side_by_side(const o_pass_args* a) {
       const float in[2] = {o_varying_at(&pl[0], x, y, lo), o_varying_at(&pl[1], x, y, lo)};
       float out[4] = {0.f, 0.f, 0.f, 0.f};
       side_by_side_fs(Uf, in, out, (void*)a->in);
+      const o_vec4 o = {out[0], out[1], out[2], out[3]};
+      o_store_pixel(a, x, y, o);
+    }
+  o_fp_leave(csr);
+}
+
+/* handheld/shaders/sameboy-lcd.glsl (handheld/sameboy-lcd.glslp, sameboy-lcd-gbc-color-motionblur.glslp): SameBoy's LCD filter - nine taps around
+ * the pixel, the sub-pixel position picking which neighbours and in what proportion, a scanline term; ~265 operations, 7 branches with taps inside.
+ * params: COLOR_LOW, COLOR_HIGH, SCANLINE_DEPTH.  VS: TEX0 = TexCoord. */
+void o_pass_sameboy_lcd(const o_pass_args* a) {
+  static const char* const names[3] = {"COLOR_LOW", "COLOR_HIGH", "SCANLINE_DEPTH"};
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  float U[8] = {0};
+  put_sizes(U, sameboy_lcd_fs_uniforms, a, 1);
+  for (int k = 0; k < 3; ++k) put(U, sameboy_lcd_fs_uniforms, names[k], &a->params[k], 1);
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float in[2] = {o_varying_at(&tu, x, y, lo), o_varying_at(&tv, x, y, lo)};
+      float out[4] = {0.f, 0.f, 0.f, 0.f};
+      sameboy_lcd_fs(U, in, out, (void*)a->in);
       const o_vec4 o = {out[0], out[1], out[2], out[3]};
       o_store_pixel(a, x, y, o);
     }

@@ -563,6 +563,12 @@ std::vector<KernelEntry> build() {
                    {}, rck::launch_side_by_side, setupSideBySide, false};
     sb.texture_height_override = true;
     r.push_back(sb);
+    KernelEntry sl{"handheld/shaders/sameboy-lcd.glsl", "sameboy-lcd",
+                   {{"COLOR_LOW", 0.8f, 0.0f, 1.5f, 0.05f, "Color Low"}, {"COLOR_HIGH", 1.0f, 0.0f, 1.5f, 0.05f, "Color High"},
+                    {"SCANLINE_DEPTH", 0.1f, 0.0f, 2.0f, 0.05f, "Scanline Depth"}},
+                   {}, rck::launch_sameboy_lcd, setupSameboyLcd, false};
+    sl.texture_height_override = true;
+    r.push_back(sl);
     KernelEntry j{"windowed/shaders/jinc2-sharper.glsl", "jinc2-sharper", {}, {}, rck::launch_jinc2_sharper, setupJinc2Sharper, false};
     j.texture_height_override = true;
     r.push_back(j);

@@ -9,3 +9,4 @@ constexpr int kJinc2U = 2;              // jinc2_sharper_fs_uniforms: TextureSiz
 constexpr int kLottesU = 24;            // crt_lottes_fs_uniforms: sizes, 13 parameters, gl_FbWposYTransform at 20
 constexpr int kFakeLottesU = 20;        // fakelottes_fs_uniforms: sizes, 10 parameters, gl_FbWposYTransform at 16
 constexpr int kSbsU = 9;                // side_by_side_fs_uniforms: TextureSize, InputSize, five parameters
+constexpr int kSameboyLcdU = 5;         // sameboy_lcd_fs_uniforms: TextureSize, three parameters

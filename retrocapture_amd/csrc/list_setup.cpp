@@ -27,6 +27,7 @@ namespace {
 #include "kernels/gen/crt_lottes_fs.inc"
 #include "kernels/gen/fakelottes_fs.inc"
 #include "kernels/gen/side_by_side_fs.inc"
+#include "kernels/gen/sameboy_lcd_fs.inc"
 #undef RCN_TABLES_ONLY
 #pragma clang diagnostic pop
 
@@ -106,6 +107,16 @@ void setupSideBySide(const PassGeometry& g, rcd::PassLaunch& L) {
     side_by_side_vs(Uv, in, out[v], nullptr);
   }
   for (int c = 0; c < 2; ++c) L.plane[c] = makePlane(out[0][c], out[1][c], out[2][c], out[3][c], g.out_w, g.out_h, g.out_fmt);
+}
+
+void setupSameboyLcd(const PassGeometry& g, rcd::PassLaunch& L) {
+  static const char* const names[3] = {"COLOR_LOW", "COLOR_HIGH", "SCANLINE_DEPTH"};
+  L.plane[0] = planeU(1.0f, g.out_w, g.out_h, g.out_fmt);
+  L.plane[1] = planeV(1.0f, g.out_w, g.out_h, g.out_fmt);
+  float* U = L.params + kListU0;
+  for (int k = 0; k < kSameboyLcdU; ++k) U[k] = 0.0f;
+  putSizes(U, sameboy_lcd_fs_uniforms, g, kSameboyLcdU);
+  for (int k = 0; k < 3; ++k) put(U, sameboy_lcd_fs_uniforms, names[k], &L.params[k], 1, kSameboyLcdU);
 }
 
 void setupJinc2Sharper(const PassGeometry& g, rcd::PassLaunch& L) {

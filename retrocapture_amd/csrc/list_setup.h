@@ -9,4 +9,5 @@ void setupJinc2Sharper(const PassGeometry& g, rcd::PassLaunch& L);
 void setupCrtLottes(const PassGeometry& g, rcd::PassLaunch& L);
 void setupFakeLottes(const PassGeometry& g, rcd::PassLaunch& L);
 void setupSideBySide(const PassGeometry& g, rcd::PassLaunch& L);
+void setupSameboyLcd(const PassGeometry& g, rcd::PassLaunch& L);
 }  // namespace rc

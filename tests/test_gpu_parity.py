@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "sameboy_lcd_64x48_to_320x240": "sameboy-lcd",
+    "sameboy_lcd_params_40x30_to_233x171": "sameboy-lcd",
     "side_by_side_64x48_to_320x240": "side-by-side",
     "sbs_warp_mobile_64x36_to_320x180": "sbs-warp-mobile-16x9",
     "side_by_side_bare_params_40x30_to_233x171": "side-by-side-bare",
@@ -467,7 +469,8 @@ HISTORY_CASES = {"mix_frames_72x40_to_72x40_f3": "mix-frames", "mix_frames_48x36
                  "console_border_gbc_retro_v2_2x_40x36_to_233x171_f3": "gbc-retro-v2-2x",
                  "console_border_gba_3x_48x32_to_300x200_f9": "gba-3x",
                  "sameboy_dmg_response_time_48x36_to_48x36_f9": "sameboy-dmg-response-time",
-                 "sameboy_dmg_response_time_48x36_to_131x77_f4": "sameboy-dmg-response-time"}
+                 "sameboy_dmg_response_time_48x36_to_131x77_f4": "sameboy-dmg-response-time",
+                 "sameboy_lcd_gbc_color_motionblur_48x36_to_200x150_f4": "sameboy-lcd-gbc-color-motionblur"}
 
 
 @pytest.mark.parametrize("case", sorted(HISTORY_CASES))

@@ -62,6 +62,9 @@ CASES = {
     "imgborder_sgb_crt_geom_1x_40x36_to_256x224": "sgb-crt-geom-1x",
     "imgborder_sgb_bare_params_40x30_to_233x171": "imgborder-sgb-bare",
     "console_border_ngpc_3x_40x38_to_300x200": "ngpc-3x",
+    "sameboy_lcd_64x48_to_320x240": "sameboy-lcd",
+    "sameboy_lcd_params_40x30_to_233x171": "sameboy-lcd",
+    "sameboy_lcd_gbc_color_motionblur_48x36_to_200x150_f4": "sameboy-lcd-gbc-color-motionblur",
     "side_by_side_64x48_to_320x240": "side-by-side",
     "sbs_warp_mobile_64x36_to_320x180": "sbs-warp-mobile-16x9",
     "side_by_side_bare_params_40x30_to_233x171": "side-by-side-bare",
@@ -235,7 +238,7 @@ def run_sequence(passes, frames_rgb, vw, vh, **kw):
     return outs, st
 
 
-HISTORY_PRESETS = ("sameboy-dmg-response-time", "gba-3x", "gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "agb001-gba-color-motionblur", "lcd-grid-v2-psp-color-motionblur", "lcd-grid-v2-motionblur", "mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
+HISTORY_PRESETS = ("sameboy-lcd-gbc-color-motionblur", "sameboy-dmg-response-time", "gba-3x", "gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "agb001-gba-color-motionblur", "lcd-grid-v2-psp-color-motionblur", "lcd-grid-v2-motionblur", "mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
 
 
 @pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] in HISTORY_PRESETS))
@@ -338,6 +341,7 @@ FLOAT_CASES = {
     "f32_psp_color_48x36_to_131x77": ("psp-color", {}),
     "f32_vba_color_48x36_to_131x77": ("vba-color", {}),
     "f32_imgborder_sgb_bare_params_40x30_to_233x171": ("imgborder-sgb-bare", {}),
+    "f32_sameboy_lcd_48x36_to_200x150": ("sameboy-lcd", {}),
     "f32_side_by_side_bare_params_48x36_to_200x150": ("side-by-side-bare", {}),
     "f32_crt_lottes_48x36_to_200x150": ("crt-lottes", {}),
     "f32_fakelottes_48x36_to_200x150": ("fakelottes", {}),
