@@ -45,6 +45,7 @@ static void rcn_tex(void* ctx, float u, float v, float* dst) {
 #include "gen/side_by_side_vs.inc"
 #include "gen/side_by_side_fs.inc"
 #include "gen/sameboy_lcd_fs.inc"
+#include "gen/crt_consumer_fs.inc"
 #include "gen/image_adjustment_vs.inc"
 #include "gen/image_adjustment_fs.inc"
 #pragma GCC diagnostic pop
@@ -152,15 +153,22 @@ void o_pass_jinc2_sharper(const o_pass_args* a) {
  * shadow masks on gl_FragCoord, 48 branches) and crt/shaders/fakelottes.glsl (crt/fakelottes.glslp: its one-tap cousin).  Both read
  * gl_FragCoord (pixel + 0.5; handed over in the list's input slots 32..35) through gl_FbWposYTransform = (1, 0, -1, height).
  * params in #pragma order. */
+static void run_fragcoord_list_k(const o_pass_args* a, void (*fs)(const float*, const float*, float*, void*), const void* table, const char* const* names, int n,
+                                 float k);
 static void run_fragcoord_list(const o_pass_args* a, void (*fs)(const float*, const float*, float*, void*), const void* table, const char* const* names, int n) {
+  run_fragcoord_list_k(a, fs, table, names, n, 1.0f);
+}
+/* k: the vertex stage's TEX0 = TexCoord * k */
+static void run_fragcoord_list_k(const o_pass_args* a, void (*fs)(const float*, const float*, float*, void*), const void* table, const char* const* names, int n,
+                                 float k) {
   unsigned csr = o_fp_enter();
   const int W = a->out_w, H = a->out_h;
-  float U[48] = {0};
+  float U[64] = {0};
   const float ytr[4] = {1.0f, 0.0f, -1.0f, (float)H};
   put_sizes(U, table, a, 1);
   put(U, table, "gl_FbWposYTransform", ytr, 4);
   for (int k = 0; k < n; ++k) put(U, table, names[k], &a->params[k], 1);
-  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  o_varying tu = o_varying_setup(0.f * k, 1.f * k, 1.f * k, 0.f * k, W, H, a->out_fmt), tv = o_varying_setup(0.f * k, 0.f * k, 1.f * k, 1.f * k, W, H, a->out_fmt);
   for (int y = a->y0; y < a->y1; ++y)
     for (int x = 0; x < W; ++x) {
       const int lo = o_lower_tri(x, y, W, H);
@@ -241,4 +249,11 @@ void o_pass_sameboy_lcd(const o_pass_args* a) {
       o_store_pixel(a, x, y, o);
     }
   o_fp_leave(csr);
+}
+
+/* crt/shaders/crt-consumer.glsl (crt/crt-consumer.glslp; ~970 operations, 24 taps, 19 branches: blur, warp, corner, beam / scanline profiles, three
+ * mask families on gl_FragCoord, glow, noise seeded by FrameCount, vignette).  VS: TEX0 = TexCoord * 1.0001.  33 params in #pragma order. */
+void o_pass_crt_consumer(const o_pass_args* a) {
+  static const char* const names[33] = {"blurx", "blury", "warpx", "warpy", "corner", "smoothness", "scanlow", "scanhigh", "beamlow", "beamhigh", "brightboost1", "brightboost2", "Shadowmask", "masksize", "MaskDark", "MaskLight", "slotmask", "slotwidth", "double_slot", "slotms", "GAMMA_IN", "GAMMA_OUT", "glow", "Size", "sat", "contrast", "nois", "WP", "inter", "vignette", "vpower", "vstr", "alloff"};
+  run_fragcoord_list_k(a, crt_consumer_fs, crt_consumer_fs_uniforms, names, 33, 1.0001f);
 }

@@ -569,6 +569,43 @@ std::vector<KernelEntry> build() {
                    {}, rck::launch_sameboy_lcd, setupSameboyLcd, false};
     sl.texture_height_override = true;
     r.push_back(sl);
+    KernelEntry cc{"crt/shaders/crt-consumer.glsl", "crt-consumer",
+                   {{"blurx", 0.25f, -2.0f, 2.0f, 0.05f, "Convergence X"},
+                    {"blury", -0.15f, -2.0f, 2.0f, 0.05f, "Convergence Y"},
+                    {"warpx", 0.03f, 0.0f, 0.12f, 0.01f, "Curvature X"},
+                    {"warpy", 0.04f, 0.0f, 0.12f, 0.01f, "Curvature Y"},
+                    {"corner", 0.01f, 0.0f, 0.1f, 0.01f, "Corner size"},
+                    {"smoothness", 400.0f, 25.0f, 600.0f, 5.0f, "Border Smoothness"},
+                    {"scanlow", 6.0f, 1.0f, 15.0f, 1.0f, "Beam low"},
+                    {"scanhigh", 8.0f, 1.0f, 15.0f, 1.0f, "Beam high"},
+                    {"beamlow", 1.35f, 0.5f, 2.5f, 0.05f, "Scanlines dark"},
+                    {"beamhigh", 1.05f, 0.5f, 2.5f, 0.05f, "Scanlines bright"},
+                    {"brightboost1", 1.1f, 0.0f, 3.0f, 0.05f, "Bright boost dark pixels"},
+                    {"brightboost2", 1.05f, 0.0f, 3.0f, 0.05f, "Bright boost bright pixels"},
+                    {"Shadowmask", 7.0f, -1.0f, 8.0f, 1.0f, "Mask Type"},
+                    {"masksize", 1.0f, 1.0f, 2.0f, 1.0f, "Mask Size"},
+                    {"MaskDark", 0.5f, 0.0f, 2.0f, 0.1f, "Mask dark"},
+                    {"MaskLight", 1.5f, 0.0f, 2.0f, 0.1f, "Mask light"},
+                    {"slotmask", 0.0f, 0.0f, 1.0f, 0.05f, "Slot Mask Strength"},
+                    {"slotwidth", 2.0f, 1.0f, 6.0f, 0.5f, "Slot Mask Width"},
+                    {"double_slot", 1.0f, 1.0f, 2.0f, 1.0f, "Slot Mask Height: 2x1 or 4x1"},
+                    {"slotms", 1.0f, 1.0f, 2.0f, 1.0f, "Slot Mask Size"},
+                    {"GAMMA_IN", 2.5f, 0.0f, 4.0f, 0.1f, "Gamma In"},
+                    {"GAMMA_OUT", 2.2f, 0.0f, 4.0f, 0.1f, "Gamma Out"},
+                    {"glow", 0.05f, 0.0f, 0.5f, 0.01f, "Glow Strength"},
+                    {"Size", 1.0f, 0.1f, 4.0f, 0.05f, "Glow Size"},
+                    {"sat", 1.1f, 0.0f, 2.0f, 0.05f, "Saturation"},
+                    {"contrast", 1.0f, 0.0f, 2.0f, 0.05f, "Contrast, 1.0:Off"},
+                    {"nois", 0.0f, 0.0f, 32.0f, 1.0f, "Noise"},
+                    {"WP", 0.0f, -100.0f, 100.0f, 5.0f, "Color Temperature %"},
+                    {"inter", 1.0f, 0.0f, 1.0f, 1.0f, "Interlacing Toggle"},
+                    {"vignette", 1.0f, 0.0f, 1.0f, 1.0f, "Vignette On/Off"},
+                    {"vpower", 0.2f, 0.0f, 1.0f, 0.01f, "Vignette Power"},
+                    {"vstr", 40.0f, 0.0f, 50.0f, 1.0f, "Vignette strength"},
+                    {"alloff", 0.0f, 0.0f, 1.0f, 1.0f, "Switch off shader"}},
+                   {}, rck::launch_crt_consumer, setupCrtConsumer, false};
+    cc.texture_height_override = true;
+    r.push_back(cc);
     KernelEntry j{"windowed/shaders/jinc2-sharper.glsl", "jinc2-sharper", {}, {}, rck::launch_jinc2_sharper, setupJinc2Sharper, false};
     j.texture_height_override = true;
     r.push_back(j);

@@ -28,6 +28,7 @@ namespace {
 #include "kernels/gen/fakelottes_fs.inc"
 #include "kernels/gen/side_by_side_fs.inc"
 #include "kernels/gen/sameboy_lcd_fs.inc"
+#include "kernels/gen/crt_consumer_fs.inc"
 #undef RCN_TABLES_ONLY
 #pragma clang diagnostic pop
 
@@ -83,6 +84,12 @@ void setupFragCoordList(const PassGeometry& g, rcd::PassLaunch& L, const T* tabl
   for (int k = 0; k < n; ++k) put(U, table, names[k], &L.params[k], 1, nu);
 }
 }  // namespace
+void setupCrtConsumer(const PassGeometry& g, rcd::PassLaunch& L) {
+  static const char* const names[33] = {"blurx", "blury", "warpx", "warpy", "corner", "smoothness", "scanlow", "scanhigh", "beamlow", "beamhigh", "brightboost1", "brightboost2", "Shadowmask", "masksize", "MaskDark", "MaskLight", "slotmask", "slotwidth", "double_slot", "slotms", "GAMMA_IN", "GAMMA_OUT", "glow", "Size", "sat", "contrast", "nois", "WP", "inter", "vignette", "vpower", "vstr", "alloff"};
+  setupFragCoordList(g, L, crt_consumer_fs_uniforms, names, 33, kConsumerU);
+  L.plane[0] = planeU(1.0001f, g.out_w, g.out_h, g.out_fmt);   // VS: TEX0 = TexCoord * 1.0001
+  L.plane[1] = planeV(1.0001f, g.out_w, g.out_h, g.out_fmt);
+}
 void setupCrtLottes(const PassGeometry& g, rcd::PassLaunch& L) { setupFragCoordList(g, L, crt_lottes_fs_uniforms, kLottesNames, 13, kLottesU); }
 void setupFakeLottes(const PassGeometry& g, rcd::PassLaunch& L) { setupFragCoordList(g, L, fakelottes_fs_uniforms, kFakeLottesNames, 10, kFakeLottesU); }
 

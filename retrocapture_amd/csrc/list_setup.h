@@ -10,4 +10,5 @@ void setupCrtLottes(const PassGeometry& g, rcd::PassLaunch& L);
 void setupFakeLottes(const PassGeometry& g, rcd::PassLaunch& L);
 void setupSideBySide(const PassGeometry& g, rcd::PassLaunch& L);
 void setupSameboyLcd(const PassGeometry& g, rcd::PassLaunch& L);
+void setupCrtConsumer(const PassGeometry& g, rcd::PassLaunch& L);
 }  // namespace rc

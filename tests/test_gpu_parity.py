@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "crt_consumer_64x48_to_320x240": "crt-consumer",
+    "crt_consumer_params_40x30_to_233x171_f2": "crt-consumer",
     "sameboy_lcd_64x48_to_320x240": "sameboy-lcd",
     "sameboy_lcd_params_40x30_to_233x171": "sameboy-lcd",
     "side_by_side_64x48_to_320x240": "side-by-side",
