@@ -11,6 +11,7 @@
 #   stereoscopic-3d/shaders/side-by-side-simple.glsl (both stages)     -> side_by_side_{vs,fs}.inc
 #   handheld/shaders/sameboy-lcd.glsl (fragment stage)                 -> sameboy_lcd_fs.inc
 #   crt/shaders/crt-consumer.glsl (fragment stage)                     -> crt_consumer_fs.inc
+#   anti-aliasing/shaders/reverse-aa.glsl (fragment stage)             -> reverse_aa_fs.inc
 # written to oracle/gen/ for the oracle and, the same text, to retrocapture_amd/csrc/kernels/gen/ for the HIP kernels.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -51,4 +52,5 @@ listing "$S" LP_DEBUG=fs "$T/sbs.txt" && emit "$T/sbs.txt" fragment side_by_side
 listing "$S" GALLIVM_DEBUG=tgsi "$T/sbsv.txt" && emit "$T/sbsv.txt" vertex side_by_side_vs
 listing handheld/shaders/sameboy-lcd.glsl LP_DEBUG=fs "$T/sl.txt" && emit "$T/sl.txt" fragment sameboy_lcd_fs
 listing crt/shaders/crt-consumer.glsl LP_DEBUG=fs "$T/cc.txt" && emit "$T/cc.txt" fragment crt_consumer_fs
+listing anti-aliasing/shaders/reverse-aa.glsl LP_DEBUG=fs "$T/ra.txt" && emit "$T/ra.txt" fragment reverse_aa_fs
 wc -l "$ROOT"/oracle/gen/*.inc

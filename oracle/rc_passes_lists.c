@@ -46,6 +46,7 @@ static void rcn_tex(void* ctx, float u, float v, float* dst) {
 #include "gen/side_by_side_fs.inc"
 #include "gen/sameboy_lcd_fs.inc"
 #include "gen/crt_consumer_fs.inc"
+#include "gen/reverse_aa_fs.inc"
 #include "gen/image_adjustment_vs.inc"
 #include "gen/image_adjustment_fs.inc"
 #pragma GCC diagnostic pop
@@ -256,4 +257,27 @@ void o_pass_sameboy_lcd(const o_pass_args* a) {
 void o_pass_crt_consumer(const o_pass_args* a) {
   static const char* const names[33] = {"blurx", "blury", "warpx", "warpy", "corner", "smoothness", "scanlow", "scanhigh", "beamlow", "beamhigh", "brightboost1", "brightboost2", "Shadowmask", "masksize", "MaskDark", "MaskLight", "slotmask", "slotwidth", "double_slot", "slotms", "GAMMA_IN", "GAMMA_OUT", "glow", "Size", "sat", "contrast", "nois", "WP", "inter", "vignette", "vpower", "vstr", "alloff"};
   run_fragcoord_list_k(a, crt_consumer_fs, crt_consumer_fs_uniforms, names, 33, 1.0001f);
+}
+
+/* anti-aliasing/shaders/reverse-aa.glsl (anti-aliasing/reverse-aa.glslp): Christoph Feck's reverse anti-aliasing - a 3x3 neighbourhood, tilt
+ * estimates clamped by the local range, two sub-pixel corrections; ~230 operations.  VS: TEX0 = TexCoord * 1.0001.  params: REVERSEAA_SHARPNESS. */
+void o_pass_reverse_aa(const o_pass_args* a) {
+  static const char* const names[1] = {"REVERSEAA_SHARPNESS"};
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  float U[8] = {0};
+  put_sizes(U, reverse_aa_fs_uniforms, a, 1);
+  put(U, reverse_aa_fs_uniforms, names[0], &a->params[0], 1);
+  o_varying tu = o_varying_setup(0.f * 1.0001f, 1.f * 1.0001f, 1.f * 1.0001f, 0.f * 1.0001f, W, H, a->out_fmt);
+  o_varying tv = o_varying_setup(0.f * 1.0001f, 0.f * 1.0001f, 1.f * 1.0001f, 1.f * 1.0001f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      const float in[2] = {o_varying_at(&tu, x, y, lo), o_varying_at(&tv, x, y, lo)};
+      float out[4] = {0.f, 0.f, 0.f, 0.f};
+      reverse_aa_fs(U, in, out, (void*)a->in);
+      const o_vec4 o = {out[0], out[1], out[2], out[3]};
+      o_store_pixel(a, x, y, o);
+    }
+  o_fp_leave(csr);
 }

@@ -606,6 +606,9 @@ std::vector<KernelEntry> build() {
                    {}, rck::launch_crt_consumer, setupCrtConsumer, false};
     cc.texture_height_override = true;
     r.push_back(cc);
+    KernelEntry ra{"anti-aliasing/shaders/reverse-aa.glsl", "reverse-aa", {{"REVERSEAA_SHARPNESS", 2.0f, 0.0f, 10.0f, 0.01f, "ReverseAA Sharpness"}}, {}, rck::launch_reverse_aa, setupReverseAa, false};
+    ra.texture_height_override = true;
+    r.push_back(ra);
     KernelEntry j{"windowed/shaders/jinc2-sharper.glsl", "jinc2-sharper", {}, {}, rck::launch_jinc2_sharper, setupJinc2Sharper, false};
     j.texture_height_override = true;
     r.push_back(j);

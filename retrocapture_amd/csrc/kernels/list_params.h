@@ -11,3 +11,4 @@ constexpr int kFakeLottesU = 20;        // fakelottes_fs_uniforms: sizes, 10 par
 constexpr int kSbsU = 9;                // side_by_side_fs_uniforms: TextureSize, InputSize, five parameters
 constexpr int kSameboyLcdU = 5;         // sameboy_lcd_fs_uniforms: TextureSize, three parameters
 constexpr int kConsumerU = 44;          // crt_consumer_fs_uniforms: FrameCount at 0, sizes, 33 parameters, gl_FbWposYTransform at 40
+constexpr int kReverseAaU = 3;          // reverse_aa_fs_uniforms: TextureSize, REVERSEAA_SHARPNESS

@@ -72,10 +72,11 @@ struct Lists {
 #include "gen/side_by_side_fs.inc"
 #include "gen/sameboy_lcd_fs.inc"
 #include "gen/crt_consumer_fs.inc"
+#include "gen/reverse_aa_fs.inc"
 #include "gen/image_adjustment_fs.inc"
 #pragma clang diagnostic pop
 };
-enum { LIST_TVOUT, LIST_JINC2, LIST_LOTTES, LIST_FAKELOTTES, LIST_SBS, LIST_SAMEBOY_LCD, LIST_CONSUMER, LIST_IMAGE_ADJ };
+enum { LIST_TVOUT, LIST_JINC2, LIST_LOTTES, LIST_FAKELOTTES, LIST_SBS, LIST_SAMEBOY_LCD, LIST_CONSUMER, LIST_REVERSE_AA, LIST_IMAGE_ADJ };
 template <class SI, int WHICH>
 __device__ __forceinline__ void run_list(const float* U, const float* in, float* out, void* ctx) {
   if (WHICH == LIST_TVOUT) Lists<SI>::tvout_tweaks_fs(U, in, out, ctx);
@@ -85,6 +86,7 @@ __device__ __forceinline__ void run_list(const float* U, const float* in, float*
   else if (WHICH == LIST_SBS) Lists<SI>::side_by_side_fs(U, in, out, ctx);
   else if (WHICH == LIST_SAMEBOY_LCD) Lists<SI>::sameboy_lcd_fs(U, in, out, ctx);
   else if (WHICH == LIST_CONSUMER) Lists<SI>::crt_consumer_fs(U, in, out, ctx);
+  else if (WHICH == LIST_REVERSE_AA) Lists<SI>::reverse_aa_fs(U, in, out, ctx);
   else Lists<SI>::image_adjustment_fs(U, in, out, ctx);
 }
 
@@ -149,5 +151,7 @@ hipError_t launch_side_by_side(const PassLaunch& L, hipStream_t s) { return laun
 hipError_t launch_sameboy_lcd(const PassLaunch& L, hipStream_t s) { return launch_list<kSameboyLcdU, -1, LIST_SAMEBOY_LCD>(L, s); }
 // crt/shaders/crt-consumer.glsl: ~970 operations, 24 taps, 19 branches; FrameCount (noise) at dword 0 of its block
 hipError_t launch_crt_consumer(const PassLaunch& L, hipStream_t s) { return launch_list<kConsumerU, 0, LIST_CONSUMER>(L, s); }
+// anti-aliasing/shaders/reverse-aa.glsl: 3x3 neighbourhood, clamped tilt estimates, two sub-pixel corrections
+hipError_t launch_reverse_aa(const PassLaunch& L, hipStream_t s) { return launch_list<kReverseAaU, -1, LIST_REVERSE_AA>(L, s); }
 hipError_t launch_image_adjustment(const PassLaunch& L, hipStream_t s) { return launch_list<kImageAdjU, kImageAdjFrameCount, LIST_IMAGE_ADJ>(L, s); }
 }  // namespace rck

@@ -29,6 +29,7 @@ namespace {
 #include "kernels/gen/side_by_side_fs.inc"
 #include "kernels/gen/sameboy_lcd_fs.inc"
 #include "kernels/gen/crt_consumer_fs.inc"
+#include "kernels/gen/reverse_aa_fs.inc"
 #undef RCN_TABLES_ONLY
 #pragma clang diagnostic pop
 
@@ -124,6 +125,15 @@ void setupSameboyLcd(const PassGeometry& g, rcd::PassLaunch& L) {
   for (int k = 0; k < kSameboyLcdU; ++k) U[k] = 0.0f;
   putSizes(U, sameboy_lcd_fs_uniforms, g, kSameboyLcdU);
   for (int k = 0; k < 3; ++k) put(U, sameboy_lcd_fs_uniforms, names[k], &L.params[k], 1, kSameboyLcdU);
+}
+
+void setupReverseAa(const PassGeometry& g, rcd::PassLaunch& L) {
+  L.plane[0] = planeU(1.0001f, g.out_w, g.out_h, g.out_fmt);   // VS: TEX0 = TexCoord * 1.0001
+  L.plane[1] = planeV(1.0001f, g.out_w, g.out_h, g.out_fmt);
+  float* U = L.params + kListU0;
+  for (int k = 0; k < kReverseAaU; ++k) U[k] = 0.0f;
+  putSizes(U, reverse_aa_fs_uniforms, g, kReverseAaU);
+  put(U, reverse_aa_fs_uniforms, "REVERSEAA_SHARPNESS", &L.params[0], 1, kReverseAaU);
 }
 
 void setupJinc2Sharper(const PassGeometry& g, rcd::PassLaunch& L) {

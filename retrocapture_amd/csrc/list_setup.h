@@ -11,4 +11,5 @@ void setupFakeLottes(const PassGeometry& g, rcd::PassLaunch& L);
 void setupSideBySide(const PassGeometry& g, rcd::PassLaunch& L);
 void setupSameboyLcd(const PassGeometry& g, rcd::PassLaunch& L);
 void setupCrtConsumer(const PassGeometry& g, rcd::PassLaunch& L);
+void setupReverseAa(const PassGeometry& g, rcd::PassLaunch& L);
 }  // namespace rc
