@@ -12,6 +12,7 @@
 #   handheld/shaders/sameboy-lcd.glsl (fragment stage)                 -> sameboy_lcd_fs.inc
 #   crt/shaders/crt-consumer.glsl (fragment stage)                     -> crt_consumer_fs.inc
 #   anti-aliasing/shaders/reverse-aa.glsl (fragment stage)             -> reverse_aa_fs.inc
+#   anti-aliasing/shaders/advanced-aa.glsl (both stages)               -> advanced_aa_{vs,fs}.inc
 # written to oracle/gen/ for the oracle and, the same text, to retrocapture_amd/csrc/kernels/gen/ for the HIP kernels.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -53,4 +54,7 @@ listing "$S" GALLIVM_DEBUG=tgsi "$T/sbsv.txt" && emit "$T/sbsv.txt" vertex side_
 listing handheld/shaders/sameboy-lcd.glsl LP_DEBUG=fs "$T/sl.txt" && emit "$T/sl.txt" fragment sameboy_lcd_fs
 listing crt/shaders/crt-consumer.glsl LP_DEBUG=fs "$T/cc.txt" && emit "$T/cc.txt" fragment crt_consumer_fs
 listing anti-aliasing/shaders/reverse-aa.glsl LP_DEBUG=fs "$T/ra.txt" && emit "$T/ra.txt" fragment reverse_aa_fs
+A=anti-aliasing/shaders/advanced-aa.glsl
+listing "$A" LP_DEBUG=fs "$T/aa.txt" && emit "$T/aa.txt" fragment advanced_aa_fs
+listing "$A" GALLIVM_DEBUG=tgsi "$T/aav.txt" && emit "$T/aav.txt" vertex advanced_aa_vs
 wc -l "$ROOT"/oracle/gen/*.inc

@@ -150,6 +150,7 @@ void o_pass_braid_rewind(const o_pass_args* a);       /* history declared, not u
 void o_pass_response_time(const o_pass_args* a);      /* 1 param; extra[0..6] = PrevTexture, Prev1 .. Prev6 */
 void o_pass_crt_lottes(const o_pass_args* a);         /* 13 params (rc_passes_lists.c) */
 void o_pass_fakelottes(const o_pass_args* a);         /* 10 params (rc_passes_lists.c) */
+void o_pass_advanced_aa(const o_pass_args* a);        /* 2 params (rc_passes_lists.c) */
 void o_pass_reverse_aa(const o_pass_args* a);         /* 1 param (rc_passes_lists.c) */
 void o_pass_crt_consumer(const o_pass_args* a);       /* 33 params (rc_passes_lists.c) */
 void o_pass_sameboy_lcd(const o_pass_args* a);        /* 3 params (rc_passes_lists.c) */

@@ -47,6 +47,8 @@ static void rcn_tex(void* ctx, float u, float v, float* dst) {
 #include "gen/sameboy_lcd_fs.inc"
 #include "gen/crt_consumer_fs.inc"
 #include "gen/reverse_aa_fs.inc"
+#include "gen/advanced_aa_vs.inc"
+#include "gen/advanced_aa_fs.inc"
 #include "gen/image_adjustment_vs.inc"
 #include "gen/image_adjustment_fs.inc"
 #pragma GCC diagnostic pop
@@ -276,6 +278,39 @@ void o_pass_reverse_aa(const o_pass_args* a) {
       const float in[2] = {o_varying_at(&tu, x, y, lo), o_varying_at(&tv, x, y, lo)};
       float out[4] = {0.f, 0.f, 0.f, 0.f};
       reverse_aa_fs(U, in, out, (void*)a->in);
+      const o_vec4 o = {out[0], out[1], out[2], out[3]};
+      o_store_pixel(a, x, y, o);
+    }
+  o_fp_leave(csr);
+}
+
+/* anti-aliasing/shaders/advanced-aa.glsl (anti-aliasing/advanced-aa.glslp): nine taps at coordinates its vertex stage prepares (six varyings: the
+ * pixel and its neighbours at 1 / AA_RESOLUTION, or 1 / TextureSize when the parameters are 0), edge-directed blend.  Both stages are the GL's lists.
+ * params: AA_RESOLUTION_X, AA_RESOLUTION_Y. */
+void o_pass_advanced_aa(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  const int W = a->out_w, H = a->out_h;
+  float Uv[32] = {0}, Uf[4] = {0};
+  static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  put(Uv, advanced_aa_vs_uniforms, "MVPMatrix", ident, 16);
+  put_sizes(Uv, advanced_aa_vs_uniforms, a, 1);
+  put(Uv, advanced_aa_vs_uniforms, "AA_RESOLUTION_X", &a->params[0], 1);
+  put(Uv, advanced_aa_vs_uniforms, "AA_RESOLUTION_Y", &a->params[1], 1);
+  static const float pos[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}}, uv[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+  float vout[4][48];
+  for (int v = 0; v < 4; ++v) {
+    const float in[8] = {pos[v][0], pos[v][1], 0.0f, 1.0f, uv[v][0], uv[v][1], 0.0f, 1.0f};
+    memset(vout[v], 0, sizeof vout[v]);
+    advanced_aa_vs(Uv, in, vout[v], 0);
+  }
+  o_varying pl[6];
+  for (int c = 0; c < 6; ++c) pl[c] = o_varying_setup(vout[0][c], vout[1][c], vout[2][c], vout[3][c], W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int lo = o_lower_tri(x, y, W, H);
+      float in[6], out[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < 6; ++c) in[c] = o_varying_at(&pl[c], x, y, lo);
+      advanced_aa_fs(Uf, in, out, (void*)a->in);
       const o_vec4 o = {out[0], out[1], out[2], out[3]};
       o_store_pixel(a, x, y, o);
     }

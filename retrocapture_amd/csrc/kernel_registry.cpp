@@ -609,6 +609,11 @@ std::vector<KernelEntry> build() {
     KernelEntry ra{"anti-aliasing/shaders/reverse-aa.glsl", "reverse-aa", {{"REVERSEAA_SHARPNESS", 2.0f, 0.0f, 10.0f, 0.01f, "ReverseAA Sharpness"}}, {}, rck::launch_reverse_aa, setupReverseAa, false};
     ra.texture_height_override = true;
     r.push_back(ra);
+    KernelEntry aa{"anti-aliasing/shaders/advanced-aa.glsl", "advanced-aa",
+                   {{"AA_RESOLUTION_X", 0.0f, 0.0f, 1920.0f, 1.0f, "AA Input Res X"}, {"AA_RESOLUTION_Y", 0.0f, 0.0f, 1920.0f, 1.0f, "AA Input Res Y"}},
+                   {}, rck::launch_advanced_aa, setupAdvancedAa, false};
+    aa.texture_height_override = true;
+    r.push_back(aa);
     KernelEntry j{"windowed/shaders/jinc2-sharper.glsl", "jinc2-sharper", {}, {}, rck::launch_jinc2_sharper, setupJinc2Sharper, false};
     j.texture_height_override = true;
     r.push_back(j);

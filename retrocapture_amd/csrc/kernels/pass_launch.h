@@ -49,6 +49,7 @@ hipError_t launch_side_by_side(const PassLaunch& L, hipStream_t s);
 hipError_t launch_sameboy_lcd(const PassLaunch& L, hipStream_t s);
 hipError_t launch_crt_consumer(const PassLaunch& L, hipStream_t s);
 hipError_t launch_reverse_aa(const PassLaunch& L, hipStream_t s);
+hipError_t launch_advanced_aa(const PassLaunch& L, hipStream_t s);
 hipError_t launch_lcd_grid_v2(const PassLaunch& L, hipStream_t s);
 hipError_t launch_lcd_grid(const PassLaunch& L, hipStream_t s);     // pass_lcd_grid.hip
 hipError_t launch_gbc_gambatte_color(const PassLaunch& L, hipStream_t s);

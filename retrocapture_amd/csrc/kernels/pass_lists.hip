@@ -73,10 +73,11 @@ struct Lists {
 #include "gen/sameboy_lcd_fs.inc"
 #include "gen/crt_consumer_fs.inc"
 #include "gen/reverse_aa_fs.inc"
+#include "gen/advanced_aa_fs.inc"
 #include "gen/image_adjustment_fs.inc"
 #pragma clang diagnostic pop
 };
-enum { LIST_TVOUT, LIST_JINC2, LIST_LOTTES, LIST_FAKELOTTES, LIST_SBS, LIST_SAMEBOY_LCD, LIST_CONSUMER, LIST_REVERSE_AA, LIST_IMAGE_ADJ };
+enum { LIST_TVOUT, LIST_JINC2, LIST_LOTTES, LIST_FAKELOTTES, LIST_SBS, LIST_SAMEBOY_LCD, LIST_CONSUMER, LIST_REVERSE_AA, LIST_ADVANCED_AA, LIST_IMAGE_ADJ };
 template <class SI, int WHICH>
 __device__ __forceinline__ void run_list(const float* U, const float* in, float* out, void* ctx) {
   if (WHICH == LIST_TVOUT) Lists<SI>::tvout_tweaks_fs(U, in, out, ctx);
@@ -87,6 +88,7 @@ __device__ __forceinline__ void run_list(const float* U, const float* in, float*
   else if (WHICH == LIST_SAMEBOY_LCD) Lists<SI>::sameboy_lcd_fs(U, in, out, ctx);
   else if (WHICH == LIST_CONSUMER) Lists<SI>::crt_consumer_fs(U, in, out, ctx);
   else if (WHICH == LIST_REVERSE_AA) Lists<SI>::reverse_aa_fs(U, in, out, ctx);
+  else if (WHICH == LIST_ADVANCED_AA) Lists<SI>::advanced_aa_fs(U, in, out, ctx);
   else Lists<SI>::image_adjustment_fs(U, in, out, ctx);
 }
 
@@ -104,6 +106,10 @@ __global__ void __launch_bounds__(256) k_list_pass(const PassLaunch L) {
   float in[36];
   in[0] = vary(L.plane[0], x, y, lo);
   in[1] = vary(L.plane[1], x, y, lo);
+  if (WHICH == LIST_ADVANCED_AA) {   // six varyings (the neighbour coordinates its vertex stage prepares): planes 2..5 as well
+#pragma unroll
+    for (int k = 2; k < 6; ++k) in[k] = vary(L.plane[k], x, y, lo);
+  }
   in[32] = (float)x + 0.5f;
   in[33] = (float)y + 0.5f;
   in[34] = 0.5f;
@@ -153,5 +159,7 @@ hipError_t launch_sameboy_lcd(const PassLaunch& L, hipStream_t s) { return launc
 hipError_t launch_crt_consumer(const PassLaunch& L, hipStream_t s) { return launch_list<kConsumerU, 0, LIST_CONSUMER>(L, s); }
 // anti-aliasing/shaders/reverse-aa.glsl: 3x3 neighbourhood, clamped tilt estimates, two sub-pixel corrections
 hipError_t launch_reverse_aa(const PassLaunch& L, hipStream_t s) { return launch_list<kReverseAaU, -1, LIST_REVERSE_AA>(L, s); }
+// anti-aliasing/shaders/advanced-aa.glsl: nine taps at vertex-stage coordinates, edge-directed blend; no uniform block
+hipError_t launch_advanced_aa(const PassLaunch& L, hipStream_t s) { return launch_list<1, -1, LIST_ADVANCED_AA>(L, s); }
 hipError_t launch_image_adjustment(const PassLaunch& L, hipStream_t s) { return launch_list<kImageAdjU, kImageAdjFrameCount, LIST_IMAGE_ADJ>(L, s); }
 }  // namespace rck

@@ -14,12 +14,14 @@ namespace {
 #define RCN_FN static
 #define RCN_BITS(u) rcd::bits2f(u)
 #define RCN_DIV(a, b) ((a) / (b))
+#define RCN_RCP(x) (1.0f / (x))
 #define RCN_TEX(ctx, unit, u, v, dst) ((void)0)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wunused-but-set-variable"
 #pragma clang diagnostic ignored "-Wunused-variable"
 #include "kernels/gen/image_adjustment_vs.inc"
 #include "kernels/gen/side_by_side_vs.inc"
+#include "kernels/gen/advanced_aa_vs.inc"
 #define RCN_TABLES_ONLY
 #include "kernels/gen/image_adjustment_fs.inc"
 #include "kernels/gen/tvout_tweaks_fs.inc"
@@ -125,6 +127,23 @@ void setupSameboyLcd(const PassGeometry& g, rcd::PassLaunch& L) {
   for (int k = 0; k < kSameboyLcdU; ++k) U[k] = 0.0f;
   putSizes(U, sameboy_lcd_fs_uniforms, g, kSameboyLcdU);
   for (int k = 0; k < 3; ++k) put(U, sameboy_lcd_fs_uniforms, names[k], &L.params[k], 1, kSameboyLcdU);
+}
+
+// advanced-aa.glsl: the vertex stage (the pixel's and its neighbours' coordinates, six varyings) at the quad's vertices
+void setupAdvancedAa(const PassGeometry& g, rcd::PassLaunch& L) {
+  float Uv[32] = {};
+  static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  put(Uv, advanced_aa_vs_uniforms, "MVPMatrix", ident, 16, 32);
+  putSizes(Uv, advanced_aa_vs_uniforms, g, 32);
+  put(Uv, advanced_aa_vs_uniforms, "AA_RESOLUTION_X", &L.params[0], 1, 32);
+  put(Uv, advanced_aa_vs_uniforms, "AA_RESOLUTION_Y", &L.params[1], 1, 32);
+  static const float pos[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}}, uv[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+  float out[4][48] = {};
+  for (int v = 0; v < 4; ++v) {
+    const float in[8] = {pos[v][0], pos[v][1], 0.0f, 1.0f, uv[v][0], uv[v][1], 0.0f, 1.0f};
+    advanced_aa_vs(Uv, in, out[v], nullptr);
+  }
+  for (int c = 0; c < 6; ++c) L.plane[c] = makePlane(out[0][c], out[1][c], out[2][c], out[3][c], g.out_w, g.out_h, g.out_fmt);
 }
 
 void setupReverseAa(const PassGeometry& g, rcd::PassLaunch& L) {

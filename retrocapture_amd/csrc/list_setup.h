@@ -12,4 +12,5 @@ void setupSideBySide(const PassGeometry& g, rcd::PassLaunch& L);
 void setupSameboyLcd(const PassGeometry& g, rcd::PassLaunch& L);
 void setupCrtConsumer(const PassGeometry& g, rcd::PassLaunch& L);
 void setupReverseAa(const PassGeometry& g, rcd::PassLaunch& L);
+void setupAdvancedAa(const PassGeometry& g, rcd::PassLaunch& L);
 }  // namespace rc

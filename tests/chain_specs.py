@@ -405,6 +405,7 @@ PRESETS["sameboy-lcd"] = ("handheld/sameboy-lcd.glslp", 'shaders = 1\n\nshader0 
 PRESETS["sameboy-lcd-gbc-color-motionblur"] = ("handheld/sameboy-lcd-gbc-color-motionblur.glslp", 'shaders = 3\n\nshader0 = ../motionblur/shaders/response-time.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n\nshader1 = shaders/sameboy-lcd.glsl\nfilter_linear1 = false\nscale_type1 = viewport\nscale1 = "1.0"\n\nshader2 = shaders/color/gbc-color.glsl\nfilter_linear2 = false\nscale_type2 = viewport\n')
 PRESETS["crt-consumer"] = ("crt/crt-consumer.glslp", 'shaders = "1"\nshader0 = "shaders/crt-consumer.glsl"\nfilter_linear0 = "true"\nwrap_mode0 = "clamp_to_border"\nmipmap_input0 = "false"\nalias0 = ""\nfloat_framebuffer0 = "false"\nsrgb_framebuffer0 = "false"\n\n')
 PRESETS["reverse-aa"] = ("anti-aliasing/reverse-aa.glslp", 'shaders = 1\n\nshader0 = shaders/reverse-aa.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 2.0\n')
+PRESETS["advanced-aa"] = ("anti-aliasing/advanced-aa.glslp", 'shaders = 2\n\nshader0 = shaders/advanced-aa.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale_x0 = 2.0\nscale_y0 = 2.0\n\nshader1 = ../stock.glsl\nfilter_linear1 = true\n')
 PRESETS["crt-lottes"] = ("crt/crt-lottes.glslp", 'shaders = 1\n\nshader0 = shaders/crt-lottes.glsl\nfilter_linear0 = false\n')
 PRESETS["fakelottes"] = ("crt/fakelottes.glslp", 'shaders = 1\n\nshader0 = shaders/fakelottes.glsl\nfilter_linear0 = true\n')
 PRESETS["jinc2-sharper"] = ("windowed/jinc2-sharper.glslp", 'shaders = 1\n\nshader0 = shaders/jinc2-sharper.glsl\nfilter_linear0 = false\n')
@@ -716,6 +717,7 @@ SHADERS = {
     "handheld/shaders/sameboy-lcd.glsl": {"oracle": "sameboy_lcd", "samplers": [], "params": [('COLOR_LOW', 0.800000011920929), ('COLOR_HIGH', 1.0), ('SCANLINE_DEPTH', 0.10000000149011612)]},
     "crt/shaders/crt-consumer.glsl": {"oracle": "crt_consumer", "samplers": [], "params": [('blurx', 0.25), ('blury', -0.15000000596046448), ('warpx', 0.029999999329447746), ('warpy', 0.03999999910593033), ('corner', 0.009999999776482582), ('smoothness', 400.0), ('scanlow', 6.0), ('scanhigh', 8.0), ('beamlow', 1.350000023841858), ('beamhigh', 1.0499999523162842), ('brightboost1', 1.100000023841858), ('brightboost2', 1.0499999523162842), ('Shadowmask', 7.0), ('masksize', 1.0), ('MaskDark', 0.5), ('MaskLight', 1.5), ('slotmask', 0.0), ('slotwidth', 2.0), ('double_slot', 1.0), ('slotms', 1.0), ('GAMMA_IN', 2.5), ('GAMMA_OUT', 2.200000047683716), ('glow', 0.05000000074505806), ('Size', 1.0), ('sat', 1.100000023841858), ('contrast', 1.0), ('nois', 0.0), ('WP', 0.0), ('inter', 1.0), ('vignette', 1.0), ('vpower', 0.20000000298023224), ('vstr', 40.0), ('alloff', 0.0)]},
     "anti-aliasing/shaders/reverse-aa.glsl": {"oracle": "reverse_aa", "samplers": [], "params": [('REVERSEAA_SHARPNESS', 2.0)]},
+    "anti-aliasing/shaders/advanced-aa.glsl": {"oracle": "advanced_aa", "samplers": [], "params": [("AA_RESOLUTION_X", 0.0), ("AA_RESOLUTION_Y", 0.0)]},
     "crt/shaders/crt-lottes.glsl": {"oracle": "crt_lottes", "samplers": [], "params": [('hardScan', -8.0), ('hardPix', -3.0), ('warpX', 0.03099999949336052), ('warpY', 0.04100000113248825), ('maskDark', 0.5), ('maskLight', 1.5), ('scaleInLinearGamma', 1.0), ('shadowMask', 3.0), ('brightBoost', 1.0), ('hardBloomPix', -1.5), ('hardBloomScan', -2.0), ('bloomAmount', 0.15000000596046448), ('shape', 2.0)]},
     "crt/shaders/fakelottes.glsl": {"oracle": "fakelottes", "samplers": [], "params": [('shadowMask', 1.0), ('SCANLINE_SINE_COMP_B', 0.4000000059604645), ('warpX', 0.03099999949336052), ('warpY', 0.04100000113248825), ('maskDark', 0.5), ('maskLight', 1.5), ('crt_gamma', 2.5), ('monitor_gamma', 2.200000047683716), ('SCANLINE_SINE_COMP_A', 0.0), ('SCANLINE_BASE_BRIGHTNESS', 0.949999988079071)]},
     "windowed/shaders/jinc2-sharper.glsl": {"oracle": "jinc2_sharper", "samplers": [], "params": []},

@@ -532,6 +532,13 @@ def case_reverse_aa():
     run_case("f32_reverse_aa_48x36_to_200x150", A, mixed(48, 36, 282), 200, 150, f32=True)
 
 
+def case_advanced_aa():
+    A = GLSL + "/anti-aliasing/advanced-aa.glslp"
+    run_case("advanced_aa_64x48_to_320x240", A, mixed(64, 48, 290), 320, 240)
+    run_case("advanced_aa_params_40x30_to_233x171", A, noise(40, 30, 291), 233, 171, params=[("AA_RESOLUTION_X", 64.0), ("AA_RESOLUTION_Y", 48.0)])
+    run_case("f32_advanced_aa_48x36_to_200x150", A, mixed(48, 36, 292), 200, 150, f32=True)
+
+
 def case_lottes():
     L, F = GLSL + "/crt/crt-lottes.glslp", GLSL + "/crt/fakelottes.glslp"
     run_case("crt_lottes_64x48_to_320x240", L, mixed(64, 48, 230), 320, 240)
@@ -924,7 +931,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"reverse_aa": case_reverse_aa, "crt_consumer": case_crt_consumer, "sameboy_lcd": case_sameboy_lcd, "side_by_side": case_side_by_side, "sameboy": case_sameboy, "lottes": case_lottes, "jinc2": case_jinc2, "interlacing": case_interlacing, "tvout": case_tvout, "ntsc_gauss": case_ntsc_gauss, "crt_potato": case_crt_potato, "gb_palette": case_gb_palette, "reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"advanced_aa": case_advanced_aa, "reverse_aa": case_reverse_aa, "crt_consumer": case_crt_consumer, "sameboy_lcd": case_sameboy_lcd, "side_by_side": case_side_by_side, "sameboy": case_sameboy, "lottes": case_lottes, "jinc2": case_jinc2, "interlacing": case_interlacing, "tvout": case_tvout, "ntsc_gauss": case_ntsc_gauss, "crt_potato": case_crt_potato, "gb_palette": case_gb_palette, "reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 GOLDEN_CASES = {
+    "advanced_aa_64x48_to_320x240": "advanced-aa",
+    "advanced_aa_params_40x30_to_233x171": "advanced-aa",
     "reverse_aa_64x48_to_320x240": "reverse-aa",
     "reverse_aa_params_40x30_to_233x171": "reverse-aa",
     "crt_consumer_64x48_to_320x240": "crt-consumer",

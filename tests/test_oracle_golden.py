@@ -68,6 +68,8 @@ CASES = {
     "side_by_side_64x48_to_320x240": "side-by-side",
     "sbs_warp_mobile_64x36_to_320x180": "sbs-warp-mobile-16x9",
     "side_by_side_bare_params_40x30_to_233x171": "side-by-side-bare",
+    "advanced_aa_64x48_to_320x240": "advanced-aa",
+    "advanced_aa_params_40x30_to_233x171": "advanced-aa",
     "reverse_aa_64x48_to_320x240": "reverse-aa",
     "reverse_aa_params_40x30_to_233x171": "reverse-aa",
     "crt_consumer_64x48_to_320x240": "crt-consumer",
@@ -347,6 +349,7 @@ FLOAT_CASES = {
     "f32_imgborder_sgb_bare_params_40x30_to_233x171": ("imgborder-sgb-bare", {}),
     "f32_sameboy_lcd_48x36_to_200x150": ("sameboy-lcd", {}),
     "f32_side_by_side_bare_params_48x36_to_200x150": ("side-by-side-bare", {}),
+    "f32_advanced_aa_48x36_to_200x150": ("advanced-aa", {}),
     "f32_reverse_aa_48x36_to_200x150": ("reverse-aa", {}),
     "f32_crt_consumer_48x36_to_200x150": ("crt-consumer", {}),
     "f32_crt_lottes_48x36_to_200x150": ("crt-lottes", {}),
