@@ -263,6 +263,10 @@ int rc_selftest_fastmath(int device, uint64_t mismatches[3]);
  * For tests: both must equal the oracle's byte for every float. */
 int rc_selftest_srgb8_host(const float* src, uint8_t* dst, size_t n);
 int rc_selftest_srgb8_device(int device, const float* d_src, uint8_t* d_dst, size_t n, void* stream);
+/* The same through the second form of the table (form = 2: one entry per run from the first float that stores a non-zero
+ * byte, the linear segment included; the strip kernels' encode - clamp, one LDS read, one add); form = 1 is the above. */
+int rc_selftest_srgb8_host_form(const float* src, uint8_t* dst, size_t n, int form);
+int rc_selftest_srgb8_device_form(int device, const float* d_src, uint8_t* d_dst, size_t n, void* stream, int form);
 /* crt-royale's scanline pass (crt-royale-scanlines-vertical-interlacing.glsl) runs, at 1:1 geometry, from an
  * expansion table of the beam function around its possible colours with a certified remainder bound
  * (csrc/kernels/pass_royale_scan.hip).  This returns the host-built part of that table for sub-pixel offset

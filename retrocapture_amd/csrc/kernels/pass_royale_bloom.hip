@@ -202,24 +202,30 @@ void buildBvTables(const PassLaunch& L, hipStream_t s, BvTables* T) {
 }
 
 // ----------------------------------------------------------------- P10, strip form ------
-// One wave renders 64 columns x kBhRows rows.  The nine blur taps of a pixel read a row of the input texture
-// (pass 9's sRGB8 target) through a LINEAR sampler at horizontal offsets of up to 7.x texels: the wave decodes each
-// source row ONCE into a segment of floats in LDS (its 64 columns + 10 either side, indices clamped like the
-// sampler clamps them) and the taps read decoded neighbours from there.  Per tap a thread holds (first texel, weight)
-// of its column - for both triangles - in registers (k_bloomh_geometry).  A row whose vertical weight is exactly 0
-// (the usual case at 1:1) filters one source row, any other row the pair the sampler would fetch.
+// One wave renders 64 columns x kBhRows rows, TWO target rows per lane and step, so that every float operation of the
+// filter runs as a packed v_pk_{fma,mul,add}_f32 over the row pair (the same IEEE operation per component).
+//
+// The nine blur taps of a pixel are LINEAR taps of one row (or row pair) of pass 9's sRGB8 target at horizontal offsets of
+// up to 7.x texels: lerp(wx, T[j], T[j+1]) = fma(wx, T[j+1] - T[j], T[j]).  The difference D[j] = T[j+1] - T[j] does not
+// depend on the tap, so it is formed ONCE per staged texel (the neighbour's texel arrives by a DPP wave shift folded into
+// the subtraction) and a tap is one fma.  Per step the wave stages, for its 64 columns + 10 either side (clamped like
+// the sampler clamps them), per column and channel the quad {T(lo row), T(hi row), D(lo row), D(hi row)} of the row pair's
+// FIRST source rows ("top" slot) and, if either row has a vertical weight, of their SECOND source rows ("bottom" slot): one
+// ds_read_b128 per tap, channel and slot delivers both rows' operands in adjacent registers.  Column quantities (tap
+// offset as an LDS address, weight) sit in registers per strip, row quantities are wave-uniform scalars, global
+// accesses are buffer loads / stores with the row base in an SGPR (no per-lane 64-bit address arithmetic).
+// At 1:1 a target row's first source row is y or y - 1 (weight 0 / a few 1e-5 / 1 minus that, irregularly from row to row:
+// k_bloomh_geometry), so the wave keeps a rolling window of four decoded source rows y - 1 .. y + 2 in registers and two new
+// rows enter per step.  A strip the quad's diagonal crosses is rendered once per triangle, each pixel stored by the
+// pass of its own triangle.
 constexpr int kBhRows = 16;
 constexpr int kBhWaves = 12;
 constexpr int kBhSeg = 84;      // staged columns: 10 + 64 + 10
 constexpr int kBhSegLeft = 10;
-// A staged row holds, per column j, the PAIR of texels (j, j + 1) every horizontal lerp needs: red and green
-// interleaved {R[j], R[j+1], G[j], G[j+1]} (one ds_read_b128, 4 LDS cycles) and blue {B[j], B[j+1]} (one ds_read_b64,
-// 2 cycles) - a float4 per texel would be read as two ds_read_b96 at 8 cycles each.  The staging lane of column j gets
-// column j + 1's decoded texel from the next lane (ds_bpermute) and writes the whole pair entry with 16- and 8-byte stores.
-// Twelve waves share one workgroup (one copy of the 35 KB sRGB tables + 12 rings = 108 KB of LDS, one workgroup per CU).
-constexpr int kBhRowRG = kBhSeg * 16;             // bytes: the {R, R', G, G'} plane of a staged row
-constexpr int kBhRowBytes = kBhSeg * 24;          // ... followed by the {B, B'} plane
-constexpr int kBhRingDwords = 3 * kBhRowBytes / 4;   // per wave: three staged rows
+constexpr int kBhColBytes = 48;                       // three channels x {T lo, T hi, D lo, D hi}
+constexpr int kBhSlotBytes = kBhSeg * kBhColBytes;    // 4032
+constexpr int kBhLdsTables = (256 + (int)kSrgb2Runs + 3) & ~3;   // dwords: decode table, second-form encode table
+constexpr int kBhWaveDwords = 2 * kBhSlotBytes / 4;   // per wave: top and bottom slot
 enum { BH_DX = 0, BH_WX = 9, BH_IDIM_X = 18, BH_BRIGHT_X = 19, BH_HAL_X0 = 20, BH_HAL_W = 21, BH_COL_FIELDS = 22 };
 enum { BH_Y0 = 0, BH_WY = 1, BH_IDIM_Y = 2, BH_BRIGHT_Y = 3, BH_HAL_Y0 = 4, BH_HAL_WY = 5, BH_ROW_FIELDS = 8 };
 
@@ -250,6 +256,7 @@ __global__ void __launch_bounds__(256) k_bloomh_geometry(const PassLaunch L, uin
       for (int q = 0; q < 9; ++q) {
         const LinTap t = lin_tap(us[q], L.in.w);
         const int d = t.i0 - i;
+        // staged column of the tap's first texel: lane + kBhSegLeft + d in [0, kBhSeg - 2] (its partner is the next one)
         if (d < -kBhSegLeft || d + 1 > kBhSeg - kBhSegLeft - 64) why |= 1u;
         cols[((BH_DX + q) * 2 + side) * W + i] = (uint32_t)d;
         cols[((BH_WX + q) * 2 + side) * W + i] = f2bits(t.w);
@@ -267,7 +274,7 @@ __global__ void __launch_bounds__(256) k_bloomh_geometry(const PassLaunch L, uin
       uint32_t* r = rows + ((size_t)i * 2 + side) * BH_ROW_FIELDS;
       const float v = vary(L.plane[1], 0, i, lo);
       const LinTap t = lin_tap(v - k[0] * 0.0f, L.in.h);   // every tap: v -+ k * 0 = v
-      // the strip keeps three consecutive source rows staged: the pair must lie within one row of the target row
+      // the strip's window holds source rows y - 1 .. y + 2 of a target row pair (y, y + 1): the pair must start at y - 1 or y
       if (t.i0 < i - 1 || t.i0 > i) why |= 2u;
       r[BH_Y0] = (uint32_t)t.i0;
       r[BH_WY] = f2bits(t.w);
@@ -282,279 +289,298 @@ __global__ void __launch_bounds__(256) k_bloomh_geometry(const PassLaunch L, uin
   if (why) atomicOr(bad, why);
 }
 
-struct BhCol {   // one triangle's column quantities of a thread
-  uint32_t off[9];   // byte offset of tap q's first texel inside a staged row
-  float wx[9];
-  int idim_x, bright_x, hal_x0;
-  float hal_w;
-};
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 struct BhRow {
   int y0;
   float wy;
   int idim_y, bright_y, hal_y0;
   float hal_wy;
 };
-
-__device__ __forceinline__ float3 f3(float4 v) { return make_float3(v.x, v.y, v.z); }
-__device__ __forceinline__ float3 lerp3(float w, float3 a, float3 b) {
-  return make_float3(fma_(w, b.x - a.x, a.x), fma_(w, b.y - a.y, a.y), fma_(w, b.z - a.z, a.z));
-}
-__device__ __forceinline__ float3 dec3(uint32_t t, const SrgbLds& l) {
-  return make_float3(l.dec[t & 255u], l.dec[(t >> 8) & 255u], l.dec[(t >> 16) & 255u]);
-}
-
-// the pair (texel j, texel j + 1) of staged column j of a ring row
-__device__ __forceinline__ void ring_store(uint8_t* row, int j, float r, float g, float b, float r1, float g1, float b1) {
-  *reinterpret_cast<float4*>(row + j * 16) = make_float4(r, r1, g, g1);
-  *reinterpret_cast<float2*>(row + kBhRowRG + j * 8) = make_float2(b, b1);
-}
-// value of the next lane (lane 63 gets lane 0's): a cross-lane read through the LDS crossbar, no memory access
-__device__ __forceinline__ float next_lane(float v, int lane) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, __builtin_bit_cast(int, v)));
-}
-// one target pixel; ring = this wave's three staged rows (row r in slot r % 3), `TWO`: the vertical weight is not 0
-// HALC: the two horizontally filtered halation rows of the pixel's row pair are handed over (hal_rows[0..2], [3..5])
-// PRE: the texels of the two NEAREST taps were fetched ahead (pre_idim, pre_bright)
-template <class SO, bool TWO, bool HALC, bool PRE = false>
-__device__ __forceinline__ void bloomh_pixel(const PassLaunch& L, const SrgbLds& lds, const uint8_t* ring, const BhCol& c, const BhRow& r,
-                                             int x, int y, int z, const float* hal_rows, uint32_t pre_idim = 0u, uint32_t pre_bright = 0u) {
-  const float* P = L.params;
-  const int Hin = L.in.h;
-  const uint8_t* rowA = ring + (uint32_t)(clampi(r.y0, 0, Hin - 1) % 3) * (uint32_t)kBhRowBytes;
-  const uint8_t* rowB = ring + (uint32_t)(clampi(r.y0 + 1, 0, Hin - 1) % 3) * (uint32_t)kBhRowBytes;
-  auto pair_lerp = [&](const uint8_t* row, int q) -> float3 {   // c.off[q]: byte offset of the pair in the blue plane (8 B per column)
-    const float4 rg = *reinterpret_cast<const float4*>(row + 2u * c.off[q]);
-    const float2 bb = *reinterpret_cast<const float2*>(row + kBhRowRG + c.off[q]);
-    return lerp3(c.wx[q], make_float3(rg.x, rg.z, bb.x), make_float3(rg.y, rg.w, bb.y));
-  };
-  auto tap = [&](int q) -> float3 {
-    float3 top = pair_lerp(rowA, q);
-    if (TWO) top = lerp3(r.wy, top, pair_lerp(rowB, q));
-    return top;
-  };
-  // tex2Dblur17fast in the GL's evaluation order (see blur17 above)
-  const float w[4] = {P[RPG_W78], P[RPG_W56], P[RPG_W34], P[RPG_W12]};
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const float3 s = tap(q);
-    sx += w[q] * s.x; sy += w[q] * s.y; sz += w[q] * s.z;
-  }
-  {
-    const float3 d = tap(3), s = tap(4);
-    sx += 1.0f * s.x; sy += 1.0f * s.y; sz += 1.0f * s.z;
-    sx += w[3] * d.x; sy += w[3] * d.y; sz += w[3] * d.z;
-  }
-#pragma unroll
-  for (int q = 3; q >= 0; --q) {
-    const float3 s = tap(8 - q);
-    sx += w[q] * s.x; sy += w[q] * s.y; sz += w[q] * s.z;
-  }
-  const float si = P[RPG_SUM_INV];
-  const float bl[3] = {sx * si, sy * si, sz * si};
-  // the three single taps: MASKED_SCANLINES and BRIGHTPASS (NEAREST), HALATION_BLUR (LINEAR, 320x240)
-  const uint32_t* i0 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[0], z));
-  const uint32_t* i1 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[1], z));
-  const uint32_t* i2 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[2], z));
-  const float3 idim = dec3(PRE ? pre_idim : i0[r.idim_y * L.extra[0].w + c.idim_x], lds);
-  const float3 bright = dec3(PRE ? pre_bright : i1[r.bright_y * L.extra[1].w + c.bright_x], lds);
-  float3 hal;
-  if (HALC) {
-    hal = lerp3(r.hal_wy, make_float3(hal_rows[0], hal_rows[1], hal_rows[2]), make_float3(hal_rows[3], hal_rows[4], hal_rows[5]));
-  } else {
-    const int hw = L.extra[2].w, hh = L.extra[2].h;
-    const int hx0 = clampi(c.hal_x0, 0, hw - 1), hx1 = clampi(c.hal_x0 + 1, 0, hw - 1);
-    const int hy0 = clampi(r.hal_y0, 0, hh - 1), hy1 = clampi(r.hal_y0 + 1, 0, hh - 1);
-    const float3 h00 = dec3(i2[hy0 * hw + hx0], lds), h10 = dec3(i2[hy0 * hw + hx1], lds);
-    const float3 h01 = dec3(i2[hy1 * hw + hx0], lds), h11 = dec3(i2[hy1 * hw + hx1], lds);
-    hal = lerp3(r.hal_wy, lerp3(c.hal_w, h00, h10), lerp3(c.hal_w, h01, h11));
-  }
-  const float mask_amplify = P[RPG_MASK_AMPLIFY];
-  const float i3[3] = {idim.x, idim.y, idim.z}, b3[3] = {bright.x, bright.y, bright.z}, h3[3] = {hal.x, hal.y, hal.z};
-  float out[3];
-#pragma unroll
-  for (int ch = 0; ch < 3; ++ch) {
-    const float dimpass = i3[ch] - b3[ch];
-    out[ch] = (dimpass + bl[ch]) * ((mask_amplify * 2.0f) * (1.0f - 0.075f)) + h3[ch] * 0.075f;   // as k_royale_bloom_h
-  }
-  SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], 1.0f), &lds);
-}
-
-__device__ __forceinline__ BhRow load_bh_row(const uint32_t* rows, int y, int side) {
+__device__ __forceinline__ BhRow load_bh_row(const uint32_t* __restrict__ rows, int y, int side) {
   const uint32_t* r = rows + ((size_t)y * 2 + side) * BH_ROW_FIELDS;
   return BhRow{(int)r[BH_Y0], bits2f(r[BH_WY]), (int)r[BH_IDIM_Y], (int)r[BH_BRIGHT_Y], (int)r[BH_HAL_Y0], bits2f(r[BH_HAL_WY])};
 }
 
-__device__ __forceinline__ BhCol load_bh_col(const uint32_t* cols, int W, int xc, int xw, int side) {
-  BhCol c;
-#pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    c.off[q] = (uint32_t)((int)cols[((BH_DX + q) * 2 + side) * W + xc] + (xc - xw) + kBhSegLeft) * 8u;
-    c.wx[q] = bits2f(cols[((BH_WX + q) * 2 + side) * W + xc]);
-  }
-  c.idim_x = (int)cols[(BH_IDIM_X * 2 + side) * W + xc];
-  c.bright_x = (int)cols[(BH_BRIGHT_X * 2 + side) * W + xc];
-  c.hal_x0 = (int)cols[(BH_HAL_X0 * 2 + side) * W + xc];
-  c.hal_w = bits2f(cols[(BH_HAL_W * 2 + side) * W + xc]);
-  return c;
+// One decoded source row as a lane holds it: the texel of its main staged column (lane) and of its extra one (63 + lane,
+// lanes 0..20) per channel, and the difference to the next staged column's texel.
+struct BhDec {
+  float t0[3], d0[3], t1[3], d1[3];
+};
+// value of the next lane (lane 63: 0); the compiler folds the move into the subtraction that consumes it (v_sub_f32_dpp)
+__device__ __forceinline__ float next_lane_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
 }
-
-// One strip whose pixels all lie in one triangle (SIDE 0 lower, 1 upper: all but the few strips the quad's diagonal
-// crosses): one set of column quantities in registers, row quantities wave-uniform.  The loop is software-pipelined:
-// the row quantities, the texels of the next source row to stage and the texels of the two NEAREST taps of the
-// next target row are fetched one iteration ahead, so that their latency hides behind the current row's arithmetic.
-template <class SO, int SIDE>
-__device__ __forceinline__ void bloomh_strip_side(const PassLaunch& L, const SrgbLds& lds, uint8_t* ring, const uint32_t* __restrict__ cols,
-                                                  const uint32_t* __restrict__ rows, int z, int xw, int ys, int lane) {
-  const int W = L.out_w, H = L.out_h, Win = L.in.w, Hin = L.in.h;
-  const int x = xw + lane;
-  const bool live = x < W;
-  const int xc = live ? x : W - 1;
-  const BhCol c0 = load_bh_col(cols, W, xc, xw, SIDE);
-  const uint32_t* img = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
-  const uint32_t* i0 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[0], z));
-  const uint32_t* i1 = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[1], z));
-  const uint32_t* himg = reinterpret_cast<const uint32_t*>(frame_ptr(L.extra[2], z));
-  // the staged segment: columns xw - 10 .. xw + 73 (clamped like the sampler clamps them); lane l fetches column
-  // l and, for l < 20, column 64 + l
-  const int sx0 = clampi(xw - kBhSegLeft + lane, 0, Win - 1), sx1 = clampi(xw - kBhSegLeft + 64 + lane, 0, Win - 1);
-  const bool second = lane < kBhSeg - 64;
-  auto fetch_row = [&](int r, uint32_t* t0, uint32_t* t1) {
-    *t0 = img[r * Win + sx0];
-    *t1 = second ? img[r * Win + sx1] : 0u;
-  };
-  auto store_row = [&](int r, uint32_t t0, uint32_t t1) {   // row r lives in ring slot r % 3
-    uint8_t* slot = ring + (r % 3) * kBhRowBytes;
-    const float a0 = lds.dec[t0 & 255u], a1 = lds.dec[(t0 >> 8) & 255u], a2 = lds.dec[(t0 >> 16) & 255u];
-    const float b0 = lds.dec[t1 & 255u], b1 = lds.dec[(t1 >> 8) & 255u], b2 = lds.dec[(t1 >> 16) & 255u];   // lanes >= 20: unused
-    // the right-hand partner of column `lane` is the next lane's texel, of column 63 it is column 64 (lane 0's second texel)
-    float n0 = next_lane(a0, lane), n1 = next_lane(a1, lane), n2 = next_lane(a2, lane);
-    const float m0 = next_lane(b0, lane), m1 = next_lane(b1, lane), m2 = next_lane(b2, lane);
-    if (lane == 63) {
-      n0 = m0;   // lane 63's next_lane(b.) is lane 0's b.: the texel of column 64
-      n1 = m1;
-      n2 = m2;
-    }
-    ring_store(slot, lane, a0, a1, a2, n0, n1, n2);
-    if (second) ring_store(slot, 64 + lane, b0, b1, b2, m0, m1, m2);   // (column 83's partner is never read)
-  };
-  auto hal_hrow = [&](int r, float* h) {
-    const int hw = L.extra[2].w;
-    const uint32_t* p = himg + clampi(r, 0, L.extra[2].h - 1) * hw;
-    const uint32_t ta = p[clampi(c0.hal_x0, 0, hw - 1)], tb = p[clampi(c0.hal_x0 + 1, 0, hw - 1)];
+__device__ __forceinline__ void bh_decode(BhDec& r, uint32_t tm, uint32_t te, const float* dec) {
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    r.t0[ch] = dec[(tm >> (8 * ch)) & 255u];
+    r.t1[ch] = dec[(te >> (8 * ch)) & 255u];
+    // main lane 63's difference is wrong (its neighbour is the extra batch's lane 1): the extra batch starts at staged column 63
+    // and overwrites that entry (bh_stage)
+    r.d0[ch] = next_lane_dpp(r.t0[ch]) - r.t0[ch];
+    r.d1[ch] = next_lane_dpp(r.t1[ch]) - r.t1[ch];
+  }
+}
+// the slot entries of this lane's two staged columns for the row pair (lo, hi)
+__device__ __forceinline__ void bh_stage(uint8_t* slot, int lane, const BhDec& lo, const BhDec& hi) {
+  uint8_t* p0 = slot + lane * kBhColBytes;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    *reinterpret_cast<float2*>(p0 + 16 * ch) = make_float2(lo.t0[ch], hi.t0[ch]);
+    *reinterpret_cast<float2*>(p0 + 16 * ch + 8) = make_float2(lo.d0[ch], hi.d0[ch]);
+  }
+  if (lane < kBhSeg - 63) {
+    uint8_t* p1 = p0 + 63 * kBhColBytes;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      const float a = lds.dec[(ta >> (8 * ch)) & 255u], b = lds.dec[(tb >> (8 * ch)) & 255u];
-      h[ch] = fma_(c0.hal_w, b - a, a);
+      *reinterpret_cast<float2*>(p1 + 16 * ch) = make_float2(lo.t1[ch], hi.t1[ch]);
+      *reinterpret_cast<float2*>(p1 + 16 * ch + 8) = make_float2(lo.d1[ch], hi.d1[ch]);
     }
-  };
-  int staged = -1;        // highest source row in the ring
-  int pre_row = -1;       // source row whose texels are in pre_t0 / pre_t1 (fetched ahead), or -1
-  uint32_t pre_t0 = 0u, pre_t1 = 0u;
-  float hal_rows[6];      // the two horizontally filtered halation rows of the current pair (changes every few rows)
-  int hal_have = -1000;
-  BhRow cur = load_bh_row(rows, ys, SIDE);
-  uint32_t cur_idim = i0[cur.idim_y * L.extra[0].w + c0.idim_x], cur_bright = i1[cur.bright_y * L.extra[1].w + c0.bright_x];
-#pragma unroll 1
-  for (int k = 0; k < kBhRows; ++k) {
-    const int y = ys + k;
-    if (y >= H) break;
-    const int need_lo = clampi(cur.y0, 0, Hin - 1), need_hi = clampi(cur.y0 + 1, 0, Hin - 1);   // k_bloomh_geometry: y - 1 <= y0 <= y
-    // ---- stage what this row needs (normally: nothing, or the one row fetched during the previous iteration).
-    // Other lanes read what a lane writes here: the compiler must not move LDS accesses across the staging (the LDS
-    // itself executes a wave's operations in order); a compiler-level memory barrier does that without draining the
-    // loads that were issued ahead.
-    if (staged < need_lo - 1) staged = need_lo - 1;
-    asm volatile("" ::: "memory");
-    while (staged < need_hi) {
-      ++staged;
-      if (staged == pre_row) {
-        store_row(staged, pre_t0, pre_t1);
-      } else {
-        uint32_t t0, t1;
-        fetch_row(staged, &t0, &t1);
-        store_row(staged, t0, t1);
-      }
-    }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    // ---- fetch ahead for the next target row: its row quantities, the texels of its two NEAREST taps, and the source
-    // row it will add to the ring (at most one: y0 grows by at most 1 per row)
-    const int yn = y + 1 < H ? y + 1 : y;
-    const BhRow nxt = load_bh_row(rows, yn, SIDE);
-    const uint32_t nxt_idim = i0[nxt.idim_y * L.extra[0].w + c0.idim_x], nxt_bright = i1[nxt.bright_y * L.extra[1].w + c0.bright_x];
-    const int next_hi = clampi(nxt.y0 + 1, 0, Hin - 1);
-    pre_row = -1;
-    if (next_hi > staged) {
-      pre_row = staged + 1;
-      fetch_row(pre_row, &pre_t0, &pre_t1);
-    }
-    if (cur.hal_y0 != hal_have) {
-      if (cur.hal_y0 == hal_have + 1) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) hal_rows[ch] = hal_rows[3 + ch];
-      } else {
-        hal_hrow(cur.hal_y0, hal_rows);
-      }
-      hal_hrow(cur.hal_y0 + 1, hal_rows + 3);
-      hal_have = cur.hal_y0;
-    }
-    if (live) {
-      if (cur.wy != 0.0f) bloomh_pixel<SO, true, true, true>(L, lds, ring, c0, cur, x, y, z, hal_rows, cur_idim, cur_bright);
-      else bloomh_pixel<SO, false, true, true>(L, lds, ring, c0, cur, x, y, z, hal_rows, cur_idim, cur_bright);
-    }
-    cur = nxt;
-    cur_idim = nxt_idim;
-    cur_bright = nxt_bright;
   }
 }
 
-// A strip the quad's diagonal crosses (rare): per-lane triangle, the column quantities come from memory per pixel.
-template <class SO>
-__device__ __forceinline__ void bloomh_strip_mixed(const PassLaunch& L, const SrgbLds& lds, uint8_t* ring, const uint32_t* __restrict__ cols,
-                                                   const uint32_t* __restrict__ rows, int z, int xw, int ys, int lane) {
+struct BhCtx {   // per-strip lane state
+  const float* dec;
+  const uint32_t* enc2;
+  uint8_t* slots;
+  const uint8_t* tap[9];   // LDS address of tap q's entry in the top slot
+  float wx[9];
+  float w78, w56, w34, w12, si, c_main;
+};
+
+// The filter and the reconstitute of one row pair.  TWO: at least one of the rows has a vertical weight.
+template <bool TWO>
+__device__ __forceinline__ void bh_compute(const BhCtx& c, v2f wy2, uint32_t ia, uint32_t ib, uint32_t ja, uint32_t jb, const v2f* hal2, uint32_t* pa,
+                                           uint32_t* pb) {
+  auto tap = [&](int q, v2f* h) {
+    const v2f wx2 = {c.wx[q], c.wx[q]};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const v4f e = *reinterpret_cast<const v4f*>(c.tap[q] + 16 * ch);
+      h[ch] = __builtin_elementwise_fma(wx2, v2f{e.z, e.w}, v2f{e.x, e.y});
+      if (TWO) {
+        const v4f f = *reinterpret_cast<const v4f*>(c.tap[q] + kBhSlotBytes + 16 * ch);
+        const v2f hb = __builtin_elementwise_fma(wx2, v2f{f.z, f.w}, v2f{f.x, f.y});
+        h[ch] = __builtin_elementwise_fma(wy2, hb - h[ch], h[ch]);
+      }
+    }
+  };
+  // tex2Dblur17fast in the GL's evaluation order (blur17 above): taps 0 1 2, the centre (weight 1: a plain addend) before tap 3, 5 .. 8
+  v2f s[3], h[3];
+  tap(0, h);
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) s[ch] = c.w78 * h[ch];
+  tap(1, h);
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w56 * h[ch];
+  tap(2, h);
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w34 * h[ch];
+  tap(4, h);
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) s[ch] += h[ch];
+  tap(3, h);
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w12 * h[ch];
+  tap(5, h);
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w12 * h[ch];
+  tap(6, h);
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w34 * h[ch];
+  tap(7, h);
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w56 * h[ch];
+  tap(8, h);
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w78 * h[ch];
+  uint32_t oa = 0xff000000u, ob = 0xff000000u;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const v2f bl = s[ch] * c.si;
+    const v2f idim = {c.dec[(ia >> (8 * ch)) & 255u], c.dec[(ib >> (8 * ch)) & 255u]};
+    const v2f bright = {c.dec[(ja >> (8 * ch)) & 255u], c.dec[(jb >> (8 * ch)) & 255u]};
+    const v2f dimpass = idim - bright;
+    const v2f o = (dimpass + bl) * c.c_main + hal2[ch] * 0.075f;   // as k_royale_bloom_h
+    oa |= srgb8_t2(o.x, c.enc2) << (8 * ch);
+    ob |= srgb8_t2(o.y, c.enc2) << (8 * ch);
+  }
+  *pa = oa;
+  *pb = ob;
+}
+
+// One strip as seen from one triangle (SIDE 0 lower, 1 upper).  `mixed`: the diagonal crosses the strip and only the
+// pixels of this triangle are stored.
+template <int SIDE>
+__device__ __forceinline__ void bloomh_strip_side(const PassLaunch& L, const float* dec, const uint32_t* enc2, uint8_t* slots,
+                                                  const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows, int z, int xw, int ys, int lane,
+                                                  bool mixed) {
   const int W = L.out_w, H = L.out_h, Win = L.in.w, Hin = L.in.h;
   const int x = xw + lane;
   const bool live = x < W;
   const int xc = live ? x : W - 1;
-  const uint32_t* img = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
-  auto stage = [&](int r) {
-    uint8_t* slot = ring + (r % 3) * kBhRowBytes;
-    for (int j = lane; j < kBhSeg; j += 64) {   // (rare path: both texels of the pair fetched and decoded by the lane)
-      const uint32_t t = img[r * Win + clampi(xw - kBhSegLeft + j, 0, Win - 1)], u = img[r * Win + clampi(xw - kBhSegLeft + j + 1, 0, Win - 1)];
-      ring_store(slot, j, lds.dec[t & 255u], lds.dec[(t >> 8) & 255u], lds.dec[(t >> 16) & 255u], lds.dec[u & 255u], lds.dec[(u >> 8) & 255u],
-                 lds.dec[(u >> 16) & 255u]);
+  const float* P = L.params;
+  BhCtx c;
+  c.dec = dec;
+  c.enc2 = enc2;
+  c.slots = slots;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    c.tap[q] = slots + (uint32_t)((int)cols[((BH_DX + q) * 2 + SIDE) * W + xc] + (xc - xw) + kBhSegLeft) * (uint32_t)kBhColBytes;
+    c.wx[q] = bits2f(cols[((BH_WX + q) * 2 + SIDE) * W + xc]);
+  }
+  c.w78 = P[RPG_W78]; c.w56 = P[RPG_W56]; c.w34 = P[RPG_W34]; c.w12 = P[RPG_W12]; c.si = P[RPG_SUM_INV];
+  c.c_main = (P[RPG_MASK_AMPLIFY] * 2.0f) * (1.0f - 0.075f);
+  const int idim_x = (int)cols[(BH_IDIM_X * 2 + SIDE) * W + xc], bright_x = (int)cols[(BH_BRIGHT_X * 2 + SIDE) * W + xc];
+  const int hal_x0 = (int)cols[(BH_HAL_X0 * 2 + SIDE) * W + xc];
+  const float hal_w = bits2f(cols[(BH_HAL_W * 2 + SIDE) * W + xc]);
+  // buffer resources: frame bases are wave-uniform, a lane's column offset is fixed for the strip, the row base is a scalar
+  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frame_ptr(L.in, z)), 0, Win * Hin * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_i0 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frame_ptr(L.extra[0], z)), 0, L.extra[0].w * L.extra[0].h * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_i1 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frame_ptr(L.extra[1], z)), 0, L.extra[1].w * L.extra[1].h * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_hal =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frame_ptr(L.extra[2], z)), 0, L.extra[2].w * L.extra[2].h * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_out =
+      __builtin_amdgcn_make_buffer_rsrc(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z, 0, W * H * 4, 0x00020000);
+  // staged columns: lane l holds column xw - 10 + l and, for l < 21, column xw + 53 + l (staged column 63 + l)
+  const int sx0 = clampi(xw - kBhSegLeft + lane, 0, Win - 1) * 4, sx1 = clampi(xw - kBhSegLeft + 63 + lane, 0, Win - 1) * 4;
+  auto fetch = [&](int r, uint32_t* tm, uint32_t* te) {
+    const int ro = clampi(r, 0, Hin - 1) * Win * 4;
+    *tm = __builtin_amdgcn_raw_buffer_load_b32(r_in, sx0, ro, 0);
+    *te = __builtin_amdgcn_raw_buffer_load_b32(r_in, sx1, ro, 0);
+  };
+  const int hw = L.extra[2].w, hh = L.extra[2].h;
+  const int hxa = clampi(hal_x0, 0, hw - 1) * 4, hxb = clampi(hal_x0 + 1, 0, hw - 1) * 4;
+  auto hal_hrow = [&](int r, float* h) {   // the sampler's horizontal lerp of halation row r (clamped), three channels
+    const int ro = clampi(r, 0, hh - 1) * hw * 4;
+    const uint32_t ta = __builtin_amdgcn_raw_buffer_load_b32(r_hal, hxa, ro, 0), tb = __builtin_amdgcn_raw_buffer_load_b32(r_hal, hxb, ro, 0);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float a = dec[(ta >> (8 * ch)) & 255u], b = dec[(tb >> (8 * ch)) & 255u];
+      h[ch] = fma_(hal_w, b - a, a);
     }
   };
-  int staged = -1;
-#pragma unroll 1
-  for (int k = 0; k < kBhRows; ++k) {
+  uint8_t* top = slots;
+  uint8_t* bot = slots + kBhSlotBytes;
+  // window of decoded source rows y - 1, y, y + 1, y + 2 of the current target row pair; two rows enter per step
+  BhDec rm1, r0, r1, r2;
+  uint32_t n1m, n1e, n2m, n2e;   // raw texels of the two rows that enter next, in flight
+  {
+    uint32_t am, ae, bm, be;
+    fetch(ys - 1, &am, &ae);
+    fetch(ys, &bm, &be);
+    fetch(ys + 1, &n1m, &n1e);
+    fetch(ys + 2, &n2m, &n2e);
+    bh_decode(r1, am, ae, dec);   // shifted into place at the top of the first step
+    bh_decode(r2, bm, be, dec);
+  }
+  float hl[3][3];   // horizontally filtered halation rows hbase, hbase + 1, hbase + 2
+  int hbase = -1000, hvalid = 0;
+#pragma unroll 2
+  for (int k = 0; k < kBhRows; k += 2) {
     const int y = ys + k;
     if (y >= H) break;
-    const BhRow r0 = load_bh_row(rows, y, 0), r1 = load_bh_row(rows, y, 1);
-    const int need_lo = clampi(min(r0.y0, r1.y0), 0, Hin - 1);
-    const int need_hi = clampi(max(r0.y0, r1.y0) + 1, 0, Hin - 1);
-    if (staged < need_lo - 1) staged = need_lo - 1;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    while (staged < need_hi) stage(++staged);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const int yb = y + 1 < H ? y + 1 : y;
+    const BhRow ra = load_bh_row(rows, y, SIDE), rb = load_bh_row(rows, yb, SIDE);
+    // the NEAREST taps of the two rows (consumed after the filter)
+    const uint32_t ia = __builtin_amdgcn_raw_buffer_load_b32(r_i0, idim_x * 4, ra.idim_y * L.extra[0].w * 4, 0);
+    const uint32_t ib = __builtin_amdgcn_raw_buffer_load_b32(r_i0, idim_x * 4, rb.idim_y * L.extra[0].w * 4, 0);
+    const uint32_t ja = __builtin_amdgcn_raw_buffer_load_b32(r_i1, bright_x * 4, ra.bright_y * L.extra[1].w * 4, 0);
+    const uint32_t jb = __builtin_amdgcn_raw_buffer_load_b32(r_i1, bright_x * 4, rb.bright_y * L.extra[1].w * 4, 0);
+    // window: rows y + 1, y + 2 enter
+    rm1 = r1;
+    r0 = r2;
+    bh_decode(r1, n1m, n1e, dec);
+    bh_decode(r2, n2m, n2e, dec);
+    fetch(y + 3, &n1m, &n1e);
+    fetch(y + 4, &n2m, &n2e);
+    // stage: the other lanes' reads follow in program order (the LDS executes a wave's operations in order); the compiler
+    // must not move LDS accesses across the staging
+    const bool up_a = ra.y0 < y, up_b = rb.y0 < y + 1;   // the row's pair starts one row above it
+    const bool two = ra.wy != 0.0f || rb.wy != 0.0f;
+    asm volatile("" ::: "memory");
+    if (up_a) {
+      if (up_b) bh_stage(top, lane, rm1, r0); else bh_stage(top, lane, rm1, r1);
+    } else {
+      if (up_b) bh_stage(top, lane, r0, r0); else bh_stage(top, lane, r0, r1);
+    }
+    if (two) {
+      if (up_a) {
+        if (up_b) bh_stage(bot, lane, r0, r1); else bh_stage(bot, lane, r0, r2);
+      } else {
+        if (up_b) bh_stage(bot, lane, r1, r1); else bh_stage(bot, lane, r1, r2);
+      }
+    }
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if (!live) continue;
-    const bool lo = rcd::lower_tri(x, y, W, H);
-    const BhCol c = load_bh_col(cols, W, xc, xw, lo ? 0 : 1);
-    const BhRow r{lo ? r0.y0 : r1.y0, lo ? r0.wy : r1.wy, lo ? r0.idim_y : r1.idim_y, lo ? r0.bright_y : r1.bright_y,
-                  lo ? r0.hal_y0 : r1.hal_y0, lo ? r0.hal_wy : r1.hal_wy};
-    bloomh_pixel<SO, true, false>(L, lds, ring, c, r, x, y, z, nullptr);
+    // halation: rows ra.hal_y0, +1 for the first row, rb.hal_y0, +1 for the second (the same pair or the next one)
+    {
+      const int a = ra.hal_y0;
+      if (a != hbase) {
+        if (a == hbase + 1 && hvalid >= 2) {
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            hl[0][ch] = hl[1][ch];
+            hl[1][ch] = hl[2][ch];
+          }
+          hvalid -= 1;
+        } else {
+          hvalid = 0;
+        }
+        hbase = a;
+      }
+      if (hvalid < 1) hal_hrow(a, hl[0]);
+      if (hvalid < 2) hal_hrow(a + 1, hl[1]);
+      if (hvalid < 2) hvalid = 2;
+      if (rb.hal_y0 != a && hvalid < 3) {
+        hal_hrow(a + 2, hl[2]);
+        hvalid = 3;
+      }
+    }
+    v2f hal2[3];
+    if (rb.hal_y0 == ra.hal_y0) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float d = hl[1][ch] - hl[0][ch];
+        hal2[ch] = __builtin_elementwise_fma(v2f{ra.hal_wy, rb.hal_wy}, v2f{d, d}, v2f{hl[0][ch], hl[0][ch]});
+      }
+    } else if (rb.hal_y0 == ra.hal_y0 + 1) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+        hal2[ch] = __builtin_elementwise_fma(v2f{ra.hal_wy, rb.hal_wy}, v2f{hl[1][ch], hl[2][ch]} - v2f{hl[0][ch], hl[1][ch]}, v2f{hl[0][ch], hl[1][ch]});
+    } else {   // never at magnification >= 1: the second row's pair on its own
+      float b0[3], b1[3];
+      hal_hrow(rb.hal_y0, b0);
+      hal_hrow(rb.hal_y0 + 1, b1);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+        hal2[ch] = v2f{fma_(ra.hal_wy, hl[1][ch] - hl[0][ch], hl[0][ch]), fma_(rb.hal_wy, b1[ch] - b0[ch], b0[ch])};
+    }
+    uint32_t pa, pb;
+    if (two) bh_compute<true>(c, v2f{ra.wy, rb.wy}, ia, ib, ja, jb, hal2, &pa, &pb);
+    else bh_compute<false>(c, v2f{0.f, 0.f}, ia, ib, ja, jb, hal2, &pa, &pb);
+    asm volatile("" ::: "memory");
+    const bool sa = live && (!mixed || rcd::lower_tri(x, y, W, H) == (SIDE == 0));
+    const bool sb = live && y + 1 < H && (!mixed || rcd::lower_tri(x, y + 1, W, H) == (SIDE == 0));
+    if (sa) __builtin_amdgcn_raw_buffer_store_b32(pa, r_out, x * 4, y * W * 4, 0);
+    if (sb) __builtin_amdgcn_raw_buffer_store_b32(pb, r_out, x * 4, (y + 1) * W * 4, 0);
   }
 }
 
-template <class SO>
 __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const PassLaunch L, const uint32_t* __restrict__ cols,
                                                                           const uint32_t* __restrict__ rows) {
-  RC_SRGB_LDS(lds, L);
+  extern __shared__ uint32_t rc_dyn_lds_[];
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  uint8_t* ring = reinterpret_cast<uint8_t*>(rc_dyn_lds_ + ((256 + (int)kSrgbRuns + 3) & ~3) + wave * kBhRingDwords);
+  float* dec = reinterpret_cast<float*>(rc_dyn_lds_);
+  uint32_t* enc2 = rc_dyn_lds_ + 256;
+  for (int i = tid; i < 256; i += kBhWaves * 64) dec[i] = k_srgb_decode[i];
+  for (int i = tid; i < (int)kSrgb2Runs; i += kBhWaves * 64) enc2[i] = L.srgb_enc[kSrgbRuns + i];
+  __syncthreads();
+  uint8_t* slots = reinterpret_cast<uint8_t*>(rc_dyn_lds_ + kBhLdsTables + wave * kBhWaveDwords);
   const StripGrid<kBhRows> G(L.out_w, L.out_h, L.n_frames);
   const int W = G.W, H = G.H;
   for (int strip = (int)blockIdx.x * kBhWaves + wave; strip < G.total; strip += (int)gridDim.x * kBhWaves) {
@@ -563,9 +589,9 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
     // the lower triangle holds the pixels with (2y+1) W <= (2x+1) H: the strip is all lower if its (min x, max y)
     // pixel is, all upper if its (max x, min y) pixel is not
     const int xmax = min(xw + 63, W - 1), ymax = min(ys + kBhRows - 1, H - 1);
-    if (rcd::lower_tri(xw, ymax, W, H)) bloomh_strip_side<SO, 0>(L, lds, ring, cols, rows, z, xw, ys, lane);
-    else if (!rcd::lower_tri(xmax, ys, W, H)) bloomh_strip_side<SO, 1>(L, lds, ring, cols, rows, z, xw, ys, lane);
-    else bloomh_strip_mixed<SO>(L, lds, ring, cols, rows, z, xw, ys, lane);
+    const bool all_lo = rcd::lower_tri(xw, ymax, W, H), all_up = !rcd::lower_tri(xmax, ys, W, H);
+    if (!all_up) bloomh_strip_side<0>(L, dec, enc2, slots, cols, rows, z, xw, ys, lane, !all_lo);
+    if (!all_lo) bloomh_strip_side<1>(L, dec, enc2, slots, cols, rows, z, xw, ys, lane, !all_up);
   }
 }
 
@@ -583,43 +609,6 @@ void buildBhTables(const PassLaunch& L, hipStream_t s, BhTables* T) {
   }
   if (bad) (void)hipFree(bad);
   T->usable = ok && hbad == 0;
-  if (std::getenv("RC_DEBUG_BH") && ok) {
-    std::vector<uint32_t> hc(colWords), hr(rowWords);
-    (void)hipMemcpy(hc.data(), T->cols, colWords * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(hr.data(), T->rows, rowWords * 4, hipMemcpyDeviceToHost);
-    const int W = L.out_w, H = L.out_h;
-    int cdiff = 0, rdiff = 0, wy0 = 0, wyhi = 0, y0eq = 0;
-    std::map<std::vector<int>, int> pat;
-    for (int i = 0; i < W; ++i) {
-      bool d = false;
-      std::vector<int> pv;
-      for (int f = 0; f < BH_COL_FIELDS; ++f) {
-        if (hc[(f * 2 + 0) * W + i] != hc[(f * 2 + 1) * W + i]) d = true;
-        if (f < 9) pv.push_back((int)hc[(f * 2 + 0) * W + i]);
-      }
-      pv.push_back((int)hc[(BH_IDIM_X * 2) * W + i] - i);
-      pv.push_back((int)hc[(BH_BRIGHT_X * 2) * W + i] - i);
-      pat[pv]++;
-      cdiff += d;
-    }
-    for (int i = 0; i < H; ++i) {
-      bool d = false;
-      for (int f = 0; f < 6; ++f) if (hr[((size_t)i * 2 + 0) * BH_ROW_FIELDS + f] != hr[((size_t)i * 2 + 1) * BH_ROW_FIELDS + f]) d = true;
-      rdiff += d;
-      const float wy = bits2f(hr[((size_t)i * 2) * BH_ROW_FIELDS + BH_WY]);
-      wy0 += wy == 0.0f;
-      wyhi += wy > 0.5f;
-      y0eq += (int)hr[((size_t)i * 2) * BH_ROW_FIELDS + BH_Y0] == i;
-    }
-    std::fprintf(stderr, "[rc bloom-h dbg] cols differing between sides %d/%d, rows %d/%d; rows wy==0 %d, wy>0.5 %d, y0==y %d; patterns %zu\n", cdiff, W, rdiff, H, wy0, wyhi, y0eq, pat.size());
-    for (auto& kv : pat) {
-      std::fprintf(stderr, "   pattern x%d:", kv.second);
-      for (int v : kv.first) std::fprintf(stderr, " %d", v);
-      std::fprintf(stderr, "\n");
-    }
-    int hx = 0; for (int i = 1; i < W; ++i) hx += hc[(BH_HAL_X0 * 2) * W + i] != hc[(BH_HAL_X0 * 2) * W + i - 1];
-    std::fprintf(stderr, "   hal x0 changes %d, hal texture %dx%d, params k %g %g %g %g dx %g\n", hx, L.extra[2].w, L.extra[2].h, L.params[RPG_K78], L.params[RPG_K56], L.params[RPG_K34], L.params[RPG_K12], L.params[RPG_DXY]);
-  }
   if (!T->usable) {
     if (T->cols) (void)hipFree(T->cols);
     if (T->rows) (void)hipFree(T->rows);
@@ -672,8 +661,8 @@ hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
       if (const BhTables* T = geo_tables<BhTables>(L, s, mu, cache, buildBhTables)) {
         const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kBhRows - 1) / kBhRows) * L.n_frames;
         const long blocks = (strips + kBhWaves - 1) / kBhWaves;
-        const unsigned lds = (unsigned)(((256 + (int)kSrgbRuns + 3) & ~3) + kBhWaves * kBhRingDwords) * 4u;
-        auto kernel = k_royale_bloom_h_strip<OutS>;
+        const unsigned lds = (unsigned)(kBhLdsTables + kBhWaves * kBhWaveDwords) * 4u;
+        auto kernel = k_royale_bloom_h_strip;
         static bool attr = false;
         if (!attr) {
           if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return hipGetLastError();

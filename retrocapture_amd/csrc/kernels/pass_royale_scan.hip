@@ -438,6 +438,8 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
     // this tile's uncertain pixels: one range of the global list, reserved by one atomic
     __syncthreads();
     const uint32_t n_fail = cnt[0];
+    // every wave has read the count before any wave moves on to the next tile, where it may append to the list again
+    __syncthreads();
     if (n_fail) {   // uniform
       if (tid == 0) cnt[1] = atomicAdd(fix_counter(L), n_fail);
       __syncthreads();

@@ -225,6 +225,12 @@ constexpr float kSrgbLinScale = 12.92f * 255.0f;
 constexpr uint32_t kSrgbRun0 = 0x3b4d2e1cu >> 13;  // run (float bits >> 13) that contains kSrgbLinMax
 constexpr uint32_t kSrgbRuns = (0x3f7fffffu >> 13) - kSrgbRun0 + 2u;  // 8599 runs up to the last float below 1, and a spare entry (255 << 16) for the run of 1.0
 
+// Second form of the encode table (srgb_encode.cpp buildSrgbRunTable2; in device memory right after the first form):
+// runs from the first float that can store a non-zero byte up to the run that starts at 1.0, the linear segment included.
+constexpr uint32_t kSrgb2MinBits = 0x391d4000u;    // 1.4997e-4: x * 12.92 * 255 = 0.494 still rounds to 0
+constexpr uint32_t kSrgb2Run0 = kSrgb2MinBits >> 13;
+constexpr uint32_t kSrgb2Runs = (0x3f800000u >> 13) - kSrgb2Run0 + 1u;   // 13 079 entries (52 KB)
+
 // Both tables live in dynamic LDS (the launch passes srgb_lds_bytes(L)): 1 KiB for the decode table,
 // plus 34 KiB for the encode table only when the pass stores to an sRGB8 target.
 struct SrgbLds {
@@ -402,6 +408,14 @@ __device__ __forceinline__ uint32_t srgb8(float x, const SrgbLds* t) {
   const uint32_t b = f2bits(x);
   const uint32_t e = t->enc[(b >> 13) - kSrgbRun0];
   return (e >> 16) + ((b & 0x1fffu) >= (e & 0x3fffu) ? 1u : 0u);
+}
+
+// The same byte from the second form of the table (`enc2`: kSrgb2Runs entries in LDS): clamp into the table's range - a NaN
+// comes out of v_med3_f32 as the smallest operand, the lower bound, whose byte is 0 like srgb8's - one LDS read, one add.
+__device__ __forceinline__ uint32_t srgb8_t2(float x, const uint32_t* enc2) {
+  const uint32_t b = f2bits(__builtin_amdgcn_fmed3f(x, bits2f(kSrgb2MinBits), 1.0f));
+  const uint32_t e = enc2[(b >> 13) - kSrgb2Run0];
+  return ((e + (b & 0x1fffu)) >> 13) & 255u;
 }
 
 template <int OUT_FMT>

@@ -51,10 +51,22 @@ __global__ void __launch_bounds__(256) k_selftest_srgb8(const float* src, uint8_
   for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = (uint8_t)srgb8(src[i], &lds);
 }
 
+// ... and the second form of the table (rc_device.h srgb8_t2: the strip kernels' encode)
+__global__ void __launch_bounds__(256) k_selftest_srgb8_t2(const float* src, uint8_t* dst, size_t n, const uint32_t* __restrict__ table2) {
+  extern __shared__ uint32_t enc2[];
+  for (uint32_t i = threadIdx.x; i < kSrgb2Runs; i += 256u) enc2[i] = table2[i];
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = (uint8_t)srgb8_t2(src[i], enc2);
+}
+
 }  // namespace
 
 namespace rck {
-hipError_t launch_selftest_srgb8(const float* d_src, uint8_t* d_dst, size_t n, const uint32_t* table, hipStream_t s) {
+hipError_t launch_selftest_srgb8(const float* d_src, uint8_t* d_dst, size_t n, const uint32_t* table, hipStream_t s, int form) {
+  if (form == 2) {
+    hipLaunchKernelGGL(k_selftest_srgb8_t2, dim3(512), dim3(256), kSrgb2Runs * 4u, s, d_src, d_dst, n, table + kSrgbRuns);
+    return hipGetLastError();
+  }
   PassLaunch L = {};
   L.out_fmt = FMT_SRGB8;
   L.srgb_enc = table;

@@ -13,6 +13,10 @@ uint8_t srgb8Encode(float x);
 // the measured structure does not hold
 bool buildSrgbRunTable(std::vector<uint32_t>* table);
 uint8_t srgb8EncodeByRunTable(float x, const uint32_t* table);
-// the table in device memory of `device` (current device must be `device`); created on first use
+// second form (rcd::kSrgb2Runs entries, (byte << 13) + (8192 - crossing), bit 30 = the first form's bit 14): covers the
+// linear segment too, so the device encode is clamp, one LDS read, one add, one bit-field extract
+bool buildSrgbRunTable2(std::vector<uint32_t>* table);
+uint8_t srgb8EncodeByRunTable2(float x, const uint32_t* table);
+// both tables (first form, then second form at + rcd::kSrgbRuns) in device memory of `device` (current device must be `device`); created on first use
 const uint32_t* deviceSrgbRunTable(int device);
 }  // namespace rc

@@ -100,6 +100,8 @@ SYMBOLS = [
     ("rc_selftest_royale_scan_tables", C.c_int, [C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     ("rc_selftest_srgb8_device", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("rc_selftest_crt_geom_vertex", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rc_selftest_srgb8_host_form", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    ("rc_selftest_srgb8_device_form", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
     ("rc_last_error", C.c_char_p, []),
     ("rc_version", C.c_char_p, []),
     ("rc_kernel_list", C.c_size_t, [C.c_char_p, C.c_size_t]),
@@ -285,22 +287,23 @@ def selftest_fastmath(device=0):
     return list(out)
 
 
-def srgb8_encode_host(values):
-    """The sRGB8 store of the pass kernels, evaluated on the host through the same per-run table (numpy float32 in)."""
+def srgb8_encode_host(values, form=1):
+    """The sRGB8 store of the pass kernels, evaluated on the host through the same per-run table (numpy float32 in);
+    form 2: the table the strip kernels use (linear segment included)."""
     import numpy as np
     v = np.ascontiguousarray(values, dtype=np.float32)
     out = np.empty(v.size, dtype=np.uint8)
-    rc = load_library().rc_selftest_srgb8_host(v.ctypes.data, out.ctypes.data, v.size)
+    rc = load_library().rc_selftest_srgb8_host_form(v.ctypes.data, out.ctypes.data, v.size, int(form))
     if rc != 0:
-        raise RcError("rc_selftest_srgb8_host failed (%d)" % rc)
+        raise RcError("rc_selftest_srgb8_host_form failed (%d)" % rc)
     return out.reshape(v.shape)
 
 
-def srgb8_encode_device(d_values, d_out, n, device=0, stream=0):
+def srgb8_encode_device(d_values, d_out, n, device=0, stream=0, form=1):
     """The same on the device: d_values (float32) / d_out (uint8) are device pointers or torch tensors."""
-    rc = load_library().rc_selftest_srgb8_device(int(device), _ptr(d_values), _ptr(d_out), int(n), C.c_void_p(int(stream)))
+    rc = load_library().rc_selftest_srgb8_device_form(int(device), _ptr(d_values), _ptr(d_out), int(n), C.c_void_p(int(stream)), int(form))
     if rc != 0:
-        raise RcError("rc_selftest_srgb8_device failed (%d)" % rc)
+        raise RcError("rc_selftest_srgb8_device_form failed (%d)" % rc)
 
 
 def royale_scan_tables(off):

@@ -43,6 +43,22 @@ def probe_values():
     return np.concatenate(parts).view(np.float32)
 
 
+def probe_values_linear_segment():
+    """The second form of the table also covers the linear segment (byte = rint(x * 12.92 * 255) up to 0.0031308): every float
+    within +-40 of each of its ten crossings, every run boundary +-2, the clamp's lower end, and random floats below the segment boundary."""
+    rng = np.random.default_rng(12)
+    lin = int(np.float32(0.0031308).view(np.uint32))
+    lo = 0x391D4000
+    parts = [rng.integers(0, lin + 1, 1 << 21, dtype=np.uint32), np.arange(lo - 20000, lo + 20000, dtype=np.uint32)]
+    runs = np.arange(lo >> 13, (lin >> 13) + 2, dtype=np.uint32) << 13
+    parts.append((runs[:, None] + np.arange(-2, 3, dtype=np.int64)[None, :]).astype(np.uint32).reshape(-1))
+    for k in range(11):
+        x = np.float32((k + 0.5) / (12.92 * 255.0))
+        b = int(x.view(np.uint32))
+        parts.append(np.arange(b - 40, b + 41, dtype=np.uint32))
+    return np.concatenate(parts).view(np.float32)
+
+
 def test_oracle_known_answers():
     v = np.array([0.0, 1.0, 2.0, -1.0, np.nan, 0.0031308, 0.5, 0.2], dtype=np.float32)
     got = oracle_encode(v)
@@ -55,6 +71,34 @@ def test_run_table_matches_oracle(rc_lib):
     from retrocapture_amd import engine
     v = probe_values()
     assert np.array_equal(engine.srgb8_encode_host(v), oracle_encode(v))
+
+
+def test_second_form_run_table_matches_oracle(rc_lib):
+    from retrocapture_amd import engine
+    v = np.concatenate([probe_values(), probe_values_linear_segment()])
+    assert np.array_equal(engine.srgb8_encode_host(v, form=2), oracle_encode(v))
+
+
+def test_second_form_linear_segment_exhaustive(rc_lib):
+    """Every float of every run of the linear segment (36 M values) through the second form of the table."""
+    from retrocapture_amd import engine
+    lin = int(np.float32(0.0031308).view(np.uint32))
+    lo = 0x391D4000 - 8192
+    for start in range(lo, lin + 8192, 1 << 23):
+        v = np.arange(start, min(start + (1 << 23), lin + 8192), dtype=np.uint32).view(np.float32)
+        assert np.array_equal(engine.srgb8_encode_host(v, form=2), oracle_encode(v))
+
+
+@pytest.mark.gpu
+def test_device_second_form_matches_oracle(rc_lib):
+    import torch
+    from retrocapture_amd import engine
+    v = np.concatenate([probe_values(), probe_values_linear_segment()])
+    d = torch.from_numpy(v.copy()).cuda()
+    o = torch.empty(v.size, dtype=torch.uint8, device="cuda")
+    engine.srgb8_encode_device(d, o, v.size, stream=torch.cuda.current_stream().cuda_stream, form=2)
+    torch.cuda.synchronize()
+    assert np.array_equal(o.cpu().numpy(), oracle_encode(v))
 
 
 @pytest.mark.gpu
