@@ -1,6 +1,8 @@
 // crt-royale passes 9 and 10 (bloom-vertical.glsl, bloom-horizontal-reconstitute.glsl): the general per-pixel
 // kernels, and the strip forms that run separable geometry (royale_strip.h) - the shipped preset at any size.
+#include <algorithm>
 #include <cstdio>
+#include <vector>
 #include <cstdlib>
 
 #include "royale_strip.h"
@@ -202,30 +204,34 @@ void buildBvTables(const PassLaunch& L, hipStream_t s, BvTables* T) {
 }
 
 // ----------------------------------------------------------------- P10, strip form ------
-// One wave renders 64 columns x kBhRows rows, TWO target rows per lane and step, so that every float operation of the
-// filter runs as a packed v_pk_{fma,mul,add}_f32 over the row pair (the same IEEE operation per component).
+// One wave renders a band of 128 columns, one target row per step, TWO pixels per lane: columns x and x + 64 of the row, so
+// that every float operation of the filter runs as a packed v_pk_{fma,mul,add}_f32 over the pixel pair (the same IEEE
+// operation per component).
 //
 // The nine blur taps of a pixel are LINEAR taps of one row (or row pair) of pass 9's sRGB8 target at horizontal offsets of
 // up to 7.x texels: lerp(wx, T[j], T[j+1]) = fma(wx, T[j+1] - T[j], T[j]).  The difference D[j] = T[j+1] - T[j] does not
 // depend on the tap, so it is formed ONCE per staged texel (the neighbour's texel arrives by a DPP wave shift folded into
-// the subtraction) and a tap is one fma.  Per step the wave stages, for its 64 columns + 10 either side (clamped like
-// the sampler clamps them), per column and channel the quad {T(lo row), T(hi row), D(lo row), D(hi row)} of the row pair's
-// FIRST source rows ("top" slot) and, if either row has a vertical weight, of their SECOND source rows ("bottom" slot): one
-// ds_read_b128 per tap, channel and slot delivers both rows' operands in adjacent registers.  Column quantities (tap
-// offset as an LDS address, weight) sit in registers per strip, row quantities are wave-uniform scalars, global
-// accesses are buffer loads / stores with the row base in an SGPR (no per-lane 64-bit address arithmetic).
+// the subtraction) and a tap is one fma.  A source row is decoded and staged in LDS once: per staged column k (84 = 64 + 10
+// either side, clamped like the sampler clamps them) and channel the quad {T_A[k], T_B[k], D_A[k], D_B[k]} of the band's two
+// column groups A (columns xw - 10 + k) and B (64 further right), written by one conflict-free ds_write_b128 straight from
+// the registers the decode leaves them in.  A tap whose first texel sits at the same offset for both of a lane's pixels -
+// every tap but the centre one, whose coordinate lies on a texel centre up to rounding - is one ds_read_b128 per channel
+// that delivers both pixels' operands in adjacent registers; the others read the two quads separately.  Per-column
+// quantities (tap offsets as LDS addresses, weights as pairs) sit in registers for the whole band, row quantities are
+// wave-uniform scalars, global accesses are buffer loads / stores with the row base in an SGPR.
 // At 1:1 a target row's first source row is y or y - 1 (weight 0 / a few 1e-5 / 1 minus that, irregularly from row to row:
-// k_bloomh_geometry), so the wave keeps a rolling window of four decoded source rows y - 1 .. y + 2 in registers and two new
-// rows enter per step.  A strip the quad's diagonal crosses is rendered once per triangle, each pixel stored by the
-// pass of its own triangle.
-constexpr int kBhRows = 16;
+// k_bloomh_geometry): source rows are staged in order into a two-row ring as target rows first need them, their texels
+// fetched two rows ahead.  Rows whose vertical weight is exactly 0 filter one source row.  The launch is cut into equal
+// runs of consecutive (frame, band, row) steps, one per wave; rows are walked in blocks of 8, and a block the quad's
+// diagonal crosses is rendered once per triangle, each pixel stored by the pass of its own triangle.
 constexpr int kBhWaves = 12;
-constexpr int kBhSeg = 84;      // staged columns: 10 + 64 + 10
+constexpr int kBhBlockRows = 8;   // rows classified together by triangle
+constexpr int kBhSeg = 84;        // staged columns per group: 10 + 64 + 10
 constexpr int kBhSegLeft = 10;
-constexpr int kBhColBytes = 48;                       // three channels x {T lo, T hi, D lo, D hi}
-constexpr int kBhSlotBytes = kBhSeg * kBhColBytes;    // 4032
+constexpr int kBhColBytes = 48;                       // three channels x {T_A, T_B, D_A, D_B}
+constexpr int kBhSlotBytes = kBhSeg * kBhColBytes;    // 4032: one staged source row
 constexpr int kBhLdsTables = (256 + (int)kSrgb2Runs + 3) & ~3;   // dwords: decode table, second-form encode table
-constexpr int kBhWaveDwords = 2 * kBhSlotBytes / 4;   // per wave: top and bottom slot
+constexpr int kBhWaveDwords = 2 * kBhSlotBytes / 4;   // per wave: a ring of two staged rows (row r in slot r & 1)
 enum { BH_DX = 0, BH_WX = 9, BH_IDIM_X = 18, BH_BRIGHT_X = 19, BH_HAL_X0 = 20, BH_HAL_W = 21, BH_COL_FIELDS = 22 };
 enum { BH_Y0 = 0, BH_WY = 1, BH_IDIM_Y = 2, BH_BRIGHT_Y = 3, BH_HAL_Y0 = 4, BH_HAL_WY = 5, BH_ROW_FIELDS = 8 };
 
@@ -233,6 +239,10 @@ struct BhTables {
   uint32_t* cols = nullptr;   // [BH_COL_FIELDS][2 sides][W] (ints and float bits)
   uint32_t* rows = nullptr;   // [H][2 sides][BH_ROW_FIELDS]
   bool usable = false;
+  // host: running sum of a cost estimate per (band, row) step of one frame (rows with a vertical weight filter two source rows,
+  // blocks on the diagonal are rendered twice), and per (frames, waves) of a launch the step at which each wave's run begins
+  std::vector<uint32_t> cost_sum;
+  std::map<std::pair<int, int>, uint32_t*> runs;
 };
 
 __global__ void __launch_bounds__(256) k_bloomh_geometry(const PassLaunch L, uint32_t* cols, uint32_t* rows, uint32_t* bad) {
@@ -274,7 +284,7 @@ __global__ void __launch_bounds__(256) k_bloomh_geometry(const PassLaunch L, uin
       uint32_t* r = rows + ((size_t)i * 2 + side) * BH_ROW_FIELDS;
       const float v = vary(L.plane[1], 0, i, lo);
       const LinTap t = lin_tap(v - k[0] * 0.0f, L.in.h);   // every tap: v -+ k * 0 = v
-      // the strip's window holds source rows y - 1 .. y + 2 of a target row pair (y, y + 1): the pair must start at y - 1 or y
+      // source rows are staged in increasing order as target rows need them: the pair must start at y - 1 or y
       if (t.i0 < i - 1 || t.i0 > i) why |= 2u;
       r[BH_Y0] = (uint32_t)t.i0;
       r[BH_WY] = f2bits(t.w);
@@ -302,296 +312,345 @@ __device__ __forceinline__ BhRow load_bh_row(const uint32_t* __restrict__ rows, 
   return BhRow{(int)r[BH_Y0], bits2f(r[BH_WY]), (int)r[BH_IDIM_Y], (int)r[BH_BRIGHT_Y], (int)r[BH_HAL_Y0], bits2f(r[BH_HAL_WY])};
 }
 
-// One decoded source row as a lane holds it: the texel of its main staged column (lane) and of its extra one (63 + lane,
-// lanes 0..20) per channel, and the difference to the next staged column's texel.
-struct BhDec {
-  float t0[3], d0[3], t1[3], d1[3];
-};
+// LDS accesses of this kernel go through absolute byte offsets (the kernel has no static LDS, so its dynamic LDS starts
+// at 0 - checked once at kernel entry): an address is a register the arithmetic left it in, plus an immediate.
+#define RC_AS3 __attribute__((address_space(3)))
+__device__ __forceinline__ float lds_f32(uint32_t off) { return *reinterpret_cast<const RC_AS3 float*>((uintptr_t)off); }
+__device__ __forceinline__ uint32_t lds_u32(uint32_t off) { return *reinterpret_cast<const RC_AS3 uint32_t*>((uintptr_t)off); }
+__device__ __forceinline__ v4f lds_v4f(uint32_t off) { return *reinterpret_cast<const RC_AS3 v4f*>((uintptr_t)off); }
+__device__ __forceinline__ void lds_put_v4f(uint32_t off, v4f v) { *reinterpret_cast<RC_AS3 v4f*>((uintptr_t)off) = v; }
+constexpr uint32_t kBhLdsDec = 0u, kBhLdsEnc = 1024u;   // byte offsets of the decode table and of the second-form encode table
+
 // value of the next lane (lane 63: 0); the compiler folds the move into the subtraction that consumes it (v_sub_f32_dpp)
 __device__ __forceinline__ float next_lane_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
 }
-__device__ __forceinline__ void bh_decode(BhDec& r, uint32_t tm, uint32_t te, const float* dec) {
-#pragma unroll
-  for (int ch = 0; ch < 3; ++ch) {
-    r.t0[ch] = dec[(tm >> (8 * ch)) & 255u];
-    r.t1[ch] = dec[(te >> (8 * ch)) & 255u];
-    // main lane 63's difference is wrong (its neighbour is the extra batch's lane 1): the extra batch starts at staged column 63
-    // and overwrites that entry (bh_stage)
-    r.d0[ch] = next_lane_dpp(r.t0[ch]) - r.t0[ch];
-    r.d1[ch] = next_lane_dpp(r.t1[ch]) - r.t1[ch];
-  }
+// the decoded value of byte N of texel t: its offset in the table of floats at LDS offset 0 is one SDWA instruction
+template <int N>
+__device__ __forceinline__ float dec_byte(uint32_t t) {
+  uint32_t r;
+  if (N == 0) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(t));
+  if (N == 1) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(t));
+  if (N == 2) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(t));
+  return lds_f32(kBhLdsDec + r);
 }
-// the slot entries of this lane's two staged columns for the row pair (lo, hi)
-__device__ __forceinline__ void bh_stage(uint8_t* slot, int lane, const BhDec& lo, const BhDec& hi) {
-  uint8_t* p0 = slot + lane * kBhColBytes;
-#pragma unroll
-  for (int ch = 0; ch < 3; ++ch) {
-    *reinterpret_cast<float2*>(p0 + 16 * ch) = make_float2(lo.t0[ch], hi.t0[ch]);
-    *reinterpret_cast<float2*>(p0 + 16 * ch + 8) = make_float2(lo.d0[ch], hi.d0[ch]);
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// srgb8_t2 (rc_device.h) on the table at kBhLdsEnc
+__device__ __forceinline__ uint32_t bh_srgb8(float x) {
+  const uint32_t b = f2bits(__builtin_amdgcn_fmed3f(x, bits2f(kSrgb2MinBits), 1.0f));
+  const uint32_t e = lds_u32(((b >> 13) << 2) + (kBhLdsEnc - (kSrgb2Run0 << 2)));
+  return ((e + (b & 0x1fffu)) >> 13) & 255u;
+}
+
+// One source row of this lane's staged column (its texel in group A and in group B) into its ring entry: decode, difference
+// to the next staged column, one 16-byte store per channel.
+__device__ __forceinline__ void bh_stage_entry(uint32_t entry, uint32_t ta, uint32_t tb) {
+  {
+    const float a = dec_byte<0>(ta), b = dec_byte<0>(tb);
+    lds_put_v4f(entry, v4f{a, b, next_lane_dpp(a) - a, next_lane_dpp(b) - b});
   }
-  if (lane < kBhSeg - 63) {
-    uint8_t* p1 = p0 + 63 * kBhColBytes;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      *reinterpret_cast<float2*>(p1 + 16 * ch) = make_float2(lo.t1[ch], hi.t1[ch]);
-      *reinterpret_cast<float2*>(p1 + 16 * ch + 8) = make_float2(lo.d1[ch], hi.d1[ch]);
-    }
+  {
+    const float a = dec_byte<1>(ta), b = dec_byte<1>(tb);
+    lds_put_v4f(entry + 16, v4f{a, b, next_lane_dpp(a) - a, next_lane_dpp(b) - b});
+  }
+  {
+    const float a = dec_byte<2>(ta), b = dec_byte<2>(tb);
+    lds_put_v4f(entry + 32, v4f{a, b, next_lane_dpp(a) - a, next_lane_dpp(b) - b});
   }
 }
 
-struct BhCtx {   // per-strip lane state
-  const float* dec;
-  const uint32_t* enc2;
-  uint8_t* slots;
-  const uint8_t* tap[9];   // LDS address of tap q's entry in the top slot
-  float wx[9];
-  float w78, w56, w34, w12, si, c_main;
+struct BhBand {   // per-band lane state of one triangle
+  uint32_t tap_a[9];   // LDS offset of tap q's entry in ring slot 0, for the lane's pixel in group A
+  uint32_t tap_d[2];   // ... and, packed 6 bits per tap, how many staged columns further right group B's pixel starts
+                       // (0 where both pixels' taps start at the same offset: every tap but the centre one, away from the edges)
+  v2f wx[9];
 };
+__device__ __forceinline__ uint32_t bh_tap_b(const BhBand& c, int q) {
+  const int d = ((int)(c.tap_d[q / 5] << (26 - 6 * (q % 5)))) >> 26;   // signed 6-bit field
+  return c.tap_a[q] + (uint32_t)(d * kBhColBytes);
+}
 
-// The filter and the reconstitute of one row pair.  TWO: at least one of the rows has a vertical weight.
-template <bool TWO>
-__device__ __forceinline__ void bh_compute(const BhCtx& c, v2f wy2, uint32_t ia, uint32_t ib, uint32_t ja, uint32_t jb, const v2f* hal2, uint32_t* pa,
-                                           uint32_t* pb) {
-  auto tap = [&](int q, v2f* h) {
-    const v2f wx2 = {c.wx[q], c.wx[q]};
+// the horizontal lerps of tap q from the ring slot at byte offset `slot`: both pixels, three channels.  PAIR: both pixels'
+// taps start at the same staged column - one quad holds both pixels' operands.
+template <bool PAIR>
+__device__ __forceinline__ void bh_tap_row(const BhBand& c, int q, uint32_t slot, v2f* h) {
+  const uint32_t pa = c.tap_a[q] + slot;
+  if (PAIR) {
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      const v4f e = *reinterpret_cast<const v4f*>(c.tap[q] + 16 * ch);
-      h[ch] = __builtin_elementwise_fma(wx2, v2f{e.z, e.w}, v2f{e.x, e.y});
-      if (TWO) {
-        const v4f f = *reinterpret_cast<const v4f*>(c.tap[q] + kBhSlotBytes + 16 * ch);
-        const v2f hb = __builtin_elementwise_fma(wx2, v2f{f.z, f.w}, v2f{f.x, f.y});
-        h[ch] = __builtin_elementwise_fma(wy2, hb - h[ch], h[ch]);
-      }
+      const v4f e = lds_v4f(pa + 16 * ch);
+      h[ch] = fma2(c.wx[q], v2f{e.z, e.w}, v2f{e.x, e.y});
     }
-  };
-  // tex2Dblur17fast in the GL's evaluation order (blur17 above): taps 0 1 2, the centre (weight 1: a plain addend) before tap 3, 5 .. 8
-  v2f s[3], h[3];
-  tap(0, h);
+  } else {
+    const uint32_t pb = bh_tap_b(c, q) + slot;
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) s[ch] = c.w78 * h[ch];
-  tap(1, h);
+    for (int ch = 0; ch < 3; ++ch) {
+      const v4f e = lds_v4f(pa + 16 * ch);
+      const v4f f = lds_v4f(pb + 16 * ch);
+      h[ch] = v2f{fma_(c.wx[q].x, e.z, e.x), fma_(c.wx[q].y, f.w, f.y)};
+    }
+  }
+}
+template <bool TWO, bool PAIR>
+__device__ __forceinline__ void bh_tap(const BhBand& c, int q, uint32_t slot_a, uint32_t slot_b, float wy, v2f* h) {
+  bh_tap_row<PAIR>(c, q, slot_a, h);
+  if (TWO) {
+    v2f g[3];
+    bh_tap_row<PAIR>(c, q, slot_b, g);
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w56 * h[ch];
-  tap(2, h);
+    for (int ch = 0; ch < 3; ++ch) h[ch] = fma2(v2f{wy, wy}, g[ch] - h[ch], h[ch]);
+  }
+}
+
+// The filter of one target row for the lane's two pixels: tex2Dblur17fast in the GL's evaluation order (blur17 above):
+// taps 0 1 2, the centre (weight 1: a plain addend) before tap 3, then 5 .. 8.  TWO: the row has a vertical weight.
+// EDGE: a band at the frame's edge, where clamped coordinates give the two pixels different tap offsets.
+template <bool TWO, bool EDGE>
+__device__ __forceinline__ void bh_filter(const BhBand& c, uint32_t slot_a, uint32_t slot_b, float wy, float w78, float w56, float w34, float w12,
+                                          v2f* s) {
+  v2f h[3];
+  bh_tap<TWO, !EDGE>(c, 0, slot_a, slot_b, wy, h);
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w34 * h[ch];
-  tap(4, h);
+  for (int ch = 0; ch < 3; ++ch) s[ch] = w78 * h[ch];
+  bh_tap<TWO, !EDGE>(c, 1, slot_a, slot_b, wy, h);
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) s[ch] += w56 * h[ch];
+  bh_tap<TWO, !EDGE>(c, 2, slot_a, slot_b, wy, h);
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) s[ch] += w34 * h[ch];
+  bh_tap<TWO, false>(c, 4, slot_a, slot_b, wy, h);   // the centre tap sits on a texel centre: its pair flips with rounding
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) s[ch] += h[ch];
-  tap(3, h);
+  bh_tap<TWO, !EDGE>(c, 3, slot_a, slot_b, wy, h);
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w12 * h[ch];
-  tap(5, h);
+  for (int ch = 0; ch < 3; ++ch) s[ch] += w12 * h[ch];
+  bh_tap<TWO, !EDGE>(c, 5, slot_a, slot_b, wy, h);
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w12 * h[ch];
-  tap(6, h);
+  for (int ch = 0; ch < 3; ++ch) s[ch] += w12 * h[ch];
+  bh_tap<TWO, !EDGE>(c, 6, slot_a, slot_b, wy, h);
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w34 * h[ch];
-  tap(7, h);
+  for (int ch = 0; ch < 3; ++ch) s[ch] += w34 * h[ch];
+  bh_tap<TWO, !EDGE>(c, 7, slot_a, slot_b, wy, h);
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w56 * h[ch];
-  tap(8, h);
+  for (int ch = 0; ch < 3; ++ch) s[ch] += w56 * h[ch];
+  bh_tap<TWO, !EDGE>(c, 8, slot_a, slot_b, wy, h);
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) s[ch] += c.w78 * h[ch];
-  uint32_t oa = 0xff000000u, ob = 0xff000000u;
-#pragma unroll
-  for (int ch = 0; ch < 3; ++ch) {
-    const v2f bl = s[ch] * c.si;
-    const v2f idim = {c.dec[(ia >> (8 * ch)) & 255u], c.dec[(ib >> (8 * ch)) & 255u]};
-    const v2f bright = {c.dec[(ja >> (8 * ch)) & 255u], c.dec[(jb >> (8 * ch)) & 255u]};
-    const v2f dimpass = idim - bright;
-    const v2f o = (dimpass + bl) * c.c_main + hal2[ch] * 0.075f;   // as k_royale_bloom_h
-    oa |= srgb8_t2(o.x, c.enc2) << (8 * ch);
-    ob |= srgb8_t2(o.y, c.enc2) << (8 * ch);
-  }
-  *pa = oa;
-  *pb = ob;
-}
-
-// One strip as seen from one triangle (SIDE 0 lower, 1 upper).  `mixed`: the diagonal crosses the strip and only the
-// pixels of this triangle are stored.
-template <int SIDE>
-__device__ __forceinline__ void bloomh_strip_side(const PassLaunch& L, const float* dec, const uint32_t* enc2, uint8_t* slots,
-                                                  const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows, int z, int xw, int ys, int lane,
-                                                  bool mixed) {
-  const int W = L.out_w, H = L.out_h, Win = L.in.w, Hin = L.in.h;
-  const int x = xw + lane;
-  const bool live = x < W;
-  const int xc = live ? x : W - 1;
-  const float* P = L.params;
-  BhCtx c;
-  c.dec = dec;
-  c.enc2 = enc2;
-  c.slots = slots;
-#pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    c.tap[q] = slots + (uint32_t)((int)cols[((BH_DX + q) * 2 + SIDE) * W + xc] + (xc - xw) + kBhSegLeft) * (uint32_t)kBhColBytes;
-    c.wx[q] = bits2f(cols[((BH_WX + q) * 2 + SIDE) * W + xc]);
-  }
-  c.w78 = P[RPG_W78]; c.w56 = P[RPG_W56]; c.w34 = P[RPG_W34]; c.w12 = P[RPG_W12]; c.si = P[RPG_SUM_INV];
-  c.c_main = (P[RPG_MASK_AMPLIFY] * 2.0f) * (1.0f - 0.075f);
-  const int idim_x = (int)cols[(BH_IDIM_X * 2 + SIDE) * W + xc], bright_x = (int)cols[(BH_BRIGHT_X * 2 + SIDE) * W + xc];
-  const int hal_x0 = (int)cols[(BH_HAL_X0 * 2 + SIDE) * W + xc];
-  const float hal_w = bits2f(cols[(BH_HAL_W * 2 + SIDE) * W + xc]);
-  // buffer resources: frame bases are wave-uniform, a lane's column offset is fixed for the strip, the row base is a scalar
-  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frame_ptr(L.in, z)), 0, Win * Hin * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_i0 =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frame_ptr(L.extra[0], z)), 0, L.extra[0].w * L.extra[0].h * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_i1 =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frame_ptr(L.extra[1], z)), 0, L.extra[1].w * L.extra[1].h * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_hal =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frame_ptr(L.extra[2], z)), 0, L.extra[2].w * L.extra[2].h * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_out =
-      __builtin_amdgcn_make_buffer_rsrc(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z, 0, W * H * 4, 0x00020000);
-  // staged columns: lane l holds column xw - 10 + l and, for l < 21, column xw + 53 + l (staged column 63 + l)
-  const int sx0 = clampi(xw - kBhSegLeft + lane, 0, Win - 1) * 4, sx1 = clampi(xw - kBhSegLeft + 63 + lane, 0, Win - 1) * 4;
-  auto fetch = [&](int r, uint32_t* tm, uint32_t* te) {
-    const int ro = clampi(r, 0, Hin - 1) * Win * 4;
-    *tm = __builtin_amdgcn_raw_buffer_load_b32(r_in, sx0, ro, 0);
-    *te = __builtin_amdgcn_raw_buffer_load_b32(r_in, sx1, ro, 0);
-  };
-  const int hw = L.extra[2].w, hh = L.extra[2].h;
-  const int hxa = clampi(hal_x0, 0, hw - 1) * 4, hxb = clampi(hal_x0 + 1, 0, hw - 1) * 4;
-  auto hal_hrow = [&](int r, float* h) {   // the sampler's horizontal lerp of halation row r (clamped), three channels
-    const int ro = clampi(r, 0, hh - 1) * hw * 4;
-    const uint32_t ta = __builtin_amdgcn_raw_buffer_load_b32(r_hal, hxa, ro, 0), tb = __builtin_amdgcn_raw_buffer_load_b32(r_hal, hxb, ro, 0);
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      const float a = dec[(ta >> (8 * ch)) & 255u], b = dec[(tb >> (8 * ch)) & 255u];
-      h[ch] = fma_(hal_w, b - a, a);
-    }
-  };
-  uint8_t* top = slots;
-  uint8_t* bot = slots + kBhSlotBytes;
-  // window of decoded source rows y - 1, y, y + 1, y + 2 of the current target row pair; two rows enter per step
-  BhDec rm1, r0, r1, r2;
-  uint32_t n1m, n1e, n2m, n2e;   // raw texels of the two rows that enter next, in flight
-  {
-    uint32_t am, ae, bm, be;
-    fetch(ys - 1, &am, &ae);
-    fetch(ys, &bm, &be);
-    fetch(ys + 1, &n1m, &n1e);
-    fetch(ys + 2, &n2m, &n2e);
-    bh_decode(r1, am, ae, dec);   // shifted into place at the top of the first step
-    bh_decode(r2, bm, be, dec);
-  }
-  float hl[3][3];   // horizontally filtered halation rows hbase, hbase + 1, hbase + 2
-  int hbase = -1000, hvalid = 0;
-#pragma unroll 2
-  for (int k = 0; k < kBhRows; k += 2) {
-    const int y = ys + k;
-    if (y >= H) break;
-    const int yb = y + 1 < H ? y + 1 : y;
-    const BhRow ra = load_bh_row(rows, y, SIDE), rb = load_bh_row(rows, yb, SIDE);
-    // the NEAREST taps of the two rows (consumed after the filter)
-    const uint32_t ia = __builtin_amdgcn_raw_buffer_load_b32(r_i0, idim_x * 4, ra.idim_y * L.extra[0].w * 4, 0);
-    const uint32_t ib = __builtin_amdgcn_raw_buffer_load_b32(r_i0, idim_x * 4, rb.idim_y * L.extra[0].w * 4, 0);
-    const uint32_t ja = __builtin_amdgcn_raw_buffer_load_b32(r_i1, bright_x * 4, ra.bright_y * L.extra[1].w * 4, 0);
-    const uint32_t jb = __builtin_amdgcn_raw_buffer_load_b32(r_i1, bright_x * 4, rb.bright_y * L.extra[1].w * 4, 0);
-    // window: rows y + 1, y + 2 enter
-    rm1 = r1;
-    r0 = r2;
-    bh_decode(r1, n1m, n1e, dec);
-    bh_decode(r2, n2m, n2e, dec);
-    fetch(y + 3, &n1m, &n1e);
-    fetch(y + 4, &n2m, &n2e);
-    // stage: the other lanes' reads follow in program order (the LDS executes a wave's operations in order); the compiler
-    // must not move LDS accesses across the staging
-    const bool up_a = ra.y0 < y, up_b = rb.y0 < y + 1;   // the row's pair starts one row above it
-    const bool two = ra.wy != 0.0f || rb.wy != 0.0f;
-    asm volatile("" ::: "memory");
-    if (up_a) {
-      if (up_b) bh_stage(top, lane, rm1, r0); else bh_stage(top, lane, rm1, r1);
-    } else {
-      if (up_b) bh_stage(top, lane, r0, r0); else bh_stage(top, lane, r0, r1);
-    }
-    if (two) {
-      if (up_a) {
-        if (up_b) bh_stage(bot, lane, r0, r1); else bh_stage(bot, lane, r0, r2);
-      } else {
-        if (up_b) bh_stage(bot, lane, r1, r1); else bh_stage(bot, lane, r1, r2);
-      }
-    }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    // halation: rows ra.hal_y0, +1 for the first row, rb.hal_y0, +1 for the second (the same pair or the next one)
-    {
-      const int a = ra.hal_y0;
-      if (a != hbase) {
-        if (a == hbase + 1 && hvalid >= 2) {
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            hl[0][ch] = hl[1][ch];
-            hl[1][ch] = hl[2][ch];
-          }
-          hvalid -= 1;
-        } else {
-          hvalid = 0;
-        }
-        hbase = a;
-      }
-      if (hvalid < 1) hal_hrow(a, hl[0]);
-      if (hvalid < 2) hal_hrow(a + 1, hl[1]);
-      if (hvalid < 2) hvalid = 2;
-      if (rb.hal_y0 != a && hvalid < 3) {
-        hal_hrow(a + 2, hl[2]);
-        hvalid = 3;
-      }
-    }
-    v2f hal2[3];
-    if (rb.hal_y0 == ra.hal_y0) {
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float d = hl[1][ch] - hl[0][ch];
-        hal2[ch] = __builtin_elementwise_fma(v2f{ra.hal_wy, rb.hal_wy}, v2f{d, d}, v2f{hl[0][ch], hl[0][ch]});
-      }
-    } else if (rb.hal_y0 == ra.hal_y0 + 1) {
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch)
-        hal2[ch] = __builtin_elementwise_fma(v2f{ra.hal_wy, rb.hal_wy}, v2f{hl[1][ch], hl[2][ch]} - v2f{hl[0][ch], hl[1][ch]}, v2f{hl[0][ch], hl[1][ch]});
-    } else {   // never at magnification >= 1: the second row's pair on its own
-      float b0[3], b1[3];
-      hal_hrow(rb.hal_y0, b0);
-      hal_hrow(rb.hal_y0 + 1, b1);
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch)
-        hal2[ch] = v2f{fma_(ra.hal_wy, hl[1][ch] - hl[0][ch], hl[0][ch]), fma_(rb.hal_wy, b1[ch] - b0[ch], b0[ch])};
-    }
-    uint32_t pa, pb;
-    if (two) bh_compute<true>(c, v2f{ra.wy, rb.wy}, ia, ib, ja, jb, hal2, &pa, &pb);
-    else bh_compute<false>(c, v2f{0.f, 0.f}, ia, ib, ja, jb, hal2, &pa, &pb);
-    asm volatile("" ::: "memory");
-    const bool sa = live && (!mixed || rcd::lower_tri(x, y, W, H) == (SIDE == 0));
-    const bool sb = live && y + 1 < H && (!mixed || rcd::lower_tri(x, y + 1, W, H) == (SIDE == 0));
-    if (sa) __builtin_amdgcn_raw_buffer_store_b32(pa, r_out, x * 4, y * W * 4, 0);
-    if (sb) __builtin_amdgcn_raw_buffer_store_b32(pb, r_out, x * 4, (y + 1) * W * 4, 0);
-  }
+  for (int ch = 0; ch < 3; ++ch) s[ch] += w78 * h[ch];
 }
 
 __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const PassLaunch L, const uint32_t* __restrict__ cols,
-                                                                          const uint32_t* __restrict__ rows) {
+                                                                          const uint32_t* __restrict__ rows, const uint32_t* __restrict__ runs) {
   extern __shared__ uint32_t rc_dyn_lds_[];
+  if ((uint32_t)(uintptr_t)(RC_AS3 uint32_t*)rc_dyn_lds_ != 0u) __builtin_trap();   // see lds_f32
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* dec = reinterpret_cast<float*>(rc_dyn_lds_);
-  uint32_t* enc2 = rc_dyn_lds_ + 256;
-  for (int i = tid; i < 256; i += kBhWaves * 64) dec[i] = k_srgb_decode[i];
-  for (int i = tid; i < (int)kSrgb2Runs; i += kBhWaves * 64) enc2[i] = L.srgb_enc[kSrgbRuns + i];
+  for (int i = tid; i < 256; i += kBhWaves * 64) rc_dyn_lds_[i] = f2bits(k_srgb_decode[i]);
+  for (int i = tid; i < (int)kSrgb2Runs; i += kBhWaves * 64) rc_dyn_lds_[256 + i] = L.srgb_enc[kSrgbRuns + i];
   __syncthreads();
-  uint8_t* slots = reinterpret_cast<uint8_t*>(rc_dyn_lds_ + kBhLdsTables + wave * kBhWaveDwords);
-  const StripGrid<kBhRows> G(L.out_w, L.out_h, L.n_frames);
-  const int W = G.W, H = G.H;
-  for (int strip = (int)blockIdx.x * kBhWaves + wave; strip < G.total; strip += (int)gridDim.x * kBhWaves) {
-    int z, xw, ys;
-    G.locate(strip, &z, &xw, &ys);
-    // the lower triangle holds the pixels with (2y+1) W <= (2x+1) H: the strip is all lower if its (min x, max y)
-    // pixel is, all upper if its (max x, min y) pixel is not
-    const int xmax = min(xw + 63, W - 1), ymax = min(ys + kBhRows - 1, H - 1);
-    const bool all_lo = rcd::lower_tri(xw, ymax, W, H), all_up = !rcd::lower_tri(xmax, ys, W, H);
-    if (!all_up) bloomh_strip_side<0>(L, dec, enc2, slots, cols, rows, z, xw, ys, lane, !all_lo);
-    if (!all_lo) bloomh_strip_side<1>(L, dec, enc2, slots, cols, rows, z, xw, ys, lane, !all_up);
+  const uint32_t ring = (uint32_t)(kBhLdsTables + wave * kBhWaveDwords) * 4u;   // LDS offset of this wave's two row slots
+  const int W = L.out_w, H = L.out_h, Win = L.in.w, Hin = L.in.h;
+  const float* P = L.params;
+  const float w78 = P[RPG_W78], w56 = P[RPG_W56], w34 = P[RPG_W34], w12 = P[RPG_W12], si = P[RPG_SUM_INV];
+  const float c_main = (P[RPG_MASK_AMPLIFY] * 2.0f) * (1.0f - 0.075f);
+  const int i0w = L.extra[0].w, i1w = L.extra[1].w, hw = L.extra[2].w, hh = L.extra[2].h;
+  // this wave's run of consecutive (frame, band, row) steps: runs of equal estimated cost (launch_royale_bloom_h)
+  const int bands = (W + 127) >> 7;
+  const int me = (int)blockIdx.x * kBhWaves + wave;
+  long t = runs[me];
+  const long t_end = runs[me + 1];
+  const uint32_t e_main = ring + (uint32_t)lane * kBhColBytes;   // this lane's ring entries (slot 0): staged column `lane` ...
+  const uint32_t e_extra = e_main + 63u * kBhColBytes;           // ... and, lanes 0..20, staged column 63 + lane
+  while (t < t_end) {
+    const int z = (int)(t / ((long)bands * H));
+    const int rem = (int)(t - (long)z * bands * H);
+    const int band = rem / H, y_first = rem - band * H;
+    const int y_last = (int)min((long)H, (long)y_first + (t_end - t));   // exclusive
+    t += y_last - y_first;
+    const int xw = band << 7;
+    const int xa = xw + lane, xb = xa + 64;
+    const bool live_a = xa < W, live_b = xb < W;
+    const int xca = live_a ? xa : W - 1, xcb = live_b ? xb : W - 1;
+    const int xmax = min(xw + 127, W - 1);
+    // frame bases are wave-uniform, a lane's column offset is fixed for the band, the row base is a scalar: buffer accesses
+    // for the filtered input and the target, scalar-base global loads for the single taps
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frame_ptr(L.in, z)), 0, Win * Hin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out =
+        __builtin_amdgcn_make_buffer_rsrc(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z, 0, W * H * 4, 0x00020000);
+    const uint8_t* i0_base = frame_ptr(L.extra[0], z);
+    const uint8_t* i1_base = frame_ptr(L.extra[1], z);
+    const uint8_t* hal_base = frame_ptr(L.extra[2], z);
+    // staged columns: lane l holds staged column l (group A: source column xw - 10 + l, group B: 64 further right) and, for
+    // l < 21, staged column 63 + l; column 63 is staged twice: its main entry's differences are wrong (the DPP shift has
+    // no lane 64) and the extra batch, stored second, overwrites it
+    const int sxa0 = clampi(xw - kBhSegLeft + lane, 0, Win - 1) * 4, sxb0 = clampi(xw - kBhSegLeft + 64 + lane, 0, Win - 1) * 4;
+    const int sxa1 = clampi(xw - kBhSegLeft + 63 + lane, 0, Win - 1) * 4, sxb1 = clampi(xw - kBhSegLeft + 127 + lane, 0, Win - 1) * 4;
+    auto fetch = [&](int r, uint32_t* q) __attribute__((always_inline)) {
+      const int ro = clampi(r, 0, Hin - 1) * Win * 4;
+      q[0] = __builtin_amdgcn_raw_buffer_load_b32(r_in, sxa0, ro, 0);
+      q[1] = __builtin_amdgcn_raw_buffer_load_b32(r_in, sxb0, ro, 0);
+      q[2] = __builtin_amdgcn_raw_buffer_load_b32(r_in, sxa1, ro, 0);
+      q[3] = __builtin_amdgcn_raw_buffer_load_b32(r_in, sxb1, ro, 0);
+    };
+    // what of the source image is staged / in flight: rows are staged in increasing order into ring slot (row & 1)
+    int st_hi = -1000;           // highest source row in the ring
+    uint32_t q0[4], q1[4];       // raw texels (main A, main B, extra A, extra B) of rows st_q, st_q + 1, in flight
+    int st_q = -1000;
+    // the column quantities of the lane's two pixels for one triangle (`have_side`), reloaded when the triangle changes
+    BhBand c;
+    bool edge = false;
+    uint32_t idim_xa = 0u, idim_xb = 0u, bright_xa = 0u, bright_xb = 0u;
+    uint32_t hal_a0 = 0u, hal_a1 = 0u, hal_b0 = 0u, hal_b1 = 0u;   // byte offsets of the clamped halation texel pair, per pixel
+    v2f hal_w = {0.f, 0.f};
+    int have_side = -1;
+    // halation (320 x 240, magnified): the horizontally filtered rows hbase, hbase + 1 of the current row pair stay in
+    // registers; the texels of row hbase + 2 are fetched ahead
+    auto hal_fetch = [&](int r, uint32_t* q) __attribute__((always_inline)) {
+      const uint8_t* p = hal_base + (size_t)(clampi(r, 0, hh - 1) * hw) * 4u;
+      q[0] = *reinterpret_cast<const uint32_t*>(p + hal_a0);
+      q[1] = *reinterpret_cast<const uint32_t*>(p + hal_a1);
+      q[2] = *reinterpret_cast<const uint32_t*>(p + hal_b0);
+      q[3] = *reinterpret_cast<const uint32_t*>(p + hal_b1);
+    };
+    auto hal_filter = [&](const uint32_t* q, v2f* h) __attribute__((always_inline)) {   // the sampler's horizontal lerp, both pixels
+      const v2f l0 = {dec_byte<0>(q[0]), dec_byte<0>(q[2])}, r0 = {dec_byte<0>(q[1]), dec_byte<0>(q[3])};
+      const v2f l1 = {dec_byte<1>(q[0]), dec_byte<1>(q[2])}, r1 = {dec_byte<1>(q[1]), dec_byte<1>(q[3])};
+      const v2f l2 = {dec_byte<2>(q[0]), dec_byte<2>(q[2])}, r2 = {dec_byte<2>(q[1]), dec_byte<2>(q[3])};
+      h[0] = fma2(hal_w, r0 - l0, l0);
+      h[1] = fma2(hal_w, r1 - l1, l1);
+      h[2] = fma2(hal_w, r2 - l2, l2);
+    };
+    v2f hl0[3], hl1[3];
+    uint32_t hq[4];
+    int hbase = -1000, hq_row = -1000;
+    // walk the rows in blocks that do not straddle a multiple of kBhBlockRows
+    for (int yb = y_first; yb < y_last;) {
+      const int ye = min(y_last, (yb / kBhBlockRows + 1) * kBhBlockRows);
+      // the lower triangle holds the pixels with (2y+1) W <= (2x+1) H: the block is all lower if its (min x, max y)
+      // pixel is, all upper if its (max x, min y) pixel is not
+      const bool all_lo = rcd::lower_tri(xw, ye - 1, W, H), all_up = !rcd::lower_tri(xmax, yb, W, H);
+      for (int side = all_up ? 1 : 0; side <= (all_lo ? 0 : 1); ++side) {
+        const bool mixed = !all_lo && !all_up;
+        if (side != have_side) {
+          have_side = side;
+          hbase = hq_row = -1000;   // the halation rows in registers were filtered with the other triangle's columns
+          c.tap_d[0] = c.tap_d[1] = 0u;
+          edge = false;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            const int da = (int)cols[((BH_DX + q) * 2 + side) * W + xca] + (xca - xa), db = (int)cols[((BH_DX + q) * 2 + side) * W + xcb] + (xcb - xb);
+            c.tap_a[q] = ring + (uint32_t)(lane + kBhSegLeft + da) * (uint32_t)kBhColBytes;
+            c.tap_d[q / 5] |= ((uint32_t)(db - da) & 63u) << (6 * (q % 5));   // |db - da| <= 19 (k_bloomh_geometry)
+            c.wx[q] = v2f{bits2f(cols[((BH_WX + q) * 2 + side) * W + xca]), bits2f(cols[((BH_WX + q) * 2 + side) * W + xcb])};
+            if (q != 4 && __builtin_amdgcn_ballot_w64(da != db) != 0ull) edge = true;
+          }
+          idim_xa = cols[(BH_IDIM_X * 2 + side) * W + xca] * 4u;
+          idim_xb = cols[(BH_IDIM_X * 2 + side) * W + xcb] * 4u;
+          bright_xa = cols[(BH_BRIGHT_X * 2 + side) * W + xca] * 4u;
+          bright_xb = cols[(BH_BRIGHT_X * 2 + side) * W + xcb] * 4u;
+          const int ha = (int)cols[(BH_HAL_X0 * 2 + side) * W + xca], hb = (int)cols[(BH_HAL_X0 * 2 + side) * W + xcb];
+          hal_a0 = (uint32_t)clampi(ha, 0, hw - 1) * 4u;
+          hal_a1 = (uint32_t)clampi(ha + 1, 0, hw - 1) * 4u;
+          hal_b0 = (uint32_t)clampi(hb, 0, hw - 1) * 4u;
+          hal_b1 = (uint32_t)clampi(hb + 1, 0, hw - 1) * 4u;
+          hal_w = v2f{bits2f(cols[(BH_HAL_W * 2 + side) * W + xca]), bits2f(cols[(BH_HAL_W * 2 + side) * W + xcb])};
+        }
+        if (mixed && side == 1) st_hi = -1000;   // the block's rows once more: source rows from the top of the block again
+        BhRow nxt = load_bh_row(rows, yb, side);
+#pragma unroll 1
+        for (int y = yb; y < ye; ++y) {
+          const BhRow ra = nxt;
+          nxt = load_bh_row(rows, min(y + 1, H - 1), side);   // consumed by the next step
+          const bool two = ra.wy != 0.0f;
+          const int row_a = clampi(ra.y0, 0, Hin - 1), row_b = clampi(ra.y0 + 1, 0, Hin - 1);
+          const int need = two ? row_b : row_a;
+          // ---- stage the source rows this target row needs and the ring does not hold yet (normally one).  Other lanes read
+          // what a lane writes here: the LDS executes a wave's operations in order, the compiler must not reorder them
+          if (st_hi < row_a - 1 || st_hi > need + 1) st_hi = row_a - 1;
+          asm volatile("" ::: "memory");
+          while (st_hi < need) {
+            const int r = st_hi + 1;
+            if (st_q != r) {   // queue stale (start of a run, a jump): refill
+              fetch(r, q0);
+              fetch(r + 1, q1);
+              st_q = r;
+            }
+            const uint32_t slot = (r & 1) ? (uint32_t)kBhSlotBytes : 0u;
+            bh_stage_entry(e_main + slot, q0[0], q0[1]);
+            if (lane < kBhSeg - 63) bh_stage_entry(e_extra + slot, q0[2], q0[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q0[i] = q1[i];
+            fetch(r + 2, q1);
+            st_q = r + 1;
+            st_hi = r;
+          }
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+          // ---- the two NEAREST taps (issued behind the staging so that its waits do not cover them; consumed after the filter)
+          const uint8_t* i0_row = i0_base + (size_t)(ra.idim_y * i0w) * 4u;
+          const uint8_t* i1_row = i1_base + (size_t)(ra.bright_y * i1w) * 4u;
+          const uint32_t ia = *reinterpret_cast<const uint32_t*>(i0_row + idim_xa), ib = *reinterpret_cast<const uint32_t*>(i0_row + idim_xb);
+          const uint32_t ja = *reinterpret_cast<const uint32_t*>(i1_row + bright_xa), jb = *reinterpret_cast<const uint32_t*>(i1_row + bright_xb);
+          // ---- halation rows ra.hal_y0, + 1
+          if (ra.hal_y0 != hbase) {
+            if (ra.hal_y0 == hbase + 1) {
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) hl0[ch] = hl1[ch];
+            } else {
+              uint32_t q[4];
+              hal_fetch(ra.hal_y0, q);
+              hal_filter(q, hl0);
+            }
+            if (hq_row != ra.hal_y0 + 1) hal_fetch(ra.hal_y0 + 1, hq);
+            hal_filter(hq, hl1);
+            hbase = ra.hal_y0;
+            hq_row = hbase + 2;
+            hal_fetch(hq_row, hq);
+          }
+          // ---- filter
+          const uint32_t slot_a = (row_a & 1) ? (uint32_t)kBhSlotBytes : 0u, slot_b = (row_b & 1) ? (uint32_t)kBhSlotBytes : 0u;
+          v2f s[3];
+          if (!edge) {
+            if (two) bh_filter<true, false>(c, slot_a, slot_b, ra.wy, w78, w56, w34, w12, s);
+            else bh_filter<false, false>(c, slot_a, slot_a, 0.0f, w78, w56, w34, w12, s);
+          } else {
+            if (two) bh_filter<true, true>(c, slot_a, slot_b, ra.wy, w78, w56, w34, w12, s);
+            else bh_filter<false, true>(c, slot_a, slot_a, 0.0f, w78, w56, w34, w12, s);
+          }
+          // ---- reconstitute (as k_royale_bloom_h) and store
+          uint32_t oa = 0xff000000u, ob = 0xff000000u;
+          {
+            const v2f bl = s[0] * si;
+            const v2f dimpass = v2f{dec_byte<0>(ia), dec_byte<0>(ib)} - v2f{dec_byte<0>(ja), dec_byte<0>(jb)};
+            const v2f hal = fma2(v2f{ra.hal_wy, ra.hal_wy}, hl1[0] - hl0[0], hl0[0]);
+            const v2f o = (dimpass + bl) * c_main + hal * 0.075f;
+            oa |= bh_srgb8(o.x);
+            ob |= bh_srgb8(o.y);
+          }
+          {
+            const v2f bl = s[1] * si;
+            const v2f dimpass = v2f{dec_byte<1>(ia), dec_byte<1>(ib)} - v2f{dec_byte<1>(ja), dec_byte<1>(jb)};
+            const v2f hal = fma2(v2f{ra.hal_wy, ra.hal_wy}, hl1[1] - hl0[1], hl0[1]);
+            const v2f o = (dimpass + bl) * c_main + hal * 0.075f;
+            oa |= bh_srgb8(o.x) << 8;
+            ob |= bh_srgb8(o.y) << 8;
+          }
+          {
+            const v2f bl = s[2] * si;
+            const v2f dimpass = v2f{dec_byte<2>(ia), dec_byte<2>(ib)} - v2f{dec_byte<2>(ja), dec_byte<2>(jb)};
+            const v2f hal = fma2(v2f{ra.hal_wy, ra.hal_wy}, hl1[2] - hl0[2], hl0[2]);
+            const v2f o = (dimpass + bl) * c_main + hal * 0.075f;
+            oa |= bh_srgb8(o.x) << 16;
+            ob |= bh_srgb8(o.y) << 16;
+          }
+          asm volatile("" ::: "memory");
+          const bool sa = live_a && (!mixed || rcd::lower_tri(xa, y, W, H) == (side == 0));
+          const bool sb = live_b && (!mixed || rcd::lower_tri(xb, y, W, H) == (side == 0));
+          if (sa) __builtin_amdgcn_raw_buffer_store_b32(oa, r_out, xa * 4, y * W * 4, 0);
+          if (sb) __builtin_amdgcn_raw_buffer_store_b32(ob, r_out, xb * 4, y * W * 4, 0);
+        }
+      }
+      yb = ye;
+    }
   }
 }
 
@@ -609,11 +668,58 @@ void buildBhTables(const PassLaunch& L, hipStream_t s, BhTables* T) {
   }
   if (bad) (void)hipFree(bad);
   T->usable = ok && hbad == 0;
+  if (T->usable) {
+    // cost estimate per step, as the kernel will walk it: blocks of kBhBlockRows rows, per triangle the block touches;
+    // a row with a vertical weight filters two source rows (measured: about 1.45 x the work)
+    std::vector<uint32_t> hr(rowWords);
+    T->usable = hipMemcpy(hr.data(), T->rows, rowWords * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    const int W = L.out_w, H = L.out_h, bands = (W + 127) / 128;
+    auto lower = [&](int x, int y) { return (long)(2 * y + 1) * W <= (long)(2 * x + 1) * H; };
+    T->cost_sum.assign((size_t)bands * H + 1, 0u);
+    for (int b = 0; b < bands; ++b)
+      for (int y = 0; y < H; ++y) {
+        const int yb = y / kBhBlockRows * kBhBlockRows, ye = std::min(H, yb + kBhBlockRows);
+        const int xw = b * 128, xmax = std::min(xw + 127, W - 1);
+        const bool all_lo = lower(xw, ye - 1), all_up = !lower(xmax, yb);
+        uint32_t cost = 0;
+        for (int side = all_up ? 1 : 0; side <= (all_lo ? 0 : 1); ++side)
+          cost += bits2f(hr[((size_t)y * 2 + side) * BH_ROW_FIELDS + BH_WY]) != 0.0f ? 29u : 20u;
+        T->cost_sum[(size_t)b * H + y + 1] = T->cost_sum[(size_t)b * H + y] + cost;
+      }
+  }
   if (!T->usable) {
     if (T->cols) (void)hipFree(T->cols);
     if (T->rows) (void)hipFree(T->rows);
     *T = BhTables();
   }
+}
+
+// Where each wave's run of (frame, band, row) steps begins for a launch of n_frames frames on n_waves waves: runs of equal
+// estimated cost (n_waves + 1 entries in device memory, built once per (n_frames, n_waves) and kept with the tables).
+const uint32_t* bhRuns(BhTables* T, int n_frames, int n_waves) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = T->runs.find({n_frames, n_waves});
+  if (it != T->runs.end()) return it->second;
+  const size_t per_frame = T->cost_sum.size() - 1;
+  const uint64_t frame_cost = T->cost_sum.back(), total = frame_cost * (uint64_t)n_frames;
+  std::vector<uint32_t> h((size_t)n_waves + 1);
+  for (int w = 0; w <= n_waves; ++w) {
+    const uint64_t target = total * (uint64_t)w / (uint64_t)n_waves;
+    const uint64_t z = std::min<uint64_t>(target / frame_cost, (uint64_t)n_frames), rem = target - z * frame_cost;
+    // first step of frame z whose running cost reaches `rem`
+    const size_t i = (size_t)(std::lower_bound(T->cost_sum.begin(), T->cost_sum.end(), (uint32_t)rem) - T->cost_sum.begin());
+    h[(size_t)w] = (uint32_t)(z * per_frame + std::min(i, per_frame));
+  }
+  h[(size_t)n_waves] = (uint32_t)(per_frame * (size_t)n_frames);
+  uint32_t* d = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d), h.size() * 4) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(d);
+    return nullptr;
+  }
+  T->runs[{n_frames, n_waves}] = d;
+  return d;
 }
 
 }  // namespace
@@ -659,8 +765,11 @@ hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
       static std::mutex mu;
       static std::map<GeoKey, BhTables> cache;
       if (const BhTables* T = geo_tables<BhTables>(L, s, mu, cache, buildBhTables)) {
-        const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kBhRows - 1) / kBhRows) * L.n_frames;
-        const long blocks = (strips + kBhWaves - 1) / kBhWaves;
+        // one workgroup per CU; every wave gets a run of (frame, band, row) steps of equal estimated cost
+        const long steps = (long)((L.out_w + 127) / 128) * L.out_h * L.n_frames;
+        const long blocks = std::min<long>((steps + kBhWaves * 8 - 1) / (kBhWaves * 8), 256);
+        const uint32_t* runs = (uint64_t)steps < (1ull << 32) ? bhRuns(const_cast<BhTables*>(T), L.n_frames, (int)blocks * kBhWaves) : nullptr;
+        if (!runs) GO(k_royale_bloom_h<SrgbLinEdge, SrgbNearEdge, SrgbNearEdge, SrgbLinEdge, OutS>);
         const unsigned lds = (unsigned)(kBhLdsTables + kBhWaves * kBhWaveDwords) * 4u;
         auto kernel = k_royale_bloom_h_strip;
         static bool attr = false;
@@ -668,7 +777,7 @@ hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
           if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return hipGetLastError();
           attr = true;
         }
-        hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(kBhWaves * 64), lds, s, L, T->cols, T->rows);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBhWaves * 64), lds, s, L, T->cols, T->rows, runs);
         return hipGetLastError();
       }
     }
