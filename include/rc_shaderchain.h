@@ -271,9 +271,15 @@ int rc_selftest_srgb8_device_form(int device, const float* d_src, uint8_t* d_dst
  * expansion table of the beam function around its possible colours with a certified remainder bound
  * (csrc/kernels/pass_royale_scan.hip).  This returns the host-built part of that table for sub-pixel offset
  * `off` so that tests can check the bound against exact evaluations: A = [9][nodes][4] floats (0, dK/dc,
- * d2K/dc2 / 2, dK/ddist), B = [9][nodes][2] words (bound as float bits, node colour as float bits), index
+ * d2K/dc2 / 2, dK/ddist), B = [9][nodes][2] words (0, node colour as float bits: the bounds are measured on the device, below), index
  * 9 = scanline * 3 + channel.  Returns the node count (also with null pointers), negative on error. */
 int rc_selftest_royale_scan_tables(float off, float* A, uint32_t* B, size_t a_floats, size_t b_words);
+/* The complete tables as the device builds them for sub-pixel offset `off` and the row distances dists[0 .. n_dists) of a
+ * geometry: A = [9][nodes][4] floats WITH the node values (T, dK/dc, d2K/dc2 / 2, dK/ddist), bound = [9][nodes] floats - for
+ * every node the largest difference between the exact beam function and the expansion over EVERY float colour the node is
+ * selected for and every given distance, measured exhaustively on the device (see pass_royale_scan.hip).  Needs a GPU.
+ * Returns the node count, negative on error. */
+int rc_selftest_royale_scan_bounds(int device, float off, const float* dists, int n_dists, float* A, float* bound, size_t a_floats, size_t bound_floats);
 
 /* crt/crt-geom.glslp: what the shader's VERTEX stage hands every pixel (it depends on uniforms only), evaluated on the
  * host exactly as the engine does per launch (csrc/kernels/geom_math.h): params = the 17 #pragma parameters in

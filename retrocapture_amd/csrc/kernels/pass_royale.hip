@@ -8,10 +8,12 @@
 // uv scales) is computed once per launch on the host (royale_setup.cpp) with the same float
 // operations and handed over in PassLaunch::params / planes; the kernels do the per-pixel part.
 // One thread per target pixel, 64x4 workgroups, blockIdx.z = frame.
+#include <cmath>
 #include <cstdio>
+#include <vector>
 #include <cstdlib>
 
-#include "royale_strip.h"
+#include "royale_strip2.h"
 
 using namespace rcd;
 using namespace rcroyale;
@@ -676,6 +678,116 @@ __global__ void __launch_bounds__(512) k_royale_brightpass_strip(const PassLaunc
   }
 }
 
+// ---- P8, strip form, two pixels per lane (royale_strip2.h): columns x and x + 64 of a 128-column band, so the blur-ratio
+// algebra runs as packed float operations over the pixel pair.  The two IEEE divisions of a channel take div_safe_'s
+// sequence: the first divides 1 - 0.8 max_area, in [0.2, 1], by input * 8.86.. (a decoded byte: 0 or >= 3e-4; a zero input
+// makes the quotient NaN or infinite either way and the channel stores 0 either way: 0 * clamp(..) with clamp(NaN) = 0 as in
+// brightpass_pixel), the second divides by the launch constant center_weight - 1.  A strip the quad's diagonal crosses
+// is rendered once per triangle, each pixel stored by the pass of its own triangle.
+__device__ __forceinline__ v2f brightpass_pair(v2f in, v2f bl, float cw, float mask_amplify) {
+  using namespace rcstrip2;
+  const v2f intensity = (in * 2.0f) * mask_amplify;             // in * 2 * mask_amplify * 1
+  const v2f area = bl - cw * intensity;                         // 1 * blur - center_weight * intensity
+  const v2f max_area = {__builtin_fmaxf(area.x, 0.0f), __builtin_fmaxf(area.y, 0.0f)};
+  const v2f area_under = 0.8f * max_area;
+  const v2f int_under = in * ((2.0f * mask_amplify) * 0.8f);
+  const v2f q = div_safe2(1.0f - area_under, int_under);
+  const v2f ratio = div_safe2(q - 1.0f, splat2(cw - 1.0f));
+  const v2f cl = {__builtin_fminf(__builtin_fmaxf(ratio.x, 0.0f), 1.0f), __builtin_fminf(__builtin_fmaxf(ratio.y, 0.0f), 1.0f)};
+  return in * cl;
+}
+
+__global__ void __launch_bounds__(512) k_royale_brightpass_strip2(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
+  using namespace rcstrip2;
+  extern __shared__ uint32_t rc_dyn_lds_[];
+  strip2_load_tables(rc_dyn_lds_, L, true);
+  const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int W = L.out_w, H = L.out_h;
+  const int bands = (W + 127) >> 7, rss = (H + kBpRows - 1) / kBpRows, per_frame = bands * rss, total = per_frame * L.n_frames;
+  const Tex& blur = L.extra[0];
+  const float cw = L.params[RP8_CENTER_WEIGHT], mask_amplify = L.params[RP8_MASK_AMPLIFY];
+  for (int strip = (int)blockIdx.x * 8 + wave; strip < total; strip += (int)gridDim.x * 8) {
+    const int z = strip / per_frame, rem = strip - z * per_frame, rs = rem / bands;
+    const int xw = (rem - rs * bands) << 7, ys = rs * kBpRows;
+    const int xa = xw + lane, xb = xa + 64;
+    const bool live_a = xa < W, live_b = xb < W;
+    const int xca = live_a ? xa : W - 1, xcb = live_b ? xb : W - 1;
+    const int xmax = min(xw + 127, W - 1), ymax = min(ys + kBpRows - 1, H - 1);
+    const bool all_lo = rcd::lower_tri(xw, ymax, W, H), all_up = !rcd::lower_tri(xmax, ys, W, H);
+    const uint8_t* iimg = frame_ptr(L.in, z);
+    const uint8_t* bimg = frame_ptr(blur, z);
+    const __amdgpu_buffer_rsrc_t r_out = frame_rsrc(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z, W, H);
+    const int tri_a = (2 * xa + 1) * H, tri_b = (2 * xb + 1) * H;
+    for (int side = all_up ? 1 : 0; side <= (all_lo ? 0 : 1); ++side) {
+      const bool mixed = !all_lo && !all_up;
+      const uint32_t ixa = cols[(BP_IX * 2 + side) * W + xca] * 4u, ixb = cols[(BP_IX * 2 + side) * W + xcb] * 4u;
+      const int ba = (int)cols[(BP_BX0 * 2 + side) * W + xca], bb = (int)cols[(BP_BX0 * 2 + side) * W + xcb];
+      const uint32_t ba0 = (uint32_t)clampi(ba, 0, blur.w - 1) * 4u, ba1 = (uint32_t)clampi(ba + 1, 0, blur.w - 1) * 4u;
+      const uint32_t bb0 = (uint32_t)clampi(bb, 0, blur.w - 1) * 4u, bb1 = (uint32_t)clampi(bb + 1, 0, blur.w - 1) * 4u;
+      const v2f bwx = {bits2f(cols[(BP_BWX * 2 + side) * W + xca]), bits2f(cols[(BP_BWX * 2 + side) * W + xcb])};
+      auto hrow = [&](int r, v2f* h) __attribute__((always_inline)) {   // the sampler's horizontal lerp of blur row r (clamped), both pixels
+        const uint8_t* p = bimg + (size_t)(clampi(r, 0, blur.h - 1) * blur.w) * 4u;
+        const uint32_t a0 = *reinterpret_cast<const uint32_t*>(p + ba0), a1 = *reinterpret_cast<const uint32_t*>(p + ba1);
+        const uint32_t b0 = *reinterpret_cast<const uint32_t*>(p + bb0), b1 = *reinterpret_cast<const uint32_t*>(p + bb1);
+        const v2f l0 = {dec_byte<0>(a0), dec_byte<0>(b0)}, r0 = {dec_byte<0>(a1), dec_byte<0>(b1)};
+        const v2f l1 = {dec_byte<1>(a0), dec_byte<1>(b0)}, r1 = {dec_byte<1>(a1), dec_byte<1>(b1)};
+        const v2f l2 = {dec_byte<2>(a0), dec_byte<2>(b0)}, r2 = {dec_byte<2>(a1), dec_byte<2>(b1)};
+        h[0] = fma2(bwx, r0 - l0, l0);
+        h[1] = fma2(bwx, r1 - l1, l1);
+        h[2] = fma2(bwx, r2 - l2, l2);
+      };
+      v2f h0[3], h1[3], hd[3];
+      int have = -1000;
+      // the NEAREST tap of a row is fetched one step ahead
+      const uint32_t* r0p = rows + ((size_t)ys * 2 + side) * BP_ROW_FIELDS;
+      uint32_t nia = *reinterpret_cast<const uint32_t*>(iimg + (size_t)(r0p[BP_IY] * (uint32_t)L.in.w) * 4u + ixa);
+      uint32_t nib = *reinterpret_cast<const uint32_t*>(iimg + (size_t)(r0p[BP_IY] * (uint32_t)L.in.w) * 4u + ixb);
+#pragma unroll 1
+      for (int y = ys; y <= ymax; ++y) {
+        const uint32_t* rr = rows + ((size_t)y * 2 + side) * BP_ROW_FIELDS;
+        const int by0 = (int)rr[BP_BY0];
+        const float bwy = bits2f(rr[BP_BWY]);
+        const uint32_t ia = nia, ib = nib;
+        {
+          const uint32_t* rn = rows + ((size_t)min(y + 1, H - 1) * 2 + side) * BP_ROW_FIELDS;
+          const uint8_t* p = iimg + (size_t)(rn[BP_IY] * (uint32_t)L.in.w) * 4u;
+          nia = *reinterpret_cast<const uint32_t*>(p + ixa);
+          nib = *reinterpret_cast<const uint32_t*>(p + ixb);
+        }
+        uint32_t pa = 0xff000000u, pb = 0xff000000u;
+        // decode(0) = 0: a zero input stores 0 whatever the ratio (as the per-pixel form); skip rows that are black across the wave
+        if (__builtin_amdgcn_ballot_w64(((ia | ib) & 0x00ffffffu) != 0u) != 0ull) {
+          if (by0 != have) {
+            if (by0 == have + 1) {
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) h0[ch] = h1[ch];
+            } else {
+              hrow(by0, h0);
+            }
+            hrow(by0 + 1, h1);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) hd[ch] = h1[ch] - h0[ch];
+            have = by0;
+          }
+          v2f o[3];
+          o[0] = brightpass_pair(v2f{dec_byte<0>(ia), dec_byte<0>(ib)}, fma2(splat2(bwy), hd[0], h0[0]), cw, mask_amplify);
+          o[1] = brightpass_pair(v2f{dec_byte<1>(ia), dec_byte<1>(ib)}, fma2(splat2(bwy), hd[1], h0[1]), cw, mask_amplify);
+          o[2] = brightpass_pair(v2f{dec_byte<2>(ia), dec_byte<2>(ib)}, fma2(splat2(bwy), hd[2], h0[2]), cw, mask_amplify);
+          srgb8_pack2(o, &pa, &pb);
+        }
+        bool sa = live_a, sb = live_b;
+        if (mixed) {
+          const int tri_y = (2 * y + 1) * W;
+          sa = sa && (tri_y <= tri_a) == (side == 0);
+          sb = sb && (tri_y <= tri_b) == (side == 0);
+        }
+        if (sa) __builtin_amdgcn_raw_buffer_store_b32(pa, r_out, xa * 4, y * W * 4, 0);
+        if (sb) __builtin_amdgcn_raw_buffer_store_b32(pb, r_out, xb * 4, y * W * 4, 0);
+      }
+    }
+  }
+}
+
 void buildBpTables(const PassLaunch& L, hipStream_t s, BpTables* T) {
   bool ok = hipMalloc(reinterpret_cast<void**>(&T->cols), (size_t)BP_COL_FIELDS * 2 * L.out_w * 4) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&T->rows), (size_t)L.out_h * 2 * BP_ROW_FIELDS * 4) == hipSuccess;
@@ -762,8 +874,62 @@ enum { LS_Y0 = 0, LS_WY = 1, LS_BY = 2, LS_ROW_FIELDS = 4 };
 struct LastTables {
   uint32_t* cols = nullptr;   // [LS_COL_FIELDS][2][W]
   uint32_t* rows = nullptr;   // [H][2][LS_ROW_FIELDS]
+  float4* gamma_tab = nullptr;   // certified expansion of the output-gamma pow around every decoded byte (below), or null
   bool usable = false;
 };
+
+// ---- the output gamma from a table, with a proven bound ------------------------------------------------------------
+// At 1:1 the one LINEAR tap of a pixel lands on a texel centre up to float rounding: its weights are within kLastMaxW of 0
+// or 1 (k_last_geometry verifies it per column / row), so the sampled colour c is the decoded byte c0 of the pixel's own
+// texel plus a perturbation |delta| <= kLastMaxDelta, and away from the border the pass stores unorm8(G(c)), G(c) =
+// exp2(log2(c) / lcd_gamma) in the GL's polynomials.  Per byte the table holds T = G(c0) (the float the exact code computes),
+// the slope S, and Q, R such that |G(c) - fma(S, delta, T)| <= Q delta^2 + R for EVERY float c in [c0 - kLastMaxDelta,
+// c0 + kLastMaxDelta]: k_last_gamma_err evaluates the exact float G at all of them (about 40 M arguments per table) against
+// the very expression the strip kernel evaluates - a bound by exhaustion, not by sampling.  The strip kernel stores the
+// byte when the whole interval rounds to one byte (x -> rint(clamp(x) * 255) is monotone) and re-renders the few other
+// pixels with the exact per-pixel code.  Bytes 0 to 3 (colours within kLastMaxDelta of 0, where G has no expansion) carry
+// Q = 3e38: certain only for delta = 0.
+constexpr float kLastMaxW = 5e-4f;           // largest off-centre bilinear weight per axis
+constexpr float kLastMaxDelta = 1.05e-3f;    // > 2 * kLastMaxW * 1.0: largest |c - c0|
+constexpr float kLastInner = kLastMaxDelta / 256.0f;  // |delta| up to here defines R (the rounding noise of the exact evaluation)
+__device__ __forceinline__ float last_gamma(float c, float inv_gamma) { return exp2_(log2_(c) * inv_gamma); }   // = the strips' packed form per component
+__device__ __forceinline__ float last_node_colour(int b) { return k_srgb_decode[b]; }
+// phase 0: T; phase 1: R = max error for |delta| <= kLastInner; phase 2: Q = max (error - R) / delta^2 beyond
+__global__ void __launch_bounds__(256) k_last_gamma_err(float inv_gamma, float4* tab, int phase) {
+  const int b = (int)blockIdx.y;
+  const float c0 = last_node_colour(b);
+  if (phase == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) tab[b].x = last_gamma(c0, inv_gamma);
+    return;
+  }
+  if (b < 4) return;   // host: Q = 3e38, R = 0
+  const float4 e = tab[b];
+  const uint32_t lo = f2bits(c0 - kLastMaxDelta), hi = f2bits(fminf(c0 + kLastMaxDelta, 1.0f));   // c0 >= dec[4] > kLastMaxDelta: positive normals
+  uint32_t worst = 0u;
+  for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i <= hi; i += gridDim.x * 256u) {
+    const float c = bits2f(i), delta = c - c0;
+    const double err = fabs((double)last_gamma(c, inv_gamma) - (double)fma_(e.y, delta, e.x));
+    const bool inner = fabsf(delta) <= kLastInner;
+    if (phase == 1 && inner) worst = max(worst, f2bits(__double2float_ru(err)));
+    if (phase == 2 && !inner && err > (double)e.w) worst = max(worst, f2bits(__double2float_ru((err - (double)e.w) / ((double)delta * (double)delta))));
+  }
+  if (worst) atomicMax(reinterpret_cast<uint32_t*>(phase == 1 ? &tab[b].w : &tab[b].z), worst);   // non-negative floats order like their bits
+}
+// the stored bound absorbs the roundings of the strip kernel's own bound arithmetic (delta^2 and the two fmas, each within 2^-24
+// relative); the rounding of lin -+ bound itself (half an ulp of a value near lin) is added there, relative to lin
+__global__ void __launch_bounds__(256) k_last_gamma_finish(float4* tab) {
+  const int b = (int)threadIdx.x;
+  float4 e = tab[b];
+  if (b < 4) {
+    e.z = 3e38f;
+    e.w = 0.0f;
+  } else {
+    e.z = e.z * 1.000001f;
+    e.w = e.w * 1.000001f + 1e-12f;
+  }
+  tab[b] = e;
+}
+
 __global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint32_t* cols, uint32_t* rows, uint32_t* bad) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const float tsx = (float)L.in.w, tsy = (float)L.in.h;
@@ -777,6 +943,8 @@ __global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint3
       const float fu = u * (tsx * vsix);
       const float vu = (fu - 0.5f) / osx + 0.5f;
       const rcstrip::LinTap t = rcstrip::lin_tap(vu * (tsx * vsix), L.in.w);
+      // gamma table form: the pair is (x, x + 1) with a weight near 0 or (x - 1, x) with a weight near 1
+      if (!((t.i0 == i && t.w <= kLastMaxW) || (t.i0 == i - 1 && 1.0f - t.w <= kLastMaxW))) atomicOr(bad + 1, 1u);
       const float ex = minps(vu, 1.0f - vu) * P[RP11_ASPECT_X];
       cols[(LS_X0 * 2 + side) * L.out_w + i] = (uint32_t)t.i0;
       cols[(LS_WX * 2 + side) * L.out_w + i] = f2bits(t.w);
@@ -791,18 +959,42 @@ __global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint3
       const float ey = minps(vv, 1.0f - vv) * P[RP11_ASPECT_Y];
       uint32_t* r = rows + ((size_t)i * 2 + side) * LS_ROW_FIELDS;
       if (t.i0 < i - 1 || t.i0 > i) why |= 1u;   // the strip keeps rows y-1 .. y+2 of a row pair
+      if (!((t.i0 == i && t.w <= kLastMaxW) || (t.i0 == i - 1 && 1.0f - t.w <= kLastMaxW))) atomicOr(bad + 1, 2u);
       r[LS_Y0] = (uint32_t)t.i0;
       r[LS_WY] = f2bits(t.w);
       r[LS_BY] = f2bits(maxps(border_size - ey, 0.0f));
       r[3] = 0u;
     }
   if (!(border_size > 0.0f)) why |= 2u;   // border_size = 0 makes the penetration 0/0 everywhere: general form
+  if (L.in.w != L.out_w || L.in.h != L.out_h) atomicOr(bad + 1, 4u);
   if (why) atomicOr(bad, why);
 }
 
+constexpr uint32_t kLastLdsTab = 1024u;   // LDS byte offset of the gamma table (behind the decode table; the kernel has no static LDS)
+// one channel of one pixel from the gamma table: sampled colour c, the pixel's own texel `own` and its decoded value `c0`;
+// returns the byte, sets *fail when it is not certain
+template <int N>
+__device__ __forceinline__ uint32_t last_gamma_byte(float c, uint32_t own, float c0, bool* fail) {
+  typedef float last_v4f __attribute__((ext_vector_type(4)));
+  const last_v4f q = *reinterpret_cast<const RC_AS3 last_v4f*>((uintptr_t)(kLastLdsTab + rcstrip2::byte_shl<N, 4>(own)));
+  const float4 e = make_float4(q.x, q.y, q.z, q.w);
+  const float delta = c - c0;
+  const float lin = fma_(e.y, delta, e.x), bound = fma_(lin, 1.2e-7f, fma_(delta * delta, e.z, e.w));   // + 2^-23 lin: the two roundings below
+  const float ylo = __builtin_amdgcn_fmed3f(lin - bound, 0.0f, 1.0f) * 255.0f, yhi = __builtin_amdgcn_fmed3f(lin + bound, 0.0f, 1.0f) * 255.0f;
+  const float rlo = __builtin_rintf(ylo);
+  *fail = *fail || rlo != __builtin_rintf(yhi);
+  return (uint32_t)rlo;
+}
+
 template <class SO>
-__global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
+__global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows,
+                                                         const float4* __restrict__ gamma_tab) {
   RC_SRGB_LDS(lds, L);
+  if (gamma_tab) {   // uniform
+    if ((uint32_t)(uintptr_t)(RC_AS3 uint32_t*)rc_dyn_lds_ != 0u) __builtin_trap();   // the table is addressed by absolute LDS offsets
+    if (threadIdx.x < 256) reinterpret_cast<float4*>(rc_dyn_lds_ + kLastLdsTab / 4)[threadIdx.x] = gamma_tab[threadIdx.x];
+    __syncthreads();
+  }
   const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const rcstrip::StripGrid<kLastRows> G(L.out_w, L.out_h, L.n_frames);
   const int W = G.W, H = G.H, Win = L.in.w, Hin = L.in.h;
@@ -823,25 +1015,34 @@ __global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, c
     const int x0 = (int)cols[(LS_X0 * 2 + side) * W + x];
     const float wx = bits2f(cols[(LS_WX * 2 + side) * W + x]), bx = bits2f(cols[(LS_BX * 2 + side) * W + x]);
     const int xa = clampi(x0, 0, Win - 1), xb = clampi(x0 + 1, 0, Win - 1);
+    const bool own_b = x0 < x;   // the pixel's own texel is the pair's second one
+    // the gamma table serves pixels away from the border (border factor exactly 1): strips whose columns all are
+    const bool tab_cols = gamma_tab != nullptr && __builtin_amdgcn_ballot_w64(bx != 0.0f) == 0ull;
     const uint32_t* img = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
-    auto hrow = [&](int r, float* h) {   // the sampler's horizontal lerp of source row r (clamped), three channels
+    // the sampler's horizontal lerp of source row r (clamped), three channels; the pixel's own texel of that row, decoded and raw
+    auto hrow = [&](int r, float* h, float* own_c, uint32_t* own_t) {
       const uint32_t* p = img + clampi(r, 0, Hin - 1) * Win;
       const uint32_t ta = p[xa], tb = p[xb];
+      *own_t = own_b ? tb : ta;
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         const float a = lds.dec[(ta >> (8 * ch)) & 255u], b = lds.dec[(tb >> (8 * ch)) & 255u];
         h[ch] = fma_(wx, b - a, a);
+        own_c[ch] = own_b ? b : a;
       }
     };
     float w0[3], w1[3], w2[3], w3[3];   // rows y-1, y, y+1, y+2 of the current row pair
-    hrow(ys - 1, w0);
-    hrow(ys, w1);
+    float c1[3], c2[3], c3[3];          // the own texel of rows y, y+1, y+2, decoded ...
+    uint32_t t1, t2, t3;                // ... and raw
+    hrow(ys - 1, w0, c1, &t1);
+    hrow(ys, w1, c1, &t1);
+    uint32_t failed = 0u;   // bit k: row ys + k of this column is not certain from the table
 #pragma unroll
     for (int k = 0; k < kLastRows; k += 2) {
       const int y = ys + k;
       if (y >= H) break;
-      hrow(y + 1, w2);
-      hrow(y + 2, w3);
+      hrow(y + 1, w2, c2, &t2);
+      hrow(y + 2, w3, c3, &t3);
       const uint32_t* ra = rows + ((size_t)y * 2 + side) * LS_ROW_FIELDS;
       const uint32_t* rb = rows + ((size_t)min(y + 1, H - 1) * 2 + side) * LS_ROW_FIELDS;
       const bool a_up = (int)ra[LS_Y0] == y - 1, b_up = (int)rb[LS_Y0] == y;   // the pair starts one row above the target row
@@ -854,46 +1055,91 @@ __global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, c
         ca[ch] = fma_(wya, ha - la, la);
         cb[ch] = fma_(wyb, hb - lb, lb);
       }
-      // border dimming (get_border_dim_factor, as k_royale_last): 1 unless the pixel is within border_size of an edge
-      auto dim = [&](float by) -> float {
-        float f = 1.0f;
-        if (bx != 0.0f || by != 0.0f) {
-          const float pen = __builtin_sqrtf(bx * bx + by * by) / border_size;
-          const float esc = maxps(1.0f - pen, 0.0f);
-          f = minps(pow_(esc, border_darkness) * maxps(1.0f, border_compress), 1.0f);
+      if (tab_cols && bya == 0.0f && byb == 0.0f) {   // uniform: both rows away from the border
+        bool fa = false, fb = false;
+        const uint32_t pa = 0xff000000u | last_gamma_byte<0>(ca[0], t1, c1[0], &fa) | (last_gamma_byte<1>(ca[1], t1, c1[1], &fa) << 8) |
+                            (last_gamma_byte<2>(ca[2], t1, c1[2], &fa) << 16);
+        const uint32_t pb = 0xff000000u | last_gamma_byte<0>(cb[0], t2, c2[0], &fb) | (last_gamma_byte<1>(cb[1], t2, c2[1], &fb) << 8) |
+                            (last_gamma_byte<2>(cb[2], t2, c2[2], &fb) << 16);
+        uint32_t* out = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z);
+        if (!fa) out[(size_t)y * W + x] = pa; else failed |= 1u << k;
+        if (y + 1 < H) {
+          if (!fb) out[(size_t)(y + 1) * W + x] = pb; else failed |= 2u << k;
         }
-        return f;
-      };
-      const float fa = dim(bya), fb = dim(byb);
-      // six output-gamma pows as three packed pairs
-      const v2f rg_a = exp2_v<v2f>(log2_v(v2f{ca[0] * fa, ca[1] * fa}) * inv_gamma);
-      const v2f rg_b = exp2_v<v2f>(log2_v(v2f{cb[0] * fb, cb[1] * fb}) * inv_gamma);
-      const v2f bb = exp2_v<v2f>(log2_v(v2f{ca[2] * fa, cb[2] * fb}) * inv_gamma);
-      SO::put(L, z, x, y, make_float4(rg_a.x, rg_a.y, bb.x, 1.0f), &lds);
-      if (y + 1 < H) SO::put(L, z, x, y + 1, make_float4(rg_b.x, rg_b.y, bb.y, 1.0f), &lds);
+      } else {
+        // border dimming (get_border_dim_factor, as k_royale_last): 1 unless the pixel is within border_size of an edge
+        auto dim = [&](float by) -> float {
+          float f = 1.0f;
+          if (bx != 0.0f || by != 0.0f) {
+            const float pen = __builtin_sqrtf(bx * bx + by * by) / border_size;
+            const float esc = maxps(1.0f - pen, 0.0f);
+            f = minps(pow_(esc, border_darkness) * maxps(1.0f, border_compress), 1.0f);
+          }
+          return f;
+        };
+        const float fa = dim(bya), fb = dim(byb);
+        // six output-gamma pows as three packed pairs
+        const v2f rg_a = exp2_v<v2f>(log2_v(v2f{ca[0] * fa, ca[1] * fa}) * inv_gamma);
+        const v2f rg_b = exp2_v<v2f>(log2_v(v2f{cb[0] * fb, cb[1] * fb}) * inv_gamma);
+        const v2f bb = exp2_v<v2f>(log2_v(v2f{ca[2] * fa, cb[2] * fb}) * inv_gamma);
+        SO::put(L, z, x, y, make_float4(rg_a.x, rg_a.y, bb.x, 1.0f), &lds);
+        if (y + 1 < H) SO::put(L, z, x, y + 1, make_float4(rg_b.x, rg_b.y, bb.y, 1.0f), &lds);
+      }
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         w0[ch] = w2[ch];
         w1[ch] = w3[ch];
+        c1[ch] = c3[ch];
+      }
+      t1 = t3;
+    }
+    // the pixels the table could not certify: the exact per-pixel form (a few per strip)
+    while (__builtin_amdgcn_ballot_w64(failed != 0u) != 0ull) {
+      if (failed) {
+        const int k = __builtin_ctz(failed);
+        failed &= failed - 1u;
+        last_pixel<SrgbLinEdge, SO, false>(L, lds, x, ys + k, z, side == 0);
       }
     }
   }
 }
 
 void buildLastTables(const PassLaunch& L, hipStream_t s, LastTables* T) {
-  uint32_t* bad = nullptr;
+  uint32_t* bad = nullptr;   // [0]: the strip form does not apply, [1]: the gamma table does not
   bool ok = hipMalloc(reinterpret_cast<void**>(&T->cols), (size_t)LS_COL_FIELDS * 2 * L.out_w * 4) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&T->rows), (size_t)L.out_h * 2 * LS_ROW_FIELDS * 4) == hipSuccess &&
-            hipMalloc(reinterpret_cast<void**>(&bad), 4) == hipSuccess;
-  uint32_t hbad = 1;
-  if (ok) ok = hipMemsetAsync(bad, 0, 4, s) == hipSuccess;
+            hipMalloc(reinterpret_cast<void**>(&bad), 8) == hipSuccess;
+  uint32_t hbad[2] = {1, 1};
+  if (ok) ok = hipMemsetAsync(bad, 0, 8, s) == hipSuccess;
   if (ok) {
     const int n = L.out_w > L.out_h ? L.out_w : L.out_h;
     hipLaunchKernelGGL(k_last_geometry, dim3((n + 255) / 256), dim3(256), 0, s, L, T->cols, T->rows, bad);
-    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(hbad, bad, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
   }
   if (bad) (void)hipFree(bad);
-  T->usable = ok && hbad == 0;
+  T->usable = ok && hbad[0] == 0;
+  if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc last] %dx%d: ok %d strip flags %u, gamma table flags %u\n", L.out_w, L.out_h, (int)ok, hbad[0], hbad[1]);
+  if (T->usable && hbad[1] == 0 && hipMalloc(reinterpret_cast<void**>(&T->gamma_tab), 256 * sizeof(float4)) == hipSuccess) {
+    // slopes from the closed form in double precision (any slope is valid: the bound is measured against what is stored)
+    const float inv_gamma = 1.0f / L.params[1];
+    std::vector<float4> h(256);
+    for (int b = 0; b < 256; ++b) {
+      const double c0 = (double)k_srgb_decode_host[b];
+      h[(size_t)b] = make_float4(0.0f, b < 4 ? 0.0f : (float)((double)inv_gamma * std::pow(c0, (double)inv_gamma - 1.0)), 0.0f, 0.0f);
+    }
+    bool tok = hipMemcpyAsync(T->gamma_tab, h.data(), 256 * sizeof(float4), hipMemcpyHostToDevice, s) == hipSuccess;
+    if (tok) {
+      hipLaunchKernelGGL(k_last_gamma_err, dim3(1, 256), dim3(256), 0, s, inv_gamma, T->gamma_tab, 0);
+      hipLaunchKernelGGL(k_last_gamma_err, dim3(64, 256), dim3(256), 0, s, inv_gamma, T->gamma_tab, 1);
+      hipLaunchKernelGGL(k_last_gamma_err, dim3(64, 256), dim3(256), 0, s, inv_gamma, T->gamma_tab, 2);
+      hipLaunchKernelGGL(k_last_gamma_finish, dim3(1), dim3(256), 0, s, T->gamma_tab);
+      tok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;   // h must outlive the copy
+    }
+    if (!tok) {
+      (void)hipFree(T->gamma_tab);
+      T->gamma_tab = nullptr;
+    }
+  }
   if (!T->usable) {
     if (T->cols) (void)hipFree(T->cols);
     if (T->rows) (void)hipFree(T->rows);
@@ -985,10 +1231,9 @@ hipError_t launch_royale_brightpass(const PassLaunch& L, hipStream_t s) {
       static std::mutex mu;
       static std::map<rcstrip::GeoKey, BpTables> cache;
       if (const BpTables* T = rcstrip::geo_tables<BpTables>(L, s, mu, cache, buildBpTables)) {
-        const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kBpRows - 1) / kBpRows) * L.n_frames;
+        const long strips = (long)((L.out_w + 127) / 128) * ((L.out_h + kBpRows - 1) / kBpRows) * L.n_frames;
         const long blocks = (strips + 7) / 8;
-        hipLaunchKernelGGL((k_royale_brightpass_strip<OutS>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512), rcd::srgb_lds_bytes(L), s, L,
-                           T->cols, T->rows);
+        hipLaunchKernelGGL(k_royale_brightpass_strip2, dim3((unsigned)(blocks < 768 ? blocks : 768)), dim3(512), rcstrip2::kStrip2LdsUser, s, L, T->cols, T->rows);
         return hipGetLastError();
       }
     }
@@ -1011,8 +1256,8 @@ hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
       if (const LastTables* T = rcstrip::geo_tables<LastTables>(L, s, mu, cache, buildLastTables)) {
         const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kLastRows - 1) / kLastRows) * L.n_frames;
         const long blocks = (strips + 7) / 8;
-        hipLaunchKernelGGL((k_royale_last_strip<St<FMT_RGBA8>>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512), rcd::srgb_lds_bytes(L), s, L,
-                           T->cols, T->rows);
+        hipLaunchKernelGGL((k_royale_last_strip<St<FMT_RGBA8>>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512),
+                           rcd::srgb_lds_bytes(L) + 256 * sizeof(float4), s, L, T->cols, T->rows, T->gamma_tab);
         return hipGetLastError();
       }
     }

@@ -5,11 +5,12 @@
 #include <vector>
 #include <cstdlib>
 
-#include "royale_strip.h"
+#include "royale_strip2.h"
 
 using namespace rcd;
 using namespace rcroyale;
 using namespace rcstrip;
+using namespace rcstrip2;
 
 namespace {
 
@@ -230,7 +231,6 @@ constexpr int kBhSeg = 84;        // staged columns per group: 10 + 64 + 10
 constexpr int kBhSegLeft = 10;
 constexpr int kBhColBytes = 48;                       // three channels x {T_A, T_B, D_A, D_B}
 constexpr int kBhSlotBytes = kBhSeg * kBhColBytes;    // 4032: one staged source row
-constexpr int kBhLdsTables = (256 + (int)kSrgb2Runs + 3) & ~3;   // dwords: decode table, second-form encode table
 constexpr int kBhWaveDwords = 2 * kBhSlotBytes / 4;   // per wave: a ring of two staged rows (row r in slot r & 1)
 enum { BH_DX = 0, BH_WX = 9, BH_IDIM_X = 18, BH_BRIGHT_X = 19, BH_HAL_X0 = 20, BH_HAL_W = 21, BH_COL_FIELDS = 22 };
 enum { BH_Y0 = 0, BH_WY = 1, BH_IDIM_Y = 2, BH_BRIGHT_Y = 3, BH_HAL_Y0 = 4, BH_HAL_WY = 5, BH_ROW_FIELDS = 8 };
@@ -299,48 +299,34 @@ __global__ void __launch_bounds__(256) k_bloomh_geometry(const PassLaunch L, uin
   if (why) atomicOr(bad, why);
 }
 
-typedef float v4f __attribute__((ext_vector_type(4)));
-
 struct BhRow {
   int y0;
   float wy;
   int idim_y, bright_y, hal_y0;
   float hal_wy;
 };
-__device__ __forceinline__ BhRow load_bh_row(const uint32_t* __restrict__ rows, int y, int side) {
-  const uint32_t* r = rows + ((size_t)y * 2 + side) * BH_ROW_FIELDS;
-  return BhRow{(int)r[BH_Y0], bits2f(r[BH_WY]), (int)r[BH_IDIM_Y], (int)r[BH_BRIGHT_Y], (int)r[BH_HAL_Y0], bits2f(r[BH_HAL_WY])};
+// A row's quantities, fetched one step ahead.  They are wave-uniform, but a scalar load in flight would turn every LDS wait of
+// the step into a full drain (scalar loads return out of order, so the compiler waits for lgkmcnt(0) while one is pending):
+// the record is fetched through the vector path (every lane the same address) and moved to scalar registers when it is used.
+struct BhRowRaw {
+  v4u a;
+  v2u32 b;
+};
+__device__ __forceinline__ BhRowRaw fetch_bh_row(__amdgpu_buffer_rsrc_t r_rows, int y, int side) {
+  const int off = (y * 2 + side) * BH_ROW_FIELDS * 4;
+  BhRowRaw r;
+  r.a = __builtin_amdgcn_raw_buffer_load_b128(r_rows, 0, off, 0);
+  r.b = __builtin_amdgcn_raw_buffer_load_b64(r_rows, 0, off + 16, 0);
+  return r;
+}
+__device__ __forceinline__ BhRow use_bh_row(const BhRowRaw& r) {
+  return BhRow{(int)__builtin_amdgcn_readfirstlane(r.a.x), bits2f(__builtin_amdgcn_readfirstlane(r.a.y)), (int)__builtin_amdgcn_readfirstlane(r.a.z),
+               (int)__builtin_amdgcn_readfirstlane(r.a.w), (int)__builtin_amdgcn_readfirstlane(r.b.x), bits2f(__builtin_amdgcn_readfirstlane(r.b.y))};
 }
 
-// LDS accesses of this kernel go through absolute byte offsets (the kernel has no static LDS, so its dynamic LDS starts
-// at 0 - checked once at kernel entry): an address is a register the arithmetic left it in, plus an immediate.
-#define RC_AS3 __attribute__((address_space(3)))
-__device__ __forceinline__ float lds_f32(uint32_t off) { return *reinterpret_cast<const RC_AS3 float*>((uintptr_t)off); }
-__device__ __forceinline__ uint32_t lds_u32(uint32_t off) { return *reinterpret_cast<const RC_AS3 uint32_t*>((uintptr_t)off); }
-__device__ __forceinline__ v4f lds_v4f(uint32_t off) { return *reinterpret_cast<const RC_AS3 v4f*>((uintptr_t)off); }
-__device__ __forceinline__ void lds_put_v4f(uint32_t off, v4f v) { *reinterpret_cast<RC_AS3 v4f*>((uintptr_t)off) = v; }
-constexpr uint32_t kBhLdsDec = 0u, kBhLdsEnc = 1024u;   // byte offsets of the decode table and of the second-form encode table
-
-// value of the next lane (lane 63: 0); the compiler folds the move into the subtraction that consumes it (v_sub_f32_dpp)
-__device__ __forceinline__ float next_lane_dpp(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
-}
-// the decoded value of byte N of texel t: its offset in the table of floats at LDS offset 0 is one SDWA instruction
-template <int N>
-__device__ __forceinline__ float dec_byte(uint32_t t) {
-  uint32_t r;
-  if (N == 0) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(t));
-  if (N == 1) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(t));
-  if (N == 2) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(t));
-  return lds_f32(kBhLdsDec + r);
-}
-__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-// srgb8_t2 (rc_device.h) on the table at kBhLdsEnc
-__device__ __forceinline__ uint32_t bh_srgb8(float x) {
-  const uint32_t b = f2bits(__builtin_amdgcn_fmed3f(x, bits2f(kSrgb2MinBits), 1.0f));
-  const uint32_t e = lds_u32(((b >> 13) << 2) + (kBhLdsEnc - (kSrgb2Run0 << 2)));
-  return ((e + (b & 0x1fffu)) >> 13) & 255u;
-}
+// LDS accesses, the decode / encode tables and the packed helpers: royale_strip2.h
+constexpr uint32_t kBhLdsUser = rcstrip2::kStrip2LdsUser;
+__device__ __forceinline__ uint32_t bh_srgb8(float x) { return srgb8_lds(x); }
 
 // One source row of this lane's staged column (its texel in group A and in group B) into its ring entry: decode, difference
 // to the next staged column, one 16-byte store per channel.
@@ -363,10 +349,14 @@ struct BhBand {   // per-band lane state of one triangle
   uint32_t tap_a[9];   // LDS offset of tap q's entry in ring slot 0, for the lane's pixel in group A
   uint32_t tap_d[2];   // ... and, packed 6 bits per tap, how many staged columns further right group B's pixel starts
                        // (0 where both pixels' taps start at the same offset: every tap but the centre one, away from the edges)
+  uint32_t tap_b4;     // the centre tap's entry for the pixel in group B
   v2f wx[9];
 };
 __device__ __forceinline__ uint32_t bh_tap_b(const BhBand& c, int q) {
-  const int d = ((int)(c.tap_d[q / 5] << (26 - 6 * (q % 5)))) >> 26;   // signed 6-bit field
+  if (q == 4) return c.tap_b4;
+  uint32_t packed = c.tap_d[q / 5];
+  asm volatile("" : "+v"(packed));   // edge bands only: unpack where it is used instead of holding eight more registers across the band
+  const int d = ((int)(packed << (26 - 6 * (q % 5)))) >> 26;   // signed 6-bit field
   return c.tap_a[q] + (uint32_t)(d * kBhColBytes);
 }
 
@@ -441,13 +431,10 @@ __device__ __forceinline__ void bh_filter(const BhBand& c, uint32_t slot_a, uint
 __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const PassLaunch L, const uint32_t* __restrict__ cols,
                                                                           const uint32_t* __restrict__ rows, const uint32_t* __restrict__ runs) {
   extern __shared__ uint32_t rc_dyn_lds_[];
-  if ((uint32_t)(uintptr_t)(RC_AS3 uint32_t*)rc_dyn_lds_ != 0u) __builtin_trap();   // see lds_f32
+  strip2_load_tables(rc_dyn_lds_, L, true);
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 256; i += kBhWaves * 64) rc_dyn_lds_[i] = f2bits(k_srgb_decode[i]);
-  for (int i = tid; i < (int)kSrgb2Runs; i += kBhWaves * 64) rc_dyn_lds_[256 + i] = L.srgb_enc[kSrgbRuns + i];
-  __syncthreads();
-  const uint32_t ring = (uint32_t)(kBhLdsTables + wave * kBhWaveDwords) * 4u;   // LDS offset of this wave's two row slots
+  const uint32_t ring = kBhLdsUser + (uint32_t)(wave * kBhWaveDwords) * 4u;   // LDS offset of this wave's two row slots
   const int W = L.out_w, H = L.out_h, Win = L.in.w, Hin = L.in.h;
   const float* P = L.params;
   const float w78 = P[RPG_W78], w56 = P[RPG_W56], w34 = P[RPG_W34], w12 = P[RPG_W12], si = P[RPG_SUM_INV];
@@ -476,6 +463,7 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
     const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frame_ptr(L.in, z)), 0, Win * Hin * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_out =
         __builtin_amdgcn_make_buffer_rsrc(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z, 0, W * H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rows = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(rows), 0, H * 2 * BH_ROW_FIELDS * 4, 0x00020000);
     const uint8_t* i0_base = frame_ptr(L.extra[0], z);
     const uint8_t* i1_base = frame_ptr(L.extra[1], z);
     const uint8_t* hal_base = frame_ptr(L.extra[2], z);
@@ -519,7 +507,7 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
       h[1] = fma2(hal_w, r1 - l1, l1);
       h[2] = fma2(hal_w, r2 - l2, l2);
     };
-    v2f hl0[3], hl1[3];
+    v2f hl0[3], hl1[3], hld[3];   // rows hbase, hbase + 1 and their difference
     uint32_t hq[4];
     int hbase = -1000, hq_row = -1000;
     // walk the rows in blocks that do not straddle a multiple of kBhBlockRows
@@ -541,6 +529,7 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
             c.tap_a[q] = ring + (uint32_t)(lane + kBhSegLeft + da) * (uint32_t)kBhColBytes;
             c.tap_d[q / 5] |= ((uint32_t)(db - da) & 63u) << (6 * (q % 5));   // |db - da| <= 19 (k_bloomh_geometry)
             c.wx[q] = v2f{bits2f(cols[((BH_WX + q) * 2 + side) * W + xca]), bits2f(cols[((BH_WX + q) * 2 + side) * W + xcb])};
+            if (q == 4) c.tap_b4 = ring + (uint32_t)(lane + kBhSegLeft + db) * (uint32_t)kBhColBytes;
             if (q != 4 && __builtin_amdgcn_ballot_w64(da != db) != 0ull) edge = true;
           }
           idim_xa = cols[(BH_IDIM_X * 2 + side) * W + xca] * 4u;
@@ -555,11 +544,28 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
           hal_w = v2f{bits2f(cols[(BH_HAL_W * 2 + side) * W + xca]), bits2f(cols[(BH_HAL_W * 2 + side) * W + xcb])};
         }
         if (mixed && side == 1) st_hi = -1000;   // the block's rows once more: source rows from the top of the block again
-        BhRow nxt = load_bh_row(rows, yb, side);
+        BhRowRaw nxt_raw = fetch_bh_row(r_rows, yb, side);
+        BhRow nxt = use_bh_row(nxt_raw);
+        // the two NEAREST taps of a row (MASKED_SCANLINES, BRIGHTPASS) are fetched one step ahead, like the row quantities
+        uint32_t nia, nib, nja, njb;
+        auto near_fetch = [&](const BhRow& r) __attribute__((always_inline)) {
+          const uint8_t* i0_row = i0_base + (size_t)(r.idim_y * i0w) * 4u;
+          const uint8_t* i1_row = i1_base + (size_t)(r.bright_y * i1w) * 4u;
+          nia = *reinterpret_cast<const uint32_t*>(i0_row + idim_xa);
+          nib = *reinterpret_cast<const uint32_t*>(i0_row + idim_xb);
+          nja = *reinterpret_cast<const uint32_t*>(i1_row + bright_xa);
+          njb = *reinterpret_cast<const uint32_t*>(i1_row + bright_xb);
+        };
+        near_fetch(nxt);
+        nxt_raw = fetch_bh_row(r_rows, min(yb + 1, H - 1), side);
+        // mixed blocks: a pixel is stored by the pass of its own triangle, (2y+1) W <= (2x+1) H tells which
+        const int tri_a = (2 * xa + 1) * H, tri_b = (2 * xb + 1) * H;
 #pragma unroll 1
         for (int y = yb; y < ye; ++y) {
           const BhRow ra = nxt;
-          nxt = load_bh_row(rows, min(y + 1, H - 1), side);   // consumed by the next step
+          nxt = use_bh_row(nxt_raw);                                      // row y + 1, fetched during the previous step
+          nxt_raw = fetch_bh_row(r_rows, min(y + 2, H - 1), side);        // row y + 2
+          const uint32_t ia = nia, ib = nib, ja = nja, jb = njb;
           const bool two = ra.wy != 0.0f;
           const int row_a = clampi(ra.y0, 0, Hin - 1), row_b = clampi(ra.y0 + 1, 0, Hin - 1);
           const int need = two ? row_b : row_a;
@@ -585,11 +591,7 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
           }
           asm volatile("" ::: "memory");
           __builtin_amdgcn_wave_barrier();
-          // ---- the two NEAREST taps (issued behind the staging so that its waits do not cover them; consumed after the filter)
-          const uint8_t* i0_row = i0_base + (size_t)(ra.idim_y * i0w) * 4u;
-          const uint8_t* i1_row = i1_base + (size_t)(ra.bright_y * i1w) * 4u;
-          const uint32_t ia = *reinterpret_cast<const uint32_t*>(i0_row + idim_xa), ib = *reinterpret_cast<const uint32_t*>(i0_row + idim_xb);
-          const uint32_t ja = *reinterpret_cast<const uint32_t*>(i1_row + bright_xa), jb = *reinterpret_cast<const uint32_t*>(i1_row + bright_xb);
+          near_fetch(nxt);   // (issued behind the staging, so that its waits do not cover these loads)
           // ---- halation rows ra.hal_y0, + 1
           if (ra.hal_y0 != hbase) {
             if (ra.hal_y0 == hbase + 1) {
@@ -602,6 +604,8 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
             }
             if (hq_row != ra.hal_y0 + 1) hal_fetch(ra.hal_y0 + 1, hq);
             hal_filter(hq, hl1);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) hld[ch] = hl1[ch] - hl0[ch];
             hbase = ra.hal_y0;
             hq_row = hbase + 2;
             hal_fetch(hq_row, hq);
@@ -621,7 +625,7 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
           {
             const v2f bl = s[0] * si;
             const v2f dimpass = v2f{dec_byte<0>(ia), dec_byte<0>(ib)} - v2f{dec_byte<0>(ja), dec_byte<0>(jb)};
-            const v2f hal = fma2(v2f{ra.hal_wy, ra.hal_wy}, hl1[0] - hl0[0], hl0[0]);
+            const v2f hal = fma2(v2f{ra.hal_wy, ra.hal_wy}, hld[0], hl0[0]);
             const v2f o = (dimpass + bl) * c_main + hal * 0.075f;
             oa |= bh_srgb8(o.x);
             ob |= bh_srgb8(o.y);
@@ -629,7 +633,7 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
           {
             const v2f bl = s[1] * si;
             const v2f dimpass = v2f{dec_byte<1>(ia), dec_byte<1>(ib)} - v2f{dec_byte<1>(ja), dec_byte<1>(jb)};
-            const v2f hal = fma2(v2f{ra.hal_wy, ra.hal_wy}, hl1[1] - hl0[1], hl0[1]);
+            const v2f hal = fma2(v2f{ra.hal_wy, ra.hal_wy}, hld[1], hl0[1]);
             const v2f o = (dimpass + bl) * c_main + hal * 0.075f;
             oa |= bh_srgb8(o.x) << 8;
             ob |= bh_srgb8(o.y) << 8;
@@ -637,14 +641,18 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
           {
             const v2f bl = s[2] * si;
             const v2f dimpass = v2f{dec_byte<2>(ia), dec_byte<2>(ib)} - v2f{dec_byte<2>(ja), dec_byte<2>(jb)};
-            const v2f hal = fma2(v2f{ra.hal_wy, ra.hal_wy}, hl1[2] - hl0[2], hl0[2]);
+            const v2f hal = fma2(v2f{ra.hal_wy, ra.hal_wy}, hld[2], hl0[2]);
             const v2f o = (dimpass + bl) * c_main + hal * 0.075f;
             oa |= bh_srgb8(o.x) << 16;
             ob |= bh_srgb8(o.y) << 16;
           }
           asm volatile("" ::: "memory");
-          const bool sa = live_a && (!mixed || rcd::lower_tri(xa, y, W, H) == (side == 0));
-          const bool sb = live_b && (!mixed || rcd::lower_tri(xb, y, W, H) == (side == 0));
+          bool sa = live_a, sb = live_b;
+          if (mixed) {
+            const int tri_y = (2 * y + 1) * W;
+            sa = sa && (tri_y <= tri_a) == (side == 0);
+            sb = sb && (tri_y <= tri_b) == (side == 0);
+          }
           if (sa) __builtin_amdgcn_raw_buffer_store_b32(oa, r_out, xa * 4, y * W * 4, 0);
           if (sb) __builtin_amdgcn_raw_buffer_store_b32(ob, r_out, xb * 4, y * W * 4, 0);
         }
@@ -770,7 +778,7 @@ hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
         const long blocks = std::min<long>((steps + kBhWaves * 8 - 1) / (kBhWaves * 8), 256);
         const uint32_t* runs = (uint64_t)steps < (1ull << 32) ? bhRuns(const_cast<BhTables*>(T), L.n_frames, (int)blocks * kBhWaves) : nullptr;
         if (!runs) GO(k_royale_bloom_h<SrgbLinEdge, SrgbNearEdge, SrgbNearEdge, SrgbLinEdge, OutS>);
-        const unsigned lds = (unsigned)(kBhLdsTables + kBhWaves * kBhWaveDwords) * 4u;
+        const unsigned lds = kBhLdsUser + (unsigned)(kBhWaves * kBhWaveDwords) * 4u;
         auto kernel = k_royale_bloom_h_strip;
         static bool attr = false;
         if (!attr) {

@@ -13,13 +13,17 @@
 // k_royale_scan_v_tab therefore evaluates K from a table: the exact float value T of K at the node (computed by
 // the very beam_k code of the general kernel, on the device), corrected by a second-order expansion in delta and
 // a first-order one in dist whose coefficients come from the closed-form K in double precision, together with a
-// bound on everything the expansion leaves out (remainder of the expansion per node, sampled in double
-// precision with a safety factor; float rounding noise of the exact evaluation, measured and bounded by 5e-6 K).
+// bound on everything the expansion leaves out.  That bound is MEASURED EXHAUSTIVELY, not sampled: when the tables of a
+// geometry are built, k_scan_tab_bounds evaluates the exact float K (the general kernel's beam_k) at EVERY float colour a
+// node can be selected for (all 2^20 floats of a log bucket; every float within kMaxDelta of a byte's decoded value, above
+// 2^-8) and every distance the geometry's rows actually produce (a handful of values: k_scan_geometry), and records the
+// largest difference to the very expression the table kernel evaluates - about 2 * 10^9 exact evaluations per distance.
 // If the sRGB8 byte is the same over the whole interval [S - B, S + B] the byte is certain and is stored;
 // otherwise (about 0.6 % of the pixels on uniform noise) the pixel goes to a per-tile list and is recomputed
 // with the general form by otherwise idle lanes.  The result is bit-identical to the general kernel whenever
-// the bound holds; tests/test_gpu_parity.py compares both forms on full-size noise and natural-like frames, and
-// tests/test_royale_scan_table.py checks the bound itself against the oracle's exact K on the CPU.
+// the bound holds - which it does by construction for every input the geometry can produce; tests/test_royale_fullsize.py
+// compares both forms on full-size noise and natural-like frames, and tests/test_royale_scan_table.py checks the
+// measured bound against the oracle's exact K (every float of a node's range for some nodes, random ones for all).
 // Colours below 2^-8 (where K is strongly non-linear in colour) use log-spaced nodes, 8 per octave, instead of
 // the byte nodes, so the relative perturbation stays below 4.6 %.
 #include <cmath>
@@ -211,12 +215,16 @@ constexpr int kStripRows = 8;                // target rows one thread walks
 constexpr int kTabWaves = 16;                // 1024 threads: one workgroup per CU (the tables fill its LDS)
 constexpr int kTabThreads = kTabWaves * 64;
 
-// dynamic LDS layout, in dwords (after the 256-entry decode table and the sRGB8 encode table of RC_SRGB_LDS)
-constexpr int kLdsA = (256 + (int)kSrgbRuns + 3) & ~3;        // float4 A[9][kNodes]: T, dK/dc, d2K/dc2 / 2, dK/ddist
-constexpr int kLdsB = kLdsA + 9 * kNodes * 4;                 // uint2 B[9][kNodes]: bound of the expansion at this node, node colour
-constexpr int kLdsFail = kLdsB + 9 * kNodes * 2;              // uint16 fails[kTabThreads * kStripRows]: tile-local ids of uncertain pixels
-constexpr int kLdsCnt = kLdsFail + kTabThreads * kStripRows / 2;  // their count, and the base of the tile's range in the global list
+// dynamic LDS layout, in dwords: decode table, second form of the sRGB8 encode table (rc_device.h), then
+constexpr int kLdsEnc2 = 256;
+constexpr int kLdsA = (kLdsEnc2 + (int)kSrgb2Runs + 3) & ~3;   // float4 A[9][kNodes]: T, dK/dc, d2K/dc2 / 2, dK/ddist
+constexpr int kLdsBound = kLdsA + 9 * kNodes * 4;             // float bound[9][kNodes]: the measured bound of the expansion at this node
+constexpr int kLdsNode = kLdsBound + 9 * kNodes;              // float colour[kNodes]: the node's colour
+constexpr int kFailCap = 4096;                                // tile-local ids of uncertain pixels (more: straight to the global list)
+constexpr int kLdsFail = (kLdsNode + kNodes + 3) & ~3;        // uint16 fails[kFailCap]
+constexpr int kLdsCnt = kLdsFail + kFailCap / 2;              // their count, and the base of the tile's range in the global list
 constexpr int kLdsTotal = kLdsCnt + 4;
+constexpr int kMaxDists = 24;                                 // distinct row distances a geometry may have for the table form
 
 // Pixels whose byte the table form could not certify are collected per tile in LDS and appended (one global atomic
 // per tile) to a list in the pass's scratch buffer (PassLaunch::scratch: a counter, then entries
@@ -241,13 +249,64 @@ __device__ __forceinline__ float scan_dd(int j, int ch, float dist, float dist_r
 }
 
 // T of every node: the general kernel's own beam_k at the node colour and the role's distance for dist = 0
-__global__ void __launch_bounds__(256) k_scan_tab_nodes(float4* A, const uint2* B, float off) {
+__global__ void __launch_bounds__(256) k_scan_tab_nodes(float4* A, const float* __restrict__ node, float off) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 9 * kNodes) return;
   const int jc = i / kNodes;
   const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
-  const float c = bits2f(B[i].y);
+  const float c = node[i - jc * kNodes];
   A[i].x = beam_k<float, true>(c, scan_dd(jc / 3, jc % 3, 0.0f, 0.0f), off, sigma_range, shape_range);
+}
+
+// The bound of every node: the largest difference, over EVERY float colour the table kernel can select the node for and
+// every row distance of the geometry (dists[0 .. n_dists)), between the exact K (beam_k, the general kernel's code) and the
+// expansion exactly as k_royale_scan_v_tab evaluates it.  blockIdx.y = role * kNodes + node; the node's colours are split
+// over blockIdx.x.  bound[] must be zero on entry; non-negative floats order like their bit patterns.
+__device__ __forceinline__ void scan_node_range(int n, float c0, uint32_t* lo, uint32_t* hi) {
+  if (n < kLogNodes) {   // a log bucket: 2^20 consecutive floats
+    *lo = kLogBits0 + ((uint32_t)n << 20);
+    *hi = *lo + (1u << 20) - 1u;
+  } else {               // a byte: every float within kMaxDelta, not below 2^-8 (smaller colours select a log node), not above 1
+    *lo = f2bits(fmaxf(c0 - kMaxDelta, kLogMax));
+    *hi = f2bits(fminf(c0 + kMaxDelta, 1.0f));
+  }
+}
+__global__ void __launch_bounds__(256) k_scan_tab_bounds(const float4* __restrict__ A, const float* __restrict__ node, const float* __restrict__ dists,
+                                                        int n_dists, float off, float* bound) {
+  const int e = (int)blockIdx.y, jc = e / kNodes, n = e - jc * kNodes;
+  const float c0 = node[n];
+  if (n == kLogNodes) return;                                   // the zero colour: bound set by the host (no expansion, K < 2.5e-8)
+  if (n > kLogNodes && !(c0 + kMaxDelta >= kLogMax)) return;   // a byte below the log range: never selected
+  uint32_t lo, hi;
+  scan_node_range(n, c0, &lo, &hi);
+  const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
+  const float4 a = A[e];
+  float worst = 0.0f;
+  // two consecutive colours per step through the packed form of beam_k (the same IEEE operations per component)
+  for (uint32_t i = lo + 2u * (blockIdx.x * 256u + threadIdx.x); i <= hi; i += 2u * gridDim.x * 256u) {
+    const v2f c = {bits2f(i), bits2f(i + 1u <= hi ? i + 1u : i)};
+    const v2f delta = c - c0;
+    for (int d = 0; d < n_dists; ++d) {
+      const float dist = dists[d], dd = scan_dd(jc / 3, jc % 3, dist, 0.0f);
+      const v2f k = beam_k<v2f, true>(c, v2f{dd, dd}, off, sigma_range, shape_range);
+      const float base = fma_(a.w, dist, a.x);
+      // the kernel: fma(delta, fma(delta, a.z, a.y), fma(a.w, dist, a.x))
+      const float kx = fma_(delta.x, fma_(delta.x, a.z, a.y), base), ky = fma_(delta.y, fma_(delta.y, a.z, a.y), base);
+      const double ex = fabs((double)k.x - (double)kx), ey = fabs((double)k.y - (double)ky);
+      worst = fmaxf(worst, __double2float_ru(ex > ey ? ex : ey));
+    }
+  }
+  if (worst > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(&bound[e]), f2bits(worst));
+}
+// the stored bound absorbs the roundings of the table kernel's own sums of the three K and of the three bounds
+__global__ void __launch_bounds__(256) k_scan_tab_bounds_finish(float* bound, const float* __restrict__ node) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 9 * kNodes) return;
+  const int n = e % kNodes;
+  float b = bound[e] * 1.000001f + 1e-12f;
+  if (n == kLogNodes) b = 2.5e-8f;   // colours below 2^-32 (and 0): 0 <= K <= 81 colour < 1.9e-8 (beta <= 4, 1/alpha <= 35.4, gamma_impl >= 0.88)
+  if (n > kLogNodes && !(node[n] + kMaxDelta >= kLogMax)) b = 1e30f;
+  bound[e] = b;
 }
 
 // Where the samples of every target row / column land, evaluated with the operations of scan_v_gather and of the
@@ -310,42 +369,43 @@ __global__ void __launch_bounds__(256) k_scan_geometry(const PassLaunch L, ScanR
 }
 
 // Is the sRGB8 byte the same for every value in [s - b, s + b]?  Returns the byte; *ok tells whether it is certain.
-// Certain means: the interval lies inside the linear segment (monotone) and both ends round to the same byte, or
-// inside ONE RSQRTPS run of the power segment - where the byte is monotone - with both ends on the same side of
-// the run's crossing, or inside two neighbouring runs with no crossing between the ends and the same byte either
-// side of the run boundary (flag bit 14 of the table entry; the encode is not monotone across run boundaries).
-__device__ __forceinline__ uint32_t srgb8_interval(float s, float b, const SrgbLds& t, bool* ok) {
-  const float lo = s - b, hi = s + b;
-  // power segment
-  const uint32_t bl = f2bits(__builtin_amdgcn_fmed3f(lo, 0.00313080009f, 0.99999994f)), bh = f2bits(hi);
-  const uint32_t ri = (bl >> 13) - kSrgbRun0;
-  const uint32_t el = t.enc[ri], eh = t.enc[ri + 1u];   // (the table has a spare entry after the last run)
-  const uint32_t cl = el & 0x3fffu, ch = eh & 0x3fffu;
-  const uint32_t ol = bl & 0x1fffu, oh = bh & 0x1fffu;
-  const bool pl = ol >= cl;
-  const uint32_t dr = (bh >> 13) - (bl >> 13);
-  const bool same = dr == 0u && pl == (oh >= cl);
-  const bool next = dr == 1u && (el & 0x4000u) && (pl || cl == 8192u) && oh < ch;
-  const bool ok_pow = lo > kSrgbLinMax && hi < 1.0f && (same || next);
-  const uint32_t byte_pow = (el >> 16) + (pl ? 1u : 0u);
-  // linear segment
-  const float ll = __builtin_rintf((lo > 0.0f ? lo : 0.0f) * kSrgbLinScale), lh = __builtin_rintf(hi * kSrgbLinScale);
-  const bool lin = hi <= kSrgbLinMax;
-  *ok = lin ? (ll == lh && hi >= 0.0f) : ok_pow;
-  return lin ? (uint32_t)ll : byte_pow;
+// With the second form of the encode table (one entry per RSQRTPS run from the first float that stores a non-zero byte, the
+// linear segment included): both ends are clamped into the table's range (everything below stores 0 like its first float,
+// everything above 1 stores 255 like 1) and looked up; inside one run the byte is monotone, and across the boundary to
+// the next run it is where bit 30 of the entry says so (the encode is not monotone across every run boundary).  So the byte
+// is certain when both ends give the same byte and lie in one run, or in two neighbouring runs with a monotone boundary.
+__device__ __forceinline__ uint32_t srgb8_interval(float s, float b, const uint32_t* enc2, bool* ok) {
+  const uint32_t bl = f2bits(__builtin_amdgcn_fmed3f(s - b, bits2f(kSrgb2MinBits), 1.0f)), bh = f2bits(__builtin_amdgcn_fmed3f(s + b, bits2f(kSrgb2MinBits), 1.0f));
+  const uint32_t rl = bl >> 13, rh = bh >> 13;
+  const uint32_t el = enc2[rl - kSrgb2Run0], eh = enc2[rh - kSrgb2Run0];
+  const uint32_t byte_l = ((el + (bl & 0x1fffu)) >> 13) & 255u, byte_h = ((eh + (bh & 0x1fffu)) >> 13) & 255u;
+  *ok = byte_l == byte_h && (rh - rl) <= ((el >> 30) & 1u);
+  return byte_l;
 }
 
 template <class SI, class SO>
-__global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLaunch L, const float4* __restrict__ gA, const uint2* __restrict__ gB,
-                                                                  const ScanRow* __restrict__ rows, const float* __restrict__ cols) {
-  RC_SRGB_LDS(lds, L);
-  float4* A = reinterpret_cast<float4*>(rc_dyn_lds_ + kLdsA);
-  uint2* B = reinterpret_cast<uint2*>(rc_dyn_lds_ + kLdsB);
+__global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLaunch L, const float4* __restrict__ gA, const float* __restrict__ gBound,
+                                                                  const float* __restrict__ gNode, const ScanRow* __restrict__ rows,
+                                                                  const float* __restrict__ cols) {
+  extern __shared__ uint32_t rc_dyn_lds_[];
   const int tid = (int)threadIdx.x;
+  SrgbLds lds;
+  {
+    float* dec = reinterpret_cast<float*>(rc_dyn_lds_);
+    for (int i = tid; i < 256; i += kTabThreads) dec[i] = k_srgb_decode[i];
+    for (int i = tid; i < (int)kSrgb2Runs; i += kTabThreads) rc_dyn_lds_[kLdsEnc2 + i] = L.srgb_enc[kSrgbRuns + i];
+    lds.dec = dec;
+    lds.enc = L.srgb_enc;   // (first form, in device memory: not used by this kernel)
+  }
+  const uint32_t* enc2 = rc_dyn_lds_ + kLdsEnc2;
+  float4* A = reinterpret_cast<float4*>(rc_dyn_lds_ + kLdsA);
+  float* Bound = reinterpret_cast<float*>(rc_dyn_lds_ + kLdsBound);
+  float* Node = reinterpret_cast<float*>(rc_dyn_lds_ + kLdsNode);
   for (int i = tid; i < 9 * kNodes; i += kTabThreads) {
     A[i] = gA[i];
-    B[i] = gB[i];
+    Bound[i] = gBound[i];
   }
+  for (int i = tid; i < kNodes; i += kTabThreads) Node[i] = gNode[i];
   uint16_t* fails = reinterpret_cast<uint16_t*>(rc_dyn_lds_ + kLdsFail);
   uint32_t* cnt = rc_dyn_lds_ + kLdsCnt;
   if (tid == 0) cnt[0] = 0u;
@@ -412,20 +472,24 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
               if (c < kLogMax) idx = cb >= kLogBits0 ? (cb - kLogBits0) >> 20 : (uint32_t)kLogNodes;
               const uint32_t e = (uint32_t)((j * 3 + ch) * kNodes) + idx;
               const float4 a = A[e];
-              const uint2 bb = B[e];
-              const float delta = c - bits2f(bb.y);   // at most kMaxDelta (byte nodes: k_scan_geometry bounds the weights) or half a bucket
+              const float delta = c - Node[idx];   // at most kMaxDelta (byte nodes: k_scan_geometry bounds the weights) or half a bucket
               kj[j] = fma_(delta, fma_(delta, a.z, a.y), fma_(a.w, dist, a.x));
-              bj[j] = bits2f(bb.x);
+              bj[j] = Bound[e];
             }
             const float s = ((kj[0] + kj[1]) + kj[2]) * 0.5f;
             const float b = fma_(5e-7f, s, 0.5f * ((bj[0] + bj[1]) + bj[2]));
             bool ok;
-            const uint32_t byte = srgb8_interval(s, b, lds, &ok);
+            const uint32_t byte = srgb8_interval(s, b, enc2, &ok);
             fail |= ok ? 0u : 1u;
             px |= byte << (8 * ch);
           }
-          if (fail == 0u) out[(size_t)y * W + x] = px;
-          else fails[atomicAdd(cnt, 1u)] = (uint16_t)((wave << 9) | (k << 6) | lane);
+          if (fail == 0u) {
+            out[(size_t)y * W + x] = px;
+          } else {
+            const uint32_t slot = atomicAdd(cnt, 1u);
+            if (slot < (uint32_t)kFailCap) fails[slot] = (uint16_t)((wave << 9) | (k << 6) | lane);
+            else fix_list(L)[atomicAdd(fix_counter(L), 1u)] = (uint32_t)((z * H + y) * W + x);   // (a tile with more uncertain pixels than the local list holds)
+          }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             t[i] = t[i + 1];
@@ -437,7 +501,7 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
     }
     // this tile's uncertain pixels: one range of the global list, reserved by one atomic
     __syncthreads();
-    const uint32_t n_fail = cnt[0];
+    const uint32_t n_fail = min(cnt[0], (uint32_t)kFailCap);
     // every wave has read the count before any wave moves on to the next tile, where it may append to the list again
     __syncthreads();
     if (n_fail) {   // uniform
@@ -513,55 +577,68 @@ float nodeColour(int n) {
   return n < kLogNodes ? bits2f(kLogBits0 + ((uint32_t)n << 20) + (1u << 19)) : k_srgb_decode_host[n - kLogNodes];
 }
 
-void buildScanTablesHost(float off, std::vector<float>* A, std::vector<uint32_t>* B) {
+// host-built part: the expansion coefficients around every node (A: 0, dK/dc, d2K/dc2 / 2, dK/ddist; the node value T is
+// filled in on the device by k_scan_tab_nodes) and the node colours.  Any coefficients are valid - the bound is measured
+// against what is stored (k_scan_tab_bounds) - good ones make it small.
+void buildScanTablesHost(float off, std::vector<float>* A, std::vector<float>* node) {
   A->assign((size_t)9 * kNodes * 4, 0.0f);
-  B->assign((size_t)9 * kNodes * 2, 0u);
+  node->assign((size_t)kNodes, 0.0f);
   const BeamModel M{(double)off};
-  const double dm = (double)kMaxDist;
+  for (int n = 0; n < kNodes; ++n) (*node)[(size_t)n] = nodeColour(n);
   for (int jc = 0; jc < 9; ++jc) {
     const int j = jc / 3, ch = jc % 3;
     const double D0 = modelDd(j, ch, 0.0);
     for (int n = 0; n < kNodes; ++n) {
       const size_t i = (size_t)jc * kNodes + n;
-      const float cf = nodeColour(n);
-      (*B)[i * 2 + 1] = f2bits(cf);
-      const double c0 = (double)cf;
-      if (!(c0 > 0.0)) {  // the zero colour: K = 0; also takes colours below 2^-32, where K < 1e-8
-        (*B)[i * 2] = f2bits(1.5e-8f);
-        continue;
-      }
-      double dmax;  // largest |colour - node| this node is used for
-      if (n < kLogNodes) dmax = std::ldexp(1.0, std::ilogb(c0)) / 16.0 * 1.0001;
-      else if (c0 + (double)kMaxDelta < (double)kLogMax) {  // byte node below the log range: never selected
-        (*B)[i * 2] = f2bits(1e30f);
-        continue;
-      } else dmax = (double)kMaxDelta;
+      const double c0 = (double)(*node)[(size_t)n];
+      if (!(c0 > 0.0)) continue;  // the zero colour: K = 0; also takes colours below 2^-32
       const double h = 1e-4 * c0;
       const double k0 = M.K(c0, D0), kp = M.K(c0 + h, D0), km = M.K(c0 - h, D0);
-      const double Tc = (kp - km) / (2.0 * h), Tcc2 = 0.5 * (kp - 2.0 * k0 + km) / (h * h);
-      const double Td = (M.K(c0, modelDd(j, ch, 1e-6)) - M.K(c0, modelDd(j, ch, -1e-6))) / 2e-6;
-      double rmax = 0.0;  // largest remainder of the expansion over this node's colour range and |dist| <= kMaxDist
-      const int G = 32;
-      const double dists[5] = {-dm, -0.5 * dm, 0.0, 0.5 * dm, dm};
-      for (int g = -G; g <= G; ++g) {
-        const double d = dmax * g / G, c = c0 + d > 0.0 ? c0 + d : 0.0, dc = c - c0;
-        const double quad = k0 + Tc * dc + Tcc2 * dc * dc;
-        for (double dist : dists) rmax = std::fmax(rmax, std::fabs(M.K(c, modelDd(j, ch, dist)) - (quad + Td * dist)));
-      }
-      // safety factor 2 on the sampled remainder; 5e-6 K + 2e-9: rounding noise of the exact float evaluation
-      // (measured: <= 1.6e-6 K, tests/test_royale_scan_table.py)
-      const double bound = 2.0 * rmax + 5e-6 * std::fabs(k0) + 2e-9;
-      (*A)[i * 4 + 1] = (float)Tc;
-      (*A)[i * 4 + 2] = (float)Tcc2;
-      (*A)[i * 4 + 3] = (float)Td;
-      (*B)[i * 2] = f2bits((float)(bound * 1.0000002));
+      (*A)[i * 4 + 1] = (float)((kp - km) / (2.0 * h));
+      (*A)[i * 4 + 2] = (float)(0.5 * (kp - 2.0 * k0 + km) / (h * h));
+      (*A)[i * 4 + 3] = (float)((M.K(c0, modelDd(j, ch, 1e-6)) - M.K(c0, modelDd(j, ch, -1e-6))) / 2e-6);
     }
   }
 }
 
-struct ScanTables {
+// Device tables for sub-pixel offset `off` and the given row distances: A (with T), measured bounds, node colours.
+struct ScanNodeTables {
   float4* A = nullptr;
-  uint2* B = nullptr;
+  float* bound = nullptr;
+  float* node = nullptr;
+};
+void freeScanNodeTables(ScanNodeTables* T) {
+  if (T->A) (void)hipFree(T->A);
+  if (T->bound) (void)hipFree(T->bound);
+  if (T->node) (void)hipFree(T->node);
+  *T = ScanNodeTables();
+}
+bool buildScanNodeTables(float off, const std::vector<float>& dists, hipStream_t s, ScanNodeTables* T) {
+  if (dists.empty() || dists.size() > (size_t)kMaxDists) return false;
+  std::vector<float> hA, hNode;
+  buildScanTablesHost(off, &hA, &hNode);
+  float* dd = nullptr;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&T->A), hA.size() * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&T->bound), (size_t)9 * kNodes * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&T->node), hNode.size() * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&dd), dists.size() * 4) == hipSuccess;
+  if (ok)
+    ok = hipMemcpyAsync(T->A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(T->node, hNode.data(), hNode.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(dd, dists.data(), dists.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemsetAsync(T->bound, 0, (size_t)9 * kNodes * 4, s) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(k_scan_tab_nodes, dim3((9 * kNodes + 255) / 256), dim3(256), 0, s, T->A, T->node, off);
+    hipLaunchKernelGGL(k_scan_tab_bounds, dim3(16, 9 * kNodes), dim3(256), 0, s, T->A, T->node, dd, (int)dists.size(), off, T->bound);
+    hipLaunchKernelGGL(k_scan_tab_bounds_finish, dim3((9 * kNodes + 255) / 256), dim3(256), 0, s, T->bound, T->node);
+    // the host vectors must outlive the asynchronous copies
+    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  }
+  if (dd) (void)hipFree(dd);
+  if (!ok) freeScanNodeTables(T);
+  return ok;
+}
+
+struct ScanTables {
+  ScanNodeTables nodes;
   ScanRow* rows = nullptr;
   float* cols = nullptr;
   bool usable = false;
@@ -572,8 +649,10 @@ struct ScanKey {
   bool operator<(const ScanKey& o) const { return std::memcmp(this, &o, sizeof(ScanKey)) < 0; }
 };
 
-// Tables for this launch's geometry on the current device, built on first use (two small kernels on `s` and one
-// synchronisation to learn whether the geometry is the regular one); nullptr when the table form does not apply.
+// Tables for this launch's geometry on the current device, built on first use: the geometry kernel and one synchronisation to
+// learn whether the geometry is the regular one and which row distances it has, then the node tables with their measured
+// bounds (a few 10^9 exact evaluations per distance: tenths of a second, once per geometry and process); nullptr when the
+// table form does not apply.
 const ScanTables* scanTablesFor(const PassLaunch& L, hipStream_t s) {
   if (L.in.w != L.out_w || L.in.h != L.out_h || L.out_h < 8 || L.params[RP1_Y_STEP] != 1.0f || L.params[RP1_TSY] != (float)L.in.h) return nullptr;
   const Plane &pu = L.plane[0], &pv = L.plane[1];
@@ -591,34 +670,43 @@ const ScanTables* scanTablesFor(const PassLaunch& L, hipStream_t s) {
   if (it != cache.end()) return it->second.usable ? &it->second : nullptr;
   if (cache.size() > 64) return nullptr;  // geometries keep changing (e.g. a window being resized): stay with the general form
   ScanTables T;
-  std::vector<float> hA;
-  std::vector<uint32_t> hB;
-  buildScanTablesHost(L.params[RP1_PH] / 3.0f, &hA, &hB);
   uint32_t* bad = nullptr;
-  bool ok = hipMalloc(reinterpret_cast<void**>(&T.A), hA.size() * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&T.B), hB.size() * 4) == hipSuccess &&
-            hipMalloc(reinterpret_cast<void**>(&T.rows), sizeof(ScanRow) * (size_t)L.out_h) == hipSuccess &&
+  bool ok = hipMalloc(reinterpret_cast<void**>(&T.rows), sizeof(ScanRow) * (size_t)L.out_h) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&T.cols), sizeof(float) * (size_t)L.out_w) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&bad), 4) == hipSuccess;
   uint32_t hbad = 1;
+  std::vector<ScanRow> hrows((size_t)L.out_h);
+  if (ok) ok = hipMemsetAsync(bad, 0, 4, s) == hipSuccess;
   if (ok) {
-    ok = hipMemcpyAsync(T.A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
-         hipMemcpyAsync(T.B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemsetAsync(bad, 0, 4, s) == hipSuccess;
-    if (ok) {
-      hipLaunchKernelGGL(k_scan_tab_nodes, dim3((9 * kNodes + 255) / 256), dim3(256), 0, s, T.A, T.B, L.params[RP1_PH] / 3.0f);
-      const int n = L.out_w > L.out_h ? L.out_w : L.out_h;
-      hipLaunchKernelGGL(k_scan_geometry, dim3((n + 255) / 256), dim3(256), 0, s, L, T.rows, T.cols, bad);
-      // hA / hB must outlive the asynchronous copies: the synchronising copy below orders that
-      ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
-           hipStreamSynchronize(s) == hipSuccess;
-    }
+    const int n = L.out_w > L.out_h ? L.out_w : L.out_h;
+    hipLaunchKernelGGL(k_scan_geometry, dim3((n + 255) / 256), dim3(256), 0, s, L, T.rows, T.cols, bad);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+         hipMemcpyAsync(hrows.data(), T.rows, sizeof(ScanRow) * hrows.size(), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
   }
   if (bad) (void)hipFree(bad);
+  size_t n_dists = 0;
+  if (ok && hbad == 0) {
+    // the distances of the rows that take the table form (rows 2 .. H - 3 whose distance is within kMaxDist, per triangle)
+    std::vector<float> dists;
+    auto add = [&](float d) {
+      for (float e : dists)
+        if (f2bits(e) == f2bits(d)) return;
+      dists.push_back(d);
+    };
+    for (int y = 2; y < L.out_h - 2; ++y) {
+      if (!(hrows[(size_t)y].up & 256u)) add(hrows[(size_t)y].dist_lo);
+      if (!(hrows[(size_t)y].up & 512u)) add(hrows[(size_t)y].dist_up);
+    }
+    n_dists = dists.size();
+    ok = buildScanNodeTables(L.params[RP1_PH] / 3.0f, dists, s, &T.nodes);
+  }
   T.usable = ok && hbad == 0;
   RC_LOG_DEBUG("crt-royale scanline pass " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h) + ": expansion tables " +
-               (ok && hbad == 0 ? "in use" : "not usable (geometry flags " + std::to_string(hbad) + "), exact per-pixel form"));
+               (T.usable ? "in use (" + std::to_string(n_dists) + " row distances)"
+                         : "not usable (geometry flags " + std::to_string(hbad) + ", " + std::to_string(n_dists) + " row distances), exact per-pixel form"));
+  if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc scan-v] %dx%d: usable %d flags %u, %zu row distances\n", L.out_w, L.out_h, (int)T.usable, hbad, n_dists);
   if (!T.usable) {
-    if (T.A) (void)hipFree(T.A);
-    if (T.B) (void)hipFree(T.B);
+    freeScanNodeTables(&T.nodes);
     if (T.rows) (void)hipFree(T.rows);
     if (T.cols) (void)hipFree(T.cols);
     T = ScanTables();
@@ -630,13 +718,25 @@ const ScanTables* scanTablesFor(const PassLaunch& L, hipStream_t s) {
 }  // namespace
 
 namespace rck {
-// for tests/test_royale_scan_table.py: the host-built part of the tables (A: 0, dK/dc, d2K/dc2 / 2, dK/ddist; B: bound, node colour)
+// for tests/test_royale_scan_table.py: the host-built part of the tables (A: 0, dK/dc, d2K/dc2 / 2, dK/ddist; B: 0, node colour) ...
 void royale_scan_tables_host(float off, float* A, uint32_t* B) {
-  std::vector<float> a;
-  std::vector<uint32_t> b;
-  buildScanTablesHost(off, &a, &b);
+  std::vector<float> a, node;
+  buildScanTablesHost(off, &a, &node);
   std::memcpy(A, a.data(), a.size() * sizeof(float));
-  std::memcpy(B, b.data(), b.size() * sizeof(uint32_t));
+  for (int jc = 0; jc < 9; ++jc)
+    for (int n = 0; n < kNodes; ++n) {
+      B[((size_t)jc * kNodes + n) * 2] = 0u;
+      B[((size_t)jc * kNodes + n) * 2 + 1] = f2bits(node[(size_t)n]);
+    }
+}
+// ... and the complete device tables for the given row distances: A with the node values T, and the measured bounds
+hipError_t royale_scan_tables_device(float off, const float* dists, int n_dists, float* A, float* bound, hipStream_t s) {
+  ScanNodeTables T;
+  if (n_dists < 1 || !buildScanNodeTables(off, std::vector<float>(dists, dists + n_dists), s, &T)) return hipErrorInvalidValue;
+  hipError_t e = hipMemcpy(A, T.A, (size_t)9 * kNodes * 16, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(bound, T.bound, (size_t)9 * kNodes * 4, hipMemcpyDeviceToHost);
+  freeScanNodeTables(&T);
+  return e;
 }
 int royale_scan_table_nodes() { return kNodes; }
 
@@ -664,7 +764,8 @@ hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s) {
       const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kStripRows - 1) / kStripRows) * L.n_frames;
       const long tiles = (strips + kTabWaves - 1) / kTabWaves;
       if (hipMemsetAsync(L.scratch, 0, kFixHeader, s) != hipSuccess) return hipGetLastError();
-      hipLaunchKernelGGL(kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(kTabThreads), kLdsTotal * 4, s, L, T->A, T->B, T->rows, T->cols);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(kTabThreads), kLdsTotal * 4, s, L, T->nodes.A, T->nodes.bound, T->nodes.node, T->rows,
+                         T->cols);
       hipLaunchKernelGGL((k_royale_scan_v_fix<SrgbLinEdge, OutS>), dim3(512), dim3(256), rcd::srgb_lds_bytes(L), s, L);
       return hipGetLastError();
     }

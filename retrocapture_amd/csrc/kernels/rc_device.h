@@ -237,15 +237,22 @@ struct SrgbLds {
   const float* dec;
   const uint32_t* enc;
 };
-inline unsigned srgb_lds_bytes(const PassLaunch& L) { return 1024u + (L.out_fmt == FMT_SRGB8 ? kSrgbRuns * 4u : 0u); }
+// A small sRGB8 target (crt-royale's 320 x 240 passes: a few hundred pixels per workgroup) reads the encode table where it is,
+// in device memory (34 KB, L2-resident): copying it into every workgroup's LDS would move more bytes than the pass itself.
+__host__ __device__ inline bool srgb_enc_in_lds(const PassLaunch& L) {
+  return L.out_fmt == FMT_SRGB8 && (long)L.out_w * L.out_h * L.n_frames >= (1L << 21);
+}
+inline unsigned srgb_lds_bytes(const PassLaunch& L) { return 1024u + (srgb_enc_in_lds(L) ? kSrgbRuns * 4u : 0u); }
 // Every thread of the block must call this (RC_SRGB_LDS) before sampling sRGB textures / storing sRGB.
 __device__ __forceinline__ SrgbLds load_srgb_tables(uint32_t* dyn, const PassLaunch& L) {
   float* dec = reinterpret_cast<float*>(dyn);
-  uint32_t* enc = dyn + 256;
+  const uint32_t* enc = L.srgb_enc;
   const int nt = blockDim.x * blockDim.y, t0 = threadIdx.y * blockDim.x + threadIdx.x;
   for (int i = t0; i < 256; i += nt) dec[i] = k_srgb_decode[i];
-  if (L.out_fmt == FMT_SRGB8)
-    for (int i = t0; i < (int)kSrgbRuns; i += nt) enc[i] = L.srgb_enc[i];
+  if (srgb_enc_in_lds(L)) {
+    for (int i = t0; i < (int)kSrgbRuns; i += nt) dyn[256 + i] = L.srgb_enc[i];
+    enc = dyn + 256;
+  }
   __syncthreads();
   return SrgbLds{dec, enc};
 }

@@ -408,6 +408,12 @@ int rc_selftest_royale_scan_tables(float off, float* A, uint32_t* B, size_t a_fl
     return (int)n;
   });
 }
+int rc_selftest_royale_scan_bounds(int device, float off, const float* dists, int n_dists, float* A, float* bound, size_t a_floats, size_t bound_floats) {
+  const size_t n = (size_t)rck::royale_scan_table_nodes();
+  if (!dists || !A || !bound || a_floats < 9 * n * 4 || bound_floats < 9 * n) return RC_ERR_INVALID;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return RC_ERR_DEVICE;
+  return guarded([&] { return rck::royale_scan_tables_device(off, dists, n_dists, A, bound, nullptr) == hipSuccess ? (int)n : (int)RC_ERR_DEVICE; });
+}
 int rc_selftest_crt_geom_vertex(const float* params, float* out) {
   if (!params || !out) return RC_ERR_INVALID;
   float P[rcd::kMaxParams] = {};

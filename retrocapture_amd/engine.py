@@ -100,6 +100,7 @@ SYMBOLS = [
     ("rc_selftest_royale_scan_tables", C.c_int, [C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     ("rc_selftest_srgb8_device", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("rc_selftest_crt_geom_vertex", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rc_selftest_royale_scan_bounds", C.c_int, [C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     ("rc_selftest_srgb8_host_form", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     ("rc_selftest_srgb8_device_form", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
     ("rc_last_error", C.c_char_p, []),
@@ -317,6 +318,20 @@ def royale_scan_tables(off):
     if lib.rc_selftest_royale_scan_tables(C.c_float(off), A.ctypes.data, B.ctypes.data, A.size, B.size) != n:
         raise RcError("rc_selftest_royale_scan_tables failed")
     return A, B[..., 0].copy().view(np.float32), B[..., 1].copy().view(np.float32)
+
+
+def royale_scan_bounds(off, dists, device=0):
+    """The complete tables as the device builds them for the given row distances (needs a GPU): (A [9, nodes, 4] float32 with the
+    node values, bound [9, nodes] float32 - the exhaustively measured bound of the expansion at every node)."""
+    import numpy as np
+    lib = load_library()
+    n = lib.rc_selftest_royale_scan_tables(C.c_float(off), None, None, 0, 0)
+    d = np.ascontiguousarray(dists, np.float32)
+    A = np.zeros((9, n, 4), np.float32)
+    B = np.zeros((9, n), np.float32)
+    if lib.rc_selftest_royale_scan_bounds(int(device), C.c_float(off), d.ctypes.data, int(d.size), A.ctypes.data, B.ctypes.data, A.size, B.size) != n:
+        raise RcError("rc_selftest_royale_scan_bounds failed")
+    return A, B
 
 
 def crt_geom_vertex(params):
