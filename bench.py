@@ -338,11 +338,17 @@ def dry_run(args):
     for _ in range(args.steps):
         done += len(mine)                                      # stands in for applyShaderBatch over this rank's shard
         time.sleep(0.001 * (rank + 1))
+    own = time.perf_counter() - t0                             # this rank's own work, before it waits for the others
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     counts = [len(mine)]
+    per_rank = [own]
     if world > 1:
+        pr = torch.zeros(world, dtype=torch.float64)
+        pr[rank] = own
+        dist.all_reduce(pr)
+        per_rank = [float(v) for v in pr.tolist()]
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -354,6 +360,8 @@ def dry_run(args):
     if rank == 0:
         print(json.dumps({"metric": "dry-run", "value": aggregate(counts, args.steps, dt), "unit": "frames/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "frames_per_rank": counts, "scaling": "weak",
+                          "ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
+                          "world_size_observed": dist.get_world_size() if world > 1 else 1,
                           "data": "none (dry run: launch / shard / reduce path only)"}))
     if world > 1:
         dist.destroy_process_group()
@@ -363,7 +371,7 @@ def dry_run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40, help="timed steps (default: about 2 s of GPU work per measured mode at 1080p)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (256 x 1080p = 2.1 GB in, 2.1 GB out)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per kernel launch (0 = engine default)")
@@ -466,6 +474,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0        # this rank's own work, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     def max_over_ranks(seconds):
@@ -475,6 +485,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_ranks(seconds):
+        """every rank's own time (so that a straggler shows in the one line the driver keeps), and the world size the
+        communicator itself reports"""
+        if world == 1:
+            return [seconds], 1
+        t = torch.zeros(world, dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        t[rank] = seconds
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()], int(dist.get_world_size())
+
+    per_rank_s, comm_world = gather_ranks(own)
     dt = max_over_ranks(dt)
     if world > 1:
         assert dist.get_world_size() == args.gpus
@@ -527,7 +548,8 @@ def main():
         "metric": ("1080p frames/sec, crt-royale 12-pass, 1/2/4/8 MI355X; % HBM roofline" if wl == "crt-royale"
                    else "frames/sec, %s; %% HBM roofline" % wl),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank_s],
+        "world_size_observed": comm_world, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "float_target_storage": "f16" if args.fp16_targets else "f32",
         "config": {"workload": desc + (" [" + ", ".join(args.param) + "]" if args.param else ""), "frames_per_gpu_per_step": args.batch, "global_batch": args.batch * world,

@@ -498,6 +498,153 @@ __global__ void __launch_bounds__(512) k_royale_scan_h_strip(const PassLaunch L,
   }
 }
 
+// ---- P7, strip form, two pixels per lane (royale_strip2.h): columns x and x + 64 of a 128-column band; the lerps and the
+// Quilez mix of the pixel pair run as packed float operations.  Per source row a lane decodes the three texels x - 1, x,
+// x + 1 of each of its pixels once and keeps the horizontally filtered pair of the current row pair (six values per channel
+// pair).  A strip the quad's diagonal crosses is rendered once per triangle, each pixel stored by the pass of its own triangle.
+__global__ void __launch_bounds__(512) k_royale_scan_h_strip2(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
+  using namespace rcstrip2;
+  extern __shared__ uint32_t rc_dyn_lds_[];
+  strip2_load_tables(rc_dyn_lds_, L, true);
+  const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int W = L.out_w, H = L.out_h;
+  const int bands = (W + 127) >> 7, rss = (H + kShRows - 1) / kShRows, per_frame = bands * rss, total = per_frame * L.n_frames;
+  const Tex& scan = L.extra[0];
+  const int sw = scan.w, sh = scan.h;
+  for (int strip = (int)blockIdx.x * 8 + wave; strip < total; strip += (int)gridDim.x * 8) {
+    const int z = strip / per_frame, rem = strip - z * per_frame, rs = rem / bands;
+    const int xw = (rem - rs * bands) << 7, ys = rs * kShRows;
+    const int xa = xw + lane, xb = xa + 64;
+    const bool live_a = xa < W, live_b = xb < W;
+    const int xca = live_a ? xa : W - 1, xcb = live_b ? xb : W - 1;
+    const int xmax = min(xw + 127, W - 1), ymax = min(ys + kShRows - 1, H - 1);
+    const bool all_lo = rcd::lower_tri(xw, ymax, W, H), all_up = !rcd::lower_tri(xmax, ys, W, H);
+    const uint8_t* mimg = frame_ptr(L.in, z);
+    const uint8_t* simg = frame_ptr(scan, z);
+    const __amdgpu_buffer_rsrc_t r_out = frame_rsrc(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z, W, H);
+    const int tri_a = (2 * xa + 1) * H, tri_b = (2 * xb + 1) * H;
+    // texels x - 1, x, x + 1 of both pixels (k_scanh_geometry: every channel's two taps are (x - 1, x) and (x, x + 1))
+    const uint32_t la = (uint32_t)clampi(xca - 1, 0, sw - 1) * 4u, ma = (uint32_t)clampi(xca, 0, sw - 1) * 4u, ra_ = (uint32_t)clampi(xca + 1, 0, sw - 1) * 4u;
+    const uint32_t lb = (uint32_t)clampi(xcb - 1, 0, sw - 1) * 4u, mb = (uint32_t)clampi(xcb, 0, sw - 1) * 4u, rb_ = (uint32_t)clampi(xcb + 1, 0, sw - 1) * 4u;
+    for (int side = all_up ? 1 : 0; side <= (all_lo ? 0 : 1); ++side) {
+      const bool mixed = !all_lo && !all_up;
+      v2f wxa[3], wxb[3], fy[3], fz[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        wxa[ch] = v2f{bits2f(cols[((SH_WXA + ch) * 2 + side) * W + xca]), bits2f(cols[((SH_WXA + ch) * 2 + side) * W + xcb])};
+        wxb[ch] = v2f{bits2f(cols[((SH_WXB + ch) * 2 + side) * W + xca]), bits2f(cols[((SH_WXB + ch) * 2 + side) * W + xcb])};
+        fy[ch] = v2f{bits2f(cols[((SH_FY + ch) * 2 + side) * W + xca]), bits2f(cols[((SH_FY + ch) * 2 + side) * W + xcb])};
+        fz[ch] = v2f{bits2f(cols[((SH_FZ + ch) * 2 + side) * W + xca]), bits2f(cols[((SH_FZ + ch) * 2 + side) * W + xcb])};
+      }
+      const uint32_t mxa = cols[(SH_MX * 2 + side) * W + xca] * 4u, mxb = cols[(SH_MX * 2 + side) * W + xcb] * 4u;
+      // horizontally filtered source row: ha = tap 1 (texels x - 1, x), hb = tap 2 (texels x, x + 1), per channel, both pixels;
+      // the six texels of the next source row are fetched ahead of their use
+      auto hfetch = [&](int r, uint32_t* q) __attribute__((always_inline)) {
+        const uint8_t* p = simg + (size_t)(clampi(r, 0, sh - 1) * sw) * 4u;
+        q[0] = *reinterpret_cast<const uint32_t*>(p + la);
+        q[1] = *reinterpret_cast<const uint32_t*>(p + ma);
+        q[2] = *reinterpret_cast<const uint32_t*>(p + ra_);
+        q[3] = *reinterpret_cast<const uint32_t*>(p + lb);
+        q[4] = *reinterpret_cast<const uint32_t*>(p + mb);
+        q[5] = *reinterpret_cast<const uint32_t*>(p + rb_);
+      };
+      auto hfilter = [&](const uint32_t* q, v2f* ha, v2f* hb) __attribute__((always_inline)) {
+        {
+          const v2f dl = {dec_byte<0>(q[0]), dec_byte<0>(q[3])}, dm = {dec_byte<0>(q[1]), dec_byte<0>(q[4])}, dr = {dec_byte<0>(q[2]), dec_byte<0>(q[5])};
+          ha[0] = fma2(wxa[0], dm - dl, dl);
+          hb[0] = fma2(wxb[0], dr - dm, dm);
+        }
+        {
+          const v2f dl = {dec_byte<1>(q[0]), dec_byte<1>(q[3])}, dm = {dec_byte<1>(q[1]), dec_byte<1>(q[4])}, dr = {dec_byte<1>(q[2]), dec_byte<1>(q[5])};
+          ha[1] = fma2(wxa[1], dm - dl, dl);
+          hb[1] = fma2(wxb[1], dr - dm, dm);
+        }
+        {
+          const v2f dl = {dec_byte<2>(q[0]), dec_byte<2>(q[3])}, dm = {dec_byte<2>(q[1]), dec_byte<2>(q[4])}, dr = {dec_byte<2>(q[2]), dec_byte<2>(q[5])};
+          ha[2] = fma2(wxa[2], dm - dl, dl);
+          hb[2] = fma2(wxb[2], dr - dm, dm);
+        }
+      };
+      uint32_t nq[6];
+      int nq_row = -1000;
+      v2f a0[3], b0[3], a1[3], b1[3];   // the row pair in use: source rows `have` and `have + 1`
+      int have = -1000;
+      // the mask texel of a row is fetched one step ahead
+      uint32_t nma, nmb;
+      {
+        const uint32_t* r0p = rows + ((size_t)ys * 2 + side) * SH_ROW_FIELDS;
+        const uint8_t* p = mimg + (size_t)(r0p[SH_MY] * (uint32_t)L.in.w) * 4u;
+        nma = *reinterpret_cast<const uint32_t*>(p + mxa);
+        nmb = *reinterpret_cast<const uint32_t*>(p + mxb);
+      }
+#pragma unroll 1
+      for (int y = ys; y <= ymax; ++y) {
+        const uint32_t* rr = rows + ((size_t)y * 2 + side) * SH_ROW_FIELDS;
+        const int y0 = (int)rr[SH_Y0];
+        const float wy = bits2f(rr[SH_WY]);
+        const uint32_t mta = nma, mtb = nmb;
+        {
+          const uint32_t* rn = rows + ((size_t)min(y + 1, H - 1) * 2 + side) * SH_ROW_FIELDS;
+          const uint8_t* p = mimg + (size_t)(rn[SH_MY] * (uint32_t)L.in.w) * 4u;
+          nma = *reinterpret_cast<const uint32_t*>(p + mxa);
+          nmb = *reinterpret_cast<const uint32_t*>(p + mxb);
+        }
+        uint32_t pa = 0xff000000u, pb = 0xff000000u;   // scan * 0 (or NaN): stored as 0, alpha 1
+        // rows whose mask texels are all zero across the wave skip the scanline work, as the per-pixel form does per pixel
+        if (__builtin_amdgcn_ballot_w64(((mta | mtb) & 0x00ffffffu) != 0u) != 0ull) {
+          if (y0 != have) {
+            if (y0 == have + 1) {
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) {
+                a0[ch] = a1[ch];
+                b0[ch] = b1[ch];
+              }
+            } else {
+              uint32_t q[6];
+              hfetch(y0, q);
+              hfilter(q, a0, b0);
+            }
+            if (nq_row != y0 + 1) hfetch(y0 + 1, nq);
+            hfilter(nq, a1, b1);
+            have = y0;
+            nq_row = y0 + 2;
+            hfetch(nq_row, nq);
+          }
+          const float k255 = 1.0f / 255.0f;
+          v2f o[3];
+          {
+            const v2f c1 = fma2(splat2(wy), a1[0] - a0[0], a0[0]), c2 = fma2(splat2(wy), b1[0] - b0[0], b0[0]);
+            const v2f m = c1 * fy[0] + c2 * fz[0];   // ((0*fx + c1*fy) + c2*fz) + 0*fw with fx = fw = 0
+            const v2f mask = v2f{(float)(mta & 255u), (float)(mtb & 255u)} * k255;
+            o[0] = v2f{maxps(m.x, 0.0f), maxps(m.y, 0.0f)} * mask;
+          }
+          {
+            const v2f c1 = fma2(splat2(wy), a1[1] - a0[1], a0[1]), c2 = fma2(splat2(wy), b1[1] - b0[1], b0[1]);
+            const v2f m = c1 * fy[1] + c2 * fz[1];
+            const v2f mask = v2f{(float)((mta >> 8) & 255u), (float)((mtb >> 8) & 255u)} * k255;
+            o[1] = v2f{maxps(m.x, 0.0f), maxps(m.y, 0.0f)} * mask;
+          }
+          {
+            const v2f c1 = fma2(splat2(wy), a1[2] - a0[2], a0[2]), c2 = fma2(splat2(wy), b1[2] - b0[2], b0[2]);
+            const v2f m = c1 * fy[2] + c2 * fz[2];
+            const v2f mask = v2f{(float)((mta >> 16) & 255u), (float)((mtb >> 16) & 255u)} * k255;
+            o[2] = v2f{maxps(m.x, 0.0f), maxps(m.y, 0.0f)} * mask;
+          }
+          srgb8_pack2(o, &pa, &pb);
+        }
+        bool sa = live_a, sb = live_b;
+        if (mixed) {
+          const int tri_y = (2 * y + 1) * W;
+          sa = sa && (tri_y <= tri_a) == (side == 0);
+          sb = sb && (tri_y <= tri_b) == (side == 0);
+        }
+        if (sa) __builtin_amdgcn_raw_buffer_store_b32(pa, r_out, xa * 4, y * W * 4, 0);
+        if (sb) __builtin_amdgcn_raw_buffer_store_b32(pb, r_out, xb * 4, y * W * 4, 0);
+      }
+    }
+  }
+}
+
 void buildScanHTables(const PassLaunch& L, hipStream_t s, ScanHTables* T) {
   uint32_t* bad = nullptr;
   bool ok = hipMalloc(reinterpret_cast<void**>(&T->cols), (size_t)SH_COL_FIELDS * 2 * L.out_w * 4) == hipSuccess &&
@@ -874,60 +1021,49 @@ enum { LS_Y0 = 0, LS_WY = 1, LS_BY = 2, LS_ROW_FIELDS = 4 };
 struct LastTables {
   uint32_t* cols = nullptr;   // [LS_COL_FIELDS][2][W]
   uint32_t* rows = nullptr;   // [H][2][LS_ROW_FIELDS]
-  float4* gamma_tab = nullptr;   // certified expansion of the output-gamma pow around every decoded byte (below), or null
+  float4* gamma_tab = nullptr;   // certified expansion of the output-gamma pow (below), or null
   bool usable = false;
 };
 
 // ---- the output gamma from a table, with a proven bound ------------------------------------------------------------
-// At 1:1 the one LINEAR tap of a pixel lands on a texel centre up to float rounding: its weights are within kLastMaxW of 0
-// or 1 (k_last_geometry verifies it per column / row), so the sampled colour c is the decoded byte c0 of the pixel's own
-// texel plus a perturbation |delta| <= kLastMaxDelta, and away from the border the pass stores unorm8(G(c)), G(c) =
-// exp2(log2(c) / lcd_gamma) in the GL's polynomials.  Per byte the table holds T = G(c0) (the float the exact code computes),
-// the slope S, and Q, R such that |G(c) - fma(S, delta, T)| <= Q delta^2 + R for EVERY float c in [c0 - kLastMaxDelta,
-// c0 + kLastMaxDelta]: k_last_gamma_err evaluates the exact float G at all of them (about 40 M arguments per table) against
-// the very expression the strip kernel evaluates - a bound by exhaustion, not by sampling.  The strip kernel stores the
-// byte when the whole interval rounds to one byte (x -> rint(clamp(x) * 255) is monotone) and re-renders the few other
-// pixels with the exact per-pixel code.  Bytes 0 to 3 (colours within kLastMaxDelta of 0, where G has no expansion) carry
-// Q = 3e38: certain only for delta = 0.
-constexpr float kLastMaxW = 5e-4f;           // largest off-centre bilinear weight per axis
-constexpr float kLastMaxDelta = 1.05e-3f;    // > 2 * kLastMaxW * 1.0: largest |c - c0|
-constexpr float kLastInner = kLastMaxDelta / 256.0f;  // |delta| up to here defines R (the rounding noise of the exact evaluation)
+// Away from the border the pass stores unorm8(G(c)) for the sampled colour c, G(c) = exp2(log2(c) / lcd_gamma) in the GL's
+// polynomials (~40 float operations, three per pixel).  G is smooth, so the strip kernel evaluates it from a table of
+// log-spaced nodes: 32 per octave (the top five mantissa bits of c select the node, its colour c0 is the bucket's midpoint)
+// from 2^-20 - below which G(c) * 255 < 0.47 and the byte is 0 for certain - up to 1.  Per node: T = G(c0) (the float the
+// exact code computes), slope and half curvature from the closed form, and a bound R on |G(c) - fma(d, fma(d, G''/2, G'), T)|,
+// d = c - c0, that k_last_gamma_err MEASURES over EVERY float of the bucket (2^18 floats; 168 M exact evaluations per
+// table) against the very expression the strip kernel evaluates - a bound by exhaustion, not by sampling: third-order
+// remainder and float noise together stay below 4e-7 G.  The kernel stores the byte when the whole interval rounds to one byte
+// (x -> rint(clamp(x) * 255) is monotone) and re-renders the few other pixels with the exact per-pixel code.
+constexpr uint32_t kLastTabBits0 = 0x35800000u;   // 2^-20
+constexpr int kLastTabShift = 18;                 // 2^18 floats per node: 32 nodes per octave
+constexpr int kLastTabNodes = (int)((0x3f800000u - kLastTabBits0) >> kLastTabShift) + 1;   // 641: the last one is the colour 1.0 alone
 __device__ __forceinline__ float last_gamma(float c, float inv_gamma) { return exp2_(log2_(c) * inv_gamma); }   // = the strips' packed form per component
-__device__ __forceinline__ float last_node_colour(int b) { return k_srgb_decode[b]; }
-// phase 0: T; phase 1: R = max error for |delta| <= kLastInner; phase 2: Q = max (error - R) / delta^2 beyond
+__host__ __device__ __forceinline__ float last_node_colour(int n) {
+  return n == kLastTabNodes - 1 ? 1.0f : bits2f(kLastTabBits0 + ((uint32_t)n << kLastTabShift) + (1u << (kLastTabShift - 1)));
+}
+// phase 0: T; phase 1: R = the largest error over the node's floats
 __global__ void __launch_bounds__(256) k_last_gamma_err(float inv_gamma, float4* tab, int phase) {
-  const int b = (int)blockIdx.y;
-  const float c0 = last_node_colour(b);
+  const int n = (int)blockIdx.y;
+  const float c0 = last_node_colour(n);
   if (phase == 0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) tab[b].x = last_gamma(c0, inv_gamma);
+    if (blockIdx.x == 0 && threadIdx.x == 0) tab[n].x = last_gamma(c0, inv_gamma);
     return;
   }
-  if (b < 4) return;   // host: Q = 3e38, R = 0
-  const float4 e = tab[b];
-  const uint32_t lo = f2bits(c0 - kLastMaxDelta), hi = f2bits(fminf(c0 + kLastMaxDelta, 1.0f));   // c0 >= dec[4] > kLastMaxDelta: positive normals
+  const float4 e = tab[n];
+  const uint32_t lo = kLastTabBits0 + ((uint32_t)n << kLastTabShift), hi = n == kLastTabNodes - 1 ? lo : lo + (1u << kLastTabShift) - 1u;
   uint32_t worst = 0u;
   for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i <= hi; i += gridDim.x * 256u) {
     const float c = bits2f(i), delta = c - c0;
-    const double err = fabs((double)last_gamma(c, inv_gamma) - (double)fma_(e.y, delta, e.x));
-    const bool inner = fabsf(delta) <= kLastInner;
-    if (phase == 1 && inner) worst = max(worst, f2bits(__double2float_ru(err)));
-    if (phase == 2 && !inner && err > (double)e.w) worst = max(worst, f2bits(__double2float_ru((err - (double)e.w) / ((double)delta * (double)delta))));
+    const double err = fabs((double)last_gamma(c, inv_gamma) - (double)fma_(delta, fma_(delta, e.z, e.y), e.x));
+    worst = max(worst, f2bits(__double2float_ru(err)));
   }
-  if (worst) atomicMax(reinterpret_cast<uint32_t*>(phase == 1 ? &tab[b].w : &tab[b].z), worst);   // non-negative floats order like their bits
+  if (worst) atomicMax(reinterpret_cast<uint32_t*>(&tab[n].w), worst);   // non-negative floats order like their bits
 }
-// the stored bound absorbs the roundings of the strip kernel's own bound arithmetic (delta^2 and the two fmas, each within 2^-24
-// relative); the rounding of lin -+ bound itself (half an ulp of a value near lin) is added there, relative to lin
+// the stored bound absorbs its own rounding; the roundings of lin -+ bound are added in the kernel, relative to lin
 __global__ void __launch_bounds__(256) k_last_gamma_finish(float4* tab) {
-  const int b = (int)threadIdx.x;
-  float4 e = tab[b];
-  if (b < 4) {
-    e.z = 3e38f;
-    e.w = 0.0f;
-  } else {
-    e.z = e.z * 1.000001f;
-    e.w = e.w * 1.000001f + 1e-12f;
-  }
-  tab[b] = e;
+  const int n = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (n < kLastTabNodes) tab[n].w = tab[n].w * 1.000001f + 1e-12f;
 }
 
 __global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint32_t* cols, uint32_t* rows, uint32_t* bad) {
@@ -943,8 +1079,6 @@ __global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint3
       const float fu = u * (tsx * vsix);
       const float vu = (fu - 0.5f) / osx + 0.5f;
       const rcstrip::LinTap t = rcstrip::lin_tap(vu * (tsx * vsix), L.in.w);
-      // gamma table form: the pair is (x, x + 1) with a weight near 0 or (x - 1, x) with a weight near 1
-      if (!((t.i0 == i && t.w <= kLastMaxW) || (t.i0 == i - 1 && 1.0f - t.w <= kLastMaxW))) atomicOr(bad + 1, 1u);
       const float ex = minps(vu, 1.0f - vu) * P[RP11_ASPECT_X];
       cols[(LS_X0 * 2 + side) * L.out_w + i] = (uint32_t)t.i0;
       cols[(LS_WX * 2 + side) * L.out_w + i] = f2bits(t.w);
@@ -959,27 +1093,27 @@ __global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint3
       const float ey = minps(vv, 1.0f - vv) * P[RP11_ASPECT_Y];
       uint32_t* r = rows + ((size_t)i * 2 + side) * LS_ROW_FIELDS;
       if (t.i0 < i - 1 || t.i0 > i) why |= 1u;   // the strip keeps rows y-1 .. y+2 of a row pair
-      if (!((t.i0 == i && t.w <= kLastMaxW) || (t.i0 == i - 1 && 1.0f - t.w <= kLastMaxW))) atomicOr(bad + 1, 2u);
       r[LS_Y0] = (uint32_t)t.i0;
       r[LS_WY] = f2bits(t.w);
       r[LS_BY] = f2bits(maxps(border_size - ey, 0.0f));
       r[3] = 0u;
     }
   if (!(border_size > 0.0f)) why |= 2u;   // border_size = 0 makes the penetration 0/0 everywhere: general form
-  if (L.in.w != L.out_w || L.in.h != L.out_h) atomicOr(bad + 1, 4u);
   if (why) atomicOr(bad, why);
 }
 
 constexpr uint32_t kLastLdsTab = 1024u;   // LDS byte offset of the gamma table (behind the decode table; the kernel has no static LDS)
-// one channel of one pixel from the gamma table: sampled colour c, the pixel's own texel `own` and its decoded value `c0`;
-// returns the byte, sets *fail when it is not certain
-template <int N>
-__device__ __forceinline__ uint32_t last_gamma_byte(float c, uint32_t own, float c0, bool* fail) {
+// one channel of one pixel from the gamma table; returns the byte, sets *fail when it is not certain.  c is a LINEAR sample of
+// decoded sRGB texels: 0 <= c <= 1.
+__device__ __forceinline__ uint32_t last_gamma_byte(float c, bool* fail) {
   typedef float last_v4f __attribute__((ext_vector_type(4)));
-  const last_v4f q = *reinterpret_cast<const RC_AS3 last_v4f*>((uintptr_t)(kLastLdsTab + rcstrip2::byte_shl<N, 4>(own)));
-  const float4 e = make_float4(q.x, q.y, q.z, q.w);
-  const float delta = c - c0;
-  const float lin = fma_(e.y, delta, e.x), bound = fma_(lin, 1.2e-7f, fma_(delta * delta, e.z, e.w));   // + 2^-23 lin: the two roundings below
+  // colours below the table's first node store 0 like that node's first colour does (G is monotone, G(2^-20) * 255 < 0.47)
+  const uint32_t cb = max(f2bits(c), kLastTabBits0);
+  const uint32_t off = ((cb - kLastTabBits0) >> (kLastTabShift - 4)) & ~15u;
+  const float c0 = bits2f(cb == 0x3f800000u ? cb : ((cb & ~((1u << kLastTabShift) - 1u)) | (1u << (kLastTabShift - 1))));
+  const last_v4f e = *reinterpret_cast<const RC_AS3 last_v4f*>((uintptr_t)(kLastLdsTab + off));
+  const float delta = bits2f(cb) - c0;
+  const float lin = fma_(delta, fma_(delta, e.z, e.y), e.x), bound = fma_(lin, 1.2e-7f, e.w);   // + 2^-23 lin: the two roundings below
   const float ylo = __builtin_amdgcn_fmed3f(lin - bound, 0.0f, 1.0f) * 255.0f, yhi = __builtin_amdgcn_fmed3f(lin + bound, 0.0f, 1.0f) * 255.0f;
   const float rlo = __builtin_rintf(ylo);
   *fail = *fail || rlo != __builtin_rintf(yhi);
@@ -992,7 +1126,7 @@ __global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, c
   RC_SRGB_LDS(lds, L);
   if (gamma_tab) {   // uniform
     if ((uint32_t)(uintptr_t)(RC_AS3 uint32_t*)rc_dyn_lds_ != 0u) __builtin_trap();   // the table is addressed by absolute LDS offsets
-    if (threadIdx.x < 256) reinterpret_cast<float4*>(rc_dyn_lds_ + kLastLdsTab / 4)[threadIdx.x] = gamma_tab[threadIdx.x];
+    for (int i = (int)threadIdx.x; i < kLastTabNodes; i += 512) reinterpret_cast<float4*>(rc_dyn_lds_ + kLastLdsTab / 4)[i] = gamma_tab[i];
     __syncthreads();
   }
   const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -1015,34 +1149,44 @@ __global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, c
     const int x0 = (int)cols[(LS_X0 * 2 + side) * W + x];
     const float wx = bits2f(cols[(LS_WX * 2 + side) * W + x]), bx = bits2f(cols[(LS_BX * 2 + side) * W + x]);
     const int xa = clampi(x0, 0, Win - 1), xb = clampi(x0 + 1, 0, Win - 1);
-    const bool own_b = x0 < x;   // the pixel's own texel is the pair's second one
     // the gamma table serves pixels away from the border (border factor exactly 1): strips whose columns all are
     const bool tab_cols = gamma_tab != nullptr && __builtin_amdgcn_ballot_w64(bx != 0.0f) == 0ull;
     const uint32_t* img = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
-    // the sampler's horizontal lerp of source row r (clamped), three channels; the pixel's own texel of that row, decoded and raw
-    auto hrow = [&](int r, float* h, float* own_c, uint32_t* own_t) {
+    // the sampler's horizontal lerp of a source row, three channels; the row's two texels are fetched a step ahead of their use
+    auto fetch = [&](int r, uint32_t* ta, uint32_t* tb) {
       const uint32_t* p = img + clampi(r, 0, Hin - 1) * Win;
-      const uint32_t ta = p[xa], tb = p[xb];
-      *own_t = own_b ? tb : ta;
+      *ta = p[xa];
+      *tb = p[xb];
+    };
+    auto hfilter = [&](uint32_t ta, uint32_t tb, float* h) {
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         const float a = lds.dec[(ta >> (8 * ch)) & 255u], b = lds.dec[(tb >> (8 * ch)) & 255u];
         h[ch] = fma_(wx, b - a, a);
-        own_c[ch] = own_b ? b : a;
       }
     };
     float w0[3], w1[3], w2[3], w3[3];   // rows y-1, y, y+1, y+2 of the current row pair
-    float c1[3], c2[3], c3[3];          // the own texel of rows y, y+1, y+2, decoded ...
-    uint32_t t1, t2, t3;                // ... and raw
-    hrow(ys - 1, w0, c1, &t1);
-    hrow(ys, w1, c1, &t1);
+    uint32_t n2a, n2b, n3a, n3b;        // texels of rows y+1, y+2, in flight
+    {
+      uint32_t ta, tb, ua, ub;
+      fetch(ys - 1, &ta, &tb);
+      fetch(ys, &ua, &ub);
+      fetch(ys + 1, &n2a, &n2b);
+      fetch(ys + 2, &n3a, &n3b);
+      hfilter(ta, tb, w0);
+      hfilter(ua, ub, w1);
+    }
     uint32_t failed = 0u;   // bit k: row ys + k of this column is not certain from the table
 #pragma unroll
     for (int k = 0; k < kLastRows; k += 2) {
       const int y = ys + k;
       if (y >= H) break;
-      hrow(y + 1, w2, c2, &t2);
-      hrow(y + 2, w3, c3, &t3);
+      hfilter(n2a, n2b, w2);
+      hfilter(n3a, n3b, w3);
+      if (k + 2 < kLastRows) {
+        fetch(y + 3, &n2a, &n2b);
+        fetch(y + 4, &n3a, &n3b);
+      }
       const uint32_t* ra = rows + ((size_t)y * 2 + side) * LS_ROW_FIELDS;
       const uint32_t* rb = rows + ((size_t)min(y + 1, H - 1) * 2 + side) * LS_ROW_FIELDS;
       const bool a_up = (int)ra[LS_Y0] == y - 1, b_up = (int)rb[LS_Y0] == y;   // the pair starts one row above the target row
@@ -1057,10 +1201,8 @@ __global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, c
       }
       if (tab_cols && bya == 0.0f && byb == 0.0f) {   // uniform: both rows away from the border
         bool fa = false, fb = false;
-        const uint32_t pa = 0xff000000u | last_gamma_byte<0>(ca[0], t1, c1[0], &fa) | (last_gamma_byte<1>(ca[1], t1, c1[1], &fa) << 8) |
-                            (last_gamma_byte<2>(ca[2], t1, c1[2], &fa) << 16);
-        const uint32_t pb = 0xff000000u | last_gamma_byte<0>(cb[0], t2, c2[0], &fb) | (last_gamma_byte<1>(cb[1], t2, c2[1], &fb) << 8) |
-                            (last_gamma_byte<2>(cb[2], t2, c2[2], &fb) << 16);
+        const uint32_t pa = 0xff000000u | last_gamma_byte(ca[0], &fa) | (last_gamma_byte(ca[1], &fa) << 8) | (last_gamma_byte(ca[2], &fa) << 16);
+        const uint32_t pb = 0xff000000u | last_gamma_byte(cb[0], &fb) | (last_gamma_byte(cb[1], &fb) << 8) | (last_gamma_byte(cb[2], &fb) << 16);
         uint32_t* out = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z);
         if (!fa) out[(size_t)y * W + x] = pa; else failed |= 1u << k;
         if (y + 1 < H) {
@@ -1089,9 +1231,7 @@ __global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, c
       for (int ch = 0; ch < 3; ++ch) {
         w0[ch] = w2[ch];
         w1[ch] = w3[ch];
-        c1[ch] = c3[ch];
       }
-      t1 = t3;
     }
     // the pixels the table could not certify: the exact per-pixel form (a few per strip)
     while (__builtin_amdgcn_ballot_w64(failed != 0u) != 0ull) {
@@ -1119,20 +1259,21 @@ void buildLastTables(const PassLaunch& L, hipStream_t s, LastTables* T) {
   if (bad) (void)hipFree(bad);
   T->usable = ok && hbad[0] == 0;
   if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc last] %dx%d: ok %d strip flags %u, gamma table flags %u\n", L.out_w, L.out_h, (int)ok, hbad[0], hbad[1]);
-  if (T->usable && hbad[1] == 0 && hipMalloc(reinterpret_cast<void**>(&T->gamma_tab), 256 * sizeof(float4)) == hipSuccess) {
-    // slopes from the closed form in double precision (any slope is valid: the bound is measured against what is stored)
+  if (T->usable && hbad[1] == 0 && hipMalloc(reinterpret_cast<void**>(&T->gamma_tab), kLastTabNodes * sizeof(float4)) == hipSuccess) {
+    // slope and half curvature from the closed form in double precision (any coefficients are valid: the bound is measured
+    // against what is stored)
     const float inv_gamma = 1.0f / L.params[1];
-    std::vector<float4> h(256);
-    for (int b = 0; b < 256; ++b) {
-      const double c0 = (double)k_srgb_decode_host[b];
-      h[(size_t)b] = make_float4(0.0f, b < 4 ? 0.0f : (float)((double)inv_gamma * std::pow(c0, (double)inv_gamma - 1.0)), 0.0f, 0.0f);
+    const double g = (double)inv_gamma;
+    std::vector<float4> h((size_t)kLastTabNodes);
+    for (int n = 0; n < kLastTabNodes; ++n) {
+      const double c0 = (double)last_node_colour(n);
+      h[(size_t)n] = make_float4(0.0f, (float)(g * std::pow(c0, g - 1.0)), (float)(0.5 * g * (g - 1.0) * std::pow(c0, g - 2.0)), 0.0f);
     }
-    bool tok = hipMemcpyAsync(T->gamma_tab, h.data(), 256 * sizeof(float4), hipMemcpyHostToDevice, s) == hipSuccess;
+    bool tok = hipMemcpyAsync(T->gamma_tab, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice, s) == hipSuccess;
     if (tok) {
-      hipLaunchKernelGGL(k_last_gamma_err, dim3(1, 256), dim3(256), 0, s, inv_gamma, T->gamma_tab, 0);
-      hipLaunchKernelGGL(k_last_gamma_err, dim3(64, 256), dim3(256), 0, s, inv_gamma, T->gamma_tab, 1);
-      hipLaunchKernelGGL(k_last_gamma_err, dim3(64, 256), dim3(256), 0, s, inv_gamma, T->gamma_tab, 2);
-      hipLaunchKernelGGL(k_last_gamma_finish, dim3(1), dim3(256), 0, s, T->gamma_tab);
+      hipLaunchKernelGGL(k_last_gamma_err, dim3(1, kLastTabNodes), dim3(256), 0, s, inv_gamma, T->gamma_tab, 0);
+      hipLaunchKernelGGL(k_last_gamma_err, dim3(16, kLastTabNodes), dim3(256), 0, s, inv_gamma, T->gamma_tab, 1);
+      hipLaunchKernelGGL(k_last_gamma_finish, dim3((kLastTabNodes + 255) / 256), dim3(256), 0, s, T->gamma_tab);
       tok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;   // h must outlive the copy
     }
     if (!tok) {
@@ -1207,10 +1348,9 @@ hipError_t launch_royale_scan_h(const PassLaunch& L, hipStream_t s) {
       static std::mutex mu;
       static std::map<rcstrip::GeoKey, ScanHTables> cache;
       if (const ScanHTables* T = rcstrip::geo_tables<ScanHTables>(L, s, mu, cache, buildScanHTables)) {
-        const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kShRows - 1) / kShRows) * L.n_frames;
+        const long strips = (long)((L.out_w + 127) / 128) * ((L.out_h + kShRows - 1) / kShRows) * L.n_frames;
         const long blocks = (strips + 7) / 8;
-        hipLaunchKernelGGL((k_royale_scan_h_strip<OutS>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512), rcd::srgb_lds_bytes(L), s, L, T->cols,
-                           T->rows);
+        hipLaunchKernelGGL(k_royale_scan_h_strip2, dim3((unsigned)(blocks < 768 ? blocks : 768)), dim3(512), rcstrip2::kStrip2LdsUser, s, L, T->cols, T->rows);
         return hipGetLastError();
       }
     }
@@ -1257,7 +1397,7 @@ hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
         const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kLastRows - 1) / kLastRows) * L.n_frames;
         const long blocks = (strips + 7) / 8;
         hipLaunchKernelGGL((k_royale_last_strip<St<FMT_RGBA8>>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512),
-                           rcd::srgb_lds_bytes(L) + 256 * sizeof(float4), s, L, T->cols, T->rows, T->gamma_tab);
+                           rcd::srgb_lds_bytes(L) + kLastTabNodes * sizeof(float4), s, L, T->cols, T->rows, T->gamma_tab);
         return hipGetLastError();
       }
     }

@@ -28,6 +28,11 @@ def test_two_ranks_through_the_real_entry_point():
     assert line["n_gpus"] == 2 and line["frames_per_rank"] == [5, 5] and line["scaling"] == "weak"
     # whole-job value: both ranks' frames over the slowest rank's time (rank 1 sleeps 2 ms per step)
     assert 0 < line["value"] <= 2 * 5 * 4 / (4 * 0.002)
+    # every rank's own time is in the line (a straggler must show: rank 1 sleeps twice as long as rank 0), the divisor of
+    # `value` is the slowest one, and the communicator saw both ranks
+    pr = line["per_rank_ms_per_step"]
+    assert len(pr) == 2 and pr[1] > pr[0] > 0 and line["world_size_observed"] == 2
+    assert max(pr) <= line["ms_per_step"] * 1.001
 
 
 def test_sharding_helpers():
