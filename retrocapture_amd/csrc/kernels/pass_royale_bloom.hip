@@ -92,6 +92,7 @@ constexpr int kBvRows = 8;
 struct BvTables {
   int pattern = -1;   // bit q: the q-th tap pair (k12, k34, k56, k78) sits at distance 2q + 2 instead of 2q + 1
   bool usable = false;
+  void release() {}
 };
 __global__ void __launch_bounds__(256) k_bloomv_geometry(const PassLaunch L, int* offs, uint32_t* bad) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -243,6 +244,13 @@ struct BhTables {
   // blocks on the diagonal are rendered twice), and per (frames, waves) of a launch the step at which each wave's run begins
   std::vector<uint32_t> cost_sum;
   std::map<std::pair<int, int>, uint32_t*> runs;
+  void release() {
+    if (cols) (void)hipFree(cols);
+    if (rows) (void)hipFree(rows);
+    for (auto& r : runs)
+      if (r.second) (void)hipFree(r.second);
+    *this = BhTables();
+  }
 };
 
 __global__ void __launch_bounds__(256) k_bloomh_geometry(const PassLaunch L, uint32_t* cols, uint32_t* rows, uint32_t* bad) {
@@ -751,7 +759,7 @@ hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s) {
   if (SrgbNearEdge::matches(L.in) && OutS::matches(L)) {
     if (!(L.flags & RC_FLAG_GENERAL_ONLY) && separable(L, 0, 1) && L.in.w == L.out_w) {
       static std::mutex mu;
-      static std::map<GeoKey, BvTables> cache;
+      static std::map<GeoKey, GeoCached<BvTables>> cache;
       if (const BvTables* T = geo_tables<BvTables>(L, s, mu, cache, buildBvTables)) {
         switch (T->pattern) {
 #define RC_BV(p) case p: return launch_bloom_v_strip<p>(L, s);
@@ -771,7 +779,7 @@ hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
       SrgbLinEdge::matches(L.extra[2]) && OutS::matches(L)) {
     if (!(L.flags & RC_FLAG_GENERAL_ONLY) && separable(L, 0, 4) && L.in.frame_stride && L.extra[0].frame_stride && L.extra[1].frame_stride) {
       static std::mutex mu;
-      static std::map<GeoKey, BhTables> cache;
+      static std::map<GeoKey, GeoCached<BhTables>> cache;
       if (const BhTables* T = geo_tables<BhTables>(L, s, mu, cache, buildBhTables)) {
         // one workgroup per CU; every wave gets a run of (frame, band, row) steps of equal estimated cost
         const long steps = (long)((L.out_w + 127) / 128) * L.out_h * L.n_frames;
@@ -780,11 +788,8 @@ hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
         if (!runs) GO(k_royale_bloom_h<SrgbLinEdge, SrgbNearEdge, SrgbNearEdge, SrgbLinEdge, OutS>);
         const unsigned lds = kBhLdsUser + (unsigned)(kBhWaves * kBhWaveDwords) * 4u;
         auto kernel = k_royale_bloom_h_strip;
-        static bool attr = false;
-        if (!attr) {
-          if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return hipGetLastError();
-          attr = true;
-        }
+        // (set on every launch: the attribute is per device, and this needs no shared flag)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return hipGetLastError();
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBhWaves * 64), lds, s, L, T->cols, T->rows, runs);
         return hipGetLastError();
       }

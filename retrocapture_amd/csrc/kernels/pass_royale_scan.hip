@@ -37,6 +37,7 @@
 
 #include "../rc_log.h"
 #include "royale_common.h"
+#include "royale_strip2.h"
 
 using namespace rcd;
 using namespace rcroyale;
@@ -215,15 +216,26 @@ constexpr int kStripRows = 8;                // target rows one thread walks
 constexpr int kTabWaves = 16;                // 1024 threads: one workgroup per CU (the tables fill its LDS)
 constexpr int kTabThreads = kTabWaves * 64;
 
-// dynamic LDS layout, in dwords: decode table, second form of the sRGB8 encode table (rc_device.h), then
-constexpr int kLdsEnc2 = 256;
-constexpr int kLdsA = (kLdsEnc2 + (int)kSrgb2Runs + 3) & ~3;   // float4 A[9][kNodes]: T, dK/dc, d2K/dc2 / 2, dK/ddist
-constexpr int kLdsBound = kLdsA + 9 * kNodes * 4;             // float bound[9][kNodes]: the measured bound of the expansion at this node
-constexpr int kLdsNode = kLdsBound + 9 * kNodes;              // float colour[kNodes]: the node's colour
-constexpr int kFailCap = 4096;                                // tile-local ids of uncertain pixels (more: straight to the global list)
-constexpr int kLdsFail = (kLdsNode + kNodes + 3) & ~3;        // uint16 fails[kFailCap]
-constexpr int kLdsCnt = kLdsFail + kFailCap / 2;              // their count, and the base of the tile's range in the global list
-constexpr int kLdsTotal = kLdsCnt + 4;
+// dynamic LDS layout of the table kernel, in bytes (the kernel has no static LDS: absolute offsets, see royale_strip2.h).  The
+// expansion table comes first, so that a node's record is addressed by (byte or bucket) * 16 plus an immediate for the role.
+constexpr uint32_t kLdsA = 0u;                                        // float4 A[9][kNodes]: T, dK/dc, d2K/dc2 / 2, W
+constexpr uint32_t kLdsDec = kLdsA + 9u * kNodes * 16u;               // the sRGB decode table (256 floats)
+constexpr uint32_t kLdsEnc2 = kLdsDec + 1024u;                        // second form of the sRGB8 encode table (rc_device.h)
+constexpr int kFailCap = 4096;                                        // tile-local ids of uncertain pixels (more: straight to the global list)
+constexpr uint32_t kLdsFail = (kLdsEnc2 + kSrgb2Runs * 4u + 15u) & ~15u;   // uint16 fails[kFailCap]
+constexpr uint32_t kLdsCnt = kLdsFail + kFailCap * 2u;                // their count, and the base of the tile's range in the global list
+constexpr uint32_t kLdsTotalBytes = kLdsCnt + 16u;
+static_assert(kLdsDec + 1020u < 65536u && 8u * kNodes * 16u + (kNodes - 1u) * 16u < 65536u, "immediate offsets of the LDS reads");
+// W of a record: dK/ddist with its low 11 mantissa bits replaced by the node's bound, a 5-bit exponent and a 6-bit mantissa
+// rounded up: (1 + m / 64) 2^(e - 40).  (The coefficient's truncation is part of what the bound is measured against.)
+__host__ __device__ __forceinline__ float scan_w_slope(float w) { return bits2f(f2bits(w) & 0xfffff800u); }
+__host__ __device__ __forceinline__ float scan_w_bound(float w) { return bits2f(((f2bits(w) & 0x7ffu) << 17) + 0x2b800000u); }
+__host__ __device__ inline uint32_t scan_bound_code(float b) {   // smallest code whose value is >= b
+  const uint32_t lo = 0x2b800000u, u = f2bits(b);
+  if (!(b > bits2f(lo))) return 0u;
+  const uint32_t code = (u - lo + 0x1ffffu) >> 17;   // round the 23-bit mantissa up to 6 bits
+  return code > 0x7ffu ? 0x7ffu : code;
+}
 constexpr int kMaxDists = 24;                                 // distinct row distances a geometry may have for the table form
 
 // Pixels whose byte the table form could not certify are collected per tile in LDS and appended (one global atomic
@@ -289,7 +301,7 @@ __global__ void __launch_bounds__(256) k_scan_tab_bounds(const float4* __restric
     for (int d = 0; d < n_dists; ++d) {
       const float dist = dists[d], dd = scan_dd(jc / 3, jc % 3, dist, 0.0f);
       const v2f k = beam_k<v2f, true>(c, v2f{dd, dd}, off, sigma_range, shape_range);
-      const float base = fma_(a.w, dist, a.x);
+      const float base = fma_(scan_w_slope(a.w), dist, a.x);
       // the kernel: fma(delta, fma(delta, a.z, a.y), fma(a.w, dist, a.x))
       const float kx = fma_(delta.x, fma_(delta.x, a.z, a.y), base), ky = fma_(delta.y, fma_(delta.y, a.z, a.y), base);
       const double ex = fabs((double)k.x - (double)kx), ey = fabs((double)k.y - (double)ky);
@@ -298,15 +310,19 @@ __global__ void __launch_bounds__(256) k_scan_tab_bounds(const float4* __restric
   }
   if (worst > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(&bound[e]), f2bits(worst));
 }
-// the stored bound absorbs the roundings of the table kernel's own sums of the three K and of the three bounds
-__global__ void __launch_bounds__(256) k_scan_tab_bounds_finish(float* bound, const float* __restrict__ node) {
+// the stored bound absorbs the roundings of the table kernel's own sums of the three K and of the three bounds; it goes into
+// the low bits of the record's W, rounded up to its 11-bit code (bound[] keeps the value that code stands for)
+__global__ void __launch_bounds__(256) k_scan_tab_bounds_finish(float4* A, float* bound, const float* __restrict__ node) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= 9 * kNodes) return;
   const int n = e % kNodes;
   float b = bound[e] * 1.000001f + 1e-12f;
   if (n == kLogNodes) b = 2.5e-8f;   // colours below 2^-32 (and 0): 0 <= K <= 81 colour < 1.9e-8 (beta <= 4, 1/alpha <= 35.4, gamma_impl >= 0.88)
-  if (n > kLogNodes && !(node[n] + kMaxDelta >= kLogMax)) b = 1e30f;
-  bound[e] = b;
+  uint32_t code = scan_bound_code(b);
+  if (n > kLogNodes && !(node[n] + kMaxDelta >= kLogMax)) code = 0x7ffu;   // a byte below the log range: never selected
+  const float w = bits2f((f2bits(A[e].w) & 0xfffff800u) | code);
+  A[e].w = w;
+  bound[e] = scan_w_bound(w);
 }
 
 // Where the samples of every target row / column land, evaluated with the operations of scan_v_gather and of the
@@ -374,40 +390,45 @@ __global__ void __launch_bounds__(256) k_scan_geometry(const PassLaunch L, ScanR
 // everything above 1 stores 255 like 1) and looked up; inside one run the byte is monotone, and across the boundary to
 // the next run it is where bit 30 of the entry says so (the encode is not monotone across every run boundary).  So the byte
 // is certain when both ends give the same byte and lie in one run, or in two neighbouring runs with a monotone boundary.
-__device__ __forceinline__ uint32_t srgb8_interval(float s, float b, const uint32_t* enc2, bool* ok) {
+__device__ __forceinline__ uint32_t srgb8_interval(float s, float b, bool* ok) {
   const uint32_t bl = f2bits(__builtin_amdgcn_fmed3f(s - b, bits2f(kSrgb2MinBits), 1.0f)), bh = f2bits(__builtin_amdgcn_fmed3f(s + b, bits2f(kSrgb2MinBits), 1.0f));
   const uint32_t rl = bl >> 13, rh = bh >> 13;
-  const uint32_t el = enc2[rl - kSrgb2Run0], eh = enc2[rh - kSrgb2Run0];
+  const uint32_t el = rcstrip2::lds_u32((rl << 2) + (kLdsEnc2 - (kSrgb2Run0 << 2))), eh = rcstrip2::lds_u32((rh << 2) + (kLdsEnc2 - (kSrgb2Run0 << 2)));
   const uint32_t byte_l = ((el + (bl & 0x1fffu)) >> 13) & 255u, byte_h = ((eh + (bh & 0x1fffu)) >> 13) & 255u;
   *ok = byte_l == byte_h && (rh - rl) <= ((el >> 30) & 1u);
   return byte_l;
 }
 
+// One (scanline, channel) evaluation from the table.  c: the sampled colour; byte_addr: (kLogNodes + the own texel's byte) * 16;
+// d: that texel's decoded value; ROLE = scanline * 3 + channel.  Returns the expanded K, adds the node's bound to *bsum.
+template <int ROLE>
+__device__ __forceinline__ float scan_tab_eval(float c, uint32_t byte_addr, float d, float dist, float* bsum) {
+  using namespace rcstrip2;
+  const uint32_t cb = f2bits(c);
+  const uint32_t t = cb - kLogBits0;
+  // colours in [2^-32, 2^-8) select a log bucket (8 per octave: index = t >> 20), everything else the own texel's byte node
+  // (a colour below 2^-32 belongs to a zero byte: the zero node)
+  const bool dark = t < (0x3b800000u - kLogBits0);
+  const uint32_t addr = dark ? ((t >> 16) & ~15u) : byte_addr;
+  const float node = dark ? bits2f((cb & 0xfff00000u) | 0x00080000u) : d;
+  const v4f a = lds_v4f(kLdsA + (uint32_t)ROLE * kNodes * 16u + addr);
+  const float delta = c - node;   // at most kMaxDelta (byte nodes: k_scan_geometry bounds the weights) or half a bucket
+  *bsum += scan_w_bound(a.w);
+  return fma_(delta, fma_(delta, a.z, a.y), fma_(scan_w_slope(a.w), dist, a.x));
+}
+
 template <class SI, class SO>
-__global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLaunch L, const float4* __restrict__ gA, const float* __restrict__ gBound,
-                                                                  const float* __restrict__ gNode, const ScanRow* __restrict__ rows,
+__global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLaunch L, const float4* __restrict__ gA, const ScanRow* __restrict__ rows,
                                                                   const float* __restrict__ cols) {
+  using namespace rcstrip2;
   extern __shared__ uint32_t rc_dyn_lds_[];
+  if ((uint32_t)(uintptr_t)(RC_AS3 uint32_t*)rc_dyn_lds_ != 0u) __builtin_trap();   // absolute LDS offsets
   const int tid = (int)threadIdx.x;
-  SrgbLds lds;
-  {
-    float* dec = reinterpret_cast<float*>(rc_dyn_lds_);
-    for (int i = tid; i < 256; i += kTabThreads) dec[i] = k_srgb_decode[i];
-    for (int i = tid; i < (int)kSrgb2Runs; i += kTabThreads) rc_dyn_lds_[kLdsEnc2 + i] = L.srgb_enc[kSrgbRuns + i];
-    lds.dec = dec;
-    lds.enc = L.srgb_enc;   // (first form, in device memory: not used by this kernel)
-  }
-  const uint32_t* enc2 = rc_dyn_lds_ + kLdsEnc2;
-  float4* A = reinterpret_cast<float4*>(rc_dyn_lds_ + kLdsA);
-  float* Bound = reinterpret_cast<float*>(rc_dyn_lds_ + kLdsBound);
-  float* Node = reinterpret_cast<float*>(rc_dyn_lds_ + kLdsNode);
-  for (int i = tid; i < 9 * kNodes; i += kTabThreads) {
-    A[i] = gA[i];
-    Bound[i] = gBound[i];
-  }
-  for (int i = tid; i < kNodes; i += kTabThreads) Node[i] = gNode[i];
-  uint16_t* fails = reinterpret_cast<uint16_t*>(rc_dyn_lds_ + kLdsFail);
-  uint32_t* cnt = rc_dyn_lds_ + kLdsCnt;
+  for (int i = tid; i < 9 * kNodes; i += kTabThreads) reinterpret_cast<float4*>(rc_dyn_lds_)[i] = gA[i];
+  for (int i = tid; i < 256; i += kTabThreads) rc_dyn_lds_[kLdsDec / 4 + i] = f2bits(k_srgb_decode[i]);
+  for (int i = tid; i < (int)kSrgb2Runs; i += kTabThreads) rc_dyn_lds_[kLdsEnc2 / 4 + i] = L.srgb_enc[kSrgbRuns + i];
+  uint16_t* fails = reinterpret_cast<uint16_t*>(rc_dyn_lds_ + kLdsFail / 4);
+  uint32_t* cnt = rc_dyn_lds_ + kLdsCnt / 4;
   if (tid == 0) cnt[0] = 0u;
   __syncthreads();
   const int W = L.out_w, H = L.out_h;
@@ -425,77 +446,107 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
         uint32_t* out = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z);
         const float wx = cols[x];
         const int xr = x + 1 < W ? x + 1 : W - 1;
-        // rolling window of five source rows (y-2 .. y+2 of the current target row): the texel (its bytes select the
-        // nodes) and, per channel, the sampler's horizontal lerp of that row, exactly as the GL evaluates it
-        uint32_t t[5];
-        float crow[5][3];
-        auto decode_row = [&](uint32_t tc, uint32_t tr, int slot) {
-          t[slot] = tc;
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            const float d = lds.dec[(tc >> (8 * ch)) & 255u], dr = lds.dec[(tr >> (8 * ch)) & 255u];
-            crow[slot][ch] = fma_(wx, dr - d, d);
+        const int tri_x = (2 * x + 1) * H;
+        // Window of source rows around the four target rows of a step (rows y0 - 2 .. y0 + 5, slot i = row y0 - 2 + i): per row
+        // and channel the sampler's horizontal lerp `crow` exactly as the GL evaluates it, the difference to the next row's, the
+        // own texel's decoded value and its byte as a table address.
+        constexpr int kStep = 4, kWin = kStep + 4;
+        float crow[kWin][3], drow[kWin][3], own[kWin][3];
+        uint32_t baddr[kWin][3];
+        auto decode_row = [&](uint32_t tc, uint32_t tr, int slot) __attribute__((always_inline)) {
+          {
+            const float d = lds_f32(kLdsDec + byte_shl<0, 2>(tc)), dr = lds_f32(kLdsDec + byte_shl<0, 2>(tr));
+            crow[slot][0] = fma_(wx, dr - d, d);
+            own[slot][0] = d;
+            baddr[slot][0] = byte_shl<0, 4>(tc) + (uint32_t)kLogNodes * 16u;
+          }
+          {
+            const float d = lds_f32(kLdsDec + byte_shl<1, 2>(tc)), dr = lds_f32(kLdsDec + byte_shl<1, 2>(tr));
+            crow[slot][1] = fma_(wx, dr - d, d);
+            own[slot][1] = d;
+            baddr[slot][1] = byte_shl<1, 4>(tc) + (uint32_t)kLogNodes * 16u;
+          }
+          {
+            const float d = lds_f32(kLdsDec + byte_shl<2, 2>(tc)), dr = lds_f32(kLdsDec + byte_shl<2, 2>(tr));
+            crow[slot][2] = fma_(wx, dr - d, d);
+            own[slot][2] = d;
+            baddr[slot][2] = byte_shl<2, 4>(tc) + (uint32_t)kLogNodes * 16u;
           }
         };
+        uint32_t nc[kStep], nr[kStep];   // raw texels of the four rows that enter with the next step, in flight
+        auto fetch_rows = [&](int first) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = clampi(ys - 2 + i, 0, H - 1);
-          decode_row(img[r * W + x], img[r * W + xr], i);
-        }
-        int rn = clampi(ys + 2, 0, H - 1);
-        uint32_t nc = img[rn * W + x], nr = img[rn * W + xr];   // row y+2 of the first target row, in flight
+          for (int i = 0; i < kStep; ++i) {
+            const int r = clampi(first + i, 0, H - 1);
+            nc[i] = img[r * W + x];
+            nr[i] = img[r * W + xr];
+          }
+        };
+        fetch_rows(ys - 2);
+#pragma unroll
+        for (int i = 0; i < kStep; ++i) decode_row(nc[i], nr[i], i);
+        fetch_rows(ys + 2);
 #pragma unroll 1
-        for (int k = 0; k < kStripRows; ++k) {
-          const int y = ys + k;
-          if (y >= H) break;
-          decode_row(nc, nr, 4);
-          rn = clampi(y + 3, 0, H - 1);
-          nc = img[rn * W + x];   // next iteration's row
-          nr = img[rn * W + xr];
-          const ScanRow ri = rows[y];
-          const bool lo = rcd::lower_tri(x, y, W, H);
-          const float dist = lo ? ri.dist_lo : ri.dist_up;
-          uint32_t fail = (y < 2 || y >= H - 2) ? 1u : ((ri.up >> (lo ? 8 : 9)) & 1u);
-          uint32_t px = 0xff000000u;
+        for (int k0 = 0; k0 < kStripRows; k0 += kStep) {
+          const int y0 = ys + k0;
+          if (y0 >= H) break;
 #pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            float kj[3], bj[3];
+          for (int i = 0; i < kStep; ++i) decode_row(nc[i], nr[i], kStep + i);
+          fetch_rows(y0 + kStep + 2);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-              const int wi = 2 + (j == 0 ? 0 : (j == 1 ? 1 : -1));
-              const bool up = (ri.up >> j) & 1u;
-              const float lowc = up ? crow[wi - 1][ch] : crow[wi][ch], highc = up ? crow[wi][ch] : crow[wi + 1][ch];
-              const float c = fma_(ri.wy[j], highc - lowc, lowc);   // ... and its vertical lerp: the sampled colour
-              const uint32_t cb = f2bits(c);
-              const uint32_t byte = (t[wi] >> (8 * ch)) & 255u;
-              uint32_t idx = (uint32_t)kLogNodes + byte;
-              if (c < kLogMax) idx = cb >= kLogBits0 ? (cb - kLogBits0) >> 20 : (uint32_t)kLogNodes;
-              const uint32_t e = (uint32_t)((j * 3 + ch) * kNodes) + idx;
-              const float4 a = A[e];
-              const float delta = c - Node[idx];   // at most kMaxDelta (byte nodes: k_scan_geometry bounds the weights) or half a bucket
-              kj[j] = fma_(delta, fma_(delta, a.z, a.y), fma_(a.w, dist, a.x));
-              bj[j] = Bound[e];
+          for (int i = 0; i + 1 < kWin; ++i)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) drow[i][ch] = crow[i + 1][ch] - crow[i][ch];
+#pragma unroll
+          for (int k = 0; k < kStep; ++k) {
+            const int y = y0 + k;
+            if (y < H) {
+              const ScanRow ri = rows[y];
+              const bool lo = (2 * y + 1) * W <= tri_x;
+              const float dist = lo ? ri.dist_lo : ri.dist_up;
+              uint32_t fail = (y < 2 || y >= H - 2) ? 1u : ((ri.up >> (lo ? 8 : 9)) & 1u);
+              uint32_t px = 0xff000000u;
+              // scanline j of the target row: the row pair (wi - 1, wi) or (wi, wi + 1) around window slot wi, by ri.up
+              const int w0 = k + 2, w1 = k + 3, w2 = k + 1;
+              const bool up0 = ri.up & 1u, up1 = ri.up & 2u, up2 = ri.up & 4u;
+#define RC_SCAN_CH(ch)                                                                                                        \
+              {                                                                                                               \
+                const float c0 = fma_(ri.wy[0], up0 ? drow[w0 - 1][ch] : drow[w0][ch], up0 ? crow[w0 - 1][ch] : crow[w0][ch]);  \
+                const float c1 = fma_(ri.wy[1], up1 ? drow[w1 - 1][ch] : drow[w1][ch], up1 ? crow[w1 - 1][ch] : crow[w1][ch]);  \
+                const float c2 = fma_(ri.wy[2], up2 ? drow[w2 - 1][ch] : drow[w2][ch], up2 ? crow[w2 - 1][ch] : crow[w2][ch]);  \
+                float bs = 0.0f;                                                                                              \
+                const float q0 = scan_tab_eval<0 + ch>(c0, baddr[w0][ch], own[w0][ch], dist, &bs);                             \
+                const float q1 = scan_tab_eval<3 + ch>(c1, baddr[w1][ch], own[w1][ch], dist, &bs);                             \
+                const float q2 = scan_tab_eval<6 + ch>(c2, baddr[w2][ch], own[w2][ch], dist, &bs);                             \
+                const float s = ((q0 + q1) + q2) * 0.5f;                                                                      \
+                const float b = fma_(5e-7f, s, 0.5f * bs);                                                                    \
+                bool ok;                                                                                                      \
+                const uint32_t byte = srgb8_interval(s, b, &ok);                                                              \
+                fail |= ok ? 0u : 1u;                                                                                         \
+                px |= byte << (8 * ch);                                                                                       \
+              }
+              RC_SCAN_CH(0)
+              RC_SCAN_CH(1)
+              RC_SCAN_CH(2)
+#undef RC_SCAN_CH
+              if (fail == 0u) {
+                out[(size_t)y * W + x] = px;
+              } else {
+                const uint32_t slot = atomicAdd(cnt, 1u);
+                if (slot < (uint32_t)kFailCap) fails[slot] = (uint16_t)((wave << 9) | ((k0 + k) << 6) | lane);
+                else fix_list(L)[atomicAdd(fix_counter(L), 1u)] = (uint32_t)((z * H + y) * W + x);   // (a tile with more uncertain pixels than the local list holds)
+              }
             }
-            const float s = ((kj[0] + kj[1]) + kj[2]) * 0.5f;
-            const float b = fma_(5e-7f, s, 0.5f * ((bj[0] + bj[1]) + bj[2]));
-            bool ok;
-            const uint32_t byte = srgb8_interval(s, b, enc2, &ok);
-            fail |= ok ? 0u : 1u;
-            px |= byte << (8 * ch);
           }
-          if (fail == 0u) {
-            out[(size_t)y * W + x] = px;
-          } else {
-            const uint32_t slot = atomicAdd(cnt, 1u);
-            if (slot < (uint32_t)kFailCap) fails[slot] = (uint16_t)((wave << 9) | (k << 6) | lane);
-            else fix_list(L)[atomicAdd(fix_counter(L), 1u)] = (uint32_t)((z * H + y) * W + x);   // (a tile with more uncertain pixels than the local list holds)
-          }
+          // the last four rows of the window are the first four of the next step's
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            t[i] = t[i + 1];
+          for (int i = 0; i < kStep; ++i)
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) crow[i][ch] = crow[i + 1][ch];
-          }
+            for (int ch = 0; ch < 3; ++ch) {
+              crow[i][ch] = crow[i + kStep][ch];
+              own[i][ch] = own[i + kStep][ch];
+              baddr[i][ch] = baddr[i + kStep][ch];
+            }
         }
       }
     }
@@ -596,7 +647,7 @@ void buildScanTablesHost(float off, std::vector<float>* A, std::vector<float>* n
       const double k0 = M.K(c0, D0), kp = M.K(c0 + h, D0), km = M.K(c0 - h, D0);
       (*A)[i * 4 + 1] = (float)((kp - km) / (2.0 * h));
       (*A)[i * 4 + 2] = (float)(0.5 * (kp - 2.0 * k0 + km) / (h * h));
-      (*A)[i * 4 + 3] = (float)((M.K(c0, modelDd(j, ch, 1e-6)) - M.K(c0, modelDd(j, ch, -1e-6))) / 2e-6);
+      (*A)[i * 4 + 3] = scan_w_slope((float)((M.K(c0, modelDd(j, ch, 1e-6)) - M.K(c0, modelDd(j, ch, -1e-6))) / 2e-6));
     }
   }
 }
@@ -628,7 +679,7 @@ bool buildScanNodeTables(float off, const std::vector<float>& dists, hipStream_t
   if (ok) {
     hipLaunchKernelGGL(k_scan_tab_nodes, dim3((9 * kNodes + 255) / 256), dim3(256), 0, s, T->A, T->node, off);
     hipLaunchKernelGGL(k_scan_tab_bounds, dim3(16, 9 * kNodes), dim3(256), 0, s, T->A, T->node, dd, (int)dists.size(), off, T->bound);
-    hipLaunchKernelGGL(k_scan_tab_bounds_finish, dim3((9 * kNodes + 255) / 256), dim3(256), 0, s, T->bound, T->node);
+    hipLaunchKernelGGL(k_scan_tab_bounds_finish, dim3((9 * kNodes + 255) / 256), dim3(256), 0, s, T->A, T->bound, T->node);
     // the host vectors must outlive the asynchronous copies
     ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
   }
@@ -642,6 +693,7 @@ struct ScanTables {
   ScanRow* rows = nullptr;
   float* cols = nullptr;
   bool usable = false;
+  uint64_t last_use = 0;
 };
 struct ScanKey {
   int device, in_w, in_h, out_w, out_h;
@@ -666,9 +718,22 @@ const ScanTables* scanTablesFor(const PassLaunch& L, hipStream_t s) {
   static std::mutex mu;
   static std::map<ScanKey, ScanTables> cache;
   std::lock_guard<std::mutex> lock(mu);
+  static uint64_t clock = 0;
   auto it = cache.find(key);
-  if (it != cache.end()) return it->second.usable ? &it->second : nullptr;
-  if (cache.size() > 64) return nullptr;  // geometries keep changing (e.g. a window being resized): stay with the general form
+  if (it != cache.end()) {
+    it->second.last_use = ++clock;
+    return it->second.usable ? &it->second : nullptr;
+  }
+  if (cache.size() >= 16) {   // geometries keep changing (a window being resized): release the least recently used tables
+    auto victim = cache.begin();
+    for (auto c = cache.begin(); c != cache.end(); ++c)
+      if (c->second.last_use < victim->second.last_use) victim = c;
+    (void)hipDeviceSynchronize();   // launches that read them may still be in flight
+    freeScanNodeTables(&victim->second.nodes);
+    if (victim->second.rows) (void)hipFree(victim->second.rows);
+    if (victim->second.cols) (void)hipFree(victim->second.cols);
+    cache.erase(victim);
+  }
   ScanTables T;
   uint32_t* bad = nullptr;
   bool ok = hipMalloc(reinterpret_cast<void**>(&T.rows), sizeof(ScanRow) * (size_t)L.out_h) == hipSuccess &&
@@ -711,6 +776,7 @@ const ScanTables* scanTablesFor(const PassLaunch& L, hipStream_t s) {
     if (T.cols) (void)hipFree(T.cols);
     T = ScanTables();
   }
+  T.last_use = ++clock;
   auto ins = cache.emplace(key, T);
   return ins.first->second.usable ? &ins.first->second : nullptr;
 }
@@ -755,17 +821,13 @@ hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s) {
     const ScanTables* T = room ? scanTablesFor(L, s) : nullptr;
     if (T) {
       auto kernel = k_royale_scan_v_tab<SrgbLinEdge, OutS>;
-      static bool attr = false;
-      if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal * 4) != hipSuccess)
-          return hipGetLastError();
-        attr = true;
-      }
+      // (set on every launch: the attribute is per device, and this needs no shared flag)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsTotalBytes) != hipSuccess)
+        return hipGetLastError();
       const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kStripRows - 1) / kStripRows) * L.n_frames;
       const long tiles = (strips + kTabWaves - 1) / kTabWaves;
       if (hipMemsetAsync(L.scratch, 0, kFixHeader, s) != hipSuccess) return hipGetLastError();
-      hipLaunchKernelGGL(kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(kTabThreads), kLdsTotal * 4, s, L, T->nodes.A, T->nodes.bound, T->nodes.node, T->rows,
-                         T->cols);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(kTabThreads), kLdsTotalBytes, s, L, T->nodes.A, T->rows, T->cols);
       hipLaunchKernelGGL((k_royale_scan_v_fix<SrgbLinEdge, OutS>), dim3(512), dim3(256), rcd::srgb_lds_bytes(L), s, L);
       return hipGetLastError();
     }

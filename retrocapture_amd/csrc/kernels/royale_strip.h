@@ -76,19 +76,39 @@ inline bool separable(const PassLaunch& L, int first, int pairs) {
 }
 
 // Per-geometry device tables, built on first use by `build` (which launches its kernels on `s`, synchronises once
-// to read back whether the geometry qualifies, and fills T->usable) and kept for the life of the process.
+// to read back whether the geometry qualifies, and fills T->usable).  At most kGeoCacheEntries geometries are kept per
+// table kind: when a new one arrives (a parameter being swept, a window being resized) the least recently used one is
+// released - after a device synchronisation, since launches that read its tables may still be in flight.
+constexpr size_t kGeoCacheEntries = 32;
+template <class Tables>
+struct GeoCached {
+  Tables tables;
+  uint64_t last_use = 0;
+};
 template <class Tables, class Build>
-const Tables* geo_tables(const PassLaunch& L, hipStream_t s, std::mutex& mu, std::map<GeoKey, Tables>& cache, Build build) {
+const Tables* geo_tables(const PassLaunch& L, hipStream_t s, std::mutex& mu, std::map<GeoKey, GeoCached<Tables>>& cache, Build build) {
   GeoKey key;
   if (!make_geo_key(L, &key)) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
+  static uint64_t clock = 0;
   auto it = cache.find(key);
-  if (it != cache.end()) return it->second.usable ? &it->second : nullptr;
-  if (cache.size() > 64) return nullptr;  // geometries keep changing (a window being resized): stay with the general form
-  Tables T;
-  build(L, s, &T);
-  auto ins = cache.emplace(key, T);
-  return ins.first->second.usable ? &ins.first->second : nullptr;
+  if (it != cache.end()) {
+    it->second.last_use = ++clock;
+    return it->second.tables.usable ? &it->second.tables : nullptr;
+  }
+  if (cache.size() >= kGeoCacheEntries) {
+    auto victim = cache.begin();
+    for (auto c = cache.begin(); c != cache.end(); ++c)
+      if (c->second.last_use < victim->second.last_use) victim = c;
+    (void)hipDeviceSynchronize();
+    victim->second.tables.release();
+    cache.erase(victim);
+  }
+  GeoCached<Tables> e;
+  build(L, s, &e.tables);
+  e.last_use = ++clock;
+  auto ins = cache.emplace(key, e);
+  return ins.first->second.tables.usable ? &ins.first->second.tables : nullptr;
 }
 
 }  // namespace rcstrip

@@ -1,6 +1,8 @@
 // ShaderEngine on HIP.  Section references are to the reference implementation
 // (src/shader/ShaderEngine.cpp) whose observable behaviour each block keeps.
 #include "shader_engine.h"
+
+#include <atomic>
 #include "varying.h"
 
 #include <algorithm>
@@ -466,6 +468,8 @@ bool ShaderEngine::ensureBuffer(DeviceBuffer& b, size_t bytes) {
   if (bytes == 0) return true;
   if (!hipOk(hipMalloc(&b.ptr, bytes), "hipMalloc")) return false;
   b.bytes = bytes;
+  static std::atomic<uint64_t> generation{0};
+  b.gen = ++generation;   // (a frame-invariant pass kept in a buffer that was re-allocated must be rendered again)
   return true;
 }
 
@@ -903,7 +907,12 @@ bool ShaderEngine::pushHistory(const void* finalFrame, int frameCount, const rcd
     auto it = m_pass0Units.find(k.samplers[s]);
     const int u = it == m_pass0Units.end() ? 0 : it->second;
     L.extra[s] = (u > 0 && u < (int)m_units.size()) ? m_units[(size_t)u] : L.in;
-    if (recycled && L.extra[s].base == recycled) L.extra[s].base = m_historyCleared.ptr;
+    if (recycled && L.extra[s].base == recycled) {
+      // the reference re-specifies the recycled texture at the new size before it clears it (:1768-1798)
+      L.extra[s].base = m_historyCleared.ptr;
+      L.extra[s].w = (int)lastPass.width;
+      L.extra[s].h = (int)lastPass.height;
+    }
   }
   for (size_t q = 0; q < k.params.size() && q < (size_t)rcd::kMaxParams; ++q) L.params[q] = effectiveParameter(p0, k.params[q], custom);
   PassGeometry geo;
@@ -1056,6 +1065,7 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
       }
       // Frame-invariant pass (see ShaderPassData::invariant): every texture it samples is shared by all frames
       bool servedFromCache = false;
+      std::vector<uint8_t> invariantCandidate;
       pd.invariant = false;
       if (k.frame_invariant && !last && !pd.feedbackEnabled && !m_generalOnly) {
         bool inv = !k.reads_input || L.in.frame_stride == 0;
@@ -1064,10 +1074,17 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
           pd.invariant = true;
           L.n_frames = 1;
           L.frame_count0 = 0;
-          std::vector<uint8_t> key(sizeof(L));
-          std::memcpy(key.data(), &L, sizeof(L));
-          servedFromCache = key == pd.invariantKey;
-          pd.invariantKey.swap(key);
+          // the key: the launch descriptor, which allocation the target is (not just its address), and how often the
+          // frame-invariant passes before this one have been rendered (their targets are what this pass samples)
+          invariantCandidate.assign(sizeof(L), 0);
+          std::memcpy(invariantCandidate.data(), &L, sizeof(L));
+          auto append = [&](uint64_t v) {
+            const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
+            invariantCandidate.insert(invariantCandidate.end(), b, b + sizeof(v));
+          };
+          append(pd.target.gen);
+          for (size_t j = 0; j < i; ++j) append(m_passes[j].invariant ? m_passes[j].renderCount : 0);
+          servedFromCache = invariantCandidate == pd.invariantKey;
         }
       }
       if (!pd.invariant) pd.invariantKey.clear();
@@ -1098,7 +1115,12 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
         if (!hipOk(hipEventCreate(&tl.start), "hipEventCreate") || !hipOk(hipEventCreate(&tl.stop), "hipEventCreate")) return false;
         (void)hipEventRecord(tl.start, m_stream);
       }
-      if (!hipOk(k.launch(L, m_stream), k.name)) return false;
+      if (!hipOk(k.launch(L, m_stream), k.name)) {
+        pd.invariantKey.clear();
+        return false;
+      }
+      ++pd.renderCount;
+      if (pd.invariant) pd.invariantKey.swap(invariantCandidate);   // only a pass that was launched counts as rendered
       if (m_profiling) {
         (void)hipEventRecord(tl.stop, m_stream);
         m_timed.push_back(tl);

@@ -30,6 +30,7 @@ namespace rc {
 struct DeviceBuffer {
   void* ptr = nullptr;
   size_t bytes = 0;
+  uint64_t gen = 0;   // allocation generation: changes whenever the buffer is (re)allocated, even at the same address
 };
 
 struct ShaderPassData {  // reference ShaderEngine.h:19-40
@@ -58,6 +59,7 @@ struct ShaderPassData {  // reference ShaderEngine.h:19-40
   // depends on changes (sizes, parameters, flags, the textures bound): `invariantKey` is the launch it was rendered with.
   bool invariant = false;
   std::vector<uint8_t> invariantKey;
+  uint64_t renderCount = 0;   // how often this pass has actually been rendered (a consumer's key includes its producers' counts)
   size_t frameBytes = 0;
   std::map<std::string, float> extractedParameters;
   std::map<std::string, ShaderParameterInfo> parameterInfo;
