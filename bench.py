@@ -386,6 +386,10 @@ def main():
     ap.add_argument("--io", action="store_true",
                     help="also time the ingest / egress kernels and the whole host-to-host frame path (side "
                          "measurements under \"io\"; never part of `value`)")
+    ap.add_argument("--modes", default="both", choices=["both", "default", "mask"],
+                    help="crt-royale: which behaviour of pass 6's unwritten varying to measure - both (the default line with its "
+                         "`mask_rendered` object), `default` only, or `mask` only (mask rendered; for per-mode rocprofv3 kernel statistics: "
+                         "then `value` IS the mask-rendered figure and config.mask_mode says so)")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise the launch / sharding / reduction path without a GPU (gloo, no engine): for tests")
     args = ap.parse_args()
@@ -450,6 +454,8 @@ def main():
             raise SystemExit("unknown shader parameter " + name)
     if args.chunk:
         e.setChunkFrames(args.chunk)
+    if args.modes == "mask":
+        e.setUndefinedVaryingZero(True)
 
     # synthetic frames, resident in HBM before the timed region: uniform noise, alpha 255
     g = torch.Generator(device="cuda")
@@ -519,7 +525,7 @@ def main():
     # the same with pass 6's unwritten varying read as 0 (GPU GL drivers): the phosphor mask is rendered and passes 7-10
     # carry signal everywhere.  Same steps, same barriers; its own per-pass timing.
     mask_rendered = None
-    if key.startswith("crt-royale"):
+    if key.startswith("crt-royale") and args.modes == "both":
         e.setUndefinedVaryingZero(True)
         for _ in range(args.warmup):
             step()
@@ -554,6 +560,7 @@ def main():
         "float_target_storage": "f16" if args.fp16_targets else "f32",
         "config": {"workload": desc + (" [" + ", ".join(args.param) + "]" if args.param else ""), "frames_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
                    "chunk_frames": args.chunk or "default", "parallelism": "frames sharded, no collective",
+                   "mask_mode": "rendered (rc_engine_set_undefined_varying_zero)" if args.modes == "mask" else "llvmpipe (pass 6 discards)",
                    "algorithmic_bytes_per_frame": chain_bytes,
                    "hbm_roofline_frac_whole_chain": value / world * chain_bytes / (HBM_PEAK_GBS * 1e9),
                    "stream_copy_ceiling_GBs": ceiling,

@@ -1075,10 +1075,7 @@ __global__ void __launch_bounds__(256) k_last_gamma_err(float inv_gamma, float4*
   uint32_t worst = 0u;
   for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i <= hi; i += gridDim.x * 256u) {
     const float c = bits2f(i), delta = c - c0;
-    const double lin = (double)fma_(delta, fma_(delta, e.z, e.y), e.x);
-    double err = fabs((double)last_gamma(c, inv_gamma) - lin);
-    // the two-pixel strip evaluates the colour 1.0 at the last float below it: that float's bound covers G(1) too
-    if (i == 0x3f7fffffu) err = fmax(err, fabs((double)last_gamma(1.0f, inv_gamma) - lin));
+    const double err = fabs((double)last_gamma(c, inv_gamma) - (double)fma_(delta, fma_(delta, e.z, e.y), e.x));
     worst = max(worst, f2bits(__double2float_ru(err)));
   }
   if (worst) atomicMax(reinterpret_cast<uint32_t*>(&tab[n].w), worst);   // non-negative floats order like their bits
@@ -1267,160 +1264,6 @@ __global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, c
   }
 }
 
-// ---- P11, strip form, two pixels per lane (royale_strip2.h): columns x and x + 64 of a 128-column band.  The lerps run as
-// packed float operations over the pixel pair and so do the three output-gamma pows of the rows next to the border; away from
-// it the gamma comes from the certified table (above).  A strip the quad's diagonal crosses is rendered once per triangle,
-// each pixel stored by the pass of its own triangle.
-// one channel of one pixel from the gamma table: the byte, *fail set when it is not certain.  With y = fl(lin * 255) and
-// r = rint(y): the exact code stores rint(fl(clamp(G) * 255)), |G - lin| <= bound, and the two products round within
-// 2^-24 * 255 each, so the byte is r whenever |y - r| + 255 bound + 3.1e-5 < 0.5 (clamping r to [0, 255] commutes with it).
-__device__ __forceinline__ uint32_t last_gamma_byte2(float c, bool* fail) {
-  using namespace rcstrip2;
-  // colours below the table's first node store 0 like that node's first colour does (G is monotone, G(2^-20) * 255 < 0.47);
-  // 1.0 is evaluated at the last float below it (its own error against G(1) is part of that node's measured bound)
-  const uint32_t cb = min(max(f2bits(c), kLastTabBits0), 0x3f7fffffu);
-  const uint32_t off = ((cb - kLastTabBits0) >> (kLastTabShift - 4)) & ~15u;
-  const float c0 = bits2f((cb & ~((1u << kLastTabShift) - 1u)) | (1u << (kLastTabShift - 1)));
-  const v4f e = lds_v4f(kLastLdsTab + off);
-  const float delta = bits2f(cb) - c0;
-  const float y = fma_(delta, fma_(delta, e.z, e.y), e.x) * 255.0f;
-  const float r = __builtin_rintf(y);
-  *fail = *fail || !(__builtin_fabsf(y - r) + fma_(e.w, 255.0f, 3.1e-5f) < 0.5f);
-  return (uint32_t)__builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);
-}
-
-template <class SO>
-__global__ void __launch_bounds__(512) k_royale_last_strip2(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows,
-                                                          const float4* __restrict__ gamma_tab) {
-  using namespace rcstrip2;
-  extern __shared__ uint32_t rc_dyn_lds_[];
-  strip2_load_tables(rc_dyn_lds_, L, false);
-  if (gamma_tab) {   // uniform
-    for (int i = (int)threadIdx.x; i < kLastTabNodes; i += 512) reinterpret_cast<float4*>(rc_dyn_lds_ + kLastLdsTab / 4)[i] = gamma_tab[i];
-    __syncthreads();
-  }
-  SrgbLds lds{reinterpret_cast<const float*>(rc_dyn_lds_), L.srgb_enc};   // for the per-pixel form (a plain RGBA8 target: no encode table)
-  const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int W = L.out_w, H = L.out_h, Win = L.in.w, Hin = L.in.h;
-  const int bands = (W + 127) >> 7, rss = (H + kLastRows - 1) / kLastRows, per_frame = bands * rss, total = per_frame * L.n_frames;
-  const float* P = L.params;
-  const float inv_gamma = 1.0f / P[1], border_size = P[39], border_darkness = P[40], border_compress = P[41];
-  for (int strip = (int)blockIdx.x * 8 + wave; strip < total; strip += (int)gridDim.x * 8) {
-    const int z = strip / per_frame, rem = strip - z * per_frame, rs = rem / bands;
-    const int xw = (rem - rs * bands) << 7, ys = rs * kLastRows;
-    const int xa = xw + lane, xb = xa + 64;
-    const bool live_a = xa < W, live_b = xb < W;
-    const int xca = live_a ? xa : W - 1, xcb = live_b ? xb : W - 1;
-    const int xmax = min(xw + 127, W - 1), ymax = min(ys + kLastRows - 1, H - 1);
-    const bool all_lo = rcd::lower_tri(xw, ymax, W, H), all_up = !rcd::lower_tri(xmax, ys, W, H);
-    const uint8_t* img = frame_ptr(L.in, z);
-    const __amdgpu_buffer_rsrc_t r_out = frame_rsrc(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z, W, H);
-    const int tri_a = (2 * xa + 1) * H, tri_b = (2 * xb + 1) * H;
-    for (int side = all_up ? 1 : 0; side <= (all_lo ? 0 : 1); ++side) {
-      const bool mixed = !all_lo && !all_up;
-      const int x0a = (int)cols[(LS_X0 * 2 + side) * W + xca], x0b = (int)cols[(LS_X0 * 2 + side) * W + xcb];
-      const v2f wx = {bits2f(cols[(LS_WX * 2 + side) * W + xca]), bits2f(cols[(LS_WX * 2 + side) * W + xcb])};
-      const float bxa = bits2f(cols[(LS_BX * 2 + side) * W + xca]), bxb = bits2f(cols[(LS_BX * 2 + side) * W + xcb]);
-      const uint32_t a0 = (uint32_t)clampi(x0a, 0, Win - 1) * 4u, a1 = (uint32_t)clampi(x0a + 1, 0, Win - 1) * 4u;
-      const uint32_t b0 = (uint32_t)clampi(x0b, 0, Win - 1) * 4u, b1 = (uint32_t)clampi(x0b + 1, 0, Win - 1) * 4u;
-      // the gamma table serves pixels away from the border (border factor exactly 1): strips whose columns all are
-      const bool tab_cols = gamma_tab != nullptr && __builtin_amdgcn_ballot_w64(bxa != 0.0f || bxb != 0.0f) == 0ull;
-      auto fetch = [&](int r, uint32_t* q) __attribute__((always_inline)) {
-        const uint8_t* p = img + (size_t)(clampi(r, 0, Hin - 1) * Win) * 4u;
-        q[0] = *reinterpret_cast<const uint32_t*>(p + a0);
-        q[1] = *reinterpret_cast<const uint32_t*>(p + a1);
-        q[2] = *reinterpret_cast<const uint32_t*>(p + b0);
-        q[3] = *reinterpret_cast<const uint32_t*>(p + b1);
-      };
-      auto hfilter = [&](const uint32_t* q, v2f* h) __attribute__((always_inline)) {   // the sampler's horizontal lerp, both pixels
-        const v2f l0 = {dec_byte<0>(q[0]), dec_byte<0>(q[2])}, r0 = {dec_byte<0>(q[1]), dec_byte<0>(q[3])};
-        const v2f l1 = {dec_byte<1>(q[0]), dec_byte<1>(q[2])}, r1 = {dec_byte<1>(q[1]), dec_byte<1>(q[3])};
-        const v2f l2 = {dec_byte<2>(q[0]), dec_byte<2>(q[2])}, r2 = {dec_byte<2>(q[1]), dec_byte<2>(q[3])};
-        h[0] = fma2(wx, r0 - l0, l0);
-        h[1] = fma2(wx, r1 - l1, l1);
-        h[2] = fma2(wx, r2 - l2, l2);
-      };
-      v2f w0[3], w1[3], w2[3];   // rows y - 1, y, y + 1
-      uint32_t nq[4];            // texels of row y + 2, in flight
-      {
-        uint32_t q[4];
-        fetch(ys - 1, q);
-        hfilter(q, w0);
-        fetch(ys, q);
-        hfilter(q, w1);
-        fetch(ys + 1, q);
-        hfilter(q, w2);
-        fetch(ys + 2, nq);
-      }
-      uint32_t failed = 0u;   // bit k / bit 8 + k: row ys + k of pixel A / B is not certain from the table
-#pragma unroll 1
-      for (int y = ys; y <= ymax; ++y) {
-        const uint32_t* rr = rows + ((size_t)y * 2 + side) * LS_ROW_FIELDS;
-        const bool up = (int)rr[LS_Y0] == y - 1;   // the pair starts one row above the target row
-        const float wy = bits2f(rr[LS_WY]), by = bits2f(rr[LS_BY]);
-        v2f c[3];
-        if (up) {
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) c[ch] = fma2(splat2(wy), w1[ch] - w0[ch], w0[ch]);
-        } else {
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) c[ch] = fma2(splat2(wy), w2[ch] - w1[ch], w1[ch]);
-        }
-        bool sa = live_a, sb = live_b;
-        if (mixed) {
-          const int tri_y = (2 * y + 1) * W;
-          sa = sa && (tri_y <= tri_a) == (side == 0);
-          sb = sb && (tri_y <= tri_b) == (side == 0);
-        }
-        uint32_t pa, pb;
-        if (tab_cols && by == 0.0f) {   // uniform: the whole row segment is away from the border
-          bool fa = false, fb = false;
-          pa = 0xff000000u | last_gamma_byte2(c[0].x, &fa) | (last_gamma_byte2(c[1].x, &fa) << 8) | (last_gamma_byte2(c[2].x, &fa) << 16);
-          pb = 0xff000000u | last_gamma_byte2(c[0].y, &fb) | (last_gamma_byte2(c[1].y, &fb) << 8) | (last_gamma_byte2(c[2].y, &fb) << 16);
-          if (fa && sa) failed |= 1u << (y - ys);
-          if (fb && sb) failed |= 256u << (y - ys);
-          sa = sa && !fa;
-          sb = sb && !fb;
-        } else {
-          // border dimming (get_border_dim_factor, as k_royale_last): 1 unless the pixel is within border_size of an edge
-          auto dim = [&](float bx) -> float {
-            float f = 1.0f;
-            if (bx != 0.0f || by != 0.0f) {
-              const float pen = __builtin_sqrtf(bx * bx + by * by) / border_size;
-              const float esc = maxps(1.0f - pen, 0.0f);
-              f = minps(pow_(esc, border_darkness) * maxps(1.0f, border_compress), 1.0f);
-            }
-            return f;
-          };
-          const v2f f = {dim(bxa), dim(bxb)};
-          // the three output-gamma pows of both pixels as packed pairs
-          const v2f o0 = exp2_v<v2f>(log2_v(c[0] * f) * inv_gamma), o1 = exp2_v<v2f>(log2_v(c[1] * f) * inv_gamma), o2 = exp2_v<v2f>(log2_v(c[2] * f) * inv_gamma);
-          pa = unorm8(o0.x) | (unorm8(o1.x) << 8) | (unorm8(o2.x) << 16) | 0xff000000u;
-          pb = unorm8(o0.y) | (unorm8(o1.y) << 8) | (unorm8(o2.y) << 16) | 0xff000000u;
-        }
-        if (sa) __builtin_amdgcn_raw_buffer_store_b32(pa, r_out, xa * 4, y * W * 4, 0);
-        if (sb) __builtin_amdgcn_raw_buffer_store_b32(pb, r_out, xb * 4, y * W * 4, 0);
-        // rows move up by one; row y + 2 enters, row y + 3 is fetched
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          w0[ch] = w1[ch];
-          w1[ch] = w2[ch];
-        }
-        hfilter(nq, w2);
-        fetch(y + 3, nq);
-      }
-      // the pixels the table could not certify: the exact per-pixel form (a few per strip)
-      while (__builtin_amdgcn_ballot_w64(failed != 0u) != 0ull) {
-        if (failed) {
-          const int k = __builtin_ctz(failed);
-          failed &= failed - 1u;
-          last_pixel<SrgbLinEdge, SO, false>(L, lds, k < 8 ? xa : xb, ys + (k & 7), z, side == 0);
-        }
-      }
-    }
-  }
-}
-
 void buildLastTables(const PassLaunch& L, hipStream_t s, LastTables* T) {
   uint32_t* bad = nullptr;   // [0]: the strip form does not apply, [1]: the gamma table does not
   bool ok = hipMalloc(reinterpret_cast<void**>(&T->cols), (size_t)LS_COL_FIELDS * 2 * L.out_w * 4) == hipSuccess &&
@@ -1452,6 +1295,15 @@ void buildLastTables(const PassLaunch& L, hipStream_t s, LastTables* T) {
       hipLaunchKernelGGL(k_last_gamma_err, dim3(16, kLastTabNodes), dim3(256), 0, s, inv_gamma, T->gamma_tab, 1);
       hipLaunchKernelGGL(k_last_gamma_finish, dim3((kLastTabNodes + 255) / 256), dim3(256), 0, s, T->gamma_tab);
       tok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;   // h must outlive the copy
+      if (tok && std::getenv("RC_DEBUG_SCAN") && hipMemcpy(h.data(), T->gamma_tab, h.size() * sizeof(float4), hipMemcpyDeviceToHost) == hipSuccess) {
+        double worst_rel = 0.0, worst_abs = 0.0;
+        for (int n = 0; n < kLastTabNodes; ++n) {
+          worst_abs = std::max(worst_abs, (double)h[(size_t)n].w);
+          worst_rel = std::max(worst_rel, (double)h[(size_t)n].w / std::max(1e-30, (double)h[(size_t)n].x));
+        }
+        std::fprintf(stderr, "[rc last] gamma table: %d nodes, largest bound %.3g (%.3g of the node value); node 0: T %.4g S %.4g C %.4g R %.3g; node 320: T %.4g R %.3g\n",
+                     kLastTabNodes, worst_abs, worst_rel, h[0].x, h[0].y, h[0].z, h[0].w, h[320].x, h[320].w);
+      }
     }
     if (!tok) {
       (void)hipFree(T->gamma_tab);
@@ -1571,10 +1423,10 @@ hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
       static std::mutex mu;
       static std::map<rcstrip::GeoKey, rcstrip::GeoCached<LastTables>> cache;
       if (const LastTables* T = rcstrip::geo_tables<LastTables>(L, s, mu, cache, buildLastTables)) {
-        const long strips = (long)((L.out_w + 127) / 128) * ((L.out_h + kLastRows - 1) / kLastRows) * L.n_frames;
+        const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kLastRows - 1) / kLastRows) * L.n_frames;
         const long blocks = (strips + 7) / 8;
-        hipLaunchKernelGGL((k_royale_last_strip2<St<FMT_RGBA8>>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512),
-                           kLastLdsTab + kLastTabNodes * sizeof(float4), s, L, T->cols, T->rows, T->gamma_tab);
+        hipLaunchKernelGGL((k_royale_last_strip<St<FMT_RGBA8>>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512),
+                           rcd::srgb_lds_bytes(L) + kLastTabNodes * sizeof(float4), s, L, T->cols, T->rows, T->gamma_tab);
         return hipGetLastError();
       }
     }

@@ -175,6 +175,99 @@ __global__ void __launch_bounds__(512) k_royale_bloom_v_strip(const PassLaunch L
   }
 }
 
+// ---- P9, strip form, two pixels per lane (royale_strip2.h): columns x and x + 64 of a 128-column band; the nine weighted
+// taps of the pixel pair run as packed float operations.  A wave walks a run of consecutive rows of one band (equal runs of
+// (frame, band, row) steps per wave) four target rows at a time with the 4 + 16 decoded source rows of the step in
+// registers; after a step the window moves up by four rows (packed register moves) and four new rows, fetched a step
+// ahead, are decoded: every source row is decoded once per run.
+constexpr int kBv2Step = 4, kBv2Win = kBv2Step + 16, kBv2Waves = 12;
+template <int PATTERN>
+__global__ void __launch_bounds__(kBv2Waves * 64) k_royale_bloom_v_strip2(const PassLaunch L) {
+  extern __shared__ uint32_t rc_dyn_lds_[];
+  strip2_load_tables(rc_dyn_lds_, L, true);
+  constexpr int o12 = 1 + ((PATTERN >> 0) & 1), o34 = 3 + ((PATTERN >> 1) & 1), o56 = 5 + ((PATTERN >> 2) & 1), o78 = 7 + ((PATTERN >> 3) & 1);
+  const float* P = L.params;
+  const float w78 = P[RPG_W78], w56 = P[RPG_W56], w34 = P[RPG_W34], w12 = P[RPG_W12], si = P[RPG_SUM_INV];
+  const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int W = L.out_w, H = L.out_h, Hin = L.in.h, Win = L.in.w;
+  const int bands = (W + 127) >> 7;
+  const long total = (long)L.n_frames * bands * H;
+  const long n_waves = (long)gridDim.x * kBv2Waves, me = (long)blockIdx.x * kBv2Waves + wave;
+  long t = total * me / n_waves;
+  const long t_end = total * (me + 1) / n_waves;
+  while (t < t_end) {
+    const int z = (int)(t / ((long)bands * H));
+    const int rem = (int)(t - (long)z * bands * H);
+    const int band = rem / H, y_first = rem - band * H;
+    const int y_last = (int)min((long)H, (long)y_first + (t_end - t));   // exclusive
+    t += y_last - y_first;
+    const int xa = (band << 7) + lane, xb = xa + 64;
+    const bool live_a = xa < W, live_b = xb < W;
+    const uint32_t ca = (uint32_t)min(xa, Win - 1) * 4u, cb = (uint32_t)min(xb, Win - 1) * 4u;   // (k_bloomv_geometry: the taps' column is the pixel's own)
+    const uint8_t* img = frame_ptr(L.in, z);
+    const __amdgpu_buffer_rsrc_t r_out = frame_rsrc(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z, W, H);
+    v2f win[kBv2Win][3];              // decoded source rows y0 - 8 .. y0 + 11 of the step at y0
+    uint32_t na[kBv2Step], nb[kBv2Step];   // raw texels of the four rows that enter with the next step, in flight
+    auto fetch4 = [&](int first) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < kBv2Step; ++i) {
+        const uint8_t* p = img + (size_t)(clampi(first + i, 0, Hin - 1) * Win) * 4u;
+        na[i] = *reinterpret_cast<const uint32_t*>(p + ca);
+        nb[i] = *reinterpret_cast<const uint32_t*>(p + cb);
+      }
+    };
+    auto decode4 = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < kBv2Step; ++i) {
+        win[slot + i][0] = v2f{dec_byte<0>(na[i]), dec_byte<0>(nb[i])};
+        win[slot + i][1] = v2f{dec_byte<1>(na[i]), dec_byte<1>(nb[i])};
+        win[slot + i][2] = v2f{dec_byte<2>(na[i]), dec_byte<2>(nb[i])};
+      }
+    };
+    // prime: rows y_first - 8 .. y_first + 7 into slots 4 .. 19 (they move down by four at the top of the first step)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      fetch4(y_first - 8 + 4 * g);
+      decode4(kBv2Step + 4 * g);
+    }
+    fetch4(y_first + 8);
+#pragma unroll 1
+    for (int y0 = y_first; y0 < y_last; y0 += kBv2Step) {
+#pragma unroll
+      for (int i = 0; i < kBv2Win - kBv2Step; ++i)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) win[i][ch] = win[i + kBv2Step][ch];
+      decode4(kBv2Win - kBv2Step);
+      fetch4(y0 + kBv2Step + 8);
+#pragma unroll
+      for (int k = 0; k < kBv2Step; ++k) {
+        const int y = y0 + k;
+        if (y < y_last) {
+          v2f o[3];
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            // tex2Dblur17fast in the GL's evaluation order (blur17 above)
+            v2f a = w78 * win[k + 8 - o78][ch];
+            a += w56 * win[k + 8 - o56][ch];
+            a += w34 * win[k + 8 - o34][ch];
+            a += win[k + 8][ch];
+            a += w12 * win[k + 8 - o12][ch];
+            a += w12 * win[k + 8 + o12][ch];
+            a += w34 * win[k + 8 + o34][ch];
+            a += w56 * win[k + 8 + o56][ch];
+            a += w78 * win[k + 8 + o78][ch];
+            o[ch] = a * si;
+          }
+          uint32_t pa, pb;
+          srgb8_pack2(o, &pa, &pb);
+          if (live_a) __builtin_amdgcn_raw_buffer_store_b32(pa, r_out, xa * 4, y * W * 4, 0);
+          if (live_b) __builtin_amdgcn_raw_buffer_store_b32(pb, r_out, xb * 4, y * W * 4, 0);
+        }
+      }
+    }
+  }
+}
+
 void buildBvTables(const PassLaunch& L, hipStream_t s, BvTables* T) {
   int* offs = nullptr;
   uint32_t* bad = nullptr;
@@ -750,9 +843,11 @@ using OutS = St<FMT_SRGB8>;
 
 template <int PATTERN>
 hipError_t launch_bloom_v_strip(const PassLaunch& L, hipStream_t s) {
-  const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kBvRows - 1) / kBvRows) * L.n_frames;
-  const long blocks = (strips + 7) / 8;
-  hipLaunchKernelGGL((k_royale_bloom_v_strip<OutS, PATTERN>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512), rcd::srgb_lds_bytes(L), s, L);
+  // one run of rows per wave, one workgroup of twelve waves per CU (the window's 154 registers allow three waves per SIMD):
+  // 8 frames of 1080p make runs of 42 rows, 16 more being the window's lead-in
+  const long steps = (long)((L.out_w + 127) / 128) * L.out_h * L.n_frames;
+  const long blocks = std::max<long>(1, std::min<long>(256, steps / (kBv2Waves * 16)));
+  hipLaunchKernelGGL((k_royale_bloom_v_strip2<PATTERN>), dim3((unsigned)blocks), dim3(kBv2Waves * 64), rcstrip2::kStrip2LdsUser, s, L);
   return hipGetLastError();
 }
 hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s) {

@@ -284,7 +284,7 @@ __device__ __forceinline__ void scan_node_range(int n, float c0, uint32_t* lo, u
   }
 }
 __global__ void __launch_bounds__(256) k_scan_tab_bounds(const float4* __restrict__ A, const float* __restrict__ node, const float* __restrict__ dists,
-                                                        int n_dists, float off, float* bound) {
+                                                        int n_dists, float off, float* bound, float* kmax) {
   const int e = (int)blockIdx.y, jc = e / kNodes, n = e - jc * kNodes;
   const float c0 = node[n];
   if (n == kLogNodes) return;                                   // the zero colour: bound set by the host (no expansion, K < 2.5e-8)
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256) k_scan_tab_bounds(const float4* __restric
   scan_node_range(n, c0, &lo, &hi);
   const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
   const float4 a = A[e];
-  float worst = 0.0f;
+  float worst = 0.0f, largest = 0.0f;   // ... and the largest exact K itself, per role (kmax[9]: see kScanSkipBelow)
   // two consecutive colours per step through the packed form of beam_k (the same IEEE operations per component)
   for (uint32_t i = lo + 2u * (blockIdx.x * 256u + threadIdx.x); i <= hi; i += 2u * gridDim.x * 256u) {
     const v2f c = {bits2f(i), bits2f(i + 1u <= hi ? i + 1u : i)};
@@ -306,9 +306,11 @@ __global__ void __launch_bounds__(256) k_scan_tab_bounds(const float4* __restric
       const float kx = fma_(delta.x, fma_(delta.x, a.z, a.y), base), ky = fma_(delta.y, fma_(delta.y, a.z, a.y), base);
       const double ex = fabs((double)k.x - (double)kx), ey = fabs((double)k.y - (double)ky);
       worst = fmaxf(worst, __double2float_ru(ex > ey ? ex : ey));
+      largest = fmaxf(largest, fmaxf(__builtin_fabsf(k.x), __builtin_fabsf(k.y)));
     }
   }
   if (worst > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(&bound[e]), f2bits(worst));
+  if (largest > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(&kmax[jc]), f2bits(largest));
 }
 // the stored bound absorbs the roundings of the table kernel's own sums of the three K and of the three bounds; it goes into
 // the low bits of the record's W, rounded up to its 11-bit code (bound[] keeps the value that code stands for)
@@ -417,9 +419,10 @@ __device__ __forceinline__ float scan_tab_eval(float c, uint32_t byte_addr, floa
   return fma_(delta, fma_(delta, a.z, a.y), fma_(scan_w_slope(a.w), dist, a.x));
 }
 
-template <class SI, class SO>
+// SKIP1: the scanline below contributes less than skip_r / _g / _b whatever its colour (ScanNodeTables): taken as 0, bound added
+template <class SI, class SO, bool SKIP1>
 __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLaunch L, const float4* __restrict__ gA, const ScanRow* __restrict__ rows,
-                                                                  const float* __restrict__ cols) {
+                                                                  const float* __restrict__ cols, float skip_r, float skip_g, float skip_b) {
   using namespace rcstrip2;
   extern __shared__ uint32_t rc_dyn_lds_[];
   if ((uint32_t)(uintptr_t)(RC_AS3 uint32_t*)rc_dyn_lds_ != 0u) __builtin_trap();   // absolute LDS offsets
@@ -512,11 +515,13 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
 #define RC_SCAN_CH(ch)                                                                                                        \
               {                                                                                                               \
                 const float c0 = fma_(ri.wy[0], up0 ? drow[w0 - 1][ch] : drow[w0][ch], up0 ? crow[w0 - 1][ch] : crow[w0][ch]);  \
-                const float c1 = fma_(ri.wy[1], up1 ? drow[w1 - 1][ch] : drow[w1][ch], up1 ? crow[w1 - 1][ch] : crow[w1][ch]);  \
                 const float c2 = fma_(ri.wy[2], up2 ? drow[w2 - 1][ch] : drow[w2][ch], up2 ? crow[w2 - 1][ch] : crow[w2][ch]);  \
-                float bs = 0.0f;                                                                                              \
+                float bs = SKIP1 ? (ch == 0 ? skip_r : (ch == 1 ? skip_g : skip_b)) : 0.0f, q1 = 0.0f;                                                               \
                 const float q0 = scan_tab_eval<0 + ch>(c0, baddr[w0][ch], own[w0][ch], dist, &bs);                             \
-                const float q1 = scan_tab_eval<3 + ch>(c1, baddr[w1][ch], own[w1][ch], dist, &bs);                             \
+                if (!SKIP1) {                                                                                                 \
+                  const float c1 = fma_(ri.wy[1], up1 ? drow[w1 - 1][ch] : drow[w1][ch], up1 ? crow[w1 - 1][ch] : crow[w1][ch]); \
+                  q1 = scan_tab_eval<3 + ch>(c1, baddr[w1][ch], own[w1][ch], dist, &bs);                                       \
+                }                                                                                                             \
                 const float q2 = scan_tab_eval<6 + ch>(c2, baddr[w2][ch], own[w2][ch], dist, &bs);                             \
                 const float s = ((q0 + q1) + q2) * 0.5f;                                                                      \
                 const float b = fma_(5e-7f, s, 0.5f * bs);                                                                    \
@@ -653,10 +658,17 @@ void buildScanTablesHost(float off, std::vector<float>* A, std::vector<float>* n
 }
 
 // Device tables for sub-pixel offset `off` and the given row distances: A (with T), measured bounds, node colours.
+// The scanline BELOW the pixel's own (role 1: source row y + 1, at 1.2 .. 1.6 scanlines from the sample) contributes next to
+// nothing at the shipped beam parameters: the same exhaustive sweep that measures the bounds records the largest exact K of
+// every role, and when that is below kScanSkipBelow for all three channels of role 1 (measured at 1080p: 1.2e-8, 1.9e-18, 1.4e-35) the table kernel
+// does not evaluate that scanline at all - it takes 0 for it and adds the channel's recorded maximum to the pixel's bound (a
+// proven bound like the others, and small against them).
+constexpr float kScanSkipBelow = 5e-8f;    // (a node's own bound is 1e-7 .. 1e-6)
 struct ScanNodeTables {
   float4* A = nullptr;
   float* bound = nullptr;
   float* node = nullptr;
+  float kmax[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // host copy: the largest exact K of each role over everything the tables cover
 };
 void freeScanNodeTables(ScanNodeTables* T) {
   if (T->A) (void)hipFree(T->A);
@@ -669,21 +681,24 @@ bool buildScanNodeTables(float off, const std::vector<float>& dists, hipStream_t
   std::vector<float> hA, hNode;
   buildScanTablesHost(off, &hA, &hNode);
   float* dd = nullptr;
+  float* kmax = nullptr;
   bool ok = hipMalloc(reinterpret_cast<void**>(&T->A), hA.size() * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&T->bound), (size_t)9 * kNodes * 4) == hipSuccess &&
-            hipMalloc(reinterpret_cast<void**>(&T->node), hNode.size() * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&dd), dists.size() * 4) == hipSuccess;
+            hipMalloc(reinterpret_cast<void**>(&T->node), hNode.size() * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&dd), dists.size() * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&kmax), 9 * 4) == hipSuccess;
   if (ok)
     ok = hipMemcpyAsync(T->A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
          hipMemcpyAsync(T->node, hNode.data(), hNode.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
          hipMemcpyAsync(dd, dists.data(), dists.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
-         hipMemsetAsync(T->bound, 0, (size_t)9 * kNodes * 4, s) == hipSuccess;
+         hipMemsetAsync(T->bound, 0, (size_t)9 * kNodes * 4, s) == hipSuccess && hipMemsetAsync(kmax, 0, 9 * 4, s) == hipSuccess;
   if (ok) {
     hipLaunchKernelGGL(k_scan_tab_nodes, dim3((9 * kNodes + 255) / 256), dim3(256), 0, s, T->A, T->node, off);
-    hipLaunchKernelGGL(k_scan_tab_bounds, dim3(16, 9 * kNodes), dim3(256), 0, s, T->A, T->node, dd, (int)dists.size(), off, T->bound);
+    hipLaunchKernelGGL(k_scan_tab_bounds, dim3(16, 9 * kNodes), dim3(256), 0, s, T->A, T->node, dd, (int)dists.size(), off, T->bound, kmax);
     hipLaunchKernelGGL(k_scan_tab_bounds_finish, dim3((9 * kNodes + 255) / 256), dim3(256), 0, s, T->A, T->bound, T->node);
     // the host vectors must outlive the asynchronous copies
-    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(T->kmax, kmax, 9 * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
   }
   if (dd) (void)hipFree(dd);
+  if (kmax) (void)hipFree(kmax);
   if (!ok) freeScanNodeTables(T);
   return ok;
 }
@@ -769,7 +784,10 @@ const ScanTables* scanTablesFor(const PassLaunch& L, hipStream_t s) {
   RC_LOG_DEBUG("crt-royale scanline pass " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h) + ": expansion tables " +
                (T.usable ? "in use (" + std::to_string(n_dists) + " row distances)"
                          : "not usable (geometry flags " + std::to_string(hbad) + ", " + std::to_string(n_dists) + " row distances), exact per-pixel form"));
-  if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc scan-v] %dx%d: usable %d flags %u, %zu row distances\n", L.out_w, L.out_h, (int)T.usable, hbad, n_dists);
+  if (std::getenv("RC_DEBUG_SCAN"))
+    std::fprintf(stderr, "[rc scan-v] %dx%d: usable %d flags %u, %zu row distances; largest K per role %.3g %.3g %.3g | %.3g %.3g %.3g | %.3g %.3g %.3g\n", L.out_w, L.out_h,
+                 (int)T.usable, hbad, n_dists, T.nodes.kmax[0], T.nodes.kmax[1], T.nodes.kmax[2], T.nodes.kmax[3], T.nodes.kmax[4], T.nodes.kmax[5], T.nodes.kmax[6],
+                 T.nodes.kmax[7], T.nodes.kmax[8]);
   if (!T.usable) {
     freeScanNodeTables(&T.nodes);
     if (T.rows) (void)hipFree(T.rows);
@@ -820,14 +838,17 @@ hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s) {
                       (uint64_t)L.n_frames * L.out_w * L.out_h < (1ull << 32);
     const ScanTables* T = room ? scanTablesFor(L, s) : nullptr;
     if (T) {
-      auto kernel = k_royale_scan_v_tab<SrgbLinEdge, OutS>;
+      const float* km = T->nodes.kmax;
+      const bool skip1 = km[3] < kScanSkipBelow && km[4] < kScanSkipBelow && km[5] < kScanSkipBelow;
+      const float skip_r = km[3] * 1.000001f + 1e-30f, skip_g = km[4] * 1.000001f + 1e-30f, skip_b = km[5] * 1.000001f + 1e-30f;
+      auto kernel = skip1 ? k_royale_scan_v_tab<SrgbLinEdge, OutS, true> : k_royale_scan_v_tab<SrgbLinEdge, OutS, false>;
       // (set on every launch: the attribute is per device, and this needs no shared flag)
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsTotalBytes) != hipSuccess)
         return hipGetLastError();
       const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kStripRows - 1) / kStripRows) * L.n_frames;
       const long tiles = (strips + kTabWaves - 1) / kTabWaves;
       if (hipMemsetAsync(L.scratch, 0, kFixHeader, s) != hipSuccess) return hipGetLastError();
-      hipLaunchKernelGGL(kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(kTabThreads), kLdsTotalBytes, s, L, T->nodes.A, T->rows, T->cols);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(kTabThreads), kLdsTotalBytes, s, L, T->nodes.A, T->rows, T->cols, skip_r, skip_g, skip_b);
       hipLaunchKernelGGL((k_royale_scan_v_fix<SrgbLinEdge, OutS>), dim3(512), dim3(256), rcd::srgb_lds_bytes(L), s, L);
       return hipGetLastError();
     }
