@@ -515,6 +515,7 @@ __global__ void __launch_bounds__(512) k_royale_scan_h_strip2(const PassLaunch L
   using namespace rcstrip2;
   extern __shared__ uint32_t rc_dyn_lds_[];
   strip2_load_tables(rc_dyn_lds_, L, true);
+  const uint32_t dcopy = strip2_lane_copy();   // this lane's copy of the decode table
   const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int W = L.out_w, H = L.out_h;
   const int bands = (W + 127) >> 7, rss = (H + kShRows - 1) / kShRows, per_frame = bands * rss, total = per_frame * L.n_frames;
@@ -559,17 +560,17 @@ __global__ void __launch_bounds__(512) k_royale_scan_h_strip2(const PassLaunch L
       };
       auto hfilter = [&](const uint32_t* q, v2f* ha, v2f* hb) __attribute__((always_inline)) {
         {
-          const v2f dl = {dec_byte<0>(q[0]), dec_byte<0>(q[3])}, dm = {dec_byte<0>(q[1]), dec_byte<0>(q[4])}, dr = {dec_byte<0>(q[2]), dec_byte<0>(q[5])};
+          const v2f dl = {dec_byte<0>(q[0], dcopy), dec_byte<0>(q[3], dcopy)}, dm = {dec_byte<0>(q[1], dcopy), dec_byte<0>(q[4], dcopy)}, dr = {dec_byte<0>(q[2], dcopy), dec_byte<0>(q[5], dcopy)};
           ha[0] = fma2(wxa[0], dm - dl, dl);
           hb[0] = fma2(wxb[0], dr - dm, dm);
         }
         {
-          const v2f dl = {dec_byte<1>(q[0]), dec_byte<1>(q[3])}, dm = {dec_byte<1>(q[1]), dec_byte<1>(q[4])}, dr = {dec_byte<1>(q[2]), dec_byte<1>(q[5])};
+          const v2f dl = {dec_byte<1>(q[0], dcopy), dec_byte<1>(q[3], dcopy)}, dm = {dec_byte<1>(q[1], dcopy), dec_byte<1>(q[4], dcopy)}, dr = {dec_byte<1>(q[2], dcopy), dec_byte<1>(q[5], dcopy)};
           ha[1] = fma2(wxa[1], dm - dl, dl);
           hb[1] = fma2(wxb[1], dr - dm, dm);
         }
         {
-          const v2f dl = {dec_byte<2>(q[0]), dec_byte<2>(q[3])}, dm = {dec_byte<2>(q[1]), dec_byte<2>(q[4])}, dr = {dec_byte<2>(q[2]), dec_byte<2>(q[5])};
+          const v2f dl = {dec_byte<2>(q[0], dcopy), dec_byte<2>(q[3], dcopy)}, dm = {dec_byte<2>(q[1], dcopy), dec_byte<2>(q[4], dcopy)}, dr = {dec_byte<2>(q[2], dcopy), dec_byte<2>(q[5], dcopy)};
           ha[2] = fma2(wxa[2], dm - dl, dl);
           hb[2] = fma2(wxb[2], dr - dm, dm);
         }
@@ -862,6 +863,7 @@ __global__ void __launch_bounds__(512) k_royale_brightpass_strip2(const PassLaun
   using namespace rcstrip2;
   extern __shared__ uint32_t rc_dyn_lds_[];
   strip2_load_tables(rc_dyn_lds_, L, true);
+  const uint32_t dcopy = strip2_lane_copy();   // this lane's copy of the decode table
   const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int W = L.out_w, H = L.out_h;
   const int bands = (W + 127) >> 7, rss = (H + kBpRows - 1) / kBpRows, per_frame = bands * rss, total = per_frame * L.n_frames;
@@ -890,9 +892,9 @@ __global__ void __launch_bounds__(512) k_royale_brightpass_strip2(const PassLaun
         const uint8_t* p = bimg + (size_t)(clampi(r, 0, blur.h - 1) * blur.w) * 4u;
         const uint32_t a0 = *reinterpret_cast<const uint32_t*>(p + ba0), a1 = *reinterpret_cast<const uint32_t*>(p + ba1);
         const uint32_t b0 = *reinterpret_cast<const uint32_t*>(p + bb0), b1 = *reinterpret_cast<const uint32_t*>(p + bb1);
-        const v2f l0 = {dec_byte<0>(a0), dec_byte<0>(b0)}, r0 = {dec_byte<0>(a1), dec_byte<0>(b1)};
-        const v2f l1 = {dec_byte<1>(a0), dec_byte<1>(b0)}, r1 = {dec_byte<1>(a1), dec_byte<1>(b1)};
-        const v2f l2 = {dec_byte<2>(a0), dec_byte<2>(b0)}, r2 = {dec_byte<2>(a1), dec_byte<2>(b1)};
+        const v2f l0 = {dec_byte<0>(a0, dcopy), dec_byte<0>(b0, dcopy)}, r0 = {dec_byte<0>(a1, dcopy), dec_byte<0>(b1, dcopy)};
+        const v2f l1 = {dec_byte<1>(a0, dcopy), dec_byte<1>(b0, dcopy)}, r1 = {dec_byte<1>(a1, dcopy), dec_byte<1>(b1, dcopy)};
+        const v2f l2 = {dec_byte<2>(a0, dcopy), dec_byte<2>(b0, dcopy)}, r2 = {dec_byte<2>(a1, dcopy), dec_byte<2>(b1, dcopy)};
         h[0] = fma2(bwx, r0 - l0, l0);
         h[1] = fma2(bwx, r1 - l1, l1);
         h[2] = fma2(bwx, r2 - l2, l2);
@@ -931,9 +933,9 @@ __global__ void __launch_bounds__(512) k_royale_brightpass_strip2(const PassLaun
             have = by0;
           }
           v2f o[3];
-          o[0] = brightpass_pair(v2f{dec_byte<0>(ia), dec_byte<0>(ib)}, fma2(splat2(bwy), hd[0], h0[0]), cw, mask_amplify);
-          o[1] = brightpass_pair(v2f{dec_byte<1>(ia), dec_byte<1>(ib)}, fma2(splat2(bwy), hd[1], h0[1]), cw, mask_amplify);
-          o[2] = brightpass_pair(v2f{dec_byte<2>(ia), dec_byte<2>(ib)}, fma2(splat2(bwy), hd[2], h0[2]), cw, mask_amplify);
+          o[0] = brightpass_pair(v2f{dec_byte<0>(ia, dcopy), dec_byte<0>(ib, dcopy)}, fma2(splat2(bwy), hd[0], h0[0]), cw, mask_amplify);
+          o[1] = brightpass_pair(v2f{dec_byte<1>(ia, dcopy), dec_byte<1>(ib, dcopy)}, fma2(splat2(bwy), hd[1], h0[1]), cw, mask_amplify);
+          o[2] = brightpass_pair(v2f{dec_byte<2>(ia, dcopy), dec_byte<2>(ib, dcopy)}, fma2(splat2(bwy), hd[2], h0[2]), cw, mask_amplify);
           srgb8_pack2(o, &pa, &pb);
         }
         bool sa = live_a, sb = live_b;
@@ -1123,8 +1125,10 @@ __global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint3
 }
 
 constexpr uint32_t kLastLdsTab = 1024u;   // LDS byte offset of the gamma table (behind the decode table; the kernel has no static LDS)
-// one channel of one pixel from the gamma table; returns the byte, sets *fail when it is not certain.  c is a LINEAR sample of
-// decoded sRGB texels: 0 <= c <= 1.
+// one channel of one pixel from the gamma table: the byte, *fail set when it is not certain.  c is a LINEAR sample of decoded
+// sRGB texels: 0 <= c <= 1.  With y = fl(lin * 255) and r = rint(y): the exact code stores rint(fl(clamp(G) * 255)),
+// |G - lin| <= bound, and the two products round within 2^-24 * 255 each, so the byte is r whenever
+// |y - r| + 255 bound + 3.1e-5 < 0.5 (clamping r to [0, 255] commutes with it).
 __device__ __forceinline__ uint32_t last_gamma_byte(float c, bool* fail) {
   typedef float last_v4f __attribute__((ext_vector_type(4)));
   // colours below the table's first node store 0 like that node's first colour does (G is monotone, G(2^-20) * 255 < 0.47)
@@ -1133,19 +1137,18 @@ __device__ __forceinline__ uint32_t last_gamma_byte(float c, bool* fail) {
   const float c0 = bits2f(cb == 0x3f800000u ? cb : ((cb & ~((1u << kLastTabShift) - 1u)) | (1u << (kLastTabShift - 1))));
   const last_v4f e = *reinterpret_cast<const RC_AS3 last_v4f*>((uintptr_t)(kLastLdsTab + off));
   const float delta = bits2f(cb) - c0;
-  const float lin = fma_(delta, fma_(delta, e.z, e.y), e.x), bound = fma_(lin, 1.2e-7f, e.w);   // + 2^-23 lin: the two roundings below
-  const float ylo = __builtin_amdgcn_fmed3f(lin - bound, 0.0f, 1.0f) * 255.0f, yhi = __builtin_amdgcn_fmed3f(lin + bound, 0.0f, 1.0f) * 255.0f;
-  const float rlo = __builtin_rintf(ylo);
-  *fail = *fail || rlo != __builtin_rintf(yhi);
-  return (uint32_t)rlo;
+  const float y = fma_(delta, fma_(delta, e.z, e.y), e.x) * 255.0f;
+  const float r = __builtin_rintf(y);
+  *fail = *fail || !(__builtin_fabsf(y - r) + fma_(e.w, 255.0f, 3.1e-5f) < 0.5f);
+  return (uint32_t)__builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);
 }
 
 template <class SO>
 __global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows,
                                                          const float4* __restrict__ gamma_tab) {
   RC_SRGB_LDS(lds, L);
+  if ((uint32_t)(uintptr_t)(RC_AS3 uint32_t*)rc_dyn_lds_ != 0u) __builtin_trap();   // the tables are addressed by absolute LDS offsets
   if (gamma_tab) {   // uniform
-    if ((uint32_t)(uintptr_t)(RC_AS3 uint32_t*)rc_dyn_lds_ != 0u) __builtin_trap();   // the table is addressed by absolute LDS offsets
     for (int i = (int)threadIdx.x; i < kLastTabNodes; i += 512) reinterpret_cast<float4*>(rc_dyn_lds_ + kLastLdsTab / 4)[i] = gamma_tab[i];
     __syncthreads();
   }
@@ -1178,11 +1181,18 @@ __global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, c
       *ta = p[xa];
       *tb = p[xb];
     };
-    auto hfilter = [&](uint32_t ta, uint32_t tb, float* h) {
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float a = lds.dec[(ta >> (8 * ch)) & 255u], b = lds.dec[(tb >> (8 * ch)) & 255u];
-        h[ch] = fma_(wx, b - a, a);
+    auto hfilter = [&](uint32_t ta, uint32_t tb, float* h) {   // (the decode table sits at LDS offset 0: royale_strip2.h dec_byte)
+      {
+        const float a = rcstrip2::dec_byte_plain<0>(ta), b = rcstrip2::dec_byte_plain<0>(tb);
+        h[0] = fma_(wx, b - a, a);
+      }
+      {
+        const float a = rcstrip2::dec_byte_plain<1>(ta), b = rcstrip2::dec_byte_plain<1>(tb);
+        h[1] = fma_(wx, b - a, a);
+      }
+      {
+        const float a = rcstrip2::dec_byte_plain<2>(ta), b = rcstrip2::dec_byte_plain<2>(tb);
+        h[2] = fma_(wx, b - a, a);
       }
     };
     float w0[3], w1[3], w2[3], w3[3];   // rows y-1, y, y+1, y+2 of the current row pair
