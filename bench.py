@@ -100,17 +100,20 @@ def cpu_baseline(key, w, h, vw, vh, tree, budget_s=15.0):
                       % (n, cores, dt)}
 
 
+PMC_FRAMES_PER_LAUNCH = 32.0   # launch shape of the newest profiles/r*_royale_pmc.csv (profiles/collect.sh: the engine's default chunk)
+
+
 def pmc_traffic(kernel_name, frames_per_launch):
     """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary
     (profiles/r*_royale_pmc.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, KiB).
     Correction per /opt/skills/guides/MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the
     bytes of coalesced streaming reads (re-checked here on the frame-I/O kernels, whose byte counts
     are known: 4, 8, 12 and 16 B per lane all read exactly 1/2), WRITE_SIZE is exact.  Only valid
-    for the launch shape it was collected at (8 frames per launch); otherwise None."""
+    for the launch shape it was collected at (PMC_FRAMES_PER_LAUNCH); otherwise None."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_royale_pmc.csv")))
-    if not files or abs(frames_per_launch - 8.0) > 1e-6:
+    if not files or abs(frames_per_launch - PMC_FRAMES_PER_LAUNCH) > 1e-6:
         return None
     want = "k_" + kernel_name.replace("-", "_")
     alias = {"k_royale_scanlines_v": "k_royale_scan_v", "k_royale_scanlines_h": "k_royale_scan_h",
@@ -131,7 +134,7 @@ def pmc_valu(kernel_name, frames_per_launch, avg_launch_ms):
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_royale_pmc.csv")))
-    if not files or abs(frames_per_launch - 8.0) > 1e-6 or avg_launch_ms <= 0:
+    if not files or abs(frames_per_launch - PMC_FRAMES_PER_LAUNCH) > 1e-6 or avg_launch_ms <= 0:
         return None
     want = {"royale-scanlines-v": "k_royale_scan_v", "royale-bloom-h": "k_royale_bloom_h"}.get(kernel_name, "k_" + kernel_name.replace("-", "_"))
     rows = {r["kernel"]: r for r in csv.DictReader(open(files[-1]))}
@@ -371,7 +374,7 @@ def dry_run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40, help="timed steps (default: about 2 s of GPU work per measured mode at 1080p)")
+    ap.add_argument("--steps", type=int, default=150, help="timed steps (default: 150 x 256 frames = about 2.4 s of GPU work per measured mode at 1080p)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (256 x 1080p = 2.1 GB in, 2.1 GB out)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per kernel launch (0 = engine default)")

@@ -30,11 +30,13 @@ if not os.environ.get('SKIPCMP'):
 for mask in (False, True):
     e = make_engine(tree['crt-royale'], W, H)
     e.setUndefinedVaryingZero(mask)
-    fr = np.random.default_rng(0).integers(0, 256, (8, H, W, 3), dtype=np.uint8)
+    NB = int(os.environ.get('BATCH', 8))   # frames per batch (= per launch while it does not exceed the engine's chunk)
+    fr = np.random.default_rng(0).integers(0, 256, (NB, H, W, 3), dtype=np.uint8)
     d = to_device_rgba(fr)
-    for _ in range(3): e.applyShaderBatch(d, 8, W, H)
+    if NB > 8: e.setChunkFrames(NB)
+    for _ in range(3): e.applyShaderBatch(d, NB, W, H)
     e.sync(); e.setProfiling(True)
-    for _ in range(10): e.applyShaderBatch(d, 8, W, H)
+    for _ in range(10): e.applyShaderBatch(d, NB, W, H)
     t = [round(e.passProfile(i)['total_ms'] / max(1, e.passProfile(i)['frames']) * 1000, 1) for i in range(12)]
     print("mask %d us/frame per pass %s  total %.1f" % (mask, t, sum(t)))
     e.shutdown()

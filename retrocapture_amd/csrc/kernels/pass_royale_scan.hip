@@ -260,14 +260,20 @@ __device__ __forceinline__ float scan_dd(int j, int ch, float dist, float dist_r
   return mix_rt(dist + (1.0f - conv_y[ch]), (2.0f + conv_y[ch]) - dist, dist_round);
 }
 
-// T of every node: the general kernel's own beam_k at the node colour and the role's distance for dist = 0
+// T of every node - the general kernel's own beam_k at the node colour and the role's distance for dist = 0 - and with it the
+// record's polynomial in the colour ITSELF (not in colour - node: the table kernel then needs neither the node value nor the
+// subtraction): K(c) ~ a0 + c (a1 + c a2) with a2 = K''/2, a1 = K' - 2 a2 node, a0 = T - K' node + a2 node^2, from the
+// host's K', K''/2 (A[i].y, .z on entry).  Rounding these to float is part of what the bound is measured against.
 __global__ void __launch_bounds__(256) k_scan_tab_nodes(float4* A, const float* __restrict__ node, float off) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 9 * kNodes) return;
   const int jc = i / kNodes;
   const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
   const float c = node[i - jc * kNodes];
-  A[i].x = beam_k<float, true>(c, scan_dd(jc / 3, jc % 3, 0.0f, 0.0f), off, sigma_range, shape_range);
+  const float T = beam_k<float, true>(c, scan_dd(jc / 3, jc % 3, 0.0f, 0.0f), off, sigma_range, shape_range);
+  const double n = (double)c, d1 = (double)A[i].y, d2 = (double)A[i].z;
+  A[i].x = (float)((double)T - d1 * n + d2 * n * n);
+  A[i].y = (float)(d1 - 2.0 * d2 * n);
 }
 
 // The bound of every node: the largest difference, over EVERY float colour the table kernel can select the node for and
@@ -297,15 +303,21 @@ __global__ void __launch_bounds__(256) k_scan_tab_bounds(const float4* __restric
   // two consecutive colours per step through the packed form of beam_k (the same IEEE operations per component)
   for (uint32_t i = lo + 2u * (blockIdx.x * 256u + threadIdx.x); i <= hi; i += 2u * gridDim.x * 256u) {
     const v2f c = {bits2f(i), bits2f(i + 1u <= hi ? i + 1u : i)};
-    const v2f delta = c - c0;
+    const float px = fma_(c.x, a.z, a.y), py = fma_(c.y, a.z, a.y);
     for (int d = 0; d < n_dists; ++d) {
       const float dist = dists[d], dd = scan_dd(jc / 3, jc % 3, dist, 0.0f);
       const v2f k = beam_k<v2f, true>(c, v2f{dd, dd}, off, sigma_range, shape_range);
-      const float base = fma_(scan_w_slope(a.w), dist, a.x);
-      // the kernel: fma(delta, fma(delta, a.z, a.y), fma(a.w, dist, a.x))
-      const float kx = fma_(delta.x, fma_(delta.x, a.z, a.y), base), ky = fma_(delta.y, fma_(delta.y, a.z, a.y), base);
-      const double ex = fabs((double)k.x - (double)kx), ey = fabs((double)k.y - (double)ky);
-      worst = fmaxf(worst, __double2float_ru(ex > ey ? ex : ey));
+      // the kernel: fma(c, fma(c, a.z, a.y), fma(W, dist, a.x)), W = the distance slope with the bound's code in its low 11
+      // bits - not known yet: the result is monotone in W, so the worse of the two extreme codes covers whichever is stored
+      float ek = 0.0f;
+#pragma unroll
+      for (int end = 0; end < 2; ++end) {
+        const float base = fma_(bits2f((f2bits(a.w) & 0xfffff800u) | (end ? 0x7ffu : 0u)), dist, a.x);
+        const float kx = fma_(c.x, px, base), ky = fma_(c.y, py, base);
+        const double ex = fabs((double)k.x - (double)kx), ey = fabs((double)k.y - (double)ky);
+        ek = fmaxf(ek, __double2float_ru(ex > ey ? ex : ey));
+      }
+      worst = fmaxf(worst, ek);
       largest = fmaxf(largest, fmaxf(__builtin_fabsf(k.x), __builtin_fabsf(k.y)));
     }
   }
@@ -394,29 +406,35 @@ __global__ void __launch_bounds__(256) k_scan_geometry(const PassLaunch L, ScanR
 // is certain when both ends give the same byte and lie in one run, or in two neighbouring runs with a monotone boundary.
 __device__ __forceinline__ uint32_t srgb8_interval(float s, float b, bool* ok) {
   const uint32_t bl = f2bits(__builtin_amdgcn_fmed3f(s - b, bits2f(kSrgb2MinBits), 1.0f)), bh = f2bits(__builtin_amdgcn_fmed3f(s + b, bits2f(kSrgb2MinBits), 1.0f));
-  const uint32_t rl = bl >> 13, rh = bh >> 13;
-  const uint32_t el = rcstrip2::lds_u32((rl << 2) + (kLdsEnc2 - (kSrgb2Run0 << 2))), eh = rcstrip2::lds_u32((rh << 2) + (kLdsEnc2 - (kSrgb2Run0 << 2)));
-  const uint32_t byte_l = ((el + (bl & 0x1fffu)) >> 13) & 255u, byte_h = ((eh + (bh & 0x1fffu)) >> 13) & 255u;
-  *ok = byte_l == byte_h && (rh - rl) <= ((el >> 30) & 1u);
-  return byte_l;
+  const uint32_t el = rcstrip2::lds_u32(((bl >> 13) << 2) + (kLdsEnc2 - (kSrgb2Run0 << 2)));
+  const uint32_t tl = el + (bl & 0x1fffu);
+  // both ends in one run (nearly always: a run is 8192 floats wide): the upper end's position follows from the lower one's,
+  // and "same run, same byte" is one comparison - the two positions and the two bit patterns agree above bit 12
+  const uint32_t th = tl + (bh - bl);
+  bool certain = ((tl ^ th) | (bl ^ bh)) < 8192u;
+  if (__builtin_amdgcn_ballot_w64((bl ^ bh) >= 8192u) != 0ull) {   // (wave-uniform) some lane's interval straddles two runs
+    const uint32_t rl = bl >> 13, rh = bh >> 13;
+    const uint32_t eh = rcstrip2::lds_u32((rh << 2) + (kLdsEnc2 - (kSrgb2Run0 << 2)));
+    const uint32_t byte_l = (tl >> 13) & 255u, byte_h = ((eh + (bh & 0x1fffu)) >> 13) & 255u;
+    certain = byte_l == byte_h && (rh - rl) <= ((el >> 30) & 1u);
+  }
+  *ok = certain;
+  return (tl >> 13) & 255u;
 }
 
 // One (scanline, channel) evaluation from the table.  c: the sampled colour; byte_addr: (kLogNodes + the own texel's byte) * 16;
-// d: that texel's decoded value; ROLE = scanline * 3 + channel.  Returns the expanded K, adds the node's bound to *bsum.
+// ROLE = scanline * 3 + channel.  Returns the expanded K, adds the node's bound to *bsum.
 template <int ROLE>
-__device__ __forceinline__ float scan_tab_eval(float c, uint32_t byte_addr, float d, float dist, float* bsum) {
+__device__ __forceinline__ float scan_tab_eval(float c, uint32_t byte_addr, float dist, float* bsum) {
   using namespace rcstrip2;
-  const uint32_t cb = f2bits(c);
-  const uint32_t t = cb - kLogBits0;
+  const uint32_t t = f2bits(c) - kLogBits0;
   // colours in [2^-32, 2^-8) select a log bucket (8 per octave: index = t >> 20), everything else the own texel's byte node
-  // (a colour below 2^-32 belongs to a zero byte: the zero node)
+  // (a colour below 2^-32 belongs to a zero byte: the zero node, whose polynomial is the constant 0)
   const bool dark = t < (0x3b800000u - kLogBits0);
   const uint32_t addr = dark ? ((t >> 16) & ~15u) : byte_addr;
-  const float node = dark ? bits2f((cb & 0xfff00000u) | 0x00080000u) : d;
   const v4f a = lds_v4f(kLdsA + (uint32_t)ROLE * kNodes * 16u + addr);
-  const float delta = c - node;   // at most kMaxDelta (byte nodes: k_scan_geometry bounds the weights) or half a bucket
   *bsum += scan_w_bound(a.w);
-  return fma_(delta, fma_(delta, a.z, a.y), fma_(scan_w_slope(a.w), dist, a.x));
+  return fma_(c, fma_(c, a.z, a.y), fma_(a.w, dist, a.x));   // (a.w as it is: k_scan_tab_bounds measured it with the code bits in)
 }
 
 // SKIP1: the scanline below contributes less than skip_r / _g / _b whatever its colour (ScanNodeTables): taken as 0, bound added
@@ -454,25 +472,22 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
         // and channel the sampler's horizontal lerp `crow` exactly as the GL evaluates it, the difference to the next row's, the
         // own texel's decoded value and its byte as a table address.
         constexpr int kStep = 4, kWin = kStep + 4;
-        float crow[kWin][3], drow[kWin][3], own[kWin][3];
+        float crow[kWin][3], drow[kWin][3];
         uint32_t baddr[kWin][3];
         auto decode_row = [&](uint32_t tc, uint32_t tr, int slot) __attribute__((always_inline)) {
           {
             const float d = lds_f32(kLdsDec + byte_shl<0, 2>(tc)), dr = lds_f32(kLdsDec + byte_shl<0, 2>(tr));
             crow[slot][0] = fma_(wx, dr - d, d);
-            own[slot][0] = d;
             baddr[slot][0] = byte_shl<0, 4>(tc) + (uint32_t)kLogNodes * 16u;
           }
           {
             const float d = lds_f32(kLdsDec + byte_shl<1, 2>(tc)), dr = lds_f32(kLdsDec + byte_shl<1, 2>(tr));
             crow[slot][1] = fma_(wx, dr - d, d);
-            own[slot][1] = d;
             baddr[slot][1] = byte_shl<1, 4>(tc) + (uint32_t)kLogNodes * 16u;
           }
           {
             const float d = lds_f32(kLdsDec + byte_shl<2, 2>(tc)), dr = lds_f32(kLdsDec + byte_shl<2, 2>(tr));
             crow[slot][2] = fma_(wx, dr - d, d);
-            own[slot][2] = d;
             baddr[slot][2] = byte_shl<2, 4>(tc) + (uint32_t)kLogNodes * 16u;
           }
         };
@@ -517,12 +532,12 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
                 const float c0 = fma_(ri.wy[0], up0 ? drow[w0 - 1][ch] : drow[w0][ch], up0 ? crow[w0 - 1][ch] : crow[w0][ch]);  \
                 const float c2 = fma_(ri.wy[2], up2 ? drow[w2 - 1][ch] : drow[w2][ch], up2 ? crow[w2 - 1][ch] : crow[w2][ch]);  \
                 float bs = SKIP1 ? (ch == 0 ? skip_r : (ch == 1 ? skip_g : skip_b)) : 0.0f, q1 = 0.0f;                                                               \
-                const float q0 = scan_tab_eval<0 + ch>(c0, baddr[w0][ch], own[w0][ch], dist, &bs);                             \
+                const float q0 = scan_tab_eval<0 + ch>(c0, baddr[w0][ch], dist, &bs);                             \
                 if (!SKIP1) {                                                                                                 \
                   const float c1 = fma_(ri.wy[1], up1 ? drow[w1 - 1][ch] : drow[w1][ch], up1 ? crow[w1 - 1][ch] : crow[w1][ch]); \
-                  q1 = scan_tab_eval<3 + ch>(c1, baddr[w1][ch], own[w1][ch], dist, &bs);                                       \
+                  q1 = scan_tab_eval<3 + ch>(c1, baddr[w1][ch], dist, &bs);                                       \
                 }                                                                                                             \
-                const float q2 = scan_tab_eval<6 + ch>(c2, baddr[w2][ch], own[w2][ch], dist, &bs);                             \
+                const float q2 = scan_tab_eval<6 + ch>(c2, baddr[w2][ch], dist, &bs);                             \
                 const float s = ((q0 + q1) + q2) * 0.5f;                                                                      \
                 const float b = fma_(5e-7f, s, 0.5f * bs);                                                                    \
                 bool ok;                                                                                                      \
@@ -549,7 +564,6 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
               crow[i][ch] = crow[i + kStep][ch];
-              own[i][ch] = own[i + kStep][ch];
               baddr[i][ch] = baddr[i + kStep][ch];
             }
         }

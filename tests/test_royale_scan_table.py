@@ -1,7 +1,8 @@
 """crt-royale pass 1 at 1:1 geometry runs from an expansion table with a MEASURED bound
 (retrocapture_amd/csrc/kernels/pass_royale_scan.hip): when the tables of a geometry are built, the device evaluates the
 exact beam function at every float colour a node can be selected for and every row distance of the geometry, and records
-the largest difference to the expansion  fma(d, fma(d, K''/2, K'), fma(dK/ddist, dist, T))  the table kernel evaluates.
+the largest difference to the polynomial  fma(c, fma(c, a2, a1), fma(W, dist, a0))  the table kernel evaluates (a0..a2: the
+second-order expansion around the node written in the colour c itself; W: dK/ddist with the bound's 11-bit code in its low bits).
 Checked here against the oracle's exact float evaluation of the beam function (which the GPU parity tests hold bit-equal
 to the device's): on the CPU the host-built coefficients and the zero node's analytic bound; on the GPU the measured bound
 itself - it must hold for random colours of every node, and for whole nodes enumerated float by float it must be EXACTLY
@@ -117,13 +118,11 @@ def test_measured_bound_holds_for_every_node(rc_lib):
         c = bits.view(F)
         dist = DISTS[rng.integers(0, DISTS.size, c.shape)]
         exact = beam(dd_of(j, ch, dist.reshape(-1)), c.reshape(-1)).reshape(c.shape).astype(np.float64)
-        a = A[jc][idx].copy()
-        a[:, 3] = (a[:, 3].view(np.uint32) & np.uint32(0xFFFFF800)).view(F)   # W: dK/ddist in the upper bits, the bound's code below
-        a = a.astype(np.float64)
-        dl = (c - c0[idx][:, None]).astype(np.float64)             # the kernel's float subtraction
+        a = A[jc][idx].astype(np.float64)   # (W as stored: the kernel multiplies dist by it with the bound's code bits in)
+        cd = c.astype(np.float64)
         # the kernel's three fmas in double (products of floats are exact there; the two roundings can move the model by one
         # float ulp, which the tolerance below allows)
-        model = (dl * (dl * a[:, 2:3] + a[:, 1:2]).astype(F) + (a[:, 3:4] * dist + a[:, 0:1]).astype(F)).astype(F).astype(np.float64)
+        model = (cd * (cd * a[:, 2:3] + a[:, 1:2]).astype(F) + (a[:, 3:4] * dist + a[:, 0:1]).astype(F)).astype(F).astype(np.float64)
         err = np.abs(exact - model)
         ulp = np.spacing(np.abs(model).astype(F)).astype(np.float64)
         assert (err <= bound[jc][idx][:, None] + 1.01 * ulp).all(), "role %d: the expansion leaves its measured bound" % jc
@@ -144,15 +143,17 @@ def test_measured_bound_is_the_exhaustive_maximum(jc, n, rc_lib):
     lo, hi = node_range(n, c0)
     c = np.arange(lo, hi + 1, dtype=np.uint32).view(F)
     a = A[jc][n]
-    delta = c - c0
-    inner = fma32(delta, a[2], a[1])
-    slope = (a[3:4].view(np.uint32) & np.uint32(0xFFFFF800)).view(F)[0]   # W: dK/ddist in the upper bits, the bound's code below
+    inner = fma32(c, a[2], a[1])
+    # W: dK/ddist in the upper bits, the bound's code below - unknown while the bound is being measured, so the device takes
+    # the worse of the two extreme codes (the polynomial is monotone in W)
+    w_ends = [((a[3:4].view(np.uint32) & np.uint32(0xFFFFF800)) | np.uint32(code)).view(F)[0] for code in (0, 0x7FF)]
     worst = 0.0
     for dist in DISTS:
         exact = beam(np.broadcast_to(dd_of(j, ch, np.array([dist], F)), c.shape).copy(), c).astype(np.float64)
-        base = fma32(slope, dist, a[0])
-        model = fma32(delta, inner, np.broadcast_to(base, c.shape)).astype(np.float64)
-        worst = max(worst, float(np.abs(exact - model).max()))
+        for w in w_ends:
+            base = fma32(w, dist, a[0])
+            model = fma32(c, inner, np.broadcast_to(base, c.shape)).astype(np.float64)
+            worst = max(worst, float(np.abs(exact - model).max()))
     want = F(F(np.nextafter(F(worst), F(np.inf)) if F(worst) < worst else F(worst)) * F(1.000001) + F(1e-12))
     # the table keeps the bound as an 11-bit code rounded up (6 mantissa bits): at most 1/64 above the measured value
     assert float(want) <= float(bound[jc][n]) <= float(want) * (1.0 + 1.0 / 64.0) * 1.0001, (bound[jc][n], want, worst)
