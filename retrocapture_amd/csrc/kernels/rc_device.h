@@ -519,6 +519,13 @@ __device__ __forceinline__ float lod_from_quad(const Tex& t, float s_dx0, float 
   const float ax = (s_dx1 - s_dx0) * fw, bx = (v_dx1 - v_dx0) * fh;
   const float ay = (s_dy1 - s_dy0) * fw, by = (v_dy1 - v_dy0) * fh;
   const float rx = ax * ax + bx * bx, ry = ay * ay + by * by;
+  if (!t.linear) {
+    // GL_NEAREST_MIPMAP_NEAREST (mipmap_input without filter_linear): the level itself, (exponent(rho^2) + 1) >> 1 - not
+    // round(lod) of the float below, which differs one ulp below an odd power of two (oracle/rc_sampler.c, measured)
+    const float rho2 = rx > ry ? rx : ry;
+    const int lv = ((int)((f2bits(rho2) >> 23) & 255u) - 126) >> 1;
+    return (float)(rho2 > 0.0f ? min(max(lv, 0), t.n_levels - 1) : 0);
+  }
   float lod = 0.5f * fast_log2_(rx > ry ? rx : ry);
   if (!(lod > 0.0f)) lod = 0.0f;
   return fminf(lod, (float)(t.n_levels - 1));
@@ -527,6 +534,10 @@ __device__ __forceinline__ float4 sample_mip(const Tex& t, int z, float s, float
   const float fl = __builtin_floorf(lod), w = lod - fl;
   const int l0 = (int)fl, l1 = min(l0 + 1, t.n_levels - 1);
   const uint8_t *i0, *i1;
+  if (!t.linear) {   // one level, NEAREST (lod_from_quad returned the level)
+    const Tex tn = mip_level(t, z, l0, &i0);
+    return sample_rt(tn, i0, s, v, lds);
+  }
   const Tex t0 = mip_level(t, z, l0, &i0), t1 = mip_level(t, z, l1, &i1);
   const float4 c0 = sample_rt(t0, i0, s, v, lds), c1 = sample_rt(t1, i1, s, v, lds);
   // RGBA8 / GL_RGB textures on the 8-bit filter path: the blend between the two level samples (bytes) is 8-bit too,

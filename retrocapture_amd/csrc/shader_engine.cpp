@@ -942,7 +942,7 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
   sourceTex.wrap = wrapFromString(m_passes[0].passInfo.wrapMode);
 
   // mipmap_input0: the reference generates the chain on the source texture as well (ShaderEngine.cpp:1019-1031)
-  if (m_passes[0].kernel && m_passes[0].kernel->mip_aware && m_passes[0].passInfo.mipmapInput && m_passes[0].passInfo.filterLinear) {
+  if (m_passes[0].kernel && m_passes[0].kernel->mip_aware && m_passes[0].passInfo.mipmapInput) {
     int levels = 0;
     size_t frameBytes = 0;
     if (!buildMipLevels(sourceTex, nFrames, &m_sourceMips, &levels, &frameBytes)) return false;
@@ -1021,10 +1021,8 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
         L.params[q] = effectiveParameter(pd, k.params[q], custom);
       }
       if (pd.passInfo.mipmapInput && k.mip_aware) {
-        if (current.n_levels <= 1 && (current.w > 1 || current.h > 1)) {
-          RC_LOG_ERROR("pass " + std::to_string(i) + ": mipmap_input without filter_linear (GL_NEAREST_MIPMAP_NEAREST) is not restated");
-          return false;
-        }
+        // (the chain was built when this texture became `current`: GL_LINEAR_MIPMAP_LINEAR with filter_linear,
+        // GL_NEAREST_MIPMAP_NEAREST without - the samplers in rc_device.h tell them apart by Tex::linear)
       } else if (pd.passInfo.mipmapInput && (current.w != L.out_w || current.h != L.out_h)) {
         RC_LOG_ERROR("pass " + std::to_string(i) + ": mipmap_input with a " + std::to_string(current.w) + "x" + std::to_string(current.h) +
                      " input and a " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h) +
@@ -1131,8 +1129,7 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
       return false;
     // mipmap_input of the next pass: the reference generates the chain when that pass binds this texture
     pd.mipLevels = 0;
-    if (!last && m_passes[i + 1].kernel && m_passes[i + 1].kernel->mip_aware && m_passes[i + 1].passInfo.mipmapInput &&
-        m_passes[i + 1].passInfo.filterLinear) {
+    if (!last && m_passes[i + 1].kernel && m_passes[i + 1].kernel->mip_aware && m_passes[i + 1].passInfo.mipmapInput) {
       if (!buildMipChain(i, target, nFrames)) return false;
     }
     // this pass's output becomes the next pass's input

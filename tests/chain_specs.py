@@ -114,6 +114,14 @@ filter_linear5 = true
                              "shaders = 2\nshader0 = ../stock.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n"
                              "shader1 = shaders/glow/blur_horiz.glsl\nfilter_linear1 = true\nmipmap_input1 = true\n"
                              "scale_type1 = source\nscale1 = %s\n" % sc) for sc in ("0.37", "0.6")},
+    # ... and without filter_linear: GL_NEAREST_MIPMAP_NEAREST
+    **{"mipnearest-source-%s" % sc: ("crt/t-mipnearest-source-%s.glslp" % sc,
+                                     "shaders = 1\nshader0 = shaders/glow/blur_horiz.glsl\nfilter_linear0 = false\nmipmap_input0 = true\n"
+                                     "scale_type0 = source\nscale0 = %s\n" % sc) for sc in ("0.4", "0.17")},
+    "mipnearest-rgba8-0.6": ("crt/t-mipnearest-rgba8-0.6.glslp",
+                             "shaders = 2\nshader0 = ../stock.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n"
+                             "shader1 = shaders/glow/blur_horiz.glsl\nfilter_linear1 = false\nmipmap_input1 = true\n"
+                             "scale_type1 = source\nscale1 = 0.6\n"),
     "crt-geom": ("crt/crt-geom.glslp", 'shaders = 1\n\nshader0 = shaders/crt-geom.glsl\nfilter_linear0 = false\n'),
     "crt-easymode": ("crt/crt-easymode.glslp", 'shaders = 1\n\nshader0 = shaders/crt-easymode.glsl\nfilter_linear0 = false\n'),
     "crt-nes-mini": ("crt/crt-nes-mini.glslp", 'shaders = 1\n\nshader0 = shaders/crt-nes-mini.glsl\n'),

@@ -903,6 +903,18 @@ def case_mip_rgba8():
         run_case("mip_rgba8_101x67_s0.6", write_preset(d, fbo % (GLSL, GLSL, "0.6")), mixed(101, 67, 173), 200, 150)
 
 
+def case_mip_nearest():
+    """mipmap_input WITHOUT filter_linear: GL_NEAREST_MIPMAP_NEAREST (ShaderEngine.cpp:1019-1030) on the GL_RGB source frame
+    and on a plain RGBA8 render target - one level per quad, (exponent(rho^2) + 1) >> 1, NEAREST texel."""
+    with tempfile.TemporaryDirectory() as d:
+        src = 'shaders = 1\nshader0 = %s/crt/shaders/glow/blur_horiz.glsl\nfilter_linear0 = false\nmipmap_input0 = true\nscale_type0 = source\nscale0 = %s\n'
+        run_case("mipnearest_source_96x64_s0.4", write_preset(d, src % (GLSL, "0.4")), noise(96, 64, 174), 200, 150)
+        run_case("mipnearest_source_125x95_s0.17", write_preset(d, src % (GLSL, "0.17")), mixed(125, 95, 175), 200, 150)
+        fbo = ('shaders = 2\nshader0 = %s/stock.glsl\nfilter_linear0 = false\nscale_type0 = source\nscale0 = 1.0\n'
+               'shader1 = %s/crt/shaders/glow/blur_horiz.glsl\nfilter_linear1 = false\nmipmap_input1 = true\nscale_type1 = source\nscale1 = %s\n')
+        run_case("mipnearest_rgba8_101x67_s0.6", write_preset(d, fbo % (GLSL, GLSL, "0.6")), mixed(101, 67, 176), 200, 150)
+
+
 def case_lcd3x():
     Q = GLSL + "/handheld/lcd1x.glslp"
     run_case("lcd1x_64x48_to_192x144", Q, mixed(64, 48, 153), 192, 144)
@@ -931,7 +943,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"advanced_aa": case_advanced_aa, "reverse_aa": case_reverse_aa, "crt_consumer": case_crt_consumer, "sameboy_lcd": case_sameboy_lcd, "side_by_side": case_side_by_side, "sameboy": case_sameboy, "lottes": case_lottes, "jinc2": case_jinc2, "interlacing": case_interlacing, "tvout": case_tvout, "ntsc_gauss": case_ntsc_gauss, "crt_potato": case_crt_potato, "gb_palette": case_gb_palette, "reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"advanced_aa": case_advanced_aa, "reverse_aa": case_reverse_aa, "crt_consumer": case_crt_consumer, "sameboy_lcd": case_sameboy_lcd, "side_by_side": case_side_by_side, "sameboy": case_sameboy, "lottes": case_lottes, "jinc2": case_jinc2, "interlacing": case_interlacing, "tvout": case_tvout, "ntsc_gauss": case_ntsc_gauss, "crt_potato": case_crt_potato, "gb_palette": case_gb_palette, "reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "mip_nearest": case_mip_nearest, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

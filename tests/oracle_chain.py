@@ -98,13 +98,13 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
         nxt = passes[k + 1] if k + 1 < len(passes) else {"filter_linear": True, "wrap": "clamp_to_edge"}
         # mipmap_input of the consuming pass (ShaderEngine.cpp:1022-1033): the chain is generated when that pass
         # binds its input and stays on the texture (as does the min filter) for later PassPrev reads
-        mip = bool(nxt.get("mipmap")) and nxt["filter_linear"]
+        mip = bool(nxt.get("mipmap"))   # LINEAR_MIPMAP_LINEAR with filter_linear, NEAREST_MIPMAP_NEAREST without
         if k not in mip_cache:
             mip_cache[k] = Tex(given[k] if given is not None else outs[k], fmts[k], nxt["filter_linear"], nxt["wrap"], mipmap=mip)
         return mip_cache[k]
 
     # mipmap_input0: the reference generates the chain on the SOURCE texture too (ShaderEngine.cpp:1019-1031)
-    source_tex = Tex(src, "rgbx8", passes[0]["filter_linear"], passes[0]["wrap"], mipmap=bool(passes[0].get("mipmap")) and passes[0]["filter_linear"])
+    source_tex = Tex(src, "rgbx8", passes[0]["filter_linear"], passes[0]["wrap"], mipmap=bool(passes[0].get("mipmap")))
     cur = source_tex
     pass0_call = None
     for i, p in enumerate(passes):

@@ -867,7 +867,10 @@ def test_crt_geom_matches_oracle_at_size(params, preset_tree, rc_lib):
 
 
 @pytest.mark.parametrize("case,key", [("mip_source_96x64_s0.4", "mip-source-0.4"), ("mip_source_125x95_s0.23", "mip-source-0.23"),
-                                      ("mip_rgba8_96x64_s0.37", "mip-rgba8-0.37"), ("mip_rgba8_101x67_s0.6", "mip-rgba8-0.6")])
+                                      ("mip_rgba8_96x64_s0.37", "mip-rgba8-0.37"), ("mip_rgba8_101x67_s0.6", "mip-rgba8-0.6"),
+                                      # mipmap_input without filter_linear: GL_NEAREST_MIPMAP_NEAREST, one level per quad
+                                      ("mipnearest_source_96x64_s0.4", "mipnearest-source-0.4"), ("mipnearest_source_125x95_s0.17", "mipnearest-source-0.17"),
+                                      ("mipnearest_rgba8_101x67_s0.6", "mipnearest-rgba8-0.6")])
 def test_mipmap_input_on_8bit_textures_matches_llvmpipe(case, key, preset_tree, rc_lib):
     """mipmap_input on the GL_RGB source frame and on a plain RGBA8 render target: llvmpipe builds those levels with the
     ordinary 8-bit LINEAR filter (not its blit fast path) and blends the two level samples in 8 bits

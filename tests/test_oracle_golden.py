@@ -20,6 +20,9 @@ CASES = {
     "mip_source_125x95_s0.23": "mip-source-0.23",
     "mip_rgba8_96x64_s0.37": "mip-rgba8-0.37",                  # mipmap_input on a plain RGBA8 render target
     "mip_rgba8_101x67_s0.6": "mip-rgba8-0.6",
+    "mipnearest_source_96x64_s0.4": "mipnearest-source-0.4",    # mipmap_input without filter_linear: GL_NEAREST_MIPMAP_NEAREST
+    "mipnearest_source_125x95_s0.17": "mipnearest-source-0.17",
+    "mipnearest_rgba8_101x67_s0.6": "mipnearest-rgba8-0.6",
     "crt_geom_96x64_to_301x217": "crt-geom",
     "crt_geom_params_80x60_to_320x240": "crt-geom",            # tilt, overscan, corner, SHARPER 2, saturation ...
     "crt_geom_flat_72x56_to_288x224": "crt-geom",              # CURVATURE 0
