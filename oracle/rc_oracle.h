@@ -110,6 +110,11 @@ typedef struct {
   int chain_w[16], chain_h[16];
   int vp_w, vp_h;
   int flags;             /* pass specific, see O_FLAG_* */
+  /* The size uniforms as the shader reads them, where they are NOT the real sizes of `in` and the target: the reference's
+   * history push re-draws the final output through pass 0's program with the uniforms pass 0's own draw left behind
+   * (ShaderEngine.cpp:1805-1834).  TextureSize == InputSize = uni_tex, OutputSize = uni_out; 0 = the real sizes.
+   * Read by the passes that declare it (chain_specs "stale_size_uniforms"). */
+  int uni_tex_w, uni_tex_h, uni_out_w, uni_out_h;
 } o_pass_args;
 
 /* crt-royale pass 6 reads a varying its vertex shader never writes.  On Mesa llvmpipe the
@@ -144,6 +149,7 @@ void o_pass_smootheststep(const o_pass_args* a);
 void o_pass_sharp_bilinear(const o_pass_args* a);      /* 2 params */
 void o_pass_zfast_crt(const o_pass_args* a);           /* 6 params (always the reference's fixed values) */
 void o_pass_feedback_persist(const o_pass_args* a);   /* fixture; extra = PassFeedback0, PassFeedback1; 1 param */
+void o_pass_history_size(const o_pass_args* a);      /* fixture; extra = PrevTexture, Prev1Texture; 1 param; reads uni_* */
 void o_pass_mix_frames(const o_pass_args* a);         /* extra[0] = PrevTexture (frame history) */
 void o_pass_motionblur_simple(const o_pass_args* a);  /* extra[0..6] = Prev6 .. Prev1, PrevTexture */
 void o_pass_braid_rewind(const o_pass_args* a);       /* history declared, not used (FrameDirection = 1) */

@@ -335,6 +335,43 @@ void o_pass_feedback_persist(const o_pass_args* a) {
   o_fp_leave(csr);
 }
 
+/* Conformance fixture tests/fixtures/conformance/history-size.glsl (this repository's own shader): a frame-history shader
+ * that reads TextureSize.x (a one-texel offset), OutputSize.y (a two-row pattern) and InputSize.y / TextureSize.y, to pin
+ * the stale size uniforms of the reference's history re-draw (o_pass_args::uni_*).  Operation order from llvmpipe's NIR:
+ * now = cur * 0.75 + right * 0.25; t = (old0 * 0.625 - now) + old1 * 0.375; (now + t * HS_MIX) * dim * (InputSize.y /
+ * TextureSize.y), no contraction.  extra[0] = PrevTexture, extra[1] = Prev1Texture.  params: HS_MIX */
+static void o_pass_history_size_body(const o_pass_args* a) {
+  const int W = a->out_w, H = a->out_h;
+  const float mixw = a->params[0];
+  const float ts_x = (float)(a->uni_tex_w ? a->uni_tex_w : a->in->w), ts_y = (float)(a->uni_tex_h ? a->uni_tex_h : a->in->h);
+  const float os_y = (float)(a->uni_out_h ? a->uni_out_h : a->out_h);
+  const float inv = 1.0f / ts_x, cover = ts_y / ts_y;   /* InputSize == TextureSize in the reference (ShaderEngine.cpp:2401-2437) */
+  o_varying tu = o_varying_setup(0.f, 1.f, 1.f, 0.f, W, H, a->out_fmt), tv = o_varying_setup(0.f, 0.f, 1.f, 1.f, W, H, a->out_fmt);
+  for (int y = a->y0; y < a->y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      int lo = o_lower_tri(x, y, W, H);
+      float u = o_varying_at(&tu, x, y, lo), v = o_varying_at(&tv, x, y, lo);
+      const float u2 = u + inv;
+      o_vec4 c = o_sample(a->in, u, v), r = o_sample(a->in, u2, v), p0 = o_sample(a->extra[0], u, v), p1 = o_sample(a->extra[1], u2, v);
+      const float row = floorf(v * os_y), hrow = row * 0.5f, fr = hrow + (-floorf(hrow));
+      const float dim = fr < 0.25f ? 1.0f : 0.75f;
+      const float cc[3] = {c.x, c.y, c.z}, rr[3] = {r.x, r.y, r.z}, a0[3] = {p0.x, p0.y, p0.z}, a1[3] = {p1.x, p1.y, p1.z};
+      float o[3];
+      for (int k = 0; k < 3; ++k) {
+        const float now = cc[k] * 0.75f + rr[k] * 0.25f;
+        const float t = (a0[k] * 0.625f + (-now)) + a1[k] * 0.375f;
+        o[k] = ((now + t * mixw) * dim) * cover;
+      }
+      o_vec4 ov = {o[0], o[1], o[2], 1.0f};
+      store_px(a, x, y, ov);
+    }
+}
+void o_pass_history_size(const o_pass_args* a) {
+  unsigned csr = o_fp_enter();
+  o_pass_history_size_body(a);
+  o_fp_leave(csr);
+}
+
 /* crt/shaders/zfast_crt.glsl (crt/zfast-crt.glslp), FINEMASK as the file defines it; VS 101-108, FS 168-198.
  * params: BLURSCALEX, LOWLUMSCAN, HILUMSCAN, BRIGHTBOOST, MASK_DARK, MASK_FADE - the six names the reference
  * overwrites with fixed values after the pragma parameters (ShaderEngine.cpp:2260-2294), so they always arrive as

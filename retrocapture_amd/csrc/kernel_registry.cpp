@@ -461,6 +461,13 @@ std::vector<KernelEntry> build() {
   // shader of the reference's tree declares
   r.push_back({"conformance/feedback-persist.glsl", "feedback-persist", {{"PERSIST", 0.8f, 0.0f, 1.0f, 0.05f, "Persistence"}},
                {"PassFeedback0", "PassFeedback1"}, rck::launch_feedback_persist, setupTexCoord, false});
+  {
+    // ... and one that pins the STALE SIZE UNIFORMS of the history re-draw (a history shader that reads its size uniforms)
+    KernelEntry e{"conformance/history-size.glsl", "history-size", {{"HS_MIX", 0.3f, 0.0f, 1.0f, 0.05f, "History weight"}},
+                  {"PrevTexture", "Prev1Texture"}, rck::launch_history_size, setupTexCoord, false};
+    e.stale_size_uniforms = true;
+    r.push_back(e);
+  }
   r.push_back({"motionblur/shaders/mix_frames.glsl", "mix-frames", {}, {"PrevTexture"}, rck::launch_mix_frames, setupCrtPi,
                false, true, nullptr, nullptr, true});  // VS: TEX0 = TexCoord * 1.0001 (mix_frames.glsl:53)
   // the other four motionblur/ presets: frame history down to Prev6Texture (kernels/pass_basic.hip)

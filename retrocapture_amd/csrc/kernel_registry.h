@@ -50,6 +50,8 @@ struct KernelEntry {
   // only on the textures bound and the target size.  Needed for the frame-history re-draw, which runs
   // pass 0's program with stale size uniforms (shader_engine.cpp pushHistory).
   bool size_independent = false;
+  // ... or it reads them through PassLaunch::uni_* (rc_device.h), which the re-draw fills with pass 0's stale values.
+  bool stale_size_uniforms = false;
   // The kernel samples its input as llvmpipe samples a mip-mapped texture (mipmap_input of its pass:
   // GL_LINEAR_MIPMAP_LINEAR + glGenerateMipmap, ShaderEngine.cpp:1022-1033); the engine then builds the chain.
   bool mip_aware = false;

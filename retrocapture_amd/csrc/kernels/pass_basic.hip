@@ -437,6 +437,35 @@ __global__ void __launch_bounds__(256) k_feedback_persist(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
+// Conformance fixture tests/fixtures/conformance/history-size.glsl (this repository's own shader): a frame-history shader that
+// reads TextureSize.x, OutputSize.y and InputSize.y / TextureSize.y - through PassLaunch::uni_* where the history re-draw leaves
+// them stale (oracle/rc_passes_basic.c o_pass_history_size: operation order from llvmpipe's NIR).
+// extra[0] = PrevTexture, extra[1] = Prev1Texture; params: HS_MIX
+__global__ void __launch_bounds__(256) k_history_size(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  const float mixw = L.params[0];
+  const float ts_x = (float)(L.uni_tex_w ? L.uni_tex_w : L.in.w), ts_y = (float)(L.uni_tex_h ? L.uni_tex_h : L.in.h);
+  const float os_y = (float)(L.uni_out_h ? L.uni_out_h : L.out_h);
+  const float inv = 1.0f / ts_x, cover = ts_y / ts_y;
+  const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
+  const float u2 = u + inv;
+  const float4 c = sample_rt(L.in, frame_ptr(L.in, z), u, v, &lds), r = sample_rt(L.in, frame_ptr(L.in, z), u2, v, &lds);
+  const float4 p0 = sample_rt(L.extra[0], frame_ptr(L.extra[0], z), u, v, &lds), p1 = sample_rt(L.extra[1], frame_ptr(L.extra[1], z), u2, v, &lds);
+  const float row = __builtin_floorf(v * os_y), hrow = row * 0.5f, fr = hrow + (-__builtin_floorf(hrow));
+  const float dim = fr < 0.25f ? 1.0f : 0.75f;
+  const float cc[3] = {c.x, c.y, c.z}, rr[3] = {r.x, r.y, r.z}, a0[3] = {p0.x, p0.y, p0.z}, a1[3] = {p1.x, p1.y, p1.z};
+  float o[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float now = cc[k] * 0.75f + rr[k] * 0.25f;
+    const float t = (a0[k] * 0.625f + (-now)) + a1[k] * 0.375f;
+    o[k] = ((now + t * mixw) * dim) * cover;
+  }
+  store_rt(L, z, x, y, make_float4(o[0], o[1], o[2], 1.0f), &lds);
+  RC_TILE_LOOP_END
+}
+
 // crt/shaders/zfast_crt.glsl (FINEMASK), VS 101-108, FS 168-198; plane[0], plane[1]: TEX0 = TexCoord * 1.0001.
 // params: BLURSCALEX, LOWLUMSCAN, HILUMSCAN, BRIGHTBOOST, MASK_DARK, MASK_FADE (always the reference's fixed values,
 // ShaderEngine.cpp:2260-2294)
@@ -785,6 +814,7 @@ hipError_t launch_mix_frames(const PassLaunch& L, hipStream_t s) {
     hipLaunchKernelGGL(kernel, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);       \
     return hipGetLastError();                                                               \
   }
+RC_SIMPLE_LAUNCH(launch_history_size, k_history_size)
 RC_SIMPLE_LAUNCH(launch_motionblur_simple, k_motionblur_simple)
 RC_SIMPLE_LAUNCH(launch_braid_rewind, k_braid_rewind)
 RC_SIMPLE_LAUNCH(launch_response_time, k_response_time)

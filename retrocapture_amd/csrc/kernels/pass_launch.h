@@ -24,6 +24,7 @@ hipError_t launch_bayer(const PassLaunch& L, hipStream_t s);
 hipError_t launch_smootheststep(const PassLaunch& L, hipStream_t s);
 hipError_t launch_sharp_bilinear(const PassLaunch& L, hipStream_t s);
 hipError_t launch_feedback_persist(const PassLaunch& L, hipStream_t s);
+hipError_t launch_history_size(const PassLaunch& L, hipStream_t s);
 hipError_t launch_mix_frames(const PassLaunch& L, hipStream_t s);
 hipError_t launch_motionblur_simple(const PassLaunch& L, hipStream_t s);
 hipError_t launch_braid_rewind(const PassLaunch& L, hipStream_t s);

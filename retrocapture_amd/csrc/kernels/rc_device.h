@@ -64,6 +64,11 @@ struct PassLaunch {
   int frame_count0;       // FrameCount of frame 0 of this launch; frame z sees frame_count0+z
   int n_frames;
   int flags;              // kernel specific (e.g. RC_FLAG_UNDEF_VARYING_ZERO)
+  // The size uniforms as the shader reads them where they are NOT the real sizes of `in` and the target: the history push
+  // re-draws the final output through pass 0's program with the uniforms of pass 0's own draw still set (reference
+  // ShaderEngine.cpp:1805-1834).  TextureSize == InputSize = uni_tex, OutputSize = uni_out; 0 = the real sizes.  Only kernels
+  // registered with KernelEntry::stale_size_uniforms read them.
+  int uni_tex_w, uni_tex_h, uni_out_w, uni_out_h;
   const uint32_t* srgb_enc;  // per-run table of the sRGB8 encode in device memory (srgb_encode.cpp); needed when out_fmt is sRGB8
   Plane plane[kMaxPlanes];
   float params[kMaxParams];

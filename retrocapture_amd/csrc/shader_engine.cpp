@@ -857,9 +857,10 @@ bool ShaderEngine::pushHistory(const void* finalFrame, int frameCount, const rcd
   if (!p0.kernel) return true;
   const KernelEntry& k = *p0.kernel;
   const bool sameSizes = m_passes.size() == 1 && lastPass.width == m_sourceWidth && lastPass.height == m_sourceHeight;
-  if (!k.size_independent && !sameSizes) {
+  if (!k.size_independent && !k.stale_size_uniforms && !sameSizes) {
     RC_LOG_ERROR(std::string("frame history: pass 0 kernel '") + k.name +
-                 "' reads size uniforms; its history re-draw is only supported at 1:1 single-pass geometry");
+                 "' reads size uniforms and does not take them from PassLaunch::uni_*; its history re-draw is only supported at "
+                 "1:1 single-pass geometry");
     return false;
   }
   HistoryFrame hf;
@@ -903,6 +904,14 @@ bool ShaderEngine::pushHistory(const void* finalFrame, int frameCount, const rcd
   L.frame_count0 = frameCount;
   L.n_frames = 1;
   L.flags = (m_undefVaryingZero ? 1 : 0) | (m_generalOnly ? rcd::RC_FLAG_GENERAL_ONLY : 0);
+  if (k.stale_size_uniforms && !sameSizes) {
+    // the program's size uniforms are what pass 0's own draw of this frame set (:2401-2437): its input - the source frame -
+    // and its output
+    L.uni_tex_w = (int)m_sourceWidth;
+    L.uni_tex_h = (int)m_sourceHeight;
+    L.uni_out_w = (int)p0.width;
+    L.uni_out_h = (int)p0.height;
+  }
   for (size_t s = 0; s < k.samplers.size() && s < (size_t)rcd::kMaxExtra; ++s) {
     auto it = m_pass0Units.find(k.samplers[s]);
     const int u = it == m_pass0Units.end() ? 0 : it->second;

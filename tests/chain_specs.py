@@ -69,6 +69,12 @@ scale_y1 = 1.0
     "feedback-persist": ("feedback-persist.glslp",
                          'shaders = 2\nshader0 = stock.glsl\nfilter_linear0 = false\nscale_type0 = source\n'
                          'shader1 = conformance/feedback-persist.glsl\nfilter_linear1 = true\n'),
+    # frame history through a pass 0 that READS its size uniforms (this repository's fixture shader), scaled 2x, stock behind it:
+    # the history re-draw runs it on the final output with pass 0's stale TextureSize / OutputSize
+    "history-size": ("history-size.glslp",
+                     'shaders = 2\nshader0 = conformance/history-size.glsl\nfilter_linear0 = true\nscale_type0 = source\nscale0 = 2.0\n'
+                     'shader1 = stock.glsl\nfilter_linear1 = true\n'),
+    "history-size-single": ("history-size-single.glslp", 'shaders = 1\nshader0 = conformance/history-size.glsl\nfilter_linear0 = false\n'),
     # same keys / values as the reference's crt/crt-hyllian-glow.glslp (its smoke-test default preset)
     "crt-hyllian-glow": ("crt/crt-hyllian-glow.glslp", """shaders = 6
 
@@ -691,6 +697,9 @@ SHADERS = {
     # uniforms, reference ShaderEngine.cpp:1805-1834) is well defined for any geometry
     "conformance/feedback-persist.glsl": {"oracle": "feedback_persist", "params": [("PERSIST", 0.8)],
                                           "samplers": ["PassFeedback0", "PassFeedback1"]},
+    # stale_size_uniforms: reads them, and its oracle pass / kernel take the stale values of the history re-draw separately
+    "conformance/history-size.glsl": {"oracle": "history_size", "params": [("HS_MIX", 0.3)], "samplers": ["PrevTexture", "Prev1Texture"],
+                                      "stale_size_uniforms": True},
     "motionblur/shaders/mix_frames.glsl": {"oracle": "mix_frames", "params": [], "samplers": ["PrevTexture"],
                                            "size_independent": True},
     "motionblur/shaders/motionblur-simple.glsl": {"oracle": "motionblur_simple", "params": [], "size_independent": True,

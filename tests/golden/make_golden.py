@@ -347,6 +347,20 @@ def case_feedback():
         run_case("feedback_persist_64x40_to_150x90_f5", p, moving(64, 40, 5, 31), 150, 90, params=[("PERSIST", 0.6)])
 
 
+def case_history_size():
+    """The history re-draw through a pass 0 that reads its size uniforms (ShaderEngine.cpp:1805-1834: the program keeps what pass
+    0's own draw set - stale whenever the final output's size is not pass 0's), pinned with this repository's fixture shader:
+    pass 0 scaled 2x, stock behind it to the viewport; ring content after 4 and 9 frames (the recycling rule included)."""
+    fixture = os.path.join(ROOT, "tests", "fixtures", "conformance", "history-size.glsl")
+    with tempfile.TemporaryDirectory() as d:
+        p = write_preset(d, 'shaders = 2\nshader0 = %s\nfilter_linear0 = true\nscale_type0 = source\nscale0 = 2.0\n'
+                            'shader1 = %s/stock.glsl\nfilter_linear1 = true\n' % (fixture, GLSL))
+        run_case("history_size_48x36_to_120x90_f4", p, moving(48, 36, 4, 61), 120, 90)
+        run_case("history_size_params_40x30_to_131x77_f9", p, moving(40, 30, 9, 62), 131, 77, params=[("HS_MIX", 0.55)])
+        q = write_preset(d, 'shaders = 1\nshader0 = %s\nfilter_linear0 = false\n' % fixture)
+        run_case("history_size_single_48x36_to_100x75_f3", q, moving(48, 36, 3, 63), 100, 75)
+
+
 def case_sampler_matrix():
     """Wrap modes and filters at chain level: crt-pi reading the source, stock reading crt-pi's (sRGB8 /
     RGBA8) target, both with the wrap mode under test, LINEAR.  Pins clamp_to_border / repeat /
@@ -943,7 +957,7 @@ def case_interp():
     run_case("f32_sharp_bilinear_64x48_to_200x150", P, noise(64, 48, 134), 200, 150, f32=True)
 
 
-CASES = {"advanced_aa": case_advanced_aa, "reverse_aa": case_reverse_aa, "crt_consumer": case_crt_consumer, "sameboy_lcd": case_sameboy_lcd, "side_by_side": case_side_by_side, "sameboy": case_sameboy, "lottes": case_lottes, "jinc2": case_jinc2, "interlacing": case_interlacing, "tvout": case_tvout, "ntsc_gauss": case_ntsc_gauss, "crt_potato": case_crt_potato, "gb_palette": case_gb_palette, "reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "mip_nearest": case_mip_nearest, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
+CASES = {"advanced_aa": case_advanced_aa, "reverse_aa": case_reverse_aa, "crt_consumer": case_crt_consumer, "sameboy_lcd": case_sameboy_lcd, "side_by_side": case_side_by_side, "sameboy": case_sameboy, "lottes": case_lottes, "jinc2": case_jinc2, "interlacing": case_interlacing, "tvout": case_tvout, "ntsc_gauss": case_ntsc_gauss, "crt_potato": case_crt_potato, "gb_palette": case_gb_palette, "reshade_lut": case_reshade_lut, "imgborder": case_imgborder, "lcd_grid": case_lcd_grid, "console_border": case_console_border, "agb001": case_agb001, "retro_v2": case_retro_v2, "lcd_grid_v2": case_lcd_grid_v2, "handheld_color": case_handheld_color, "history_more": case_history_more, "royale_fake_bloom_geom": case_royale_fake_bloom_geom, "hyllian_layouts": case_hyllian_layouts, "crt_royale_geom": case_crt_royale_geom, "motionblur": case_motionblur, "mip_rgba8": case_mip_rgba8, "history_size": case_history_size, "mip_nearest": case_mip_nearest, "crt_geom": case_crt_geom, "scalefx": case_scalefx, "bayer": case_bayer, "lcd3x": case_lcd3x, "epx": case_epx, "interp": case_interp, "nes_mini": case_nes_mini, "easymode": case_easymode, "zfast": case_zfast, "stock_presets": case_stock_presets, "royale_ntsc": case_royale_ntsc, "xbr_lv2": case_xbr_lv2, "hyllian_glow": case_hyllian_glow, "royale_fake_bloom": case_royale_fake_bloom, "present": case_present, "sampler_matrix": case_sampler_matrix, "float": case_float, "ntsc_family": case_ntsc_family, "feedback": case_feedback, "mix_frames": case_mix_frames, "ntsc": case_ntsc, "xbr": case_xbr, "scanline": case_scanline, "crt_pi": case_crt_pi, "crt_royale": case_crt_royale,
          "crt_royale_mask_active": case_crt_royale_mask_active}
 
 if __name__ == "__main__":

@@ -214,8 +214,12 @@ def run_chain(passes, rgb, vw, vh, frame_count=1, luts=None, custom=None, global
         # uniforms as they stand, unit 0 = the final output, every other unit as the frame left it -
         # into an RGBA8 texture of the output size
         spec, call = pass0_call
-        if not (spec.get("size_independent") or (len(passes) == 1 and sizes[-1] == (w, h))):
+        same = len(passes) == 1 and sizes[-1] == (w, h)
+        if not (spec.get("size_independent") or spec.get("stale_size_uniforms") or same):
             raise NotImplementedError("history re-draw with stale size uniforms")
+        if spec.get("stale_size_uniforms") and not same:
+            # the program's size uniforms still hold what pass 0's own draw set: its input (the source frame) and its output
+            call = dict(call, uni=(w, h, sizes[0][0], sizes[0][1]))
         final = cur
         extra = [units[state.pass0_units[n]] if state.pass0_units.get(n, 0) else final for n in spec["samplers"]]
         ow, oh = sizes[-1]

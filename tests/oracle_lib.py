@@ -29,7 +29,7 @@ class OPassArgs(C.Structure):
                 ("frame_count", C.c_int), ("params", C.POINTER(C.c_float)), ("dst", C.c_void_p),
                 ("y0", C.c_int), ("y1", C.c_int), ("pass_index", C.c_int), ("n_passes", C.c_int),
                 ("chain_w", C.c_int * 16), ("chain_h", C.c_int * 16), ("vp_w", C.c_int), ("vp_h", C.c_int),
-                ("flags", C.c_int)]
+                ("flags", C.c_int), ("uni_tex_w", C.c_int), ("uni_tex_h", C.c_int), ("uni_out_w", C.c_int), ("uni_out_h", C.c_int)]
 
 
 def lib():
@@ -80,7 +80,7 @@ def gen_mipmaps(level0, fmt):
 
 
 def _call(name, tex, out_w, out_h, y0, y1, out_fmt, params, frame_count, extra, src_w, src_h, chain, pass_index,
-          vp, flags, threads):
+          vp, flags, threads, uni):
     L = lib()
     fn = getattr(L, "o_pass_" + name)
     fn.restype = None
@@ -103,6 +103,8 @@ def _call(name, tex, out_w, out_h, y0, y1, out_fmt, params, frame_count, extra, 
         a.chain_w[k], a.chain_h[k] = cw, ch
     a.vp_w, a.vp_h = vp if vp else (out_w, out_h)
     a.flags = flags
+    if uni:
+        a.uni_tex_w, a.uni_tex_h, a.uni_out_w, a.uni_out_h = uni
     rows = y1 - y0
     if threads > 1 and rows >= 4 * threads:
         import threading
@@ -123,17 +125,18 @@ def _call(name, tex, out_w, out_h, y0, y1, out_fmt, params, frame_count, extra, 
 
 
 def run_pass(name, tex, out_w, out_h, out_fmt="rgba8", params=(), frame_count=1, extra=(), src_w=None, src_h=None,
-             chain=None, pass_index=0, vp=None, flags=0):
-    """Render one pass with the oracle; returns (out_h, out_w, 4) uint8 or float32."""
+             chain=None, pass_index=0, vp=None, flags=0, uni=None):
+    """Render one pass with the oracle; returns (out_h, out_w, 4) uint8 or float32.  uni = (tex_w, tex_h, out_w, out_h): the
+    size uniforms as the shader reads them where they are not the real sizes (o_pass_args::uni_*)."""
     return _call(name, tex, out_w, out_h, 0, out_h, out_fmt, params, frame_count, extra, src_w, src_h, chain,
-                 pass_index, vp, flags, _THREADS)
+                 pass_index, vp, flags, _THREADS, uni)
 
 
 def run_pass_rows(name, tex, out_w, out_h, y0, y1, out_fmt="rgba8", params=(), frame_count=1, extra=(),
                   src_w=None, src_h=None, chain=None, pass_index=0, vp=None, flags=0):
     """Rows [y0, y1) of a pass rendered at full target size (for full-size spot checks)."""
     return _call(name, tex, out_w, out_h, y0, y1, out_fmt, params, frame_count, extra, src_w, src_h, chain,
-                 pass_index, vp, flags, 1)[y0:y1].copy()
+                 pass_index, vp, flags, 1, None)[y0:y1].copy()
 
 
 class OVec4(C.Structure):

@@ -459,7 +459,10 @@ def test_engine_matches_oracle(key, w, h, vw, vh, preset_tree, rc_lib):
     e.shutdown()
 
 
-HISTORY_CASES = {"mix_frames_72x40_to_72x40_f3": "mix-frames", "mix_frames_48x36_to_120x90_f9": "mix-frames",
+HISTORY_CASES = {# the history re-draw through a pass 0 that reads its size uniforms: they are stale (pass 0's own), this repository's fixture shader
+                 "history_size_48x36_to_120x90_f4": "history-size", "history_size_params_40x30_to_131x77_f9": "history-size",
+                 "history_size_single_48x36_to_100x75_f3": "history-size-single",
+                 "mix_frames_72x40_to_72x40_f3": "mix-frames", "mix_frames_48x36_to_120x90_f9": "mix-frames",
                  "motionblur_simple_48x36_to_120x90_f9": "motionblur-simple", "motionblur_simple_40x30_to_40x30_f3": "motionblur-simple",
                  "braid_rewind_48x36_to_120x90_f8": "braid-rewind", "response_time_48x36_to_120x90_f9": "response-time",
                  "response_time_params_40x30_to_100x75_f4": "response-time", "mix_frames_smart_48x36_to_120x90_f8": "mix-frames-smart",

@@ -43,6 +43,9 @@ CASES = {
     "crt_royale_fake_bloom_geom_sphere_maskon_96x72_to_240x180": "crt-royale-fake-bloom",
     "crt_royale_fake_bloom_geom_cylinder_tilt_maskon_96x72_to_240x180": "crt-royale-fake-bloom",
     "crt_royale_fake_bloom_geom_flat_overscan_maskon_96x72_to_240x180": "crt-royale-fake-bloom",
+    "history_size_48x36_to_120x90_f4": "history-size",           # history re-draw with pass 0's stale size uniforms (fixture shader)
+    "history_size_params_40x30_to_131x77_f9": "history-size",
+    "history_size_single_48x36_to_100x75_f3": "history-size-single",
     "feedback_persist_64x40_to_64x40_f1": "feedback-persist",
     "feedback_persist_64x40_to_64x40_f2": "feedback-persist",
     "feedback_persist_64x40_to_150x90_f5": "feedback-persist",
@@ -247,7 +250,7 @@ def run_sequence(passes, frames_rgb, vw, vh, **kw):
     return outs, st
 
 
-HISTORY_PRESETS = ("sameboy-lcd-gbc-color-motionblur", "sameboy-dmg-response-time", "gba-3x", "gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "agb001-gba-color-motionblur", "lcd-grid-v2-psp-color-motionblur", "lcd-grid-v2-motionblur", "mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
+HISTORY_PRESETS = ("history-size", "history-size-single", "sameboy-lcd-gbc-color-motionblur", "sameboy-dmg-response-time", "gba-3x", "gba-lcd-grid-v2-3x", "gbc-retro-v2-2x", "agb001-gba-color-motionblur", "lcd-grid-v2-psp-color-motionblur", "lcd-grid-v2-motionblur", "mix-frames", "motionblur-simple", "braid-rewind", "response-time", "mix-frames-smart", "shutter-3d", "anti-flicker")
 
 
 @pytest.mark.parametrize("case", sorted(c for c in CASES if CASES[c] in HISTORY_PRESETS))
