@@ -345,6 +345,9 @@ std::vector<KernelEntry> build() {
                 {"INPUT_GAMMA", 2.4f, 0.0f, 5.0f, 0.01f, "Input gamma"},
                 {"OUTPUT_GAMMA", 2.2f, 0.0f, 5.0f, 0.01f, "Output gamma"}},
                {}, rck::launch_crt_pi, setupCrtPi, false});
+  // the strip form lists the pixels its gamma tables cannot certify in this scratch: a 256-byte header and one 4-byte entry per pixel
+  // (kernels/pass_crt_pi.hip)
+  r.back().scratch_bytes = [](const PassGeometry& g) -> uint64_t { return 256 + (uint64_t)g.out_w * g.out_h * 4; };
   r.push_back({"dithering/shaders/bayer-matrix-dithering.glsl", "bayer-matrix-dithering",
                {{"animate", 0.0f, 0.0f, 1.0f, 1.0f, "Dithering Animation"}, {"dither_size", 0.0f, 0.0f, 0.95f, 0.05f, "Dither Size"}},
                {}, rck::launch_bayer, setupTexCoord, false});

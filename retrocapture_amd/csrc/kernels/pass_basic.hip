@@ -2,8 +2,7 @@
 //   stock.glsl                         shaders/shaders_glsl/stock.glsl
 //   scanlines/shaders/scanline.glsl    VS line 50, FS lines 107-113
 //   motionblur/shaders/mix_frames.glsl VS lines 51-55, FS lines 94-107 (samples PrevTexture)
-//   crt/shaders/crt-pi.glsl            VS lines 96-103, FS lines 131-232
-//     (compile-time switches as shipped: SCANLINES, MULTISAMPLE, GAMMA, MASK_TYPE 1)
+//   (crt/shaders/crt-pi.glsl: pass_crt_pi.hip)
 // One thread per target pixel; blockIdx.z = frame of the batch.
 #include "pass_launch.h"
 
@@ -736,62 +735,6 @@ __global__ void __launch_bounds__(256) k_crt_easymode(const PassLaunch L) {
   RC_TILE_LOOP_END
 }
 
-__device__ __forceinline__ float crtpi_weight(float dist, float sw, float gap) {
-  float w = 1.0f - (dist * dist) * sw;
-  return w > gap ? w : gap;
-}
-
-// params: CURVATURE_X, CURVATURE_Y, MASK_BRIGHTNESS, SCANLINE_WEIGHT,
-//         SCANLINE_GAP_BRIGHTNESS, BLOOM_FACTOR, INPUT_GAMMA, OUTPUT_GAMMA
-// plane[0], plane[1]: TEX0 = TexCoord * 1.0001
-template <int IN_FMT, int IN_LINEAR, int IN_WRAP, int OUT_FMT, bool GENERIC>
-__global__ void __launch_bounds__(256) k_crt_pi(const PassLaunch L) {
-  RC_SRGB_LDS(lds, L);
-  RC_TILE_LOOP_BEGIN
-  const float mask_b = L.params[2], sw = L.params[3], gap = L.params[4], bloom = L.params[5];
-  const float in_gamma = L.params[6], out_gamma = L.params[7];
-  const float tsy = (float)L.in.h;
-  const float filter_width = (tsy / (float)L.out_h) / 3.0f;
-  const float inv_out_gamma = 1.0f / out_gamma;
-  const float tcx = vary(L.plane[0], x, y, lo), tcy = vary(L.plane[1], x, y, lo);
-  const float pix_y = tcy * tsy;
-  const float temp_y = __builtin_floorf(pix_y) + 0.5f;
-  const float y_coord = temp_y / tsy;
-  float dy = pix_y - temp_y;
-  float slw = crtpi_weight(dy, sw, gap);
-  slw += crtpi_weight(dy - filter_width, sw, gap);
-  slw += crtpi_weight(dy + filter_width, sw, gap);
-  slw *= 0.3333333f;
-  const float sign_y = dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f);
-  dy = dy * dy;
-  dy = dy * dy;
-  dy *= 8.0f;
-  dy /= tsy;
-  dy *= sign_y;
-  const uint8_t* img = frame_ptr(L.in, z);
-  const float4 c = GENERIC ? sample_rt(L.in, img, tcx, y_coord + dy, &lds)
-                           : sample<IN_FMT, IN_LINEAR, IN_WRAP>(L.in, img, tcx, y_coord + dy, &lds);
-  float r = pow_(c.x, in_gamma), g = pow_(c.y, in_gamma), b = pow_(c.z, in_gamma);
-  slw *= bloom;
-  r *= slw;
-  g *= slw;
-  b *= slw;
-  r = pow_(r, inv_out_gamma);
-  g = pow_(g, inv_out_gamma);
-  b = pow_(b, inv_out_gamma);
-  const float fx = ((float)x + 0.5f) * 1.0001f * 0.5f;
-  const float which = fx - __builtin_floorf(fx);
-  float4 o;
-  if (which < 0.5f) {
-    o = make_float4(r * mask_b, g * 1.0f, b * mask_b, 1.0f);
-  } else {
-    o = make_float4(r * 1.0f, g * mask_b, b * 1.0f, 1.0f);
-  }
-  if (GENERIC) store_rt(L, z, x, y, o, &lds);
-  else store<OUT_FMT>(L, z, x, y, o, &lds);
-  RC_TILE_LOOP_END
-}
-
 }  // namespace
 
 namespace rck {
@@ -887,14 +830,4 @@ hipError_t launch_zfast_crt(const PassLaunch& L, hipStream_t s) {
   else hipLaunchKernelGGL(k_zfast_crt<true>, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
   return hipGetLastError();
 }
-hipError_t launch_crt_pi(const PassLaunch& L, hipStream_t s) {
-  // the shipped preset's configuration (crt/crt-pi.glslp: linear, clamp_to_border, RGBA8 out,
-  // on the RGB source frame) gets a specialised instantiation
-  if (L.in.fmt == FMT_RGBX8 && L.in.linear && L.in.wrap == WRAP_BORDER && L.out_fmt == FMT_RGBA8)
-    hipLaunchKernelGGL((k_crt_pi<FMT_RGBX8, 1, WRAP_BORDER, FMT_RGBA8, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
-  else
-    hipLaunchKernelGGL((k_crt_pi<0, 0, 0, 0, true>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
-  return hipGetLastError();
-}
-
 }  // namespace rck

@@ -1,0 +1,435 @@
+// crt/shaders/crt-pi.glsl (crt/crt-pi.glslp; BASELINE config 2): VS lines 96-103, FS lines 131-232, compile-time switches as
+// shipped (SCANLINES, MULTISAMPLE, GAMMA, MASK_TYPE 1; no CURVATURE, no SHARPER).
+//   k_crt_pi          one thread per pixel, the GLSL's arithmetic statement by statement (six exact pows per pixel)
+//   k_crt_pi_strip    the shipped configuration on a separable geometry: per-column / per-row tables of everything the
+//                     shader derives from a coordinate, and the two gamma pows from TABLES WITH MEASURED BOUNDS - a pixel's
+//                     byte is taken from them only when it is certain, the rest go to k_crt_pi_fix (the exact form)
+// params: CURVATURE_X, CURVATURE_Y, MASK_BRIGHTNESS, SCANLINE_WEIGHT, SCANLINE_GAP_BRIGHTNESS, BLOOM_FACTOR, INPUT_GAMMA,
+//         OUTPUT_GAMMA;  plane[0], plane[1]: TEX0 = TexCoord * 1.0001
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "pass_launch.h"
+#include "royale_strip.h"
+#include "royale_strip2.h"
+
+using namespace rcd;
+
+namespace {
+
+__device__ __forceinline__ float crtpi_weight(float dist, float sw, float gap) {
+  float w = 1.0f - (dist * dist) * sw;
+  return w > gap ? w : gap;
+}
+// what the fragment shader derives from the vertical coordinate alone: the sample's v and the scanline weight * BLOOM_FACTOR
+struct CrtPiRow {
+  float v, s;
+};
+__device__ __forceinline__ CrtPiRow crtpi_row(const PassLaunch& L, float tcy) {
+  const float sw = L.params[3], gap = L.params[4], bloom = L.params[5];
+  const float tsy = (float)L.in.h;
+  const float filter_width = (tsy / (float)L.out_h) / 3.0f;
+  const float pix_y = tcy * tsy;
+  const float temp_y = __builtin_floorf(pix_y) + 0.5f;
+  const float y_coord = temp_y / tsy;
+  float dy = pix_y - temp_y;
+  float slw = crtpi_weight(dy, sw, gap);
+  slw += crtpi_weight(dy - filter_width, sw, gap);
+  slw += crtpi_weight(dy + filter_width, sw, gap);
+  slw *= 0.3333333f;
+  const float sign_y = dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f);
+  dy = dy * dy;
+  dy = dy * dy;
+  dy *= 8.0f;
+  dy /= tsy;
+  dy *= sign_y;
+  slw *= bloom;
+  return CrtPiRow{y_coord + dy, slw};
+}
+__device__ __forceinline__ bool crtpi_mask_first(int x) {   // MASK_TYPE 1: which of the two column masks
+  const float fx = ((float)x + 0.5f) * 1.0001f * 0.5f;
+  return fx - __builtin_floorf(fx) < 0.5f;
+}
+// the colour a pixel stores, from its sampled texel colour c (exact form)
+__device__ __forceinline__ float4 crtpi_shade(const PassLaunch& L, float4 c, float s, bool first) {
+  const float mask_b = L.params[2], in_gamma = L.params[6], inv_out_gamma = 1.0f / L.params[7];
+  float r = pow_(c.x, in_gamma), g = pow_(c.y, in_gamma), b = pow_(c.z, in_gamma);
+  r *= s;
+  g *= s;
+  b *= s;
+  r = pow_(r, inv_out_gamma);
+  g = pow_(g, inv_out_gamma);
+  b = pow_(b, inv_out_gamma);
+  return first ? make_float4(r * mask_b, g * 1.0f, b * mask_b, 1.0f) : make_float4(r * 1.0f, g * mask_b, b * 1.0f, 1.0f);
+}
+template <int IN_FMT, int IN_LINEAR, int IN_WRAP, int OUT_FMT, bool GENERIC>
+__device__ __forceinline__ void crtpi_pixel(const PassLaunch& L, const SrgbLds* lds, int x, int y, int z, bool lo) {
+  const float tcx = vary(L.plane[0], x, y, lo), tcy = vary(L.plane[1], x, y, lo);
+  const CrtPiRow r = crtpi_row(L, tcy);
+  const uint8_t* img = frame_ptr(L.in, z);
+  const float4 c = GENERIC ? sample_rt(L.in, img, tcx, r.v, lds) : sample<IN_FMT, IN_LINEAR, IN_WRAP>(L.in, img, tcx, r.v, lds);
+  const float4 o = crtpi_shade(L, c, r.s, crtpi_mask_first(x));
+  if (GENERIC) store_rt(L, z, x, y, o, lds);
+  else store<OUT_FMT>(L, z, x, y, o, lds);
+}
+template <int IN_FMT, int IN_LINEAR, int IN_WRAP, int OUT_FMT, bool GENERIC>
+__global__ void __launch_bounds__(256) k_crt_pi(const PassLaunch L) {
+  RC_SRGB_LDS(lds, L);
+  RC_TILE_LOOP_BEGIN
+  crtpi_pixel<IN_FMT, IN_LINEAR, IN_WRAP, OUT_FMT, GENERIC>(L, &lds, x, y, z, lo);
+  RC_TILE_LOOP_END
+}
+
+// ------------------------------------------------------------------------------------------- strip form -----
+// The shipped configuration (GL_RGB source, LINEAR, clamp_to_border, RGBA8 target) on a geometry whose TEX0.x depends on the
+// column and TEX0.y on the row alone.  Per column (k_crtpi_geometry, the sampler's own operations): first texel, weight, mask;
+// per row: first texel row, weight, scanline weight.  Per pixel the exact form then evaluates, per channel,
+//     stored = unorm8( pow_( pow_(c, INPUT_GAMMA) * s, 1 / OUTPUT_GAMMA ) * m )          (m = MASK_BRIGHTNESS or 1)
+// - two pows of ~40 float operations each.  Both are smooth powers of their argument, so each is tabulated: 32 log-spaced nodes
+// per octave (the top five mantissa bits select the node), per node a quadratic in the argument ITSELF, a0 + x (a1 + x a2), fitted
+// at the node's midpoint: value = the exact code's own float there, derivatives from the closed form.  What makes the tables safe
+// is MEASURED, by exhaustion, when they are built (buildCrtPiTables): the largest relative difference RA between table A and
+// pow_(c, INPUT_GAMMA) over EVERY float c of its range, and for table B the largest relative difference RB to pow_(v, 1 / OUTPUT_GAMMA)
+// over every float of every node's range WIDENED by 2^-12 on both sides (the table is entered with v' = a' s, which differs from the
+// exact v = a s by the relative RA + 2^-23: v lies in the widened range of the node v' selects), plus the largest logarithmic slope
+// DB = |B_n'(x)| x / pow_(x) of any node polynomial.  Then b' = B(v') and the exact b differ by at most (RB + DB (RA + 2^-23)) b,
+// the two products by m and by 255 add 2^-23, and with y' = fl(fl(b' m) 255), r = rint(y'):
+//     the exact code stores r  whenever  |y' - r| + K y' < 0.5,   K = 1.001 (RB + DB (RA + 2^-23) + 2^-22)
+// (unorm8 clamps: r is clamped the same way).  Arguments below a table's first node are not tabulated: a zero argument takes the
+// exact code's own value at 0 (node 0 of each table), any other fails.  Failing pixels (about 0.1 %) are listed in the pass's scratch
+// and rendered by k_crt_pi_fix with the exact per-pixel form.  tests: tests/test_gpu_parity.py (strip == general == oracle).
+constexpr int kPiShift = 18;                       // 2^18 floats per node: 32 nodes per octave
+constexpr uint32_t kPiA0 = 0x39800000u;            // table A from 2^-12 (a texel byte is >= 2^-8; smaller colours are thin lerps against black)
+constexpr uint32_t kPiA1 = 0x3f800000u;            // ... to 1.0 (its own node)
+constexpr uint32_t kPiB0 = 0x2e800000u;            // table B from 2^-34 ...
+constexpr uint32_t kPiB1 = 0x41000000u;            // ... to 8.0 exclusive (BLOOM_FACTOR <= 5)
+constexpr int kPiNodesA = (int)((kPiA1 - kPiA0) >> kPiShift) + 2;   // node 0: below the range; last: 1.0 alone
+constexpr int kPiNodesB = (int)((kPiB1 - kPiB0) >> kPiShift) + 1;   // node 0: below the range
+constexpr uint32_t kPiLdsA = 0u, kPiLdsB = kPiLdsA + (uint32_t)kPiNodesA * 16u, kPiLdsBytes = kPiLdsB + (uint32_t)kPiNodesB * 16u;
+constexpr float kPiWiden = 1.0f / 4096.0f;         // relative widening of a node's range for table B's measurement
+constexpr int kPiRows = 16;                        // target rows one thread walks
+constexpr int kPiWaveList = 256;                   // entries of a wave's list of uncertain pixels in LDS
+constexpr uint32_t kPiFixHeader = 256;             // scratch: a counter, then one entry (frame * H + y) * W + x per failing pixel
+enum { PI_X0 = 0, PI_WX = 1, PI_COL_FIELDS = 2 };
+enum { PI_Y0 = 0, PI_WY = 1, PI_S = 2, PI_ROW_FIELDS = 4 };
+
+__host__ __device__ __forceinline__ float crtpi_node_mid(uint32_t bits0, int n) {   // n >= 1
+  return bits2f(bits0 + ((uint32_t)(n - 1) << kPiShift) + (1u << (kPiShift - 1)));
+}
+// one table lookup in two halves, so that the reads of independent lookups can be in flight together: the record's LDS offset
+// (x >= 0; *fail is set for a non-zero argument below the table's range or at / above its end), then the polynomial
+template <uint32_t BITS0, uint32_t BITS1>
+__device__ __forceinline__ uint32_t crtpi_tab_off(float x, bool* fail) {
+  const uint32_t xb = f2bits(x);
+  const uint32_t cl = max(xb, BITS0 - (1u << kPiShift));   // everything below the range: node 0
+  *fail = *fail || (xb - 1u) < (BITS0 - 1u) || xb >= BITS1 + (BITS1 == kPiA1 ? 1u : 0u);
+  return ((cl - (BITS0 - (1u << kPiShift))) >> (kPiShift - 4)) & ~15u;
+}
+__device__ __forceinline__ float crtpi_poly(float x, rcstrip2::v4f e) { return fma_(x, fma_(x, e.z, e.y), e.x); }
+
+// Tables of one power p over [bits0, bits1): phase 0 writes node n's polynomial (node 0: the exact code's value at 0; A's last
+// node: at 1.0), phase 1 measures (res[0] = largest relative error as float bits, res[1] = largest logarithmic slope).
+__global__ void __launch_bounds__(256) k_crtpi_tab(float p, uint32_t bits0, uint32_t bits1, int nodes, bool last_is_one, float widen, float4* tab,
+                                                  uint32_t* res, int phase) {
+  const int n = (int)blockIdx.y;
+  if (phase == 0) {
+    if (blockIdx.x || threadIdx.x) return;
+    if (n == 0) {
+      tab[0] = make_float4(pow_(0.0f, p), 0.0f, 0.0f, 0.0f);
+      return;
+    }
+    const bool one = last_is_one && n == nodes - 1;
+    const float x0 = one ? 1.0f : crtpi_node_mid(bits0, n);
+    const double T = (double)pow_(x0, p), X = (double)x0, P = (double)p;
+    const double g1 = P * pow(X, P - 1.0), g2 = 0.5 * P * (P - 1.0) * pow(X, P - 2.0);
+    tab[n] = one ? make_float4((float)T, 0.0f, 0.0f, 0.0f) : make_float4((float)(T - g1 * X + g2 * X * X), (float)(g1 - 2.0 * g2 * X), (float)g2, 0.0f);
+    return;
+  }
+  if (n == 0) return;
+  const bool one = last_is_one && n == nodes - 1;
+  const float4 e = tab[n];
+  const uint32_t lo0 = bits0 + ((uint32_t)(n - 1) << kPiShift), hi0 = one ? lo0 : lo0 + (1u << kPiShift) - 1u;
+  // the widened range, in float bit patterns (positive floats order like their bits)
+  const uint32_t lo = one ? lo0 : f2bits(bits2f(lo0) * (1.0f - widen)), hi = one ? hi0 : f2bits(bits2f(hi0) * (1.0f + widen));
+  uint32_t worst = 0u, slope = 0u;
+  for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i <= hi; i += gridDim.x * 256u) {
+    const float x = bits2f(i);
+    const float exact = pow_(x, p), tabv = fma_(x, fma_(x, e.z, e.y), e.x);
+    const double rel = fabs((double)tabv - (double)exact) / (double)exact;
+    worst = max(worst, f2bits(__double2float_ru(rel)));
+    const double ls = fabs((double)e.y + 2.0 * (double)e.z * (double)x) * (double)x / (double)exact;
+    slope = max(slope, f2bits(__double2float_ru(ls)));
+  }
+  if (worst) atomicMax(&res[0], worst);
+  if (slope) atomicMax(&res[1], slope);
+}
+
+__global__ void __launch_bounds__(256) k_crtpi_geometry(const PassLaunch L, uint32_t* cols, uint32_t* rows) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < L.out_w)
+    for (int side = 0; side < 2; ++side) {
+      const float tcx = vary(L.plane[0], i, 0, side == 0);
+      const float u = linear_coord<WRAP_BORDER>(tcx, L.in.w);
+      const float x0f = __builtin_floorf(u);
+      cols[(PI_X0 * 2 + side) * L.out_w + i] = (uint32_t)(int)x0f;
+      cols[(PI_WX * 2 + side) * L.out_w + i] = f2bits(u - x0f);
+    }
+  if (i < L.out_h)
+    for (int side = 0; side < 2; ++side) {
+      const CrtPiRow r = crtpi_row(L, vary(L.plane[1], 0, i, side == 0));
+      const float w = linear_coord<WRAP_BORDER>(r.v, L.in.h);
+      const float y0f = __builtin_floorf(w);
+      uint32_t* o = rows + ((size_t)i * 2 + side) * PI_ROW_FIELDS;
+      o[PI_Y0] = (uint32_t)(int)y0f;
+      o[PI_WY] = f2bits(w - y0f);
+      o[PI_S] = f2bits(r.s);
+      o[3] = 0u;
+    }
+}
+
+struct CrtPiTables {
+  uint32_t* cols = nullptr;
+  uint32_t* rows = nullptr;
+  float4* tab = nullptr;   // table A, then table B
+  float K = 0.0f;          // the certification constant above
+  bool usable = false;
+  void release() {
+    if (cols) (void)hipFree(cols);
+    if (rows) (void)hipFree(rows);
+    if (tab) (void)hipFree(tab);
+    *this = CrtPiTables();
+  }
+};
+
+__global__ void __launch_bounds__(kPiRows * 32) k_crt_pi_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows,
+                                                               const float4* __restrict__ tab, float K, int one_plane) {
+  using namespace rcstrip2;
+  extern __shared__ uint32_t rc_dyn_lds_[];
+  if ((uint32_t)(uintptr_t)(RC_AS3 uint32_t*)rc_dyn_lds_ != 0u) __builtin_trap();   // the tables are addressed by absolute LDS offsets
+  for (int i = (int)threadIdx.x; i < kPiNodesA + kPiNodesB; i += (int)blockDim.x) reinterpret_cast<float4*>(rc_dyn_lds_)[i] = tab[i];
+  __syncthreads();
+  const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), waves = (int)blockDim.x >> 6;
+  const rcstrip::StripGrid<kPiRows> G(L.out_w, L.out_h, L.n_frames);
+  const int W = G.W, H = G.H, Win = L.in.w, Hin = L.in.h;
+  const float mask_b = L.params[2];
+  uint32_t* fix_count = static_cast<uint32_t*>(L.scratch);
+  uint32_t* fix_list = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.scratch) + kPiFixHeader);
+  uint32_t* my_list = rc_dyn_lds_ + kPiLdsBytes / 4 + wave * kPiWaveList;   // this wave's uncertain pixels, not yet in the fix list
+  uint32_t n_listed = 0u;                                                    // (wave-uniform)
+  auto flush = [&]() __attribute__((always_inline)) {
+    n_listed = __builtin_amdgcn_readfirstlane(n_listed);
+    if (n_listed == 0u) return;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS stores, in order
+    uint32_t base = 0u;
+    if (lane == 0) base = atomicAdd(fix_count, n_listed);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (uint32_t i = (uint32_t)lane; i < n_listed; i += 64u) fix_list[base + i] = my_list[i];
+    asm volatile("" ::: "memory");
+    n_listed = __builtin_amdgcn_readfirstlane(0u);
+  };
+  SrgbLds nolds;   // (the exact form of this configuration reads no sRGB table)
+  for (int strip = (int)blockIdx.x * waves + wave; strip < G.total; strip += (int)gridDim.x * waves) {
+    int z, xw, ys;
+    G.locate(strip, &z, &xw, &ys);
+    const int x = xw + lane;
+    if (x >= W) continue;
+    const int xmax = min(xw + 63, W - 1), ymax = min(ys + kPiRows - 1, H - 1);
+    const bool all_lo = rcd::lower_tri(xw, ymax, W, H), all_up = !rcd::lower_tri(xmax, ys, W, H);
+    // (one_plane: both triangles carry the same plane equations - llvmpipe's rectangle path for plain RGBA8 targets - and the
+    // tables' two sides are equal)
+    if (!one_plane && !all_lo && !all_up) {   // the quad's diagonal crosses this strip: per-pixel form
+      for (int y = ys; y <= ymax; ++y) crtpi_pixel<FMT_RGBX8, 1, WRAP_BORDER, FMT_RGBA8, false>(L, &nolds, x, y, z, rcd::lower_tri(x, y, W, H));
+      continue;
+    }
+    const int side = (one_plane || all_lo) ? 0 : 1;
+    const int x0 = (int)cols[(PI_X0 * 2 + side) * W + x];
+    const float wx = bits2f(cols[(PI_WX * 2 + side) * W + x]);
+    // clamp_to_border: a texel outside the texture reads 0 - fetched from a clamped address and masked
+    const uint32_t ka = (x0 >= 0 && x0 < Win) ? 0xffffffffu : 0u, kb = (x0 + 1 >= 0 && x0 + 1 < Win) ? 0xffffffffu : 0u;
+    const int xa = clampi(x0, 0, Win - 1) * 4, xb = clampi(x0 + 1, 0, Win - 1) * 4;
+    const bool first = crtpi_mask_first(x);
+    const float mr = first ? mask_b : 1.0f, mg = first ? 1.0f : mask_b;   // (blue takes red's)
+    const __amdgpu_buffer_rsrc_t r_in = frame_rsrc(frame_ptr(L.in, z), Win, Hin);
+    const __amdgpu_buffer_rsrc_t r_out = frame_rsrc(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z, W, H);
+    const __amdgpu_buffer_rsrc_t r_rows = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(rows), 0, H * 2 * PI_ROW_FIELDS * 4, 0x00020000);
+    auto fetch = [&](int r, uint32_t* ta, uint32_t* tb) __attribute__((always_inline)) {
+      const int ro = clampi(r, 0, Hin - 1) * Win * 4;
+      *ta = __builtin_amdgcn_raw_buffer_load_b32(r_in, xa, ro, 0);
+      *tb = __builtin_amdgcn_raw_buffer_load_b32(r_in, xb, ro, 0);
+    };
+    // the sampler's horizontal lerp of source row r (texels already fetched), three channels; a row outside the texture reads 0
+    auto hfilter = [&](int r, uint32_t ta, uint32_t tb, float* h) __attribute__((always_inline)) {
+      const bool in = r >= 0 && r < Hin;   // uniform
+      ta = in ? (ta & ka) : 0u;
+      tb = in ? (tb & kb) : 0u;
+      const float k = 1.0f / 255.0f;
+      const float a0 = (float)(ta & 255u) * k, b0 = (float)(tb & 255u) * k;
+      const float a1 = (float)((ta >> 8) & 255u) * k, b1 = (float)((tb >> 8) & 255u) * k;
+      const float a2 = (float)((ta >> 16) & 255u) * k, b2 = (float)((tb >> 16) & 255u) * k;
+      h[0] = fma_(wx, b0 - a0, a0);
+      h[1] = fma_(wx, b1 - a1, a1);
+      h[2] = fma_(wx, b2 - a2, a2);
+    };
+    // a row's record is wave-uniform but fetched through the vector path, two rows ahead, and made scalar when it is used (a
+    // scalar load in the loop would drain every outstanding LDS read with it)
+    auto row_fetch = [&](int y) __attribute__((always_inline)) {
+      return __builtin_amdgcn_raw_buffer_load_b128(r_rows, 0, (min(y, H - 1) * 2 + side) * PI_ROW_FIELDS * 4, 0);
+    };
+    // A regular software pipeline, no data-dependent control flow: the four texels of a target row's two source rows are fetched
+    // one step ahead of their use (neighbouring target rows share source rows - those second fetches hit the cache - but a row
+    // cache would put uniform branches around the loads, and the compiler then waits for each load where it is issued)
+    struct Rec {
+      int y0;
+      float wy, s;
+    };
+    auto rec_of = [&](v4u raw) __attribute__((always_inline)) {
+      return Rec{(int)__builtin_amdgcn_readfirstlane(raw.x), bits2f(__builtin_amdgcn_readfirstlane(raw.y)), bits2f(__builtin_amdgcn_readfirstlane(raw.z))};
+    };
+    Rec nxt = rec_of(row_fetch(ys));
+    v4u raw_nn = row_fetch(ys + 1);
+    uint32_t q[4];   // texels (x0, y0) (x0+1, y0) (x0, y0+1) (x0+1, y0+1) of the NEXT step's row, in flight
+    fetch(nxt.y0, &q[0], &q[1]);
+    fetch(nxt.y0 + 1, &q[2], &q[3]);
+    uint32_t failed = 0u;   // bit k: row ys + k of this column is not certain from the tables
+#pragma unroll 2
+    for (int k = 0; k < kPiRows; ++k) {
+      const int y = ys + k;
+      if (y >= H) break;
+      const Rec cur = nxt;
+      const float wy = cur.wy, s = cur.s;
+      float top[3], bot[3];
+      hfilter(cur.y0, q[0], q[1], top);
+      hfilter(cur.y0 + 1, q[2], q[3], bot);
+      nxt = rec_of(raw_nn);            // row y + 1, fetched a step ago
+      raw_nn = row_fetch(y + 2);
+      fetch(nxt.y0, &q[0], &q[1]);
+      fetch(nxt.y0 + 1, &q[2], &q[3]);
+      bool fail = false;
+      uint32_t px = 0xff000000u;
+      // the three channels side by side: three reads of table A in flight, then three of table B
+      float c[3], v[3];
+      v4f ea[3], eb[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        c[ch] = fma_(wy, bot[ch] - top[ch], top[ch]);
+        ea[ch] = lds_v4f(kPiLdsA + crtpi_tab_off<kPiA0, kPiA1>(c[ch], &fail));
+      }
+      asm volatile("" : "+v"(ea[0]), "+v"(ea[1]), "+v"(ea[2]));   // (all three reads issued before the first is waited for)
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        v[ch] = crtpi_poly(c[ch], ea[ch]) * s;
+        eb[ch] = lds_v4f(kPiLdsB + crtpi_tab_off<kPiB0, kPiB1>(v[ch], &fail));
+      }
+      asm volatile("" : "+v"(eb[0]), "+v"(eb[1]), "+v"(eb[2]));
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float yv = (crtpi_poly(v[ch], eb[ch]) * (ch == 1 ? mg : mr)) * 255.0f;
+        const float r = __builtin_rintf(yv);
+        fail = fail || !(__builtin_fabsf(yv - r) + K * yv < 0.5f);
+        px |= (uint32_t)__builtin_amdgcn_fmed3f(r, 0.0f, 255.0f) << (8 * ch);
+      }
+      if (!fail) __builtin_amdgcn_raw_buffer_store_b32(px, r_out, x * 4, y * W * 4, 0);
+      else failed |= 1u << k;
+    }
+    // the pixels the tables could not certify go to this wave's list in LDS (no atomics: positions from the ballot), which is
+    // flushed to the pass's fix list with ONE global atomic when it is about to overflow and when the wave is done.  (A global
+    // atomic per strip - the first version - cost 15 us per frame: every wave waited for the counter's round trip 8 times.)
+    while (true) {
+      const uint64_t any = __builtin_amdgcn_ballot_w64(failed != 0u);
+      if (any == 0ull) break;
+      const uint32_t n = (uint32_t)__builtin_popcountll(any);
+      if (__builtin_amdgcn_readfirstlane(n_listed) + n > (uint32_t)kPiWaveList) flush();
+      if (failed) {
+        const int kk = __builtin_ctz(failed);
+        failed &= failed - 1u;
+        const uint32_t pos = n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+        my_list[pos] = (uint32_t)((z * H + ys + kk) * W + x);
+      }
+      n_listed = __builtin_amdgcn_readfirstlane(n_listed + n);   // (kept scalar: lanes beyond the frame's right edge skip this code)
+    }
+  }
+  flush();
+}
+
+__global__ void __launch_bounds__(256) k_crt_pi_fix(const PassLaunch L) {
+  const uint32_t n = *static_cast<const uint32_t*>(L.scratch);
+  const uint32_t* list = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(L.scratch) + kPiFixHeader);
+  SrgbLds nolds;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const uint32_t id = list[i];
+    const int x = (int)(id % (uint32_t)L.out_w), t = (int)(id / (uint32_t)L.out_w), y = t % L.out_h, z = t / L.out_h;
+    crtpi_pixel<FMT_RGBX8, 1, WRAP_BORDER, FMT_RGBA8, false>(L, &nolds, x, y, z, rcd::lower_tri(x, y, L.out_w, L.out_h));
+  }
+}
+
+void buildCrtPiTables(const PassLaunch& L, hipStream_t s, CrtPiTables* T) {
+  const float in_gamma = L.params[6], inv_out_gamma = 1.0f / L.params[7], bloom = L.params[5];
+  uint32_t* res = nullptr;
+  bool ok = in_gamma >= 1.0f && in_gamma <= 5.0f && inv_out_gamma > 0.0f && inv_out_gamma <= 1.0f && bloom >= 0.0f && bloom <= 5.0f &&
+            hipMalloc(reinterpret_cast<void**>(&T->cols), (size_t)PI_COL_FIELDS * 2 * L.out_w * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&T->rows), (size_t)L.out_h * 2 * PI_ROW_FIELDS * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&T->tab), (size_t)(kPiNodesA + kPiNodesB) * sizeof(float4)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&res), 16) == hipSuccess && hipMemsetAsync(res, 0, 16, s) == hipSuccess;
+  uint32_t h[4] = {0, 0, 0, 0};
+  float4 zero[2];
+  if (ok) {
+    hipLaunchKernelGGL(k_crtpi_geometry, dim3((unsigned)((std::max(L.out_w, L.out_h) + 255) / 256)), dim3(256), 0, s, L, T->cols, T->rows);
+    float4* A = T->tab;
+    float4* B = T->tab + kPiNodesA;
+    hipLaunchKernelGGL(k_crtpi_tab, dim3(1, kPiNodesA), dim3(256), 0, s, in_gamma, kPiA0, kPiA1, kPiNodesA, true, 0.0f, A, res, 0);
+    hipLaunchKernelGGL(k_crtpi_tab, dim3(16, kPiNodesA), dim3(256), 0, s, in_gamma, kPiA0, kPiA1, kPiNodesA, true, 0.0f, A, res, 1);
+    hipLaunchKernelGGL(k_crtpi_tab, dim3(1, kPiNodesB), dim3(256), 0, s, inv_out_gamma, kPiB0, kPiB1, kPiNodesB, false, kPiWiden, B, res + 2, 0);
+    hipLaunchKernelGGL(k_crtpi_tab, dim3(16, kPiNodesB), dim3(256), 0, s, inv_out_gamma, kPiB0, kPiB1, kPiNodesB, false, kPiWiden, B, res + 2, 1);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h, res, 16, hipMemcpyDeviceToHost, s) == hipSuccess &&
+         hipMemcpyAsync(&zero[0], A, sizeof(float4), hipMemcpyDeviceToHost, s) == hipSuccess &&
+         hipMemcpyAsync(&zero[1], B, sizeof(float4), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  }
+  if (res) (void)hipFree(res);
+  if (ok) {
+    const double RA = (double)bits2f(h[0]), RB = (double)bits2f(h[2]), DB = (double)bits2f(h[3]);
+    const double eps = 1.0 / 8388608.0;   // 2^-23
+    const double K = 1.001 * (RB + DB * (RA + eps) + 2.0 * eps);
+    // the derivation needs v within the widened range of the node v' selects, and the exact code's value at 0 to be 0 for both pows
+    ok = RA + eps < (double)kPiWiden * 0.5 && K < 1e-4 && zero[0].x == 0.0f && zero[1].x == 0.0f;
+    T->K = (float)K * 1.0000002f;
+  }
+  if (!ok) {
+    T->release();
+    return;
+  }
+  T->usable = true;
+}
+
+}  // namespace
+
+namespace rck {
+
+hipError_t launch_crt_pi(const PassLaunch& L, hipStream_t s) {
+  // the shipped preset's configuration (crt/crt-pi.glslp: linear, clamp_to_border, RGBA8 out, on the RGB source frame)
+  if (L.in.fmt == FMT_RGBX8 && L.in.linear && L.in.wrap == WRAP_BORDER && L.in.n_levels <= 1 && L.out_fmt == FMT_RGBA8) {
+    if (!(L.flags & RC_FLAG_GENERAL_ONLY) && L.scratch && rcstrip::separable(L, 0, 1) && (uint64_t)L.out_w * L.out_h * L.n_frames < (1ull << 32)) {
+      static std::mutex mu;
+      static std::map<rcstrip::GeoKey, rcstrip::GeoCached<CrtPiTables>> cache;
+      if (const CrtPiTables* T = rcstrip::geo_tables<CrtPiTables>(L, s, mu, cache, buildCrtPiTables)) {
+        if (hipMemsetAsync(L.scratch, 0, kPiFixHeader, s) != hipSuccess) return hipGetLastError();
+        auto same = [](const Plane& p) { return p.a0_lo == p.a0_up && p.dx_lo == p.dx_up && p.dy_lo == p.dy_up; };
+        const bool one_plane = same(L.plane[0]) && same(L.plane[1]);
+        const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kPiRows - 1) / kPiRows) * L.n_frames;
+        const int waves = 8;
+        const long blocks = std::min<long>((strips + waves - 1) / waves, 256L * 4);
+        hipLaunchKernelGGL(k_crt_pi_strip, dim3((unsigned)std::max<long>(blocks, 1)), dim3(waves * 64), kPiLdsBytes + waves * kPiWaveList * 4, s, L, T->cols, T->rows, T->tab, T->K,
+                           one_plane ? 1 : 0);
+        hipLaunchKernelGGL(k_crt_pi_fix, dim3(256), dim3(256), 0, s, L);
+        return hipGetLastError();
+      }
+    }
+    hipLaunchKernelGGL((k_crt_pi<FMT_RGBX8, 1, WRAP_BORDER, FMT_RGBA8, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  } else {
+    hipLaunchKernelGGL((k_crt_pi<0, 0, 0, 0, true>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace rck

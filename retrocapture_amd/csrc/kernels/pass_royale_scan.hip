@@ -463,10 +463,11 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
       const int z = strip / strips_per_frame, rem = strip - z * strips_per_frame;
       const int rs = rem / cgs, x = (rem - rs * cgs) * 64 + lane, ys = rs * kStripRows;
       if (x < W) {
-        const uint32_t* img = reinterpret_cast<const uint32_t*>(frame_ptr(L.in, z));
-        uint32_t* out = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z);
+        // wave-uniform frame bases as buffer resources: a lane's column offset is fixed, the row offset is a scalar
+        const __amdgpu_buffer_rsrc_t r_img = frame_rsrc(frame_ptr(L.in, z), W, H);
+        const __amdgpu_buffer_rsrc_t r_out = frame_rsrc(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z, W, H);
         const float wx = cols[x];
-        const int xr = x + 1 < W ? x + 1 : W - 1;
+        const int xo = x * 4, xro = (x + 1 < W ? x + 1 : W - 1) * 4;
         const int tri_x = (2 * x + 1) * H;
         // Window of source rows around the four target rows of a step (rows y0 - 2 .. y0 + 5, slot i = row y0 - 2 + i): per row
         // and channel the sampler's horizontal lerp `crow` exactly as the GL evaluates it, the difference to the next row's, the
@@ -495,9 +496,9 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
         auto fetch_rows = [&](int first) __attribute__((always_inline)) {
 #pragma unroll
           for (int i = 0; i < kStep; ++i) {
-            const int r = clampi(first + i, 0, H - 1);
-            nc[i] = img[r * W + x];
-            nr[i] = img[r * W + xr];
+            const int ro = clampi(first + i, 0, H - 1) * W * 4;
+            nc[i] = __builtin_amdgcn_raw_buffer_load_b32(r_img, xo, ro, 0);
+            nr[i] = __builtin_amdgcn_raw_buffer_load_b32(r_img, xro, ro, 0);
           }
         };
         fetch_rows(ys - 2);
@@ -550,7 +551,7 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
               RC_SCAN_CH(2)
 #undef RC_SCAN_CH
               if (fail == 0u) {
-                out[(size_t)y * W + x] = px;
+                __builtin_amdgcn_raw_buffer_store_b32(px, r_out, xo, y * W * 4, 0);
               } else {
                 const uint32_t slot = atomicAdd(cnt, 1u);
                 if (slot < (uint32_t)kFailCap) fails[slot] = (uint16_t)((wave << 9) | ((k0 + k) << 6) | lane);

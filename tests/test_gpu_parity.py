@@ -692,6 +692,39 @@ def test_inactive_engine_returns_input(rc_lib):
     e.shutdown()
 
 
+@pytest.mark.parametrize("src,vp,params", [((1080, 1920), (1920, 1080), {}), ((240, 320), (1920, 1080), {}), ((480, 640), (1003, 701), {}),
+                                           ((1080, 1920), (640, 360), {}),        # minification: source rows are skipped
+                                           ((224, 256), (1280, 960), {"INPUT_GAMMA": 1.8, "OUTPUT_GAMMA": 2.6, "BLOOM_FACTOR": 3.0, "MASK_BRIGHTNESS": 0.35}),
+                                           ((224, 256), (800, 600), {"SCANLINE_GAP_BRIGHTNESS": 0.0, "SCANLINE_WEIGHT": 15.0})])
+def test_crt_pi_table_form_equals_exact_form(src, vp, params, preset_tree, rc_lib):
+    """crt-pi's strip kernel takes its two gamma pows from tables with measured bounds and sends what it cannot certify to the exact
+    per-pixel form (kernels/pass_crt_pi.hip): every byte must equal the exact form's (rc_engine_set_general_kernels_only) - on noise,
+    on smooth ramps (colours between the byte values), on black / white edges (thin lerps against 0: the tables' low end) - and a
+    band of it the oracle's."""
+    from gpu_util import make_engine, run_engine
+    h, w = src
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    ramp = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx + yy) % 256)], -1).astype(np.uint8)
+    bars = np.where(((xx // 3 + yy // 5) % 2)[..., None] == 0, 0, np.array([255, 1, 254])).astype(np.uint8)
+    frames = np.stack([noise, ramp, bars])
+    e = make_engine(preset_tree["crt-pi"], vp[0], vp[1])
+    for k, v in params.items():
+        assert e.setShaderParameter(k, v)
+    fast = run_engine(e, frames).copy()
+    e.setGeneralKernelsOnly(True)
+    exact = run_engine(e, frames)
+    assert np.array_equal(fast, exact), "%d differing bytes" % int((fast != exact).sum())
+    e.shutdown()
+    from oracle_lib import Tex, run_pass_rows
+    t = Tex(np.concatenate([noise, np.full((h, w, 1), 255, np.uint8)], -1), "rgbx8", True, "clamp_to_border")
+    vals = [params.get(n, d) for n, d in chain_specs.SHADERS["crt/shaders/crt-pi.glsl"]["params"]]
+    y0 = vp[1] // 3
+    rows = run_pass_rows("crt_pi", t, vp[0], vp[1], y0, y0 + 24, params=vals)
+    assert np.array_equal(fast[0][y0:y0 + 24], rows)
+
+
 def test_full_size_properties(preset_tree, rc_lib):
     """BASELINE config 2 at full size (1920x1080 crt-pi), checked through properties that do
     not need the slow oracle: determinism, frame independence inside a batch, agreement of a
