@@ -19,8 +19,8 @@
 // 2^-8) and every distance the geometry's rows actually produce (a handful of values: k_scan_geometry), and records the
 // largest difference to the very expression the table kernel evaluates - about 2 * 10^9 exact evaluations per distance.
 // If the sRGB8 byte is the same over the whole interval [S - B, S + B] the byte is certain and is stored;
-// otherwise (about 0.6 % of the pixels on uniform noise) the pixel goes to a per-tile list and is recomputed
-// with the general form by otherwise idle lanes.  The result is bit-identical to the general kernel whenever
+// otherwise (about 0.6 % of the pixels on uniform noise) the pixel goes to its wave's list and from there to the pass's fix
+// list, which k_royale_scan_v_fix renders with the general form.  The result is bit-identical to the general kernel whenever
 // the bound holds - which it does by construction for every input the geometry can produce; tests/test_royale_fullsize.py
 // compares both forms on full-size noise and natural-like frames, and tests/test_royale_scan_table.py checks the
 // measured bound against the oracle's exact K (every float of a node's range for some nodes, random ones for all).
@@ -221,10 +221,9 @@ constexpr int kTabThreads = kTabWaves * 64;
 constexpr uint32_t kLdsA = 0u;                                        // float4 A[9][kNodes]: T, dK/dc, d2K/dc2 / 2, W
 constexpr uint32_t kLdsDec = kLdsA + 9u * kNodes * 16u;               // the sRGB decode table (256 floats)
 constexpr uint32_t kLdsEnc2 = kLdsDec + 1024u;                        // second form of the sRGB8 encode table (rc_device.h)
-constexpr int kFailCap = 4096;                                        // tile-local ids of uncertain pixels (more: straight to the global list)
-constexpr uint32_t kLdsFail = (kLdsEnc2 + kSrgb2Runs * 4u + 15u) & ~15u;   // uint16 fails[kFailCap]
-constexpr uint32_t kLdsCnt = kLdsFail + kFailCap * 2u;                // their count, and the base of the tile's range in the global list
-constexpr uint32_t kLdsTotalBytes = kLdsCnt + 16u;
+constexpr int kWaveList = 256;                                        // a wave's uncertain pixels, collected in LDS until it flushes them
+constexpr uint32_t kLdsFail = (kLdsEnc2 + kSrgb2Runs * 4u + 15u) & ~15u;   // uint32 list[kTabWaves][kWaveList]
+constexpr uint32_t kLdsTotalBytes = kLdsFail + (uint32_t)kTabWaves * kWaveList * 4u;
 static_assert(kLdsDec + 1020u < 65536u && 8u * kNodes * 16u + (kNodes - 1u) * 16u < 65536u, "immediate offsets of the LDS reads");
 // W of a record: dK/ddist with its low 11 mantissa bits replaced by the node's bound, a 5-bit exponent and a 6-bit mantissa
 // rounded up: (1 + m / 64) 2^(e - 40).  (The coefficient's truncation is part of what the bound is measured against.)
@@ -238,8 +237,8 @@ __host__ __device__ inline uint32_t scan_bound_code(float b) {   // smallest cod
 }
 constexpr int kMaxDists = 24;                                 // distinct row distances a geometry may have for the table form
 
-// Pixels whose byte the table form could not certify are collected per tile in LDS and appended (one global atomic
-// per tile) to a list in the pass's scratch buffer (PassLaunch::scratch: a counter, then entries
+// Pixels whose byte the table form could not certify are collected per wave in LDS and appended (one global atomic
+// per flush of a wave's list) to a list in the pass's scratch buffer (PassLaunch::scratch: a counter, then entries
 // (frame * H + y) * W + x); k_royale_scan_v_fix renders them with the general form.
 constexpr uint32_t kFixHeader = 256;  // bytes reserved for the counter (the registry sizes the scratch: header + 4 bytes per pixel, per frame)
 __device__ __forceinline__ uint32_t* fix_counter(const PassLaunch& L) { return static_cast<uint32_t*>(L.scratch); }
@@ -448,15 +447,27 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
   for (int i = tid; i < 9 * kNodes; i += kTabThreads) reinterpret_cast<float4*>(rc_dyn_lds_)[i] = gA[i];
   for (int i = tid; i < 256; i += kTabThreads) rc_dyn_lds_[kLdsDec / 4 + i] = f2bits(k_srgb_decode[i]);
   for (int i = tid; i < (int)kSrgb2Runs; i += kTabThreads) rc_dyn_lds_[kLdsEnc2 / 4 + i] = L.srgb_enc[kSrgbRuns + i];
-  uint16_t* fails = reinterpret_cast<uint16_t*>(rc_dyn_lds_ + kLdsFail / 4);
-  uint32_t* cnt = rc_dyn_lds_ + kLdsCnt / 4;
-  if (tid == 0) cnt[0] = 0u;
   __syncthreads();
   const int W = L.out_w, H = L.out_h;
   const int cgs = (W + 63) >> 6, rss = (H + kStripRows - 1) / kStripRows;
   const int strips_per_frame = cgs * rss, n_strips = strips_per_frame * L.n_frames;
   const int n_tiles = (n_strips + kTabWaves - 1) / kTabWaves;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // Pixels whose byte is not certain go to this wave's list in LDS - positions from a ballot, no atomics, no barriers - which
+  // the wave appends to the pass's global fix list with one global atomic when it is about to overflow and at the end.
+  uint32_t* my_list = rc_dyn_lds_ + kLdsFail / 4 + wave * kWaveList;
+  uint32_t n_listed = 0u;   // wave-uniform, kept scalar (lanes beyond the frame's right edge skip the code that updates it)
+  auto flush = [&]() __attribute__((always_inline)) {
+    n_listed = __builtin_amdgcn_readfirstlane(n_listed);
+    if (n_listed == 0u) return;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS stores, in order
+    uint32_t base = 0u;
+    if (lane == 0) base = atomicAdd(fix_counter(L), n_listed);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (uint32_t i = (uint32_t)lane; i < n_listed; i += 64u) fix_list(L)[base + i] = my_list[i];
+    asm volatile("" ::: "memory");
+    n_listed = __builtin_amdgcn_readfirstlane(0u);
+  };
   for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
     const int strip = tile * kTabWaves + wave;
     if (strip < n_strips) {
@@ -505,6 +516,7 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
 #pragma unroll
         for (int i = 0; i < kStep; ++i) decode_row(nc[i], nr[i], i);
         fetch_rows(ys + 2);
+        uint32_t failed = 0u;   // bit k: row ys + k of this column is not certain
 #pragma unroll 1
         for (int k0 = 0; k0 < kStripRows; k0 += kStep) {
           const int y0 = ys + k0;
@@ -550,13 +562,8 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
               RC_SCAN_CH(1)
               RC_SCAN_CH(2)
 #undef RC_SCAN_CH
-              if (fail == 0u) {
-                __builtin_amdgcn_raw_buffer_store_b32(px, r_out, xo, y * W * 4, 0);
-              } else {
-                const uint32_t slot = atomicAdd(cnt, 1u);
-                if (slot < (uint32_t)kFailCap) fails[slot] = (uint16_t)((wave << 9) | ((k0 + k) << 6) | lane);
-                else fix_list(L)[atomicAdd(fix_counter(L), 1u)] = (uint32_t)((z * H + y) * W + x);   // (a tile with more uncertain pixels than the local list holds)
-              }
+              if (fail == 0u) __builtin_amdgcn_raw_buffer_store_b32(px, r_out, xo, y * W * 4, 0);
+              else failed |= 1u << (k0 + k);
             }
           }
           // the last four rows of the window are the first four of the next step's
@@ -568,29 +575,23 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
               baddr[i][ch] = baddr[i + kStep][ch];
             }
         }
+        while (true) {
+          const uint64_t any = __builtin_amdgcn_ballot_w64(failed != 0u);
+          if (any == 0ull) break;
+          const uint32_t n = (uint32_t)__builtin_popcountll(any);
+          if (__builtin_amdgcn_readfirstlane(n_listed) + n > (uint32_t)kWaveList) flush();
+          if (failed) {
+            const int kk = __builtin_ctz(failed);
+            failed &= failed - 1u;
+            const uint32_t pos = n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+            my_list[pos] = (uint32_t)((z * H + ys + kk) * W + x);
+          }
+          n_listed = __builtin_amdgcn_readfirstlane(n_listed + n);
+        }
       }
-    }
-    // this tile's uncertain pixels: one range of the global list, reserved by one atomic
-    __syncthreads();
-    const uint32_t n_fail = min(cnt[0], (uint32_t)kFailCap);
-    // every wave has read the count before any wave moves on to the next tile, where it may append to the list again
-    __syncthreads();
-    if (n_fail) {   // uniform
-      if (tid == 0) cnt[1] = atomicAdd(fix_counter(L), n_fail);
-      __syncthreads();
-      const uint32_t base = cnt[1];
-      for (uint32_t i = (uint32_t)tid; i < n_fail; i += kTabThreads) {
-        const uint32_t id = fails[i];
-        const int strip2 = tile * kTabWaves + (int)(id >> 9);
-        const int z = strip2 / strips_per_frame, rem = strip2 - z * strips_per_frame;
-        const int rs = rem / cgs, x = (rem - rs * cgs) * 64 + (int)(id & 63u), y = rs * kStripRows + (int)((id >> 6) & 7u);
-        fix_list(L)[base + i] = (uint32_t)((z * H + y) * W + x);
-      }
-      __syncthreads();
-      if (tid == 0) cnt[0] = 0u;
-      __syncthreads();
     }
   }
+  flush();
 }
 
 // The listed pixels in the general form (k_royale_scan_v's arithmetic: four packed pairs and one scalar evaluation).
