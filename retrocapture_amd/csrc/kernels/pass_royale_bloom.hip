@@ -756,6 +756,11 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
             sa = sa && (tri_y <= tri_a) == (side == 0);
             sb = sb && (tri_y <= tri_b) == (side == 0);
           }
+          // Everything fetched ahead for the next step is waited for HERE, before this step's stores are issued: vmcnt counts
+          // loads and stores in one in-order queue, so a wait placed behind the stores (where the compiler puts the loop's
+          // register copies) would also wait for stores issued a few cycles earlier - a full memory round trip per step.
+          asm volatile("" : "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3]), "+v"(nia), "+v"(nib), "+v"(nja), "+v"(njb));
+          asm volatile("" : "+v"(nxt_raw.a), "+v"(nxt_raw.b), "+v"(hq[0]), "+v"(hq[1]), "+v"(hq[2]), "+v"(hq[3]));
           if (sa) __builtin_amdgcn_raw_buffer_store_b32(oa, r_out, xa * 4, y * W * 4, 0);
           if (sb) __builtin_amdgcn_raw_buffer_store_b32(ob, r_out, xb * 4, y * W * 4, 0);
         }
