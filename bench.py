@@ -551,6 +551,46 @@ def main():
                          "hbm_roofline_frac_whole_chain": vm / world * bytes_m / (HBM_PEAK_GBS * 1e9),
                          "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in profm],
                          "note": "rc_engine_set_undefined_varying_zero(1): what GL drivers that read 0 from an unwritten varying render"}
+    # ... and on frames with the statistics of video rather than of a random number generator (smooth gradients, edges, mild
+    # grain): uniform noise is the worst case for every table gather of the kernels (64 different bytes per wave access), so
+    # this is reported beside `value`, never instead of it.  Mask rendered (the mode real GL drivers produce), fewer steps.
+    natural = None
+    if key.startswith("crt-royale") and args.modes == "both" and world == 1:
+        yy = torch.arange(h, device="cuda", dtype=torch.float32).view(1, h, 1)
+        xx = torch.arange(w, device="cuda", dtype=torch.float32).view(1, 1, w)
+        ph = torch.arange(n_local, device="cuda", dtype=torch.float32).view(n_local, 1, 1)
+        base = torch.stack([128 + 100 * torch.sin(xx / 97.0 + ph * 0.3) * torch.cos(yy / 61.0),
+                            128 + 90 * torch.sin((xx + yy) / 143.0 + ph * 0.2),
+                            128 + 110 * torch.cos(yy / 53.0 - xx / 211.0 + ph * 0.1)], -1)
+        base = base + 40.0 * ((torch.floor(xx / 160.0) + torch.floor(yy / 120.0)) % 2.0).unsqueeze(-1)          # blocks: hard edges
+        base = base + torch.randint(-3, 4, (n_local, h, w, 3), device="cuda", generator=g).to(torch.float32)   # grain
+        nat = torch.empty((n_local, h, w, 4), dtype=torch.uint8, device="cuda")
+        nat[..., :3] = base.clamp_(0, 255).to(torch.uint8)
+        nat[..., 3] = 255
+        del base
+        saved = frames
+        frames = nat
+        e.setUndefinedVaryingZero(True)
+        n_steps = max(1, args.steps // 4)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        barrier()
+        dtn = time.perf_counter() - t0
+        e.setProfiling(True)
+        for _ in range(n_steps):
+            step()
+        profn = [e.passProfile(i) for i in range(e.passCount())]
+        e.setProfiling(False)
+        e.setUndefinedVaryingZero(False)
+        frames = saved
+        del nat
+        natural = {"value": aggregate([args.batch], n_steps, dtn), "unit": "frames/s", "steps": n_steps, "mask_mode": "rendered",
+                   "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in profn],
+                   "note": "synthetic frames with video-like statistics (gradients, block edges, +-3 grain); `value` stays on uniform noise"}
     ceiling = copy_ceiling(torch)
     out = {
         # BASELINE.json's metric for the default workload; other --workload values are side measurements
@@ -579,6 +619,8 @@ def main():
     }
     if mask_rendered is not None:
         out["mask_rendered"] = mask_rendered
+    if natural is not None:
+        out["natural_frames"] = natural
     if args.io and rank == 0:
         out["io"] = io_measurements(e, w, h, args.batch, max(3, args.steps))
     if rank == 0:
