@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
                 }                                                                                                             \
                 const float q2 = scan_tab_eval<6 + ch>(c2, baddr[w2][ch], dist, &bs);                             \
                 const float s = ((q0 + q1) + q2) * 0.5f;                                                                      \
-                const float b = fma_(5e-7f, s, 0.5f * bs);                                                                    \
+                const float b = fma_(2.5e-7f, s, 0.5f * bs);   /* the sums' roundings: at most four of 2^-24 (2 s) each, halved */   \
                 bool ok;                                                                                                      \
                 const uint32_t byte = srgb8_interval(s, b, &ok);                                                              \
                 fail |= ok ? 0u : 1u;                                                                                         \
