@@ -1051,9 +1051,9 @@ struct LastTables {
 // Away from the border the pass stores unorm8(G(c)) for the sampled colour c, G(c) = exp2(log2(c) / lcd_gamma) in the GL's
 // polynomials (~40 float operations, three per pixel).  G is smooth, so the strip kernel evaluates it from a table of
 // log-spaced nodes: 32 per octave (the top five mantissa bits of c select the node, its colour c0 is the bucket's midpoint)
-// from 2^-20 - below which G(c) * 255 < 0.47 and the byte is 0 for certain - up to 1.  Per node: T = G(c0) (the float the
-// exact code computes), slope and half curvature from the closed form, and a bound R on |G(c) - fma(d, fma(d, G''/2, G'), T)|,
-// d = c - c0, that k_last_gamma_err MEASURES over EVERY float of the bucket (2^18 floats; 168 M exact evaluations per
+// from 2^-20 - below which G(c) * 255 < 0.47 and the byte is 0 for certain - up to 1.  Per node: the quadratic through T = G(c0)
+// (the float the exact code computes) with slope and half curvature from the closed form, written in the colour itself,
+// a0 + c (a1 + c a2), and a bound R on |G(c) - fma(c, fma(c, a2, a1), a0)| that k_last_gamma_err MEASURES over EVERY float of the bucket (2^18 floats; 168 M exact evaluations per
 // table) against the very expression the strip kernel evaluates - a bound by exhaustion, not by sampling: third-order
 // remainder and float noise together stay below 4e-7 G.  The kernel stores the byte when the whole interval rounds to one byte
 // (x -> rint(clamp(x) * 255) is monotone) and re-renders the few other pixels with the exact per-pixel code.
@@ -1069,15 +1069,21 @@ __global__ void __launch_bounds__(256) k_last_gamma_err(float inv_gamma, float4*
   const int n = (int)blockIdx.y;
   const float c0 = last_node_colour(n);
   if (phase == 0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) tab[n].x = last_gamma(c0, inv_gamma);
+    // the node's quadratic written in the colour itself (the strip kernel then needs neither the node colour nor a subtraction):
+    // a0 + c (a1 + c a2) with a2 = G''/2, a1 = G' - 2 a2 c0, a0 = T - G' c0 + a2 c0^2 from the host's G', G''/2 (tab[n].y, .z)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const double T = (double)last_gamma(c0, inv_gamma), X = (double)c0, g1 = (double)tab[n].y, g2 = (double)tab[n].z;
+      tab[n].x = (float)(T - g1 * X + g2 * X * X);
+      tab[n].y = (float)(g1 - 2.0 * g2 * X);
+    }
     return;
   }
   const float4 e = tab[n];
   const uint32_t lo = kLastTabBits0 + ((uint32_t)n << kLastTabShift), hi = n == kLastTabNodes - 1 ? lo : lo + (1u << kLastTabShift) - 1u;
   uint32_t worst = 0u;
   for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i <= hi; i += gridDim.x * 256u) {
-    const float c = bits2f(i), delta = c - c0;
-    const double err = fabs((double)last_gamma(c, inv_gamma) - (double)fma_(delta, fma_(delta, e.z, e.y), e.x));
+    const float c = bits2f(i);
+    const double err = fabs((double)last_gamma(c, inv_gamma) - (double)fma_(c, fma_(c, e.z, e.y), e.x));
     worst = max(worst, f2bits(__double2float_ru(err)));
   }
   if (worst) atomicMax(reinterpret_cast<uint32_t*>(&tab[n].w), worst);   // non-negative floats order like their bits
@@ -1134,10 +1140,9 @@ __device__ __forceinline__ uint32_t last_gamma_byte(float c, bool* fail) {
   // colours below the table's first node store 0 like that node's first colour does (G is monotone, G(2^-20) * 255 < 0.47)
   const uint32_t cb = max(f2bits(c), kLastTabBits0);
   const uint32_t off = ((cb - kLastTabBits0) >> (kLastTabShift - 4)) & ~15u;
-  const float c0 = bits2f(cb == 0x3f800000u ? cb : ((cb & ~((1u << kLastTabShift) - 1u)) | (1u << (kLastTabShift - 1))));
   const last_v4f e = *reinterpret_cast<const RC_AS3 last_v4f*>((uintptr_t)(kLastLdsTab + off));
-  const float delta = bits2f(cb) - c0;
-  const float y = fma_(delta, fma_(delta, e.z, e.y), e.x) * 255.0f;
+  const float cc = bits2f(cb);
+  const float y = fma_(cc, fma_(cc, e.z, e.y), e.x) * 255.0f;
   const float r = __builtin_rintf(y);
   *fail = *fail || !(__builtin_fabsf(y - r) + fma_(e.w, 255.0f, 3.1e-5f) < 0.5f);
   return (uint32_t)__builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);
