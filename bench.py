@@ -100,7 +100,7 @@ def cpu_baseline(key, w, h, vw, vh, tree, budget_s=15.0):
                       % (n, cores, dt)}
 
 
-PMC_FRAMES_PER_LAUNCH = 32.0   # launch shape of the newest profiles/r*_royale_pmc.csv (profiles/collect.sh: the engine's default chunk)
+PMC_FRAMES_PER_LAUNCH = 64.0   # launch shape of the newest profiles/r*_royale_pmc.csv (profiles/collect.sh: the engine's default chunk)
 
 
 def pmc_traffic(kernel_name, frames_per_launch):

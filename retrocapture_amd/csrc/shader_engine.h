@@ -180,7 +180,7 @@ class ShaderEngine {
   float m_frameCount = 0.0f;
   float m_time = 0.0f;
   bool m_inputLinear = false;
-  uint32_t m_chunk = 32;   // frames per launch: per-launch costs (table loads, ramp and tail of the one-workgroup-per-CU kernels) are 15 % of crt-royale at 8
+  uint32_t m_chunk = 64;   // frames per launch: per-launch costs (table loads, ramp and tail of the one-workgroup-per-CU kernels) are 25 % of crt-royale at 8, 5 % at 32
   uint32_t m_lastChunkFrames = 0;
   uint32_t m_lastChunkFirst = 0;
   bool m_singleShader = false;
