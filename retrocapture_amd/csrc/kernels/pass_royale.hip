@@ -515,7 +515,6 @@ __global__ void __launch_bounds__(512) k_royale_scan_h_strip2(const PassLaunch L
   using namespace rcstrip2;
   extern __shared__ uint32_t rc_dyn_lds_[];
   strip2_load_tables(rc_dyn_lds_, L, true);
-  const uint32_t dcopy = strip2_lane_copy();   // this lane's copy of the decode table
   const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int W = L.out_w, H = L.out_h;
   const int bands = (W + 127) >> 7, rss = (H + kShRows - 1) / kShRows, per_frame = bands * rss, total = per_frame * L.n_frames;
@@ -560,17 +559,17 @@ __global__ void __launch_bounds__(512) k_royale_scan_h_strip2(const PassLaunch L
       };
       auto hfilter = [&](const uint32_t* q, v2f* ha, v2f* hb) __attribute__((always_inline)) {
         {
-          const v2f dl = {dec_byte<0>(q[0], dcopy), dec_byte<0>(q[3], dcopy)}, dm = {dec_byte<0>(q[1], dcopy), dec_byte<0>(q[4], dcopy)}, dr = {dec_byte<0>(q[2], dcopy), dec_byte<0>(q[5], dcopy)};
+          const v2f dl = {dec_byte<0>(q[0]), dec_byte<0>(q[3])}, dm = {dec_byte<0>(q[1]), dec_byte<0>(q[4])}, dr = {dec_byte<0>(q[2]), dec_byte<0>(q[5])};
           ha[0] = fma2(wxa[0], dm - dl, dl);
           hb[0] = fma2(wxb[0], dr - dm, dm);
         }
         {
-          const v2f dl = {dec_byte<1>(q[0], dcopy), dec_byte<1>(q[3], dcopy)}, dm = {dec_byte<1>(q[1], dcopy), dec_byte<1>(q[4], dcopy)}, dr = {dec_byte<1>(q[2], dcopy), dec_byte<1>(q[5], dcopy)};
+          const v2f dl = {dec_byte<1>(q[0]), dec_byte<1>(q[3])}, dm = {dec_byte<1>(q[1]), dec_byte<1>(q[4])}, dr = {dec_byte<1>(q[2]), dec_byte<1>(q[5])};
           ha[1] = fma2(wxa[1], dm - dl, dl);
           hb[1] = fma2(wxb[1], dr - dm, dm);
         }
         {
-          const v2f dl = {dec_byte<2>(q[0], dcopy), dec_byte<2>(q[3], dcopy)}, dm = {dec_byte<2>(q[1], dcopy), dec_byte<2>(q[4], dcopy)}, dr = {dec_byte<2>(q[2], dcopy), dec_byte<2>(q[5], dcopy)};
+          const v2f dl = {dec_byte<2>(q[0]), dec_byte<2>(q[3])}, dm = {dec_byte<2>(q[1]), dec_byte<2>(q[4])}, dr = {dec_byte<2>(q[2]), dec_byte<2>(q[5])};
           ha[2] = fma2(wxa[2], dm - dl, dl);
           hb[2] = fma2(wxb[2], dr - dm, dm);
         }
@@ -863,7 +862,6 @@ __global__ void __launch_bounds__(512) k_royale_brightpass_strip2(const PassLaun
   using namespace rcstrip2;
   extern __shared__ uint32_t rc_dyn_lds_[];
   strip2_load_tables(rc_dyn_lds_, L, true);
-  const uint32_t dcopy = strip2_lane_copy();   // this lane's copy of the decode table
   const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int W = L.out_w, H = L.out_h;
   const int bands = (W + 127) >> 7, rss = (H + kBpRows - 1) / kBpRows, per_frame = bands * rss, total = per_frame * L.n_frames;
@@ -892,9 +890,9 @@ __global__ void __launch_bounds__(512) k_royale_brightpass_strip2(const PassLaun
         const uint8_t* p = bimg + (size_t)(clampi(r, 0, blur.h - 1) * blur.w) * 4u;
         const uint32_t a0 = *reinterpret_cast<const uint32_t*>(p + ba0), a1 = *reinterpret_cast<const uint32_t*>(p + ba1);
         const uint32_t b0 = *reinterpret_cast<const uint32_t*>(p + bb0), b1 = *reinterpret_cast<const uint32_t*>(p + bb1);
-        const v2f l0 = {dec_byte<0>(a0, dcopy), dec_byte<0>(b0, dcopy)}, r0 = {dec_byte<0>(a1, dcopy), dec_byte<0>(b1, dcopy)};
-        const v2f l1 = {dec_byte<1>(a0, dcopy), dec_byte<1>(b0, dcopy)}, r1 = {dec_byte<1>(a1, dcopy), dec_byte<1>(b1, dcopy)};
-        const v2f l2 = {dec_byte<2>(a0, dcopy), dec_byte<2>(b0, dcopy)}, r2 = {dec_byte<2>(a1, dcopy), dec_byte<2>(b1, dcopy)};
+        const v2f l0 = {dec_byte<0>(a0), dec_byte<0>(b0)}, r0 = {dec_byte<0>(a1), dec_byte<0>(b1)};
+        const v2f l1 = {dec_byte<1>(a0), dec_byte<1>(b0)}, r1 = {dec_byte<1>(a1), dec_byte<1>(b1)};
+        const v2f l2 = {dec_byte<2>(a0), dec_byte<2>(b0)}, r2 = {dec_byte<2>(a1), dec_byte<2>(b1)};
         h[0] = fma2(bwx, r0 - l0, l0);
         h[1] = fma2(bwx, r1 - l1, l1);
         h[2] = fma2(bwx, r2 - l2, l2);
@@ -933,9 +931,9 @@ __global__ void __launch_bounds__(512) k_royale_brightpass_strip2(const PassLaun
             have = by0;
           }
           v2f o[3];
-          o[0] = brightpass_pair(v2f{dec_byte<0>(ia, dcopy), dec_byte<0>(ib, dcopy)}, fma2(splat2(bwy), hd[0], h0[0]), cw, mask_amplify);
-          o[1] = brightpass_pair(v2f{dec_byte<1>(ia, dcopy), dec_byte<1>(ib, dcopy)}, fma2(splat2(bwy), hd[1], h0[1]), cw, mask_amplify);
-          o[2] = brightpass_pair(v2f{dec_byte<2>(ia, dcopy), dec_byte<2>(ib, dcopy)}, fma2(splat2(bwy), hd[2], h0[2]), cw, mask_amplify);
+          o[0] = brightpass_pair(v2f{dec_byte<0>(ia), dec_byte<0>(ib)}, fma2(splat2(bwy), hd[0], h0[0]), cw, mask_amplify);
+          o[1] = brightpass_pair(v2f{dec_byte<1>(ia), dec_byte<1>(ib)}, fma2(splat2(bwy), hd[1], h0[1]), cw, mask_amplify);
+          o[2] = brightpass_pair(v2f{dec_byte<2>(ia), dec_byte<2>(ib)}, fma2(splat2(bwy), hd[2], h0[2]), cw, mask_amplify);
           srgb8_pack2(o, &pa, &pb);
         }
         bool sa = live_a, sb = live_b;

@@ -185,7 +185,6 @@ template <int PATTERN>
 __global__ void __launch_bounds__(kBv2Waves * 64) k_royale_bloom_v_strip2(const PassLaunch L) {
   extern __shared__ uint32_t rc_dyn_lds_[];
   strip2_load_tables(rc_dyn_lds_, L, true);
-  const uint32_t dcopy = strip2_lane_copy();   // this lane's copy of the decode table
   constexpr int o12 = 1 + ((PATTERN >> 0) & 1), o34 = 3 + ((PATTERN >> 1) & 1), o56 = 5 + ((PATTERN >> 2) & 1), o78 = 7 + ((PATTERN >> 3) & 1);
   const float* P = L.params;
   const float w78 = P[RPG_W78], w56 = P[RPG_W56], w34 = P[RPG_W34], w12 = P[RPG_W12], si = P[RPG_SUM_INV];
@@ -220,9 +219,9 @@ __global__ void __launch_bounds__(kBv2Waves * 64) k_royale_bloom_v_strip2(const 
     auto decode4 = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < kBv2Step; ++i) {
-        win[slot + i][0] = v2f{dec_byte<0>(na[i], dcopy), dec_byte<0>(nb[i], dcopy)};
-        win[slot + i][1] = v2f{dec_byte<1>(na[i], dcopy), dec_byte<1>(nb[i], dcopy)};
-        win[slot + i][2] = v2f{dec_byte<2>(na[i], dcopy), dec_byte<2>(nb[i], dcopy)};
+        win[slot + i][0] = v2f{dec_byte<0>(na[i]), dec_byte<0>(nb[i])};
+        win[slot + i][1] = v2f{dec_byte<1>(na[i]), dec_byte<1>(nb[i])};
+        win[slot + i][2] = v2f{dec_byte<2>(na[i]), dec_byte<2>(nb[i])};
       }
     };
     // prime: rows y_first - 8 .. y_first + 7 into slots 4 .. 19 (they move down by four at the top of the first step)
@@ -432,17 +431,17 @@ __device__ __forceinline__ uint32_t bh_srgb8(float x) { return srgb8_lds(x); }
 
 // One source row of this lane's staged column (its texel in group A and in group B) into its ring entry: decode, difference
 // to the next staged column, one 16-byte store per channel.
-__device__ __forceinline__ void bh_stage_entry(uint32_t entry, uint32_t ta, uint32_t tb, uint32_t dcopy) {
+__device__ __forceinline__ void bh_stage_entry(uint32_t entry, uint32_t ta, uint32_t tb) {
   {
-    const float a = dec_byte<0>(ta, dcopy), b = dec_byte<0>(tb, dcopy);
+    const float a = dec_byte<0>(ta), b = dec_byte<0>(tb);
     lds_put_v4f(entry, v4f{a, b, next_lane_dpp(a) - a, next_lane_dpp(b) - b});
   }
   {
-    const float a = dec_byte<1>(ta, dcopy), b = dec_byte<1>(tb, dcopy);
+    const float a = dec_byte<1>(ta), b = dec_byte<1>(tb);
     lds_put_v4f(entry + 16, v4f{a, b, next_lane_dpp(a) - a, next_lane_dpp(b) - b});
   }
   {
-    const float a = dec_byte<2>(ta, dcopy), b = dec_byte<2>(tb, dcopy);
+    const float a = dec_byte<2>(ta), b = dec_byte<2>(tb);
     lds_put_v4f(entry + 32, v4f{a, b, next_lane_dpp(a) - a, next_lane_dpp(b) - b});
   }
 }
@@ -534,7 +533,6 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
                                                                           const uint32_t* __restrict__ rows, const uint32_t* __restrict__ runs) {
   extern __shared__ uint32_t rc_dyn_lds_[];
   strip2_load_tables(rc_dyn_lds_, L, true);
-  const uint32_t dcopy = strip2_lane_copy();   // this lane's copy of the decode table
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t ring = kBhLdsUser + (uint32_t)(wave * kBhWaveDwords) * 4u;   // LDS offset of this wave's two row slots
@@ -603,9 +601,9 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
       q[3] = *reinterpret_cast<const uint32_t*>(p + hal_b1);
     };
     auto hal_filter = [&](const uint32_t* q, v2f* h) __attribute__((always_inline)) {   // the sampler's horizontal lerp, both pixels
-      const v2f l0 = {dec_byte<0>(q[0], dcopy), dec_byte<0>(q[2], dcopy)}, r0 = {dec_byte<0>(q[1], dcopy), dec_byte<0>(q[3], dcopy)};
-      const v2f l1 = {dec_byte<1>(q[0], dcopy), dec_byte<1>(q[2], dcopy)}, r1 = {dec_byte<1>(q[1], dcopy), dec_byte<1>(q[3], dcopy)};
-      const v2f l2 = {dec_byte<2>(q[0], dcopy), dec_byte<2>(q[2], dcopy)}, r2 = {dec_byte<2>(q[1], dcopy), dec_byte<2>(q[3], dcopy)};
+      const v2f l0 = {dec_byte<0>(q[0]), dec_byte<0>(q[2])}, r0 = {dec_byte<0>(q[1]), dec_byte<0>(q[3])};
+      const v2f l1 = {dec_byte<1>(q[0]), dec_byte<1>(q[2])}, r1 = {dec_byte<1>(q[1]), dec_byte<1>(q[3])};
+      const v2f l2 = {dec_byte<2>(q[0]), dec_byte<2>(q[2])}, r2 = {dec_byte<2>(q[1]), dec_byte<2>(q[3])};
       h[0] = fma2(hal_w, r0 - l0, l0);
       h[1] = fma2(hal_w, r1 - l1, l1);
       h[2] = fma2(hal_w, r2 - l2, l2);
@@ -684,8 +682,8 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
               st_q = r;
             }
             const uint32_t slot = (r & 1) ? (uint32_t)kBhSlotBytes : 0u;
-            bh_stage_entry(e_main + slot, q0[0], q0[1], dcopy);
-            if (lane < kBhSeg - 63) bh_stage_entry(e_extra + slot, q0[2], q0[3], dcopy);
+            bh_stage_entry(e_main + slot, q0[0], q0[1]);
+            if (lane < kBhSeg - 63) bh_stage_entry(e_extra + slot, q0[2], q0[3]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) q0[i] = q1[i];
             fetch(r + 2, q1);
@@ -727,7 +725,7 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
           uint32_t oa = 0xff000000u, ob = 0xff000000u;
           {
             const v2f bl = s[0] * si;
-            const v2f dimpass = v2f{dec_byte<0>(ia, dcopy), dec_byte<0>(ib, dcopy)} - v2f{dec_byte<0>(ja, dcopy), dec_byte<0>(jb, dcopy)};
+            const v2f dimpass = v2f{dec_byte<0>(ia), dec_byte<0>(ib)} - v2f{dec_byte<0>(ja), dec_byte<0>(jb)};
             const v2f hal = fma2(v2f{ra.hal_wy, ra.hal_wy}, hld[0], hl0[0]);
             const v2f o = (dimpass + bl) * c_main + hal * 0.075f;
             oa |= bh_srgb8(o.x);
@@ -735,7 +733,7 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
           }
           {
             const v2f bl = s[1] * si;
-            const v2f dimpass = v2f{dec_byte<1>(ia, dcopy), dec_byte<1>(ib, dcopy)} - v2f{dec_byte<1>(ja, dcopy), dec_byte<1>(jb, dcopy)};
+            const v2f dimpass = v2f{dec_byte<1>(ia), dec_byte<1>(ib)} - v2f{dec_byte<1>(ja), dec_byte<1>(jb)};
             const v2f hal = fma2(v2f{ra.hal_wy, ra.hal_wy}, hld[1], hl0[1]);
             const v2f o = (dimpass + bl) * c_main + hal * 0.075f;
             oa |= bh_srgb8(o.x) << 8;
@@ -743,7 +741,7 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
           }
           {
             const v2f bl = s[2] * si;
-            const v2f dimpass = v2f{dec_byte<2>(ia, dcopy), dec_byte<2>(ib, dcopy)} - v2f{dec_byte<2>(ja, dcopy), dec_byte<2>(jb, dcopy)};
+            const v2f dimpass = v2f{dec_byte<2>(ia), dec_byte<2>(ib)} - v2f{dec_byte<2>(ja), dec_byte<2>(jb)};
             const v2f hal = fma2(v2f{ra.hal_wy, ra.hal_wy}, hld[2], hl0[2]);
             const v2f o = (dimpass + bl) * c_main + hal * 0.075f;
             oa |= bh_srgb8(o.x) << 16;

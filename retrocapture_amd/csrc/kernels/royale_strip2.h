@@ -20,19 +20,16 @@ __device__ __forceinline__ float lds_f32(uint32_t off) { return *reinterpret_cas
 __device__ __forceinline__ uint32_t lds_u32(uint32_t off) { return *reinterpret_cast<const RC_AS3 uint32_t*>((uintptr_t)off); }
 __device__ __forceinline__ v4f lds_v4f(uint32_t off) { return *reinterpret_cast<const RC_AS3 v4f*>((uintptr_t)off); }
 __device__ __forceinline__ void lds_put_v4f(uint32_t off, v4f v) { *reinterpret_cast<RC_AS3 v4f*>((uintptr_t)off) = v; }
-// The decode table can be kept in 2^kDecCopiesLog2 copies, entry (byte, copy) at (byte << (2 + kDecCopiesLog2)) + copy * 4, a lane
-// reading copy (lane & (copies - 1)).  Measured at 1080p (profiles/dev_pass_check.py, round 3): 8 copies made P7 and P8 SLOWER
-// (5.4 -> 5.9 and 4.3 -> 5.9 us/frame; mask 11.7 -> 12.8, 8.9 -> 11.5) - neighbouring lanes of an image row hold equal or close
-// bytes, which a single table serves by broadcast / adjacent banks and a replicated one spreads onto colliding banks - so ONE copy.
-constexpr int kDecCopiesLog2 = 0;
-constexpr uint32_t kStrip2LdsDec = 0u, kStrip2LdsEnc = 1024u << kDecCopiesLog2;
+// (Replicating the decode table against gather bank conflicts was measured and rejected: 8 copies made P7 / P8 slower -
+// neighbouring lanes of an image row hold equal or close bytes, which one table serves by broadcast or adjacent banks.)
+constexpr uint32_t kStrip2LdsDec = 0u, kStrip2LdsEnc = 1024u;
 constexpr uint32_t kStrip2LdsUser = ((kStrip2LdsEnc + kSrgb2Runs * 4u) + 15u) & ~15u;   // first free byte behind the two tables
 
 // Both tables into LDS (every thread of the workgroup calls this first); `with_encode`: the pass stores to an sRGB8 target.
 __device__ __forceinline__ void strip2_load_tables(uint32_t* dyn, const PassLaunch& L, bool with_encode) {
   if ((uint32_t)(uintptr_t)(RC_AS3 uint32_t*)dyn != 0u) __builtin_trap();
   const int nt = blockDim.x * blockDim.y, t0 = threadIdx.y * blockDim.x + threadIdx.x;
-  for (int i = t0; i < (256 << kDecCopiesLog2); i += nt) dyn[i] = f2bits(k_srgb_decode[i >> kDecCopiesLog2]);
+  for (int i = t0; i < 256; i += nt) dyn[i] = f2bits(k_srgb_decode[i]);
   if (with_encode)
     for (int i = t0; i < (int)kSrgb2Runs; i += nt) dyn[kStrip2LdsEnc / 4 + i] = L.srgb_enc[kSrgbRuns + i];
   __syncthreads();
@@ -50,13 +47,11 @@ __device__ __forceinline__ uint32_t byte_shl(uint32_t t) {
   asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_%3" : "=v"(r) : "v"(t), "n"(SH), "n"(N));
   return r;
 }
-// the sRGB-decoded value of byte N of texel t, from this lane's copy of the table (strip2_lane_copy)
-__device__ __forceinline__ uint32_t strip2_lane_copy() { return (threadIdx.x & ((1u << kDecCopiesLog2) - 1u)) << 2; }
+// the sRGB-decoded value of byte N of texel t (the decode table sits at LDS offset 0)
 template <int N>
-__device__ __forceinline__ float dec_byte(uint32_t t, uint32_t copy) { return lds_f32(kStrip2LdsDec + (byte_shl<N, 2 + kDecCopiesLog2>(t) | copy)); }
-// ... and from a plain 256-entry table at LDS offset 0 (kernels that keep RC_SRGB_LDS's layout)
+__device__ __forceinline__ float dec_byte(uint32_t t) { return lds_f32(kStrip2LdsDec + byte_shl<N, 2>(t)); }
 template <int N>
-__device__ __forceinline__ float dec_byte_plain(uint32_t t) { return lds_f32(byte_shl<N, 2>(t)); }
+__device__ __forceinline__ float dec_byte_plain(uint32_t t) { return dec_byte<N>(t); }   // (kernels that keep RC_SRGB_LDS's layout: the same offset)
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat2(float x) { return v2f{x, x}; }
 // srgb8_t2 (rc_device.h) on the table at kStrip2LdsEnc
