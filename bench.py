@@ -591,6 +591,34 @@ def main():
         natural = {"value": aggregate([args.batch], n_steps, dtn), "unit": "frames/s", "steps": n_steps, "mask_mode": "rendered",
                    "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in profn],
                    "note": "synthetic frames with video-like statistics (gradients, block edges, +-3 grain); `value` stays on uniform noise"}
+    # The pixel-art upscalers on what they are made for: frames of flat-coloured tiles and sprites from a 16-colour palette
+    # instead of uniform noise, on which every xbr rule fires at nearly every pixel (the worst case; `value` stays on it).
+    pixel_art = None
+    if wl in ("xbr-lv3", "xbr-lv2", "scalefx") and world == 1:
+        pal = torch.randint(0, 256, (16, 3), dtype=torch.uint8, device="cuda", generator=g)
+        tiles = torch.randint(0, 16, (n_local, (h + 7) // 8, (w + 7) // 8), device="cuda", generator=g)
+        idx = tiles.repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :h, :w]
+        spr = torch.randint(0, 16, (n_local, h, w), device="cuda", generator=g)
+        keep = torch.rand((n_local, h, w), device="cuda", generator=g) < 0.08          # 8 % of the pixels: sprite detail
+        idx = torch.where(keep, spr, idx)
+        art = torch.empty((n_local, h, w, 4), dtype=torch.uint8, device="cuda")
+        art[..., :3] = pal[idx]
+        art[..., 3] = 255
+        saved = frames
+        frames = art
+        n_steps = max(1, args.steps // 4)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        barrier()
+        dta = time.perf_counter() - t0
+        frames = saved
+        del art, idx, spr, keep, tiles
+        pixel_art = {"value": aggregate([args.batch], n_steps, dta), "unit": "frames/s", "steps": n_steps,
+                     "note": "frames of 8x8 flat tiles from a 16-colour palette with 8 % sprite detail; `value` stays on uniform noise"}
     ceiling = copy_ceiling(torch)
     out = {
         # BASELINE.json's metric for the default workload; other --workload values are side measurements
@@ -621,6 +649,8 @@ def main():
         out["mask_rendered"] = mask_rendered
     if natural is not None:
         out["natural_frames"] = natural
+    if pixel_art is not None:
+        out["pixel_art_frames"] = pixel_art
     if args.io and rank == 0:
         out["io"] = io_measurements(e, w, h, args.batch, max(3, args.steps))
     if rank == 0:
