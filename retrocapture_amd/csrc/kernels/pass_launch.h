@@ -100,6 +100,8 @@ hipError_t launch_selftest(unsigned long long* d_counts, hipStream_t s);
 void royale_scan_tables_host(float off, float* A, uint32_t* B);
 int royale_scan_table_nodes();
 hipError_t royale_scan_tables_device(float off, const float* dists, int n_dists, float* A, float* bound, hipStream_t s);
+// pass_royale.hip: the last pass's output-gamma table for 1 / lcd_gamma (royale_common.h), cached per device; nullptr if it cannot be built
+const float4* royale_last_gamma_table(float inv_gamma, hipStream_t s);
 hipError_t launch_selftest_srgb8(const float* d_src, uint8_t* d_dst, size_t n, const uint32_t* table, hipStream_t s, int form = 1);
 
 // 64x4 pixel tiles: one wave per row segment, so each wave stores 256 contiguous bytes of an

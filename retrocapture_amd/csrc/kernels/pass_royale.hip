@@ -1055,9 +1055,7 @@ struct LastTables {
 // table) against the very expression the strip kernel evaluates - a bound by exhaustion, not by sampling: third-order
 // remainder and float noise together stay below 4e-7 G.  The kernel stores the byte when the whole interval rounds to one byte
 // (x -> rint(clamp(x) * 255) is monotone) and re-renders the few other pixels with the exact per-pixel code.
-constexpr uint32_t kLastTabBits0 = 0x35800000u;   // 2^-20
-constexpr int kLastTabShift = 18;                 // 2^18 floats per node: 32 nodes per octave
-constexpr int kLastTabNodes = (int)((0x3f800000u - kLastTabBits0) >> kLastTabShift) + 1;   // 641: the last one is the colour 1.0 alone
+// (kLastTabBits0 / kLastTabShift / kLastTabNodes / kLastLdsTab and last_gamma_byte: royale_common.h)
 __device__ __forceinline__ float last_gamma(float c, float inv_gamma) { return exp2_(log2_(c) * inv_gamma); }   // = the strips' packed form per component
 __host__ __device__ __forceinline__ float last_node_colour(int n) {
   return n == kLastTabNodes - 1 ? 1.0f : bits2f(kLastTabBits0 + ((uint32_t)n << kLastTabShift) + (1u << (kLastTabShift - 1)));
@@ -1126,24 +1124,6 @@ __global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint3
     }
   if (!(border_size > 0.0f)) why |= 2u;   // border_size = 0 makes the penetration 0/0 everywhere: general form
   if (why) atomicOr(bad, why);
-}
-
-constexpr uint32_t kLastLdsTab = 1024u;   // LDS byte offset of the gamma table (behind the decode table; the kernel has no static LDS)
-// one channel of one pixel from the gamma table: the byte, *fail set when it is not certain.  c is a LINEAR sample of decoded
-// sRGB texels: 0 <= c <= 1.  With y = fl(lin * 255) and r = rint(y): the exact code stores rint(fl(clamp(G) * 255)),
-// |G - lin| <= bound, and the two products round within 2^-24 * 255 each, so the byte is r whenever
-// |y - r| + 255 bound + 3.1e-5 < 0.5 (clamping r to [0, 255] commutes with it).
-__device__ __forceinline__ uint32_t last_gamma_byte(float c, bool* fail) {
-  typedef float last_v4f __attribute__((ext_vector_type(4)));
-  // colours below the table's first node store 0 like that node's first colour does (G is monotone, G(2^-20) * 255 < 0.47)
-  const uint32_t cb = max(f2bits(c), kLastTabBits0);
-  const uint32_t off = ((cb - kLastTabBits0) >> (kLastTabShift - 4)) & ~15u;
-  const last_v4f e = *reinterpret_cast<const RC_AS3 last_v4f*>((uintptr_t)(kLastLdsTab + off));
-  const float cc = bits2f(cb);
-  const float y = fma_(cc, fma_(cc, e.z, e.y), e.x) * 255.0f;
-  const float r = __builtin_rintf(y);
-  *fail = *fail || !(__builtin_fabsf(y - r) + fma_(e.w, 255.0f, 3.1e-5f) < 0.5f);
-  return (uint32_t)__builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);
 }
 
 template <class SO>
@@ -1277,6 +1257,23 @@ __global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, c
   }
 }
 
+// the gamma table for 1 / lcd_gamma into `tab` (kLastTabNodes records): slope and half curvature from the closed form in double
+// precision (any coefficients are valid: the bound is measured against what is stored), node values and bounds on the device.
+// `h` is the host staging of the asynchronous copy: it must outlive the stream's work (the caller synchronises).
+bool fillLastGammaTable(float inv_gamma, float4* tab, hipStream_t s, std::vector<float4>* h) {
+  const double g = (double)inv_gamma;
+  h->resize((size_t)kLastTabNodes);
+  for (int n = 0; n < kLastTabNodes; ++n) {
+    const double c0 = (double)last_node_colour(n);
+    (*h)[(size_t)n] = make_float4(0.0f, (float)(g * std::pow(c0, g - 1.0)), (float)(0.5 * g * (g - 1.0) * std::pow(c0, g - 2.0)), 0.0f);
+  }
+  if (hipMemcpyAsync(tab, h->data(), h->size() * sizeof(float4), hipMemcpyHostToDevice, s) != hipSuccess) return false;
+  hipLaunchKernelGGL(k_last_gamma_err, dim3(1, kLastTabNodes), dim3(256), 0, s, inv_gamma, tab, 0);
+  hipLaunchKernelGGL(k_last_gamma_err, dim3(16, kLastTabNodes), dim3(256), 0, s, inv_gamma, tab, 1);
+  hipLaunchKernelGGL(k_last_gamma_finish, dim3((kLastTabNodes + 255) / 256), dim3(256), 0, s, tab);
+  return hipGetLastError() == hipSuccess;
+}
+
 void buildLastTables(const PassLaunch& L, hipStream_t s, LastTables* T) {
   uint32_t* bad = nullptr;   // [0]: the strip form does not apply, [1]: the gamma table does not
   bool ok = hipMalloc(reinterpret_cast<void**>(&T->cols), (size_t)LS_COL_FIELDS * 2 * L.out_w * 4) == hipSuccess &&
@@ -1293,20 +1290,10 @@ void buildLastTables(const PassLaunch& L, hipStream_t s, LastTables* T) {
   T->usable = ok && hbad[0] == 0;
   if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc last] %dx%d: ok %d strip flags %u, gamma table flags %u\n", L.out_w, L.out_h, (int)ok, hbad[0], hbad[1]);
   if (T->usable && hbad[1] == 0 && hipMalloc(reinterpret_cast<void**>(&T->gamma_tab), kLastTabNodes * sizeof(float4)) == hipSuccess) {
-    // slope and half curvature from the closed form in double precision (any coefficients are valid: the bound is measured
-    // against what is stored)
     const float inv_gamma = 1.0f / L.params[1];
-    const double g = (double)inv_gamma;
     std::vector<float4> h((size_t)kLastTabNodes);
-    for (int n = 0; n < kLastTabNodes; ++n) {
-      const double c0 = (double)last_node_colour(n);
-      h[(size_t)n] = make_float4(0.0f, (float)(g * std::pow(c0, g - 1.0)), (float)(0.5 * g * (g - 1.0) * std::pow(c0, g - 2.0)), 0.0f);
-    }
-    bool tok = hipMemcpyAsync(T->gamma_tab, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice, s) == hipSuccess;
+    bool tok = fillLastGammaTable(inv_gamma, T->gamma_tab, s, &h);
     if (tok) {
-      hipLaunchKernelGGL(k_last_gamma_err, dim3(1, kLastTabNodes), dim3(256), 0, s, inv_gamma, T->gamma_tab, 0);
-      hipLaunchKernelGGL(k_last_gamma_err, dim3(16, kLastTabNodes), dim3(256), 0, s, inv_gamma, T->gamma_tab, 1);
-      hipLaunchKernelGGL(k_last_gamma_finish, dim3((kLastTabNodes + 255) / 256), dim3(256), 0, s, T->gamma_tab);
       tok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;   // h must outlive the copy
       if (tok && std::getenv("RC_DEBUG_SCAN") && hipMemcpy(h.data(), T->gamma_tab, h.size() * sizeof(float4), hipMemcpyDeviceToHost) == hipSuccess) {
         double worst_rel = 0.0, worst_abs = 0.0;
@@ -1333,6 +1320,44 @@ void buildLastTables(const PassLaunch& L, hipStream_t s, LastTables* T) {
 }  // namespace
 
 namespace rck {
+// The output-gamma table of 1 / lcd_gamma on the current device, for the general last-pass kernel (pass_royale_last_general.hip):
+// built on first use, at most 16 kept (least recently used released after a device synchronisation); nullptr on failure.
+const float4* royale_last_gamma_table(float inv_gamma, hipStream_t s) {
+  struct Entry {
+    float4* tab;
+    uint64_t last_use;
+  };
+  static std::mutex mu;
+  static std::map<std::pair<int, uint32_t>, Entry> cache;
+  static uint64_t clock = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(dev, rcd::f2bits(inv_gamma));
+  auto it = cache.find(key);
+  if (it != cache.end()) {
+    it->second.last_use = ++clock;
+    return it->second.tab;
+  }
+  if (cache.size() >= 16) {
+    auto victim = cache.begin();
+    for (auto c = cache.begin(); c != cache.end(); ++c)
+      if (c->second.last_use < victim->second.last_use) victim = c;
+    (void)hipDeviceSynchronize();
+    if (victim->second.tab) (void)hipFree(victim->second.tab);
+    cache.erase(victim);
+  }
+  float4* tab = nullptr;
+  std::vector<float4> h;
+  if (hipMalloc(reinterpret_cast<void**>(&tab), kLastTabNodes * sizeof(float4)) == hipSuccess &&
+      !(fillLastGammaTable(inv_gamma, tab, s, &h) && hipStreamSynchronize(s) == hipSuccess)) {
+    (void)hipFree(tab);
+    tab = nullptr;
+  }
+  cache[key] = Entry{tab, ++clock};   // (a failure is remembered too: the exact form runs instead)
+  return tab;
+}
+
 #define RC_LAUNCH(fn, kernel)                                         \
   hipError_t fn(const PassLaunch& L, hipStream_t s) {                 \
     hipLaunchKernelGGL(kernel, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);      \

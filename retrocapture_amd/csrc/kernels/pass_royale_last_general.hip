@@ -33,6 +33,8 @@ struct TexCtx {
   const uint8_t* img;
   const SrgbLds* lds;
   int z, n;
+  int n_pow;         // pow calls of the body so far (compile-time once the body is inlined)
+  bool defer_gamma;  // the three output-gamma pows - the body's last three - are left to the caller: the body returns their bases
   float tl[kMaxTaps][2], tr[kMaxTaps][2], lod[kMaxTaps];
 };
 
@@ -48,7 +50,7 @@ struct TexCtx {
 #define RCN_DIV(a, b) ((a) / (b))
 #define RCN_MIN(a, b) rcn_min(a, b)
 #define RCN_MAX(a, b) rcn_max(a, b)
-#define RCN_POW(a, b) rcn_pow(a, b)
+#define RCN_POW(a, b) rcn_pow_ctx(TEXCTX, a, b)
 
 __device__ __forceinline__ float rcn_sign(float x) { return x == 0.0f ? 0.0f : __builtin_copysignf(1.0f, x); }
 // fmin / fmax as gallivm builds them (MINPS / MAXPS, then the first operand where the second is NaN)
@@ -56,6 +58,14 @@ __device__ __forceinline__ float rcn_min(float a, float b) { return b != b ? a :
 __device__ __forceinline__ float rcn_max(float a, float b) { return b != b ? a : (a > b ? a : b); }
 // llvmpipe's pow selects 0 where "x == 0" under an unordered compare: a NaN base gives 0
 __device__ __forceinline__ float rcn_pow(float x, float y) { return x != x ? 0.0f : pow_(x, y); }
+
+// The body calls pow four times: the border's (get_border_dim_factor) first, then OUT.rgb = pow(colour, 1 / lcd_gamma).  With
+// defer_gamma those three return their base unchanged and the kernel encodes them from the gamma table (royale_common.h).
+__device__ __forceinline__ float rcn_pow_ctx(void* ctx, float x, float y) {
+  TexCtx* c = static_cast<TexCtx*>(ctx);
+  const int k = c->n_pow++;
+  return (c->defer_gamma && k >= 1) ? x : rcn_pow(x, y);
+}
 
 template <class SI, int MODE>
 __device__ __forceinline__ void rcn_tex(void* ctx, float u, float v, float* dst) {
@@ -97,9 +107,17 @@ struct LastFs {
 #undef RCN_TEX
 };
 
-template <class SI, class SO, bool MIP>
-__global__ void __launch_bounds__(256) k_royale_last_general(const PassLaunch L) {
+// GTAB: plain RGBA8 target with the gamma table in LDS behind the decode table - a pixel's bytes come from the table where they are
+// certain (colour in [0, 1], royale_common.h last_gamma_byte), from the exact pow otherwise (the body's own operations).
+template <class SI, class SO, bool MIP, bool GTAB>
+__global__ void __launch_bounds__(256) k_royale_last_general(const PassLaunch L, const float4* __restrict__ gamma_tab) {
   RC_SRGB_LDS(lds, L);
+  if (GTAB) {
+    if ((uint32_t)(uintptr_t)(RC_AS3 uint32_t*)rc_dyn_lds_ != 0u) __builtin_trap();   // the table is addressed by absolute LDS offsets
+    for (int i = (int)(threadIdx.y * blockDim.x + threadIdx.x); i < kLastTabNodes; i += (int)(blockDim.x * blockDim.y))
+      reinterpret_cast<float4*>(rc_dyn_lds_ + kLastLdsTab / 4)[i] = gamma_tab[i];
+    __syncthreads();
+  }
   const float* P = L.params;
   // the fragment stage's uniform block, in the layout the listing addresses (gen/royale_last_fs.inc, royale_last_fs_uniforms)
   const float U[12] = {P[1], P[28], P[30], P[31], P[32], P[39], P[40], P[41], (float)L.in.w, (float)L.in.h, (float)L.in.w, (float)L.in.h};
@@ -112,26 +130,44 @@ __global__ void __launch_bounds__(256) k_royale_last_general(const PassLaunch L)
   ctx.img = frame_ptr(L.in, z);
   ctx.lds = &lds;
   ctx.z = z;
+  ctx.defer_gamma = false;
   if (MIP) {
     const int x0 = x & ~1, y0 = y & ~1;
     in[0] = vary(L.plane[0], x0, y0, lo);
     in[1] = vary(L.plane[1], x0, y0, lo);
     ctx.n = 0;
+    ctx.n_pow = 0;
     LastFs<SI, TEX_REC_TL>::royale_last_fs(U, in, out, &ctx);
     in[0] = vary(L.plane[0], x0 + 1, y0, lo);
     in[1] = vary(L.plane[1], x0 + 1, y0, lo);
     ctx.n = 0;
+    ctx.n_pow = 0;
     LastFs<SI, TEX_REC_TR>::royale_last_fs(U, in, out, &ctx);
     in[0] = vary(L.plane[0], x0, y0 + 1, lo);
     in[1] = vary(L.plane[1], x0, y0 + 1, lo);
     ctx.n = 0;
+    ctx.n_pow = 0;
     LastFs<SI, TEX_REC_BL>::royale_last_fs(U, in, out, &ctx);
   }
   in[0] = vary(L.plane[0], x, y, lo);
   in[1] = vary(L.plane[1], x, y, lo);
   ctx.n = 0;
+  ctx.n_pow = 0;
+  ctx.defer_gamma = GTAB;
   LastFs<SI, MIP ? TEX_MIP : TEX_PLAIN>::royale_last_fs(U, in, out, &ctx);
-  SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], out[3]), &lds);
+  if (GTAB) {
+    // out[0..2] are the bases of the output gamma
+    bool fail = !(out[0] >= 0.0f && out[0] <= 1.0f && out[1] >= 0.0f && out[1] <= 1.0f && out[2] >= 0.0f && out[2] <= 1.0f);
+    const float c0 = fail ? 0.5f : out[0], c1 = fail ? 0.5f : out[1], c2 = fail ? 0.5f : out[2];   // (keeps the lookups inside the table)
+    uint32_t px = last_gamma_byte(c0, &fail) | (last_gamma_byte(c1, &fail) << 8) | (last_gamma_byte(c2, &fail) << 16) | (unorm8(out[3]) << 24);
+    if (fail) {
+      const float ig = 1.0f / U[0];   // the body's RCN_RCP(lcd_gamma)
+      px = unorm8(rcn_pow(out[0], ig)) | (unorm8(rcn_pow(out[1], ig)) << 8) | (unorm8(rcn_pow(out[2], ig)) << 16) | (unorm8(out[3]) << 24);
+    }
+    reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z)[(size_t)y * L.out_w + x] = px;
+  } else {
+    SO::put(L, z, x, y, make_float4(out[0], out[1], out[2], out[3]), &lds);
+  }
   RC_TILE_LOOP_END
 }
 
@@ -140,14 +176,19 @@ __global__ void __launch_bounds__(256) k_royale_last_general(const PassLaunch L)
 namespace rck {
 hipError_t launch_royale_last_general(const PassLaunch& L, hipStream_t s) {
   if (L.in.n_levels > 1) {   // mipmap_input: four evaluations per pixel, run-time sampler only
-    hipLaunchKernelGGL((k_royale_last_general<SRT, StRT, true>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+    hipLaunchKernelGGL((k_royale_last_general<SRT, StRT, true, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L, nullptr);
     return hipGetLastError();
   }
   if (SrgbLinEdge::matches(L.in) && St<FMT_RGBA8>::matches(L)) {
-    hipLaunchKernelGGL((k_royale_last_general<SrgbLinEdge, St<FMT_RGBA8>, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+    const float4* tab = (L.flags & RC_FLAG_GENERAL_ONLY) ? nullptr : royale_last_gamma_table(1.0f / L.params[1], s);
+    if (tab)
+      hipLaunchKernelGGL((k_royale_last_general<SrgbLinEdge, St<FMT_RGBA8>, false, true>), px_grid(L), px_block(),
+                         rcd::srgb_lds_bytes(L) + kLastTabNodes * sizeof(float4), s, L, tab);
+    else
+      hipLaunchKernelGGL((k_royale_last_general<SrgbLinEdge, St<FMT_RGBA8>, false, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L, nullptr);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((k_royale_last_general<SRT, StRT, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);
+  hipLaunchKernelGGL((k_royale_last_general<SRT, StRT, false, false>), px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L, nullptr);
   return hipGetLastError();
 }
 }  // namespace rck

@@ -47,4 +47,31 @@ using SrgbNearEdge = S<FMT_SRGB8, 0, WRAP_EDGE>;
 
 constexpr float kUnderHalf = 0.4995f;
 
+// ---- the last pass's output gamma from a table with a measured bound (built and described in pass_royale.hip; used by the flat
+// strip form there and by the general form in pass_royale_last_general.hip).  641 log-spaced nodes from 2^-20 to 1, a quadratic in
+// the colour itself per node and the largest error over every float of the node in .w.
+#ifndef RC_AS3
+#define RC_AS3 __attribute__((address_space(3)))
+#endif
+constexpr uint32_t kLastTabBits0 = 0x35800000u;   // 2^-20
+constexpr int kLastTabShift = 18;                 // 2^18 floats per node: 32 nodes per octave
+constexpr int kLastTabNodes = (int)((0x3f800000u - kLastTabBits0) >> kLastTabShift) + 1;   // 641: the last one is the colour 1.0 alone
+constexpr uint32_t kLastLdsTab = 1024u;   // LDS byte offset of the table (behind the decode table; the kernels have no static LDS)
+// one channel of one pixel from the gamma table: the byte, *fail set when it is not certain.  0 <= c <= 1 (callers send anything
+// else to the exact code).  With y = fl(lin * 255) and r = rint(y): the exact code stores rint(fl(clamp(G) * 255)),
+// |G - lin| <= bound, and the two products round within 2^-24 * 255 each, so the byte is r whenever
+// |y - r| + 255 bound + 3.1e-5 < 0.5 (clamping r to [0, 255] commutes with it).
+__device__ __forceinline__ uint32_t last_gamma_byte(float c, bool* fail) {
+  typedef float last_v4f __attribute__((ext_vector_type(4)));
+  // colours below the table's first node store 0 like that node's first colour does (G is monotone, G(2^-20) * 255 < 0.47)
+  const uint32_t cb = max(f2bits(c), kLastTabBits0);
+  const uint32_t off = ((cb - kLastTabBits0) >> (kLastTabShift - 4)) & ~15u;
+  const last_v4f e = *reinterpret_cast<const RC_AS3 last_v4f*>((uintptr_t)(kLastLdsTab + off));
+  const float cc = bits2f(cb);
+  const float y = fma_(cc, fma_(cc, e.z, e.y), e.x) * 255.0f;
+  const float r = __builtin_rintf(y);
+  *fail = *fail || !(__builtin_fabsf(y - r) + fma_(e.w, 255.0f, 3.1e-5f) < 0.5f);
+  return (uint32_t)__builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);
+}
+
 }  // namespace rcroyale

@@ -108,6 +108,27 @@ def test_crt_royale_1080p_curved_last_pass_against_the_oracle(params, preset_tre
     assert np.array_equal(final, want[11]) and not np.array_equal(final, flat) and final[..., :3].std() > 10
 
 
+@pytest.mark.parametrize("params", [{"geom_mode_runtime": 1.0}, {"geom_mode_runtime": 3.0, "geom_radius": 1.4, "lcd_gamma": 1.9},
+                                    {"geom_overscan_x": 0.93, "geom_overscan_y": 1.04, "aa_cubic_c": 0.8}])
+def test_crt_royale_1080p_general_last_pass_gamma_table_equals_exact(params, preset_tree, rc_lib):
+    """The general (curved / overscanned) last pass takes its three output-gamma pows from the certified table where the colour lies
+    in [0, 1] and the byte is certain (pass_royale_last_general.hip): every byte must equal the all-exact form's
+    (rc_engine_set_general_kernels_only) on noise, smooth and bar frames - the tex2Daa weights overshoot on the bars' edges, which
+    sends colours outside [0, 1] to the exact pow."""
+    from gpu_util import make_engine, run_engine
+    fr = frames3()
+    e = make_engine(preset_tree["crt-royale"], W, H)
+    e.setUndefinedVaryingZero(True)
+    for k, v in params.items():
+        assert e.setShaderParameter(k, v)
+    fast = run_engine(e, fr).copy()
+    e.setGeneralKernelsOnly(True)
+    exact = run_engine(e, fr)
+    e.shutdown()
+    assert np.array_equal(fast, exact), "%d differing bytes" % int((fast != exact).sum())
+    assert fast[..., :3].std() > 10
+
+
 def test_scanline_table_form_fallback_share(preset_tree, rc_lib):
     """Geometry that is not the regular 1:1 one (here 1080 -> 1000 lines) must take the general form: same bytes
     as the oracle on a band."""
