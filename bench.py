@@ -129,8 +129,10 @@ def pmc_traffic(kernel_name, frames_per_launch):
 
 def pmc_valu(kernel_name, frames_per_launch, avg_launch_ms):
     """The dominant kernel's real limiter when it is not HBM: VALU wave-instructions per launch from the same
-    committed PMC summary (SQ_INSTS_VALU) over the live launch time, per SIMD (256 CUs x 4), against the issue rate
-    a dependence-free FMA loop reaches on this device (0.53 G/s/SIMD)."""
+    committed PMC summary (SQ_INSTS_VALU, SQ_INSTS_LDS) over the live launch time, per SIMD (256 CUs x 4), against the
+    issue rate of this device's SLOW instruction class (4.4 cycles per wave instruction = 0.53 G/s/SIMD; fast-class
+    instructions issue in 2.5 cycles, packed ones in 4.8, a ds_read_b128 occupies the CU's LDS pipe for 4.4, and LDS time
+    ADDS to VALU time instead of overlapping: profiles/micro/*.hip)."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_royale_pmc.csv")))
@@ -143,9 +145,14 @@ def pmc_valu(kernel_name, frames_per_launch, avg_launch_ms):
         if r and r.get("SQ_INSTS_VALU_avg"):
             insts = float(r["SQ_INSTS_VALU_avg"])
             rate = insts / (avg_launch_ms * 1e-3) / (256 * 4) / 1e9
-            return {"wave_insts_per_launch": insts, "G_wave_insts_per_s_per_simd": rate, "issue_ceiling_G_per_s_per_simd": 0.53,
-                    "frac_of_issue_ceiling": rate / 0.53,
-                    "note": "this kernel is VALU-issue-bound (bit-exact polynomial pow/exp of the reference GL), not HBM-bound"}
+            out = {"wave_insts_per_launch": insts, "G_wave_insts_per_s_per_simd": rate, "issue_ceiling_G_per_s_per_simd": 0.53,
+                   "frac_of_issue_ceiling": rate / 0.53,
+                   "issue_cost_cycles_measured": {"fast": 2.5, "slow": 4.4, "packed": 4.8, "transcendental": 8.1, "ds_read_b128_per_cu": 4.4},
+                   "note": "not HBM-bound: VALU issue and LDS pipe time add up in this kernel (the GL's float arithmetic in the GL's order, "
+                           "bit-exact); the ceiling quoted is the slow instruction class's, see DESIGN.md section 7"}
+            if r.get("SQ_INSTS_LDS_avg"):
+                out["lds_wave_insts_per_launch"] = float(r["SQ_INSTS_LDS_avg"])
+            return out
     return None
 
 
