@@ -100,7 +100,8 @@ def cpu_baseline(key, w, h, vw, vh, tree, budget_s=15.0):
                       % (n, cores, dt)}
 
 
-PMC_FRAMES_PER_LAUNCH = 64.0   # launch shape of the newest profiles/r*_royale_pmc.csv (profiles/collect.sh: the engine's default chunk)
+PMC_FILE = "r03_royale_pmc.csv"   # the committed counter summary the `traffic` / `valu` figures are read from (profiles/collect.sh) ...
+PMC_FRAMES_PER_LAUNCH = 128.0     # ... and the launch shape it was collected at: the engine's default for 1080p chains
 
 
 def pmc_traffic(kernel_name, frames_per_launch):
@@ -112,7 +113,7 @@ def pmc_traffic(kernel_name, frames_per_launch):
     for the launch shape it was collected at (PMC_FRAMES_PER_LAUNCH); otherwise None."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_royale_pmc.csv")))
+    files = glob.glob(os.path.join(ROOT, "profiles", PMC_FILE))
     if not files or abs(frames_per_launch - PMC_FRAMES_PER_LAUNCH) > 1e-6:
         return None
     want = "k_" + kernel_name.replace("-", "_")
@@ -135,7 +136,7 @@ def pmc_valu(kernel_name, frames_per_launch, avg_launch_ms):
     ADDS to VALU time instead of overlapping: profiles/micro/*.hip)."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_royale_pmc.csv")))
+    files = glob.glob(os.path.join(ROOT, "profiles", PMC_FILE))
     if not files or abs(frames_per_launch - PMC_FRAMES_PER_LAUNCH) > 1e-6 or avg_launch_ms <= 0:
         return None
     want = {"royale-scanlines-v": "k_royale_scan_v", "royale-bloom-h": "k_royale_bloom_h"}.get(kernel_name, "k_" + kernel_name.replace("-", "_"))
@@ -645,7 +646,7 @@ def main():
                    "copy_ceiling_frac_whole_chain": value / world * chain_bytes / (ceiling * 1e9)},
         "roofline": {"bound": "hbm", "kernel": infos[dom]["kernel"], "pass": dom, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(infos[dom]["kernel"], frames_per_launch),
+                     "traffic": pmc_traffic(infos[dom]["kernel"], frames_per_launch), "traffic_source": "profiles/" + PMC_FILE,
                      "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "frac_of_copy_ceiling": achieved / ceiling,

@@ -776,7 +776,13 @@ const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames,
     RC_LOG_ERROR("applyShader: a preset that samples both frame history and PassFeedback is not supported");
     return inputs;
   }
-  const uint32_t chunk = (history || feedback) ? 1u : std::min(m_chunk, nFrames);
+  uint32_t chunkFrames = m_chunk;
+  if (m_chunkAuto) {
+    uint64_t largest = (uint64_t)width * height * 4;
+    for (const auto& p : m_passes) largest = std::max<uint64_t>(largest, p.frameBytes);
+    if (largest * 128ull <= (1ull << 31)) chunkFrames = 128u;
+  }
+  const uint32_t chunk = (history || feedback) ? 1u : std::min(chunkFrames, nFrames);
   for (size_t i = 0; i + 1 < m_passes.size(); ++i)
     if (!ensureBuffer(m_passes[i].target, m_passes[i].frameBytes * chunk)) return inputs;
   ShaderPassData& lastPass = m_passes.back();

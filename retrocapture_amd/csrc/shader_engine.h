@@ -126,7 +126,10 @@ class ShaderEngine {
 
   // ---- not in the reference -------------------------------------------------------------
   void setInputFilterLinear(bool linear) { m_inputLinear = linear; }  // FrameProcessor's texture filter
-  void setChunkFrames(uint32_t n) { m_chunk = n ? n : 1; }
+  void setChunkFrames(uint32_t n) {
+    m_chunk = n ? n : 1;
+    m_chunkAuto = false;
+  }
   // Accept presets whose .glsl files are absent when the registry knows the shader (the
   // registry's parameter table is used).  Off by default: the reference fails such a pass.
   void setAllowMissingSources(bool allow) { m_allowMissingSources = allow; }
@@ -180,7 +183,11 @@ class ShaderEngine {
   float m_frameCount = 0.0f;
   float m_time = 0.0f;
   bool m_inputLinear = false;
-  uint32_t m_chunk = 64;   // frames per launch: per-launch costs (table loads, ramp and tail of the one-workgroup-per-CU kernels) are 25 % of crt-royale at 8, 5 % at 32
+  // frames per launch: per-launch costs (table loads, ramp and tail of the one-workgroup-per-CU kernels) are 25 % of crt-royale
+  // at 8, 5 % at 32, 2 % at 64.  Unless the caller sets it, a batch runs 128 frames per launch where 128 frames of the largest
+  // pass target stay below 2 GiB (1080p RGBA8 chains), and m_chunk = 64 otherwise (4K targets, float targets).
+  uint32_t m_chunk = 64;
+  bool m_chunkAuto = true;
   uint32_t m_lastChunkFrames = 0;
   uint32_t m_lastChunkFirst = 0;
   bool m_singleShader = false;
