@@ -147,3 +147,32 @@ def test_scanline_table_form_fallback_share(preset_tree, rc_lib):
     rows = run_pass_rows("royale_scan_v", Tex(p0, "srgb8", True, "clamp_to_edge"), W, 1000, 470, 534, out_fmt="srgb8",
                          src_w=W, src_h=H, chain=sizes, pass_index=1, vp=(W, 1000))
     assert np.array_equal(rows, p1[470:534])
+
+
+@pytest.mark.parametrize("mask_rendered", [False, True])
+def test_crt_royale_1080p_default_launch_shape_equals_small_launches(mask_rendered, preset_tree, rc_lib):
+    """The engine's default for 1080p chains is 128 frames per kernel launch (shader_engine.cpp: applyShaderBatch); a batch of
+    136 frames - one full launch and a short one - must come out byte for byte as it does 8 frames per launch: frame indices up
+    to 127 inside a launch reach every kernel's frame / strip / run arithmetic (the per-wave runs of the bloom pass, the scanline
+    pass's fix list, the strip counts)."""
+    import torch
+    from gpu_util import make_engine
+    n = 136
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    frames = torch.randint(0, 256, (n, H, W, 4), dtype=torch.uint8, device="cuda", generator=g)
+    frames[..., 3] = 255
+    frames[3, :, :, :3] = torch.from_numpy(bars(W, H, 3)).cuda()       # not only noise
+    frames[131, :, :, :3] = torch.from_numpy(smooth(W, H, 9)).cuda()
+    big, small = make_engine(preset_tree["crt-royale"], W, H), make_engine(preset_tree["crt-royale"], W, H, chunk=8)
+    for e in (big, small):
+        e.setUndefinedVaryingZero(mask_rendered)
+        e.applyShaderBatch(frames, n, W, H)
+        e.sync()
+    last = big.passCount() - 1
+    for k in (0, 3, 7, 8, 63, 64, 126, 127, 128, 131, 135):
+        a, b = big.readPass(last, k), small.readPass(last, k)
+        assert np.array_equal(a, b), "frame %d: %d differing bytes" % (k, int((a != b).sum()))
+    assert a[..., :3].std() > 5
+    big.shutdown()
+    small.shutdown()
