@@ -599,43 +599,30 @@ def main():
         natural = {"value": aggregate([args.batch], n_steps, dtn), "unit": "frames/s", "steps": n_steps, "mask_mode": "rendered",
                    "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in profn],
                    "note": "synthetic frames with video-like statistics (gradients, block edges, +-3 grain); `value` stays on uniform noise"}
-    # ... and with the batch split over TWO engine instances on two HIP streams of this GPU (half the frames each, enqueued back
-    # to back by this one host thread): kernels of the two streams overlap, the copy-rate passes of one under the VALU / LDS
-    # bound passes of the other.  A side measurement of what a second stream inside the engine would buy;
-    # `value`, the roofline figures and the committed profiles stay on one engine and one stream.
+    # ... and with the engine's second lane switched on (rc_engine_set_lanes(2)): the second half of the batch is rendered by a
+    # helper instance on its own HIP stream, so kernels of the two streams overlap - the copy-rate passes of one under the VALU /
+    # LDS bound passes of the other.  Opt-in this round: `value`, the roofline figures and the committed
+    # profiles stay on one lane.
     two_streams = None
-    if wl == "crt-royale" and args.modes == "both" and world == 1 and not args.param and n_local >= 64 and n_local % 2 == 0:
+    if wl == "crt-royale" and args.modes == "both" and world == 1 and not args.param and n_local >= 64:
         try:
-            half = n_local // 2
-            s2 = torch.cuda.Stream()
-            e2 = ShaderEngine()
-            if e2.init(local, s2.cuda_stream):
-                e2.setAllowMissingSources(True)
-                if e2.loadPresetStatus(tree[key]) == 0:
-                    e2.setViewport(vw, vh)
-                    if args.chunk:
-                        e2.setChunkFrames(args.chunk)
-                    lo, hi = frames[:half], frames[half:]
-
-                    def step2():
-                        e.applyShaderBatch(lo, half, w, h)
-                        e2.applyShaderBatch(hi, half, w, h)
-                    n_steps = max(1, args.steps // 4)
-                    for _ in range(args.warmup):
-                        step2()
-                    barrier()
-                    t0 = time.perf_counter()
-                    for _ in range(n_steps):
-                        step2()
-                    barrier()
-                    dt2 = time.perf_counter() - t0
-                    two_streams = {"value": aggregate([args.batch], n_steps, dt2), "unit": "frames/s", "steps": n_steps, "engines": 2,
-                                   "frames_per_engine_per_step": half,
-                                   "note": "two engine instances on two HIP streams, half the batch each; `value` stays on one engine and one stream"}
-            e2.shutdown()
-            del e2
+            e.setLanes(2)     # rc_engine_set_lanes: the second half of every batch on a helper instance with its own stream
+            n_steps = max(1, args.steps // 4)
+            for _ in range(args.warmup):
+                step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                step()
+            barrier()
+            dt2 = time.perf_counter() - t0
+            two_streams = {"value": aggregate([args.batch], n_steps, dt2), "unit": "frames/s", "steps": n_steps, "lanes": 2,
+                           "note": "rc_engine_set_lanes(2): the batch's second half on a second HIP stream (a helper engine instance), "
+                                   "same bytes; opt-in - `value`, the roofline figures and the profiles stay on one lane"}
         except Exception as ex:   # a side measurement never takes the line down
             two_streams = {"value": None, "error": repr(ex)}
+        finally:
+            e.setLanes(1)
     # The pixel-art upscalers on what they are made for: frames of flat-coloured tiles and sprites from a 16-colour palette
     # instead of uniform noise, on which every xbr rule fires at nearly every pixel (the worst case; `value` stays on it).
     pixel_art = None

@@ -132,8 +132,15 @@ typedef struct {
 } rc_pass_profile;
 void rc_engine_set_profiling(rc_engine* e, int on);
 int rc_engine_pass_profile(rc_engine* e, int pass, rc_pass_profile* out);
-/* Frames processed per kernel launch through the whole chain (default 8). */
+/* Frames processed per kernel launch through the whole chain (default: 128 where 128 frames of the chain's largest pass
+ * target stay below 2 GiB, else 64). */
 void rc_engine_set_chunk_frames(rc_engine* e, uint32_t n);
+/* Not in the reference (its one GL context draws one frame at a time): n = 2 renders the second half of every batch on a
+ * second HIP stream of the same device (a helper engine instance inside `e`: same preset, parameters and flags) straight into
+ * the batch output; the helper's stream is ordered after the engine's stream at the start of the call and before it at the
+ * end, so callers still see one stream-ordered result and the same bytes.  Default 1.  Presets that sample frame history
+ * or PassFeedback, single-shader mode and profiled runs always use one lane. */
+void rc_engine_set_lanes(rc_engine* e, uint32_t n);
 /* 1: a pass whose .glsl file is unreadable still runs if its shader identity is registered
  * (built-in parameter table).  Default 0 = the reference's behaviour (pass fails). */
 void rc_engine_set_allow_missing_sources(rc_engine* e, int allow);

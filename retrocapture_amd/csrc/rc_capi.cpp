@@ -249,6 +249,9 @@ int rc_engine_pass_profile(rc_engine* e, int pass, rc_pass_profile* out) {
 void rc_engine_set_chunk_frames(rc_engine* e, uint32_t n) {
   if (e) e->impl.setChunkFrames(n);
 }
+void rc_engine_set_lanes(rc_engine* e, uint32_t n) {
+  if (e) e->impl.setLanes(n);
+}
 void rc_engine_set_undefined_varying_zero(rc_engine* e, int zero) {
   if (e) e->impl.setUndefinedVaryingZero(zero != 0);
 }

@@ -97,6 +97,7 @@ void ShaderEngine::shutdown() {  // :62-86
   clients.swap(m_clients);
   for (EngineClient* c : clients) c->engineGone();
   if (!m_initialized) return;
+  destroyHelper();
   disableShader();
   cleanupPresetPasses();
   cleanupTextureReferences();
@@ -148,6 +149,7 @@ bool ShaderEngine::loadShader(const std::string& shaderPath) {
     RC_LOG_ERROR("ShaderEngine not initialized");
     return false;
   }
+  ++m_configEpoch;
   disableShader();
   cleanupPresetPasses();
   cleanupTextureReferences();
@@ -178,6 +180,7 @@ bool ShaderEngine::loadPreset(const std::string& presetPath) {  // :228-319
     RC_LOG_ERROR("ShaderEngine not initialized");
     return false;
   }
+  ++m_configEpoch;
   disableShader();
   cleanupPresetPasses();
   cleanupTextureReferences();
@@ -714,6 +717,70 @@ const void* ShaderEngine::applyShader(const void* input, uint32_t width, uint32_
   return applyShaderBatch(input, 1, width, height, 0);
 }
 
+void ShaderEngine::destroyHelper() {
+  if (m_helper) {
+    if (m_helperStream) (void)hipStreamSynchronize(m_helperStream);
+    m_helper->m_externalOut = nullptr;
+    m_helper->shutdown();
+    m_helper.reset();
+  }
+  if (m_laneFork) (void)hipEventDestroy(m_laneFork);
+  if (m_laneJoin) (void)hipEventDestroy(m_laneJoin);
+  if (m_helperStream) (void)hipStreamDestroy(m_helperStream);
+  m_laneFork = m_laneJoin = nullptr;
+  m_helperStream = nullptr;
+  m_helperEpoch = 0;
+}
+
+// The second lane: created on first use, reloaded when this engine's preset changed, and given this engine's settings
+// before every batch.  false: stay on one lane.
+bool ShaderEngine::syncHelper() {
+  if (m_singleShader || m_presetPath.empty()) return false;
+  if (!m_helper) {
+    if (!hipOk(hipStreamCreateWithFlags(&m_helperStream, hipStreamNonBlocking), "hipStreamCreate") ||
+        !hipOk(hipEventCreateWithFlags(&m_laneFork, hipEventDisableTiming), "hipEventCreate") ||
+        !hipOk(hipEventCreateWithFlags(&m_laneJoin, hipEventDisableTiming), "hipEventCreate")) {
+      destroyHelper();
+      return false;
+    }
+    m_helper.reset(new ShaderEngine());
+    if (!m_helper->init(m_device, m_helperStream)) {
+      destroyHelper();
+      return false;
+    }
+  }
+  ShaderEngine& o = *m_helper;
+  o.m_allowMissingSources = m_allowMissingSources;
+  if (m_helperEpoch != m_configEpoch) {
+    if (hipStreamSynchronize(m_helperStream) != hipSuccess) return false;
+    if (!o.loadPreset(m_presetPath) || !o.m_shaderActive) return false;
+    m_helperEpoch = m_configEpoch;
+  }
+  if (!o.m_shaderActive || o.m_passes.size() != m_passes.size()) return false;
+  o.m_inputLinear = m_inputLinear;
+  o.m_undefVaryingZero = m_undefVaryingZero;
+  o.m_generalOnly = m_generalOnly;
+  o.m_floatTargetFp16 = m_floatTargetFp16;
+  o.m_chunk = m_chunk;
+  o.m_chunkAuto = m_chunkAuto;
+  o.m_maxShaderWidth = m_maxShaderWidth;
+  o.m_maxShaderHeight = m_maxShaderHeight;
+  o.m_viewportWidth = m_viewportWidth;
+  o.m_viewportHeight = m_viewportHeight;
+  o.m_uniforms = m_uniforms;
+  o.m_time = m_time;
+  std::map<std::string, float> custom;
+  {
+    std::lock_guard<std::mutex> lock(m_paramMutex);
+    custom = m_customParameters;
+  }
+  {
+    std::lock_guard<std::mutex> lock(o.m_paramMutex);
+    o.m_customParameters = custom;
+  }
+  return true;
+}
+
 const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames, uint32_t width, uint32_t height,
                                            uint64_t frameStride) {  // :1531-1879
   if (!m_shaderActive) return inputs;
@@ -782,19 +849,29 @@ const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames,
     for (const auto& p : m_passes) largest = std::max<uint64_t>(largest, p.frameBytes);
     if (largest * 128ull <= (1ull << 31)) chunkFrames = 128u;
   }
-  const uint32_t chunk = (history || feedback) ? 1u : std::min(chunkFrames, nFrames);
+  // two lanes (setLanes): this engine renders the first half, the helper - on its own stream - the second half
+  const bool twoLanes = m_lanes == 2 && !m_externalOut && !history && !feedback && !m_profiling && nFrames >= 2 && syncHelper();
+  const uint32_t nOwn = twoLanes ? (nFrames + 1) / 2 : nFrames;
+  const uint32_t chunk = (history || feedback) ? 1u : std::min(chunkFrames, nOwn);
   for (size_t i = 0; i + 1 < m_passes.size(); ++i)
     if (!ensureBuffer(m_passes[i].target, m_passes[i].frameBytes * chunk)) return inputs;
   ShaderPassData& lastPass = m_passes.back();
-  if (!ensureBuffer(lastPass.target, lastPass.frameBytes * nFrames)) return inputs;
+  if (!m_externalOut && !ensureBuffer(lastPass.target, lastPass.frameBytes * nFrames)) return inputs;
+  uint8_t* const outBase = m_externalOut ? m_externalOut : static_cast<uint8_t*>(lastPass.target.ptr);
+  if (twoLanes) {
+    // the helper starts once everything enqueued on this engine's stream so far (the caller's frames) is done
+    if (!hipOk(hipEventRecord(m_laneFork, m_stream), "hipEventRecord") ||
+        !hipOk(hipStreamWaitEvent(m_helperStream, m_laneFork, 0), "hipStreamWaitEvent"))
+      return inputs;
+  }
 
-  for (uint32_t f0 = 0; f0 < nFrames; f0 += chunk) {
-    const uint32_t n = std::min(chunk, nFrames - f0);
+  for (uint32_t f0 = 0; f0 < nOwn; f0 += chunk) {
+    const uint32_t n = std::min(chunk, nOwn - f0);
     // FrameCount is a float that is incremented once per frame (:1688) and handed to int
     // uniforms by truncation (:2138)
     const int firstCount = (int)(m_frameCount + 1.0f);
     const uint8_t* in = static_cast<const uint8_t*>(inputs) + frameStride * f0;
-    uint8_t* out = static_cast<uint8_t*>(lastPass.target.ptr) + lastPass.frameBytes * f0;
+    uint8_t* out = outBase + lastPass.frameBytes * f0;
     if (!runChunk(in, frameStride, width, height, n, firstCount, out)) return inputs;
     if (feedback) {
       // ping-pong swap (:1710-1718): what this frame wrote becomes next frame's "previous"; the texture
@@ -826,9 +903,29 @@ const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames,
     m_lastChunkFrames = n;
     m_lastChunkFirst = f0;
   }
+  if (twoLanes) {
+    ShaderEngine& o = *m_helper;
+    const uint32_t nOther = nFrames - nOwn;
+    o.m_frameCount = m_frameCount;   // the helper's frames follow this lane's: FrameCount continues
+    o.m_time = m_time;
+    o.m_externalOut = outBase + lastPass.frameBytes * nOwn;
+    const uint8_t* in = static_cast<const uint8_t*>(inputs) + frameStride * nOwn;
+    const void* r = o.applyShaderBatch(in, nOther, width, height, frameStride);
+    const bool ok = r == static_cast<const void*>(o.m_externalOut);
+    o.m_externalOut = nullptr;
+    // whatever happened, this engine's stream continues only after the helper's stream has drained
+    const bool joined = hipOk(hipEventRecord(m_laneJoin, m_helperStream), "hipEventRecord") &&
+                        hipOk(hipStreamWaitEvent(m_stream, m_laneJoin, 0), "hipStreamWaitEvent");
+    if (!ok || !joined) {
+      RC_LOG_ERROR("applyShader: the second lane failed");
+      return inputs;
+    }
+    m_frameCount = o.m_frameCount;
+    m_time = o.m_time;
+  }
   m_outputWidth = lastPass.width;
   m_outputHeight = lastPass.height;
-  return lastPass.target.ptr;
+  return m_externalOut ? static_cast<const void*>(m_externalOut) : lastPass.target.ptr;
 }
 
 void ShaderEngine::fillGeometry(size_t i, const rcd::Tex& inputTex, const rcd::PassLaunch& L, PassGeometry* geo) const {

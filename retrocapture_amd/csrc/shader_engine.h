@@ -16,6 +16,7 @@
 
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -142,6 +143,14 @@ class ShaderEngine {
   // float, only the storage of those targets rounds.  Off by default (bit-exact); see DESIGN.md for the tolerance.
   void setFloatTargetFp16(bool on) { m_floatTargetFp16 = on; }
   uint32_t getChunkFrames() const { return m_chunk; }
+  // Two lanes (opt-in, default 1): the second half of a batch runs on a helper engine instance with its own HIP stream - same
+  // device, preset, parameters and flags - and writes straight into this engine's batch output; the helper's stream waits
+  // for this engine's stream before it starts and is waited for before applyShaderBatch returns its pointer, so the caller
+  // sees one stream-ordered result.  Kernels of the two lanes overlap on the device (the copy-rate passes of one under the
+  // VALU / LDS bound passes of the other).  Presets that sample frame history or PassFeedback, single-shader mode and
+  // profiled runs stay on one lane.
+  void setLanes(uint32_t n) { m_lanes = n >= 2 ? 2u : 1u; }
+  uint32_t getLanes() const { return m_lanes; }
   hipStream_t stream() const { return m_stream; }
   size_t passCount() const { return m_passes.size(); }
   const ShaderPassData* pass(size_t i) const { return i < m_passes.size() ? &m_passes[i] : nullptr; }
@@ -188,6 +197,14 @@ class ShaderEngine {
   // pass target stay below 2 GiB (1080p RGBA8 chains), and m_chunk = 64 otherwise (4K targets, float targets).
   uint32_t m_chunk = 64;
   bool m_chunkAuto = true;
+  uint32_t m_lanes = 1;
+  std::unique_ptr<ShaderEngine> m_helper;   // the second lane (setLanes)
+  hipStream_t m_helperStream = nullptr;
+  hipEvent_t m_laneFork = nullptr, m_laneJoin = nullptr;
+  uint64_t m_configEpoch = 1, m_helperEpoch = 0;   // loadPreset / loadShader bump the epoch: the helper reloads when it lags
+  uint8_t* m_externalOut = nullptr;   // on a helper: where the last pass of its next batch goes (the owner's batch output)
+  bool syncHelper();
+  void destroyHelper();
   uint32_t m_lastChunkFrames = 0;
   uint32_t m_lastChunkFirst = 0;
   bool m_singleShader = false;

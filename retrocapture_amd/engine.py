@@ -72,6 +72,7 @@ SYMBOLS = [
     ("rc_engine_set_profiling", None, [C.c_void_p, C.c_int]),
     ("rc_engine_pass_profile", C.c_int, [C.c_void_p, C.c_int, C.POINTER(_RcPassProfile)]),
     ("rc_engine_set_chunk_frames", None, [C.c_void_p, C.c_uint32]),
+    ("rc_engine_set_lanes", None, [C.c_void_p, C.c_uint32]),
     ("rc_engine_set_allow_missing_sources", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_undefined_varying_zero", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_general_kernels_only", None, [C.c_void_p, C.c_int]),
@@ -487,6 +488,10 @@ class ShaderEngine:
 
     def setChunkFrames(self, n):
         self._lib.rc_engine_set_chunk_frames(self._need(), int(n))
+
+    def setLanes(self, n):
+        """2: the second half of every batch runs on a second HIP stream (rc_engine_set_lanes); default 1."""
+        self._lib.rc_engine_set_lanes(self._need(), int(n))
 
     def setAllowMissingSources(self, allow):
         self._lib.rc_engine_set_allow_missing_sources(self._need(), int(bool(allow)))

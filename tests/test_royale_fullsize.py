@@ -176,3 +176,37 @@ def test_crt_royale_1080p_default_launch_shape_equals_small_launches(mask_render
     assert a[..., :3].std() > 5
     big.shutdown()
     small.shutdown()
+
+
+@pytest.mark.parametrize("mask_rendered", [False, True])
+def test_crt_royale_1080p_two_lanes_equal_one_lane(mask_rendered, preset_tree, rc_lib):
+    """rc_engine_set_lanes(2): the second half of a batch is rendered by the helper instance on its own HIP stream into the same
+    batch output.  Every frame must equal the one-lane engine's - the frame counter (crt-royale's field parity) continues across
+    the two halves, parameters set on the engine reach the helper, and a second batch (odd size: halves of 4 and 3) continues
+    the count."""
+    import torch
+    from gpu_util import make_engine
+    n = 10
+    g = torch.Generator(device="cuda")
+    g.manual_seed(78)
+    frames = torch.randint(0, 256, (n, H, W, 4), dtype=torch.uint8, device="cuda", generator=g)
+    frames[..., 3] = 255
+    frames[6, :, :, :3] = torch.from_numpy(bars(W, H, 6)).cuda()
+    one, two = make_engine(preset_tree["crt-royale"], W, H), make_engine(preset_tree["crt-royale"], W, H)
+    two.setLanes(2)
+    last = one.passCount() - 1
+    for e in (one, two):
+        e.setUndefinedVaryingZero(mask_rendered)
+        assert e.setShaderParameter("crt_gamma", 2.4)
+    for count in (n, 7, 1):   # 1: a single frame stays on one lane
+        outs = []
+        for e in (one, two):
+            e.applyShaderBatch(frames, count, W, H)
+            e.sync()
+            outs.append([e.readPass(last, k) for k in range(count)])
+        for k in range(count):
+            assert np.array_equal(outs[0][k], outs[1][k]), "batch of %d, frame %d: %d differing bytes" % (
+                count, k, int((outs[0][k] != outs[1][k]).sum()))
+    assert outs[0][0][..., :3].std() > 5
+    one.shutdown()
+    two.shutdown()
