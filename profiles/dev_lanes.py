@@ -1,5 +1,5 @@
 """rc_engine_set_lanes(1) against (2) on several bench workloads (256 frames per step, frames resident, uniform noise; MASK=1 renders
-crt-royale's mask): frames/s each way.  Run on the GPU box from the repo root:  python3 profiles/dev_lanes.py
+crt-royale's mask; LANES="2" runs one setting only, e.g. under rocprofv3): frames/s each way.  Run on the GPU box from the repo root:  python3 profiles/dev_lanes.py
 """
 import os, sys, time, tempfile
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +19,7 @@ for wl in os.environ.get("WORKLOADS", "crt-royale crt-royale-fake-bloom crt-hyll
     e.setViewport(vw, vh)
     if os.environ.get("MASK"): e.setUndefinedVaryingZero(True)
     res = []
-    for lanes in (1, 2):
+    for lanes in [int(v) for v in os.environ.get("LANES", "1 2").split()]:
         e.setLanes(lanes)
         for _ in range(3): e.applyShaderBatch(frames, N, w, h)
         torch.cuda.synchronize()
@@ -28,5 +28,8 @@ for wl in os.environ.get("WORKLOADS", "crt-royale crt-royale-fake-bloom crt-hyll
         for _ in range(steps): e.applyShaderBatch(frames, N, w, h)
         torch.cuda.synchronize()
         res.append(N * steps / (time.perf_counter() - t0))
-    print("%-24s one lane %9.0f   two lanes %9.0f   %+5.1f %%" % (wl, res[0], res[1], (res[1] / res[0] - 1) * 100), flush=True)
+    if len(res) == 2:
+        print("%-24s one lane %9.0f   two lanes %9.0f   %+5.1f %%" % (wl, res[0], res[1], (res[1] / res[0] - 1) * 100), flush=True)
+    else:
+        print("%-24s LANES=%s %9.0f frames/s" % (wl, os.environ.get("LANES"), res[0]), flush=True)
     e.shutdown(); del frames
