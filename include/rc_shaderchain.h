@@ -139,7 +139,9 @@ void rc_engine_set_chunk_frames(rc_engine* e, uint32_t n);
  * second HIP stream of the same device (a helper engine instance inside `e`: same preset, parameters and flags) straight into
  * the batch output; the helper's stream is ordered after the engine's stream at the start of the call and before it at the
  * end, so callers still see one stream-ordered result and the same bytes.  Default 1.  Presets that sample frame history
- * or PassFeedback, single-shader mode and profiled runs always use one lane. */
+ * or PassFeedback, single-shader mode and profiled runs always use one lane.  With two lanes rc_engine_read_pass of an
+ * intermediate pass reaches the first lane's frames only (the last pass's output is complete); device memory for
+ * intermediates doubles. */
 void rc_engine_set_lanes(rc_engine* e, uint32_t n);
 /* 1: a pass whose .glsl file is unreadable still runs if its shader identity is registered
  * (built-in parameter table).  Default 0 = the reference's behaviour (pass fails). */
