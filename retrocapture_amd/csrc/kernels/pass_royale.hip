@@ -13,6 +13,7 @@
 #include <vector>
 #include <cstdlib>
 
+#include "../rc_log.h"
 #include "royale_strip2.h"
 
 using namespace rcd;
@@ -668,7 +669,7 @@ void buildScanHTables(const PassLaunch& L, hipStream_t s, ScanHTables* T) {
   }
   if (bad) (void)hipFree(bad);
   T->usable = ok && hbad == 0;
-  if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc scan-h] %dx%d: ok %d flags %u\n", L.out_w, L.out_h, (int)ok, hbad);
+  RC_LOG_DEBUG("crt-royale scanlines-horizontal " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h) + ": strip form " + (ok && hbad == 0 ? "in use" : "not usable (flags " + std::to_string(hbad) + ")"));
   if (!T->usable) {
     if (T->cols) (void)hipFree(T->cols);
     if (T->rows) (void)hipFree(T->rows);
@@ -1288,22 +1289,13 @@ void buildLastTables(const PassLaunch& L, hipStream_t s, LastTables* T) {
   }
   if (bad) (void)hipFree(bad);
   T->usable = ok && hbad[0] == 0;
-  if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc last] %dx%d: ok %d strip flags %u, gamma table flags %u\n", L.out_w, L.out_h, (int)ok, hbad[0], hbad[1]);
+  RC_LOG_DEBUG("crt-royale last pass " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h) + ": strip flags " + std::to_string(hbad[0]) + ", gamma table flags " + std::to_string(hbad[1]));
   if (T->usable && hbad[1] == 0 && hipMalloc(reinterpret_cast<void**>(&T->gamma_tab), kLastTabNodes * sizeof(float4)) == hipSuccess) {
     const float inv_gamma = 1.0f / L.params[1];
     std::vector<float4> h((size_t)kLastTabNodes);
     bool tok = fillLastGammaTable(inv_gamma, T->gamma_tab, s, &h);
     if (tok) {
       tok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;   // h must outlive the copy
-      if (tok && std::getenv("RC_DEBUG_SCAN") && hipMemcpy(h.data(), T->gamma_tab, h.size() * sizeof(float4), hipMemcpyDeviceToHost) == hipSuccess) {
-        double worst_rel = 0.0, worst_abs = 0.0;
-        for (int n = 0; n < kLastTabNodes; ++n) {
-          worst_abs = std::max(worst_abs, (double)h[(size_t)n].w);
-          worst_rel = std::max(worst_rel, (double)h[(size_t)n].w / std::max(1e-30, (double)h[(size_t)n].x));
-        }
-        std::fprintf(stderr, "[rc last] gamma table: %d nodes, largest bound %.3g (%.3g of the node value); node 0: T %.4g S %.4g C %.4g R %.3g; node 320: T %.4g R %.3g\n",
-                     kLastTabNodes, worst_abs, worst_rel, h[0].x, h[0].y, h[0].z, h[0].w, h[320].x, h[320].w);
-      }
     }
     if (!tok) {
       (void)hipFree(T->gamma_tab);

@@ -5,12 +5,14 @@
 #include <vector>
 #include <cstdlib>
 
-#include "royale_strip2.h"
+#include "../rc_log.h"
+#include "royale_bloom_h.h"
 
 using namespace rcd;
 using namespace rcroyale;
 using namespace rcstrip;
 using namespace rcstrip2;
+using namespace rcbloomh;
 
 namespace {
 
@@ -295,7 +297,7 @@ void buildBvTables(const PassLaunch& L, hipStream_t s, BvTables* T) {
   }
   T->usable = ok;
   T->pattern = ok ? pattern : -1;
-  if (std::getenv("RC_DEBUG_SCAN")) std::fprintf(stderr, "[rc bloom-v] %dx%d: ok %d flags %u pattern %d\n", L.out_w, L.out_h, (int)ok, hbad, T->pattern);
+  RC_LOG_DEBUG("crt-royale bloom-vertical " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h) + ": flags " + std::to_string(hbad) + ", tap pattern " + std::to_string(T->pattern));
 }
 
 // ----------------------------------------------------------------- P10, strip form ------
@@ -320,19 +322,21 @@ void buildBvTables(const PassLaunch& L, hipStream_t s, BvTables* T) {
 // runs of consecutive (frame, band, row) steps, one per wave; rows are walked in blocks of 8, and a block the quad's
 // diagonal crosses is rendered once per triangle, each pixel stored by the pass of its own triangle.
 constexpr int kBhWaves = 12;
-constexpr int kBhBlockRows = 8;   // rows classified together by triangle
 constexpr int kBhSeg = 84;        // staged columns per group: 10 + 64 + 10
 constexpr int kBhSegLeft = 10;
 constexpr int kBhColBytes = 48;                       // three channels x {T_A, T_B, D_A, D_B}
 constexpr int kBhSlotBytes = kBhSeg * kBhColBytes;    // 4032: one staged source row
 constexpr int kBhWaveDwords = 2 * kBhSlotBytes / 4;   // per wave: a ring of two staged rows (row r in slot r & 1)
-enum { BH_DX = 0, BH_WX = 9, BH_IDIM_X = 18, BH_BRIGHT_X = 19, BH_HAL_X0 = 20, BH_HAL_W = 21, BH_COL_FIELDS = 22 };
-enum { BH_Y0 = 0, BH_WY = 1, BH_IDIM_Y = 2, BH_BRIGHT_Y = 3, BH_HAL_Y0 = 4, BH_HAL_WY = 5, BH_ROW_FIELDS = 8 };
-
 struct BhTables {
   uint32_t* cols = nullptr;   // [BH_COL_FIELDS][2 sides][W] (ints and float bits)
   uint32_t* rows = nullptr;   // [H][2 sides][BH_ROW_FIELDS]
   bool usable = false;
+  bool quad = false;          // the geometry also qualifies for the quad form (k_royale_bloom_h_quad), with
+  int quad_taps = 0;          // bit 0 / 1: MASKED_SCANLINES / BRIGHTPASS is one texel per group of four columns (else the pixel's own column)
+  uint32_t* qsteps = nullptr; // the quad form's steps of one frame pair, four words each (buildBqSteps), with their running cost
+  int n_qsteps = 0;
+  std::vector<uint32_t> qcost_sum;
+  std::map<std::pair<int, int>, uint32_t*> qruns;
   // host: running sum of a cost estimate per (band, row) step of one frame (rows with a vertical weight filter two source rows,
   // blocks on the diagonal are rendered twice), and per (frames, waves) of a launch the step at which each wave's run begins
   std::vector<uint32_t> cost_sum;
@@ -342,17 +346,23 @@ struct BhTables {
     if (rows) (void)hipFree(rows);
     for (auto& r : runs)
       if (r.second) (void)hipFree(r.second);
+    for (auto& r : qruns)
+      if (r.second) (void)hipFree(r.second);
+    if (qsteps) (void)hipFree(qsteps);
     *this = BhTables();
   }
 };
 
-__global__ void __launch_bounds__(256) k_bloomh_geometry(const PassLaunch L, uint32_t* cols, uint32_t* rows, uint32_t* bad) {
+__global__ void __launch_bounds__(256) k_bloomh_geometry(const PassLaunch L, uint32_t* cols, uint32_t* rows, uint32_t* bad, uint32_t* quad_bad) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int W = L.out_w, H = L.out_h;
   const float* P = L.params;
   const float k[4] = {P[RPG_K78], P[RPG_K56], P[RPG_K34], P[RPG_K12]};
   const float dx = P[RPG_DXY];
-  uint32_t why = 0u;
+  uint32_t why = 0u, qwhy = 0u;
+  // quad form: with the input staged clamped to the frame, tap q of column x may read the texel pair that starts at x + kBqTapOff[q]
+  // (the centre tap at x - 1 or x, BH_CSEL) whenever that pair, clamped, is the sampler's own pair, clamped
+  auto same_pair = [&](int i0, int j) { return clampi(i0, 0, L.in.w - 1) == clampi(j, 0, L.in.w - 1) && clampi(i0 + 1, 0, L.in.w - 1) == clampi(j + 1, 0, L.in.w - 1); };
   if (i < W) {
     for (int side = 0; side < 2; ++side) {
       const bool lo = side == 0;
@@ -371,12 +381,32 @@ __global__ void __launch_bounds__(256) k_bloomh_geometry(const PassLaunch L, uin
         if (d < -kBhSegLeft || d + 1 > kBhSeg - kBhSegLeft - 64) why |= 1u;
         cols[((BH_DX + q) * 2 + side) * W + i] = (uint32_t)d;
         cols[((BH_WX + q) * 2 + side) * W + i] = f2bits(t.w);
+        const int reg[9] = {-8, -6, -4, -2, 0, 1, 3, 5, 7};
+        if (q != 4) {
+          if (!same_pair(t.i0, i + reg[q])) qwhy |= 1u;
+        } else {
+          const bool left = same_pair(t.i0, i - 1), here = same_pair(t.i0, i);
+          if (!left && !here) qwhy |= 1u;
+          cols[(BH_CSEL * 2 + side) * W + i] = here ? 0u : 1u;
+        }
       }
       cols[(BH_IDIM_X * 2 + side) * W + i] = (uint32_t)near_tap(vary(L.plane[2], i, 0, lo), L.extra[0].w);
       cols[(BH_BRIGHT_X * 2 + side) * W + i] = (uint32_t)near_tap(vary(L.plane[4], i, 0, lo), L.extra[1].w);
       const LinTap h = lin_tap(vary(L.plane[6], i, 0, lo), L.extra[2].w);
       cols[(BH_HAL_X0 * 2 + side) * W + i] = (uint32_t)h.i0;
       cols[(BH_HAL_W * 2 + side) * W + i] = f2bits(h.w);
+      // quad form: the two single taps sit on the pixel's own column, and the four columns of an aligned group start their
+      // halation pair at the group's first pair or the one after it
+      // (bits 1, 2: MASKED_SCANLINES, BRIGHTPASS not on the pixel's own column; bits 3, 4: not on one texel for the whole group -
+      // the reference hands the shader PassPrev3InputSize = the size pass 7 RECEIVED, 120 wide, so its tap magnifies 16 times)
+      const int gi = i & ~3;
+      const int n0 = near_tap(vary(L.plane[2], i, 0, lo), L.extra[0].w), n1 = near_tap(vary(L.plane[4], i, 0, lo), L.extra[1].w);
+      if (n0 != i) qwhy |= 2u;
+      if (n1 != i) qwhy |= 4u;
+      if (n0 != near_tap(vary(L.plane[2], gi, 0, lo), L.extra[0].w)) qwhy |= 8u;
+      if (n1 != near_tap(vary(L.plane[4], gi, 0, lo), L.extra[1].w)) qwhy |= 16u;
+      const int hq = lin_tap(vary(L.plane[6], gi, 0, lo), L.extra[2].w).i0;
+      if (h.i0 < hq || h.i0 > hq + 1) qwhy |= 32u;
     }
   }
   if (i < H) {
@@ -398,31 +428,7 @@ __global__ void __launch_bounds__(256) k_bloomh_geometry(const PassLaunch L, uin
     }
   }
   if (why) atomicOr(bad, why);
-}
-
-struct BhRow {
-  int y0;
-  float wy;
-  int idim_y, bright_y, hal_y0;
-  float hal_wy;
-};
-// A row's quantities, fetched one step ahead.  They are wave-uniform, but a scalar load in flight would turn every LDS wait of
-// the step into a full drain (scalar loads return out of order, so the compiler waits for lgkmcnt(0) while one is pending):
-// the record is fetched through the vector path (every lane the same address) and moved to scalar registers when it is used.
-struct BhRowRaw {
-  v4u a;
-  v2u32 b;
-};
-__device__ __forceinline__ BhRowRaw fetch_bh_row(__amdgpu_buffer_rsrc_t r_rows, int y, int side) {
-  const int off = (y * 2 + side) * BH_ROW_FIELDS * 4;
-  BhRowRaw r;
-  r.a = __builtin_amdgcn_raw_buffer_load_b128(r_rows, 0, off, 0);
-  r.b = __builtin_amdgcn_raw_buffer_load_b64(r_rows, 0, off + 16, 0);
-  return r;
-}
-__device__ __forceinline__ BhRow use_bh_row(const BhRowRaw& r) {
-  return BhRow{(int)__builtin_amdgcn_readfirstlane(r.a.x), bits2f(__builtin_amdgcn_readfirstlane(r.a.y)), (int)__builtin_amdgcn_readfirstlane(r.a.z),
-               (int)__builtin_amdgcn_readfirstlane(r.a.w), (int)__builtin_amdgcn_readfirstlane(r.b.x), bits2f(__builtin_amdgcn_readfirstlane(r.b.y))};
+  if (qwhy) atomicOr(quad_bad, qwhy);
 }
 
 // LDS accesses, the decode / encode tables and the packed helpers: royale_strip2.h
@@ -768,20 +774,26 @@ __global__ void __launch_bounds__(kBhWaves * 64, 1) k_royale_bloom_h_strip(const
   }
 }
 
+bool buildBqSteps(const PassLaunch& L, const std::vector<uint32_t>& hr, BhTables* T);
 void buildBhTables(const PassLaunch& L, hipStream_t s, BhTables* T) {
-  uint32_t* bad = nullptr;
+  uint32_t* bad = nullptr;   // two words: the strip forms' flags, the quad form's
   const size_t colWords = (size_t)BH_COL_FIELDS * 2 * L.out_w, rowWords = (size_t)L.out_h * 2 * BH_ROW_FIELDS;
   bool ok = hipMalloc(reinterpret_cast<void**>(&T->cols), colWords * 4) == hipSuccess &&
-            hipMalloc(reinterpret_cast<void**>(&T->rows), rowWords * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&bad), 4) == hipSuccess;
-  uint32_t hbad = 1;
-  if (ok) ok = hipMemsetAsync(bad, 0, 4, s) == hipSuccess;
+            hipMalloc(reinterpret_cast<void**>(&T->rows), rowWords * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&bad), 8) == hipSuccess;
+  uint32_t hbad[2] = {1, 1};
+  if (ok) ok = hipMemsetAsync(bad, 0, 8, s) == hipSuccess;
   if (ok) {
     const int n = L.out_w > L.out_h ? L.out_w : L.out_h;
-    hipLaunchKernelGGL(k_bloomh_geometry, dim3((n + 255) / 256), dim3(256), 0, s, L, T->cols, T->rows, bad);
-    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    hipLaunchKernelGGL(k_bloomh_geometry, dim3((n + 255) / 256), dim3(256), 0, s, L, T->cols, T->rows, bad, bad + 1);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(hbad, bad, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
   }
   if (bad) (void)hipFree(bad);
-  T->usable = ok && hbad == 0;
+  T->usable = ok && hbad[0] == 0;
+  // the quad form additionally wants a 1:1 pass over whole groups of four columns, both frames of a pair inside 32-bit offsets,
+  // and each single tap either on the pixel's own column or on one texel per group
+  const uint32_t q = hbad[1];
+  T->quad = T->usable && (q & (1u | 32u)) == 0 && (!(q & 2u) || !(q & 8u)) && (!(q & 4u) || !(q & 16u)) && bqGeometryOk(L, !(q & 2u), !(q & 4u));
+  T->quad_taps = ((q & 2u) ? 1 : 0) | ((q & 4u) ? 2 : 0);
   if (T->usable) {
     // cost estimate per step, as the kernel will walk it: blocks of kBhBlockRows rows, per triangle the block touches;
     // a row with a vertical weight filters two source rows (measured: about 1.45 x the work)
@@ -800,7 +812,14 @@ void buildBhTables(const PassLaunch& L, hipStream_t s, BhTables* T) {
           cost += bits2f(hr[((size_t)y * 2 + side) * BH_ROW_FIELDS + BH_WY]) != 0.0f ? 29u : 20u;
         T->cost_sum[(size_t)b * H + y + 1] = T->cost_sum[(size_t)b * H + y] + cost;
       }
+    if (T->usable && T->quad && !buildBqSteps(L, hr, T)) {
+      if (T->qsteps) (void)hipFree(T->qsteps);
+      T->qsteps = nullptr;
+      T->quad = false;
+    }
   }
+  RC_LOG_DEBUG("crt-royale bloom-horizontal " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h) + ": strip flags " + std::to_string(hbad[0]) + ", quad flags " +
+               std::to_string(hbad[1]) + (T->quad ? ": quad form" : (T->usable ? ": strip form" : ": general form")));
   if (!T->usable) {
     if (T->cols) (void)hipFree(T->cols);
     if (T->rows) (void)hipFree(T->rows);
@@ -808,21 +827,21 @@ void buildBhTables(const PassLaunch& L, hipStream_t s, BhTables* T) {
   }
 }
 
-// Where each wave's run of (frame, band, row) steps begins for a launch of n_frames frames on n_waves waves: runs of equal
-// estimated cost (n_waves + 1 entries in device memory, built once per (n_frames, n_waves) and kept with the tables).
-const uint32_t* bhRuns(BhTables* T, int n_frames, int n_waves) {
+// Where each wave's run of steps begins for a launch of n_frames frames (frame pairs, for the quad form) on n_waves waves: runs of
+// equal estimated cost (n_waves + 1 entries in device memory, built once per (n_frames, n_waves) and kept with the tables).
+const uint32_t* costRuns(const std::vector<uint32_t>& cost_sum, std::map<std::pair<int, int>, uint32_t*>& cache, int n_frames, int n_waves) {
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
-  auto it = T->runs.find({n_frames, n_waves});
-  if (it != T->runs.end()) return it->second;
-  const size_t per_frame = T->cost_sum.size() - 1;
-  const uint64_t frame_cost = T->cost_sum.back(), total = frame_cost * (uint64_t)n_frames;
+  auto it = cache.find({n_frames, n_waves});
+  if (it != cache.end()) return it->second;
+  const size_t per_frame = cost_sum.size() - 1;
+  const uint64_t frame_cost = cost_sum.back(), total = frame_cost * (uint64_t)n_frames;
   std::vector<uint32_t> h((size_t)n_waves + 1);
   for (int w = 0; w <= n_waves; ++w) {
     const uint64_t target = total * (uint64_t)w / (uint64_t)n_waves;
     const uint64_t z = std::min<uint64_t>(target / frame_cost, (uint64_t)n_frames), rem = target - z * frame_cost;
     // first step of frame z whose running cost reaches `rem`
-    const size_t i = (size_t)(std::lower_bound(T->cost_sum.begin(), T->cost_sum.end(), (uint32_t)rem) - T->cost_sum.begin());
+    const size_t i = (size_t)(std::lower_bound(cost_sum.begin(), cost_sum.end(), (uint32_t)rem) - cost_sum.begin());
     h[(size_t)w] = (uint32_t)(z * per_frame + std::min(i, per_frame));
   }
   h[(size_t)n_waves] = (uint32_t)(per_frame * (size_t)n_frames);
@@ -832,8 +851,48 @@ const uint32_t* bhRuns(BhTables* T, int n_frames, int n_waves) {
     (void)hipFree(d);
     return nullptr;
   }
-  T->runs[{n_frames, n_waves}] = d;
+  cache[{n_frames, n_waves}] = d;
   return d;
+}
+const uint32_t* bhRuns(BhTables* T, int n_frames, int n_waves) { return costRuns(T->cost_sum, T->runs, n_frames, n_waves); }
+
+#ifndef RC_BQ_COST_TWO
+#define RC_BQ_COST_TWO 26
+#endif
+// The quad form's step list of one frame pair (pass_royale_bloom_quad.hip): bands in order, rows in blocks of kBhBlockRows, a block
+// the diagonal crosses once per triangle; per step its row quantities, whether a (band, triangle) segment begins, and the
+// running cost (a row with a vertical weight filters two source rows).  `hr`: the rows table on the host.
+bool buildBqSteps(const PassLaunch& L, const std::vector<uint32_t>& hr, BhTables* T) {
+  const int W = L.out_w, H = L.out_h, bands = (W + 127) / 128;
+  if (H > 4095 || L.extra[2].h > 1021 || bands > 64 || L.extra[0].h > 65535 || L.extra[1].h > 65535) return false;
+  auto lower = [&](int x, int y) { return (long)(2 * y + 1) * W <= (long)(2 * x + 1) * H; };
+  std::vector<uint32_t> st;
+  T->qcost_sum.assign(1, 0u);
+  for (int b = 0; b < bands; ++b) {
+    int last_side = -1;
+    for (int yb = 0; yb < H; yb += kBhBlockRows) {
+      const int ye = std::min(H, yb + kBhBlockRows), xw = b * 128, xmax = std::min(xw + 127, W - 1);
+      const bool all_lo = lower(xw, ye - 1), all_up = !lower(xmax, yb), mixed = !all_lo && !all_up;
+      for (int side = all_up ? 1 : 0; side <= (all_lo ? 0 : 1); ++side)
+        for (int y = yb; y < ye; ++y) {
+          const uint32_t* r = &hr[((size_t)y * 2 + side) * BH_ROW_FIELDS];
+          const int y0 = (int)r[BH_Y0], hal_y0 = (int)r[BH_HAL_Y0];
+          if (y0 < y - 1 || y0 > y || hal_y0 < -1) return false;
+          // a segment begins with the band, when the triangle changes, and at the second rendering of a block (its source rows once more)
+          const bool newseg = side != last_side || (mixed && y == yb);
+          last_side = side;
+          st.push_back((uint32_t)y | ((uint32_t)(hal_y0 + 1) << 12) | ((uint32_t)side << 22) | ((mixed ? 1u : 0u) << 23) | ((newseg ? 1u : 0u) << 24) |
+                       ((y0 == y - 1 ? 1u : 0u) << 25) | ((uint32_t)b << 26));
+          st.push_back(r[BH_IDIM_Y] | (r[BH_BRIGHT_Y] << 16));
+          st.push_back(r[BH_WY]);
+          st.push_back(r[BH_HAL_WY]);
+          T->qcost_sum.push_back(T->qcost_sum.back() + (bits2f(r[BH_WY]) != 0.0f ? (uint32_t)RC_BQ_COST_TWO : 20u));
+        }
+    }
+  }
+  T->n_qsteps = (int)(st.size() / 4);
+  return hipMalloc(reinterpret_cast<void**>(&T->qsteps), st.size() * 4) == hipSuccess &&
+         hipMemcpy(T->qsteps, st.data(), st.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
 }
 
 }  // namespace
@@ -884,6 +943,16 @@ hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
         // one workgroup per CU; every wave gets a run of (frame, band, row) steps of equal estimated cost
         const long steps = (long)((L.out_w + 127) / 128) * L.out_h * L.n_frames;
         const long blocks = std::min<long>((steps + kBhWaves * 8 - 1) / (kBhWaves * 8), 256);
+        const uint64_t max_stride = std::max(std::max(L.in.frame_stride, L.out_frame_stride), std::max(std::max(L.extra[0].frame_stride, L.extra[1].frame_stride), L.extra[2].frame_stride));
+        if (T->quad && max_stride * (uint64_t)L.n_frames < (1ull << 31)) {
+          // two frames per wave: runs of (frame pair, band, triangle, row) steps
+          const int n_pairs = (L.n_frames + 1) / 2;
+          const uint64_t qsteps = (uint64_t)T->n_qsteps * (uint64_t)n_pairs;
+          const long qblocks = (long)std::min<uint64_t>((qsteps + (uint64_t)bq_waves() * 8 - 1) / ((uint64_t)bq_waves() * 8), 256);
+          BhTables* Tm = const_cast<BhTables*>(T);
+          const uint32_t* qruns = qsteps < (1ull << 32) ? costRuns(Tm->qcost_sum, Tm->qruns, n_pairs, (int)qblocks * bq_waves()) : nullptr;
+          if (qruns) return launch_bloom_h_quad(L, s, T->cols, T->qsteps, T->n_qsteps, qruns, (unsigned)qblocks, T->quad_taps);
+        }
         const uint32_t* runs = (uint64_t)steps < (1ull << 32) ? bhRuns(const_cast<BhTables*>(T), L.n_frames, (int)blocks * kBhWaves) : nullptr;
         if (!runs) GO(k_royale_bloom_h<SrgbLinEdge, SrgbNearEdge, SrgbNearEdge, SrgbLinEdge, OutS>);
         const unsigned lds = kBhLdsUser + (unsigned)(kBhWaves * kBhWaveDwords) * 4u;

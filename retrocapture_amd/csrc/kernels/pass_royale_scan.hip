@@ -800,10 +800,6 @@ const ScanTables* scanTablesFor(const PassLaunch& L, hipStream_t s) {
   RC_LOG_DEBUG("crt-royale scanline pass " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h) + ": expansion tables " +
                (T.usable ? "in use (" + std::to_string(n_dists) + " row distances)"
                          : "not usable (geometry flags " + std::to_string(hbad) + ", " + std::to_string(n_dists) + " row distances), exact per-pixel form"));
-  if (std::getenv("RC_DEBUG_SCAN"))
-    std::fprintf(stderr, "[rc scan-v] %dx%d: usable %d flags %u, %zu row distances; largest K per role %.3g %.3g %.3g | %.3g %.3g %.3g | %.3g %.3g %.3g\n", L.out_w, L.out_h,
-                 (int)T.usable, hbad, n_dists, T.nodes.kmax[0], T.nodes.kmax[1], T.nodes.kmax[2], T.nodes.kmax[3], T.nodes.kmax[4], T.nodes.kmax[5], T.nodes.kmax[6],
-                 T.nodes.kmax[7], T.nodes.kmax[8]);
   if (!T.usable) {
     freeScanNodeTables(&T.nodes);
     if (T.rows) (void)hipFree(T.rows);
