@@ -531,6 +531,9 @@ def main():
     avg_ms = p["total_ms"] / max(1, p["launches"])
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     chain_bytes = sum(q["read_bytes_per_frame"] + q["write_bytes_per_frame"] for q in prof)
+    # ... of which the passes that were launched move (a pass folded into its consumers - crt-royale's pass 0, a byte map at 1:1 -
+    # keeps its algorithmic bytes in `chain_bytes`, SURVEY section 8d's figure, but moves none)
+    moved_bytes = sum(q["read_bytes_per_frame"] + q["write_bytes_per_frame"] for q in prof if not q.get("folded"))
 
     value = aggregate([args.batch] * world, args.steps, dt)
     # the same with pass 6's unwritten varying read as 0 (GPU GL drivers): the phosphor mask is rendered and passes 7-10
@@ -665,6 +668,8 @@ def main():
                    "chunk_frames": args.chunk or "default", "parallelism": "frames sharded, no collective",
                    "mask_mode": "rendered (rc_engine_set_undefined_varying_zero)" if args.modes == "mask" else "llvmpipe (pass 6 discards)",
                    "algorithmic_bytes_per_frame": chain_bytes,
+                   "bytes_moved_per_frame": moved_bytes,
+                   "folded_passes": [i for i, q in enumerate(prof) if q.get("folded")],
                    "hbm_roofline_frac_whole_chain": value / world * chain_bytes / (HBM_PEAK_GBS * 1e9),
                    "stream_copy_ceiling_GBs": ceiling,
                    "copy_ceiling_frac_whole_chain": value / world * chain_bytes / (ceiling * 1e9)},

@@ -129,6 +129,8 @@ typedef struct {
   uint64_t frames;
   uint64_t read_bytes_per_frame;
   uint64_t write_bytes_per_frame;
+  uint32_t folded;     /* 1: the pass was folded into its consumers for the last chunk (rc_engine_set_fold_passes): no launch, no bytes moved */
+  uint32_t reserved;
 } rc_pass_profile;
 void rc_engine_set_profiling(rc_engine* e, int on);
 int rc_engine_pass_profile(rc_engine* e, int pass, rc_pass_profile* out);
@@ -165,6 +167,12 @@ int rc_engine_read_history(rc_engine* e, int k, uint32_t* width, uint32_t* heigh
  * rules once per source pixel when the sampling pattern allows it).  Both forms give identical
  * results; 1 forces the general form (diagnostics / tests).  Default 0. */
 void rc_engine_set_general_kernels_only(rc_engine* e, int general_only);
+/* A pass whose target is, byte for byte, a per-channel map of its input's bytes (crt-royale's first pass at 1:1: gamma 2.5
+ * through an sRGB8 target) is folded into its consumers: it is not rendered, the passes that sample its target read its input
+ * through the composed decode table - the same values, so every other pass's bytes are unchanged (tests).  Default 1.
+ * rc_engine_read_pass of a folded pass renders it on demand from the input frames of the last apply call, which the
+ * caller must still hold; rc_pass_profile::folded tells.  0 renders every pass. */
+void rc_engine_set_fold_passes(rc_engine* e, int on);
 /* float_framebuffer render targets (the reference creates GL_RGBA32F, ShaderEngine.cpp:2872-2923) stored as
  * four binary16 values per texel instead: 8 bytes instead of 16 (ntsc-256px-svideo at 1080p: 45.9 -> 28.2 MB of
  * algorithmic bytes per frame).  Every pass still computes in float; a store to such a target rounds to nearest

@@ -62,6 +62,14 @@ struct KernelEntry {
   bool texture_height_override = false;
   // validate with the whole launch in view (input texture state, target format): a reason, or nullptr to go ahead
   const char* (*validate_launch)(const rcd::PassLaunch& L) = nullptr;
+  // Folding a pass into its consumers (shader_engine.cpp runChunk).  Producer side: returns true if, for this launch, the pass
+  // stores a per-channel byte map of its input's texel under each pixel with alpha 255 into an sRGB8 target, and fills
+  // d_dec256[byte] with the target's decode of the mapped byte and d_dec256[256 + byte] with the mapped byte (rcd::kFoldedTableWords
+  // words in device memory, written on `s`).
+  bool (*byte_map)(const rcd::PassLaunch& L, hipStream_t s, float* d_dec256) = nullptr;
+  // Consumer side: which of the kernel's textures may be such a never-written target, read through rcd::Tex::dec instead
+  // (bit 0: `Texture`, bit 1 + s: samplers[s]); the kernel samples no other sRGB8 texture.
+  uint32_t decode_table_inputs = 0;
 };
 
 const KernelEntry* findKernel(const std::string& shaderPath);

@@ -79,6 +79,7 @@ hipError_t launch_glow_blur_v(const PassLaunch& L, hipStream_t s);
 hipError_t launch_crt_hyllian_glow(const PassLaunch& L, hipStream_t s);
 hipError_t launch_hyllian_resolve2(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_first(const PassLaunch& L, hipStream_t s);
+bool royale_first_byte_map(const PassLaunch& L, hipStream_t s, float* d_dec256);   // KernelEntry::byte_map
 hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_bloom_approx(const PassLaunch& L, hipStream_t s);
 hipError_t launch_blur9(const PassLaunch& L, hipStream_t s);

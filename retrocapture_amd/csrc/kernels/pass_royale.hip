@@ -132,6 +132,14 @@ __global__ void __launch_bounds__(256) k_royale_first_copy(const PassLaunch L, c
     reinterpret_cast<uint4*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z)[q] = make_uint4(m(p.x), m(p.y), m(p.z), m(p.w));
   }
 }
+// the decoded value of the byte this pass would store for source byte t in an sRGB8 target (royale_first_byte_map)
+__global__ void __launch_bounds__(256) k_first_decode_table(const PassLaunch L, float* dec) {
+  RC_SRGB_LDS(lds, L);
+  const int t = (int)threadIdx.x;
+  const uint32_t byte = srgb8(pow_((float)t * (1.0f / 255.0f), 2.5f), &lds);
+  dec[t] = k_srgb_decode[byte];
+  reinterpret_cast<uint32_t*>(dec)[256 + t] = byte;
+}
 void buildFirstTables(const PassLaunch& L, hipStream_t s, FirstTables* T) {
   uint32_t* bad = nullptr;
   bool ok = hipMalloc(reinterpret_cast<void**>(&T->map), 1024) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&bad), 4) == hipSuccess;
@@ -156,7 +164,7 @@ void buildFirstTables(const PassLaunch& L, hipStream_t s, FirstTables* T) {
 // bloom-approx.glsl FS 14053-14184: the only live statement samples extra[0] at tex_uv.
 template <class S0, class SO>
 __global__ void __launch_bounds__(256) k_royale_bloom_approx(const PassLaunch L) {
-  RC_SRGB_LDS(lds, L);
+  RC_SRGB_LDS_OF(lds, L, L.extra[0]);
   RC_TILE_LOOP_BEGIN
   const float u = vary(L.plane[0], x, y, lo), v = vary(L.plane[1], x, y, lo);
   SO::put(L, z, x, y, S0::get(L.extra[0], frame_ptr(L.extra[0], z), u, v, &lds), &lds);
@@ -1355,6 +1363,20 @@ const float4* royale_last_gamma_table(float inv_gamma, hipStream_t s) {
     hipLaunchKernelGGL(kernel, px_grid(L), px_block(), rcd::srgb_lds_bytes(L), s, L);      \
     return hipGetLastError();                                         \
   }
+// KernelEntry::byte_map of pass 0: at 1:1 on a progressive 8-bit NEAREST source with an sRGB8 target the pass stores
+// map[byte] per channel and alpha 255 (k_royale_first_copy); then d_dec256[byte] = the target's decode of map[byte], and the pass
+// need not run for consumers that read the source through that table (rcd::kFoldedTableWords words: the mapped bytes follow).
+bool royale_first_byte_map(const PassLaunch& L, hipStream_t s, float* d_dec256) {
+  const bool bytes_in = (L.in.fmt == FMT_RGBX8 || L.in.fmt == FMT_RGBA8) && !L.in.linear && L.in.wrap == WRAP_EDGE && L.in.n_levels <= 1;
+  if (!bytes_in || L.params[RP0_INTERLACED] != 0.0f || (L.flags & RC_FLAG_GENERAL_ONLY) || L.out_fmt != FMT_SRGB8 || L.in.w != L.out_w ||
+      L.in.h != L.out_h || !rcstrip::separable(L, 0, 1))
+    return false;
+  static std::mutex mu;
+  static std::map<rcstrip::GeoKey, rcstrip::GeoCached<FirstTables>> cache;
+  if (!rcstrip::geo_tables<FirstTables>(L, s, mu, cache, buildFirstTables)) return false;   // (k_first_identity: every pixel's texel is the one under it)
+  hipLaunchKernelGGL(k_first_decode_table, dim3(1), dim3(256), rcd::srgb_lds_bytes(L), s, L, d_dec256);
+  return hipGetLastError() == hipSuccess;
+}
 hipError_t launch_royale_first(const PassLaunch& L, hipStream_t s) {
   const bool bytes_in = (L.in.fmt == FMT_RGBX8 || L.in.fmt == FMT_RGBA8) && !L.in.linear && L.in.wrap == WRAP_EDGE;
   if (bytes_in && L.params[RP0_INTERLACED] == 0.0f && !(L.flags & RC_FLAG_GENERAL_ONLY)) {

@@ -91,7 +91,7 @@ __device__ __forceinline__ F beam_k(F color, F dist, float off, float sigma_rang
 
 template <class SI, class SO>
 __global__ void __launch_bounds__(256, 4) k_royale_scan_v(const PassLaunch L) {
-  RC_SRGB_LDS(lds, L);
+  RC_SRGB_LDS_OF(lds, L, L.in);
   RC_TILE_LOOP_BEGIN
   const float tsx = (float)L.in.w, tsy = L.params[RP1_TSY];   // TextureSize.y as the reference sets it (royale_setup.cpp)
   const float y_step = L.params[RP1_Y_STEP], uv_step_y = L.params[RP1_UV_STEP_Y], ph = L.params[RP1_PH];
@@ -177,7 +177,7 @@ __device__ __forceinline__ void scan_v_gather(const PassLaunch& L, const SrgbLds
 // (rc_vecmath.h).  Tiles are 64 x 8; a wave still stores 256 contiguous bytes per row.  Same results as k_royale_scan_v.
 template <class SI, class SO>
 __global__ void __launch_bounds__(256, 4) k_royale_scan_v2(const PassLaunch L) {
-  RC_SRGB_LDS(lds, L);
+  RC_SRGB_LDS_OF(lds, L, L.in);
   const int tiles_x = (L.out_w + 63) >> 6, tiles_y = (L.out_h + 7) >> 3;
   const int tiles_per_frame = tiles_x * tiles_y, n_tiles = tiles_per_frame * L.n_frames;
   const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
@@ -444,8 +444,13 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
   extern __shared__ uint32_t rc_dyn_lds_[];
   if ((uint32_t)(uintptr_t)(RC_AS3 uint32_t*)rc_dyn_lds_ != 0u) __builtin_trap();   // absolute LDS offsets
   const int tid = (int)threadIdx.x;
-  for (int i = tid; i < 9 * kNodes; i += kTabThreads) reinterpret_cast<float4*>(rc_dyn_lds_)[i] = gA[i];
-  for (int i = tid; i < 256; i += kTabThreads) rc_dyn_lds_[kLdsDec / 4 + i] = f2bits(k_srgb_decode[i]);
+  // (a folded pass 0: the texels are SOURCE bytes, and a byte's node is the node of the byte pass 0 would have stored for it)
+  const uint32_t* bmap = L.in.dec ? reinterpret_cast<const uint32_t*>(L.in.dec) + 256 : nullptr;
+  for (int i = tid; i < 9 * kNodes; i += kTabThreads) {
+    const int n = i % kNodes;
+    reinterpret_cast<float4*>(rc_dyn_lds_)[i] = gA[bmap && n >= kLogNodes ? i - n + kLogNodes + (int)bmap[n - kLogNodes] : i];
+  }
+  for (int i = tid; i < 256; i += kTabThreads) rc_dyn_lds_[kLdsDec / 4 + i] = f2bits(L.in.dec ? L.in.dec[i] : k_srgb_decode[i]);   // (a folded pass 0: its composed table)
   for (int i = tid; i < (int)kSrgb2Runs; i += kTabThreads) rc_dyn_lds_[kLdsEnc2 / 4 + i] = L.srgb_enc[kSrgbRuns + i];
   __syncthreads();
   const int W = L.out_w, H = L.out_h;
@@ -597,7 +602,7 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
 // The listed pixels in the general form (k_royale_scan_v's arithmetic: four packed pairs and one scalar evaluation).
 template <class SI, class SO>
 __global__ void __launch_bounds__(256) k_royale_scan_v_fix(const PassLaunch L) {
-  RC_SRGB_LDS(lds, L);
+  RC_SRGB_LDS_OF(lds, L, L.in);
   const float sigma_range = maxps(0.3f, 0.02f) - 0.02f, shape_range = maxps(4.0f, 2.0f) - 2.0f;
   const float off = L.params[RP1_PH] / 3.0f;
   const uint32_t stride = gridDim.x * 256u;

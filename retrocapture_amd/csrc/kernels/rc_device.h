@@ -34,6 +34,13 @@ struct Tex {
   int n_levels = 0;
   const void* mip_base = nullptr;
   uint64_t mip_frame_stride = 0;
+  // A folded pass (shader_engine.cpp runChunk): the texture is an sRGB8 render target that was never written - its bytes
+  // would be a per-channel byte map of the bytes at `base` (crt-royale's pass 0 at 1:1), so a consumer reads `base` and
+  // takes `dec[byte]` (256 floats, device memory: the target's decode of the mapped byte) for the target's decoded texel,
+  // alpha 1; the mapped byte itself - the byte the target would hold - follows as 256 words (`dec + 256`, kFoldedTableWords in
+  // all).  Only kernels registered with KernelEntry::decode_table_inputs are handed such a texture.
+  const float* dec = nullptr;
+  int alpha_one = 0;
 };
 
 // Plane equation of one varying for the two triangles of the quad (see host varying.cpp).
@@ -47,6 +54,7 @@ constexpr int RC_FLAG_STOCK_NO_BLIT = 1 << 17; // stock.glsl: the ordinary sampl
 constexpr int RC_FLAG_XBR_REGULAR = 1 << 8;
 constexpr int RC_FLAG_NTSC_REGULAR = 1 << 9; // ntsc pass 2: tap k of target column x reads source column c(x)+k-24, c(x+1) = c(x)+2  // xbr: sampled columns/rows are centre-2..centre+2 for every target pixel
 
+constexpr int kFoldedTableWords = 512;   // Tex::dec: 256 floats, then 256 mapped bytes
 constexpr int kMaxExtra = 8;
 constexpr int kMaxPlanes = 12;
 constexpr int kMaxParams = 80;
@@ -249,11 +257,11 @@ __host__ __device__ inline bool srgb_enc_in_lds(const PassLaunch& L) {
 }
 inline unsigned srgb_lds_bytes(const PassLaunch& L) { return 1024u + (srgb_enc_in_lds(L) ? kSrgbRuns * 4u : 0u); }
 // Every thread of the block must call this (RC_SRGB_LDS) before sampling sRGB textures / storing sRGB.
-__device__ __forceinline__ SrgbLds load_srgb_tables(uint32_t* dyn, const PassLaunch& L) {
+__device__ __forceinline__ SrgbLds load_srgb_tables(uint32_t* dyn, const PassLaunch& L, const float* dec_from = nullptr) {
   float* dec = reinterpret_cast<float*>(dyn);
   const uint32_t* enc = L.srgb_enc;
   const int nt = blockDim.x * blockDim.y, t0 = threadIdx.y * blockDim.x + threadIdx.x;
-  for (int i = t0; i < 256; i += nt) dec[i] = k_srgb_decode[i];
+  for (int i = t0; i < 256; i += nt) dec[i] = dec_from ? dec_from[i] : k_srgb_decode[i];   // (dec_from: Tex::dec of the one sRGB8 texture the kernel samples)
   if (srgb_enc_in_lds(L)) {
     for (int i = t0; i < (int)kSrgbRuns; i += nt) dyn[256 + i] = L.srgb_enc[i];
     enc = dyn + 256;
@@ -264,6 +272,10 @@ __device__ __forceinline__ SrgbLds load_srgb_tables(uint32_t* dyn, const PassLau
 #define RC_SRGB_LDS(name, L)                  \
   extern __shared__ uint32_t rc_dyn_lds_[];   \
   const rcd::SrgbLds name = rcd::load_srgb_tables(rc_dyn_lds_, (L))
+// ... for a kernel whose only sRGB8 texture is `tex`, which may be a folded pass's view (Tex::dec)
+#define RC_SRGB_LDS_OF(name, L, tex)          \
+  extern __shared__ uint32_t rc_dyn_lds_[];   \
+  const rcd::SrgbLds name = rcd::load_srgb_tables(rc_dyn_lds_, (L), (tex).dec)
 
 // ------------------------------------------------------------------------------ sampling ----
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -299,7 +311,7 @@ __device__ __forceinline__ float4 texel(const Tex& t, const uint8_t* img, int x,
   uint32_t p = *reinterpret_cast<const uint32_t*>(img + texel_off(t.w, x, y, 4u));
   const float k = 1.0f / 255.0f;
   uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u, a = p >> 24;
-  if (FMT == FMT_SRGB8) return make_float4(lds->dec[r], lds->dec[g], lds->dec[b], (float)a * k);
+  if (FMT == FMT_SRGB8) return make_float4(lds->dec[r], lds->dec[g], lds->dec[b], t.alpha_one ? 1.0f : (float)a * k);
   if (FMT == FMT_RGBX8) return make_float4((float)r * k, (float)g * k, (float)b * k, 1.0f);
   return make_float4((float)r * k, (float)g * k, (float)b * k, (float)a * k);
 }

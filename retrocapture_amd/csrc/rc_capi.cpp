@@ -242,6 +242,7 @@ int rc_engine_pass_profile(rc_engine* e, int pass, rc_pass_profile* out) {
     out->launches = prof[(size_t)pass].launches;
     out->frames = prof[(size_t)pass].frames;
     e->impl.passBytes((size_t)pass, &out->read_bytes_per_frame, &out->write_bytes_per_frame);
+    out->folded = e->impl.passFolded((size_t)pass) ? 1u : 0u;
     return (int)RC_OK;
   });
 }
@@ -432,6 +433,9 @@ int rc_engine_read_history(rc_engine* e, int k, uint32_t* width, uint32_t* heigh
 }
 void rc_engine_set_general_kernels_only(rc_engine* e, int general_only) {
   if (e) e->impl.setGeneralKernelsOnly(general_only != 0);
+}
+void rc_engine_set_fold_passes(rc_engine* e, int on) {
+  if (e) e->impl.setFoldPasses(on != 0);
 }
 void rc_engine_set_float_target_fp16(rc_engine* e, int on) {
   if (e) e->impl.setFloatTargetFp16(on != 0);

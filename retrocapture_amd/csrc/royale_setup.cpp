@@ -431,6 +431,10 @@ void registerRoyaleKernels(std::vector<KernelEntry>& r) {
   for (auto& e : r) {
     const std::string n = e.name;
     if (n == "royale-bloom-approx" || n == "royale-mask-v") e.reads_input = false;
+    // pass 0 at 1:1 is a byte map: its two consumers read the source frame through the composed decode table instead
+    if (n == "royale-first") e.byte_map = rck::royale_first_byte_map;
+    if (n == "royale-scanlines-v") e.decode_table_inputs = 1u;        // Texture
+    if (n == "royale-bloom-approx") e.decode_table_inputs = 1u << 1;  // PassPrev2Texture
   }
 }
 

@@ -482,6 +482,7 @@ bool ShaderEngine::ensureBuffer(DeviceBuffer& b, size_t bytes) {
 // keeps its creation state, LINEAR + CLAMP_TO_EDGE (:2903-2906).
 rcd::Tex ShaderEngine::passTexture(size_t p) const {
   const ShaderPassData& pd = m_passes[p];
+  if (pd.folded) return pd.foldedView;   // (never written this chunk: the pass's input, seen through its decode table)
   rcd::Tex t;
   t.base = pd.target.ptr;
   t.frame_stride = pd.invariant ? 0 : pd.frameBytes;
@@ -617,6 +618,39 @@ bool ShaderEngine::presetSamplesFeedback() const {
       for (const char* s : p.kernel->samplers)
         if (std::strncmp(s, "PassFeedback", 12) == 0) return true;
   return false;
+}
+
+// Whether every later pass that samples pass i's target does so through a texture its kernel can read with a decode table
+// (KernelEntry::decode_table_inputs) - the static side of bindSamplers: the next pass's `Texture`, PassPrev<n> / Prev names, the
+// alias; PassFeedback, frame history through pass 0, a mip chain on the target and a program-less consumer all rule folding out.
+bool ShaderEngine::consumersTakeDecodeTable(size_t i) const {
+  if (i + 1 >= m_passes.size() || m_passes[i].feedbackEnabled || presetSamplesFeedback()) return false;
+  if (i == 0 && presetSamplesHistory()) return false;
+  if (m_passes[i + 1].passInfo.mipmapInput) return false;
+  for (size_t j = i + 1; j < m_passes.size(); ++j) {
+    const KernelEntry* kj = m_passes[j].kernel;
+    if (!kj) {
+      if (j == i + 1) return false;   // (its cleared target replaces the chain's texture; keep the ordinary path)
+      continue;
+    }
+    if (j == i + 1 && kj->reads_input && !(kj->decode_table_inputs & 1u)) return false;
+    const std::string& al = m_passes[i].passInfo.alias;
+    for (size_t s = 0; s < kj->samplers.size() && s < (size_t)rcd::kMaxExtra; ++s) {
+      const std::string n = kj->samplers[s];
+      const bool names_i = n == "PassPrev" + std::to_string(j - i) + "Texture" || n == prevName((int)i) || (!al.empty() && n == al);
+      // a sampler left unbound reads unit 0, the pass's own input (bindSamplers): for the next pass that is this target too
+      bool unbound = j == i + 1;
+      if (unbound) {
+        for (size_t pp = 0; pp < j && unbound; ++pp)
+          unbound = !(n == "PassPrev" + std::to_string(j - pp) + "Texture" || n == prevName((int)pp) ||
+                      (!m_passes[pp].passInfo.alias.empty() && n == m_passes[pp].passInfo.alias));
+        for (size_t q = j + 1; q <= j + 12 && unbound; ++q) unbound = n != "PassPrev" + std::to_string(q) + "Texture";
+        if (n == "OrigTexture" || m_textureReferences.count(n) || n.rfind("PassFeedback", 0) == 0) unbound = false;
+      }
+      if ((names_i || unbound) && !(kj->decode_table_inputs & (1u << (1 + s)))) return false;
+    }
+  }
+  return true;
 }
 
 bool ShaderEngine::bindSamplers(size_t i, const KernelEntry& k, const rcd::Tex& inputTex, const rcd::Tex& sourceTex,
@@ -760,6 +794,7 @@ bool ShaderEngine::syncHelper() {
   o.m_inputLinear = m_inputLinear;
   o.m_undefVaryingZero = m_undefVaryingZero;
   o.m_generalOnly = m_generalOnly;
+  o.m_foldPasses = m_foldPasses;
   o.m_floatTargetFp16 = m_floatTargetFp16;
   o.m_chunk = m_chunk;
   o.m_chunkAuto = m_chunkAuto;
@@ -853,8 +888,12 @@ const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames,
   const bool twoLanes = m_lanes == 2 && !m_externalOut && !history && !feedback && !m_profiling && nFrames >= 2 && syncHelper();
   const uint32_t nOwn = twoLanes ? (nFrames + 1) / 2 : nFrames;
   const uint32_t chunk = (history || feedback) ? 1u : std::min(chunkFrames, nOwn);
-  for (size_t i = 0; i + 1 < m_passes.size(); ++i)
-    if (!ensureBuffer(m_passes[i].target, m_passes[i].frameBytes * chunk)) return inputs;
+  m_chunkCapacity = chunk;
+  for (size_t i = 0; i + 1 < m_passes.size(); ++i) {
+    // (a pass that may be folded into its consumers gets its target when it is first rendered: runChunk, readPass)
+    const bool mayFold = m_foldPasses && !m_generalOnly && m_passes[i].kernel && m_passes[i].kernel->byte_map && consumersTakeDecodeTable(i);
+    if (!mayFold && !ensureBuffer(m_passes[i].target, m_passes[i].frameBytes * chunk)) return inputs;
+  }
   ShaderPassData& lastPass = m_passes.back();
   if (!m_externalOut && !ensureBuffer(lastPass.target, lastPass.frameBytes * nFrames)) return inputs;
   uint8_t* const outBase = m_externalOut ? m_externalOut : static_cast<uint8_t*>(lastPass.target.ptr);
@@ -1173,6 +1212,48 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
           return false;
         }
       }
+      // safety net of consumersTakeDecodeTable: a folded pass's view must only reach a slot whose kernel reads it through the table
+      {
+        bool ok = !(k.reads_input && L.in.dec && !(k.decode_table_inputs & 1u));
+        for (size_t s2 = 0; s2 < k.samplers.size() && s2 < (size_t)rcd::kMaxExtra; ++s2)
+          ok = ok && !(L.extra[s2].dec && !(k.decode_table_inputs & (1u << (1 + s2))));
+        if (!ok) {
+          RC_LOG_ERROR("pass " + std::to_string(i) + ": a folded pass's target reached a sampler that cannot read it");
+          return false;
+        }
+      }
+      // A pass that is a byte map of its input (KernelEntry::byte_map) is folded into its consumers: not rendered, they read its
+      // input through its decode table
+      pd.folded = false;
+      pd.deferredPending = false;
+      if (m_foldPasses && k.byte_map && !last && !m_generalOnly && !L.in.dec && consumersTakeDecodeTable(i) && ensureBuffer(pd.foldedDec, rcd::kFoldedTableWords * sizeof(float)) &&
+          k.byte_map(L, m_stream, static_cast<float*>(pd.foldedDec.ptr))) {
+        rcd::Tex view = passTexture(i);   // this pass's format, size and the sampler state its consumer sets
+        view.base = L.in.base;
+        view.frame_stride = L.in.frame_stride;
+        view.n_levels = 0;
+        view.mip_base = nullptr;
+        view.mip_frame_stride = 0;
+        view.dec = static_cast<const float*>(pd.foldedDec.ptr);
+        view.alpha_one = 1;
+        pd.foldedView = view;
+        pd.folded = true;
+        pd.deferred = L;
+        pd.deferredPending = true;
+        pd.invariant = false;
+        pd.invariantKey.clear();
+        pd.mipLevels = 0;
+        if (m_passReadBytes.size() != m_passes.size()) m_passReadBytes.assign(m_passes.size(), 0);
+        m_passReadBytes[i] = (uint64_t)L.in.w * L.in.h * texelBytes(L.in.fmt);   // (algorithmic: what the pass would read)
+        current = view;
+        continue;
+      }
+      if (!last && !pd.target.ptr) {   // a candidate for folding that is rendered after all: its target, left out by applyShaderBatch
+        if (!ensureBuffer(pd.target, pd.frameBytes * std::max(m_chunkCapacity, nFrames))) return false;
+        target = pd.target.ptr;
+        pd.lastWritten = target;
+        L.out = target;
+      }
       // Frame-invariant pass (see ShaderPassData::invariant): every texture it samples is shared by all frames
       bool servedFromCache = false;
       std::vector<uint8_t> invariantCandidate;
@@ -1294,8 +1375,17 @@ void ShaderEngine::passBytes(size_t i, uint64_t* readBytes, uint64_t* writeBytes
 
 bool ShaderEngine::readPass(size_t i, uint32_t frame, void* host, size_t bytes) {
   if (i >= m_passes.size() || !host) return false;
-  const ShaderPassData& pd = m_passes[i];
-  if (!pd.target.ptr || bytes < pd.frameBytes) return false;
+  ShaderPassData& pd = m_passes[i];
+  if (bytes < pd.frameBytes) return false;
+  if (pd.folded && pd.deferredPending) {
+    // the pass was folded into its consumers: render it now, from the input frames of the last call (still the caller's to keep)
+    if (!ensureBuffer(pd.target, pd.frameBytes * std::max<uint32_t>(m_chunkCapacity, (uint32_t)pd.deferred.n_frames))) return false;
+    pd.deferred.out = pd.target.ptr;
+    if (!hipOk(pd.kernel->launch(pd.deferred, m_stream), pd.kernel->name)) return false;
+    pd.lastWritten = pd.target.ptr;
+    pd.deferredPending = false;
+  }
+  if (!pd.target.ptr) return false;
   const bool last = (i + 1 == m_passes.size());
   // intermediates hold the last chunk only; the last pass holds the whole batch
   uint64_t index = frame;

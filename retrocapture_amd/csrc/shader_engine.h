@@ -62,6 +62,14 @@ struct ShaderPassData {  // reference ShaderEngine.h:19-40
   std::vector<uint8_t> invariantKey;
   uint64_t renderCount = 0;   // how often this pass has actually been rendered (a consumer's key includes its producers' counts)
   size_t frameBytes = 0;
+  // A pass folded into its consumers (runChunk, KernelEntry::byte_map): not rendered for the last chunk - its consumers read ITS
+  // input through `foldedView` (this pass's format and sampler state over the input's bytes, decoded through `foldedDec`).  The
+  // launch is kept, and rendered into `target` if somebody asks for the pass's own bytes (readPass).
+  bool folded = false;
+  DeviceBuffer foldedDec;       // rcd::kFoldedTableWords words (Tex::dec)
+  rcd::Tex foldedView;
+  rcd::PassLaunch deferred;
+  bool deferredPending = false;
   std::map<std::string, float> extractedParameters;
   std::map<std::string, ShaderParameterInfo> parameterInfo;
 };
@@ -139,6 +147,11 @@ class ShaderEngine {
   // GL drivers that zero undefined varyings, and the resized phosphor mask is rendered.
   void setUndefinedVaryingZero(bool zero) { m_undefVaryingZero = zero; }
   void setGeneralKernelsOnly(bool on) { m_generalOnly = on; }
+  // Fold passes that are byte maps of their input into their consumers (default on; crt-royale's pass 0 at 1:1): same bytes in
+  // every other pass.  A folded pass's own bytes are rendered on demand by readPass from the input frames of the last call,
+  // which must still be there.
+  void setFoldPasses(bool on) { m_foldPasses = on; }
+  bool passFolded(size_t i) const { return i < m_passes.size() && m_passes[i].folded; }
   // float_framebuffer targets stored as four binary16 values (8 bytes per texel) instead of RGBA32F: arithmetic stays
   // float, only the storage of those targets rounds.  Off by default (bit-exact); see DESIGN.md for the tolerance.
   void setFloatTargetFp16(bool on) { m_floatTargetFp16 = on; }
@@ -211,6 +224,9 @@ class ShaderEngine {
   bool m_allowMissingSources = false;
   bool m_undefVaryingZero = false;
   bool m_generalOnly = false;
+  bool m_foldPasses = true;
+  uint32_t m_chunkCapacity = 0;   // frames the intermediate targets are sized for (applyShaderBatch)
+  bool consumersTakeDecodeTable(size_t i) const;
   bool m_floatTargetFp16 = false;
   struct Vec4 { float x, y, z, w; };
   std::unordered_map<std::string, Vec4> m_uniforms;

@@ -38,7 +38,8 @@ class _RcPresentDesc(C.Structure):
 
 class _RcPassProfile(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("launches", C.c_uint64), ("frames", C.c_uint64),
-                ("read_bytes_per_frame", C.c_uint64), ("write_bytes_per_frame", C.c_uint64)]
+                ("read_bytes_per_frame", C.c_uint64), ("write_bytes_per_frame", C.c_uint64),
+                ("folded", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # every symbol include/rc_shaderchain.h declares: (name, restype, argtypes)
@@ -76,6 +77,7 @@ SYMBOLS = [
     ("rc_engine_set_allow_missing_sources", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_undefined_varying_zero", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_general_kernels_only", None, [C.c_void_p, C.c_int]),
+    ("rc_engine_set_fold_passes", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_float_target_fp16", None, [C.c_void_p, C.c_int]),
     ("rc_engine_history_count", C.c_int, [C.c_void_p]),
     ("rc_engine_read_history", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p,
@@ -504,7 +506,8 @@ class ShaderEngine:
         if self._lib.rc_engine_pass_profile(self._need(), int(i), C.byref(p)) != 0:
             raise RcError("passProfile failed: " + self._lib.rc_last_error().decode())
         return {"total_ms": p.total_ms, "launches": p.launches, "frames": p.frames,
-                "read_bytes_per_frame": p.read_bytes_per_frame, "write_bytes_per_frame": p.write_bytes_per_frame}
+                "read_bytes_per_frame": p.read_bytes_per_frame, "write_bytes_per_frame": p.write_bytes_per_frame,
+                "folded": bool(p.folded)}
 
     def setUndefinedVaryingZero(self, zero):
         self._lib.rc_engine_set_undefined_varying_zero(self._need(), int(bool(zero)))
@@ -526,6 +529,10 @@ class ShaderEngine:
     def setFloatTargetFp16(self, on):
         """float_framebuffer targets stored as binary16 (opt-in; default off = RGBA32F, bit-exact)."""
         self._lib.rc_engine_set_float_target_fp16(self._need(), int(bool(on)))
+
+    def setFoldPasses(self, on):
+        """Byte-map passes folded into their consumers (default on); off renders every pass."""
+        self._lib.rc_engine_set_fold_passes(self._need(), int(bool(on)))
 
     def setGeneralKernelsOnly(self, on):
         self._lib.rc_engine_set_general_kernels_only(self._need(), int(bool(on)))

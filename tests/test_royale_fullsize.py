@@ -210,3 +210,47 @@ def test_crt_royale_1080p_two_lanes_equal_one_lane(mask_rendered, preset_tree, r
     assert outs[0][0][..., :3].std() > 5
     one.shutdown()
     two.shutdown()
+
+
+def test_crt_royale_1080p_folded_first_pass_equals_rendered(preset_tree, rc_lib):
+    """Pass 0 at 1:1 is a byte map of the source (gamma 2.5 into an sRGB8 target): by default the engine does not render it -
+    passes 1 and 2 read the source frame through the composed decode table (rc_engine_set_fold_passes).  Every other pass must
+    hold the bytes it holds with pass 0 rendered, whatever the source's alpha bytes are (the reference's source texture is
+    GL_RGB, its pass 0 writes alpha 1); the folded pass's own bytes, rendered on demand by rc_engine_read_pass, are pass 0's;
+    and an interlaced-height source (pass 0 then blends fields: not a byte map) is not folded."""
+    import torch
+    from gpu_util import make_engine
+    n = 5
+    g = torch.Generator(device="cuda")
+    g.manual_seed(79)
+    frames = torch.randint(0, 256, (n, H, W, 4), dtype=torch.uint8, device="cuda", generator=g)   # alpha: noise too
+    frames[1, :, :, :3] = torch.from_numpy(bars(W, H, 6)).cuda()
+    frames[2, :, :, :3] = torch.from_numpy(smooth(W, H, 5)).cuda()
+    folded, plain = make_engine(preset_tree["crt-royale"], W, H), make_engine(preset_tree["crt-royale"], W, H)
+    plain.setFoldPasses(False)
+    for e in (folded, plain):
+        e.setProfiling(True)
+        e.applyShaderBatch(frames, n, W, H)
+        e.sync()
+    assert folded.passProfile(0)["folded"] and folded.passProfile(0)["launches"] == 0
+    assert not plain.passProfile(0)["folded"] and plain.passProfile(0)["launches"] == 1
+    assert not any(folded.passProfile(i)["folded"] for i in range(1, 12))
+    # the algorithmic byte counts do not change with folding
+    for i in range(12):
+        a, b = folded.passProfile(i), plain.passProfile(i)
+        assert (a["read_bytes_per_frame"], a["write_bytes_per_frame"]) == (b["read_bytes_per_frame"], b["write_bytes_per_frame"]), i
+    for k in range(n):
+        for i in range(11, -1, -1):   # pass 0 last: reading it renders it
+            a, b = folded.readPass(i, k), plain.readPass(i, k)
+            assert np.array_equal(a, b), "frame %d pass %d: %d differing bytes" % (k, i, int((a != b).sum()))
+    assert plain.readPass(0, 0)[..., 3].min() == 255 and plain.readPass(2, 0)[..., 3].min() == 255
+    folded.shutdown()
+    plain.shutdown()
+    # 480 source rows: is_interlaced, pass 0 bobs fields - rendered, not folded
+    e = make_engine(preset_tree["crt-royale"], 640, 480)
+    e.setProfiling(True)
+    small = torch.randint(0, 256, (2, 480, 640, 4), dtype=torch.uint8, device="cuda", generator=g)
+    e.applyShaderBatch(small, 2, 640, 480)
+    e.sync()
+    assert not e.passProfile(0)["folded"] and e.passProfile(0)["launches"] == 1
+    e.shutdown()
