@@ -453,6 +453,7 @@ def main():
     if not e.init(local, stream.cuda_stream):
         raise SystemExit("ShaderEngine.init failed (no HIP device; there is no CPU fallback)")
     e.setAllowMissingSources(True)
+    e.setAsyncTableBuilds(False)   # the timed region must not start on the general forms while a table build is still running
     st = e.loadPresetStatus(tree[key])
     if st != 0:
         raise SystemExit("preset %s not fully supported (status %d)" % (key, st))

@@ -173,6 +173,12 @@ void rc_engine_set_general_kernels_only(rc_engine* e, int general_only);
  * rc_engine_read_pass of a folded pass renders it on demand from the input frames of the last apply call, which the
  * caller must still hold; rc_pass_profile::folded tells.  0 renders every pass. */
 void rc_engine_set_fold_passes(rc_engine* e, int on);
+/* Some specialised forms need per-(geometry, parameter) tables that take a while to build - crt-royale's scanline pass proves
+ * its tables' error bounds by exhaustion, 140 ms at 1080p; crt-pi's two pow tables likewise per gamma setting.  By default (1)
+ * such a build runs on a worker thread with its own HIP stream and the pass renders with its general form - the same bytes -
+ * until the tables are ready: no apply call waits for it (the reference's callers move parameters from a UI slider and from
+ * HTTP threads).  0: the first frame of a new configuration waits for its tables (deterministic form selection: tests, benchmarks). */
+void rc_engine_set_async_table_builds(rc_engine* e, int on);
 /* float_framebuffer render targets (the reference creates GL_RGBA32F, ShaderEngine.cpp:2872-2923) stored as
  * four binary16 values per texel instead: 8 bytes instead of 16 (ntsc-256px-svideo at 1080p: 45.9 -> 28.2 MB of
  * algorithmic bytes per frame).  Every pass still computes in float; a store to such a target rounds to nearest
@@ -273,6 +279,10 @@ void rc_pipeline_set_image_adjust(rc_pipeline* p, float brightness, float contra
  * instruction: all 2^23 mantissas / 2^26 operand pairs / 6 x 2^24 quotients.  mismatches[0..2]
  * receive the counts (all 0 on a conforming device).  Returns RC_OK or RC_ERR_DEVICE. */
 int rc_selftest_fastmath(int device, uint64_t mismatches[3]);
+/* The device's streaming rate as a kernel reaches it: `reps` grid-stride copies of `bytes` bytes (a multiple of 16), 16 bytes
+ * per lane in and out, timed with HIP events on the null stream; *gb_per_s = read + written bytes per second / 1e9.  The
+ * ceiling the byte-moving passes are measured against beside the 8 TB/s vendor figure (bench.py). */
+int rc_selftest_copy_rate(int device, size_t bytes, int reps, double* gb_per_s);
 /* The sRGB8 encode of an sRGB render target (GL_FRAMEBUFFER_SRGB, reference ShaderEngine.cpp:944-952; the
  * conversion is the GL's: Mesa llvmpipe's RSQRTPS-based lp_build_linear_to_srgb, restated exactly in
  * csrc/srgb_encode.cpp) applied to a flat array of floats: with the host-side per-run table the kernels

@@ -225,7 +225,11 @@ __global__ void __launch_bounds__(kPiRows * 32) k_crt_pi_strip(const PassLaunch 
     uint32_t base = 0u;
     if (lane == 0) base = atomicAdd(fix_count, n_listed);
     base = __builtin_amdgcn_readfirstlane(base);
-    for (uint32_t i = (uint32_t)lane; i < n_listed; i += 64u) fix_list[base + i] = my_list[i];
+    // (called with the lanes beyond the frame's right edge switched off when the width is not a multiple of 64: the entries are
+    // dealt out over the lanes that ARE active - a stride of 64 over lane numbers would leave the others' entries unwritten)
+    const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+    const uint32_t n_act = (uint32_t)__builtin_popcountll(act), rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+    for (uint32_t i = rank; i < n_listed; i += n_act) fix_list[base + i] = my_list[i];
     asm volatile("" ::: "memory");
     n_listed = __builtin_amdgcn_readfirstlane(0u);
   };
@@ -340,14 +344,21 @@ __global__ void __launch_bounds__(kPiRows * 32) k_crt_pi_strip(const PassLaunch 
       const uint64_t any = __builtin_amdgcn_ballot_w64(failed != 0u);
       if (any == 0ull) break;
       const uint32_t n = (uint32_t)__builtin_popcountll(any);
-      if (__builtin_amdgcn_readfirstlane(n_listed) + n > (uint32_t)kPiWaveList) flush();
+      // The wave's count, taken HERE from the first active lane - lane 0, which takes part in every strip: a lane that sat out a
+      // strip beyond the frame's right edge (a width that is not a multiple of 64) still holds the count from before that strip in
+      // its own copy, and inside the branch below the first active lane is the first FAILING lane, which may be such a lane.
+      uint32_t cur = __builtin_amdgcn_readfirstlane(n_listed);
+      if (cur + n > (uint32_t)kPiWaveList) {
+        flush();
+        cur = 0u;
+      }
       if (failed) {
         const int kk = __builtin_ctz(failed);
         failed &= failed - 1u;
-        const uint32_t pos = n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+        const uint32_t pos = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
         my_list[pos] = (uint32_t)((z * H + ys + kk) * W + x);
       }
-      n_listed = __builtin_amdgcn_readfirstlane(n_listed + n);   // (kept scalar: lanes beyond the frame's right edge skip this code)
+      n_listed = cur + n;   // (kept scalar: lanes beyond the frame's right edge skip this code)
     }
   }
   flush();
@@ -412,7 +423,7 @@ hipError_t launch_crt_pi(const PassLaunch& L, hipStream_t s) {
     if (!(L.flags & RC_FLAG_GENERAL_ONLY) && L.scratch && rcstrip::separable(L, 0, 1) && (uint64_t)L.out_w * L.out_h * L.n_frames < (1ull << 32)) {
       static std::mutex mu;
       static std::map<rcstrip::GeoKey, rcstrip::GeoCached<CrtPiTables>> cache;
-      if (const CrtPiTables* T = rcstrip::geo_tables<CrtPiTables>(L, s, mu, cache, buildCrtPiTables)) {
+      if (const auto T = rcstrip::geo_tables<CrtPiTables>(L, s, mu, cache, buildCrtPiTables, true)) {   // (two exhaustive error sweeps per parameter set: a slow build)
         if (hipMemsetAsync(L.scratch, 0, kPiFixHeader, s) != hipSuccess) return hipGetLastError();
         auto same = [](const Plane& p) { return p.a0_lo == p.a0_up && p.dx_lo == p.dx_up && p.dy_lo == p.dy_up; };
         const bool one_plane = same(L.plane[0]) && same(L.plane[1]);

@@ -97,6 +97,7 @@ hipError_t launch_royale_last_general(const PassLaunch& L, hipStream_t s);   // 
 hipError_t launch_ingest(const void* src, int fmt, uint32_t w, uint32_t h, uint32_t n, void* dst_rgba8, hipStream_t s);
 hipError_t launch_egress_rgb24(const void* src_rgba8, uint32_t w, uint32_t h, uint32_t n, int flip_y, void* dst, hipStream_t s);
 hipError_t launch_selftest(unsigned long long* d_counts, hipStream_t s);
+hipError_t launch_selftest_copy(const void* d_src, void* d_dst, size_t bytes, hipStream_t s);   // a 16-byte-per-lane streaming copy
 // pass_royale_scan.hip: host-built expansion tables of the crt-royale scanline pass (tests)
 void royale_scan_tables_host(float off, float* A, uint32_t* B);
 int royale_scan_table_nodes();

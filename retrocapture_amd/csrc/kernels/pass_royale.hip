@@ -1385,7 +1385,7 @@ hipError_t launch_royale_first(const PassLaunch& L, hipStream_t s) {
         (L.in.frame_stride & 15u) == 0 && (reinterpret_cast<uintptr_t>(L.in.base) & 15u) == 0 && rcstrip::separable(L, 0, 1)) {
       static std::mutex mu;
       static std::map<rcstrip::GeoKey, rcstrip::GeoCached<FirstTables>> cache;
-      if (const FirstTables* T = rcstrip::geo_tables<FirstTables>(L, s, mu, cache, buildFirstTables)) {
+      if (const auto T = rcstrip::geo_tables<FirstTables>(L, s, mu, cache, buildFirstTables)) {
         const long quads = (long)(L.out_w * L.out_h / 4) * L.n_frames;
         const long blocks = (quads + 255) / 256;
         hipLaunchKernelGGL(k_royale_first_copy, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, L, T->map);
@@ -1428,7 +1428,7 @@ hipError_t launch_royale_scan_h(const PassLaunch& L, hipStream_t s) {
     if (!(L.flags & RC_FLAG_GENERAL_ONLY) && rcstrip::separable(L, 0, 2)) {
       static std::mutex mu;
       static std::map<rcstrip::GeoKey, rcstrip::GeoCached<ScanHTables>> cache;
-      if (const ScanHTables* T = rcstrip::geo_tables<ScanHTables>(L, s, mu, cache, buildScanHTables)) {
+      if (const auto T = rcstrip::geo_tables<ScanHTables>(L, s, mu, cache, buildScanHTables)) {
         const long strips = (long)((L.out_w + 127) / 128) * ((L.out_h + kShRows - 1) / kShRows) * L.n_frames;
         const long blocks = (strips + 7) / 8;
         hipLaunchKernelGGL(k_royale_scan_h_strip2, dim3((unsigned)(blocks < 768 ? blocks : 768)), dim3(512), rcstrip2::kStrip2LdsUser, s, L, T->cols, T->rows);
@@ -1451,7 +1451,7 @@ hipError_t launch_royale_brightpass(const PassLaunch& L, hipStream_t s) {
     if (!(L.flags & RC_FLAG_GENERAL_ONLY) && rcstrip::separable(L, 0, 2)) {
       static std::mutex mu;
       static std::map<rcstrip::GeoKey, rcstrip::GeoCached<BpTables>> cache;
-      if (const BpTables* T = rcstrip::geo_tables<BpTables>(L, s, mu, cache, buildBpTables)) {
+      if (const auto T = rcstrip::geo_tables<BpTables>(L, s, mu, cache, buildBpTables)) {
         const long strips = (long)((L.out_w + 127) / 128) * ((L.out_h + kBpRows - 1) / kBpRows) * L.n_frames;
         const long blocks = (strips + 7) / 8;
         hipLaunchKernelGGL(k_royale_brightpass_strip2, dim3((unsigned)(blocks < 768 ? blocks : 768)), dim3(512), rcstrip2::kStrip2LdsUser, s, L, T->cols, T->rows);
@@ -1474,7 +1474,7 @@ hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
     if (!(L.flags & RC_FLAG_GENERAL_ONLY) && rcstrip::separable(L, 0, 1)) {
       static std::mutex mu;
       static std::map<rcstrip::GeoKey, rcstrip::GeoCached<LastTables>> cache;
-      if (const LastTables* T = rcstrip::geo_tables<LastTables>(L, s, mu, cache, buildLastTables)) {
+      if (const auto T = rcstrip::geo_tables<LastTables>(L, s, mu, cache, buildLastTables)) {
         const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kLastRows - 1) / kLastRows) * L.n_frames;
         const long blocks = (strips + 7) / 8;
         hipLaunchKernelGGL((k_royale_last_strip<St<FMT_RGBA8>>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512),

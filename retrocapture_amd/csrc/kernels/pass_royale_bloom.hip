@@ -919,7 +919,7 @@ hipError_t launch_royale_bloom_v(const PassLaunch& L, hipStream_t s) {
     if (!(L.flags & RC_FLAG_GENERAL_ONLY) && separable(L, 0, 1) && L.in.w == L.out_w) {
       static std::mutex mu;
       static std::map<GeoKey, GeoCached<BvTables>> cache;
-      if (const BvTables* T = geo_tables<BvTables>(L, s, mu, cache, buildBvTables)) {
+      if (const auto T = geo_tables<BvTables>(L, s, mu, cache, buildBvTables)) {
         switch (T->pattern) {
 #define RC_BV(p) case p: return launch_bloom_v_strip<p>(L, s);
           RC_BV(0) RC_BV(1) RC_BV(2) RC_BV(3) RC_BV(4) RC_BV(5) RC_BV(6) RC_BV(7)
@@ -939,7 +939,7 @@ hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
     if (!(L.flags & RC_FLAG_GENERAL_ONLY) && separable(L, 0, 4) && L.in.frame_stride && L.extra[0].frame_stride && L.extra[1].frame_stride) {
       static std::mutex mu;
       static std::map<GeoKey, GeoCached<BhTables>> cache;
-      if (const BhTables* T = geo_tables<BhTables>(L, s, mu, cache, buildBhTables)) {
+      if (const auto T = geo_tables<BhTables>(L, s, mu, cache, buildBhTables)) {
         // one workgroup per CU; every wave gets a run of (frame, band, row) steps of equal estimated cost
         const long steps = (long)((L.out_w + 127) / 128) * L.out_h * L.n_frames;
         const long blocks = std::min<long>((steps + kBhWaves * 8 - 1) / (kBhWaves * 8), 256);
@@ -949,11 +949,11 @@ hipError_t launch_royale_bloom_h(const PassLaunch& L, hipStream_t s) {
           const int n_pairs = (L.n_frames + 1) / 2;
           const uint64_t qsteps = (uint64_t)T->n_qsteps * (uint64_t)n_pairs;
           const long qblocks = (long)std::min<uint64_t>((qsteps + (uint64_t)bq_waves() * 8 - 1) / ((uint64_t)bq_waves() * 8), 256);
-          BhTables* Tm = const_cast<BhTables*>(T);
+          BhTables* Tm = const_cast<BhTables*>(T.get());
           const uint32_t* qruns = qsteps < (1ull << 32) ? costRuns(Tm->qcost_sum, Tm->qruns, n_pairs, (int)qblocks * bq_waves()) : nullptr;
           if (qruns) return launch_bloom_h_quad(L, s, T->cols, T->qsteps, T->n_qsteps, qruns, (unsigned)qblocks, T->quad_taps);
         }
-        const uint32_t* runs = (uint64_t)steps < (1ull << 32) ? bhRuns(const_cast<BhTables*>(T), L.n_frames, (int)blocks * kBhWaves) : nullptr;
+        const uint32_t* runs = (uint64_t)steps < (1ull << 32) ? bhRuns(const_cast<BhTables*>(T.get()), L.n_frames, (int)blocks * kBhWaves) : nullptr;
         if (!runs) GO(k_royale_bloom_h<SrgbLinEdge, SrgbNearEdge, SrgbNearEdge, SrgbLinEdge, OutS>);
         const unsigned lds = kBhLdsUser + (unsigned)(kBhWaves * kBhWaveDwords) * 4u;
         auto kernel = k_royale_bloom_h_strip;

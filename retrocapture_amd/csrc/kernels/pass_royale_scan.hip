@@ -469,7 +469,11 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
     uint32_t base = 0u;
     if (lane == 0) base = atomicAdd(fix_counter(L), n_listed);
     base = __builtin_amdgcn_readfirstlane(base);
-    for (uint32_t i = (uint32_t)lane; i < n_listed; i += 64u) fix_list(L)[base + i] = my_list[i];
+    // (called with the lanes beyond the frame's right edge switched off when the width is not a multiple of 64: the entries are
+    // dealt out over the lanes that ARE active - a stride of 64 over lane numbers would leave the others' entries unwritten)
+    const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+    const uint32_t n_act = (uint32_t)__builtin_popcountll(act), rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+    for (uint32_t i = rank; i < n_listed; i += n_act) fix_list(L)[base + i] = my_list[i];
     asm volatile("" ::: "memory");
     n_listed = __builtin_amdgcn_readfirstlane(0u);
   };
@@ -584,14 +588,21 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
           const uint64_t any = __builtin_amdgcn_ballot_w64(failed != 0u);
           if (any == 0ull) break;
           const uint32_t n = (uint32_t)__builtin_popcountll(any);
-          if (__builtin_amdgcn_readfirstlane(n_listed) + n > (uint32_t)kWaveList) flush();
+          // The wave's count, taken HERE from the first active lane - lane 0, which takes part in every strip: a lane that sat out a
+          // strip beyond the frame's right edge (a width that is not a multiple of 64) still holds the count from before that strip in
+          // its own copy, and inside the branch below the first active lane is the first FAILING lane, which may be such a lane.
+          uint32_t cur = __builtin_amdgcn_readfirstlane(n_listed);
+          if (cur + n > (uint32_t)kWaveList) {
+            flush();
+            cur = 0u;
+          }
           if (failed) {
             const int kk = __builtin_ctz(failed);
             failed &= failed - 1u;
-            const uint32_t pos = n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+            const uint32_t pos = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
             my_list[pos] = (uint32_t)((z * H + ys + kk) * W + x);
           }
-          n_listed = __builtin_amdgcn_readfirstlane(n_listed + n);
+          n_listed = cur + n;
         }
       }
     }
@@ -611,6 +622,10 @@ __global__ void __launch_bounds__(256) k_royale_scan_v_fix(const PassLaunch L) {
     const uint32_t* list = fix_list(L);
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
       const uint32_t p = list[i];
+      if (p >= (uint32_t)L.n_frames * (uint32_t)L.out_h * (uint32_t)L.out_w) {   // never expected: a list entry that is not a pixel of the launch
+        atomicAdd(fix_counter(L) + 1, 1u);
+        continue;
+      }
       const uint32_t row = p / (uint32_t)L.out_w;
       const int x = (int)(p - row * (uint32_t)L.out_w), z = (int)(row / (uint32_t)L.out_h), y = (int)(row - (uint32_t)z * (uint32_t)L.out_h);
       float col[9], dd[9], kk[9];
@@ -729,48 +744,20 @@ struct ScanTables {
   ScanRow* rows = nullptr;
   float* cols = nullptr;
   bool usable = false;
-  uint64_t last_use = 0;
-};
-struct ScanKey {
-  int device, in_w, in_h, out_w, out_h;
-  float planes[12], params[4];
-  bool operator<(const ScanKey& o) const { return std::memcmp(this, &o, sizeof(ScanKey)) < 0; }
+  void release() {
+    freeScanNodeTables(&nodes);
+    if (rows) (void)hipFree(rows);
+    if (cols) (void)hipFree(cols);
+    *this = ScanTables();
+  }
 };
 
-// Tables for this launch's geometry on the current device, built on first use: the geometry kernel and one synchronisation to
-// learn whether the geometry is the regular one and which row distances it has, then the node tables with their measured
-// bounds (a few 10^9 exact evaluations per distance: tenths of a second, once per geometry and process); nullptr when the
-// table form does not apply.
-const ScanTables* scanTablesFor(const PassLaunch& L, hipStream_t s) {
-  if (L.in.w != L.out_w || L.in.h != L.out_h || L.out_h < 8 || L.params[RP1_Y_STEP] != 1.0f || L.params[RP1_TSY] != (float)L.in.h) return nullptr;
-  const Plane &pu = L.plane[0], &pv = L.plane[1];
-  if (pu.dy_lo != 0.0f || pu.dy_up != 0.0f || pv.dx_lo != 0.0f || pv.dx_up != 0.0f) return nullptr;
-  ScanKey key;
-  std::memset(&key, 0, sizeof(key));
-  if (hipGetDevice(&key.device) != hipSuccess) return nullptr;
-  key.in_w = L.in.w; key.in_h = L.in.h; key.out_w = L.out_w; key.out_h = L.out_h;
-  std::memcpy(key.planes, &L.plane[0], sizeof(float) * 12);
-  for (int i = 0; i < 4; ++i) key.params[i] = L.params[i];
-  static std::mutex mu;
-  static std::map<ScanKey, ScanTables> cache;
-  std::lock_guard<std::mutex> lock(mu);
-  static uint64_t clock = 0;
-  auto it = cache.find(key);
-  if (it != cache.end()) {
-    it->second.last_use = ++clock;
-    return it->second.usable ? &it->second : nullptr;
-  }
-  if (cache.size() >= 16) {   // geometries keep changing (a window being resized): release the least recently used tables
-    auto victim = cache.begin();
-    for (auto c = cache.begin(); c != cache.end(); ++c)
-      if (c->second.last_use < victim->second.last_use) victim = c;
-    (void)hipDeviceSynchronize();   // launches that read them may still be in flight
-    freeScanNodeTables(&victim->second.nodes);
-    if (victim->second.rows) (void)hipFree(victim->second.rows);
-    if (victim->second.cols) (void)hipFree(victim->second.cols);
-    cache.erase(victim);
-  }
-  ScanTables T;
+// Tables for a launch's geometry: the geometry kernel and one synchronisation to learn whether the geometry is the regular one and
+// which row distances it has, then the node tables with their measured bounds (a few 10^9 exact evaluations per distance: 140 ms
+// at 1080p, once per geometry and process - a slow build in the sense of rcstrip::geo_tables, taken off the frame path).  Reads
+// nothing of the launch but its geometry.
+void buildScanTables(const PassLaunch& L, hipStream_t s, ScanTables* Tp) {
+  ScanTables& T = *Tp;
   uint32_t* bad = nullptr;
   bool ok = hipMalloc(reinterpret_cast<void**>(&T.rows), sizeof(ScanRow) * (size_t)L.out_h) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&T.cols), sizeof(float) * (size_t)L.out_w) == hipSuccess &&
@@ -801,19 +788,20 @@ const ScanTables* scanTablesFor(const PassLaunch& L, hipStream_t s) {
     n_dists = dists.size();
     ok = buildScanNodeTables(L.params[RP1_PH] / 3.0f, dists, s, &T.nodes);
   }
-  T.usable = ok && hbad == 0;
+  const bool usable = ok && hbad == 0;
   RC_LOG_DEBUG("crt-royale scanline pass " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h) + ": expansion tables " +
-               (T.usable ? "in use (" + std::to_string(n_dists) + " row distances)"
-                         : "not usable (geometry flags " + std::to_string(hbad) + ", " + std::to_string(n_dists) + " row distances), exact per-pixel form"));
-  if (!T.usable) {
-    freeScanNodeTables(&T.nodes);
-    if (T.rows) (void)hipFree(T.rows);
-    if (T.cols) (void)hipFree(T.cols);
-    T = ScanTables();
-  }
-  T.last_use = ++clock;
-  auto ins = cache.emplace(key, T);
-  return ins.first->second.usable ? &ins.first->second : nullptr;
+               (usable ? "ready (" + std::to_string(n_dists) + " row distances)"
+                       : "not usable (geometry flags " + std::to_string(hbad) + ", " + std::to_string(n_dists) + " row distances), exact per-pixel form"));
+  if (!usable) T.release();
+  T.usable = usable;
+}
+std::shared_ptr<const ScanTables> scanTablesFor(const PassLaunch& L, hipStream_t s) {
+  if (L.in.w != L.out_w || L.in.h != L.out_h || L.out_h < 8 || L.params[RP1_Y_STEP] != 1.0f || L.params[RP1_TSY] != (float)L.in.h) return nullptr;
+  const Plane &pu = L.plane[0], &pv = L.plane[1];
+  if (pu.dy_lo != 0.0f || pu.dy_up != 0.0f || pv.dx_lo != 0.0f || pv.dx_up != 0.0f) return nullptr;
+  static std::mutex mu;
+  static std::map<rcstrip::GeoKey, rcstrip::GeoCached<ScanTables>> cache;
+  return rcstrip::geo_tables<ScanTables>(L, s, mu, cache, buildScanTables, true);
 }
 
 }  // namespace
@@ -853,7 +841,7 @@ hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s) {
     if (L.flags & RC_FLAG_GENERAL_ONLY) GO((k_royale_scan_v<SrgbLinEdge, OutS>));
     const bool room = L.scratch && L.scratch_frame_stride >= (uint64_t)kFixHeader + (uint64_t)L.out_w * L.out_h * 4u &&
                       (uint64_t)L.n_frames * L.out_w * L.out_h < (1ull << 32);
-    const ScanTables* T = room ? scanTablesFor(L, s) : nullptr;
+    const std::shared_ptr<const ScanTables> T = room ? scanTablesFor(L, s) : nullptr;
     if (T) {
       const float* km = T->nodes.kmax;
       const bool skip1 = km[3] < kScanSkipBelow && km[4] < kScanSkipBelow && km[5] < kScanSkipBelow;

@@ -50,6 +50,7 @@ struct Plane {
 
 // PassLaunch::flags bits (bit 0 is crt-royale's RC_FLAG_UNDEF_VARYING_ZERO, kernels/royale_params.h)
 constexpr int RC_FLAG_GENERAL_ONLY = 1 << 16; // launchers must pick the general kernel form
+constexpr int RC_FLAG_ASYNC_TABLES = 1 << 18;  // per-geometry tables that take long to build (royale_strip.h geo_tables) are built off the frame path: the general form serves meanwhile
 constexpr int RC_FLAG_STOCK_NO_BLIT = 1 << 17; // stock.glsl: the ordinary sampler even where llvmpipe's blit fast path would apply (mip generation)
 constexpr int RC_FLAG_XBR_REGULAR = 1 << 8;
 constexpr int RC_FLAG_NTSC_REGULAR = 1 << 9; // ntsc pass 2: tap k of target column x reads source column c(x)+k-24, c(x+1) = c(x)+2  // xbr: sampled columns/rows are centre-2..centre+2 for every target pixel

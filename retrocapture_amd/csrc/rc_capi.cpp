@@ -351,6 +351,28 @@ void rc_pipeline_set_output_resolution(rc_pipeline* p, uint32_t width, uint32_t 
 void rc_pipeline_set_image_adjust(rc_pipeline* p, float brightness, float contrast) {
   if (p) p->impl.setImageAdjust(brightness, contrast);
 }
+int rc_selftest_copy_rate(int device, size_t bytes, int reps, double* gb_per_s) {
+  if (!gb_per_s || bytes < 16 || (bytes & 15) || reps < 1) return RC_ERR_INVALID;
+  return guarded([&] {
+    if (hipSetDevice(device) != hipSuccess) return (int)RC_ERR_DEVICE;
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = hipMalloc(&a, bytes) == hipSuccess && hipMalloc(&b, bytes) == hipSuccess && hipMemset(a, 7, bytes) == hipSuccess &&
+              hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    for (int i = 0; ok && i < 3; ++i) ok = rck::launch_selftest_copy(a, b, bytes, nullptr) == hipSuccess;
+    if (ok) ok = hipEventRecord(e0, nullptr) == hipSuccess;
+    for (int i = 0; ok && i < reps; ++i) ok = rck::launch_selftest_copy(a, b, bytes, nullptr) == hipSuccess;
+    float ms = 0.f;
+    if (ok) ok = hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f;
+    if (ok) *gb_per_s = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    return ok ? (int)RC_OK : (int)RC_ERR_DEVICE;
+  });
+}
+
 int rc_selftest_fastmath(int device, uint64_t mismatches[3]) {
   if (!mismatches) return RC_ERR_INVALID;
   if (device >= 0 && hipSetDevice(device) != hipSuccess) return RC_ERR_DEVICE;
@@ -433,6 +455,9 @@ int rc_engine_read_history(rc_engine* e, int k, uint32_t* width, uint32_t* heigh
 }
 void rc_engine_set_general_kernels_only(rc_engine* e, int general_only) {
   if (e) e->impl.setGeneralKernelsOnly(general_only != 0);
+}
+void rc_engine_set_async_table_builds(rc_engine* e, int on) {
+  if (e) e->impl.setAsyncTableBuilds(on != 0);
 }
 void rc_engine_set_fold_passes(rc_engine* e, int on) {
   if (e) e->impl.setFoldPasses(on != 0);

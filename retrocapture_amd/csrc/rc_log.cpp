@@ -24,6 +24,8 @@ thread_local int t_missing_depth = 0, t_missing_count = 0;
 std::mutex g_io;
 }  // namespace
 
+bool log_enabled(LogLevel level) { return level >= threshold(); }
+
 void log(LogLevel level, const std::string& msg) {
   if (level == LogLevel::Error) t_last_error = msg;
   if (level < threshold()) return;

@@ -8,6 +8,7 @@
 namespace rc {
 enum class LogLevel { Debug = 0, Info = 1, Warn = 2, Error = 3 };
 void log(LogLevel level, const std::string& msg);
+bool log_enabled(LogLevel level);   // whether a message of this level would be printed (to skip building it)
 const std::string& last_error();
 void clear_last_error();
 // While an engine that was told shader sources may be absent (setAllowMissingSources) loads a preset, the

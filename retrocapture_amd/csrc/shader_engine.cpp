@@ -795,6 +795,7 @@ bool ShaderEngine::syncHelper() {
   o.m_undefVaryingZero = m_undefVaryingZero;
   o.m_generalOnly = m_generalOnly;
   o.m_foldPasses = m_foldPasses;
+  o.m_asyncTables = m_asyncTables;
   o.m_floatTargetFp16 = m_floatTargetFp16;
   o.m_chunk = m_chunk;
   o.m_chunkAuto = m_chunkAuto;
@@ -1045,7 +1046,7 @@ bool ShaderEngine::pushHistory(const void* finalFrame, int frameCount, const rcd
   L.vp_h = (int)m_viewportHeight;
   L.frame_count0 = frameCount;
   L.n_frames = 1;
-  L.flags = (m_undefVaryingZero ? 1 : 0) | (m_generalOnly ? rcd::RC_FLAG_GENERAL_ONLY : 0);
+  L.flags = (m_undefVaryingZero ? 1 : 0) | (m_generalOnly ? rcd::RC_FLAG_GENERAL_ONLY : 0) | (m_asyncTables ? rcd::RC_FLAG_ASYNC_TABLES : 0);
   if (k.stale_size_uniforms && !sameSizes) {
     // the program's size uniforms are what pass 0's own draw of this frame set (:2401-2437): its input - the source frame -
     // and its output
@@ -1192,7 +1193,7 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
       }
       PassGeometry geo;
       fillGeometry(i, current, L, &geo);
-      L.flags = (m_undefVaryingZero ? 1 : 0) | (m_generalOnly ? rcd::RC_FLAG_GENERAL_ONLY : 0);
+      L.flags = (m_undefVaryingZero ? 1 : 0) | (m_generalOnly ? rcd::RC_FLAG_GENERAL_ONLY : 0) | (m_asyncTables ? rcd::RC_FLAG_ASYNC_TABLES : 0);
       if (k.scratch_bytes) {
         const uint64_t per_frame = k.scratch_bytes(geo);
         if (!ensureBuffer(pd.scratch, per_frame * nFrames)) return false;
@@ -1306,6 +1307,8 @@ bool ShaderEngine::runChunk(const void* inputs, uint64_t inStride, uint32_t widt
         if (!hipOk(hipEventCreate(&tl.start), "hipEventCreate") || !hipOk(hipEventCreate(&tl.stop), "hipEventCreate")) return false;
         (void)hipEventRecord(tl.start, m_stream);
       }
+      if (log_enabled(LogLevel::Debug))
+        RC_LOG_DEBUG("pass " + std::to_string(i) + " " + k.name + ": " + std::to_string(L.n_frames) + " frame(s) " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h));
       if (!hipOk(k.launch(L, m_stream), k.name)) {
         pd.invariantKey.clear();
         return false;

@@ -151,6 +151,9 @@ class ShaderEngine {
   // every other pass.  A folded pass's own bytes are rendered on demand by readPass from the input frames of the last call,
   // which must still be there.
   void setFoldPasses(bool on) { m_foldPasses = on; }
+  // Per-geometry tables that take long to build (crt-royale's scanline tables: 140 ms) are built on a worker thread while the
+  // general kernel forms serve the frames (default); off: the first frame of a new geometry waits for them.
+  void setAsyncTableBuilds(bool on) { m_asyncTables = on; }
   bool passFolded(size_t i) const { return i < m_passes.size() && m_passes[i].folded; }
   // float_framebuffer targets stored as four binary16 values (8 bytes per texel) instead of RGBA32F: arithmetic stays
   // float, only the storage of those targets rounds.  Off by default (bit-exact); see DESIGN.md for the tolerance.
@@ -225,6 +228,7 @@ class ShaderEngine {
   bool m_undefVaryingZero = false;
   bool m_generalOnly = false;
   bool m_foldPasses = true;
+  bool m_asyncTables = true;
   uint32_t m_chunkCapacity = 0;   // frames the intermediate targets are sized for (applyShaderBatch)
   bool consumersTakeDecodeTable(size_t i) const;
   bool m_floatTargetFp16 = false;

@@ -78,6 +78,7 @@ SYMBOLS = [
     ("rc_engine_set_undefined_varying_zero", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_general_kernels_only", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_fold_passes", None, [C.c_void_p, C.c_int]),
+    ("rc_engine_set_async_table_builds", None, [C.c_void_p, C.c_int]),
     ("rc_engine_set_float_target_fp16", None, [C.c_void_p, C.c_int]),
     ("rc_engine_history_count", C.c_int, [C.c_void_p]),
     ("rc_engine_read_history", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p,
@@ -99,6 +100,7 @@ SYMBOLS = [
     ("rc_pipeline_set_output_resolution", None, [C.c_void_p, C.c_uint32, C.c_uint32]),
     ("rc_pipeline_set_image_adjust", None, [C.c_void_p, C.c_float, C.c_float]),
     ("rc_selftest_fastmath", C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
+    ("rc_selftest_copy_rate", C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     ("rc_selftest_srgb8_host", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("rc_selftest_royale_scan_tables", C.c_int, [C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     ("rc_selftest_srgb8_device", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -289,6 +291,15 @@ def selftest_fastmath(device=0):
     if rc != 0:
         raise RcError("rc_selftest_fastmath failed (%d)" % rc)
     return list(out)
+
+
+def copy_rate(device=0, mib=1024, reps=20):
+    """GB/s (read + written) of a 16-byte-per-lane grid-stride copy kernel on the device: the box's streaming ceiling."""
+    out = C.c_double(0.0)
+    rc = load_library().rc_selftest_copy_rate(int(device), int(mib) << 20, int(reps), C.byref(out))
+    if rc != 0:
+        raise RcError("rc_selftest_copy_rate failed (%d)" % rc)
+    return out.value
 
 
 def srgb8_encode_host(values, form=1):
@@ -529,6 +540,10 @@ class ShaderEngine:
     def setFloatTargetFp16(self, on):
         """float_framebuffer targets stored as binary16 (opt-in; default off = RGBA32F, bit-exact)."""
         self._lib.rc_engine_set_float_target_fp16(self._need(), int(bool(on)))
+
+    def setAsyncTableBuilds(self, on):
+        """Slow per-geometry table builds on a worker thread (default on); off: the first frame of a new geometry waits."""
+        self._lib.rc_engine_set_async_table_builds(self._need(), int(bool(on)))
 
     def setFoldPasses(self, on):
         """Byte-map passes folded into their consumers (default on); off renders every pass."""

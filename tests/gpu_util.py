@@ -18,6 +18,7 @@ def make_engine(preset_path, vw, vh, chunk=None):
     e = ShaderEngine()
     assert e.init(0), "ShaderEngine.init failed: no HIP device?"
     e.setAllowMissingSources(True)
+    e.setAsyncTableBuilds(False)   # the specialised forms from the first frame on (tests compare forms; test_async_table_builds turns it on)
     if chunk:
         e.setChunkFrames(chunk)
     st = e.loadPresetStatus(preset_path)

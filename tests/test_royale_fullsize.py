@@ -254,3 +254,110 @@ def test_crt_royale_1080p_folded_first_pass_equals_rendered(preset_tree, rc_lib)
     e.sync()
     assert not e.passProfile(0)["folded"] and e.passProfile(0)["launches"] == 1
     e.shutdown()
+
+
+def test_async_table_builds_do_not_stall_the_frame_path(preset_tree, rc_lib):
+    """rc_engine_set_async_table_builds (the engine's default; the test helper switches it off): the scanline pass's tables - error
+    bounds proven by exhaustion, 140 ms at 1080p - are built on a worker thread while the exact per-pixel form serves the frames,
+    so no apply call waits for them (the reference's callers resize the window and move parameters from UI and HTTP threads);
+    the bytes are the table form's, before and after the switch.  A viewport no other test uses, so that the build is this
+    test's own."""
+    import time
+    import torch
+    from gpu_util import make_engine
+    vw, vh = 1888, 1062
+    g = torch.Generator(device="cuda")
+    g.manual_seed(80)
+    frame = torch.randint(0, 256, (1, vh, vw, 4), dtype=torch.uint8, device="cuda", generator=g)
+    e = make_engine(preset_tree["crt-royale"], vw, vh)
+    e.setAsyncTableBuilds(True)
+    last = e.passCount() - 1
+    longest, first = 0.0, None
+    t_end = time.perf_counter() + 3.0
+    n = 0
+    while time.perf_counter() < t_end and n < 400:
+        t0 = time.perf_counter()
+        e.applyShaderBatch(frame, 1, vw, vh)
+        e.sync()
+        dt = time.perf_counter() - t0
+        if n > 0: longest = max(longest, dt)      # (the first call allocates every target)
+        if first is None: first = [e.readPass(i, 0) for i in (1, last)]
+        n += 1
+    e.setProfiling(True)
+    e.applyShaderBatch(frame, 1, vw, vh)
+    e.sync()
+    late = [e.readPass(i, 0) for i in (1, last)]
+    assert np.array_equal(first[0], late[0]) and np.array_equal(first[1], late[1])
+    print("longest apply call while the tables were being built: %.2f ms over %d calls" % (longest * 1e3, n))
+    assert longest < 0.010, "an apply call took %.1f ms while the tables were being built" % (longest * 1e3)
+    e.shutdown()
+    # and the same bytes from an engine that waited for its tables
+    s = make_engine(preset_tree["crt-royale"], vw, vh)
+    s.applyShaderBatch(frame, 1, vw, vh)
+    s.sync()
+    assert np.array_equal(s.readPass(1, 0), late[0]) and np.array_equal(s.readPass(last, 0), late[1])
+    s.shutdown()
+
+
+def test_two_lanes_first_on_a_cold_geometry(preset_tree, rc_lib):
+    """The second lane's stream must never see a per-geometry table before its build has finished (every build is synchronised
+    before the tables are cached, royale_strip.h geo_tables): on a viewport no other test uses, the two-lane engine runs FIRST -
+    every table is built during its call, with both streams live - and is compared with a one-lane engine afterwards; then a
+    viewport and a parameter change between batches (the helper instance reloads its configuration)."""
+    import torch
+    from gpu_util import make_engine
+    n = 6
+    g = torch.Generator(device="cuda")
+    g.manual_seed(81)
+    for (vw, vh), param in (((1872, 1053), None), ((1856, 1044), ("crt_gamma", 2.3))):
+        frames = torch.randint(0, 256, (n, vh, vw, 4), dtype=torch.uint8, device="cuda", generator=g)
+        frames[..., 3] = 255
+        if param is None:
+            two = make_engine(preset_tree["crt-royale"], vw, vh)
+            two.setLanes(2)
+            two.setUndefinedVaryingZero(True)
+        else:
+            two.setViewport(vw, vh)
+            assert two.setShaderParameter(*param)
+        two.applyShaderBatch(frames, n, vw, vh)
+        two.sync()
+        last = two.passCount() - 1
+        got = [two.readPass(last, k) for k in range(n)]
+        one = make_engine(preset_tree["crt-royale"], vw, vh)
+        one.setUndefinedVaryingZero(True)
+        if param is not None:
+            assert one.setShaderParameter(*param)
+            one.applyShaderBatch(frames, n, vw, vh)   # (the frame counter: the two-lane engine has rendered one batch before)
+        one.applyShaderBatch(frames, n, vw, vh)
+        one.sync()
+        for k in range(n):
+            want = one.readPass(last, k)
+            assert np.array_equal(got[k], want), "%dx%d frame %d: %d differing bytes" % (vw, vh, k, int((got[k] != want).sum()))
+        one.shutdown()
+    two.shutdown()
+
+
+@pytest.mark.parametrize("size", [(1872, 1053), (1840, 1035)])
+def test_crt_royale_widths_that_leave_a_partial_wave(size, preset_tree, rc_lib):
+    """Widths that are not a multiple of 64 (16 / 48 columns in the last wave of a row): the strip and table forms against the
+    general per-pixel forms, every pass.  (Round 4 found the scanline pass's per-wave list of uncertain pixels losing entries
+    after a wave had rendered a strip with lanes beyond the right edge switched off.)"""
+    import torch
+    from gpu_util import make_engine
+    vw, vh = size
+    g = torch.Generator(device="cuda")
+    g.manual_seed(82)
+    frames = torch.randint(0, 256, (3, vh, vw, 4), dtype=torch.uint8, device="cuda", generator=g)
+    e = make_engine(preset_tree["crt-royale"], vw, vh)
+    e.setUndefinedVaryingZero(True)
+    e.applyShaderBatch(frames, 3, vw, vh)
+    e.sync()
+    mine = [[e.readPass(i, k) for i in range(12)] for k in range(3)]
+    e.setGeneralKernelsOnly(True)
+    e.applyShaderBatch(frames, 3, vw, vh)
+    e.sync()
+    for k in range(3):
+        for i in range(12):
+            want = e.readPass(i, k)
+            assert np.array_equal(mine[k][i], want), "frame %d pass %d: %d differing bytes" % (k, i, int((mine[k][i] != want).sum()))
+    e.shutdown()
