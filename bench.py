@@ -100,7 +100,7 @@ def cpu_baseline(key, w, h, vw, vh, tree, budget_s=15.0):
                       % (n, cores, dt)}
 
 
-PMC_FILE = "r03_royale_pmc.csv"   # the committed counter summary the `traffic` / `valu` figures are read from (profiles/collect.sh) ...
+PMC_FILE = "r04_royale_pmc.csv"   # the committed counter summary the `traffic` / `valu` figures are read from (profiles/collect.sh) ...
 PMC_FRAMES_PER_LAUNCH = 128.0     # ... and the launch shape it was collected at: the engine's default for 1080p chains
 
 
@@ -121,7 +121,7 @@ def pmc_traffic(kernel_name, frames_per_launch):
              "k_royale_bloom_horizontal": "k_royale_bloom_h", "k_royale_bloom_vertical": "k_royale_bloom_v"}
     want = alias.get(want, want)
     rows = {r["kernel"]: r for r in csv.DictReader(open(files[-1]))}
-    for name in (want + "_strip", want + "_tab", want + "2", want):      # the form the fast path launches
+    for name in (want + "_quad", want + "_strip", want + "_tab", want + "2", want):      # the form the fast path launches
         r = rows.get(name)
         if r and r.get("FETCH_SIZE_avg") and r.get("WRITE_SIZE_avg"):
             return (2.0 * float(r["FETCH_SIZE_avg"]) + float(r["WRITE_SIZE_avg"])) * 1024.0
@@ -141,7 +141,7 @@ def pmc_valu(kernel_name, frames_per_launch, avg_launch_ms):
         return None
     want = {"royale-scanlines-v": "k_royale_scan_v", "royale-bloom-h": "k_royale_bloom_h"}.get(kernel_name, "k_" + kernel_name.replace("-", "_"))
     rows = {r["kernel"]: r for r in csv.DictReader(open(files[-1]))}
-    for name in (want + "_strip", want + "_tab", want + "2", want):
+    for name in (want + "_quad", want + "_strip", want + "_tab", want + "2", want):
         r = rows.get(name)
         if r and r.get("SQ_INSTS_VALU_avg"):
             insts = float(r["SQ_INSTS_VALU_avg"])
@@ -158,8 +158,12 @@ def pmc_valu(kernel_name, frames_per_launch, avg_launch_ms):
 
 
 def copy_ceiling(torch, mib=1024, reps=20):
-    """Achieved stream-copy rate of this box (SURVEY.md section 8d asks for it beside the 8 TB/s vendor
-    peak): device-to-device copy of `mib` MiB, read + write bytes over the HIP-event time."""
+    """Achieved stream-copy rates of this box (SURVEY.md section 8d asks for one beside the 8 TB/s vendor peak), read + write
+    bytes over HIP-event time of a `mib` MiB device-to-device copy: (1) the library's own 16-byte-per-lane grid-stride copy
+    kernel (rc_selftest_copy_rate: the shape the hardware guide measures at 6.3 TB/s) - the ceiling a kernel can reach; (2)
+    the runtime's memcpy (torch Tensor.copy_ = __amd_rocclr_copyBuffer), which rounds 1-3 quoted and which is slower."""
+    from retrocapture_amd import engine as eng
+    kernel = eng.copy_rate(torch.cuda.current_device(), mib, reps)
     n = mib << 20
     a = torch.empty(n, dtype=torch.uint8, device="cuda")
     b = torch.empty_like(a)
@@ -172,9 +176,9 @@ def copy_ceiling(torch, mib=1024, reps=20):
         b.copy_(a)
     t1.record()
     torch.cuda.synchronize()
-    gbs = 2.0 * n * reps / (t0.elapsed_time(t1) * 1e-3) / 1e9
+    memcpy = 2.0 * n * reps / (t0.elapsed_time(t1) * 1e-3) / 1e9
     del a, b
-    return gbs
+    return kernel, memcpy
 
 
 def io_measurements(e, w, h, batch, reps):
@@ -386,6 +390,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (256 x 1080p = 2.1 GB in, 2.1 GB out)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per kernel launch (0 = engine default)")
+    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
+                    help="rc_engine_set_lanes: 2 (the engine's default) renders the second half of every batch on a second HIP stream")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
@@ -466,6 +472,7 @@ def main():
             raise SystemExit("unknown shader parameter " + name)
     if args.chunk:
         e.setChunkFrames(args.chunk)
+    e.setLanes(args.lanes)
     if args.modes == "mask":
         e.setUndefinedVaryingZero(True)
 
@@ -603,14 +610,14 @@ def main():
         natural = {"value": aggregate([args.batch], n_steps, dtn), "unit": "frames/s", "steps": n_steps, "mask_mode": "rendered",
                    "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in profn],
                    "note": "synthetic frames with video-like statistics (gradients, block edges, +-3 grain); `value` stays on uniform noise"}
-    # ... and with the engine's second lane switched on (rc_engine_set_lanes(2)): the second half of the batch is rendered by a
-    # helper instance on its own HIP stream, so kernels of the two streams overlap - the copy-rate passes of one under the VALU /
-    # LDS bound passes of the other.  Opt-in this round: `value`, the roofline figures and the committed
-    # profiles stay on one lane.
-    two_streams = None
-    if wl == "crt-royale" and args.modes == "both" and world == 1 and not args.param and n_local >= 64:
+    # ... and on ONE lane (rc_engine_set_lanes(1)): `value` is measured with the engine's default of two lanes - the second half of
+    # the batch on a helper instance with its own HIP stream, kernels of the two halves overlapping -; the per-pass times above and
+    # the roofline figures are one-lane figures (a kernel's own duration: profiled runs use one lane), and this is the whole chain
+    # at that setting.  roofline.overlap_factor = one-lane sum of pass time / two-lane wall time of the same frames.
+    one_lane = None
+    if args.lanes == 2 and args.modes != "mask" and world == 1 and n_local >= 2:
         try:
-            e.setLanes(2)     # rc_engine_set_lanes: the second half of every batch on a helper instance with its own stream
+            e.setLanes(1)
             n_steps = max(1, args.steps // 4)
             for _ in range(args.warmup):
                 step()
@@ -619,14 +626,13 @@ def main():
             for _ in range(n_steps):
                 step()
             barrier()
-            dt2 = time.perf_counter() - t0
-            two_streams = {"value": aggregate([args.batch], n_steps, dt2), "unit": "frames/s", "steps": n_steps, "lanes": 2,
-                           "note": "rc_engine_set_lanes(2): the batch's second half on a second HIP stream (a helper engine instance), "
-                                   "same bytes; opt-in - `value`, the roofline figures and the profiles stay on one lane"}
+            dt1 = time.perf_counter() - t0
+            one_lane = {"value": aggregate([args.batch], n_steps, dt1), "unit": "frames/s", "steps": n_steps, "lanes": 1,
+                        "note": "rc_engine_set_lanes(1): the whole batch on the engine's own stream, same bytes"}
         except Exception as ex:   # a side measurement never takes the line down
-            two_streams = {"value": None, "error": repr(ex)}
+            one_lane = {"value": None, "error": repr(ex)}
         finally:
-            e.setLanes(1)
+            e.setLanes(args.lanes)
     # The pixel-art upscalers on what they are made for: frames of flat-coloured tiles and sprites from a 16-colour palette
     # instead of uniform noise, on which every xbr rule fires at nearly every pixel (the worst case; `value` stays on it).
     pixel_art = None
@@ -655,7 +661,8 @@ def main():
         del art, idx, spr, keep, tiles
         pixel_art = {"value": aggregate([args.batch], n_steps, dta), "unit": "frames/s", "steps": n_steps,
                      "note": "frames of 8x8 flat tiles from a 16-colour palette with 8 % sprite detail; `value` stays on uniform noise"}
-    ceiling = copy_ceiling(torch)
+    ceiling, memcpy_rate = copy_ceiling(torch)
+    pass_ms_per_step = sum(q["total_ms"] / max(1, q["frames"]) for q in prof) * n_local
     out = {
         # BASELINE.json's metric for the default workload; other --workload values are side measurements
         "metric": ("1080p frames/sec, crt-royale 12-pass, 1/2/4/8 MI355X; % HBM roofline" if wl == "crt-royale"
@@ -672,7 +679,8 @@ def main():
                    "bytes_moved_per_frame": moved_bytes,
                    "folded_passes": [i for i, q in enumerate(prof) if q.get("folded")],
                    "hbm_roofline_frac_whole_chain": value / world * chain_bytes / (HBM_PEAK_GBS * 1e9),
-                   "stream_copy_ceiling_GBs": ceiling,
+                   "lanes": args.lanes,
+                   "stream_copy_ceiling_GBs": ceiling, "memcpy_GBs": memcpy_rate,
                    "copy_ceiling_frac_whole_chain": value / world * chain_bytes / (ceiling * 1e9)},
         "roofline": {"bound": "hbm", "kernel": infos[dom]["kernel"], "pass": dom, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -680,6 +688,8 @@ def main():
                      "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "frac_of_copy_ceiling": achieved / ceiling,
+                     "lanes_of_this_figure": 1,
+                     "overlap_factor": pass_ms_per_step / (dt / args.steps * 1e3) if args.lanes == 2 else 1.0,
                      "valu": pmc_valu(infos[dom]["kernel"], frames_per_launch, avg_ms)},
         "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in prof],
     }
@@ -687,8 +697,8 @@ def main():
         out["mask_rendered"] = mask_rendered
     if natural is not None:
         out["natural_frames"] = natural
-    if two_streams is not None:
-        out["two_streams"] = two_streams
+    if one_lane is not None:
+        out["one_lane"] = one_lane
     if pixel_art is not None:
         out["pixel_art_frames"] = pixel_art
     if args.io and rank == 0:

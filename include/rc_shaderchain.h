@@ -137,13 +137,14 @@ int rc_engine_pass_profile(rc_engine* e, int pass, rc_pass_profile* out);
 /* Frames processed per kernel launch through the whole chain (default: 128 where 128 frames of the chain's largest pass
  * target stay below 2 GiB, else 64). */
 void rc_engine_set_chunk_frames(rc_engine* e, uint32_t n);
-/* Not in the reference (its one GL context draws one frame at a time): n = 2 renders the second half of every batch on a
- * second HIP stream of the same device (a helper engine instance inside `e`: same preset, parameters and flags) straight into
- * the batch output; the helper's stream is ordered after the engine's stream at the start of the call and before it at the
- * end, so callers still see one stream-ordered result and the same bytes.  Default 1.  Presets that sample frame history
- * or PassFeedback, single-shader mode and profiled runs always use one lane.  With two lanes rc_engine_read_pass of an
- * intermediate pass reaches the first lane's frames only (the last pass's output is complete); device memory for
- * intermediates doubles. */
+/* Not in the reference (its one GL context draws one frame at a time): with n = 2 - the default since round 4 - the second half
+ * of every batch is rendered on a second HIP stream of the same device (a helper engine instance inside `e`: same preset,
+ * parameters and flags) straight into the batch output; the helper's stream is ordered after the engine's stream at the start
+ * of the call and before it at the end, so callers still see one stream-ordered result and the same bytes, and the kernels of
+ * the two halves overlap (a pass that waits on memory under one that waits on arithmetic: +4 ... 10 % on the 1080p chains).
+ * Presets that sample frame history or PassFeedback, single-shader mode, single-frame calls and profiled runs
+ * (rc_engine_set_profiling: a kernel's own duration is a one-lane figure) use one lane.  rc_engine_read_pass finds an
+ * intermediate pass of the second half in the helper; device memory for intermediates doubles.  n = 1: one lane. */
 void rc_engine_set_lanes(rc_engine* e, uint32_t n);
 /* 1: a pass whose .glsl file is unreadable still runs if its shader identity is registered
  * (built-in parameter table).  Default 0 = the reference's behaviour (pass fails). */

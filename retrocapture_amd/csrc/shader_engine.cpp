@@ -888,13 +888,24 @@ const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames,
   // two lanes (setLanes): this engine renders the first half, the helper - on its own stream - the second half
   const bool twoLanes = m_lanes == 2 && !m_externalOut && !history && !feedback && !m_profiling && nFrames >= 2 && syncHelper();
   const uint32_t nOwn = twoLanes ? (nFrames + 1) / 2 : nFrames;
-  const uint32_t chunk = (history || feedback) ? 1u : std::min(chunkFrames, nOwn);
-  m_chunkCapacity = chunk;
-  for (size_t i = 0; i + 1 < m_passes.size(); ++i) {
-    // (a pass that may be folded into its consumers gets its target when it is first rendered: runChunk, readPass)
-    const bool mayFold = m_foldPasses && !m_generalOnly && m_passes[i].kernel && m_passes[i].kernel->byte_map && consumersTakeDecodeTable(i);
-    if (!mayFold && !ensureBuffer(m_passes[i].target, m_passes[i].frameBytes * chunk)) return inputs;
+  m_lastTwoLanes = twoLanes;
+  m_lastOwnFrames = nOwn;
+  uint32_t chunk = (history || feedback) ? 1u : std::min(chunkFrames, nOwn);
+  for (;;) {
+    bool ok = true;
+    for (size_t i = 0; ok && i + 1 < m_passes.size(); ++i) {
+      // (a pass that may be folded into its consumers gets its target when it is first rendered: runChunk, readPass)
+      const bool mayFold = m_foldPasses && !m_generalOnly && m_passes[i].kernel && m_passes[i].kernel->byte_map && consumersTakeDecodeTable(i);
+      if (!mayFold) ok = ensureBuffer(m_passes[i].target, m_passes[i].frameBytes * chunk);
+    }
+    if (ok) break;
+    // out of device memory at the automatic launch size (128 frames of every intermediate target, twice with two lanes): fall
+    // back towards the old default of 8 frames per launch before giving up
+    if (!m_chunkAuto || chunk <= 8u) return inputs;
+    chunk = std::max(8u, chunk / 2u);
+    RC_LOG_WARN("applyShader: not enough device memory for the intermediate targets; " + std::to_string(chunk) + " frames per launch");
   }
+  m_chunkCapacity = chunk;
   ShaderPassData& lastPass = m_passes.back();
   if (!m_externalOut && !ensureBuffer(lastPass.target, lastPass.frameBytes * nFrames)) return inputs;
   uint8_t* const outBase = m_externalOut ? m_externalOut : static_cast<uint8_t*>(lastPass.target.ptr);
@@ -1390,6 +1401,8 @@ bool ShaderEngine::readPass(size_t i, uint32_t frame, void* host, size_t bytes) 
   }
   if (!pd.target.ptr) return false;
   const bool last = (i + 1 == m_passes.size());
+  // two lanes: the intermediates of the batch's second half are the helper instance's
+  if (!last && m_lastTwoLanes && m_helper && frame >= m_lastOwnFrames && !pd.invariant) return m_helper->readPass(i, frame - m_lastOwnFrames, host, bytes);
   // intermediates hold the last chunk only; the last pass holds the whole batch
   uint64_t index = frame;
   if (pd.invariant) {

@@ -213,7 +213,9 @@ class ShaderEngine {
   // pass target stay below 2 GiB (1080p RGBA8 chains), and m_chunk = 64 otherwise (4K targets, float targets).
   uint32_t m_chunk = 64;
   bool m_chunkAuto = true;
-  uint32_t m_lanes = 1;
+  uint32_t m_lanes = 2;
+  bool m_lastTwoLanes = false;     // the last batch was split over the two lanes, this engine taking the first m_lastOwnFrames frames
+  uint32_t m_lastOwnFrames = 0;
   std::unique_ptr<ShaderEngine> m_helper;   // the second lane (setLanes)
   hipStream_t m_helperStream = nullptr;
   hipEvent_t m_laneFork = nullptr, m_laneJoin = nullptr;
