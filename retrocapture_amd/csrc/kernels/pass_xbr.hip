@@ -599,7 +599,16 @@ __device__ __forceinline__ float xbrs_row_term(float fy) {   // per target row
 typedef float xbrs_row_t __attribute__((ext_vector_type(8)));   // the five row terms of one rule (a vector: stays in registers)
 struct XbrsPhase {   // per phase and lane: |B| fx for the four magnitudes
   float q1, qh, q2, q6;
+  // ... and, for the whole kernel, the four smoothstep widths that occur with their reciprocals, held in VECTOR registers: as
+  // literals they would reach the fused operations of the division through scalar registers, and a scalar operand makes a VALU
+  // instruction issue at the slow rate
+  float d[4], rd[4];
 };
+__device__ __forceinline__ float xbrs_max(float a, float b) {   // v_max_f32 as it is (no operand is ever a NaN: no canonicalising copies)
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 template <int K, int LINE>
 __device__ __forceinline__ float xbrs_line_value(float row_term, const XbrsPhase& q) {
   constexpr XbrsLineConst c = xbrs_const<K, LINE>();
@@ -607,8 +616,11 @@ __device__ __forceinline__ float xbrs_line_value(float row_term, const XbrsPhase
   const float bq = mag == 1.0f ? q.q1 : (mag == 0.5f ? q.qh : (mag == 2.0f ? q.q2 : q.q6));
   const float bfx = c.B < 0.0f ? -bq : bq;
   const float num = c.paired ? (row_term + bfx) - c.e0 : row_term + bfx;
-  constexpr float rd = 1.0f / c.d;
-  const float t = __builtin_amdgcn_fmed3f(div_const_(num, c.d, rd), 0.0f, 1.0f);
+  constexpr int w = c.d == 0.79999995f ? 0 : (c.d == 0.8f ? 1 : (c.d == 0.80000007f ? 2 : 3));
+  static_assert(c.d == 0.79999995f || c.d == 0.8f || c.d == 0.80000007f || c.d == 0.8000002f, "smoothstep widths");
+  // div_const_(num, d, 1 / d)
+  const float qt = num * q.rd[w];
+  const float t = __builtin_amdgcn_fmed3f(fma_(fma_(-q.d[w], qt, num), q.rd[w], qt), 0.0f, 1.0f);
   return t * (t * fma_(-2.0f, t, 3.0f));
 }
 
@@ -619,7 +631,7 @@ __device__ __forceinline__ float xbrs_line(float m, uint32_t dead, uint32_t sat,
   if (dead & bit) return m;   // (uniform)
   const float t = (sat & bit) ? 1.0f : xbrs_line_value<K, LINE>(row_term, q);
   // the test counts where the source pixel's record enables it: t & (all ones or zero from the record's bit)
-  return fmaxf(m, bits2f(f2bits(t) & (uint32_t)__builtin_amdgcn_sbfe((int)rec, 4u * LINE + K, 1u)));
+  return xbrs_max(m, bits2f(f2bits(t) & (uint32_t)__builtin_amdgcn_sbfe((int)rec, 4u * LINE + K, 1u)));
 }
 template <int K>
 __device__ __forceinline__ float xbrs_rule(uint32_t dead, uint32_t sat, uint32_t rec, const xbrs_row_t row, const XbrsPhase& q) {
@@ -672,7 +684,7 @@ __device__ __forceinline__ uint32_t xbrs_pack(float r, float g, float b) {
 // one wave = 64 source pixels of one source row of one frame; a workgroup = four waves.  Dynamic LDS per wave: the row of target
 // pixels being assembled and the fx of its columns (64 * n_phases words each), then the row's masks (2 * n_phases words)
 template <int IN_WRAP>
-__global__ void __launch_bounds__(256) k_xbr_blend_src(const PassLaunch L, const float* __restrict__ gfx, const float* __restrict__ gfy, const int* __restrict__ gx0,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) k_xbr_blend_src(const PassLaunch L, const float* __restrict__ gfx, const float* __restrict__ gfy, const int* __restrict__ gx0,
                                                       const int* __restrict__ gy0, const uint2* __restrict__ gmasks, int n_phases) {
   extern __shared__ uint32_t rc_dyn_lds_[];
   const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -699,6 +711,9 @@ __global__ void __launch_bounds__(256) k_xbr_blend_src(const PassLaunch L, const
   const int xbase = gx0[s0], span = gx0[min(s0 + 64, L.in.w)] - xbase;   // (uniform) this wave's target columns
   const int xs = gx0[sc] - xbase, cnt = gx0[sc + 1] - gx0[sc];
   for (int j = lane; j < span; j += 64) fxbuf[j] = gfx[xbase + j];
+  float wd0 = 0.79999995f, wd1 = 0.8f, wd2 = 0.80000007f, wd3 = 0.8000002f;   // (XbrsPhase::d, rd)
+  float wr0 = 1.0f / 0.79999995f, wr1 = 1.0f / 0.8f, wr2 = 1.0f / 0.80000007f, wr3 = 1.0f / 0.8000002f;
+  asm volatile("" : "+v"(wd0), "+v"(wd1), "+v"(wd2), "+v"(wd3), "+v"(wr0), "+v"(wr1), "+v"(wr2), "+v"(wr3));
   uint32_t* out_frame = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.out) + L.out_frame_stride * (uint64_t)z);
   const int y_end = gy0[sy + 1];
   for (int y = gy0[sy]; y < y_end; ++y) {
@@ -718,7 +733,7 @@ __global__ void __launch_bounds__(256) k_xbr_blend_src(const PassLaunch L, const
       const uint32_t dead = __builtin_amdgcn_readfirstlane(mbuf[2 * i]), sat = __builtin_amdgcn_readfirstlane(mbuf[2 * i + 1]);
       const bool active = live && i < cnt;
       const float fx = fxbuf[active ? xs + i : 0];
-      const XbrsPhase q = {fx, 0.5f * fx, 2.0f * fx, 6.0f * fx};
+      const XbrsPhase q = {fx, 0.5f * fx, 2.0f * fx, 6.0f * fx, {wd0, wd1, wd2, wd3}, {wr0, wr1, wr2, wr3}};
       // the rules with a test alive at this phase (uniform); the others' maxima are 0 and drop out of the selection below
       const uint32_t nd = ~dead;
       const uint32_t live_rules = ((nd | (nd >> 4) | (nd >> 8) | (nd >> 12) | (nd >> 16)) & 15u);
