@@ -74,7 +74,7 @@ def default_workload():
     return "crt-royale" if "crt-royale" in chain_specs.PRESETS else "crt-pi"
 
 
-def cpu_baseline(key, w, h, vw, vh, tree, budget_s=15.0):
+def cpu_baseline(key, w, h, vw, vh, tree, budget_s=15.0, custom=None, luts=None, f16_targets=False):
     """Oracle (C restatement) on the host cores, rows of each pass split across threads."""
     import numpy as np
     import chain_specs
@@ -87,10 +87,11 @@ def cpu_baseline(key, w, h, vw, vh, tree, budget_s=15.0):
     rng = np.random.default_rng(123)
     frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
     oracle_lib.set_threads(cores)
-    oracle_chain.run_chain(passes, frame[: max(8, h // 16)], vw, max(8, vh // 16))  # warm (page in)
+    kw = {"custom": custom or None, "luts": luts, "f16_targets": f16_targets}
+    oracle_chain.run_chain(passes, frame[: max(8, h // 16)], vw, max(8, vh // 16), **kw)  # warm (page in)
     n, t0 = 0, time.perf_counter()
     while True:
-        oracle_chain.run_chain(passes, frame, vw, vh, frame_count=n + 1)
+        oracle_chain.run_chain(passes, frame, vw, vh, frame_count=n + 1, **kw)
         n += 1
         if time.perf_counter() - t0 > budget_s or n >= 32:
             break
@@ -394,6 +395,7 @@ def main():
                     help="rc_engine_set_lanes: 2 (the engine's default) renders the second half of every batch on a second HIP stream")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of host work for the cpu_baseline sample")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
                     help="set a shader parameter before the run (side measurement, e.g. geom_mode_runtime=1: crt-royale's curved last pass)")
     ap.add_argument("--fp16-targets", action="store_true",
@@ -705,7 +707,9 @@ def main():
         out["io"] = io_measurements(e, w, h, args.batch, max(3, args.steps))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(key, w, h, vw, vh, tree)
+            out["cpu_baseline"] = cpu_baseline(key, w, h, vw, vh, tree, args.cpu_budget,
+                                               custom={kv.split("=")[0]: float(kv.split("=")[1]) for kv in args.param},
+                                               f16_targets=args.fp16_targets)
         print(json.dumps(out))
     e.shutdown()
     if world > 1:
