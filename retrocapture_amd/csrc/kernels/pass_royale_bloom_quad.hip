@@ -28,9 +28,8 @@ __device__ __forceinline__ uint32_t bh_srgb8(float x) { return srgb8_lds(x); }
 // blocks of 8 rows rendered per triangle.  A wave spans 128 columns (32 lanes) of TWO frames - same band, same row, so
 // every wave-uniform quantity is shared and only the frame offset is per lane - which keeps the band as narrow as the strip
 // form's (the share of blocks the diagonal crosses grows with the band) with all 64 lanes busy.
-// The sRGB decode table is replicated 16 times, entry-major, lane l reading copy l & 15: a gather of 64 random bytes from
-// one 256-entry table serialises about four-fold on its banks, and LDS time is the dearer half of these kernels
-// (a kernel's time is 0.81 x (VALU issue + 4 x LDS pipe) per SIMD).
+// (Replicating the sRGB decode table - lane l reading copy l & 15 or l & 31 of an entry-major table, which makes the gathers
+// of 64 random bytes conflict-free - was built and measured: 13.5 us per frame against 12.7 with the one table; dropped.)
 #ifndef RC_BQ_WAVES
 #define RC_BQ_WAVES 12
 #endif
@@ -41,19 +40,13 @@ constexpr int kBqSeg = kBqBand + 2 * kBqHalo;         // staged columns per fram
 constexpr int kBqSlotBytes = kBqSeg * 12;             // three decoded channels per staged texel: 1728
 constexpr int kBqRowBytes = 2 * kBqSlotBytes;         // both frame slots of one source row
 constexpr int kBqWaveBytes = 2 * kBqRowBytes;         // ring of two source rows (row r in slot r & 1)
-#ifndef RC_BQ_DEC_COPIES
-#define RC_BQ_DEC_COPIES 1
-#endif
-constexpr int kBqDecCopies = RC_BQ_DEC_COPIES;   // 1, 2, 4, 8, 16 or 32
-constexpr uint32_t kBqLdsDec = rcstrip2::kStrip2LdsUser;                    // [256 entries][16 copies]
-constexpr uint32_t kBqLdsRing = kBqLdsDec + 256u * kBqDecCopies * 4u;
+constexpr uint32_t kBqLdsRing = rcstrip2::kStrip2LdsUser;
 constexpr uint32_t kBqLdsBytes = kBqLdsRing + (uint32_t)(kBqWaves * kBqWaveBytes);
 static_assert(kBqLdsBytes <= 160u * 1024u, "quad form LDS");
 
-constexpr int bq_log2(int n) { return n <= 1 ? 0 : 1 + bq_log2(n / 2); }
-// byte N of texel t through the replicated table; lane_dec = (lane & (copies - 1)) * 4
+// byte N of texel t, decoded (the table at LDS offset 0)
 template <int N>
-__device__ __forceinline__ float bq_dec(uint32_t t, uint32_t lane_dec) { return lds_f32(kBqLdsDec + (byte_shl<N, bq_log2(kBqDecCopies) + 2>(t) | lane_dec)); }
+__device__ __forceinline__ float bq_dec(uint32_t t, uint32_t) { return dec_byte<N>(t); }
 
 struct BqCols {        // per-band lane state of one triangle: the lane's four columns
   float w[4][9];       // horizontal weight of tap q
@@ -184,12 +177,11 @@ __device__ __forceinline__ float in_vgpr(float x) {
 __global__ void __launch_bounds__(kBqWaves * 64, 1) k_royale_bloom_h_quad(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ steps,
                                                                          int n_steps, const uint32_t* __restrict__ runs, int group_taps) {
   extern __shared__ uint32_t rc_dyn_lds_[];
-  for (int i = (int)threadIdx.x; i < 256 * kBqDecCopies; i += kBqWaves * 64) rc_dyn_lds_[kBqLdsDec / 4 + i] = f2bits(k_srgb_decode[i / kBqDecCopies]);
   strip2_load_tables(rc_dyn_lds_, L, true);
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fslot = lane >> 5, grp = lane & 31;   // frame slot, group of four columns
-  const uint32_t lane_dec = (uint32_t)(lane & (kBqDecCopies - 1)) << 2;
+  const uint32_t lane_dec = 0u;
   const uint32_t ring = kBqLdsRing + (uint32_t)(wave * kBqWaveBytes);
   // the lane's staged group in ring slot 0 - and, the staged columns starting 8 left of the band, the start of its window
   const uint32_t e_main = ring + (uint32_t)(fslot * kBqSlotBytes + grp * 48);
@@ -498,6 +490,7 @@ __global__ void __launch_bounds__(kBqWaves * 64, 1) k_royale_bloom_h_quad(const 
   }
 }
 #undef RC_BQ_T
+
 }  // namespace
 
 namespace rcbloomh {
