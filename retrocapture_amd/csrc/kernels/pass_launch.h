@@ -83,6 +83,7 @@ bool royale_first_byte_map(const PassLaunch& L, hipStream_t s, float* d_dec256);
 hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_bloom_approx(const PassLaunch& L, hipStream_t s);
 hipError_t launch_blur9(const PassLaunch& L, hipStream_t s);
+bool launch_blur9_tile(const PassLaunch& L, hipStream_t s, hipError_t* err);   // pass_royale_blur.hip; false: not this geometry
 hipError_t launch_royale_mask_v(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_mask_h(const PassLaunch& L, hipStream_t s);
 hipError_t launch_royale_scan_h(const PassLaunch& L, hipStream_t s);

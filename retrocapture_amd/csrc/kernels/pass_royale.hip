@@ -1419,6 +1419,8 @@ hipError_t launch_royale_bloom_approx(const PassLaunch& L, hipStream_t s) {
   GO(k_royale_bloom_approx<SRT, StRT>);
 }
 hipError_t launch_blur9(const PassLaunch& L, hipStream_t s) {
+  hipError_t tile_err = hipSuccess;
+  if (launch_blur9_tile(L, s, &tile_err)) return tile_err;   // (pass_royale_blur.hip: texels decoded once per workgroup)
   if (SrgbLinEdge::matches(L.in) && OutS::matches(L)) GO(k_blur9<SrgbLinEdge, OutS>);
   GO(k_blur9<SRT, StRT>);
 }

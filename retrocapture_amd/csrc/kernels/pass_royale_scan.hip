@@ -212,7 +212,11 @@ constexpr float kLogMax = 0.00390625f;       // 2^-8
 constexpr float kMaxDelta = 2.6e-4f;         // byte nodes: largest |colour - node| the bounds are computed for
 constexpr float kMaxWeight = 1.25e-4f;       // largest off-centre bilinear weight per axis (2 * kMaxWeight * 1.0 < kMaxDelta)
 constexpr float kMaxDist = 6.103515625e-05f; // 2^-14: largest |dist| the bounds are computed for
-constexpr int kStripRows = 8;                // target rows one thread walks
+#ifndef RC_SCAN_STRIP_ROWS
+#define RC_SCAN_STRIP_ROWS 32   // (8 -> 32: 12.8 -> 12.0 us per 1080p frame: a strip decodes 4 + rows source rows)
+#endif
+constexpr int kStripRows = RC_SCAN_STRIP_ROWS;   // target rows one thread walks (at most 32: a lane's uncertain rows are a bit mask)
+static_assert(kStripRows % 4 == 0 && kStripRows <= 32, "kStripRows");
 constexpr int kTabWaves = 16;                // 1024 threads: one workgroup per CU (the tables fill its LDS)
 constexpr int kTabThreads = kTabWaves * 64;
 
@@ -244,7 +248,7 @@ constexpr uint32_t kFixHeader = 256;  // bytes reserved for the counter (the reg
 __device__ __forceinline__ uint32_t* fix_counter(const PassLaunch& L) { return static_cast<uint32_t*>(L.scratch); }
 __device__ __forceinline__ uint32_t* fix_list(const PassLaunch& L) { return reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(L.scratch) + kFixHeader); }
 
-struct ScanRow {  // per target row, the same for every pixel of the row except `dist` (one value per triangle)
+struct ScanRow {  // (32 bytes: the table kernel reads it as two float4) per target row, the same for every pixel of the row except `dist` (one value per triangle)
   float dist_lo, dist_up;
   float wy[3];     // bilinear weight between the two source rows of scanline s2 / s3 / so
   uint32_t up;     // bit j: that pair starts one row above the scanline's own row (weight 1 - tiny);
