@@ -218,7 +218,18 @@ __global__ void __launch_bounds__(kBv2Waves * 64) k_royale_bloom_v_strip2(const 
         nb[i] = *reinterpret_cast<const uint32_t*>(p + cb);
       }
     };
+    // `black`: how many of the most recent four-row groups were black in every lane of the wave (decode(0) = 0).  With the whole
+    // window black - five groups - the nine taps sum to 0 and the step stores black without the arithmetic (llvmpipe's default mode
+    // hands this pass an all-black frame: pass 7's mask is zero there; otherwise letterbox bars).  The window itself is kept as
+    // always (a black row decodes to zeros): the shortcut must not cost the ordinary path registers.
+    int black = 0;
     auto decode4 = [&](int slot) __attribute__((always_inline)) {
+      {
+        uint32_t any = 0u;
+#pragma unroll
+        for (int i = 0; i < kBv2Step; ++i) any |= na[i] | nb[i];
+        black = __builtin_amdgcn_ballot_w64((any & 0x00ffffffu) != 0u) == 0ull ? black + 1 : 0;
+      }
 #pragma unroll
       for (int i = 0; i < kBv2Step; ++i) {
         win[slot + i][0] = v2f{dec_byte<0>(na[i]), dec_byte<0>(nb[i])};
@@ -241,6 +252,17 @@ __global__ void __launch_bounds__(kBv2Waves * 64) k_royale_bloom_v_strip2(const 
         for (int ch = 0; ch < 3; ++ch) win[i][ch] = win[i + kBv2Step][ch];
       decode4(kBv2Win - kBv2Step);
       fetch4(y0 + kBv2Step + 8);
+      if (black >= kBv2Win / kBv2Step) {   // (wave-uniform) the window holds zeros only: encode(0 * sum_inv) = 0
+#pragma unroll
+        for (int k = 0; k < kBv2Step; ++k) {
+          const int y = y0 + k;
+          if (y < y_last) {
+            if (live_a) __builtin_amdgcn_raw_buffer_store_b32(0xff000000u, r_out, xa * 4, y * W * 4, 0);
+            if (live_b) __builtin_amdgcn_raw_buffer_store_b32(0xff000000u, r_out, xb * 4, y * W * 4, 0);
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int k = 0; k < kBv2Step; ++k) {
         const int y = y0 + k;

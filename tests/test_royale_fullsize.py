@@ -361,3 +361,34 @@ def test_crt_royale_widths_that_leave_a_partial_wave(size, preset_tree, rc_lib):
             want = e.readPass(i, k)
             assert np.array_equal(mine[k][i], want), "frame %d pass %d: %d differing bytes" % (k, i, int((mine[k][i] != want).sum()))
     e.shutdown()
+
+
+def test_crt_royale_1080p_letterboxed_frames_forms_agree(preset_tree, rc_lib):
+    """Black bars with the mask rendered: passes 7 - 10 see black regions NEXT to coloured ones (the bloom pass's black-window
+    shortcut must switch on and off inside a wave's run; in llvmpipe's default mode the whole frame is black for these passes
+    and no transition occurs).  Letterbox, pillarbox, a black frame, and bars that start / end off the 4-row step grid."""
+    import torch
+    from gpu_util import make_engine
+    g = torch.Generator(device="cuda")
+    g.manual_seed(83)
+    frames = torch.randint(0, 256, (4, H, W, 4), dtype=torch.uint8, device="cuda", generator=g)
+    frames[0, :137] = 0
+    frames[0, H - 141:] = 0            # letterbox
+    frames[1, :, :241] = 0
+    frames[1, :, W - 239:] = 0         # pillarbox
+    frames[2] = 0                      # a black frame
+    frames[3, 301:613, 500:1400] = 0   # a black window inside the picture
+    e = make_engine(preset_tree["crt-royale"], W, H)
+    e.setUndefinedVaryingZero(True)
+    e.applyShaderBatch(frames, 4, W, H)
+    e.sync()
+    mine = [[e.readPass(i, k) for i in range(12)] for k in range(4)]
+    assert mine[0][9][300:700, :, :3].any() and not mine[2][9][..., :3].any()
+    e.setGeneralKernelsOnly(True)
+    e.applyShaderBatch(frames, 4, W, H)
+    e.sync()
+    for k in range(4):
+        for i in range(12):
+            want = e.readPass(i, k)
+            assert np.array_equal(mine[k][i], want), "frame %d pass %d: %d differing bytes" % (k, i, int((mine[k][i] != want).sum()))
+    e.shutdown()
