@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 mkdir -p gpurun_out
 for V in "$@"; do
-  bash profiles/dev_variant.sh pass_royale_scan="$V" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --modes default --lanes 1 > gpurun_out/p1v.json 2> gpurun_out/p1v.err || { echo "variant '$V' failed"; tail -5 gpurun_out/p1v.err; continue; }
+  bash profiles/dev_variant.sh pass_royale_scan="$V" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --modes default --lanes ${LANES:-1} > gpurun_out/p1v.json 2> gpurun_out/p1v.err || { echo "variant '$V' failed"; tail -5 gpurun_out/p1v.err; continue; }
   python3 - "$V" <<'PY'
 import json, sys
 d = json.loads(open("gpurun_out/p1v.json").read().strip().splitlines()[-1])

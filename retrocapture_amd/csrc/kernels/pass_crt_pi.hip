@@ -109,7 +109,14 @@ constexpr int kPiNodesA = (int)((kPiA1 - kPiA0) >> kPiShift) + 2;   // node 0: b
 constexpr int kPiNodesB = (int)((kPiB1 - kPiB0) >> kPiShift) + 1;   // node 0: below the range
 constexpr uint32_t kPiLdsA = 0u, kPiLdsB = kPiLdsA + (uint32_t)kPiNodesA * 16u, kPiLdsBytes = kPiLdsB + (uint32_t)kPiNodesB * 16u;
 constexpr float kPiWiden = 1.0f / 4096.0f;         // relative widening of a node's range for table B's measurement
-constexpr int kPiRows = 16;                        // target rows one thread walks
+#ifndef RC_PI_ROWS
+#define RC_PI_ROWS 32    // (16 -> 32 rows and 8 -> 12 waves, round 4: 9.0 -> 8.0 us per 1080p frame)
+#endif
+#ifndef RC_PI_WAVES
+#define RC_PI_WAVES 12
+#endif
+constexpr int kPiRows = RC_PI_ROWS;                // target rows one thread walks (at most 32: a lane's uncertain rows are a bit mask)
+constexpr int kPiWaves = RC_PI_WAVES;              // waves per workgroup
 constexpr int kPiWaveList = 256;                   // entries of a wave's list of uncertain pixels in LDS
 constexpr uint32_t kPiFixHeader = 256;             // scratch: a counter, then one entry (frame * H + y) * W + x per failing pixel
 enum { PI_X0 = 0, PI_WX = 1, PI_COL_FIELDS = 2 };
@@ -203,7 +210,7 @@ struct CrtPiTables {
   }
 };
 
-__global__ void __launch_bounds__(kPiRows * 32) k_crt_pi_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows,
+__global__ void __launch_bounds__(kPiWaves * 64) k_crt_pi_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows,
                                                                const float4* __restrict__ tab, float K, int one_plane) {
   using namespace rcstrip2;
   extern __shared__ uint32_t rc_dyn_lds_[];
@@ -428,7 +435,7 @@ hipError_t launch_crt_pi(const PassLaunch& L, hipStream_t s) {
         auto same = [](const Plane& p) { return p.a0_lo == p.a0_up && p.dx_lo == p.dx_up && p.dy_lo == p.dy_up; };
         const bool one_plane = same(L.plane[0]) && same(L.plane[1]);
         const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kPiRows - 1) / kPiRows) * L.n_frames;
-        const int waves = 8;
+        const int waves = kPiWaves;
         const long blocks = std::min<long>((strips + waves - 1) / waves, 256L * 4);
         hipLaunchKernelGGL(k_crt_pi_strip, dim3((unsigned)std::max<long>(blocks, 1)), dim3(waves * 64), kPiLdsBytes + waves * kPiWaveList * 4, s, L, T->cols, T->rows, T->tab, T->K,
                            one_plane ? 1 : 0);

@@ -520,7 +520,11 @@ __global__ void __launch_bounds__(512) k_royale_scan_h_strip(const PassLaunch L,
 // Quilez mix of the pixel pair run as packed float operations.  Per source row a lane decodes the three texels x - 1, x,
 // x + 1 of each of its pixels once and keeps the horizontally filtered pair of the current row pair (six values per channel
 // pair).  A strip the quad's diagonal crosses is rendered once per triangle, each pixel stored by the pass of its own triangle.
-__global__ void __launch_bounds__(512) k_royale_scan_h_strip2(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
+#ifndef RC_SH_WAVES
+#define RC_SH_WAVES 8   // (with the mask rendered, one lane: 5 waves 8.85 us per frame against 9.5 - but three such workgroups fill a CU's LDS and the engine's second lane finds no room: 18.5 k frames/s against 19.3 k on two lanes)
+#endif
+constexpr int kSh2Waves = RC_SH_WAVES;   // waves per workgroup (the 53 KB of tables are per workgroup)
+__global__ void __launch_bounds__(kSh2Waves * 64) k_royale_scan_h_strip2(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
   using namespace rcstrip2;
   extern __shared__ uint32_t rc_dyn_lds_[];
   strip2_load_tables(rc_dyn_lds_, L, true);
@@ -529,7 +533,7 @@ __global__ void __launch_bounds__(512) k_royale_scan_h_strip2(const PassLaunch L
   const int bands = (W + 127) >> 7, rss = (H + kShRows - 1) / kShRows, per_frame = bands * rss, total = per_frame * L.n_frames;
   const Tex& scan = L.extra[0];
   const int sw = scan.w, sh = scan.h;
-  for (int strip = (int)blockIdx.x * 8 + wave; strip < total; strip += (int)gridDim.x * 8) {
+  for (int strip = (int)blockIdx.x * kSh2Waves + wave; strip < total; strip += (int)gridDim.x * kSh2Waves) {
     const int z = strip / per_frame, rem = strip - z * per_frame, rs = rem / bands;
     const int xw = (rem - rs * bands) << 7, ys = rs * kShRows;
     const int xa = xw + lane, xb = xa + 64;
@@ -867,7 +871,11 @@ __device__ __forceinline__ v2f brightpass_pair(v2f in, v2f bl, float cw, float m
   return in * cl;
 }
 
-__global__ void __launch_bounds__(512) k_royale_brightpass_strip2(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
+#ifndef RC_BP_WAVES
+#define RC_BP_WAVES 8
+#endif
+constexpr int kBp2Waves = RC_BP_WAVES;
+__global__ void __launch_bounds__(kBp2Waves * 64) k_royale_brightpass_strip2(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows) {
   using namespace rcstrip2;
   extern __shared__ uint32_t rc_dyn_lds_[];
   strip2_load_tables(rc_dyn_lds_, L, true);
@@ -876,7 +884,7 @@ __global__ void __launch_bounds__(512) k_royale_brightpass_strip2(const PassLaun
   const int bands = (W + 127) >> 7, rss = (H + kBpRows - 1) / kBpRows, per_frame = bands * rss, total = per_frame * L.n_frames;
   const Tex& blur = L.extra[0];
   const float cw = L.params[RP8_CENTER_WEIGHT], mask_amplify = L.params[RP8_MASK_AMPLIFY];
-  for (int strip = (int)blockIdx.x * 8 + wave; strip < total; strip += (int)gridDim.x * 8) {
+  for (int strip = (int)blockIdx.x * kBp2Waves + wave; strip < total; strip += (int)gridDim.x * kBp2Waves) {
     const int z = strip / per_frame, rem = strip - z * per_frame, rs = rem / bands;
     const int xw = (rem - rs * bands) << 7, ys = rs * kBpRows;
     const int xa = xw + lane, xb = xa + 64;
@@ -1135,13 +1143,17 @@ __global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint3
   if (why) atomicOr(bad, why);
 }
 
+#ifndef RC_LAST_WAVES
+#define RC_LAST_WAVES 8
+#endif
+constexpr int kLastWaves = RC_LAST_WAVES;
 template <class SO>
-__global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows,
+__global__ void __launch_bounds__(kLastWaves * 64) k_royale_last_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows,
                                                          const float4* __restrict__ gamma_tab) {
   RC_SRGB_LDS(lds, L);
   if ((uint32_t)(uintptr_t)(RC_AS3 uint32_t*)rc_dyn_lds_ != 0u) __builtin_trap();   // the tables are addressed by absolute LDS offsets
   if (gamma_tab) {   // uniform
-    for (int i = (int)threadIdx.x; i < kLastTabNodes; i += 512) reinterpret_cast<float4*>(rc_dyn_lds_ + kLastLdsTab / 4)[i] = gamma_tab[i];
+    for (int i = (int)threadIdx.x; i < kLastTabNodes; i += kLastWaves * 64) reinterpret_cast<float4*>(rc_dyn_lds_ + kLastLdsTab / 4)[i] = gamma_tab[i];
     __syncthreads();
   }
   const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -1149,7 +1161,7 @@ __global__ void __launch_bounds__(512) k_royale_last_strip(const PassLaunch L, c
   const int W = G.W, H = G.H, Win = L.in.w, Hin = L.in.h;
   const float* P = L.params;
   const float inv_gamma = 1.0f / P[1], border_size = P[39], border_darkness = P[40], border_compress = P[41];
-  for (int strip = (int)blockIdx.x * 8 + wave; strip < G.total; strip += (int)gridDim.x * 8) {
+  for (int strip = (int)blockIdx.x * kLastWaves + wave; strip < G.total; strip += (int)gridDim.x * kLastWaves) {
     int z, xw, ys;
     G.locate(strip, &z, &xw, &ys);
     const int x = xw + lane;
@@ -1432,8 +1444,8 @@ hipError_t launch_royale_scan_h(const PassLaunch& L, hipStream_t s) {
       static std::map<rcstrip::GeoKey, rcstrip::GeoCached<ScanHTables>> cache;
       if (const auto T = rcstrip::geo_tables<ScanHTables>(L, s, mu, cache, buildScanHTables)) {
         const long strips = (long)((L.out_w + 127) / 128) * ((L.out_h + kShRows - 1) / kShRows) * L.n_frames;
-        const long blocks = (strips + 7) / 8;
-        hipLaunchKernelGGL(k_royale_scan_h_strip2, dim3((unsigned)(blocks < 768 ? blocks : 768)), dim3(512), rcstrip2::kStrip2LdsUser, s, L, T->cols, T->rows);
+        const long blocks = (strips + kSh2Waves - 1) / kSh2Waves;
+        hipLaunchKernelGGL(k_royale_scan_h_strip2, dim3((unsigned)(blocks < 768 ? blocks : 768)), dim3(kSh2Waves * 64), rcstrip2::kStrip2LdsUser, s, L, T->cols, T->rows);
         return hipGetLastError();
       }
     }
@@ -1455,8 +1467,8 @@ hipError_t launch_royale_brightpass(const PassLaunch& L, hipStream_t s) {
       static std::map<rcstrip::GeoKey, rcstrip::GeoCached<BpTables>> cache;
       if (const auto T = rcstrip::geo_tables<BpTables>(L, s, mu, cache, buildBpTables)) {
         const long strips = (long)((L.out_w + 127) / 128) * ((L.out_h + kBpRows - 1) / kBpRows) * L.n_frames;
-        const long blocks = (strips + 7) / 8;
-        hipLaunchKernelGGL(k_royale_brightpass_strip2, dim3((unsigned)(blocks < 768 ? blocks : 768)), dim3(512), rcstrip2::kStrip2LdsUser, s, L, T->cols, T->rows);
+        const long blocks = (strips + kBp2Waves - 1) / kBp2Waves;
+        hipLaunchKernelGGL(k_royale_brightpass_strip2, dim3((unsigned)(blocks < 768 ? blocks : 768)), dim3(kBp2Waves * 64), rcstrip2::kStrip2LdsUser, s, L, T->cols, T->rows);
         return hipGetLastError();
       }
     }
@@ -1478,8 +1490,8 @@ hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
       static std::map<rcstrip::GeoKey, rcstrip::GeoCached<LastTables>> cache;
       if (const auto T = rcstrip::geo_tables<LastTables>(L, s, mu, cache, buildLastTables)) {
         const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kLastRows - 1) / kLastRows) * L.n_frames;
-        const long blocks = (strips + 7) / 8;
-        hipLaunchKernelGGL((k_royale_last_strip<St<FMT_RGBA8>>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(512),
+        const long blocks = (strips + kLastWaves - 1) / kLastWaves;
+        hipLaunchKernelGGL((k_royale_last_strip<St<FMT_RGBA8>>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(kLastWaves * 64),
                            rcd::srgb_lds_bytes(L) + kLastTabNodes * sizeof(float4), s, L, T->cols, T->rows, T->gamma_tab);
         return hipGetLastError();
       }

@@ -858,7 +858,10 @@ hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s) {
       const long tiles = (strips + kTabWaves - 1) / kTabWaves;
       if (hipMemsetAsync(L.scratch, 0, kFixHeader, s) != hipSuccess) return hipGetLastError();
       hipLaunchKernelGGL(kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(kTabThreads), kLdsTotalBytes, s, L, T->nodes.A, T->rows, T->cols, skip_r, skip_g, skip_b);
-      hipLaunchKernelGGL((k_royale_scan_v_fix<SrgbLinEdge, OutS>), dim3(512), dim3(256), rcd::srgb_lds_bytes(L), s, L);
+      #ifndef RC_SCAN_FIX_BLOCKS
+#define RC_SCAN_FIX_BLOCKS 1024
+#endif
+      hipLaunchKernelGGL((k_royale_scan_v_fix<SrgbLinEdge, OutS>), dim3(RC_SCAN_FIX_BLOCKS), dim3(256), rcd::srgb_lds_bytes(L), s, L);
       return hipGetLastError();
     }
     // two rows per thread: 64 x 8 tiles
