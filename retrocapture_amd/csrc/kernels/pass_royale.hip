@@ -1147,6 +1147,8 @@ __global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint3
 #define RC_LAST_WAVES 8
 #endif
 constexpr int kLastWaves = RC_LAST_WAVES;
+constexpr int kLastList = 576;   // entries of a wave's list of uncertain pixels: up to 63 carried over + the 512 a strip can add
+constexpr uint32_t kLastLdsList = (kLastLdsTab + (uint32_t)kLastTabNodes * 16u + 15u) & ~15u;   // behind the gamma table
 template <class SO>
 __global__ void __launch_bounds__(kLastWaves * 64) k_royale_last_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows,
                                                          const float4* __restrict__ gamma_tab) {
@@ -1161,16 +1163,34 @@ __global__ void __launch_bounds__(kLastWaves * 64) k_royale_last_strip(const Pas
   const int W = G.W, H = G.H, Win = L.in.w, Hin = L.in.h;
   const float* P = L.params;
   const float inv_gamma = 1.0f / P[1], border_size = P[39], border_darkness = P[40], border_compress = P[41];
-  for (int strip = (int)blockIdx.x * kLastWaves + wave; strip < G.total; strip += (int)gridDim.x * kLastWaves) {
-    int z, xw, ys;
-    G.locate(strip, &z, &xw, &ys);
-    const int x = xw + lane;
-    if (x >= W) continue;
+  // Pixels the gamma table cannot certify (0.3 % of them) are rendered with the exact per-pixel form - SIXTY-FOUR AT A TIME: a wave
+  // collects them in its list in LDS (positions from a ballot, as pass 1 does) and renders a full wave of them whenever the list
+  // holds that many, the remainder when it is done.  (Until round 4 every strip ended in a divergent loop that ran the exact form
+  // for its one or two uncertain pixels with 62 lanes idle: 0.8 such loops per strip, a quarter of the kernel's instructions.)
+  uint32_t* my_list = rc_dyn_lds_ + kLastLdsList / 4 + wave * kLastList;
+  uint32_t n_listed = 0u;   // wave-uniform (lane 0 takes part in every strip and holds the valid copy: see k_royale_scan_v_tab)
+  auto drain = [&](bool all) __attribute__((always_inline)) {   // (every lane active)
+    uint32_t n = __builtin_amdgcn_readfirstlane(n_listed);
+    while (n >= 64u || (all && n > 0u)) {
+      const uint32_t take = n < 64u ? n : 64u, first = n - take;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS stores, in order
+      if ((uint32_t)lane < take) {
+        const uint32_t id = my_list[first + (uint32_t)lane];
+        const uint32_t row = id / (uint32_t)W;
+        const int px = (int)(id - row * (uint32_t)W), pz = (int)(row / (uint32_t)H), py = (int)(row - (uint32_t)pz * (uint32_t)H);
+        last_pixel<SrgbLinEdge, SO, false>(L, lds, px, py, pz, rcd::lower_tri(px, py, W, H));
+      }
+      asm volatile("" ::: "memory");
+      n = first;
+    }
+    n_listed = n;
+  };
+  auto strip_body = [&](int z, int xw, int ys, int x) __attribute__((always_inline)) {
     const int xmax = min(xw + 63, W - 1), ymax = min(ys + kLastRows - 1, H - 1);
     const bool all_lo = rcd::lower_tri(xw, ymax, W, H), all_up = !rcd::lower_tri(xmax, ys, W, H);
     if (!all_lo && !all_up) {   // the quad's diagonal crosses this strip: per-pixel form
       for (int y = ys; y <= ymax; ++y) last_pixel<SrgbLinEdge, SO, false>(L, lds, x, y, z, rcd::lower_tri(x, y, W, H));
-      continue;
+      return;
     }
     const int side = all_lo ? 0 : 1;
     const int x0 = (int)cols[(LS_X0 * 2 + side) * W + x];
@@ -1267,15 +1287,37 @@ __global__ void __launch_bounds__(kLastWaves * 64) k_royale_last_strip(const Pas
         w1[ch] = w3[ch];
       }
     }
-    // the pixels the table could not certify: the exact per-pixel form (a few per strip)
-    while (__builtin_amdgcn_ballot_w64(failed != 0u) != 0ull) {
+    // the pixels the table could not certify go to the wave's list (pass 1's scheme: positions from the ballot, no atomics)
+    while (true) {
+      const uint64_t any = __builtin_amdgcn_ballot_w64(failed != 0u);
+      if (any == 0ull) break;
+      const uint32_t n = (uint32_t)__builtin_popcountll(any);
+      const uint32_t cur = __builtin_amdgcn_readfirstlane(n_listed);   // (lane 0's copy: taken before the branch below)
+      if (cur + n > (uint32_t)kLastList) {   // (never expected: more than kLastList - 63 uncertain pixels in one strip) in place, as before
+        if (failed) {
+          const int k = __builtin_ctz(failed);
+          failed &= failed - 1u;
+          last_pixel<SrgbLinEdge, SO, false>(L, lds, x, ys + k, z, side == 0);
+        }
+        continue;
+      }
       if (failed) {
         const int k = __builtin_ctz(failed);
         failed &= failed - 1u;
-        last_pixel<SrgbLinEdge, SO, false>(L, lds, x, ys + k, z, side == 0);
+        const uint32_t pos = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+        my_list[pos] = (uint32_t)((z * H + ys + k) * W + x);
       }
+      n_listed = cur + n;
     }
+  };
+  for (int strip = (int)blockIdx.x * kLastWaves + wave; strip < G.total; strip += (int)gridDim.x * kLastWaves) {
+    int z, xw, ys;
+    G.locate(strip, &z, &xw, &ys);
+    const int x = xw + lane;
+    if (x < W) strip_body(z, xw, ys, x);
+    drain(false);
   }
+  drain(true);
 }
 
 // the gamma table for 1 / lcd_gamma into `tab` (kLastTabNodes records): slope and half curvature from the closed form in double
@@ -1492,7 +1534,7 @@ hipError_t launch_royale_last(const PassLaunch& L, hipStream_t s) {
         const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kLastRows - 1) / kLastRows) * L.n_frames;
         const long blocks = (strips + kLastWaves - 1) / kLastWaves;
         hipLaunchKernelGGL((k_royale_last_strip<St<FMT_RGBA8>>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(kLastWaves * 64),
-                           rcd::srgb_lds_bytes(L) + kLastTabNodes * sizeof(float4), s, L, T->cols, T->rows, T->gamma_tab);
+                           kLastLdsList + (unsigned)(kLastWaves * kLastList * 4), s, L, T->cols, T->rows, T->gamma_tab);
         return hipGetLastError();
       }
     }
