@@ -361,7 +361,10 @@ __global__ void __launch_bounds__(256) k_royale_scan_h(const PassLaunch L) {
 // share one row pair.  A thread walks kShRows rows of one column and filters each source row horizontally once
 // (six values); rows whose mask texels are all zero in a wave (every row on a GL that discards pass 6's fragments)
 // skip the scanline work like the general kernel does per pixel.
-constexpr int kShRows = 8;
+#ifndef RC_SH_ROWS
+#define RC_SH_ROWS 16   // (8 -> 16, round 4: 9.5 -> 9.2 us per frame with the mask rendered)
+#endif
+constexpr int kShRows = RC_SH_ROWS;
 enum { SH_WXA = 0, SH_WXB = 3, SH_FY = 6, SH_FZ = 9, SH_MX = 12, SH_COL_FIELDS = 13 };
 enum { SH_Y0 = 0, SH_WY = 1, SH_MY = 2, SH_ROW_FIELDS = 4 };
 struct ScanHTables {
@@ -744,7 +747,10 @@ __device__ __forceinline__ float brightpass_channel(float in, float bl, float cw
 // Separable geometry (royale_strip.h): the NEAREST tap of pass 7's target is the texel (ix(x), iy(y)); the LINEAR tap
 // of the 320x240 halation blur is magnified, so a thread walking a column keeps the two horizontally filtered blur
 // rows of the current row pair and refilters only when the pair moves on (every fourth target row or so).
-constexpr int kBpRows = 8;
+#ifndef RC_BP_ROWS
+#define RC_BP_ROWS 32   // (8 -> 32, round 4: 6.8 -> 6.4 us per frame with the mask rendered)
+#endif
+constexpr int kBpRows = RC_BP_ROWS;
 enum { BP_IX = 0, BP_BX0 = 1, BP_BWX = 2, BP_COL_FIELDS = 3 };
 enum { BP_IY = 0, BP_BY0 = 1, BP_BWY = 2, BP_ROW_FIELDS = 4 };
 struct BpTables {
@@ -1046,7 +1052,10 @@ __global__ void __launch_bounds__(256) k_royale_last(const PassLaunch L) {
 // horizontally once, and evaluates two target rows per step so that their six output-gamma pows run as three
 // packed pairs (rc_vecmath.h).  The border factor is 1 away from the border (k_royale_last explains why), which
 // k_last_geometry records per column / row as "border distance is zero".
-constexpr int kLastRows = 8;
+#ifndef RC_LAST_ROWS
+#define RC_LAST_ROWS 16   // (8 -> 16, round 4: 7.6 -> 7.4 us per frame)
+#endif
+constexpr int kLastRows = RC_LAST_ROWS;   // (even, at most 32: a lane's uncertain rows are a bit mask)
 enum { LS_X0 = 0, LS_WX = 1, LS_BX = 2, LS_COL_FIELDS = 3 };
 enum { LS_Y0 = 0, LS_WY = 1, LS_BY = 2, LS_ROW_FIELDS = 4 };
 struct LastTables {
@@ -1147,7 +1156,7 @@ __global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint3
 #define RC_LAST_WAVES 8
 #endif
 constexpr int kLastWaves = RC_LAST_WAVES;
-constexpr int kLastList = 576;   // entries of a wave's list of uncertain pixels: up to 63 carried over + the 512 a strip can add
+constexpr int kLastList = 64 + 64 * kLastRows;   // entries of a wave's list of uncertain pixels: up to 63 carried over + what a strip can add
 constexpr uint32_t kLastLdsList = (kLastLdsTab + (uint32_t)kLastTabNodes * 16u + 15u) & ~15u;   // behind the gamma table
 template <class SO>
 __global__ void __launch_bounds__(kLastWaves * 64) k_royale_last_strip(const PassLaunch L, const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rows,
