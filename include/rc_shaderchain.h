@@ -292,7 +292,9 @@ int rc_selftest_copy_rate(int device, size_t bytes, int reps, double* gb_per_s);
 int rc_selftest_srgb8_host(const float* src, uint8_t* dst, size_t n);
 int rc_selftest_srgb8_device(int device, const float* d_src, uint8_t* d_dst, size_t n, void* stream);
 /* The same through the second form of the table (form = 2: one entry per run from the first float that stores a non-zero
- * byte, the linear segment included; the strip kernels' encode - clamp, one LDS read, one add); form = 1 is the above. */
+ * byte, the linear segment included; the strip kernels' encode - clamp, one LDS read, one add); form = 1 is the above (on the
+ * device: the table read where it lies in device memory, as small targets do); form = 3, device only, is form 1 with the
+ * table copied into every workgroup's LDS first, as every large sRGB8 target does. */
 int rc_selftest_srgb8_host_form(const float* src, uint8_t* dst, size_t n, int form);
 int rc_selftest_srgb8_device_form(int device, const float* d_src, uint8_t* d_dst, size_t n, void* stream, int form);
 /* crt-royale's scanline pass (crt-royale-scanlines-vertical-interlacing.glsl) runs, at 1:1 geometry, from an

@@ -370,59 +370,6 @@ __global__ void __launch_bounds__(kBqWaves * 64, 1) k_royale_bloom_h_quad(const 
     if (two) bq_filter<true>(c, win_a, win_b, wy, w78, w56, w34, w12, s);
     else bq_filter<false>(c, win_a, win_a, 0.0f, w78, w56, w34, w12, s);
 #endif
-#ifdef RC_BQ_EXP_ONE   // (development: the price of the one-row filter's 386 scalar instructions in place, on every step)
-    {
-      float s2[4][3];
-      asm volatile("" ::: "memory");
-      bq_filter<false>(c, win_a, win_a, 0.0f, w78, w56, w34, w12, s2);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) s[i][ch] = fma_(s2[i][ch], 0.0f, s[i][ch]);
-    }
-#endif
-#ifdef RC_BQ_EXP_PACKED   // (development: the same arithmetic volume as 191 packed instructions)
-    {
-      asm volatile("" ::: "memory");
-      v2f Pq[30];
-#pragma unroll
-      for (int k2 = 0; k2 < 15; ++k2) {
-        const v4f qd = lds_v4f(win_a + 16u * (uint32_t)k2);
-        Pq[2 * k2] = v2f{qd.x, qd.y};
-        Pq[2 * k2 + 1] = v2f{qd.z, qd.w};
-      }
-      v2f acc2[6];
-#pragma unroll
-      for (int o2 = 0; o2 < 6; ++o2) {
-#pragma unroll
-        for (int q2 = 0; q2 < 9; ++q2) {
-          const v2f wv = v2f{c.w[o2 & 3][q2], c.w[(o2 + 1) & 3][q2]};
-          const v2f d2 = Pq[o2 + 2 * q2 + 1] - Pq[o2 + 2 * q2];
-          const v2f h2 = fma2(wv, d2, Pq[o2 + 2 * q2]);
-          const float wt = q2 == 0 || q2 == 8 ? w78 : (q2 == 1 || q2 == 7 ? w56 : (q2 == 2 || q2 == 6 ? w34 : w12));
-          if (q2 == 0) acc2[o2] = v2f{wt, wt} * h2;
-          else acc2[o2] = acc2[o2] + v2f{wt, wt} * h2;
-        }
-      }
-#pragma unroll
-      for (int o2 = 0; o2 < 6; ++o2) {
-        s[o2 >> 1][(o2 & 1)] = fma_(acc2[o2].x, 0.0f, s[o2 >> 1][(o2 & 1)]);
-        s[3][o2 >> 1] = fma_(acc2[o2].y, 0.0f, s[3][o2 >> 1]);
-      }
-    }
-#endif
-#ifdef RC_BQ_EXP_TWICE   // (development: the price of the filter's instructions in place)
-    {
-      float s2[4][3];
-      asm volatile("" ::: "memory");
-      if (two) bq_filter<true>(c, win_a, win_b, wy, w78, w56, w34, w12, s2);
-      else bq_filter<false>(c, win_a, win_a, 0.0f, w78, w56, w34, w12, s2);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) s[i][ch] = fma_(s2[i][ch], 0.0f, s[i][ch]);
-    }
-#endif
     // ---- reconstitute (as k_royale_bloom_h) and store
     float di[4][3], dj[4][3];   // MASKED_SCANLINES, BRIGHTPASS
     if (group_taps & 1) {

@@ -80,6 +80,14 @@ hipError_t launch_selftest_srgb8(const float* d_src, uint8_t* d_dst, size_t n, c
   PassLaunch L = {};
   L.out_fmt = FMT_SRGB8;
   L.srgb_enc = table;
+  // form 1: the table where it is, in device memory (what a small sRGB8 target does); form 3: a target large enough for
+  // load_srgb_tables to copy the table into every workgroup's LDS (rc_device.h srgb_enc_in_lds) - the path of every 1080p pass
+  if (form == 3) {
+    L.out_w = 2048;
+    L.out_h = 1024;
+    L.n_frames = 1;
+    if (!rcd::srgb_enc_in_lds(L)) return hipErrorInvalidValue;
+  }
   hipLaunchKernelGGL(k_selftest_srgb8, dim3(1024), dim3(256), rcd::srgb_lds_bytes(L), s, d_src, d_dst, n, L);
   return hipGetLastError();
 }

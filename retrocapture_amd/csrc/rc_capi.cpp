@@ -407,14 +407,14 @@ int rc_selftest_srgb8_host_form(const float* src, uint8_t* dst, size_t n, int fo
   });
 }
 int rc_selftest_srgb8_device_form(int device, const float* d_src, uint8_t* d_dst, size_t n, void* stream, int form) {
-  if (form != 2) return rc_selftest_srgb8_device(device, d_src, d_dst, n, stream);
+  if (form != 2 && form != 3) return rc_selftest_srgb8_device(device, d_src, d_dst, n, stream);
   if (!d_src || !d_dst) return RC_ERR_INVALID;
   if (device >= 0 && hipSetDevice(device) != hipSuccess) return RC_ERR_DEVICE;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return RC_ERR_DEVICE;
   const uint32_t* table = rc::deviceSrgbRunTable(dev);
   if (!table) return RC_ERR_DEVICE;
-  return rck::launch_selftest_srgb8(d_src, d_dst, n, table, static_cast<hipStream_t>(stream), 2) == hipSuccess ? RC_OK : RC_ERR_DEVICE;
+  return rck::launch_selftest_srgb8(d_src, d_dst, n, table, static_cast<hipStream_t>(stream), form) == hipSuccess ? RC_OK : RC_ERR_DEVICE;
 }
 int rc_selftest_srgb8_device(int device, const float* d_src, uint8_t* d_dst, size_t n, void* stream) {
   if (!d_src || !d_dst) return RC_ERR_INVALID;

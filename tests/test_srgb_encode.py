@@ -111,3 +111,17 @@ def test_device_encode_matches_oracle(rc_lib):
     engine.srgb8_encode_device(d, o, v.size, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(o.cpu().numpy(), oracle_encode(v))
+
+
+@pytest.mark.gpu
+def test_device_encode_through_the_lds_copy_matches_oracle(rc_lib):
+    """Form 3: the first form of the table copied into every workgroup's LDS, which is how every large sRGB8 target encodes
+    (form 1 on the device reads the table in device memory, as the 320 x 240 passes do)."""
+    import torch
+    from retrocapture_amd import engine
+    v = np.concatenate([probe_values(), probe_values_linear_segment()])
+    d = torch.from_numpy(v.copy()).cuda()
+    o = torch.empty(v.size, dtype=torch.uint8, device="cuda")
+    engine.srgb8_encode_device(d, o, v.size, stream=torch.cuda.current_stream().cuda_stream, form=3)
+    torch.cuda.synchronize()
+    assert np.array_equal(o.cpu().numpy(), oracle_encode(v))
