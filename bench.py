@@ -103,6 +103,7 @@ def cpu_baseline(key, w, h, vw, vh, tree, budget_s=15.0, custom=None, luts=None,
 
 PMC_FILE = "r04_royale_pmc.csv"   # the committed counter summary the `traffic` / `valu` figures are read from (profiles/collect.sh) ...
 PMC_FRAMES_PER_LAUNCH = 128.0     # ... and the launch shape it was collected at: the engine's default for 1080p chains
+STATS_FILE = "r04_royale_kernel_stats.csv"   # the per-kernel durations of that collection (one lane): pmc_fresh
 
 
 def pmc_traffic(kernel_name, frames_per_launch):
@@ -127,6 +128,26 @@ def pmc_traffic(kernel_name, frames_per_launch):
         if r and r.get("FETCH_SIZE_avg") and r.get("WRITE_SIZE_avg"):
             return (2.0 * float(r["FETCH_SIZE_avg"]) + float(r["WRITE_SIZE_avg"])) * 1024.0
     return None
+
+
+def pmc_fresh(kernel_name, avg_launch_ms):
+    """The committed counters describe the kernel that is running now only while that kernel takes what it took when they
+    were collected: the live launch duration against the committed rocprofv3 summary of the same collection
+    (profiles/r04_royale_kernel_stats.csv), within 15 %.  Otherwise `traffic` / `valu` are withheld (null) rather than replayed."""
+    import csv
+    path = os.path.join(ROOT, "profiles", STATS_FILE)
+    if not os.path.exists(path) or avg_launch_ms <= 0:
+        return False
+    want = {"royale-scanlines-v": "k_royale_scan_v", "royale-bloom-h": "k_royale_bloom_h"}.get(kernel_name, "k_" + kernel_name.replace("-", "_"))
+    rows = {r["kernel"]: r for r in csv.DictReader(open(path))}
+    for name in (want + "_quad", want + "_strip", want + "_tab", want + "2", want):
+        r = rows.get(name)
+        if r and r.get("avg_ns"):
+            then_ms = float(r["avg_ns"]) * 1e-6
+            if rows.get(want + "_fix", {}).get("avg_ns"):   # (the pass's launch duration covers its fix-up kernel too)
+                then_ms += float(rows[want + "_fix"]["avg_ns"]) * 1e-6
+            return abs(avg_launch_ms - then_ms) <= 0.15 * then_ms
+    return False
 
 
 def pmc_valu(kernel_name, frames_per_launch, avg_launch_ms):
@@ -665,6 +686,9 @@ def main():
                      "note": "frames of 8x8 flat tiles from a 16-colour palette with 8 % sprite detail; `value` stays on uniform noise"}
     ceiling, memcpy_rate = copy_ceiling(torch)
     pass_ms_per_step = sum(q["total_ms"] / max(1, q["frames"]) for q in prof) * n_local
+    # the committed counters are replayed only for the kernel they were collected on (same launch shape, same duration within 15 %)
+    fresh = pmc_fresh(infos[dom]["kernel"], avg_ms)
+    traffic = pmc_traffic(infos[dom]["kernel"], frames_per_launch) if fresh else None
     out = {
         # BASELINE.json's metric for the default workload; other --workload values are side measurements
         "metric": ("1080p frames/sec, crt-royale 12-pass, 1/2/4/8 MI355X; % HBM roofline" if wl == "crt-royale"
@@ -686,13 +710,13 @@ def main():
                    "copy_ceiling_frac_whole_chain": value / world * chain_bytes / (ceiling * 1e9)},
         "roofline": {"bound": "hbm", "kernel": infos[dom]["kernel"], "pass": dom, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(infos[dom]["kernel"], frames_per_launch), "traffic_source": "profiles/" + PMC_FILE,
+                     "traffic": traffic, "traffic_source": ("profiles/" + PMC_FILE) if traffic is not None else None,
                      "avg_launch_ms": avg_ms, "frames_per_launch": frames_per_launch,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "frac_of_copy_ceiling": achieved / ceiling,
                      "lanes_of_this_figure": 1,
                      "overlap_factor": pass_ms_per_step / (dt / args.steps * 1e3) if args.lanes == 2 else 1.0,
-                     "valu": pmc_valu(infos[dom]["kernel"], frames_per_launch, avg_ms)},
+                     "valu": pmc_valu(infos[dom]["kernel"], frames_per_launch, avg_ms) if fresh else None},
         "per_pass_ms_per_frame": [q["total_ms"] / max(1, q["frames"]) for q in prof],
     }
     if mask_rendered is not None:
