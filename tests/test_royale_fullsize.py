@@ -392,3 +392,38 @@ def test_crt_royale_1080p_letterboxed_frames_forms_agree(preset_tree, rc_lib):
             want = e.readPass(i, k)
             assert np.array_equal(mine[k][i], want), "frame %d pass %d: %d differing bytes" % (k, i, int((mine[k][i] != want).sum()))
     e.shutdown()
+
+
+@pytest.mark.parametrize("size", [(1280, 720), (1366, 768), (2560, 1440), (854, 480), (720, 576), (1920, 1200)])
+@pytest.mark.parametrize("mask_rendered", [False, True])
+def test_crt_royale_other_frame_sizes_forms_agree(size, mask_rendered, preset_tree, rc_lib):
+    """The specialised forms (strip / table / tile / quad kernels, folded pass 0, two lanes) against the general per-pixel forms on
+    one lane at frame sizes other than 1080p - heights that are not multiples of the strips' 8 / 16 / 32 rows, widths that are not
+    multiples of 64 / 128, a 4:3 and a 16:10 frame: every pass, every byte."""
+    import torch
+    from gpu_util import make_engine
+    vw, vh = size
+    g = torch.Generator(device="cuda")
+    g.manual_seed(84 + vw)
+    n = 5
+    frames = torch.randint(0, 256, (n, vh, vw, 4), dtype=torch.uint8, device="cuda", generator=g)
+    frames[1, : vh // 7] = 0   # (a black bar: the bloom pass's black-window shortcut next to coloured rows)
+    e = make_engine(preset_tree["crt-royale"], vw, vh)
+    e.setUndefinedVaryingZero(mask_rendered)
+    e.applyShaderBatch(frames, n, vw, vh)
+    e.sync()
+    mine = [[e.readPass(i, k) for i in range(12)] for k in range(n)]
+    e.shutdown()
+    # a fresh engine for the general forms: FrameCount starts over (480- and 576-line sources are interlaced to crt-royale, and
+    # its field handling reads the frame counter's parity - a second call on the same engine renders the other fields)
+    e = make_engine(preset_tree["crt-royale"], vw, vh)
+    e.setUndefinedVaryingZero(mask_rendered)
+    e.setGeneralKernelsOnly(True)
+    e.setLanes(1)
+    e.applyShaderBatch(frames, n, vw, vh)
+    e.sync()
+    for k in range(n):
+        for i in range(12):
+            want = e.readPass(i, k)
+            assert np.array_equal(mine[k][i], want), "%dx%d frame %d pass %d: %d differing bytes" % (vw, vh, k, i, int((mine[k][i] != want).sum()))
+    e.shutdown()
