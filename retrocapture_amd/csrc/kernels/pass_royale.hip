@@ -1077,10 +1077,11 @@ struct LastTables {
 // log-spaced nodes: 32 per octave (the top five mantissa bits of c select the node, its colour c0 is the bucket's midpoint)
 // from 2^-20 - below which G(c) * 255 < 0.47 and the byte is 0 for certain - up to 1.  Per node: the quadratic through T = G(c0)
 // (the float the exact code computes) with slope and half curvature from the closed form, written in the colour itself,
-// a0 + c (a1 + c a2), and a bound R on |G(c) - fma(c, fma(c, a2, a1), a0)| that k_last_gamma_err MEASURES over EVERY float of the bucket (2^18 floats; 168 M exact evaluations per
-// table) against the very expression the strip kernel evaluates - a bound by exhaustion, not by sampling: third-order
-// remainder and float noise together stay below 4e-7 G.  The kernel stores the byte when the whole interval rounds to one byte
-// (x -> rint(clamp(x) * 255) is monotone) and re-renders the few other pixels with the exact per-pixel code.
+// a0 + c (a1 + c a2) - since round 4 scaled by 255, so that the table delivers y ~ 255 G, the value the byte is rounded from - and a bound E
+// on |fl(min(G(c), 1) * 255) - fma(c, fma(c, a2, a1), a0)|, the exact code's own pre-rounding value against the very expression the strip kernel
+// evaluates, that k_last_gamma_err MEASURES over EVERY float of the bucket (2^18 floats; 168 M exact evaluations per table): a bound by
+// exhaustion, not by sampling.  With r = rint(y) the exact code's byte is r whenever |y - r| + E < 0.5, and the kernel re-renders the
+// few other pixels with the exact per-pixel code.
 // (kLastTabBits0 / kLastTabShift / kLastTabNodes / kLastLdsTab and last_gamma_byte: royale_common.h)
 __device__ __forceinline__ float last_gamma(float c, float inv_gamma) { return exp2_(log2_(c) * inv_gamma); }   // = the strips' packed form per component
 __host__ __device__ __forceinline__ float last_node_colour(int n) {
@@ -1094,9 +1095,11 @@ __global__ void __launch_bounds__(256) k_last_gamma_err(float inv_gamma, float4*
     // the node's quadratic written in the colour itself (the strip kernel then needs neither the node colour nor a subtraction):
     // a0 + c (a1 + c a2) with a2 = G''/2, a1 = G' - 2 a2 c0, a0 = T - G' c0 + a2 c0^2 from the host's G', G''/2 (tab[n].y, .z)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+      // (... times 255: the table delivers the value the byte is rounded from, y = 255 G, in two fmas)
       const double T = (double)last_gamma(c0, inv_gamma), X = (double)c0, g1 = (double)tab[n].y, g2 = (double)tab[n].z;
-      tab[n].x = (float)(T - g1 * X + g2 * X * X);
-      tab[n].y = (float)(g1 - 2.0 * g2 * X);
+      tab[n].x = (float)(255.0 * (T - g1 * X + g2 * X * X));
+      tab[n].y = (float)(255.0 * (g1 - 2.0 * g2 * X));
+      tab[n].z = (float)(255.0 * g2);
     }
     return;
   }
@@ -1105,15 +1108,20 @@ __global__ void __launch_bounds__(256) k_last_gamma_err(float inv_gamma, float4*
   uint32_t worst = 0u;
   for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i <= hi; i += gridDim.x * 256u) {
     const float c = bits2f(i);
-    const double err = fabs((double)last_gamma(c, inv_gamma) - (double)fma_(c, fma_(c, e.z, e.y), e.x));
+    // against what the exact code rounds to its byte: fl(min(G, 1) * 255) (rc_device.h unorm8; G > 0 here)
+    const float g = last_gamma(c, inv_gamma);
+    const double err = fabs((double)((g > 1.0f ? 1.0f : g) * 255.0f) - (double)fma_(c, fma_(c, e.z, e.y), e.x));
     worst = max(worst, f2bits(__double2float_ru(err)));
   }
   if (worst) atomicMax(reinterpret_cast<uint32_t*>(&tab[n].w), worst);   // non-negative floats order like their bits
 }
-// the stored bound absorbs its own rounding; the roundings of lin -+ bound are added in the kernel, relative to lin
+// What a record keeps is not the bound E but the threshold of last_gamma_byte's test, |y - r| < 0.5 - E, taken down so that its own
+// roundings stay on the safe side (a node whose bound leaves no room keeps 0: every lookup fails over to the exact code)
 __global__ void __launch_bounds__(256) k_last_gamma_finish(float4* tab) {
   const int n = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (n < kLastTabNodes) tab[n].w = tab[n].w * 1.000001f + 1e-12f;
+  if (n >= kLastTabNodes) return;
+  const float thr = 0.5f - (tab[n].w * 1.000001f + 1e-7f);
+  tab[n].w = thr > 1e-6f ? bits2f(f2bits(thr) - 2u) : 0.0f;
 }
 
 __global__ void __launch_bounds__(256) k_last_geometry(const PassLaunch L, uint32_t* cols, uint32_t* rows, uint32_t* bad) {

@@ -58,9 +58,9 @@ constexpr int kLastTabShift = 18;                 // 2^18 floats per node: 32 no
 constexpr int kLastTabNodes = (int)((0x3f800000u - kLastTabBits0) >> kLastTabShift) + 1;   // 641: the last one is the colour 1.0 alone
 constexpr uint32_t kLastLdsTab = 1024u;   // LDS byte offset of the table (behind the decode table; the kernels have no static LDS)
 // one channel of one pixel from the gamma table: the byte, *fail set when it is not certain.  0 <= c <= 1 (callers send anything
-// else to the exact code).  With y = fl(lin * 255) and r = rint(y): the exact code stores rint(fl(clamp(G) * 255)),
-// |G - lin| <= bound, and the two products round within 2^-24 * 255 each, so the byte is r whenever
-// |y - r| + 255 bound + 3.1e-5 < 0.5 (clamping r to [0, 255] commutes with it).
+// else to the exact code).  The record's polynomial gives y ~ 255 G(c) and its .w the threshold 0.5 - E, E the measured bound on the
+// distance of y from the value the exact code rounds (pass_royale.hip k_last_gamma_err / _finish): with r = rint(y) the byte is r
+// whenever |y - r| < .w.  r needs no clamp: y lies within E of [0, 255], and the integer conversion takes a negative zero to 0.
 __device__ __forceinline__ uint32_t last_gamma_byte(float c, bool* fail) {
   typedef float last_v4f __attribute__((ext_vector_type(4)));
   // colours below the table's first node store 0 like that node's first colour does (G is monotone, G(2^-20) * 255 < 0.47)
@@ -68,10 +68,10 @@ __device__ __forceinline__ uint32_t last_gamma_byte(float c, bool* fail) {
   const uint32_t off = ((cb - kLastTabBits0) >> (kLastTabShift - 4)) & ~15u;
   const last_v4f e = *reinterpret_cast<const RC_AS3 last_v4f*>((uintptr_t)(kLastLdsTab + off));
   const float cc = bits2f(cb);
-  const float y = fma_(cc, fma_(cc, e.z, e.y), e.x) * 255.0f;
+  const float y = fma_(cc, fma_(cc, e.z, e.y), e.x);
   const float r = __builtin_rintf(y);
-  *fail = *fail || !(__builtin_fabsf(y - r) + fma_(e.w, 255.0f, 3.1e-5f) < 0.5f);
-  return (uint32_t)__builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);
+  *fail = *fail || !(__builtin_fabsf(y - r) < e.w);
+  return (uint32_t)r;
 }
 
 }  // namespace rcroyale
