@@ -233,6 +233,10 @@ static_assert(kLdsDec + 1020u < 65536u && 8u * kNodes * 16u + (kNodes - 1u) * 16
 // rounded up: (1 + m / 64) 2^(e - 40).  (The coefficient's truncation is part of what the bound is measured against.)
 __host__ __device__ __forceinline__ float scan_w_slope(float w) { return bits2f(f2bits(w) & 0xfffff800u); }
 __host__ __device__ __forceinline__ float scan_w_bound(float w) { return bits2f(((f2bits(w) & 0x7ffu) << 17) + 0x2b800000u); }
+// ... and half of it: the table kernel keeps HALVED records in LDS (the pass stores (K0 + K1 + K2) / 2: halving every coefficient
+// is exact in binary floating point and commutes with every rounding, so the sum of the halved evaluations is the halved sum bit
+// for bit, and the two multiplications by 0.5 per channel go)
+__device__ __forceinline__ float scan_w_bound_half(float w) { return bits2f(((f2bits(w) & 0x7ffu) << 17) + 0x2b000000u); }
 __host__ __device__ inline uint32_t scan_bound_code(float b) {   // smallest code whose value is >= b
   const uint32_t lo = 0x2b800000u, u = f2bits(b);
   if (!(b > bits2f(lo))) return 0u;
@@ -436,7 +440,7 @@ __device__ __forceinline__ float scan_tab_eval(float c, uint32_t byte_addr, floa
   const bool dark = t < (0x3b800000u - kLogBits0);
   const uint32_t addr = dark ? ((t >> 16) & ~15u) : byte_addr;
   const v4f a = lds_v4f(kLdsA + (uint32_t)ROLE * kNodes * 16u + addr);
-  *bsum += scan_w_bound(a.w);
+  *bsum += scan_w_bound_half(a.w);
   return fma_(c, fma_(c, a.z, a.y), fma_(a.w, dist, a.x));   // (a.w as it is: k_scan_tab_bounds measured it with the code bits in)
 }
 
@@ -452,7 +456,14 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
   const uint32_t* bmap = L.in.dec ? reinterpret_cast<const uint32_t*>(L.in.dec) + 256 : nullptr;
   for (int i = tid; i < 9 * kNodes; i += kTabThreads) {
     const int n = i % kNodes;
-    reinterpret_cast<float4*>(rc_dyn_lds_)[i] = gA[bmap && n >= kLogNodes ? i - n + kLogNodes + (int)bmap[n - kLogNodes] : i];
+    float4 r = gA[bmap && n >= kLogNodes ? i - n + kLogNodes + (int)bmap[n - kLogNodes] : i];
+    // halved (see scan_w_bound_half): a0, a1, a2 by a multiplication, W - the distance slope with the bound's code in its low bits -
+    // by one step of its exponent (a slope with a zero exponent field is a denormal, which the arithmetic flushes to 0: left as it is)
+    r.x *= 0.5f;
+    r.y *= 0.5f;
+    r.z *= 0.5f;
+    if (f2bits(r.w) & 0x7f800000u) r.w = bits2f(f2bits(r.w) - 0x00800000u);
+    reinterpret_cast<float4*>(rc_dyn_lds_)[i] = r;
   }
   for (int i = tid; i < 256; i += kTabThreads) rc_dyn_lds_[kLdsDec / 4 + i] = f2bits(L.in.dec ? L.in.dec[i] : k_srgb_decode[i]);   // (a folded pass 0: its composed table)
   for (int i = tid; i < (int)kSrgb2Runs; i += kTabThreads) rc_dyn_lds_[kLdsEnc2 / 4 + i] = L.srgb_enc[kSrgbRuns + i];
@@ -564,8 +575,8 @@ __global__ void __launch_bounds__(kTabThreads) k_royale_scan_v_tab(const PassLau
                   q1 = scan_tab_eval<3 + ch>(c1, baddr[w1][ch], dist, &bs);                                       \
                 }                                                                                                             \
                 const float q2 = scan_tab_eval<6 + ch>(c2, baddr[w2][ch], dist, &bs);                             \
-                const float s = ((q0 + q1) + q2) * 0.5f;                                                                      \
-                const float b = fma_(2.5e-7f, s, 0.5f * bs);   /* the sums' roundings: at most four of 2^-24 (2 s) each, halved */   \
+                const float s = (q0 + q1) + q2;   /* (the records are halved: this is ((K0 + K1) + K2) * 0.5 bit for bit) */           \
+                const float b = fma_(2.5e-7f, s, bs);   /* the sums' roundings: at most four of 2^-24 (2 s) each, halved */           \
                 bool ok;                                                                                                      \
                 const uint32_t byte = srgb8_interval(s, b, &ok);                                                              \
                 fail |= ok ? 0u : 1u;                                                                                         \
@@ -857,7 +868,7 @@ hipError_t launch_royale_scan_v(const PassLaunch& L, hipStream_t s) {
       const long strips = (long)((L.out_w + 63) / 64) * ((L.out_h + kStripRows - 1) / kStripRows) * L.n_frames;
       const long tiles = (strips + kTabWaves - 1) / kTabWaves;
       if (hipMemsetAsync(L.scratch, 0, kFixHeader, s) != hipSuccess) return hipGetLastError();
-      hipLaunchKernelGGL(kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(kTabThreads), kLdsTotalBytes, s, L, T->nodes.A, T->rows, T->cols, skip_r, skip_g, skip_b);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(kTabThreads), kLdsTotalBytes, s, L, T->nodes.A, T->rows, T->cols, 0.5f * skip_r, 0.5f * skip_g, 0.5f * skip_b);   // (halved like the records' bounds)
       #ifndef RC_SCAN_FIX_BLOCKS
 #define RC_SCAN_FIX_BLOCKS 1024
 #endif
