@@ -866,7 +866,7 @@ __global__ void __launch_bounds__(512) k_royale_brightpass_strip(const PassLaunc
 // is rendered once per triangle, each pixel stored by the pass of its own triangle.
 __device__ __forceinline__ v2f brightpass_pair(v2f in, v2f bl, float cw, float mask_amplify) {
   using namespace rcstrip2;
-  const v2f intensity = (in * 2.0f) * mask_amplify;             // in * 2 * mask_amplify * 1
+  const v2f intensity = in * (2.0f * mask_amplify);             // in * 2 * mask_amplify * 1: doubling is exact, so (in * 2) * m and in * (2 m) round the same product once
   const v2f area = bl - cw * intensity;                         // 1 * blur - center_weight * intensity
   const v2f max_area = {__builtin_fmaxf(area.x, 0.0f), __builtin_fmaxf(area.y, 0.0f)};
   const v2f area_under = 0.8f * max_area;
