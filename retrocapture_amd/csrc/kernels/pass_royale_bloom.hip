@@ -180,8 +180,9 @@ __global__ void __launch_bounds__(512) k_royale_bloom_v_strip(const PassLaunch L
 // ---- P9, strip form, two pixels per lane (royale_strip2.h): columns x and x + 64 of a 128-column band; the nine weighted
 // taps of the pixel pair run as packed float operations.  A wave walks a run of consecutive rows of one band (equal runs of
 // (frame, band, row) steps per wave) four target rows at a time with the 4 + 16 decoded source rows of the step in
-// registers; after a step the window moves up by four rows (packed register moves) and four new rows, fetched a step
-// ahead, are decoded: every source row is decoded once per run.
+// registers; the window stays where it is - five instantiations of the step address it rotated by four rows each, the four
+// new rows, fetched a step ahead, are decoded over the four oldest (until round 4 sixty register moves per step shifted it):
+// every source row is decoded once per run.
 constexpr int kBv2Step = 4, kBv2Win = kBv2Step + 16, kBv2Waves = 12;
 template <int PATTERN>
 __global__ void __launch_bounds__(kBv2Waves * 64) k_royale_bloom_v_strip2(const PassLaunch L) {
@@ -237,20 +238,19 @@ __global__ void __launch_bounds__(kBv2Waves * 64) k_royale_bloom_v_strip2(const 
         win[slot + i][2] = v2f{dec_byte<2>(na[i]), dec_byte<2>(nb[i])};
       }
     };
-    // prime: rows y_first - 8 .. y_first + 7 into slots 4 .. 19 (they move down by four at the top of the first step)
+    // prime: rows y_first - 8 .. y_first + 7 into slots 0 .. 15
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       fetch4(y_first - 8 + 4 * g);
-      decode4(kBv2Step + 4 * g);
+      decode4(4 * g);
     }
     fetch4(y_first + 8);
-#pragma unroll 1
-    for (int y0 = y_first; y0 < y_last; y0 += kBv2Step) {
-#pragma unroll
-      for (int i = 0; i < kBv2Win - kBv2Step; ++i)
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) win[i][ch] = win[i + kBv2Step][ch];
-      decode4(kBv2Win - kBv2Step);
+    // One step = four target rows.  The window does not move: step number n (mod 5) finds source row y0 - 8 + i in register slot
+    // (i + 4 n) mod 20 and decodes its four new rows over the four oldest - five instantiations of the step, each with its
+    // register indices as constants, instead of sixty register moves per step (a seventh of the kernel's instructions)
+    auto step = [&](auto rot, int y0) __attribute__((always_inline)) {
+      constexpr int R4 = 4 * decltype(rot)::value;
+      decode4((kBv2Win - kBv2Step + R4) % kBv2Win);
       fetch4(y0 + kBv2Step + 8);
       if (black >= kBv2Win / kBv2Step) {   // (wave-uniform) the window holds zeros only: encode(0 * sum_inv) = 0
 #pragma unroll
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(kBv2Waves * 64) k_royale_bloom_v_strip2(const 
             if (live_b) __builtin_amdgcn_raw_buffer_store_b32(0xff000000u, r_out, xb * 4, y * W * 4, 0);
           }
         }
-        continue;
+        return;
       }
 #pragma unroll
       for (int k = 0; k < kBv2Step; ++k) {
@@ -271,15 +271,15 @@ __global__ void __launch_bounds__(kBv2Waves * 64) k_royale_bloom_v_strip2(const 
 #pragma unroll
           for (int ch = 0; ch < 3; ++ch) {
             // tex2Dblur17fast in the GL's evaluation order (blur17 above)
-            v2f a = w78 * win[k + 8 - o78][ch];
-            a += w56 * win[k + 8 - o56][ch];
-            a += w34 * win[k + 8 - o34][ch];
-            a += win[k + 8][ch];
-            a += w12 * win[k + 8 - o12][ch];
-            a += w12 * win[k + 8 + o12][ch];
-            a += w34 * win[k + 8 + o34][ch];
-            a += w56 * win[k + 8 + o56][ch];
-            a += w78 * win[k + 8 + o78][ch];
+            v2f a = w78 * win[(k + 8 - o78 + R4) % kBv2Win][ch];
+            a += w56 * win[(k + 8 - o56 + R4) % kBv2Win][ch];
+            a += w34 * win[(k + 8 - o34 + R4) % kBv2Win][ch];
+            a += win[(k + 8 + R4) % kBv2Win][ch];
+            a += w12 * win[(k + 8 - o12 + R4) % kBv2Win][ch];
+            a += w12 * win[(k + 8 + o12 + R4) % kBv2Win][ch];
+            a += w34 * win[(k + 8 + o34 + R4) % kBv2Win][ch];
+            a += w56 * win[(k + 8 + o56 + R4) % kBv2Win][ch];
+            a += w78 * win[(k + 8 + o78 + R4) % kBv2Win][ch];
             o[ch] = a * si;
           }
           uint32_t pa, pb;
@@ -288,6 +288,21 @@ __global__ void __launch_bounds__(kBv2Waves * 64) k_royale_bloom_v_strip2(const 
           if (live_b) __builtin_amdgcn_raw_buffer_store_b32(pb, r_out, xb * 4, y * W * 4, 0);
         }
       }
+    };
+    static_assert(kBv2Win == 5 * kBv2Step, "five steps bring the window back to where it was");
+    int y0 = y_first;
+#pragma unroll 1
+    while (true) {
+      step(std::integral_constant<int, 0>(), y0);
+      if ((y0 += kBv2Step) >= y_last) break;
+      step(std::integral_constant<int, 1>(), y0);
+      if ((y0 += kBv2Step) >= y_last) break;
+      step(std::integral_constant<int, 2>(), y0);
+      if ((y0 += kBv2Step) >= y_last) break;
+      step(std::integral_constant<int, 3>(), y0);
+      if ((y0 += kBv2Step) >= y_last) break;
+      step(std::integral_constant<int, 4>(), y0);
+      if ((y0 += kBv2Step) >= y_last) break;
     }
   }
 }
