@@ -804,6 +804,18 @@ void buildScanTables(const PassLaunch& L, hipStream_t s, ScanTables* Tp) {
     ok = buildScanNodeTables(L.params[RP1_PH] / 3.0f, dists, s, &T.nodes);
   }
   const bool usable = ok && hbad == 0;
+  if (rc::log_enabled(rc::LogLevel::Debug) && ok) {   // how the rows' pairs sit: which of the four (scanline 0, scanline 2) patterns, weights exactly 0
+    int pat[4] = {0, 0, 0, 0}, w0z = 0, w2z = 0, dz = 0;
+    for (int y = 2; y < L.out_h - 2; ++y) {
+      const ScanRow& r = hrows[(size_t)y];
+      ++pat[(r.up & 1u) | ((r.up >> 1) & 2u)];
+      w0z += r.wy[0] == 0.0f;
+      w2z += r.wy[2] == 0.0f;
+      dz += r.dist_lo == 0.0f;
+    }
+    RC_LOG_DEBUG("crt-royale scanline pass rows: up patterns (s0|s2) " + std::to_string(pat[0]) + " / " + std::to_string(pat[1]) + " / " + std::to_string(pat[2]) + " / " +
+                 std::to_string(pat[3]) + ", wy0 == 0: " + std::to_string(w0z) + ", wy2 == 0: " + std::to_string(w2z) + ", dist == 0: " + std::to_string(dz));
+  }
   RC_LOG_DEBUG("crt-royale scanline pass " + std::to_string(L.out_w) + "x" + std::to_string(L.out_h) + ": expansion tables " +
                (usable ? "ready (" + std::to_string(n_dists) + " row distances)"
                        : "not usable (geometry flags " + std::to_string(hbad) + ", " + std::to_string(n_dists) + " row distances), exact per-pixel form"));
