@@ -335,6 +335,7 @@ std::vector<KernelEntry> build() {
                 {"SCANLINE_SINE_COMP_B", 0.25f, 0.0f, 1.0f, 0.05f, "Scanline Strength"},
                 {"size", 1.0f, 1.0f, 2.0f, 1.0f, "Grid size"}},
                {}, rck::launch_scanline, setupTexCoord, false});
+  r.back().one_lane = true;
   r.push_back({"crt/shaders/crt-pi.glsl", "crt-pi",
                {{"CURVATURE_X", 0.10f, 0.0f, 1.0f, 0.01f, "Screen curvature - horizontal"},
                 {"CURVATURE_Y", 0.15f, 0.0f, 1.0f, 0.01f, "Screen curvature - vertical"},
@@ -345,6 +346,7 @@ std::vector<KernelEntry> build() {
                 {"INPUT_GAMMA", 2.4f, 0.0f, 5.0f, 0.01f, "Input gamma"},
                 {"OUTPUT_GAMMA", 2.2f, 0.0f, 5.0f, 0.01f, "Output gamma"}},
                {}, rck::launch_crt_pi, setupCrtPi, false});
+  r.back().one_lane = true;
   // the strip form lists the pixels its gamma tables cannot certify in this scratch: a 256-byte header and one 4-byte entry per pixel
   // (kernels/pass_crt_pi.hip)
   r.back().scratch_bytes = [](const PassGeometry& g) -> uint64_t { return 256 + (uint64_t)g.out_w * g.out_h * 4; };

@@ -70,6 +70,9 @@ struct KernelEntry {
   // Consumer side: which of the kernel's textures may be such a never-written target, read through rcd::Tex::dec instead
   // (bit 0: `Texture`, bit 1 + s: samplers[s]); the kernel samples no other sRGB8 texture.
   uint32_t decode_table_inputs = 0;
+  // A single-pass preset of this kernel stays on one lane (ShaderEngine::setLanes): measured, its launches fill the device by
+  // themselves and a second lane's only contend with them (crt-pi 124 k frames/s against 118 k, scanline 2.24 M against 2.09 M)
+  bool one_lane = false;
 };
 
 const KernelEntry* findKernel(const std::string& shaderPath);

@@ -886,7 +886,9 @@ const void* ShaderEngine::applyShaderBatch(const void* inputs, uint32_t nFrames,
     if (largest * 128ull <= (1ull << 31)) chunkFrames = 128u;
   }
   // two lanes (setLanes): this engine renders the first half, the helper - on its own stream - the second half
-  const bool twoLanes = m_lanes == 2 && !m_externalOut && !history && !feedback && !m_profiling && nFrames >= 2 && syncHelper();
+  // (a single-pass preset whose kernel is marked so stays on one lane: KernelEntry::one_lane)
+  const bool oneLaneKernel = m_passes.size() == 1 && m_passes[0].kernel && m_passes[0].kernel->one_lane;
+  const bool twoLanes = m_lanes == 2 && !m_externalOut && !history && !feedback && !m_profiling && !oneLaneKernel && nFrames >= 2 && syncHelper();
   const uint32_t nOwn = twoLanes ? (nFrames + 1) / 2 : nFrames;
   m_lastTwoLanes = twoLanes;
   m_lastOwnFrames = nOwn;
